@@ -1,0 +1,201 @@
+/*
+ * amdstamp.h -- C ABI of libamdstamp.so: the MI355X (gfx950 / CDNA4) hot path behind
+ * KatherLab/STAMP's Extractor / Encoder / MIL-model seams.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host or the comment says "host";
+ *   - every function returns 0 on success and a negative amds_status on failure; the message for the
+ *     calling thread's last failure is amds_last_error(). Nothing here calls abort()/exit(): the
+ *     reference wraps each slide in try/except and skips it on error
+ *     (reference src/stamp/preprocessing/__init__.py:290-336), so failures must come back as values;
+ *   - no hidden allocation and no device synchronisation: the caller owns all memory, passes a
+ *     workspace (size from the matching *_workspace_bytes) and a hipStream_t (as void*);
+ *   - row-major contiguous tensors; leading dimensions passed where views are allowed;
+ *   - "act dtype": AMDS_F16 (default; fp16 operands, fp32 accumulate) or AMDS_BF16.
+ *
+ * Each entry point cites the reference interface (file:line under /root/reference) it stands behind.
+ */
+#ifndef AMDSTAMP_H
+#define AMDSTAMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMDS_VERSION_MAJOR 0
+#define AMDS_VERSION_MINOR 1
+
+typedef enum {
+    AMDS_OK = 0,
+    AMDS_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    AMDS_ERR_WORKSPACE = -2, /* workspace too small */
+    AMDS_ERR_HIP = -3,       /* a HIP runtime call failed */
+    AMDS_ERR_NODEVICE = -4   /* no gfx950 device visible */
+} amds_status;
+
+typedef enum { AMDS_F16 = 0, AMDS_BF16 = 1, AMDS_F32 = 2 } amds_dtype;
+
+/* GEMM epilogues (amds_gemm) */
+typedef enum {
+    AMDS_EPI_BIAS = 0,        /* out_act[m][n] = acc + bias[n]                                  */
+    AMDS_EPI_BIAS_GELU = 1,   /* out_act = gelu_erf(acc + bias)          (nn.GELU, exact erf)   */
+    AMDS_EPI_BIAS_RELU = 2,   /* out_act = max(acc + bias, 0)                                   */
+    AMDS_EPI_RESIDUAL = 3,    /* x_f32[m][n] += scale[n] * (acc + bias[n])   (LayerScale + add) */
+    AMDS_EPI_BIAS_F32 = 4,    /* out_f32[m][n] = acc + bias[n]                                  */
+    AMDS_EPI_SWIGLU = 5,      /* packed fc1: out_act[m][j] = silu(g_j) * v_j, weights block-interleaved
+                                 by amds_pack_swiglu_rows (timm SwiGLUPacked: fc1 -> chunk(2) -> silu(x1)*x2) */
+    AMDS_EPI_PATCH = 6,       /* x_f32[(m/np)*T + P + m%np][n] = acc + bias[n] + pos[m%np][n] (patch embed) */
+    AMDS_EPI_BIAS_GELU_F32 = 7,/* out_f32 = gelu_erf(acc + bias)                                 */
+    AMDS_EPI_BIAS_RELU_F32 = 8 /* out_f32 = max(acc + bias, 0)                                   */
+} amds_epilogue;
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / context
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Version as major*100+minor. */
+int amds_version(void);
+/* Message of the calling thread's most recent failing call ("" if none). */
+const char* amds_last_error(void);
+/* Fills name (<= n bytes) with the device's gcnArchName; AMDS_ERR_NODEVICE if none. */
+int amds_device_info(int device, char* name_host, int n, int* cu_count_host, size_t* hbm_bytes_host);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building blocks (also used by the MIL heads)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* fp32 -> act dtype cast with optional zero padding: dst[r][c] = c < cols ? src[r*ld_src + c]*scale_r : 0
+ * for r < rows, c < ld_dst. Used once, at weight-pack time. */
+int amds_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols,
+                  int dtype, void* stream);
+
+/* LayerNorm over the last dim (torch.nn.LayerNorm semantics: biased variance, eps inside sqrt).
+ * Replaces nn.LayerNorm calls on the path, e.g. reference
+ * src/stamp/modeling/models/vision_tranformer.py:163,189,278 and timm Block.norm1/norm2.
+ * x: fp32 rows at stride x_row_stride (elements); y: act dtype (or fp32 if out_dtype==AMDS_F32) at
+ * stride y_row_stride. cols % 4 == 0, cols <= 8192. */
+int amds_layernorm(const float* x, long x_row_stride, const float* gamma, const float* beta,
+                   void* y, long y_row_stride, int rows, int cols, float eps, int out_dtype,
+                   void* stream);
+
+/* C = A[M,K] * W[N,K]^T with a fused epilogue (nn.Linear + activation + residual).
+ * A, W: act dtype, K-contiguous, lda/ldw in elements (multiples of 8); K % 64 == 0; N % 128 == 0
+ * (pad weights with amds_cast_pad). M arbitrary. `out` is act dtype or fp32 depending on `epi`;
+ * ldo in elements. bias/scale/pos are fp32 (scale may be NULL = 1; bias may be NULL = 0).
+ * np/T/P only for AMDS_EPI_PATCH. acc_scale multiplies the accumulator before bias (1.0f normally).
+ * Replaces nn.Linear on the path: timm Attention.qkv/proj, Mlp.fc1/fc2; reference
+ * src/stamp/modeling/models/vision_tranformer.py:164-168,312-316. */
+int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+              int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
+              const float* pos, int np, int T, int P, float acc_scale, void* stream);
+
+/* Tuning hook: same as amds_gemm with an explicit block-tile configuration
+ * (0 = 128x128, 1 = 256x128, 2 = 256x256; -1 = library default). */
+int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                 int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
+                 const float* pos, int np, int T, int P, float acc_scale, void* stream);
+
+/* Reorders the 2H rows of a SwiGLUPacked fc1 weight/bias so that gate/value columns of one hidden
+ * unit land in the same MFMA lane: dst blocks of 32 rows alternate [gate 32j..][value 32j..].
+ * H % 32 == 0. src/dst fp32 [2H][cols] (bias: cols = 1). */
+int amds_pack_swiglu_rows(const float* src, float* dst, int H, int cols, void* stream);
+
+/* Multi-head self-attention over packed qkv (timm Attention.forward / F.scaled_dot_product_attention;
+ * reference nn.MultiheadAttention at src/stamp/modeling/models/vision_tranformer.py:191,217-227).
+ * qkv: act dtype [B*T][3*H*64] with q|k|v thirds (each [H][64]); out: act dtype [B*T][H*64].
+ * head_dim is fixed at 64; T <= 288 (whole K/V of a head staged in LDS). softmax(q k^T / 8) v. */
+int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tile encoder (ViT) -- the model behind Extractor.model (reference
+ * src/stamp/preprocessing/extractor/__init__.py:17-28; called at src/stamp/preprocessing/__init__.py:324-325)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    int img;          /* 224 */
+    int patch;        /* 14 or 16 */
+    int dim;          /* 1024 / 1280 / 1536 */
+    int depth;        /* 24 / 32 */
+    int heads;        /* dim / 64 */
+    int hidden;       /* MLP hidden width (input width of fc2) */
+    int n_prefix;     /* cls + register tokens */
+    int mlp_kind;     /* 0 = Linear-GELU-Linear, 1 = SwiGLUPacked (fc1 out = 2*hidden) */
+    int layerscale;   /* 0/1 */
+    int dtype;        /* AMDS_F16 / AMDS_BF16 */
+    float ln_eps;     /* 1e-6 for timm ViTs */
+} amds_vit_cfg;
+
+typedef struct {
+    const float* ln1_w; const float* ln1_b;
+    const void*  qkv_w; const float* qkv_b;     /* [3*dim][dim] act dtype, [3*dim] */
+    const void*  proj_w; const float* proj_b;   /* [dim][dim] */
+    const float* ls1;                           /* [dim] or NULL */
+    const float* ln2_w; const float* ln2_b;
+    const void*  fc1_w; const float* fc1_b;     /* GELU: [hidden][dim]; SwiGLU: [2*hidden][dim] block-interleaved */
+    const void*  fc2_w; const float* fc2_b;     /* [dim][hidden_pad] */
+    const float* ls2;
+} amds_vit_block;
+
+typedef struct {
+    const void*  patch_w;    /* [dim][kp] act dtype; conv weight flattened (c,i,j), divided by std[c]; kp = roundup(3*p*p, 64) */
+    const float* patch_b;    /* [dim] conv bias - sum_k W[k]*mean[c]/std[c] */
+    const float* prefix;     /* [n_prefix][dim] fp32: cls/reg tokens (+ their pos-embed rows if any) */
+    const float* pos_patch;  /* [n_patches][dim] fp32 */
+    const amds_vit_block* blocks_host; /* HOST array of `depth` structs holding device pointers */
+    const float* norm_w; const float* norm_b;
+} amds_vit_weights;
+
+/* Workspace bytes for a forward over at most `batch` tiles per internal chunk. */
+size_t amds_vit_workspace_bytes(const amds_vit_cfg* cfg_host, int batch);
+
+/* tiles: u8 [B][img][img][3] (HWC, as decoded) -> feats: fp16 [B][dim] = CLS token of the final
+ * LayerNorm, i.e. model(tiles)[:, 0].half() (reference src/stamp/preprocessing/__init__.py:324-325,
+ * src/stamp/preprocessing/extractor/virchow2.py:29-30). The u8 -> (x/255-mean)/std transform
+ * (reference h_optimus_0.py:22-30 etc.) is folded into patch_w/patch_b.
+ * Processes the batch in chunks of `chunk` tiles (workspace sized for `chunk`). */
+int amds_vit_forward(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host,
+                     const uint8_t* tiles, void* feats_f16, int B, int chunk,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* Same, but also returns the final-LayerNorm'd tokens (fp32 [B][T][dim]) for parity checks and for
+ * CLS (+) mean-patch extractors (reference src/stamp/preprocessing/extractor/virchow_full.py:30-35).
+ * tokens_f32 may be NULL. */
+int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host,
+                            const uint8_t* tiles, void* feats_f16, float* tokens_f32, int B, int chunk,
+                            void* ws, size_t ws_bytes, void* stream);
+
+/* u8 HWC tiles -> im2col patch matrix [B*np][kp] (act dtype, raw 0..255 values, zero padded).
+ * Exposed for tests; amds_vit_forward calls it internally. */
+int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int patch, int kp,
+                        int dtype, void* stream);
+
+/* Stand-alone tile transform: (u8/255 - mean[c]) / std[c], HWC -> CHW, fp32 out [B][3][H][W].
+ * This is Extractor.transform on an already-224x224 tile (ToTensor + Normalize; reference
+ * src/stamp/preprocessing/extractor/h_optimus_0.py:22-30, mstar.py:19-25). */
+int amds_tile_normalize_u8(const uint8_t* hwc, float* chw, int B, int H, int W,
+                           const float mean_host[3], const float std_host[3], void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gated-attention pooling (CHIEF slide encoder; reference
+ * src/stamp/encoding/encoder/chief.py:74-89 CHIEFModel.forward, :255-275 Attn_Net_Gated)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* fc_w;  const float* fc_b;   /* [L][F], [L]   attention_net.0 */
+    const float* a_w;   const float* a_b;    /* [D][L], [D]   attention_net.3.attention_a.0 */
+    const float* b_w;   const float* b_b;    /* [D][L], [D]   attention_net.3.attention_b.0 */
+    const float* c_w;   const float* c_b;    /* [1][D], [1]   attention_net.3.attention_c */
+} amds_gap_weights;
+
+size_t amds_gated_attn_pool_workspace_bytes(int N, int F, int L, int D);
+/* x: fp32 [N][F]; out: fp32 [F] = softmax_N(A) @ x  ("WSI_feature"); attn_raw: fp32 [N] (may be NULL).
+ * fp32 arithmetic throughout (the reference runs this encoder in fp32, chief.py:117). */
+int amds_gated_attn_pool(const float* x, const amds_gap_weights* w_host, float* out, float* attn_raw,
+                         int N, int F, int L, int D, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDSTAMP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libamdstamp.so (the C ABI declared in include/amdstamp.h).
+
+The library is the product; there is no Python/torch fallback.  `lib()` raises if the shared object is
+missing or does not export a declared symbol, and every wrapper raises ``RuntimeError`` with
+``amds_last_error()`` when a call returns non-zero -- STAMP's per-slide ``try/except`` then logs and skips
+the slide exactly as it does for the reference model (reference src/stamp/preprocessing/__init__.py:328-336).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libamdstamp.so"
+
+F16, BF16, F32 = 0, 1, 2
+(EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_RESIDUAL, EPI_BIAS_F32, EPI_SWIGLU, EPI_PATCH,
+ EPI_BIAS_GELU_F32, EPI_BIAS_RELU_F32) = range(9)
+
+
+class VitCfg(C.Structure):
+    _fields_ = [("img", C.c_int), ("patch", C.c_int), ("dim", C.c_int), ("depth", C.c_int),
+                ("heads", C.c_int), ("hidden", C.c_int), ("n_prefix", C.c_int), ("mlp_kind", C.c_int),
+                ("layerscale", C.c_int), ("dtype", C.c_int), ("ln_eps", C.c_float)]
+
+
+class VitBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p),
+                ("pos_patch", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+
+
+class GapWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b")]
+
+
+_vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/amdstamp.h declares
+PROTOTYPES = {
+    "amds_version": (_i, []),
+    "amds_last_error": (C.c_char_p, []),
+    "amds_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_sz)]),
+    "amds_cast_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "amds_layernorm": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp]),
+    "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "amds_gemm_ex": (_i, [_i, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "amds_pack_swiglu_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "amds_attention_vit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_vit_workspace_bytes": (_sz, [C.POINTER(VitCfg), _i]),
+    "amds_vit_forward": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_vit_forward_tokens": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),
+    "amds_gated_attn_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "amds_gated_attn_pool": (_i, [_vp, C.POINTER(GapWeights), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libamdstamp.so once; fail loudly if it (or a declared symbol) is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("AMDSTAMP_LIB", LIB_PATH))
+    if not path.is_file():
+        raise RuntimeError(
+            f"libamdstamp.so not found at {path}: build it with `make` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    handle = C.CDLL(str(path))
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libamdstamp.so does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().amds_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libamdstamp {what} failed (status {rc}): {msg}")

@@ -1,0 +1,93 @@
+// api.hip -- error plumbing, device query and the GEMM entry points of libamdstamp.
+#include "gemm_kernel.h"
+#include <stdlib.h>
+
+namespace amds {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return AMDS_ERR_HIP;
+}
+
+// default tile configuration: AMDS_GEMM_CFG overrides (tuning), else by shape
+int default_gemm_cfg(int M, int N, int K) {
+    static int env = -2;
+    if (env == -2) {
+        const char* s = getenv("AMDS_GEMM_CFG");
+        env = s ? atoi(s) : -1;
+    }
+    if (env >= 0) return env;
+    (void)K;
+    if (M <= 2048 || N < 256) return 0;
+    return 0;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_version(void) { return AMDS_VERSION_MAJOR * 100 + AMDS_VERSION_MINOR; }
+extern "C" const char* amds_last_error(void) { return g_err; }
+
+extern "C" int amds_device_info(int device, char* name_host, int n, int* cu_count_host, size_t* hbm_bytes_host) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= device || device < 0) {
+        set_error("amds_device_info: no HIP device %d (count %d)", device, cnt);
+        return AMDS_ERR_NODEVICE;
+    }
+    hipDeviceProp_t p;
+    AMDS_HIP(hipGetDeviceProperties(&p, device));
+    if (name_host && n > 0) {
+        strncpy(name_host, p.gcnArchName, (size_t)n - 1);
+        name_host[n - 1] = 0;
+    }
+    if (cu_count_host) *cu_count_host = p.multiProcessorCount;
+    if (hbm_bytes_host) *hbm_bytes_host = p.totalGlobalMem;
+    return AMDS_OK;
+}
+
+static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi,
+                     void* out, long ldo, const float* bias, const float* scale, const float* pos, int np, int T,
+                     int P, float acc_scale, void* stream) {
+    AMDS_REQUIRE(A && W && out, "amds_gemm: null pointer");
+    AMDS_REQUIRE(M >= 0 && N > 0 && K > 0, "amds_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    AMDS_REQUIRE(K % 64 == 0, "amds_gemm: K=%d must be a multiple of 64 (zero-pad with amds_cast_pad)", K);
+    AMDS_REQUIRE(N % 128 == 0, "amds_gemm: N=%d must be a multiple of 128 (zero-pad the weight rows)", N);
+    AMDS_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "amds_gemm: lda=%ld/ldw=%ld must be >= K and multiples of 8", lda, ldw);
+    AMDS_REQUIRE(ldo % 4 == 0, "amds_gemm: ldo=%ld must be a multiple of 4", ldo);
+    AMDS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0, "amds_gemm: pointers must be 16-byte aligned");
+    if (epi == AMDS_EPI_SWIGLU) AMDS_REQUIRE(bias != nullptr, "amds_gemm: SWIGLU epilogue needs a bias");
+    if (epi == AMDS_EPI_PATCH) AMDS_REQUIRE(pos && np > 0 && T >= np + P && P >= 0, "amds_gemm: PATCH epilogue needs pos/np/T/P");
+    if (M == 0) return AMDS_OK;
+    EpiArgs ep;
+    ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = scale; ep.pos = pos;
+    ep.np = np; ep.T = T; ep.P = P; ep.acc_scale = acc_scale;
+    if (cfg < 0) cfg = default_gemm_cfg(M, N, K);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AMDS_F16) return gemm_dispatch<f16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);
+    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);
+    set_error("amds_gemm: bad dtype %d", dtype);
+    return AMDS_ERR_INVALID;
+}
+
+extern "C" int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi,
+                         void* out, long ldo, const float* bias, const float* scale, const float* pos, int np, int T,
+                         int P, float acc_scale, void* stream) {
+    return gemm_impl(-1, A, lda, W, ldw, M, N, K, dtype, epi, out, ldo, bias, scale, pos, np, T, P, acc_scale, stream);
+}
+
+// tuning hook: explicit tile configuration (0 = 128x128, 1 = 256x128, 2 = 256x256)
+extern "C" int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype,
+                            int epi, void* out, long ldo, const float* bias, const float* scale, const float* pos,
+                            int np, int T, int P, float acc_scale, void* stream) {
+    return gemm_impl(cfg, A, lda, W, ldw, M, N, K, dtype, epi, out, ldo, bias, scale, pos, np, T, P, acc_scale, stream);
+}

@@ -1,0 +1,200 @@
+// attention_vit.hip -- fused multi-head self-attention for the tile encoder (T <= 288 tokens, head_dim 64).
+//
+// One workgroup per (tile, head).  The head's whole K (<= 288 x 64) and V^T (64 x <= 288) live in LDS
+// (73 KiB -> 2 workgroups / CU), so K/V are read from HBM exactly once; scores are produced 96 keys at a time and
+// folded with an online softmax (running max / sum per query lane):
+//   S^T tile = K_tile(32 keys x 64) . Q^T(64 x 32 queries)    -- MFMA 32x32x16, K rows as the "A" operand
+//   lane (q = lane&31, hi = lane>>5) then holds, for ITS query, keys 8*(r>>2)+4*hi+(r&3) of every tile:
+//   max / exp2 / sum are per-lane loops plus one cross-half exchange;
+//   O^T(64 x 32) += V^T(64 x 16 keys) . P^T(16 keys x 32)     -- P is already the "B" operand in-lane.
+// The only data movement the MFMA layouts force is the V transpose; it is done once per head while
+// staging (packed key-pair ds_write_b32 into a skewed image, see vt_row_bytes), and the key
+// order inside each 16-key group is permuted (bits 2<->3) in the LDS image so that a lane's 8 P values of
+// a K=16 step are exactly its accumulator registers 8*ks .. 8*ks+7 -- no cross-lane shuffles at all.
+#include "common.h"
+#include <type_traits>
+
+namespace amds {
+
+constexpr int ATT_D = 64;
+// V^T image: row d starts at byte d*VS + (d>>3)*16 with VS/16 = 4 (mod 8) 16-byte slots.  With that
+// stride + per-8-row shift the ds_read_b128 of a fragment (16 rows per lane group) hits 16 distinct slots
+// and the transposing ds_write_b32 of staging is at most 2-way (free) -- found by exhaustive search.
+__host__ __device__ constexpr int vt_row_bytes(int nkt) { return (nkt & 1) ? nkt * 64 : nkt * 64 + 64; }
+
+template <typename T, int NKT>  // NKT = ceil(T/32) key tiles
+__global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int KP = NKT * 32;
+    constexpr int VS = vt_row_bytes(NKT);
+    __shared__ __attribute__((aligned(16))) char smem[KP * 128 + ATT_D * VS + 8 * 16];
+    char* sK = smem;
+    char* sVt = smem + KP * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int Dm = H * ATT_D;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * ATT_D;
+
+    // ---- stage K (row-major, 16-byte chunks XOR-swizzled by (key>>1)&7) --------------------------
+    for (int c = tid; c < KP * 8; c += 256) {
+        const int key = c >> 3, ch = c & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (key < Tn) v = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
+        *reinterpret_cast<u32x4*>(sK + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = v;
+    }
+    // ---- stage V transposed: item = (key pair, 8-wide d chunk) ------------------------------------
+    for (int c = tid; c < (KP / 2) * 8; c += 256) {
+        const int kp2 = c >> 3, ch = c & 7;
+        const int k0 = kp2 * 2;
+        vec8 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v0[e] = (T)0.f; v1[e] = (T)0.f; }
+        if (k0 < Tn) v0 = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
+        if (k0 + 1 < Tn) v1 = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
+        // position of key k0 inside the permuted image: swap bits 2 and 3 of the key index
+        const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            typedef T vec2 __attribute__((ext_vector_type(2)));
+            vec2 w;
+            w[0] = v0[e]; w[1] = v1[e];
+            *reinterpret_cast<vec2*>(sVt + (ch * 8 + e) * VS + ch * 16 + pos * 2) = w;
+        }
+    }
+    __syncthreads();
+
+    const float sc = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    const int swz = (l31 >> 1) & 7;
+    const int nqb = (Tn + 31) >> 5;
+
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int q = qb * 32 + l31;
+        const int qc = min(q, Tn - 1);
+        vec8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const vec8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+
+        // ---- online softmax over chunks of CH key tiles (keeps the live score registers at CH*16) ------
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float mrun = -INFINITY, l = 0.f;
+        auto chunk = [&](auto nt_tag, const int t0) {
+            constexpr int NTC = decltype(nt_tag)::value;
+            f32x16 s[NTC];
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const vec8 kf = *reinterpret_cast<const vec8*>(sK + ((t0 + t) * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+                    s[t] = Act<T>::mfma32(kf, qf[ks], s[t]);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (t0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = s[t][r] * sc;
+                    if ((t0 + t + 1) * 32 > Tn && key >= Tn) v = -INFINITY;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = exp2f(mrun - mnew);  // first chunk: exp2(-inf) = 0
+            mrun = mnew;
+            float ls = 0.f;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(s[t][r] - mnew);
+                    s[t][r] = p;
+                    ls += p;
+                }
+            l = l * alpha + ls;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    vec8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[t][ks * 8 + e]);
+                    const int pos = (t0 + t) * 32 + ks * 16 + hi * 8;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int d = dt * 32 + l31;
+                        const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                        o[dt] = Act<T>::mfma32(vf, pf, o[dt]);
+                    }
+                }
+        };
+        constexpr int CH = 3;
+#pragma unroll 1
+        for (int c = 0; c < NKT / CH; ++c) chunk(std::integral_constant<int, CH>{}, c * CH);
+        if constexpr (NKT % CH != 0) chunk(std::integral_constant<int, (NKT % CH == 0 ? 1 : NKT % CH)>{}, (NKT / CH) * CH);
+        l += __shfl_xor(l, 32, 64);
+        if (q < Tn) {
+            const float inv = 1.0f / l;
+            T* orow = out + ((long)b * Tn + q) * Dm + h * ATT_D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    vec4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
+                    *reinterpret_cast<vec4*>(orow + dt * 32 + 8 * g + 4 * hi) = w;
+                }
+        }
+    }
+}
+
+template <typename T>
+static int launch_attn(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
+    const int nkt = (Tn + 31) / 32;
+    const dim3 grid(B * H), block(256);
+    switch (nkt) {
+#define AMDS_ATT_CASE(N) \
+    case N: hipLaunchKernelGGL((attn_vit_kernel<T, N>), grid, block, 0, st, (const T*)qkv, (T*)out, Tn, H); break;
+        AMDS_ATT_CASE(1) AMDS_ATT_CASE(2) AMDS_ATT_CASE(3) AMDS_ATT_CASE(4) AMDS_ATT_CASE(5)
+        AMDS_ATT_CASE(6) AMDS_ATT_CASE(7) AMDS_ATT_CASE(8) AMDS_ATT_CASE(9)
+#undef AMDS_ATT_CASE
+        default:
+            set_error("amds_attention_vit: T=%d > 288 unsupported by the LDS-resident kernel", Tn);
+            return AMDS_ERR_INVALID;
+    }
+    AMDS_LAUNCH_CHECK("attn_vit_kernel");
+    return AMDS_OK;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && out, "amds_attention_vit: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0, "amds_attention_vit: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AMDS_F16) return launch_attn<f16>(qkv, out, B, T, H, st);
+    if (dtype == AMDS_BF16) return launch_attn<bf16>(qkv, out, B, T, H, st);
+    set_error("amds_attention_vit: bad dtype %d", dtype);
+    return AMDS_ERR_INVALID;
+}

@@ -1,0 +1,97 @@
+// common.h -- shared device/host helpers for libamdstamp (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include "../../include/amdstamp.h"
+
+namespace amds {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+#define AMDS_HIP(call)                                           \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return amds::hip_fail(e__, #call); \
+    } while (0)
+#define AMDS_REQUIRE(cond, ...)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            amds::set_error(__VA_ARGS__);    \
+            return AMDS_ERR_INVALID;         \
+        }                                    \
+    } while (0)
+#define AMDS_LAUNCH_CHECK(name)                                   \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return amds::hip_fail(e__, name);  \
+    } while (0)
+
+// ---- per-dtype traits ------------------------------------------------------------------------
+template <typename T> struct Act;
+template <> struct Act<f16> {
+    typedef f16x8 vec8;
+    typedef f16x4 vec4;
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
+    static __device__ __forceinline__ float to_f32(f16 x) { return (float)x; }
+};
+template <> struct Act<bf16> {
+    typedef bf16x8 vec8;
+    typedef bf16x4 vec4;
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
+    static __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+};
+
+// exact-erf GELU (nn.GELU default), evaluated in fp32
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// async 16-byte global -> LDS copy; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace amds

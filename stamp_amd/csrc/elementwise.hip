@@ -1,0 +1,289 @@
+// elementwise.hip -- HBM-bound kernels of the tile-encoder path: LayerNorm, weight casts, the u8 tile
+// transform and the u8 -> patch-matrix (im2col) staging.  One wave per row / 16-byte accesses per lane;
+// none of these has inter-block reuse, so no XCD remap (guide T1: 0 % on LayerNorm).
+#include "common.h"
+
+namespace amds {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave64 per row, row kept in registers (cols <= 64*4*MAXV), two-pass statistics in
+// fp32 (mean, then centred sum of squares) -- matches torch.nn.LayerNorm's biased variance.
+// ---------------------------------------------------------------------------------------------
+template <typename TO, int MAXV>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, long xs,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, TO* __restrict__ y,
+                                                        long ys, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * xs;
+    const int nv = cols >> 2;  // float4 count
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    TO* yr = y + (long)row * ys;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if constexpr (sizeof(TO) == 4) {
+                f32x4 w = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(yr + c * 4) = w;
+            } else {
+                typedef TO vec4 __attribute__((ext_vector_type(4)));
+                vec4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (TO)o[e];
+                *reinterpret_cast<vec4*>(yr + c * 4) = w;
+            }
+        }
+    }
+}
+
+template <typename TO>
+static int launch_ln(const float* x, long xs, const float* g, const float* b, void* y, long ys, int rows,
+                     int cols, float eps, hipStream_t st) {
+    const int nv = cols / 4;
+    const int grid = cdiv(rows, 4);
+    if (nv <= 64 * 4)
+        hipLaunchKernelGGL((layernorm_kernel<TO, 4>), dim3(grid), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
+    else if (nv <= 64 * 8)
+        hipLaunchKernelGGL((layernorm_kernel<TO, 8>), dim3(grid), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<TO, 32>), dim3(grid), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
+    AMDS_LAUNCH_CHECK("layernorm_kernel");
+    return AMDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> act dtype cast with zero padding of the trailing columns (weight packing, one time)
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void cast_pad_kernel(const float* __restrict__ src, int ld_src, TO* __restrict__ dst, int ld_dst,
+                                long total, int cols) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long r = i / ld_dst;
+        const int c = (int)(i - r * ld_dst);
+        dst[i] = c < cols ? (TO)src[r * ld_src + c] : (TO)0.f;
+    }
+}
+
+// rows of a SwiGLUPacked fc1: [gate 0..H) | value 0..H)]  ->  blocks of 32: [gate 32j..][value 32j..]
+__global__ void pack_swiglu_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int cols) {
+    const long total = 2L * H * cols;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const int blk = (int)(r >> 6), within = (int)(r & 63);
+        const int is_val = within >> 5, u = blk * 32 + (within & 31);
+        dst[i] = src[((long)is_val * H + u) * cols + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile transform: u8 HWC -> fp32 CHW, (x/255 - mean)/std  (ToTensor + Normalize)
+// ---------------------------------------------------------------------------------------------
+struct Norm3 { float mean[3], inv_std[3]; };
+__global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* __restrict__ hwc, float* __restrict__ chw,
+                                                             long npix_total, int hw, Norm3 nm) {
+    // each thread: 4 consecutive pixels (12 bytes in) -> 3 float4 stores (one per channel plane)
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nq = npix_total >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; q < nq; q += stride) {
+        const long p = q << 2;
+        const long b = p / hw;
+        const int off = (int)(p - b * hw);
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(hwc + p * 3);
+        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+        uint8_t px[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { px[k] = (w0 >> (8 * k)) & 255; px[4 + k] = (w1 >> (8 * k)) & 255; px[8 + k] = (w2 >> (8 * k)) & 255; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ((float)px[k * 3 + c] / 255.0f - nm.mean[c]) * nm.inv_std[c];
+            *reinterpret_cast<f32x4*>(chw + (b * 3 + c) * hw + off) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// u8 HWC tile -> patch matrix rows (im2col for Conv2d(3, D, p, stride p)):
+//   out[(b*g*g + py*g + px)][c*p*p + i*p + j] = (act) u8[b][py*p+i][px*p+j][c],  zero for k >= 3*p*p.
+// One block per (tile, patch-row): the p image rows (p*img*3 contiguous bytes) are staged in LDS with
+// 16-byte coalesced loads, then each thread assembles 8 consecutive k (one 16-byte store).
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restrict__ tiles, TO* __restrict__ out,
+                                                        int img, int p, int kp) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srow[];
+    const int g = img / p;
+    const int b = blockIdx.x / g, py = blockIdx.x - b * g;
+    const int nbytes = p * img * 3;  // multiple of 16 for img=224
+    const uint8_t* src = tiles + ((long)b * img + (long)py * p) * img * 3;
+    for (int i = threadIdx.x * 16; i < nbytes; i += 256 * 16)
+        *reinterpret_cast<u32x4*>(srow + i) = *reinterpret_cast<const u32x4*>(src + i);
+    __syncthreads();
+    const int pp = p * p, k_real = 3 * pp;
+    const int chunks = kp >> 3;
+    TO* orow = out + ((long)b * g * g + (long)py * g) * kp;
+    typedef TO vec8 __attribute__((ext_vector_type(8)));
+    for (int w = threadIdx.x; w < g * chunks; w += 256) {
+        const int px = w / chunks, ch = w - px * chunks;
+        vec8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float v = 0.f;
+            if (k < k_real) {
+                const int c = k / pp, r = k - c * pp, i = r / p, j = r - i * p;
+                v = (float)srow[(i * img + px * p + j) * 3 + c];
+            }
+            o[e] = (TO)v;
+        }
+        *reinterpret_cast<vec8*>(orow + (long)px * kp + ch * 8) = o;
+    }
+}
+
+// x[b*T + t][:] = prefix[t][:] for t < P  (cls / register tokens, with their pos-embed already added)
+__global__ void prefix_init_kernel(const float* __restrict__ prefix, float* __restrict__ x, int B, int T, int P, int dim) {
+    const long total = (long)B * P * (dim >> 2);
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int dv = dim >> 2;
+    for (; i < total; i += stride) {
+        const long bt = i / dv;
+        const int c = (int)(i - bt * dv);
+        const long b = bt / P;
+        const int t = (int)(bt - b * P);
+        *reinterpret_cast<f32x4*>(x + ((b * T + t) * (long)dim) + c * 4) =
+            *reinterpret_cast<const f32x4*>(prefix + (long)t * dim + c * 4);
+    }
+}
+
+int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hipStream_t st) {
+    const long total = (long)B * P * (dim / 4);
+    const int grid = (int)min((long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(prefix_init_kernel, dim3(grid), dim3(256), 0, st, prefix, x, B, T, P, dim);
+    AMDS_LAUNCH_CHECK("prefix_init_kernel");
+    return AMDS_OK;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_layernorm(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y,
+                              long y_row_stride, int rows, int cols, float eps, int out_dtype, void* stream) {
+    AMDS_REQUIRE(x && gamma && beta && y, "amds_layernorm: null pointer");
+    AMDS_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 8192, "amds_layernorm: cols=%d must be a multiple of 4 and <= 8192", cols);
+    AMDS_REQUIRE(x_row_stride % 4 == 0 && y_row_stride % 4 == 0, "amds_layernorm: row strides must be multiples of 4");
+    if (rows == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (out_dtype) {
+        case AMDS_F16: return launch_ln<f16>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, cols, eps, st);
+        case AMDS_BF16: return launch_ln<bf16>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, cols, eps, st);
+        case AMDS_F32: return launch_ln<float>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, cols, eps, st);
+    }
+    set_error("amds_layernorm: bad out_dtype %d", out_dtype);
+    return AMDS_ERR_INVALID;
+}
+
+extern "C" int amds_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, int dtype,
+                             void* stream) {
+    AMDS_REQUIRE(src && dst, "amds_cast_pad: null pointer");
+    AMDS_REQUIRE(rows >= 0 && cols >= 0 && ld_dst >= cols && ld_src >= cols, "amds_cast_pad: bad shape");
+    const long total = (long)rows * ld_dst;
+    if (total == 0) return AMDS_OK;
+    const int grid = (int)min((long)4096, (total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AMDS_F16)
+        hipLaunchKernelGGL((cast_pad_kernel<f16>), dim3(grid), dim3(256), 0, st, src, ld_src, (f16*)dst, ld_dst, total, cols);
+    else if (dtype == AMDS_BF16)
+        hipLaunchKernelGGL((cast_pad_kernel<bf16>), dim3(grid), dim3(256), 0, st, src, ld_src, (bf16*)dst, ld_dst, total, cols);
+    else if (dtype == AMDS_F32)
+        hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(grid), dim3(256), 0, st, src, ld_src, (float*)dst, ld_dst, total, cols);
+    else { set_error("amds_cast_pad: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("cast_pad_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_pack_swiglu_rows(const float* src, float* dst, int H, int cols, void* stream) {
+    AMDS_REQUIRE(src && dst && src != dst, "amds_pack_swiglu_rows: null/aliased pointer");
+    AMDS_REQUIRE(H > 0 && H % 32 == 0 && cols > 0, "amds_pack_swiglu_rows: H=%d must be a positive multiple of 32", H);
+    const long total = 2L * H * cols;
+    const int grid = (int)min((long)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(pack_swiglu_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, H, cols);
+    AMDS_LAUNCH_CHECK("pack_swiglu_rows_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_tile_normalize_u8(const uint8_t* hwc, float* chw, int B, int H, int W, const float mean_host[3],
+                                      const float std_host[3], void* stream) {
+    AMDS_REQUIRE(hwc && chw && mean_host && std_host, "amds_tile_normalize_u8: null pointer");
+    AMDS_REQUIRE(B >= 0 && H > 0 && W > 0 && (H * W) % 4 == 0, "amds_tile_normalize_u8: H*W must be a multiple of 4");
+    if (B == 0) return AMDS_OK;
+    Norm3 nm;
+    for (int c = 0; c < 3; ++c) {
+        AMDS_REQUIRE(std_host[c] != 0.f, "amds_tile_normalize_u8: std[%d] == 0", c);
+        nm.mean[c] = mean_host[c];
+        nm.inv_std[c] = 1.0f / std_host[c];
+    }
+    const long npix = (long)B * H * W;
+    const int grid = (int)min((long)4096, (npix / 4 + 255) / 256);
+    hipLaunchKernelGGL(tile_normalize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, hwc, chw, npix, H * W, nm);
+    AMDS_LAUNCH_CHECK("tile_normalize_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int patch, int kp, int dtype,
+                                   void* stream) {
+    AMDS_REQUIRE(tiles && out, "amds_tile_im2col_u8: null pointer");
+    AMDS_REQUIRE(img > 0 && patch > 0 && img % patch == 0, "amds_tile_im2col_u8: img=%d not divisible by patch=%d", img, patch);
+    AMDS_REQUIRE(kp % 8 == 0 && kp >= 3 * patch * patch, "amds_tile_im2col_u8: kp=%d too small / not a multiple of 8", kp);
+    AMDS_REQUIRE((patch * img * 3) % 16 == 0 && ((long)img * img * 3) % 16 == 0, "amds_tile_im2col_u8: row block not 16-byte aligned");
+    if (B == 0) return AMDS_OK;
+    const int g = img / patch;
+    const size_t lds = (size_t)patch * img * 3;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AMDS_F16)
+        hipLaunchKernelGGL((im2col_u8_kernel<f16>), dim3(B * g), dim3(256), lds, st, tiles, (f16*)out, img, patch, kp);
+    else if (dtype == AMDS_BF16)
+        hipLaunchKernelGGL((im2col_u8_kernel<bf16>), dim3(B * g), dim3(256), lds, st, tiles, (bf16*)out, img, patch, kp);
+    else { set_error("amds_tile_im2col_u8: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("im2col_u8_kernel");
+    return AMDS_OK;
+}

@@ -1,0 +1,281 @@
+// gemm_kernel.h -- C[M,N] = A[M,K] * W[N,K]^T with fused epilogues, MFMA 32x32x16 (f16/bf16 in,
+// fp32 accumulate) for gfx950.
+//
+// Structure (v1, "one barrier per K-step"):
+//   * block tile BM x BN x 64, WM x WN waves of 64 lanes, each wave owns a (BM/WM) x (BN/WN) sub-tile
+//     made of 32x32 MFMA fragments;
+//   * both operands are K-contiguous (torch Linear weight is [out][in]), so A and W tiles are staged
+//     identically: async global->LDS copies (global_load_lds_dwordx4, no VGPR round trip) into a
+//     double-buffered LDS image of 128-byte rows;
+//   * the LDS image is XOR-swizzled at 16-byte granularity (chunk ^= (row>>1)&7).  global_load_lds
+//     writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address (a permutation
+//     inside one 128-B line: still one fully-coalesced line per 8 lanes) and again on the ds_read_b128;
+//     a wave's fragment read (32 rows x 16 B) then touches 16 distinct 16-B slots per lane group:
+//     conflict free;
+//   * the MFMA is issued with W as the "A" operand and the activation as the "B" operand, i.e. it
+//     computes C^T fragments: lane (j = lane&31, hi = lane>>5) holds output row m = j and the 4
+//     consecutive columns n = 8*(r>>2) + 4*hi + (r&3), so the epilogue does 16-byte fp32 / 8-byte
+//     fp16 accesses per lane and per-column vectors (bias, LayerScale) are float4 loads;
+//   * blockIdx -> tile map is XCD-aware: each of the 8 XCDs (private 4 MiB L2) gets a contiguous
+//     range of tiles, walked in groups of GROUP_M row-tiles x all column-tiles so that the ~64
+//     co-resident tiles of an XCD share A and W panels through its L2.
+#pragma once
+#include "common.h"
+
+namespace amds {
+
+struct EpiArgs {
+    void* out;
+    long ldo;
+    const float* bias;
+    const float* scale;
+    const float* pos;
+    int np, T, P;
+    float acc_scale;
+};
+
+template <int EPI, typename T>
+__device__ __forceinline__ void epilogue4(const EpiArgs& ep, int m, int n, float v0, float v1, float v2,
+                                          float v3) {
+    typedef typename Act<T>::vec4 vec4;
+    if (ep.acc_scale != 1.0f) { v0 *= ep.acc_scale; v1 *= ep.acc_scale; v2 *= ep.acc_scale; v3 *= ep.acc_scale; }
+    if constexpr (EPI != AMDS_EPI_SWIGLU) {
+        if (ep.bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
+            v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
+        }
+    }
+    if constexpr (EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_GELU_F32) {
+        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+    }
+    if constexpr (EPI == AMDS_EPI_BIAS_RELU || EPI == AMDS_EPI_BIAS_RELU_F32) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+    }
+    if constexpr (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU) {
+        vec4 o;
+        o[0] = Act<T>::from_f32(v0); o[1] = Act<T>::from_f32(v1);
+        o[2] = Act<T>::from_f32(v2); o[3] = Act<T>::from_f32(v3);
+        *reinterpret_cast<vec4*>(reinterpret_cast<T*>(ep.out) + (long)m * ep.ldo + n) = o;
+    } else if constexpr (EPI == AMDS_EPI_BIAS_F32 || EPI == AMDS_EPI_BIAS_GELU_F32 ||
+                         EPI == AMDS_EPI_BIAS_RELU_F32) {
+        f32x4 o = {v0, v1, v2, v3};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (long)m * ep.ldo + n) = o;
+    } else if constexpr (EPI == AMDS_EPI_RESIDUAL) {
+        if (ep.scale) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(ep.scale + n);
+            v0 *= s[0]; v1 *= s[1]; v2 *= s[2]; v3 *= s[3];
+        }
+        f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (long)m * ep.ldo + n);
+        f32x4 x = *p;
+        x[0] += v0; x[1] += v1; x[2] += v2; x[3] += v3;
+        *p = x;
+    } else if constexpr (EPI == AMDS_EPI_PATCH) {
+        const int b = m / ep.np, pi = m - b * ep.np;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(ep.pos + (long)pi * ep.ldo + n);
+        f32x4 o = {v0 + pe[0], v1 + pe[1], v2 + pe[2], v3 + pe[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) +
+                                  ((long)b * ep.T + ep.P + pi) * ep.ldo + n) = o;
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+__global__ void __launch_bounds__(64 * WM * WN)
+gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
+               EpiArgs ep, int tiles_m, int tiles_n) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BK = 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_ITERS = BM * 8 / NT, W_ITERS = BN * 8 / NT;
+    constexpr int GROUP_M = 8;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+    static_assert(EPI != AMDS_EPI_SWIGLU || (FN % 2 == 0), "swiglu needs gate/value fragment pairs");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- XCD-aware tile map -----------------------------------------------------------------
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int group = GROUP_M * tiles_n;
+        const int g = t / group, first_m = g * GROUP_M;
+        const int gm = min(tiles_m - first_m, GROUP_M);
+        const int rr = t - g * group;
+        tm = first_m + rr % gm;
+        tn = rr / gm;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses -------------------------------------------------------------------
+    const T* aptr[A_ITERS];
+    const T* wptr[W_ITERS];
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+        const int c = it * NT + tid, row = c >> 3, cp = c & 7, sc = cp ^ ((row >> 1) & 7);
+        const int gr = min(m0 + row, M - 1);
+        aptr[it] = A + (long)gr * lda + sc * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+        const int c = it * NT + tid, row = c >> 3, cp = c & 7, sc = cp ^ ((row >> 1) & 7);
+        wptr[it] = W + (long)(n0 + row) * ldw + sc * 8;
+    }
+    auto stage_load = [&](int buf, int kt) {
+        char* sa = smem + buf * STAGE;
+        char* sw = sa + A_BYTES;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) glds16(aptr[it] + koff, sa + (it * NT + wave * 64) * 16);
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) glds16(wptr[it] + koff, sw + (it * NT + wave * 64) * 16);
+    };
+
+    // ---- fragment read offsets ---------------------------------------------------------------
+    const int wm = wave / WN, wn = wave % WN;
+    const int swz = (l31 >> 1) & 7;
+    const int a_row_off = (wm * WTM + l31) * 128;
+    const int w_row_off = A_BYTES + (wn * WTN + l31) * 128;
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    stage_load(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
+        const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((ks * 2 + hi) ^ swz) << 4;
+            vec8 af[FM], wf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                af[i] = *reinterpret_cast<const vec8*>(sb + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                wf[j] = *reinterpret_cast<const vec8*>(sb + w_row_off + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = Act<T>::mfma32(wf[j], af[i], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + l31;
+        if (m < M) {
+            if constexpr (EPI == AMDS_EPI_SWIGLU) {
+#pragma unroll
+                for (int j = 0; j < FN; j += 2) {
+                    // fragment j = gate block, j+1 = value block of hidden units
+                    const int hbase = (n0 + wn * WTN + j * 32) / 2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int hcol = hbase + 8 * g + 4 * hi;
+                        float gte[4], val[4];
+                        const f32x4 bg = *reinterpret_cast<const f32x4*>(
+                            ep.bias + n0 + wn * WTN + j * 32 + 8 * g + 4 * hi);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(
+                            ep.bias + n0 + wn * WTN + (j + 1) * 32 + 8 * g + 4 * hi);
+                        vec4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gte[e] = acc[i][j][4 * g + e] * ep.acc_scale + bg[e];
+                            val[e] = acc[i][j + 1][4 * g + e] * ep.acc_scale + bv[e];
+                            o[e] = Act<T>::from_f32(silu(gte[e]) * val[e]);
+                        }
+                        *reinterpret_cast<vec4*>(reinterpret_cast<T*>(ep.out) + (long)m * ep.ldo + hcol) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+                        epilogue4<EPI, T>(ep, m, n, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1],
+                                          acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+static int launch_gemm_cfg(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                           const EpiArgs& ep, hipStream_t st) {
+    constexpr int STAGE = (BM + BN) * 64 * 2;
+    constexpr int LDS = 2 * STAGE;
+    auto kern = gemm_tn_kernel<T, BM, BN, WM, WN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles_m = cdiv(M, BM), tiles_n = N / BN;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * WM * WN), LDS, st,
+                       reinterpret_cast<const T*>(A), lda, reinterpret_cast<const T*>(W), ldw, M, N, K, ep,
+                       tiles_m, tiles_n);
+    AMDS_LAUNCH_CHECK("gemm_tn_kernel");
+    return AMDS_OK;
+}
+
+// tile configuration ids (amds_gemm_ex): 0 = 128x128 (2x2 waves), 1 = 256x128 (4x2), 2 = 256x256 (2x4)
+template <typename T, int EPI>
+static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                       const EpiArgs& ep, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_gemm_cfg<T, 128, 128, 2, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+        case 1: return launch_gemm_cfg<T, 256, 128, 4, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+        case 2:
+            if (N % 256 == 0) return launch_gemm_cfg<T, 256, 256, 2, 4, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+            return launch_gemm_cfg<T, 256, 128, 4, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+    }
+    set_error("amds_gemm: unknown tile config %d", cfg);
+    return AMDS_ERR_INVALID;
+}
+
+template <typename T>
+int gemm_dispatch(int cfg, int epi, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                  const EpiArgs& ep, hipStream_t st);
+
+#define AMDS_GEMM_DISPATCH_IMPL(T)                                                                        \
+    template <>                                                                                           \
+    int gemm_dispatch<T>(int cfg, int epi, const void* A, long lda, const void* W, long ldw, int M, int N, \
+                         int K, const EpiArgs& ep, hipStream_t st) {                                      \
+        switch (epi) {                                                                                    \
+            case AMDS_EPI_BIAS: return launch_gemm<T, AMDS_EPI_BIAS>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_BIAS_GELU: return launch_gemm<T, AMDS_EPI_BIAS_GELU>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_BIAS_RELU: return launch_gemm<T, AMDS_EPI_BIAS_RELU>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_RESIDUAL: return launch_gemm<T, AMDS_EPI_RESIDUAL>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_BIAS_F32: return launch_gemm<T, AMDS_EPI_BIAS_F32>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_SWIGLU: return launch_gemm<T, AMDS_EPI_SWIGLU>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_PATCH: return launch_gemm<T, AMDS_EPI_PATCH>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_BIAS_GELU_F32: return launch_gemm<T, AMDS_EPI_BIAS_GELU_F32>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+            case AMDS_EPI_BIAS_RELU_F32: return launch_gemm<T, AMDS_EPI_BIAS_RELU_F32>(cfg, A, lda, W, ldw, M, N, K, ep, st); \
+        }                                                                                                 \
+        set_error("amds_gemm: unknown epilogue %d", epi);                                                 \
+        return AMDS_ERR_INVALID;                                                                          \
+    }
+
+}  // namespace amds

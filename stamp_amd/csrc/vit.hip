@@ -1,0 +1,126 @@
+// vit.hip -- tile-encoder forward: u8 tiles -> fp16 CLS features, as a fixed chain of launches on one
+// stream.  Arithmetic plan per block (timm VisionTransformer Block, pre-LN, optional LayerScale):
+//   h   = LN1(x)                      fp32 -> act dtype        (layernorm_kernel)
+//   qkv = h Wqkv^T + b                act -> act               (MFMA GEMM, EPI_BIAS)
+//   a   = softmax(q k^T / 8) v        act -> act               (attn_vit_kernel)
+//   x  += ls1 * (a Wproj^T + b)       fp32 residual stream     (MFMA GEMM, EPI_RESIDUAL)
+//   h   = LN2(x)
+//   u   = gelu(h W1^T + b1) | silu(g)*v                         (MFMA GEMM, EPI_BIAS_GELU / EPI_SWIGLU)
+//   x  += ls2 * (u W2^T + b2)                                   (MFMA GEMM, EPI_RESIDUAL)
+// The residual stream x stays fp32 in HBM for the whole depth (the reference computes in fp32,
+// src/stamp/preprocessing/__init__.py:324-325); only MFMA operands are rounded to the act dtype.
+#include "common.h"
+
+namespace amds {
+int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hipStream_t st);
+
+struct VitPlan {
+    int np, T, kp, dim, hidden;
+    size_t off_x, off_h, off_qkv, off_mlp, total;
+};
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
+    AMDS_REQUIRE(c != nullptr, "vit: null cfg");
+    AMDS_REQUIRE(c->img > 0 && c->patch > 0 && c->img % c->patch == 0, "vit: img=%d not divisible by patch=%d", c->img, c->patch);
+    AMDS_REQUIRE(c->dim % 128 == 0 && c->heads * 64 == c->dim, "vit: dim=%d must be heads*64 and a multiple of 128", c->dim);
+    AMDS_REQUIRE(c->hidden % 64 == 0 && c->hidden > 0, "vit: hidden=%d must be a multiple of 64 (zero-pad)", c->hidden);
+    AMDS_REQUIRE(c->mlp_kind == 0 || c->mlp_kind == 1, "vit: bad mlp_kind");
+    AMDS_REQUIRE(c->mlp_kind == 1 || c->hidden % 128 == 0, "vit: GELU hidden=%d must be a multiple of 128", c->hidden);
+    AMDS_REQUIRE(c->dtype == AMDS_F16 || c->dtype == AMDS_BF16, "vit: bad act dtype");
+    AMDS_REQUIRE(c->depth > 0 && c->n_prefix >= 0 && batch > 0, "vit: bad depth/prefix/batch");
+    const int g = c->img / c->patch;
+    p->np = g * g;
+    p->T = p->np + c->n_prefix;
+    AMDS_REQUIRE(p->T <= 288, "vit: %d tokens > 288 unsupported", p->T);
+    p->kp = ((3 * c->patch * c->patch + 63) / 64) * 64;
+    p->dim = c->dim;
+    p->hidden = c->hidden;
+    const size_t rows = (size_t)batch * p->T;
+    size_t o = 0;
+    p->off_x = o;   o += align256(rows * c->dim * 4);
+    p->off_h = o;   o += align256(rows * c->dim * 2);
+    p->off_qkv = o; o += align256(rows * 3 * c->dim * 2);
+    const size_t mlp_b = rows * c->hidden * 2, pm_b = (size_t)batch * p->np * p->kp * 2;
+    p->off_mlp = o; o += align256(mlp_b > pm_b ? mlp_b : pm_b);
+    p->total = o;
+    return AMDS_OK;
+}
+
+static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const VitPlan& pl, const uint8_t* tiles,
+                     void* feats_f16, float* tokens_f32, int Bc, char* ws, hipStream_t st) {
+    float* x = reinterpret_cast<float*>(ws + pl.off_x);
+    void* h = ws + pl.off_h;
+    void* qkv = ws + pl.off_qkv;
+    void* mlp = ws + pl.off_mlp;
+    const int D = c->dim, T = pl.T, M = Bc * T, dt = c->dtype;
+    int rc;
+#define AMDS_TRY(call) do { rc = (call); if (rc != AMDS_OK) return rc; } while (0)
+    // patch embedding: im2col (raw 0..255 values) -> GEMM with folded normalisation, + pos-embed
+    AMDS_TRY(amds_tile_im2col_u8(tiles, mlp, Bc, c->img, c->patch, pl.kp, dt, st));
+    if (c->n_prefix > 0) AMDS_TRY(prefix_init(w->prefix, x, Bc, T, c->n_prefix, D, st));
+    AMDS_TRY(amds_gemm(mlp, pl.kp, w->patch_w, pl.kp, Bc * pl.np, D, pl.kp, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
+                       nullptr, w->pos_patch, pl.np, T, c->n_prefix, 1.0f / 255.0f, st));
+    for (int l = 0; l < c->depth; ++l) {
+        const amds_vit_block& b = w->blocks_host[l];
+        AMDS_TRY(amds_layernorm(x, D, b.ln1_w, b.ln1_b, h, D, M, D, c->ln_eps, dt, st));
+        AMDS_TRY(amds_gemm(h, D, b.qkv_w, D, M, 3 * D, D, dt, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        AMDS_TRY(amds_attention_vit(qkv, h, Bc, T, c->heads, dt, st));
+        AMDS_TRY(amds_gemm(h, D, b.proj_w, D, M, D, D, dt, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        AMDS_TRY(amds_layernorm(x, D, b.ln2_w, b.ln2_b, h, D, M, D, c->ln_eps, dt, st));
+        if (c->mlp_kind == 0)
+            AMDS_TRY(amds_gemm(h, D, b.fc1_w, D, M, c->hidden, D, dt, AMDS_EPI_BIAS_GELU, mlp, c->hidden, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        else
+            AMDS_TRY(amds_gemm(h, D, b.fc1_w, D, M, 2 * c->hidden, D, dt, AMDS_EPI_SWIGLU, mlp, c->hidden, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        AMDS_TRY(amds_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, dt, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr, nullptr, 0, 0, 0, 1.0f, st));
+    }
+    // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32
+    AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));
+    if (tokens_f32) AMDS_TRY(amds_layernorm(x, D, w->norm_w, w->norm_b, tokens_f32, D, M, D, c->ln_eps, AMDS_F32, st));
+#undef AMDS_TRY
+    return AMDS_OK;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" size_t amds_vit_workspace_bytes(const amds_vit_cfg* cfg_host, int batch) {
+    VitPlan p;
+    if (make_plan(cfg_host, batch, &p) != AMDS_OK) return 0;
+    return p.total;
+}
+
+extern "C" int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
+                                       void* feats_f16, float* tokens_f32, int B, int chunk, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    AMDS_REQUIRE(cfg_host && w_host && tiles && feats_f16 && ws, "amds_vit_forward: null pointer");
+    AMDS_REQUIRE(B >= 0 && chunk > 0, "amds_vit_forward: bad B=%d chunk=%d", B, chunk);
+    AMDS_REQUIRE(w_host->patch_w && w_host->patch_b && w_host->pos_patch && w_host->blocks_host && w_host->norm_w && w_host->norm_b,
+                 "amds_vit_forward: incomplete weights");
+    AMDS_REQUIRE(cfg_host->n_prefix == 0 || w_host->prefix, "amds_vit_forward: prefix tokens missing");
+    VitPlan pl;
+    int rc = make_plan(cfg_host, chunk, &pl);
+    if (rc != AMDS_OK) return rc;
+    if (ws_bytes < pl.total) {
+        set_error("amds_vit_forward: workspace %zu < required %zu bytes", ws_bytes, pl.total);
+        return AMDS_ERR_WORKSPACE;
+    }
+    AMDS_REQUIRE(((uintptr_t)ws & 255) == 0, "amds_vit_forward: workspace must be 256-byte aligned");
+    const size_t tile_bytes = (size_t)cfg_host->img * cfg_host->img * 3;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int bc = (B - b0 < chunk) ? B - b0 : chunk;
+        rc = vit_chunk(cfg_host, w_host, pl, tiles + (size_t)b0 * tile_bytes,
+                       reinterpret_cast<char*>(feats_f16) + (size_t)b0 * cfg_host->dim * 2,
+                       tokens_f32 ? tokens_f32 + (size_t)b0 * pl.T * cfg_host->dim : nullptr, bc,
+                       reinterpret_cast<char*>(ws), (hipStream_t)stream);
+        if (rc != AMDS_OK) return rc;
+    }
+    return AMDS_OK;
+}
+
+extern "C" int amds_vit_forward(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
+                                void* feats_f16, int B, int chunk, void* ws, size_t ws_bytes, void* stream) {
+    return amds_vit_forward_tokens(cfg_host, w_host, tiles, feats_f16, nullptr, B, chunk, ws, ws_bytes, stream);
+}

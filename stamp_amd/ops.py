@@ -1,0 +1,131 @@
+"""Thin torch-tensor wrappers over the C ABI (device pointers + the current HIP stream).
+
+torch is plumbing here: it owns device memory and streams; all arithmetic happens in libamdstamp.so.
+Every wrapper requires CUDA(HIP) tensors and raises otherwise -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32  # noqa: F401
+
+_DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("stamp_amd ops need tensors on the GPU (no CPU fallback)")
+
+
+def _p(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def act_code(dtype: torch.dtype) -> int:
+    if dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"activation dtype must be float16 or bfloat16, got {dtype}")
+    return _DT[dtype]
+
+
+def cast_pad(src: torch.Tensor, ld_dst: int, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 [rows, cols] -> dtype [rows, ld_dst] with zero padded columns."""
+    _dev(src)
+    src = src.contiguous().float()
+    rows, cols = src.shape
+    dst = torch.empty(rows, ld_dst, dtype=dtype, device=src.device)
+    _lib.check(_lib.lib().amds_cast_pad(_p(src), cols, _p(dst), ld_dst, rows, cols, _DT[dtype], _stream()), "cast_pad")
+    return dst
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+              out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    _dev(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().amds_layernorm(_p(x), cols, _p(gamma), _p(beta), _p(y), cols, rows, cols, eps,
+                                         _DT[out_dtype], _stream()), "layernorm")
+    return y
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, *, bias=None, scale=None, out=None, pos=None, np_=0, T=0, P=0,
+         acc_scale: float = 1.0, cfg: int = -1, n_out: int | None = None) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T).  See include/amdstamp.h for the epilogues."""
+    _dev(a, w, bias, scale, out, pos)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype
+    dt = act_code(a.dtype)
+    f32_out = epi in (_lib.EPI_RESIDUAL, _lib.EPI_BIAS_F32, _lib.EPI_PATCH, _lib.EPI_BIAS_GELU_F32, _lib.EPI_BIAS_RELU_F32)
+    if out is None:
+        cols = n_out if n_out is not None else (N // 2 if epi == _lib.EPI_SWIGLU else N)
+        out = torch.empty(M, cols, dtype=torch.float32 if f32_out else a.dtype, device=a.device)
+    ldo = out.stride(-2) if out.dim() >= 2 else out.shape[-1]
+    _lib.check(_lib.lib().amds_gemm_ex(cfg, _p(a), a.stride(0), _p(w), w.stride(0), M, N, K, dt, epi, _p(out), ldo,
+                                       _p(bias), _p(scale), _p(pos), np_, T, P, acc_scale, _stream()), "gemm")
+    return out
+
+
+def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+    _dev(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
+    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_vit(_p(qkv), _p(out), B, T, H, act_code(qkv.dtype), _stream()), "attention_vit")
+    return out
+
+
+def pack_swiglu_rows(w: torch.Tensor) -> torch.Tensor:
+    """[2H, cols] fp32 (gate rows then value rows) -> 32-row block-interleaved layout."""
+    _dev(w)
+    w2 = w.contiguous().float().reshape(w.shape[0], -1)
+    H, cols = w2.shape[0] // 2, w2.shape[1]
+    dst = torch.empty_like(w2)
+    _lib.check(_lib.lib().amds_pack_swiglu_rows(_p(w2), _p(dst), H, cols, _stream()), "pack_swiglu_rows")
+    return dst.reshape(w.shape)
+
+
+def tile_im2col_u8(tiles: torch.Tensor, patch: int, kp: int, dtype: torch.dtype) -> torch.Tensor:
+    _dev(tiles)
+    assert tiles.dtype == torch.uint8 and tiles.is_contiguous() and tiles.shape[-1] == 3
+    B, img = tiles.shape[0], tiles.shape[1]
+    g = img // patch
+    out = torch.empty(B * g * g, kp, dtype=dtype, device=tiles.device)
+    _lib.check(_lib.lib().amds_tile_im2col_u8(_p(tiles), _p(out), B, img, patch, kp, act_code(dtype), _stream()), "im2col")
+    return out
+
+
+def tile_normalize_u8(tiles: torch.Tensor, mean, std) -> torch.Tensor:
+    """u8 [B,H,W,3] -> fp32 [B,3,H,W] = (x/255 - mean)/std  (ToTensor + Normalize)."""
+    _dev(tiles)
+    assert tiles.dtype == torch.uint8 and tiles.is_contiguous() and tiles.shape[-1] == 3
+    B, H, W, _ = tiles.shape
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=tiles.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    _lib.check(_lib.lib().amds_tile_normalize_u8(_p(tiles), _p(out), B, H, W, m, s, _stream()), "tile_normalize")
+    return out
+
+
+def gated_attn_pool(x: torch.Tensor, weights: dict[str, torch.Tensor], return_attn: bool = False):
+    """x fp32 [N,F]; weights: fc_w/fc_b/a_w/a_b/b_w/b_b/c_w/c_b fp32 device tensors -> out [F] (+ A_raw [N])."""
+    _dev(x, *weights.values())
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    N, F = x.shape
+    L, D = weights["fc_w"].shape[0], weights["a_w"].shape[0]
+    lib = _lib.lib()
+    nbytes = lib.amds_gated_attn_pool_workspace_bytes(N, F, L, D)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+    gw = _lib.GapWeights(**{k: _p(weights[k]) for k in ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b")})
+    out = torch.empty(F, dtype=torch.float32, device=x.device)
+    araw = torch.empty(N, dtype=torch.float32, device=x.device) if return_attn else None
+    _lib.check(lib.amds_gated_attn_pool(_p(x), C.byref(gw), _p(out), _p(araw), N, F, L, D, _p(ws), nbytes, _stream()),
+               "gated_attn_pool")
+    return (out, araw) if return_attn else out

@@ -1,0 +1,294 @@
+"""Tile-encoder (timm-style VisionTransformer) on the HIP path.
+
+`HipViT` is the `model` of a STAMP ``Extractor`` (reference
+src/stamp/preprocessing/extractor/__init__.py:17-28): called as ``model(tiles)`` under
+``torch.inference_mode()`` and expected to return ``[B, D]`` features that the caller casts with ``.half()``
+(reference src/stamp/preprocessing/__init__.py:324-325).  It consumes the *decoded u8 tile* directly -- the
+``(x/255-mean)/std`` transform of the reference's extractors (e.g. h_optimus_0.py:22-30) is folded into the
+patch-embedding weights -- and returns fp16 CLS features straight from the final-LayerNorm kernel.
+
+Weights come in as a timm ``VisionTransformer`` state_dict (the naming every ViT factory of the reference ends
+up with: virchow2.py:34-39, uni2.py:17-34, reddino.py:40-45, uni.py:26-31).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field, replace
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+@dataclass(frozen=True)
+class ViTConfig:
+    img: int = 224
+    patch: int = 14
+    dim: int = 1024
+    depth: int = 24
+    heads: int = 16
+    hidden: int = 4096           # fc2 input width (for SwiGLUPacked: half of fc1's output width)
+    mlp: str = "gelu"            # "gelu" (timm Mlp) | "swiglu" (timm SwiGLUPacked + SiLU)
+    reg_tokens: int = 0
+    no_embed_class: bool = False
+    layerscale: bool = True      # timm init_values is not None
+    ln_eps: float = 1e-6
+    mean: tuple = IMAGENET_MEAN
+    std: tuple = IMAGENET_STD
+
+    @property
+    def n_patches(self) -> int:
+        return (self.img // self.patch) ** 2
+
+    @property
+    def n_prefix(self) -> int:
+        return 1 + self.reg_tokens
+
+    @property
+    def tokens(self) -> int:
+        return self.n_patches + self.n_prefix
+
+    @property
+    def hidden_pad(self) -> int:
+        return (self.hidden + 63) // 64 * 64
+
+    @property
+    def kp(self) -> int:
+        return (3 * self.patch * self.patch + 63) // 64 * 64
+
+    def matmul_flops_per_tile(self) -> float:
+        """2 FLOP per MAC, matmuls only: patch-embed + depth x (linears + attention)."""
+        T, D, np_ = self.tokens, self.dim, self.n_patches
+        fc1_out = self.hidden * (2 if self.mlp == "swiglu" else 1)
+        lin = 2 * T * (D * 3 * D + D * D + D * fc1_out + self.hidden * D)
+        att = 2 * 2 * T * T * D
+        return 2 * np_ * 3 * self.patch ** 2 * D + self.depth * (lin + att)
+
+
+PRESETS: dict[str, ViTConfig] = {
+    # DINOv2-style ViT-L/14 (reference: RedDino-large, reddino.py:40-45); the BASELINE.json headline shape
+    "vit_large_patch14_224": ViTConfig(),
+    # UNI2-h, fully specified in-tree (reference uni2.py:17-31)
+    "uni2_h": ViTConfig(dim=1536, depth=24, heads=24, hidden=4096, mlp="swiglu", reg_tokens=8, no_embed_class=True),
+    # ViT-L/16 (reference UNI, uni.py:26-31)
+    "vit_large_patch16_224": ViTConfig(patch=16),
+    # small shapes for tests
+    "test_tiny": ViTConfig(dim=128, depth=2, heads=2, hidden=256),
+    "test_tiny_swiglu": ViTConfig(dim=128, depth=2, heads=2, hidden=192, mlp="swiglu", reg_tokens=4, no_embed_class=True),
+}
+
+
+def packed_weight_bytes(cfg: ViTConfig) -> int:
+    D = cfg.dim
+    fc1 = cfg.hidden_pad * (2 if cfg.mlp == "swiglu" else 1)
+    return 2 * (D * cfg.kp + cfg.depth * (3 * D * D + D * D + fc1 * D + D * cfg.hidden_pad))
+
+
+class HipViT(nn.Module):
+    """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
+
+    def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 128) -> None:
+        super().__init__()
+        if cfg.heads * 64 != cfg.dim:
+            raise ValueError(f"head_dim must be 64 (dim={cfg.dim}, heads={cfg.heads})")
+        self.cfg = cfg
+        self.act_dtype = act_dtype
+        self.chunk = int(chunk)
+        self.device_ = torch.device(device)
+        if self.device_.type != "cuda":
+            raise RuntimeError("HipViT runs on the GPU only (no CPU fallback)")
+        _lib.lib()  # fail early and loudly if the extension is missing
+        self._keep: list[torch.Tensor] = []
+        self._ws: torch.Tensor | None = None
+        self._pack(state_dict)
+
+    # -- weight packing (one time) ----------------------------------------------------------------
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(self.device_, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _act(self, w: torch.Tensor, ld: int | None = None, rows: int | None = None) -> torch.Tensor:
+        w = w.detach().to(self.device_, torch.float32)
+        w = w.reshape(w.shape[0], -1)
+        if rows is not None and rows > w.shape[0]:
+            w = torch.cat([w, w.new_zeros(rows - w.shape[0], w.shape[1])])
+        out = ops.cast_pad(w, ld or w.shape[1], self.act_dtype)
+        self._keep.append(out)
+        return out
+
+    def _pack(self, sd: dict[str, torch.Tensor]) -> None:
+        c = self.cfg
+        D, P, np_ = c.dim, c.n_prefix, c.n_patches
+        dev = self.device_
+        mean = torch.tensor(c.mean, dtype=torch.float64)
+        std = torch.tensor(c.std, dtype=torch.float64)
+        # patch embedding with the tile transform folded in:  conv(W, (u8/255-mean)/std) + b
+        #   = (1/255) * sum W/std * u8  +  (b - sum W*mean/std)
+        pw = sd["patch_embed.proj.weight"].detach().double().cpu()           # [D,3,p,p]
+        pb = sd["patch_embed.proj.bias"].detach().double().cpu()
+        pw_f = pw / std.view(1, 3, 1, 1)
+        pb_f = pb - (pw * (mean / std).view(1, 3, 1, 1)).sum(dim=(1, 2, 3))
+        self.patch_w = self._act(pw_f.float().reshape(D, -1), ld=c.kp)
+        self.patch_b = self._f32(pb_f.float())
+        pos = sd["pos_embed"].detach().float().reshape(-1, D)
+        toks = [sd["cls_token"].detach().float().reshape(1, D)]
+        if c.reg_tokens:
+            toks.append(sd["reg_token"].detach().float().reshape(c.reg_tokens, D))
+        prefix = torch.cat(toks)
+        if c.no_embed_class:
+            assert pos.shape[0] == np_, f"pos_embed has {pos.shape[0]} rows, expected {np_}"
+            pos_patch = pos
+        else:
+            assert pos.shape[0] == np_ + P, f"pos_embed has {pos.shape[0]} rows, expected {np_ + P}"
+            prefix = prefix + pos[:P]
+            pos_patch = pos[P:]
+        self.prefix = self._f32(prefix)
+        self.pos_patch = self._f32(pos_patch)
+        self.norm_w, self.norm_b = self._f32(sd["norm.weight"]), self._f32(sd["norm.bias"])
+
+        Hp = c.hidden_pad
+        blocks = (_lib.VitBlock * c.depth)()
+        for i in range(c.depth):
+            g = lambda n: sd[f"blocks.{i}.{n}"]  # noqa: E731
+            b = blocks[i]
+            b.ln1_w, b.ln1_b = self._f32(g("norm1.weight")).data_ptr(), self._f32(g("norm1.bias")).data_ptr()
+            b.ln2_w, b.ln2_b = self._f32(g("norm2.weight")).data_ptr(), self._f32(g("norm2.bias")).data_ptr()
+            b.qkv_w, b.qkv_b = self._act(g("attn.qkv.weight")).data_ptr(), self._f32(g("attn.qkv.bias")).data_ptr()
+            b.proj_w, b.proj_b = self._act(g("attn.proj.weight")).data_ptr(), self._f32(g("attn.proj.bias")).data_ptr()
+            w1, b1 = g("mlp.fc1.weight").detach().float().to(dev), g("mlp.fc1.bias").detach().float().to(dev)
+            w2, b2 = g("mlp.fc2.weight").detach().float().to(dev), g("mlp.fc2.bias").detach().float().to(dev)
+            if c.mlp == "swiglu":
+                H = c.hidden
+                assert w1.shape[0] == 2 * H
+                # zero-pad gate and value halves to Hp units each, then block-interleave in the library
+                w1p = w1.new_zeros(2 * Hp, D)
+                w1p[:H], w1p[Hp:Hp + H] = w1[:H], w1[H:]
+                b1p = b1.new_zeros(2 * Hp)
+                b1p[:H], b1p[Hp:Hp + H] = b1[:H], b1[H:]
+                w1 = ops.pack_swiglu_rows(w1p)
+                b1 = ops.pack_swiglu_rows(b1p.reshape(-1, 1)).reshape(-1)
+            else:
+                assert w1.shape[0] == c.hidden and c.hidden % 128 == 0
+            b.fc1_w, b.fc1_b = self._act(w1).data_ptr(), self._f32(b1).data_ptr()
+            b.fc2_w, b.fc2_b = self._act(w2, ld=Hp).data_ptr(), self._f32(b2).data_ptr()
+            if c.layerscale:
+                b.ls1, b.ls2 = self._f32(g("ls1.gamma")).data_ptr(), self._f32(g("ls2.gamma")).data_ptr()
+            else:
+                b.ls1 = b.ls2 = None
+        self._blocks = blocks
+        self._cfg_c = _lib.VitCfg(c.img, c.patch, D, c.depth, c.heads, Hp, P, 1 if c.mlp == "swiglu" else 0,
+                                  1 if c.layerscale else 0, ops.act_code(self.act_dtype), c.ln_eps)
+        self._w_c = _lib.VitWeights(self.patch_w.data_ptr(), self.patch_b.data_ptr(), self.prefix.data_ptr(),
+                                    self.pos_patch.data_ptr(), C.cast(blocks, C.POINTER(_lib.VitBlock)),
+                                    self.norm_w.data_ptr(), self.norm_b.data_ptr())
+        torch.cuda.synchronize(dev)
+
+    # -- forward ----------------------------------------------------------------------------------
+    def _workspace(self, chunk: int) -> torch.Tensor:
+        need = _lib.lib().amds_vit_workspace_bytes(C.byref(self._cfg_c), chunk)
+        if need == 0:
+            _lib.check(-1, "vit_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
+        return self._ws
+
+    def _as_u8_hwc(self, tiles: torch.Tensor) -> torch.Tensor:
+        c = self.cfg
+        if tiles.dtype == torch.uint8:
+            if tiles.dim() != 4 or tiles.shape[-1] != 3:
+                raise ValueError(f"u8 tiles must be [B,H,W,3], got {tuple(tiles.shape)}")
+            return tiles.contiguous()
+        # float [B,3,H,W] that already went through ToTensor+Normalize: the map is a bijection on u8
+        # values, so undo it exactly and take the fused u8 path.
+        if tiles.dim() != 4 or tiles.shape[1] != 3:
+            raise ValueError(f"float tiles must be [B,3,H,W], got {tuple(tiles.shape)}")
+        mean = torch.tensor(c.mean, device=tiles.device, dtype=torch.float32).view(1, 3, 1, 1)
+        std = torch.tensor(c.std, device=tiles.device, dtype=torch.float32).view(1, 3, 1, 1)
+        u8 = ((tiles.float() * std + mean) * 255.0).round().clamp(0, 255).to(torch.uint8)
+        return u8.permute(0, 2, 3, 1).contiguous()
+
+    @torch.no_grad()
+    def forward(self, tiles: torch.Tensor, return_tokens: bool = False):
+        """tiles: u8 [B,H,W,3] (preferred) or normalised float [B,3,H,W] on the GPU -> fp16 [B,D]."""
+        if not tiles.is_cuda:
+            raise RuntimeError("HipViT.forward needs tiles on the GPU (no CPU fallback)")
+        c = self.cfg
+        tiles = self._as_u8_hwc(tiles)
+        B = tiles.shape[0]
+        if tiles.shape[1] != c.img or tiles.shape[2] != c.img:
+            raise ValueError(f"expected {c.img}x{c.img} tiles, got {tuple(tiles.shape)}")
+        feats = torch.empty(B, c.dim, dtype=torch.float16, device=tiles.device)
+        toks = torch.empty(B, c.tokens, c.dim, dtype=torch.float32, device=tiles.device) if return_tokens else None
+        if B == 0:
+            return (feats, toks) if return_tokens else feats
+        chunk = min(self.chunk, B)
+        ws = self._workspace(chunk)
+        rc = _lib.lib().amds_vit_forward_tokens(
+            C.byref(self._cfg_c), C.byref(self._w_c), tiles.data_ptr(), feats.data_ptr(),
+            toks.data_ptr() if toks is not None else None, B, chunk, ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "vit_forward")
+        return (feats, toks) if return_tokens else feats
+
+    # nn.Module plumbing the Extractor seam exercises: `.to(device).eval()` (preprocessing/__init__.py:243)
+    def to(self, *args, **kwargs):  # weights are packed for one device at construction
+        return self
+
+    def with_chunk(self, chunk: int) -> "HipViT":
+        self.chunk = int(chunk)
+        return self
+
+
+def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "stress") -> dict[str, torch.Tensor]:
+    """Random timm-named weights (no checkpoints are reachable offline).
+
+    init="timm":   timm's own init (trunc-normal 0.02, zero bias, LayerScale 1e-5) -- later blocks barely matter;
+    init="stress": O(1) activations everywhere (fan-in scaled weights, random biases/LN affine, LayerScale ~0.5)
+                   so that every block contributes to the output and parity is meaningful.
+    """
+    g = torch.Generator().manual_seed(seed)
+    D, p = cfg.dim, cfg.patch
+    fc1_out = cfg.hidden * (2 if cfg.mlp == "swiglu" else 1)
+    sd: dict[str, torch.Tensor] = {}
+
+    def rn(*shape, s=1.0):
+        return torch.randn(*shape, generator=g) * s
+
+    stress = init == "stress"
+    ws = (lambda fan_in: 1.0 / fan_in ** 0.5) if stress else (lambda fan_in: 0.02)
+    bs = 0.1 if stress else 0.0
+    sd["patch_embed.proj.weight"] = rn(D, 3, p, p, s=ws(3 * p * p))
+    sd["patch_embed.proj.bias"] = rn(D, s=bs)
+    sd["cls_token"] = rn(1, 1, D, s=0.5 if stress else 1e-6)
+    if cfg.reg_tokens:
+        sd["reg_token"] = rn(1, cfg.reg_tokens, D, s=0.5 if stress else 1e-6)
+    n_pos = cfg.n_patches + (0 if cfg.no_embed_class else cfg.n_prefix)
+    sd["pos_embed"] = rn(1, n_pos, D, s=0.5 if stress else 0.02)
+    for i in range(cfg.depth):
+        pre = f"blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[pre + n + ".weight"] = 1.0 + rn(D, s=0.2 if stress else 0.0)
+            sd[pre + n + ".bias"] = rn(D, s=bs)
+        sd[pre + "attn.qkv.weight"] = rn(3 * D, D, s=ws(D) * (2.0 if stress else 1.0))
+        sd[pre + "attn.qkv.bias"] = rn(3 * D, s=bs)
+        sd[pre + "attn.proj.weight"] = rn(D, D, s=ws(D))
+        sd[pre + "attn.proj.bias"] = rn(D, s=bs)
+        sd[pre + "mlp.fc1.weight"] = rn(fc1_out, D, s=ws(D))
+        sd[pre + "mlp.fc1.bias"] = rn(fc1_out, s=bs)
+        sd[pre + "mlp.fc2.weight"] = rn(D, cfg.hidden, s=ws(cfg.hidden))
+        sd[pre + "mlp.fc2.bias"] = rn(D, s=bs)
+        if cfg.layerscale:
+            sd[pre + "ls1.gamma"] = (0.5 + rn(D, s=0.1)) if stress else torch.full((D,), 1e-5)
+            sd[pre + "ls2.gamma"] = (0.5 + rn(D, s=0.1)) if stress else torch.full((D,), 1e-5)
+    sd["norm.weight"] = 1.0 + rn(D, s=0.2 if stress else 0.0)
+    sd["norm.bias"] = rn(D, s=bs)
+    return sd
+
+
+__all__ = ["ViTConfig", "PRESETS", "HipViT", "random_vit_state_dict", "packed_weight_bytes", "replace", "field"]

@@ -1,0 +1,187 @@
+"""Parity of each HIP building block (called through the C ABI) against a plain torch fp32 statement of the
+same op on identical inputs.  Tolerances are stated per test; operands are rounded to the activation dtype
+BEFORE the fp32 reference matmul so that only accumulation order / output rounding differ."""
+import pytest
+import torch
+
+from stamp_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _eps(dt):
+    return 2 ** -10 if dt == torch.float16 else 2 ** -7
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 128), (257, 1024), (1000, 1536), (33, 1280), (5, 4096), (3, 8192)])
+@pytest.mark.parametrize("odt", [torch.float16, torch.bfloat16, torch.float32])
+def test_layernorm(gpu, rows, cols, odt):
+    g = torch.Generator(device="cpu").manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 3 + 1.5).to(gpu)
+    w = (1 + 0.3 * torch.randn(cols, generator=g)).to(gpu)
+    b = (0.2 * torch.randn(cols, generator=g)).to(gpu)
+    y = ops.layernorm(x, w, b, 1e-6, odt)
+    ref = torch.nn.functional.layer_norm(x.double(), (cols,), w.double(), b.double(), 1e-6)
+    tol = 2e-6 * 8 if odt == torch.float32 else _eps(odt)
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+
+
+def _gemm_ref(a, w, bias):
+    return a.double() @ w.double().t() + (bias.double() if bias is not None else 0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
+def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(gpu, dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
+    # asymmetric structure: a transposed / row<->col swapped C write cannot pass
+    a[:, 0] += torch.arange(M, device=gpu).to(dt) * 0.01
+    bias = torch.randn(N, generator=g).to(gpu)
+    out = ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, cfg=cfg)
+    ref = _gemm_ref(a, w, bias)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()) * (1 if dt == torch.float16 else 1), err
+    # fp32 accumulate of exactly-representable products: error is accumulation-order only
+    assert (out.double() - ref).abs().mean().item() < 1e-5 * ref.abs().mean().item() + 1e-6
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_epilogues(gpu, dt):
+    M, N, K = 771, 512, 256
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(gpu, dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
+    bias = torch.randn(N, generator=g).to(gpu)
+    ref = _gemm_ref(a, w, bias)
+    e = _eps(dt)
+    out = ops.gemm(a, w, _lib.EPI_BIAS, bias=bias)
+    assert out.dtype == dt and (out.double() - ref).abs().max().item() < e * ref.abs().max().item() * 1.01
+    out = ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=bias)
+    r = torch.nn.functional.gelu(ref)
+    assert (out.double() - r).abs().max().item() < e * r.abs().max().item() * 1.01 + 1e-6
+    out = ops.gemm(a, w, _lib.EPI_BIAS_RELU, bias=bias)
+    assert (out.double() - ref.clamp(min=0)).abs().max().item() < e * ref.abs().max().item() * 1.01
+    out = ops.gemm(a, w, _lib.EPI_BIAS_GELU_F32, bias=bias)
+    assert (out.double() - r).abs().max().item() < 2e-5
+    out = ops.gemm(a, w, _lib.EPI_BIAS_RELU_F32, bias=bias)
+    assert (out.double() - ref.clamp(min=0)).abs().max().item() < 2e-5
+    # residual with LayerScale
+    x0 = torch.randn(M, N, generator=g).to(gpu)
+    scale = torch.rand(N, generator=g).to(gpu)
+    x = x0.clone()
+    ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=bias, scale=scale, out=x)
+    r = x0.double() + scale.double() * ref
+    assert (x.double() - r).abs().max().item() < 2e-5
+    x = x0.clone()
+    ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=None, scale=None, out=x)
+    assert (x.double() - (x0.double() + _gemm_ref(a, w, None))).abs().max().item() < 2e-5
+    # acc_scale
+    out = ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, acc_scale=0.25)
+    assert (out.double() - (0.25 * _gemm_ref(a, w, None) + bias.double())).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_swiglu(gpu, dt):
+    M, H, K = 300, 192, 128
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(M, K, generator=g).to(gpu, dt)
+    w = (torch.randn(2 * H, K, generator=g) / K ** 0.5).to(gpu)
+    bias = torch.randn(2 * H, generator=g).to(gpu)
+    wp = ops.pack_swiglu_rows(w).to(dt)
+    bp = ops.pack_swiglu_rows(bias.reshape(-1, 1)).reshape(-1)
+    # padded N must be a multiple of 128: 384 ok
+    out = ops.gemm(a, wp, _lib.EPI_SWIGLU, bias=bp)
+    full = a.double() @ w.to(dt).double().t() + bias.double()
+    x1, x2 = full[:, :H], full[:, H:]
+    ref = torch.nn.functional.silu(x1) * x2
+    assert out.shape == (M, H)
+    assert (out.double() - ref).abs().max().item() < _eps(dt) * ref.abs().max().item() * 1.05 + 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_patch_epilogue(gpu, dt):
+    B, np_, P, D, K = 3, 256, 5, 128, 640
+    T = np_ + P
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(0, 256, (B * np_, K), generator=g).to(gpu, dt)
+    w = (torch.randn(D, K, generator=g) / K ** 0.5).to(gpu, dt)
+    bias = torch.randn(D, generator=g).to(gpu)
+    pos = torch.randn(np_, D, generator=g).to(gpu)
+    x = torch.full((B * T, D), 7.0, device=gpu)
+    ops.gemm(a, w, _lib.EPI_PATCH, bias=bias, pos=pos, np_=np_, T=T, P=P, acc_scale=1 / 255.0, out=x)
+    ref = (a.double() @ w.double().t()) / 255.0 + bias.double()
+    ref = ref.reshape(B, np_, D) + pos.double()
+    xx = x.reshape(B, T, D)
+    assert (xx[:, :P] == 7.0).all()
+    assert (xx[:, P:].double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,H", [(2, 257, 16), (3, 261, 2), (1, 265, 24), (2, 197, 4), (2, 64, 2), (1, 33, 1), (2, 288, 2)])
+def test_attention_vit(gpu, dt, B, T, H):
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    D = H * 64
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(gpu, dt)
+    out = ops.attention_vit(qkv, B, T, H)
+    q, k, v = qkv.double().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    err = (out.double() - ref).abs().max().item()
+    # P and the output are rounded to the act dtype: 2-3 ulp of the largest value
+    assert err < 4 * _eps(dt) * max(1.0, ref.abs().max().item()), err
+
+
+def test_attention_softmax_spike(gpu):
+    """one key dominating a row / large logits: exercises the running-max rescale across chunks"""
+    B, T, H = 1, 257, 1
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * T, 192, generator=g)
+    qkv[:, :64] *= 4
+    qkv[200, 64:128] = qkv[5, :64] * 3       # key 200 (third chunk) spikes for query 5
+    qkv[10, 64:128] = qkv[7, :64] * 3        # key 10 (first chunk) spikes for query 7
+    qkv = qkv.to(gpu, torch.float16)
+    out = ops.attention_vit(qkv, B, T, H)
+    q, k, v = qkv.double().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * T, 64)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("patch", [14, 16])
+def test_im2col(gpu, patch):
+    B, img = 3, 224
+    g = torch.Generator().manual_seed(patch)
+    tiles = torch.randint(0, 256, (B, img, img, 3), dtype=torch.uint8, generator=g).to(gpu)
+    kp = (3 * patch * patch + 63) // 64 * 64
+    out = ops.tile_im2col_u8(tiles, patch, kp, torch.float16)
+    x = tiles.permute(0, 3, 1, 2).float()
+    ref = torch.nn.functional.unfold(x, patch, stride=patch).transpose(1, 2).reshape(-1, 3 * patch * patch)
+    assert torch.equal(out[:, : 3 * patch * patch].float(), ref)      # integers 0..255: exact
+    assert (out[:, 3 * patch * patch:] == 0).all()
+
+
+def test_tile_normalize(gpu):
+    from oracle.vit_tile_encoder import tile_transform
+
+    mean, std = (0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)
+    tiles = torch.randint(0, 256, (5, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    out = ops.tile_normalize_u8(tiles.to(gpu), mean, std).cpu()
+    ref = tile_transform(tiles, mean, std)
+    # one fp32 division + subtraction + multiply-by-reciprocal vs division: <= 2 ulp
+    assert (out - ref).abs().max().item() <= 4e-7 * ref.abs().max().item()
+
+
+def test_errors_are_values(gpu):
+    a = torch.zeros(8, 100, dtype=torch.float16, device=gpu)   # K not a multiple of 64
+    w = torch.zeros(128, 100, dtype=torch.float16, device=gpu)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(a, w, _lib.EPI_BIAS_F32)
+    with pytest.raises(RuntimeError, match="288"):
+        ops.attention_vit(torch.zeros(400, 192, dtype=torch.float16, device=gpu), 1, 400, 1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6)

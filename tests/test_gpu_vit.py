@@ -1,0 +1,47 @@
+"""End-to-end parity of the HIP tile encoder against the CPU oracle on identical u8 tiles and weights."""
+import pytest
+import torch
+
+from oracle.vit_tile_encoder import extract_features
+from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+@pytest.mark.parametrize("name", ["test_tiny", "test_tiny_swiglu"])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_tiny_vit_matches_oracle(gpu, name, dt):
+    cfg = PRESETS[name]
+    sd = random_vit_state_dict(cfg, seed=1, init="stress")
+    tiles = torch.randint(0, 256, (5, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    ref_f, ref_t = extract_features(tiles, sd, cfg, return_tokens=True)
+    model = HipViT(cfg, sd, device=gpu, act_dtype=dt, chunk=2)     # chunk < B: exercises the chunk loop
+    f, t = model(tiles.to(gpu), return_tokens=True)
+    tol = 2e-3 if dt == torch.float16 else 2e-2
+    assert _rel(t.cpu(), ref_t) < tol, _rel(t.cpu(), ref_t)
+    assert f.dtype == torch.float16 and _rel(f.cpu().float(), ref_f.float()) < tol
+    # determinism: same input twice -> bit-identical
+    f2 = model(tiles.to(gpu))
+    assert torch.equal(f, f2)
+    # float (already-normalised CHW) input takes the same path
+    from oracle.vit_tile_encoder import tile_transform
+    f3 = model(tile_transform(tiles, cfg.mean, cfg.std).to(gpu))
+    assert torch.equal(f, f3)
+
+
+def test_vit_large_matches_oracle(gpu):
+    """The headline shape (ViT-L/14, 257 tokens), fp16 operands / fp32 accumulate / fp32 residual stream.
+    Stated tolerance: relative L2 error of the fp16 CLS features <= 1e-3 (BASELINE.json north_star)."""
+    cfg = PRESETS["vit_large_patch14_224"]
+    sd = random_vit_state_dict(cfg, seed=0, init="stress")
+    tiles = torch.randint(0, 256, (4, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    ref_f, ref_t = extract_features(tiles, sd, cfg, return_tokens=True)
+    model = HipViT(cfg, sd, device=gpu, act_dtype=torch.float16, chunk=4)
+    f, t = model(tiles.to(gpu), return_tokens=True)
+    r_t, r_f = _rel(t.cpu(), ref_t), _rel(f.cpu().float(), ref_f.float())
+    print(f"ViT-L/14 fp16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e}")
+    assert r_f < 1e-3 and r_t < 1e-3
