@@ -1,0 +1,109 @@
+"""Pin the CPU oracle against golden vectors captured from the reference's own code (tools/make_golden.py),
+plus the known answers in the reference's docstrings.  CPU only."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gated_attention, mil_vit, misc, transmil
+
+G = Path(__file__).parent / "golden"
+
+
+def _load(name):
+    z = np.load(G / name)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    return z, sd
+
+
+@pytest.mark.parametrize("tag", ["small", "xs"])
+def test_chief_gated_attention(tag):
+    z, sd = _load(f"chief_gated_attention_{tag}.npz")
+    out = gated_attention.gated_attention_pool(torch.from_numpy(z["x"]), sd)
+    np.testing.assert_allclose(out["attention_raw"].numpy(), z["attention_raw"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["WSI_feature"].numpy(), z["wsi_feature"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,alibi", [("plain", False), ("alibi", True)])
+def test_mil_vit(tag, alibi):
+    z, sd = _load(f"mil_vit_{tag}.npz")
+    heads = int(z["hparams"][4])
+    bags, coords, mask = (torch.from_numpy(z[k]) for k in ("bags", "coords", "mask"))
+    y = mil_vit.mil_vit_forward(bags, coords, None, sd, n_heads=heads, use_alibi=alibi)
+    np.testing.assert_allclose(y.numpy(), z["logits_nomask"], rtol=2e-5, atol=2e-5)
+    y = mil_vit.mil_vit_forward(bags, coords, mask, sd, n_heads=heads, use_alibi=alibi)
+    np.testing.assert_allclose(y.numpy(), z["logits_mask"], rtol=2e-5, atol=2e-5)
+
+
+def test_alibi_running_mean_was_updated_in_golden():
+    z = np.load(G / "mil_vit_alibi.npz")
+    k = [f for f in z.files if f.startswith("w_after_train:") and "items_so_far" in f]
+    assert k and all(z[f][0] == 3.0 for f in k)       # 1 + two train-mode forwards
+
+
+@pytest.mark.parametrize("tag", ["t50", "t300"])
+def test_transmil(tag):
+    z, sd = _load(f"transmil_{tag}.npz")
+    y = transmil.transmil_forward(torch.from_numpy(z["bags"]), sd)
+    np.testing.assert_allclose(y.numpy(), z["logits"], rtol=1e-4, atol=1e-4)
+    out = transmil.nystrom_attention(torch.from_numpy(z["nys_x"]), sd, "layer1.attn.", heads=8, landmarks=int(z["hparams"][2]) // 2)
+    np.testing.assert_allclose(out.numpy(), z["nys_out"], rtol=1e-4, atol=1e-5)
+    p = transmil.pinv_iter(torch.from_numpy(z["pinv_in"]), 6)
+    np.testing.assert_allclose(p.numpy(), z["pinv_out"], rtol=1e-4, atol=1e-4)
+
+
+def test_ppeg():
+    z, sd = _load("transmil_ppeg.npz")
+    sd = {"pos_layer." + k: v for k, v in sd.items()}
+    y = transmil.ppeg(torch.from_numpy(z["x"]), sd, "pos_layer.", 8, 8)
+    np.testing.assert_allclose(y.numpy(), z["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_mlp_linear():
+    z = np.load(G / "mlp.npz")
+    sm = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp:")}
+    sl = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("lin:")}
+    for key, x in (("3", torch.from_numpy(z["x3"])), ("2", torch.from_numpy(z["x2"]))):
+        np.testing.assert_allclose(misc.mlp_forward(x, sm, 3).numpy(), z[f"mlp_y{key}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(misc.linear_forward(x, sl).numpy(), z[f"lin_y{key}"], rtol=1e-5, atol=1e-6)
+
+
+def test_cox_known_answers_and_golden():
+    # the reference's own docstring values (src/stamp/modeling/models/cox.py:192-204)
+    log_hz = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5])
+    event = torch.tensor([1, 0, 1, 0, 1], dtype=torch.bool)
+    time = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0])
+    assert abs(misc.cox_neg_partial_log_likelihood(log_hz, time, event).item() - 1.0071) < 1e-4
+    assert abs(misc.cox_neg_partial_log_likelihood(log_hz, time, event, reduction="sum").item() - 3.0214) < 1e-4
+    tie = torch.tensor([1.0, 2.0, 2.0, 4.0, 5.0])
+    assert abs(misc.cox_neg_partial_log_likelihood(log_hz, tie, event, "efron").item() - 1.0873) < 1e-4
+    assert abs(misc.cox_neg_partial_log_likelihood(log_hz, tie, event, "breslow").item() - 1.0873) < 1e-4
+    z = np.load(G / "cox.npz")
+    for k in ("doc_mean", "doc_sum", "doc_tie_efron", "doc_tie_breslow"):
+        assert np.isfinite(z[k])
+    lh, tt, ev = torch.from_numpy(z["log_hz"]), torch.from_numpy(z["time"]), torch.from_numpy(z["event"])
+    assert abs(misc.cox_neg_partial_log_likelihood(lh, tt, ev, "efron").item() - float(z["efron"])) < 1e-5
+    assert abs(misc.cox_neg_partial_log_likelihood(lh, tt, ev, "breslow").item() - float(z["breslow"])) < 1e-5
+    assert abs(misc.cox_neg_partial_log_likelihood(lh, torch.arange(40.0), ev).item() - float(z["notie"])) < 1e-5
+
+
+@pytest.mark.parametrize("name,tdt", [("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)])
+def test_vary_precision_bit_exact(name, tdt):
+    z = np.load(G / "vary_precision.npz")
+    bits_in, bits_out = z[f"in_{name}"], z[f"out_{name}"]
+    torch.manual_seed(22)       # same global-generator draw as the reference made
+    shifts = torch.randint(0, misc.vary_precision_shift_range(name, 2), bits_in.shape).numpy()
+    assert np.array_equal(misc.vary_precision_bits(bits_in, shifts), bits_out)
+
+
+def test_fixed_size_bag():
+    z = np.load(G / "fixed_size_bag.npz")
+    for n, bs in ((10, 16), (100, 16), (16, 16), (1000, 512), (1, 4)):
+        bag, coords = torch.from_numpy(z[f"bag_{n}_{bs}"]), torch.from_numpy(z[f"coords_{n}_{bs}"])
+        b, c, l = misc.to_fixed_size_bag(bag, coords, bs, deterministic=True)
+        assert np.array_equal(b.numpy(), z[f"det_bag_{n}_{bs}"]) and np.array_equal(c.numpy(), z[f"det_coords_{n}_{bs}"])
+        assert l == int(z[f"det_len_{n}_{bs}"])
+        torch.manual_seed(1234)
+        b, c, l = misc.to_fixed_size_bag(bag, coords, bs, deterministic=False)
+        assert np.array_equal(b.numpy(), z[f"rand_bag_{n}_{bs}"]) and l == int(z[f"rand_len_{n}_{bs}"])

@@ -1,0 +1,252 @@
+"""Generate golden vectors under tests/golden/ by IMPORTING the reference's own model code.
+
+Runs only in the build container (needs /root/reference).  Nothing of the reference travels: the fixtures are
+data -- seeded inputs, the state_dict the reference module was initialised with, and the outputs the
+reference module produced -- stored as .npz.  Re-run:  python tools/make_golden.py
+
+Shims (arithmetic-free): typing.assert_never / enum.StrEnum / hashlib.file_digest
+polyfills for Python 3.10, stub modules for jaxtyping / beartype / gdown, a synthetic `stamp` namespace so
+sub-modules resolve without running the package __init__s (which import h5py / openslide).
+"""
+from __future__ import annotations
+
+import ast
+import enum
+import hashlib
+import sys
+import types
+import typing
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference/src/stamp")
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def install_shims() -> None:
+    import typing_extensions
+
+    if not hasattr(typing, "assert_never"):
+        typing.assert_never = typing_extensions.assert_never
+    if not hasattr(enum, "StrEnum"):
+        class StrEnum(str, enum.Enum):
+            def __str__(self):
+                return str(self.value)
+        enum.StrEnum = StrEnum
+    if not hasattr(hashlib, "file_digest"):
+        def file_digest(f, algo):
+            h = hashlib.new(algo) if isinstance(algo, str) else algo()
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+            return h
+        hashlib.file_digest = file_digest
+
+    class _Sub:
+        def __getitem__(self, item):
+            return typing.Any
+
+    jt = types.ModuleType("jaxtyping")
+    for n in ("Float", "Bool", "Integer", "Int", "Shaped"):
+        setattr(jt, n, _Sub())
+    jt.jaxtyped = lambda *a, **k: (lambda f: f)
+    sys.modules["jaxtyping"] = jt
+    bt = types.ModuleType("beartype")
+    bt.beartype = lambda f=None, **k: f if f is not None else (lambda g: g)
+    sys.modules["beartype"] = bt
+    sys.modules["gdown"] = types.ModuleType("gdown")
+    if not hasattr(torch.nn, "Buffer"):
+        raise RuntimeError("torch.nn.Buffer missing")
+    # synthetic namespace packages
+    for name, path in (("stamp", REF), ("stamp.modeling", REF / "modeling"),
+                       ("stamp.modeling.models", REF / "modeling" / "models")):
+        m = types.ModuleType(name)
+        m.__path__ = [str(path)]
+        sys.modules[name] = m
+
+
+def load_by_path(modname: str, path: Path):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def exec_defs(path: Path, names: set[str], glb: dict) -> dict:
+    """exec only the named top-level class/function definitions of a reference file (its module top imports
+    things that are absent here)."""
+    tree = ast.parse(path.read_text())
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    missing = names - {n.name for n in body}
+    assert not missing, missing
+    code = compile(ast.Module(body=body, type_ignores=[]), str(path), "exec")
+    exec(code, glb)
+    return glb
+
+
+def sd_np(module: torch.nn.Module, prefix: str = "w:") -> dict[str, np.ndarray]:
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name: str, **arrs) -> None:
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / name, **arrs)
+    size = (OUT / name).stat().st_size
+    print(f"wrote {name}: {size/1024:.1f} KiB, keys={len(arrs)}")
+
+
+def golden_chief() -> None:
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    glb = {"nn": nn, "torch": torch, "F": F}
+    exec_defs(REF / "encoding" / "encoder" / "chief.py",
+              {"CHIEFModel", "Attn_Net_Gated", "Attn_Net", "Att_Head", "initialize_weights"}, glb)
+    for tag, size_arg, N in (("small", "small", 300), ("xs", "xs", 77)):
+        torch.manual_seed(100 + N)
+        model = glb["CHIEFModel"](size_arg=size_arg, dropout=True, n_classes=2).eval()
+        # the reference's initialize_weights gives xavier weights and zero biases; perturb biases so they matter
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+        Fdim = model.size_dict[size_arg][0]
+        x = torch.randn(N, Fdim) * 0.7
+        with torch.no_grad():
+            out = model(x)
+        save(f"chief_gated_attention_{tag}.npz", x=x.numpy(), wsi_feature=out["WSI_feature"].numpy(),
+             attention_raw=out["attention_raw"].numpy(), size_arg=np.array(size_arg),
+             **{k: v for k, v in sd_np(model).items() if k.startswith("w:attention_net.")})  # only the used path
+
+
+def golden_mil_vit() -> None:
+    vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
+    for tag, use_alibi, kw in (
+        ("plain", False, dict(dim_output=3, dim_input=48, dim_model=64, n_layers=2, n_heads=2, dim_feedforward=96)),
+        ("alibi", True, dict(dim_output=2, dim_input=40, dim_model=64, n_layers=2, n_heads=4, dim_feedforward=64)),
+    ):
+        torch.manual_seed(7 if use_alibi else 6)
+        model = vt.VisionTransformer(dropout=0.0, use_alibi=use_alibi, **kw)
+        bags = torch.randn(3, 37, kw["dim_input"])
+        coords = torch.rand(3, 37, 2) * 4000
+        mask = torch.zeros(3, 37, dtype=torch.bool)
+        mask[1, 30:] = True
+        mask[2, 11:] = True
+        arrs = dict(bags=bags.numpy(), coords=coords.numpy(), mask=mask.numpy(), **sd_np(model))
+        if use_alibi:
+            # a few train-mode forwards update the running-mean buffers exactly as training would
+            model.train()
+            for i in range(2):
+                with torch.no_grad():
+                    model(bags + i, coords=coords * (1 + i), mask=None)
+            arrs.update({k.replace("w:", "w_after_train:"): v for k, v in sd_np(model).items() if "running_mean" in k or "items_so_far" in k})
+            arrs.update(sd_np(model))          # eval goldens use the post-update buffers
+        model.eval()
+        with torch.no_grad():
+            arrs["logits_nomask"] = model(bags, coords=coords, mask=None).numpy()
+            arrs["logits_mask"] = model(bags, coords=coords, mask=mask).numpy()
+        arrs["hparams"] = np.array([kw[k] for k in ("dim_output", "dim_input", "dim_model", "n_layers", "n_heads", "dim_feedforward")])
+        save(f"mil_vit_{tag}.npz", **arrs)
+
+
+def golden_transmil() -> None:
+    tm = load_by_path("stamp.modeling.models.trans_mil", REF / "modeling" / "models" / "trans_mil.py")
+    for tag, T, dim_in, dim_h in (("t50", 50, 24, 64), ("t300", 300, 32, 64)):
+        torch.manual_seed(11 + T)
+        model = tm.TransMIL(dim_output=2, dim_input=dim_in, dim_hidden=dim_h).eval()
+        bags = torch.randn(2, T, dim_in)
+        with torch.no_grad():
+            logits = model(bags)
+            # intermediates for kernel-level checks
+            x = torch.randn(2, 70, dim_h)
+            attn_out = model.layer1.attn(x)
+            a2 = torch.softmax(torch.randn(2, 8, 32, 32), dim=-1)
+            pinv = tm.moore_penrose_iter_pinv(a2, 6)
+            ppeg = model.pos_layer(torch.randn(2, 1 + 64, dim_h), 8, 8)
+        save(f"transmil_{tag}.npz", bags=bags.numpy(), logits=logits.numpy(), nys_x=x.numpy(), nys_out=attn_out.numpy(),
+             pinv_in=a2.numpy(), pinv_out=pinv.numpy(), hparams=np.array([2, dim_in, dim_h]), **sd_np(model))
+    # PPEG input for replay
+    torch.manual_seed(5)
+    model = tm.TransMIL(dim_output=2, dim_input=8, dim_hidden=64).eval()
+    xin = torch.randn(2, 1 + 64, 64)
+    with torch.no_grad():
+        out = model.pos_layer(xin, 8, 8)
+    save("transmil_ppeg.npz", x=xin.numpy(), out=out.numpy(), **sd_np(model.pos_layer))
+
+
+def golden_mlp_cox_transforms() -> None:
+    mlp = load_by_path("stamp.modeling.models.mlp", REF / "modeling" / "models" / "mlp.py")
+    torch.manual_seed(3)
+    m = mlp.MLP(dim_input=20, dim_hidden=16, dim_output=3, num_layers=3, dropout=0.0).eval()
+    lin = mlp.Linear(dim_input=20, dim_output=2).eval()
+    x3, x2 = torch.randn(4, 9, 20), torch.randn(4, 20)
+    with torch.no_grad():
+        save("mlp.npz", x3=x3.numpy(), x2=x2.numpy(), mlp_y3=m(x3).numpy(), mlp_y2=m(x2).numpy(),
+             lin_y3=lin(x3).numpy(), lin_y2=lin(x2).numpy(),
+             **sd_np(m, "mlp:"), **sd_np(lin, "lin:"))
+    cox = load_by_path("stamp.modeling.models.cox", REF / "modeling" / "models" / "cox.py")
+    torch.manual_seed(4)
+    cases = {}
+    # the reference's own docstring known answers (cox.py:192-204)
+    log_hz = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5])
+    event = torch.tensor([1, 0, 1, 0, 1], dtype=torch.bool)
+    time = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0])
+    cases["doc_mean"] = cox.neg_partial_log_likelihood(log_hz, time, event).item()
+    cases["doc_sum"] = cox.neg_partial_log_likelihood(log_hz, time, event, reduction="sum").item()
+    time_t = torch.tensor([1.0, 2.0, 2.0, 4.0, 5.0])
+    cases["doc_tie_efron"] = cox.neg_partial_log_likelihood(log_hz, time_t, event, ties_method="efron").item()
+    cases["doc_tie_breslow"] = cox.neg_partial_log_likelihood(log_hz, time_t, event, ties_method="breslow").item()
+    lh = torch.randn(40)
+    tt = torch.randint(1, 15, (40,)).float()          # many ties
+    ev = torch.rand(40) < 0.7
+    save("cox.npz", log_hz=lh.numpy(), time=tt.numpy(), event=ev.numpy(),
+         efron=np.array(cox.neg_partial_log_likelihood(lh, tt, ev, ties_method="efron").item()),
+         breslow=np.array(cox.neg_partial_log_likelihood(lh, tt, ev, ties_method="breslow").item()),
+         notie=np.array(cox.neg_partial_log_likelihood(lh, torch.arange(40.0), ev).item()),
+         **{k: np.array(v) for k, v in cases.items()})
+    tr = load_by_path("stamp.modeling.transforms", REF / "modeling" / "transforms.py")
+    out = {}
+    for dt, name in ((torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        torch.manual_seed(21)
+        data = (torch.randn(64, 33) * 100).to(dt)
+        torch.manual_seed(22)      # the reference draws torch.randint from the global CPU generator
+        aug = tr.vary_precision(data, min_fraction_bits=2)
+        out[f"in_{name}"] = data.view(torch.int16 if dt != torch.float32 else torch.int32).numpy()
+        out[f"out_{name}"] = aug.view(torch.int16 if dt != torch.float32 else torch.int32).numpy()
+    save("vary_precision.npz", **out)
+
+
+def golden_bag() -> None:
+    # modeling/data.py imports h5py at module top; exec only the pure-torch function
+    glb = {"torch": torch, "_Bag": typing.Any, "_Coordinates": typing.Any, "BagSize": int}
+    exec_defs(REF / "modeling" / "data.py", {"_to_fixed_size_bag"}, glb)
+    f = glb["_to_fixed_size_bag"]
+    out = {}
+    for n, bs in ((10, 16), (100, 16), (16, 16), (1000, 512), (1, 4)):
+        torch.manual_seed(n)
+        bag = torch.randn(n, 6)
+        coords = torch.rand(n, 2)
+        torch.manual_seed(1234)
+        b1, c1, l1 = f(bag, coords, bs, deterministic=False)
+        b2, c2, l2 = f(bag, coords, bs, deterministic=True)
+        out.update({f"bag_{n}_{bs}": bag.numpy(), f"coords_{n}_{bs}": coords.numpy(),
+                    f"rand_bag_{n}_{bs}": b1.numpy(), f"rand_coords_{n}_{bs}": c1.numpy(), f"rand_len_{n}_{bs}": np.array(l1),
+                    f"det_bag_{n}_{bs}": b2.numpy(), f"det_coords_{n}_{bs}": c2.numpy(), f"det_len_{n}_{bs}": np.array(l2)})
+    save("fixed_size_bag.npz", **out)
+
+
+def main() -> None:
+    install_shims()
+    golden_chief()
+    golden_mil_vit()
+    golden_transmil()
+    golden_mlp_cox_transforms()
+    golden_bag()
+
+
+if __name__ == "__main__":
+    main()
