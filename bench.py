@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- tiles/s of the MI355X tile-encoder hot path (BASELINE.json configs[1]: ViT-L/14 tile extraction
+on synthetic 224x224x3 u8 tiles, random-init weights of that architecture).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one virtual slide of `--tiles` u8 tiles already resident in HBM:
+im2col -> patch-embed GEMM -> 24 x {LN, QKV GEMM, attention, proj GEMM(+residual), LN, fc1 GEMM(+GELU),
+fc2 GEMM(+residual)} -> final LN on CLS -> fp16 features in HBM.  Slides shard across ranks (weak scaling: every
+rank encodes its own slide per step); for N>1 every step ends with the path's one collective, an RCCL all-gather
+of the slide-level embeddings.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse() -> argparse.Namespace:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tiles", type=int, default=1024, help="tiles per step per GPU (one virtual slide)")
+    ap.add_argument("--chunk", type=int, default=256, help="tiles per internal forward chunk")
+    ap.add_argument("--model", default="vit_large_patch14_224")
+    ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, seconds: float) -> dict:
+    """The oracle (= the reference's algorithm on torch CPU fp32 kernels, batch 64 like the reference's
+    DataLoader, src/stamp/preprocessing/__init__.py:317) timed on this box's host cores on a bounded sample."""
+    from oracle.vit_tile_encoder import extract_features
+
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1234)
+    batch = 16
+    tiles = torch.randint(0, 256, (batch, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g)
+    extract_features(tiles[:2], sd, cfg)           # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        extract_features(tiles, sd, cfg)
+        n += batch
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 512:
+            break
+    return {"value": round(n / el, 3), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"{n} synthetic 224x224 tiles, ViT-L/14 fp32 oracle (torch CPU), batches of {batch}, {el:.1f}s"}
+
+
+def main() -> None:
+    a = parse()
+    from stamp_amd import _lib, distributed as D, ops
+    from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
+
+    ctx = D.init_from_env()
+    if ctx.device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if a.gpus != ctx.world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
+    cfg = PRESETS[a.model]
+    act = torch.float16 if a.act == "f16" else torch.bfloat16
+    sd = random_vit_state_dict(cfg, seed=0, init="moderate")
+    model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk)
+    g = torch.Generator().manual_seed(1234 + ctx.rank)
+    tiles = torch.randint(0, 256, (a.tiles, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g).to(ctx.device)
+    slide_ids = torch.tensor([ctx.rank], device=ctx.device)
+
+    def step() -> torch.Tensor:
+        feats = model(tiles)                                        # fp16 [tiles, D] in HBM
+        if ctx.world > 1:                                           # collate slide-level embeddings (RCCL)
+            emb = feats.float().mean(dim=0, keepdim=True)
+            return D.gather_slide_embeddings(ctx, emb, slide_ids, ctx.world)
+        return feats
+
+    lib = _lib.lib()
+    for _ in range(a.warmup):
+        step()
+    lib.amds_profile_reset()
+    lib.amds_profile_enable(1)
+    D.barrier(ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier(ctx)
+    elapsed = time.perf_counter() - t0
+    lib.amds_profile_enable(0)
+    elapsed = D.max_over_ranks(ctx, elapsed)
+    assert torch.isfinite(out.float()).all()
+
+    # roofline of the dominant kernel (the MFMA GEMM), from HIP events recorded around every launch of it
+    ms, n, work = C.c_double(), C.c_long(), C.c_double()
+    kinds = {}
+    for kind, name in ((0, "gemm"), (1, "attention"), (2, "layernorm"), (3, "im2col")):
+        _lib.check(lib.amds_profile_read(kind, C.byref(ms), C.byref(n), C.byref(work)), "profile_read")
+        kinds[name] = (ms.value, n.value, work.value)
+    gms, gn, gflop = kinds["gemm"]
+    achieved = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    total_tiles = a.tiles * a.steps * ctx.world
+    value = total_tiles / elapsed
+    line = {
+        "metric": "tiles/sec encoded (224x224, ViT-L/14)", "value": round(value, 2), "unit": "tiles/s",
+        "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.act, "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: ViT-L/14 (dim 1024, depth 24, 16 heads, 257 tokens, GELU MLP, "
+                               "LayerScale) tile extraction on synthetic 224x224x3 u8 tiles resident in HBM, "
+                               "random-init weights, fp16 CLS features out",
+                   "model": a.model, "tiles_per_step_per_gpu": a.tiles, "chunk": a.chunk,
+                   "operands": a.act, "accumulate": "f32", "residual_stream": "f32",
+                   "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
+                   "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
+                   "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+        "roofline": {"kernel": "gemm_tn_kernel (MFMA 32x32x16, fused epilogues)", "bound": "mfma",
+                     "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),
+                     "avg_gflop_per_launch": round(gflop / max(gn, 1) / 1e9, 2),
+                     "time_share": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kinds.items()}},
+    }
+    if ctx.is_main and ctx.world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds)
+    elif ctx.is_main:
+        line["cpu_baseline"] = None
+    if ctx.is_main:
+        print(json.dumps(line), flush=True)
+    if ctx.world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,15 @@ const char* amds_last_error(void);
 /* Fills name (<= n bytes) with the device's gcnArchName; AMDS_ERR_NODEVICE if none. */
 int amds_device_info(int device, char* name_host, int n, int* cu_count_host, size_t* hbm_bytes_host);
 
+/* Live per-kernel timing for bench.py's roofline line: while enabled, every launch made through this
+ * library is bracketed by a pair of HIP events recorded on the launch stream.  kind: 0 = MFMA GEMM
+ * (work = 2*M*N*K flops), 1 = ViT attention (flops), 2 = LayerNorm (bytes), 3 = im2col (bytes),
+ * 4 = fp32-MFMA GEMM (flops).  amds_profile_read waits for the recorded events and returns the summed
+ * duration, launch count and summed work of one kind since the last reset (at most 32768 launches). */
+int amds_profile_enable(int on);
+int amds_profile_reset(void);
+int amds_profile_read(int kind, double* total_ms_host, long* launches_host, double* total_work_host);
+
 /* ------------------------------------------------------------------------------------------------
  * Building blocks (also used by the MIL heads)
  * ---------------------------------------------------------------------------------------------- */

@@ -47,6 +47,9 @@ PROTOTYPES = {
     "amds_version": (_i, []),
     "amds_last_error": (C.c_char_p, []),
     "amds_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_sz)]),
+    "amds_profile_enable": (_i, [_i]),
+    "amds_profile_reset": (_i, []),
+    "amds_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "amds_cast_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "amds_layernorm": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp]),
     "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

@@ -18,6 +18,36 @@ int hip_fail(hipError_t e, const char* what) {
     return AMDS_ERR_HIP;
 }
 
+// ---- profiler ------------------------------------------------------------------------------------
+bool g_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+constexpr int PROF_MAX = 1 << 15;
+ProfRec* g_recs = nullptr;
+int g_nrec = 0, g_nalloc = 0;
+long g_dropped = 0;
+bool g_open = false;
+}  // namespace
+void prof_begin(int kind, double work, hipStream_t st) {
+    g_open = false;
+    if (g_nrec >= PROF_MAX) { ++g_dropped; return; }
+    if (!g_recs) g_recs = (ProfRec*)calloc(PROF_MAX, sizeof(ProfRec));
+    if (g_nrec >= g_nalloc) {
+        if (hipEventCreate(&g_recs[g_nrec].a) != hipSuccess || hipEventCreate(&g_recs[g_nrec].b) != hipSuccess) { ++g_dropped; return; }
+        g_nalloc = g_nrec + 1;
+    }
+    g_recs[g_nrec].kind = kind;
+    g_recs[g_nrec].work = work;
+    (void)hipEventRecord(g_recs[g_nrec].a, st);
+    g_open = true;
+}
+void prof_end(hipStream_t st) {
+    if (!g_open) return;
+    (void)hipEventRecord(g_recs[g_nrec].b, st);
+    ++g_nrec;
+    g_open = false;
+}
+
 // default tile configuration: AMDS_GEMM_CFG overrides (tuning), else by shape
 int default_gemm_cfg(int M, int N, int K) {
     static int env = -2;
@@ -55,6 +85,25 @@ extern "C" int amds_device_info(int device, char* name_host, int n, int* cu_coun
     return AMDS_OK;
 }
 
+extern "C" int amds_profile_enable(int on) { g_prof_on = on != 0; return AMDS_OK; }
+extern "C" int amds_profile_reset(void) { g_nrec = 0; g_dropped = 0; return AMDS_OK; }
+extern "C" int amds_profile_read(int kind, double* total_ms_host, long* launches_host, double* total_work_host) {
+    AMDS_REQUIRE(kind >= 0 && kind < PROF_NKINDS, "amds_profile_read: bad kind %d", kind);
+    double ms = 0, work = 0;
+    long n = 0;
+    for (int i = 0; i < g_nrec; ++i) {
+        if (g_recs[i].kind != kind) continue;
+        AMDS_HIP(hipEventSynchronize(g_recs[i].b));
+        float t = 0.f;
+        AMDS_HIP(hipEventElapsedTime(&t, g_recs[i].a, g_recs[i].b));
+        ms += t; work += g_recs[i].work; ++n;
+    }
+    if (total_ms_host) *total_ms_host = ms;
+    if (launches_host) *launches_host = n;
+    if (total_work_host) *total_work_host = work;
+    return AMDS_OK;
+}
+
 static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi,
                      void* out, long ldo, const float* bias, const float* scale, const float* pos, int np, int T,
                      int P, float acc_scale, void* stream) {
@@ -73,6 +122,7 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
     ep.np = np; ep.T = T; ep.P = P; ep.acc_scale = acc_scale;
     if (cfg < 0) cfg = default_gemm_cfg(M, N, K);
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);
     if (dtype == AMDS_F16) return gemm_dispatch<f16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);
     if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);
     set_error("amds_gemm: bad dtype %d", dtype);

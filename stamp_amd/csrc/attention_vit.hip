@@ -193,6 +193,7 @@ extern "C" int amds_attention_vit(const void* qkv, void* out, int B, int T, int 
     AMDS_REQUIRE(B >= 0 && T > 0 && H > 0, "amds_attention_vit: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
     if (dtype == AMDS_F16) return launch_attn<f16>(qkv, out, B, T, H, st);
     if (dtype == AMDS_BF16) return launch_attn<bf16>(qkv, out, B, T, H, st);
     set_error("amds_attention_vit: bad dtype %d", dtype);

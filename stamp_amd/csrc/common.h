@@ -92,6 +92,17 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// ---- live per-kernel timing (HIP events on the launch stream; off unless amds_profile_enable(1)) ----
+enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_GEMM_F32 = 4, PROF_NKINDS = 5 };
+extern bool g_prof_on;
+void prof_begin(int kind, double work, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(int kind, double work, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(kind, work, s); }
+    ~ProfScope() { if (on) prof_end(st); }
+};
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace amds

@@ -213,6 +213,7 @@ extern "C" int amds_layernorm(const float* x, long x_row_stride, const float* ga
     AMDS_REQUIRE(x_row_stride % 4 == 0 && y_row_stride % 4 == 0, "amds_layernorm: row strides must be multiples of 4");
     if (rows == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_LN, (double)rows * cols * (4 + (out_dtype == AMDS_F32 ? 4 : 2)), st);
     switch (out_dtype) {
         case AMDS_F16: return launch_ln<f16>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, cols, eps, st);
         case AMDS_BF16: return launch_ln<bf16>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, cols, eps, st);
@@ -279,6 +280,7 @@ extern "C" int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int i
     const int g = img / patch;
     const size_t lds = (size_t)patch * img * 3;
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_OTHER, (double)B * ((double)img * img * 3 + (double)g * g * kp * 2), st);
     if (dtype == AMDS_F16)
         hipLaunchKernelGGL((im2col_u8_kernel<f16>), dim3(B * g), dim3(256), lds, st, tiles, (f16*)out, img, patch, kp);
     else if (dtype == AMDS_BF16)

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__
 int gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* Cout, int ldc, int M, int N,
              int K, int relu, hipStream_t st) {
     const dim3 grid(cdiv(N, 64), cdiv(M, 64));
+    ProfScope prof(PROF_GEMM_F32, 2.0 * M * (double)N * K, st);
     if (relu) hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, Cout, ldc, M, N, K);
     else hipLaunchKernelGGL((gemm_f32_kernel<0>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, Cout, ldc, M, N, K);
     AMDS_LAUNCH_CHECK("gemm_f32_kernel");

@@ -1,0 +1,103 @@
+"""Slide-parallel multi-GPU plumbing: one process per GPU, RCCL (torch.distributed "nccl" on ROCm) over xGMI.
+
+The reference is strictly single-device (``devices=1``, src/stamp/modeling/train.py:541-547) and parallelises
+across machines only by "shuffle the slide list and skip existing outputs"
+(src/stamp/preprocessing/__init__.py:269-286).  The unit of work is a slide with no cross-slide state, so
+slides shard embarrassingly: every rank runs the whole tile pipeline on its own slides and writes its own
+feature files.  There is exactly ONE data-path collective: an all-gather of slide-level embeddings
+(``[slides, D]``, a few MB at most) so that every rank holds the table patient-level MIL trains on.  Tile-level
+features are never gathered.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DistCtx:
+    rank: int
+    world: int
+    local_rank: int
+    device: torch.device
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+
+def init_from_env(prefer_gpu: bool = True) -> DistCtx:
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run) and join the group if WORLD_SIZE>1."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+    use_gpu = prefer_gpu and torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": device} if use_gpu else {}
+        dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world, **kw)
+    return DistCtx(rank, world, local, device)
+
+
+def barrier(ctx: DistCtx) -> None:
+    if ctx.world > 1:
+        if ctx.device.type == "cuda":
+            dist.barrier(device_ids=[ctx.local_rank])
+        else:
+            dist.barrier()
+
+
+def shard_slides(tile_counts: list[int], world: int) -> list[list[int]]:
+    """Longest-processing-time-first assignment of slides (by tile count) to ranks; deterministic.
+
+    Returns, per rank, the slide indices it owns (each list in ascending slide order)."""
+    loads = [0] * world
+    owned: list[list[int]] = [[] for _ in range(world)]
+    for idx in sorted(range(len(tile_counts)), key=lambda i: (-tile_counts[i], i)):
+        r = min(range(world), key=lambda j: (loads[j], j))
+        owned[r].append(idx)
+        loads[r] += tile_counts[idx]
+    return [sorted(o) for o in owned]
+
+
+def gather_slide_embeddings(ctx: DistCtx, local_emb: torch.Tensor, local_ids: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather per-rank slide embeddings ``[n_local, D]`` (+ their global slide ids) into ``[n_total, D]``.
+
+    Ranks may own different numbers of slides: buffers are padded to the maximum count (one equal-size
+    all-gather instead of an all-gather-v); rows whose id is -1 are padding.  Slides nobody owns stay zero."""
+    D = local_emb.shape[1] if local_emb.dim() == 2 else 0
+    out = torch.zeros(n_total, D, dtype=local_emb.dtype, device=local_emb.device)
+    if ctx.world == 1:
+        if local_ids.numel():
+            out[local_ids.long()] = local_emb
+        return out
+    n_local = torch.tensor([local_emb.shape[0]], dtype=torch.int64, device=local_emb.device)
+    dist.all_reduce(n_local, op=dist.ReduceOp.MAX)
+    cap = int(n_local.item())
+    emb = torch.zeros(cap, D, dtype=local_emb.dtype, device=local_emb.device)
+    ids = torch.full((cap,), -1, dtype=torch.int64, device=local_emb.device)
+    emb[: local_emb.shape[0]] = local_emb
+    ids[: local_ids.shape[0]] = local_ids.to(torch.int64)
+    all_emb = torch.empty(ctx.world * cap, D, dtype=emb.dtype, device=emb.device)
+    all_ids = torch.empty(ctx.world * cap, dtype=torch.int64, device=emb.device)
+    dist.all_gather_into_tensor(all_emb, emb)
+    dist.all_gather_into_tensor(all_ids, ids)
+    valid = all_ids >= 0
+    out[all_ids[valid]] = all_emb[valid]
+    return out
+
+
+def max_over_ranks(ctx: DistCtx, value: float) -> float:
+    if ctx.world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=ctx.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

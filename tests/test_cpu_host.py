@@ -1,0 +1,100 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol; host logic; sharding; the
+world_size-2 gloo path of the slide-embedding collation."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from stamp_amd import _lib
+
+    lib = _lib.lib()
+    header = (ROOT / "include" / "amdstamp.h").read_text()
+    declared = set(re.findall(r"\b(amds_[a-z0-9_]+)\s*\(", header))
+    declared -= {"amds_status", "amds_dtype", "amds_epilogue"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/amdstamp.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert lib.amds_version() == 1
+
+
+def test_ops_refuse_cpu_tensors():
+    from stamp_amd import ops
+
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6)
+    from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
+
+    with pytest.raises(RuntimeError, match="GPU only"):
+        HipViT(PRESETS["test_tiny"], random_vit_state_dict(PRESETS["test_tiny"]), device="cpu")
+
+
+def test_product_never_imports_oracle():
+    for p in (ROOT / "stamp_amd").rglob("*.py"):
+        src = p.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{p} imports the oracle"
+
+
+def test_flops_per_tile_matches_survey():
+    from stamp_amd.vit import PRESETS
+
+    assert abs(PRESETS["vit_large_patch14_224"].matmul_flops_per_tile() / 1e9 - 162.02) < 0.01
+    assert abs(PRESETS["uni2_h"].matmul_flops_per_tile() / 1e9 - 370.94) < 0.01
+
+
+def test_shard_slides_lpt():
+    from stamp_amd.distributed import shard_slides
+
+    counts = [20000, 100, 15000, 15000, 300, 9000, 9000, 50]
+    shards = shard_slides(counts, 4)
+    assert sorted(i for s in shards for i in s) == list(range(len(counts)))
+    loads = [sum(counts[i] for i in s) for s in shards]
+    assert max(loads) == 20000 and min(loads) >= 15000
+    assert shard_slides(counts, 4) == shards                      # deterministic
+    assert shard_slides([], 3) == [[], [], []]
+    assert shard_slides([5], 2) == [[0], []]
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["REPO"])
+from stamp_amd import distributed as D
+ctx = D.init_from_env(prefer_gpu=False)
+counts = [7, 3, 9, 1, 4]
+mine = D.shard_slides(counts, ctx.world)[ctx.rank]
+emb = torch.stack([torch.full((6,), float(i + 1)) for i in mine]) if mine else torch.zeros(0, 6)
+table = D.gather_slide_embeddings(ctx, emb, torch.tensor(mine, dtype=torch.int64), len(counts))
+expect = torch.stack([torch.full((6,), float(i + 1)) for i in range(len(counts))])
+assert torch.equal(table, expect), table
+t = D.max_over_ranks(ctx, float(ctx.rank + 1))
+assert t == float(ctx.world)
+D.barrier(ctx)
+print("rank", ctx.rank, "ok")
+"""
+
+
+def test_gather_slide_embeddings_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_gather_single_rank():
+    from stamp_amd.distributed import DistCtx, gather_slide_embeddings
+
+    ctx = DistCtx(0, 1, 0, torch.device("cpu"))
+    t = gather_slide_embeddings(ctx, torch.ones(2, 3), torch.tensor([2, 0]), 4)
+    assert t[0].sum() == 3 and t[2].sum() == 3 and t[1].sum() == 0
