@@ -56,8 +56,8 @@ int default_gemm_cfg(int M, int N, int K) {
         env = s ? atoi(s) : -1;
     }
     if (env >= 0) return env;
-    (void)K;
-    if (M <= 2048 || N < 256) return 0;
+    // the staggered 256x256 pipeline wins whenever the grid fills the chip; small problems keep 128x128 tiles
+    if (N % 256 == 0 && K >= 128 && (long)cdiv(M, 256) * (N / 256) >= 192) return 3;
     return 0;
 }
 

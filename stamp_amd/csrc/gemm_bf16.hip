@@ -1,5 +1,5 @@
 // bf16-operand instantiations of the MFMA GEMM (see gemm_kernel.h)
-#include "gemm_kernel.h"
+#include "gemm_8p.h"
 namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(bf16)
 }

@@ -1,5 +1,19 @@
 // f16-operand instantiations of the MFMA GEMM (see gemm_kernel.h)
-#include "gemm_kernel.h"
+#include "gemm_8p.h"
 namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(f16)
+}
+
+// performance-archaeology entry (f16, EPI_BIAS only): ablated variants of the 8-phase kernel; results are wrong by design
+extern "C" int amds_gemm_ablate(int abl, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                                void* out, long ldo, const float* bias, void* stream) {
+    using namespace amds;
+    EpiArgs ep; ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; ep.pos = (abl & 16) ? bias : nullptr; if (abl & 16) ep.bias = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    switch (abl) {
+#define C_(x) case x: return launch_gemm_8p_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
+        C_(0) C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(12) C_(14) C_(15) C_(16) C_(17) C_(18) C_(32) C_(48) C_(64) C_(80) C_(128) C_(192) C_(208)
+#undef C_
+    }
+    return AMDS_ERR_INVALID;
 }

@@ -45,7 +45,10 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& ep, int m, int n, float
             v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
         }
     }
-    if constexpr (EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_GELU_F32) {
+    if constexpr (EPI == AMDS_EPI_BIAS_GELU) {
+        v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
+    }
+    if constexpr (EPI == AMDS_EPI_BIAS_GELU_F32) {
         v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
     }
     if constexpr (EPI == AMDS_EPI_BIAS_RELU || EPI == AMDS_EPI_BIAS_RELU_F32) {
@@ -79,7 +82,7 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& ep, int m, int n, float
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
-__global__ void __launch_bounds__(64 * WM * WN)
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
                EpiArgs ep, int tiles_m, int tiles_n) {
     typedef typename Act<T>::vec8 vec8;
@@ -156,25 +159,40 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
 
     const int nk = K / BK;
     stage_load(0, 0);
+    vec8 af[2][FM], wf[2][FN];
+    auto load_frags = [&](const char* sb, int ks, int set) {
+        const int coff = ((ks * 2 + hi) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+            af[set][i] = *reinterpret_cast<const vec8*>(sb + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            wf[set][j] = *reinterpret_cast<const vec8*>(sb + w_row_off + j * 32 * 128 + coff);
+    };
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
         const char* sb = smem + (kt & 1) * STAGE;
+        // register double-buffered fragments: the ds_reads of k-step ks+1 are in flight under the MFMAs of ks
+        load_frags(sb, 0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int coff = ((ks * 2 + hi) ^ swz) << 4;
-            vec8 af[FM], wf[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                af[i] = *reinterpret_cast<const vec8*>(sb + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                wf[j] = *reinterpret_cast<const vec8*>(sb + w_row_off + j * 32 * 128 + coff);
+            if (ks + 1 < 4) load_frags(sb, ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = Act<T>::mfma32(wf[j], af[i], acc[i][j]);
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Act<T>::mfma32(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
+            if (ks + 1 < 4) {
+                // interleave: one ds_read per MFMA for the first FM+FN MFMAs of this k-step
+#pragma unroll
+                for (int r = 0; r < FM + FN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
+            }
         }
     }
 
@@ -240,10 +258,24 @@ static int launch_gemm_cfg(const void* A, long lda, const void* W, long ldw, int
     return AMDS_OK;
 }
 
-// tile configuration ids (amds_gemm_ex): 0 = 128x128 (2x2 waves), 1 = 256x128 (4x2), 2 = 256x256 (2x4)
+template <typename T, int EPI, int VARIANT>
+static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                          hipStream_t st);   // gemm_8p.h
+
+// tile configuration ids (amds_gemm_ex): 0 = 128x128 (2x2 waves), 1 = 256x128 (4x2), 2 = 256x256 (2x4),
+// 3 = 256x256 staggered 8-wave pipeline (gemm_8p.h; needs N % 256 == 0 and K >= 128, else falls back to 0)
 template <typename T, int EPI>
 static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                        const EpiArgs& ep, hipStream_t st) {
+    if (cfg >= 3 && cfg <= 6) {   // 8-phase kernel; 4..6 are A/B variants kept for tuning
+        if (N % 256 == 0 && K >= 128) {
+            if (cfg == 3) return launch_gemm_8p<T, EPI, 0>(A, lda, W, ldw, M, N, K, ep, st);
+            if (cfg == 4) return launch_gemm_8p<T, EPI, 256>(A, lda, W, ldw, M, N, K, ep, st);        // direct epilogue
+            if (cfg == 5) return launch_gemm_8p<T, EPI, 128 + 64>(A, lda, W, ldw, M, N, K, ep, st);   // AGPR acc + loader prio
+            return launch_gemm_8p<T, EPI, 128 + 64 + 256>(A, lda, W, ldw, M, N, K, ep, st);           // both
+        }
+        cfg = 0;
+    }
     switch (cfg) {
         case 0: return launch_gemm_cfg<T, 128, 128, 2, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
         case 1: return launch_gemm_cfg<T, 256, 128, 4, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);

@@ -92,7 +92,7 @@ class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
-                 act_dtype: torch.dtype = torch.float16, chunk: int = 128) -> None:
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 255) -> None:
         super().__init__()
         if cfg.heads * 64 != cfg.dim:
             raise ValueError(f"head_dim must be 64 (dim={cfg.dim}, heads={cfg.heads})")

@@ -34,7 +34,7 @@ def _gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
 def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
@@ -52,7 +52,26 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_epilogues(gpu, dt):
+@pytest.mark.parametrize("M,N,K", [(1, 256, 128), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
+                                   (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
+def test_gemm_8phase_pipeline(gpu, dt, M, N, K):
+    """cfg 3 (staggered 4-stage LDS ring, counted vmcnt): exact-shape sweep incl. the minimum K (4 phases), ragged M,
+    and a race screen -- 6 launches must be bitwise identical and match an fp64 reference."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a = torch.randn(M, K, generator=g).to(gpu, dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
+    a[:, 0] += torch.arange(M, device=gpu).to(dt) * 0.01
+    bias = torch.randn(N, generator=g).to(gpu)
+    ref = _gemm_ref(a, w, bias)
+    outs = [ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, cfg=3) for _ in range(6)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    err = (outs[0].double() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()) * (K / 1024 + 1), err
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_epilogues(gpu, dt, cfg=-1):
     M, N, K = 771, 512, 256
     g = torch.Generator().manual_seed(5)
     a = torch.randn(M, K, generator=g).to(gpu, dt)

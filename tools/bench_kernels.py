@@ -26,7 +26,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--dtype", default="f16")
-    ap.add_argument("--cfgs", default="0,1,2")
+    ap.add_argument("--cfgs", default="0,2,3")
+    ap.add_argument("--rounds", type=int, default=1)
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
     dev = torch.device("cuda:0")
@@ -42,7 +43,7 @@ def main():
         w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev, dt)
         bias = torch.randn(N, generator=g).to(dev)
         out = x.clone() if epi == _lib.EPI_RESIDUAL else torch.empty(M, N, dtype=dt, device=dev)
-        for cfg in [int(c) for c in a.cfgs.split(",")]:
+        for cfg in [int(c) for c in a.cfgs.split(",")] * a.rounds:
             t = timeit(lambda: ops.gemm(A, w, epi, bias=bias, out=out, cfg=cfg))
             print(f"gemm {name:5s} M={M} N={N} K={K} cfg={cfg}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)

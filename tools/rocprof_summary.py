@@ -1,0 +1,31 @@
+"""Summarise a rocprofv3 rocpd (.db) kernel trace into a per-kernel table (name, calls, total/avg/min/max us, %)."""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("void amds::", "").replace("amds::", "")
+    return name[:110]
+
+
+def main(path: str) -> None:
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = db.execute(f"select {namecol}, start, end from kernels").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0])
+        d = (e - s) / 1e3
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    print(f"{'kernel':110s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k:110s} {a[0]:7d} {a[1]:12.1f} {a[1]/a[0]:10.2f} {a[2]:10.2f} {a[3]:10.2f} {100*a[1]/tot:6.2f}")
+    print(f"{'TOTAL':110s} {sum(a[0] for a in agg.values()):7d} {tot:12.1f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
