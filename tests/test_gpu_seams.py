@@ -1,0 +1,78 @@
+"""The Extractor / Encoder seams on the GPU: golden parity for gated-attention pooling (fixtures captured from the
+reference's CHIEFModel), the Extractor object contract, empty / ragged inputs."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+
+
+@pytest.mark.parametrize("tag", ["small", "xs"])
+def test_gated_attention_matches_reference_golden(gpu, tag):
+    from stamp_amd.encoder import HipGatedAttentionEncoder
+
+    z = np.load(G / f"chief_gated_attention_{tag}.npz")
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    enc = HipGatedAttentionEncoder(sd, device=gpu)
+    x = torch.from_numpy(z["x"])
+    emb = enc._generate_slide_embedding(x, gpu)
+    assert emb.shape == (x.shape[1],) and emb.dtype == np.float32
+    np.testing.assert_allclose(emb, z["wsi_feature"].reshape(-1), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(enc.attention_raw(x).cpu().numpy(), z["attention_raw"].reshape(-1), rtol=2e-5, atol=2e-5)
+    # patient level = concatenation of slides (chief.py:129-135)
+    emb2 = enc._generate_patient_embedding([x[:100], x[100:]], gpu)
+    np.testing.assert_allclose(emb2, emb, rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        enc._generate_slide_embedding(torch.zeros(0, x.shape[1]), gpu)
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 1024, 5000])
+def test_gated_attention_sizes_vs_oracle(gpu, N):
+    from oracle.gated_attention import KEYS, gated_attention_pool
+    from stamp_amd import ops
+
+    g = torch.Generator().manual_seed(N)
+    F, L, D = 768, 512, 256
+    sd = {KEYS["fc_w"]: torch.randn(L, F, generator=g) / F ** 0.5, KEYS["fc_b"]: torch.randn(L, generator=g) * 0.1,
+          KEYS["a_w"]: torch.randn(D, L, generator=g) / L ** 0.5, KEYS["a_b"]: torch.randn(D, generator=g) * 0.1,
+          KEYS["b_w"]: torch.randn(D, L, generator=g) / L ** 0.5, KEYS["b_b"]: torch.randn(D, generator=g) * 0.1,
+          KEYS["c_w"]: torch.randn(1, D, generator=g) * 2, KEYS["c_b"]: torch.randn(1, generator=g)}
+    x = torch.randn(N, F, generator=g)
+    ref = gated_attention_pool(x, sd)
+    w = {k: sd[v].to(gpu).contiguous() for k, v in KEYS.items()}
+    out, araw = ops.gated_attn_pool(x.to(gpu), w, return_attn=True)
+    np.testing.assert_allclose(araw.cpu().numpy(), ref["attention_raw"].reshape(-1).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), ref["WSI_feature"].reshape(-1).numpy(), rtol=1e-4, atol=1e-5)
+    out2 = ops.gated_attn_pool(x.to(gpu), w)
+    assert torch.equal(out, out2)          # deterministic (no atomics)
+
+
+def test_extractor_seam(gpu):
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd.extractor import Extractor, extract_tiles, hip_vit_extractor, u8_tile_transform
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+
+    cfg = PRESETS["test_tiny"]
+    sd = random_vit_state_dict(cfg, seed=9)
+    ex = hip_vit_extractor("test_tiny", sd, device=gpu, chunk=3)
+    assert isinstance(ex, Extractor) and ex.identifier == "amdstamp-test_tiny"
+    with pytest.raises(Exception):
+        ex.identifier = "x"                 # frozen, like the reference dataclass
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (224, 224, 3), dtype=np.uint8) for _ in range(7)]
+    tiles = torch.stack([ex.transform(im) for im in imgs])          # what the reference's DataLoader collates
+    assert tiles.dtype == torch.uint8 and tiles.shape == (7, 224, 224, 3)
+    model = ex.model.to(gpu).eval()                                   # preprocessing/__init__.py:243
+    with torch.inference_mode():
+        feats = model(tiles.to(gpu)).detach().half().cpu()            # :324-325
+    ref = extract_features(tiles, sd, cfg)
+    assert feats.dtype == torch.float16 and ((feats.float() - ref.float()).norm() / ref.float().norm()).item() < 2e-3
+    assert torch.equal(extract_tiles(ex, tiles, batch_size=4, device=gpu), feats)
+    assert extract_tiles(ex, tiles[:0], device=gpu).shape == (0, cfg.dim)      # slide without tiles
+    with pytest.raises(ValueError):
+        u8_tile_transform(np.zeros((224, 224), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 100, 100, 3, dtype=torch.uint8, device=gpu))      # wrong tile size: an exception, not abort()
