@@ -130,7 +130,7 @@ def main() -> None:
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-        "roofline": {"kernel": "gemm_8p_kernel (256x256x32 staggered 8-wave MFMA 32x32x16 pipeline, fused epilogues)", "bound": "mfma",
+        "roofline": {"kernel": "gemm_8p64_kernel (256x256x64 staggered two-group 8-wave MFMA 32x32x16 pipeline, fused LDS-staged epilogues)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),

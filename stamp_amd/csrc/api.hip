@@ -57,7 +57,7 @@ int default_gemm_cfg(int M, int N, int K) {
     }
     if (env >= 0) return env;
     // the staggered 256x256 pipeline wins whenever the grid fills the chip; small problems keep 128x128 tiles
-    if (N % 256 == 0 && K >= 128 && (long)cdiv(M, 256) * (N / 256) >= 192) return 3;
+    if (N % 256 == 0 && (long)cdiv(M, 256) * (N / 256) >= 192) return 8;
     return 0;
 }
 

@@ -1,5 +1,7 @@
 // bf16-operand instantiations of the MFMA GEMM (see gemm_kernel.h)
 #include "gemm_8p.h"
+#include "gemm_4w.h"
+#include "gemm_8p64.h"
 namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(bf16)
 }

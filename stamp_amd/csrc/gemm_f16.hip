@@ -1,5 +1,7 @@
 // f16-operand instantiations of the MFMA GEMM (see gemm_kernel.h)
 #include "gemm_8p.h"
+#include "gemm_4w.h"
+#include "gemm_8p64.h"
 namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(f16)
 }
@@ -14,6 +16,11 @@ extern "C" int amds_gemm_ablate(int abl, const void* A, long lda, const void* W,
 #define C_(x) case x: return launch_gemm_8p_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
         C_(0) C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(12) C_(14) C_(15) C_(16) C_(17) C_(18) C_(32) C_(48) C_(64) C_(80) C_(128) C_(192) C_(208)
 #undef C_
+    }
+    switch (abl - 1000) {     // 1000 + bits: the 4-wave kernel
+#define D_(x) case x: return launch_gemm_4w_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
+        D_(0) D_(1) D_(4) D_(5) D_(8) D_(9) D_(12) D_(13)
+#undef D_
     }
     return AMDS_ERR_INVALID;
 }

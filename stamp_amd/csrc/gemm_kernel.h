@@ -258,6 +258,12 @@ static int launch_gemm_cfg(const void* A, long lda, const void* W, long ldw, int
     return AMDS_OK;
 }
 
+template <typename T, int EPI>
+static int launch_gemm_8p64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                            hipStream_t st);   // gemm_8p64.h
+template <typename T, int EPI>
+static int launch_gemm_4w(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                          hipStream_t st);   // gemm_4w.h
 template <typename T, int EPI, int VARIANT>
 static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                           hipStream_t st);   // gemm_8p.h
@@ -267,6 +273,10 @@ static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int 
 template <typename T, int EPI>
 static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                        const EpiArgs& ep, hipStream_t st) {
+    if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 8) cfg = 0;
+    if (cfg == 7 && N % 256 == 0 && K >= 128) return launch_gemm_4w<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 7) cfg = 0;
     if (cfg >= 3 && cfg <= 6) {   // 8-phase kernel; 4..6 are A/B variants kept for tuning
         if (N % 256 == 0 && K >= 128) {
             if (cfg == 3) return launch_gemm_8p<T, EPI, 0>(A, lda, W, ldw, M, N, K, ep, st);

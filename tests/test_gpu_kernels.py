@@ -34,7 +34,7 @@ def _gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
 def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
@@ -54,7 +54,8 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1, 256, 128), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
                                    (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
-def test_gemm_8phase_pipeline(gpu, dt, M, N, K):
+@pytest.mark.parametrize("cfg", [3, 7, 8])
+def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
     """cfg 3 (staggered 4-stage LDS ring, counted vmcnt): exact-shape sweep incl. the minimum K (4 phases), ragged M,
     and a race screen -- 6 launches must be bitwise identical and match an fp64 reference."""
     g = torch.Generator().manual_seed(M * 3 + N + K)
@@ -63,7 +64,7 @@ def test_gemm_8phase_pipeline(gpu, dt, M, N, K):
     a[:, 0] += torch.arange(M, device=gpu).to(dt) * 0.01
     bias = torch.randn(N, generator=g).to(gpu)
     ref = _gemm_ref(a, w, bias)
-    outs = [ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, cfg=3) for _ in range(6)]
+    outs = [ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, cfg=cfg) for _ in range(6)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     err = (outs[0].double() - ref).abs().max().item()
@@ -71,37 +72,45 @@ def test_gemm_8phase_pipeline(gpu, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_epilogues(gpu, dt, cfg=-1):
+@pytest.mark.parametrize("cfg", [0, 3, 7, 8])
+def test_gemm_epilogues(gpu, dt, cfg):
     M, N, K = 771, 512, 256
+    _g = ops.gemm
+    class _O:      # route every call of this test through the chosen kernel family
+        @staticmethod
+        def gemm(*a, **k):
+            k.setdefault("cfg", cfg)
+            return _g(*a, **k)
+    ops_ = _O
     g = torch.Generator().manual_seed(5)
     a = torch.randn(M, K, generator=g).to(gpu, dt)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
     bias = torch.randn(N, generator=g).to(gpu)
     ref = _gemm_ref(a, w, bias)
     e = _eps(dt)
-    out = ops.gemm(a, w, _lib.EPI_BIAS, bias=bias)
+    out = ops_.gemm(a, w, _lib.EPI_BIAS, bias=bias)
     assert out.dtype == dt and (out.double() - ref).abs().max().item() < e * ref.abs().max().item() * 1.01
-    out = ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=bias)
+    out = ops_.gemm(a, w, _lib.EPI_BIAS_GELU, bias=bias)
     r = torch.nn.functional.gelu(ref)
     assert (out.double() - r).abs().max().item() < e * r.abs().max().item() * 1.01 + 1e-6
-    out = ops.gemm(a, w, _lib.EPI_BIAS_RELU, bias=bias)
+    out = ops_.gemm(a, w, _lib.EPI_BIAS_RELU, bias=bias)
     assert (out.double() - ref.clamp(min=0)).abs().max().item() < e * ref.abs().max().item() * 1.01
-    out = ops.gemm(a, w, _lib.EPI_BIAS_GELU_F32, bias=bias)
+    out = ops_.gemm(a, w, _lib.EPI_BIAS_GELU_F32, bias=bias)
     assert (out.double() - r).abs().max().item() < 2e-5
-    out = ops.gemm(a, w, _lib.EPI_BIAS_RELU_F32, bias=bias)
+    out = ops_.gemm(a, w, _lib.EPI_BIAS_RELU_F32, bias=bias)
     assert (out.double() - ref.clamp(min=0)).abs().max().item() < 2e-5
     # residual with LayerScale
     x0 = torch.randn(M, N, generator=g).to(gpu)
     scale = torch.rand(N, generator=g).to(gpu)
     x = x0.clone()
-    ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=bias, scale=scale, out=x)
+    ops_.gemm(a, w, _lib.EPI_RESIDUAL, bias=bias, scale=scale, out=x)
     r = x0.double() + scale.double() * ref
     assert (x.double() - r).abs().max().item() < 2e-5
     x = x0.clone()
-    ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=None, scale=None, out=x)
+    ops_.gemm(a, w, _lib.EPI_RESIDUAL, bias=None, scale=None, out=x)
     assert (x.double() - (x0.double() + _gemm_ref(a, w, None))).abs().max().item() < 2e-5
     # acc_scale
-    out = ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, acc_scale=0.25)
+    out = ops_.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, acc_scale=0.25)
     assert (out.double() - (0.25 * _gemm_ref(a, w, None) + bias.double())).abs().max().item() < 2e-5
 
 
