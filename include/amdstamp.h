@@ -118,6 +118,12 @@ int amds_pack_swiglu_rows(const float* src, float* dst, int H, int cols, void* s
  * head_dim is fixed at 64; T <= 288 (whole K/V of a head staged in LDS). softmax(q k^T / 8) v. */
 int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
 
+/* Same contract for ANY T (K/V streamed through LDS in 64-key tiles, online softmax; the T x T matrix is never
+ * materialised).  Used by the MIL heads: bags of 1024 tiles in training, whole slides (tens of thousands of
+ * tiles) at deploy time (reference src/stamp/modeling/models/vision_tranformer.py:191, 217-227, mask=None path
+ * of src/stamp/modeling/models/__init__.py:286-313). */
+int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tile encoder (ViT) -- the model behind Extractor.model (reference
  * src/stamp/preprocessing/extractor/__init__.py:17-28; called at src/stamp/preprocessing/__init__.py:324-325)

@@ -1,0 +1,192 @@
+// attention_flash.hip -- multi-head self-attention for ANY sequence length (head_dim 64): the MIL heads attend over
+// a whole bag (T+1 = 1025 tokens in training, up to tens of thousands at deploy time, where the reference simply
+// materialises the T x T matrix -- src/stamp/modeling/models/__init__.py:286-313 disables the mask "to reduce
+// memory").  Reference op: nn.MultiheadAttention / F.scaled_dot_product_attention at
+// src/stamp/modeling/models/vision_tranformer.py:191, 217-227 (mask = None path).
+//
+// One workgroup = 128 queries (4 waves x 32) of one (bag, head); K / V stream through LDS in tiles of 64 keys,
+// double buffered (global -> registers -> LDS; V is transposed on the way, see attention_vit.hip for the layout
+// rules: S^T = K Q^T keeps a query's scores in one lane, the key order inside 16-key groups is bit-permuted so P is
+// already the MFMA B operand).  Scores never leave registers: N^2 is never materialised, K/V are re-read once per
+// 128-query block (L2-resident: 2 x T x 128 B per head).
+#include "common.h"
+
+namespace amds {
+
+constexpr int FA_KT = 64;                       // keys per tile
+constexpr int FA_VS = 192;                      // V^T row stride in bytes (12 slots) + 16 B skew per 8 rows: conflict-free
+constexpr int FA_K_BYTES = FA_KT * 128;         // 8 KB
+constexpr int FA_V_BYTES = 64 * FA_VS + 8 * 16; // 12.1 KB
+constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES;
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+    const int Dm = H * 64;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * 64;
+    const int ntile = (Tn + FA_KT - 1) / FA_KT;
+
+    // staging registers (global -> regs -> LDS so the next tile's loads fly during this tile's MFMAs)
+    u32x4 kreg[2];
+    vec8 v0reg, v1reg;
+    const int k_key[2] = {tid >> 3, (tid >> 3) + 32};
+    const int k_ch = tid & 7;
+    const int v_kp = tid >> 3, v_ch = tid & 7;            // key pair 0..31, d chunk 0..7
+    auto stage_load = [&](int j) {
+        const int key0 = j * FA_KT;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int key = key0 + k_key[r];
+            kreg[r] = u32x4{0u, 0u, 0u, 0u};
+            if (key < Tn) kreg[r] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + k_ch * 8);
+        }
+        const int vk = key0 + v_kp * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v0reg[e] = (T)0.f; v1reg[e] = (T)0.f; }
+        if (vk < Tn) v0reg = *reinterpret_cast<const vec8*>(base + (long)vk * ld + 2 * Dm + v_ch * 8);
+        if (vk + 1 < Tn) v1reg = *reinterpret_cast<const vec8*>(base + (long)(vk + 1) * ld + 2 * Dm + v_ch * 8);
+    };
+    auto stage_store = [&](int buf) {
+        char* sK = smem + buf * FA_STAGE;
+        char* sV = sK + FA_K_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int key = k_key[r];
+            *reinterpret_cast<u32x4*>(sK + key * 128 + ((k_ch ^ ((key >> 1) & 7)) << 4)) = kreg[r];
+        }
+        const int k0 = v_kp * 2;
+        const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            typedef T vec2 __attribute__((ext_vector_type(2)));
+            vec2 w;
+            w[0] = v0reg[e]; w[1] = v1reg[e];
+            *reinterpret_cast<vec2*>(sV + (v_ch * 8 + e) * FA_VS + v_ch * 16 + pos * 2) = w;
+        }
+    };
+
+    // this wave's 32 queries
+    const int q = qblk * 128 + wave * 32 + l31;
+    const int qc = min(q, Tn - 1);
+    vec8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const vec8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float mrun = -INFINITY, l = 0.f;
+    const float sc = 0.125f * 1.44269504088896340736f;
+    const int swz = (l31 >> 1) & 7;
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int j = 0; j < ntile; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < ntile) stage_load(j + 1);
+        const char* sK = smem + buf * FA_STAGE;
+        const char* sV = sK + FA_K_BYTES;
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 kf = *reinterpret_cast<const vec8*>(sK + (t * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+                s[t] = Act<T>::mfma32(kf, qf[ks], s[t]);
+            }
+        }
+        const int key0 = j * FA_KT;
+        const bool ragged = key0 + FA_KT > Tn;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = s[t][r] * sc;
+                if (ragged && key >= Tn) v = -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = exp2f(mrun - mnew);
+        mrun = mnew;
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[t][r] - mnew);
+                s[t][r] = p;
+                ls += p;
+            }
+        l = l * alpha + ls;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                vec8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[t][ks * 8 + e]);
+                const int pos = t * 32 + ks * 16 + hi * 8;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + l31;
+                    const vec8 vf = *reinterpret_cast<const vec8*>(sV + d * FA_VS + (d >> 3) * 16 + pos * 2);
+                    o[dt] = Act<T>::mfma32(vf, pf, o[dt]);
+                }
+            }
+        if (j + 1 < ntile) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q < Tn) {
+        const float inv = 1.0f / l;
+        T* orow = out + ((long)b * Tn + q) * Dm + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
+                *reinterpret_cast<vec4*>(orow + dt * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && out, "amds_attention: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H);
+    else { set_error("amds_attention: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel");
+    return AMDS_OK;
+}

@@ -1,0 +1,135 @@
+"""MIL heads on the HIP path -- inference forward (deploy / validation), reference state_dict keys.
+
+`VisionTransformer` here mirrors the reference's MIL model class of the same name
+(src/stamp/modeling/models/vision_tranformer.py:298-384): same keyword-only constructor, same parameter names
+(`class_token`, `project_features.0.*`, `transformer.layers.{l}.0.{norm,mhsa.in_proj_*,mhsa.out_proj.*}`,
+`transformer.layers.{l}.1.{0,1,4}.*`, `transformer.norm.*`, `mlp_head.0.*`), so checkpoints interchange through
+`load_state_dict`; ``forward(bags, *, coords, mask)`` has the reference signature (pinned by tests/test_model.py:28-32).
+
+Round-1 coverage: the ``mask=None`` forward the Lightning wrappers actually use for validation / predict
+(src/stamp/modeling/models/__init__.py:286-313), without ALiBi, in ``torch.no_grad`` / eval.  Training (backward),
+``mask != None`` and ``use_alibi=True`` raise NotImplementedError -- loudly, there is no torch fallback.
+
+Arithmetic plan: bags are fp16 on disk (preprocessing/__init__.py:325), so the projection GEMM consumes them
+exactly; MFMA operands fp16, fp32 accumulate, fp32 residual stream and LayerNorm, exact-erf GELU on the fp32
+projection output, streaming attention (never materialises T x T, so whole-slide bags fit).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+
+def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
+    r = (-w.shape[0]) % mult
+    return w if r == 0 else torch.cat([w, w.new_zeros(r, *w.shape[1:])])
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, *, dim_output: int, dim_input: int, dim_model: int, n_layers: int, n_heads: int,
+                 dim_feedforward: int, dropout: float, use_alibi: bool) -> None:
+        super().__init__()
+        if use_alibi:
+            raise NotImplementedError("use_alibi=True is not on the HIP path yet (oracle/mil_vit.py restates it)")
+        if n_heads * 64 != dim_model or dim_model % 128 or dim_feedforward % 128:
+            raise NotImplementedError(f"HIP MIL vit needs head_dim 64 and dims that are multiples of 128 "
+                                      f"(dim_model={dim_model}, n_heads={n_heads}, dim_feedforward={dim_feedforward})")
+        self.dim_output, self.dim_input, self.dim_model = dim_output, dim_input, dim_model
+        self.n_layers, self.n_heads, self.dim_feedforward = n_layers, n_heads, dim_feedforward
+        D = dim_model
+        # parameters with the reference's names and shapes (registered flat; state_dict keys match the reference)
+        self.class_token = nn.Parameter(torch.randn(D))
+        P = nn.ParameterDict()
+        def add(name, *shape, ones=False, zeros=False):
+            t = torch.ones(*shape) if ones else torch.zeros(*shape) if zeros else torch.randn(*shape) / (shape[-1] ** 0.5)
+            P[name.replace(".", "/")] = nn.Parameter(t)
+        add("project_features.0.weight", D, dim_input); add("project_features.0.bias", D, zeros=True)
+        for l in range(n_layers):
+            p = f"transformer.layers.{l}."
+            add(p + "0.norm.weight", D, ones=True); add(p + "0.norm.bias", D, zeros=True)
+            add(p + "0.mhsa.in_proj_weight", 3 * D, D); add(p + "0.mhsa.in_proj_bias", 3 * D, zeros=True)
+            add(p + "0.mhsa.out_proj.weight", D, D); add(p + "0.mhsa.out_proj.bias", D, zeros=True)
+            add(p + "1.0.weight", D, ones=True); add(p + "1.0.bias", D, zeros=True)
+            add(p + "1.1.weight", dim_feedforward, D); add(p + "1.1.bias", dim_feedforward, zeros=True)
+            add(p + "1.4.weight", D, dim_feedforward); add(p + "1.4.bias", D, zeros=True)
+        add("transformer.norm.weight", D, ones=True); add("transformer.norm.bias", D, zeros=True)
+        add("mlp_head.0.weight", dim_output, D); add("mlp_head.0.bias", dim_output, zeros=True)
+        self._p = P
+        self._packed = None
+
+    # ---- reference-compatible state_dict ---------------------------------------------------------------------
+    def state_dict(self, *a, **k):   # type: ignore[override]
+        sd = {"class_token": self.class_token.detach()}
+        sd.update({n.replace("/", "."): p.detach() for n, p in self._p.items()})
+        return sd
+
+    def load_state_dict(self, sd, strict: bool = True):   # type: ignore[override]
+        own = self.state_dict()
+        missing, unexpected = [k for k in own if k not in sd], [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"state_dict mismatch: missing {missing}, unexpected {unexpected}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k == "class_token":
+                    self.class_token.copy_(v)
+                elif k in own:
+                    self._p[k.replace(".", "/")].copy_(v)
+        self._packed = None
+        return self
+
+    def _pack(self, dev):
+        g = lambda n: self._p[n.replace(".", "/")].detach().to(dev, torch.float32).contiguous()  # noqa: E731
+        h16 = lambda w: ops.cast_pad(_pad_rows(w, 128), (w.shape[1] + 63) // 64 * 64, torch.float16)  # noqa: E731
+        pk = {"cls": self.class_token.detach().to(dev, torch.float32),
+              "proj_w": h16(g("project_features.0.weight")), "proj_b": g("project_features.0.bias"), "layers": []}
+        for l in range(self.n_layers):
+            p = f"transformer.layers.{l}."
+            pk["layers"].append(dict(
+                ln1=(g(p + "0.norm.weight"), g(p + "0.norm.bias")),
+                qkv=(h16(g(p + "0.mhsa.in_proj_weight")), g(p + "0.mhsa.in_proj_bias")),
+                out=(h16(g(p + "0.mhsa.out_proj.weight")), g(p + "0.mhsa.out_proj.bias")),
+                ln2=(g(p + "1.0.weight"), g(p + "1.0.bias")),
+                fc1=(h16(g(p + "1.1.weight")), g(p + "1.1.bias")),
+                fc2=(h16(g(p + "1.4.weight")), g(p + "1.4.bias"))))
+        pk["norm"] = (g("transformer.norm.weight"), g("transformer.norm.bias"))
+        hb = g("mlp_head.0.bias")
+        pk["head"] = (h16(g("mlp_head.0.weight")), torch.cat([hb, hb.new_zeros((-hb.shape[0]) % 128)]))
+        return pk
+
+    def forward(self, bags: torch.Tensor, *, coords: torch.Tensor | None = None, mask: torch.Tensor | None = None):
+        if mask is not None:
+            raise NotImplementedError("mask != None is not on the HIP path (the reference's Lit wrappers always pass None)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("training (backward) through the HIP MIL head is not implemented; call under "
+                                      "torch.no_grad() / .eval() for deploy-time forward")
+        if not bags.is_cuda:
+            raise RuntimeError("HIP MIL head needs bags on the GPU (no CPU fallback)")
+        Bb, T, F = bags.shape
+        if F != self.dim_input:
+            raise ValueError(f"bags have {F} features, model expects {self.dim_input}")
+        dev, D, H = bags.device, self.dim_model, self.n_heads
+        if self._packed is None or self._packed["cls"].device != dev:
+            self._packed = self._pack(dev)
+        pk = self._packed
+        Kp = (F + 63) // 64 * 64
+        a = bags.reshape(Bb * T, F)
+        a = a.contiguous() if (a.dtype == torch.float16 and Kp == F) else ops.cast_pad(a.float(), Kp, torch.float16)
+        proj = ops.gemm(a, pk["proj_w"], _lib.EPI_BIAS_GELU_F32, bias=pk["proj_b"])          # [Bb*T, D] fp32
+        S = T + 1
+        x = torch.empty(Bb, S, D, dtype=torch.float32, device=dev)
+        x[:, 0] = pk["cls"]                                                                  # vision_tranformer.py:347-348
+        x[:, 1:] = proj.view(Bb, T, D)
+        x = x.view(Bb * S, D)
+        for L in pk["layers"]:
+            h = ops.layernorm(x, *L["ln1"], 1e-5, torch.float16)
+            qkv = ops.gemm(h, L["qkv"][0], _lib.EPI_BIAS, bias=L["qkv"][1])
+            att = ops.attention(qkv, Bb, S, H)
+            ops.gemm(att, L["out"][0], _lib.EPI_RESIDUAL, bias=L["out"][1], out=x)           # x = attn(x) + x   (:291-292)
+            h = ops.layernorm(x, *L["ln2"], 1e-5, torch.float16)
+            u = ops.gemm(h, L["fc1"][0], _lib.EPI_BIAS_GELU, bias=L["fc1"][1])
+            ops.gemm(u, L["fc2"][0], _lib.EPI_RESIDUAL, bias=L["fc2"][1], out=x)             # x = ff(x) + x     (:293)
+        cls = ops.layernorm_rows(x, Bb, D, S * D, *pk["norm"], 1e-5, torch.float16)          # final LN, class token only
+        logits = ops.gemm(cls, pk["head"][0], _lib.EPI_BIAS_F32, bias=pk["head"][1])
+        return logits[:, : self.dim_output].contiguous()

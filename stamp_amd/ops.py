@@ -56,6 +56,17 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y
 
 
+def layernorm_rows(x: torch.Tensor, rows: int, cols: int, x_row_stride: int, gamma: torch.Tensor, beta: torch.Tensor,
+                   eps: float, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """LayerNorm of `rows` rows of `cols` elements that start every `x_row_stride` elements of x (e.g. CLS tokens)."""
+    _dev(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty(rows, cols, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().amds_layernorm(_p(x), x_row_stride, _p(gamma), _p(beta), _p(y), cols, rows, cols, eps,
+                                         _DT[out_dtype], _stream()), "layernorm")
+    return y
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, *, bias=None, scale=None, out=None, pos=None, np_=0, T=0, P=0,
          acc_scale: float = 1.0, cfg: int = -1, n_out: int | None = None) -> torch.Tensor:
     """out = epilogue(a[M,K] @ w[N,K]^T).  See include/amdstamp.h for the epilogues."""
@@ -79,6 +90,15 @@ def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
     out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
     _lib.check(_lib.lib().amds_attention_vit(_p(qkv), _p(out), B, T, H, act_code(qkv.dtype), _stream()), "attention_vit")
+    return out
+
+
+def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+    """softmax(q k^T / 8) v for any T (streaming K/V kernel); qkv [B*T, 3*H*64] -> [B*T, H*64]."""
+    _dev(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
+    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention(_p(qkv), _p(out), B, T, H, act_code(qkv.dtype), _stream()), "attention")
     return out
 
 

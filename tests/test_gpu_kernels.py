@@ -164,6 +164,23 @@ def test_attention_vit(gpu, dt, B, T, H):
     assert err < 4 * _eps(dt) * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,H", [(2, 1025, 8), (1, 300, 2), (1, 64, 1), (1, 63, 1), (3, 129, 4), (1, 5000, 2), (2, 257, 16), (1, 1, 1)])
+def test_attention_streaming_any_length(gpu, dt, B, T, H):
+    g = torch.Generator().manual_seed(B * 77 + T + H)
+    D = H * 64
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(gpu, dt)
+    out = ops.attention(qkv, B, T, H)
+    q, k, v = qkv.double().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 4 * _eps(dt) * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(out, ops.attention(qkv, B, T, H))
+    if T <= 288:      # the two kernels implement the same op
+        o2 = ops.attention_vit(qkv, B, T, H)
+        assert (out.double() - o2.double()).abs().max().item() < 4 * _eps(dt) * max(1.0, ref.abs().max().item())
+
+
 def test_attention_softmax_spike(gpu):
     """one key dominating a row / large logits: exercises the running-max rescale across chunks"""
     B, T, H = 1, 257, 1
