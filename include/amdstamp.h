@@ -210,6 +210,26 @@ size_t amds_gated_attn_pool_workspace_bytes(int N, int F, int L, int D);
 int amds_gated_attn_pool(const float* x, const amds_gap_weights* w_host, float* out, float* attn_raw,
                          int N, int F, int L, int D, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Small rows of the MIL path
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Fixed-size bag building: dst[i] = i < n_idx ? (out dtype) src[idx[i]] : 0 for i < n_out -- the gather + ".float()"
+ * + zero padding of reference src/stamp/modeling/data.py:811-862 (`_to_fixed_size_bag`); the indices (randperm /
+ * linspace.round) are drawn by the caller.  idx: int64 device.  dtype pairs: f16->f32, f16->f16, f32->f32. */
+int amds_gather_rows(const void* src, long src_ld, const long* idx, int n_idx, void* dst, long dst_ld, int n_out,
+                     int cols, int in_dtype, int out_dtype, void* stream);
+
+/* vary_precision (reference src/stamp/modeling/transforms.py:5-29): out = bits & (~0 << shifts[i]) on the 16- or
+ * 32-bit pattern of every element; shifts (u8, drawn by the caller with torch.randint like the reference). */
+int amds_vary_precision(const void* bits_in, const uint8_t* shifts, void* bits_out, long n, int elem_bytes, void* stream);
+
+/* Mean over tiles: x [B][T][F] (f16/f32) -> out fp32 [B][F] (reference src/stamp/modeling/models/mlp.py:40-41). */
+int amds_mean_pool(const void* x, float* out, int B, int T, int F, int in_dtype, void* stream);
+
+/* out[M][N] = (relu?)(x[M][K] w[N][K]^T + bias) in exact fp32 (fp32-input MFMA); MLP / Linear heads, mlp.py:24-33. */
+int amds_linear_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

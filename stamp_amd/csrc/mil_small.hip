@@ -1,0 +1,96 @@
+// mil_small.hip -- the small, HBM/latency-bound rows of the MIL path:
+//   * amds_gather_rows     fixed-size bag building: gather sampled tile rows (+ fp16 -> fp32 ".float()") and zero-pad
+//                          (reference src/stamp/modeling/data.py:811-862 `_to_fixed_size_bag`, :584-655 BagDataset)
+//   * amds_vary_precision  random mantissa truncation, pure integer bit-ops (reference src/stamp/modeling/transforms.py:5-29)
+//   * amds_mean_pool       mean over the tiles of a bag (reference src/stamp/modeling/models/mlp.py:40-41, 58-59)
+//   * amds_linear_f32      exact-fp32 Linear (+ReLU) on the fp32 MFMA, for the MLP / Linear heads (mlp.py:24-33, 50-51)
+#include "common.h"
+
+namespace amds {
+int gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* Cout, int ldc, int M, int N,
+             int K, int relu, hipStream_t st);   // gap.hip
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const TI* __restrict__ src, long src_ld, const long* __restrict__ idx,
+                                                          int n_idx, TO* __restrict__ dst, long dst_ld, int n_out, int cols) {
+    const int row = blockIdx.x;
+    if (row >= n_out) return;
+    TO* d = dst + (long)row * dst_ld;
+    if (row < n_idx) {
+        const TI* s = src + idx[row] * src_ld;
+        for (int c = threadIdx.x; c < cols; c += 256) d[c] = (TO)s[c];
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256) d[c] = (TO)0.f;
+    }
+}
+
+template <typename W>
+__global__ void vary_precision_kernel(const W* __restrict__ in, const uint8_t* __restrict__ shifts, W* __restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i] & (W)(~(W)0 << shifts[i]);
+}
+
+template <typename TI>
+__global__ void __launch_bounds__(256) mean_pool_kernel(const TI* __restrict__ x, float* __restrict__ out, int T, int F) {
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const TI* p = x + (long)b * T * F + f;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += (float)p[(long)t * F];    // sequential over tiles: deterministic
+    out[(long)b * F + f] = s / (float)T;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_gather_rows(const void* src, long src_ld, const long* idx, int n_idx, void* dst, long dst_ld, int n_out,
+                                int cols, int in_dtype, int out_dtype, void* stream) {
+    AMDS_REQUIRE(src && dst && (idx || n_idx == 0), "amds_gather_rows: null pointer");
+    AMDS_REQUIRE(n_idx >= 0 && n_out >= n_idx && cols > 0, "amds_gather_rows: bad sizes n_idx=%d n_out=%d cols=%d", n_idx, n_out, cols);
+    if (n_out == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(n_out), block(256);
+    if (in_dtype == AMDS_F16 && out_dtype == AMDS_F32)
+        hipLaunchKernelGGL((gather_rows_kernel<f16, float>), grid, block, 0, st, (const f16*)src, src_ld, idx, n_idx, (float*)dst, dst_ld, n_out, cols);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F16)
+        hipLaunchKernelGGL((gather_rows_kernel<f16, f16>), grid, block, 0, st, (const f16*)src, src_ld, idx, n_idx, (f16*)dst, dst_ld, n_out, cols);
+    else if (in_dtype == AMDS_F32 && out_dtype == AMDS_F32)
+        hipLaunchKernelGGL((gather_rows_kernel<float, float>), grid, block, 0, st, (const float*)src, src_ld, idx, n_idx, (float*)dst, dst_ld, n_out, cols);
+    else { set_error("amds_gather_rows: unsupported dtype pair %d -> %d", in_dtype, out_dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("gather_rows_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_vary_precision(const void* bits_in, const uint8_t* shifts, void* bits_out, long n, int elem_bytes, void* stream) {
+    AMDS_REQUIRE(bits_in && shifts && bits_out, "amds_vary_precision: null pointer");
+    AMDS_REQUIRE(n >= 0 && (elem_bytes == 2 || elem_bytes == 4), "amds_vary_precision: elem_bytes must be 2 or 4");
+    if (n == 0) return AMDS_OK;
+    const int grid = (int)min((long)4096, (n + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (elem_bytes == 2) hipLaunchKernelGGL((vary_precision_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, (const uint16_t*)bits_in, shifts, (uint16_t*)bits_out, n);
+    else hipLaunchKernelGGL((vary_precision_kernel<uint32_t>), dim3(grid), dim3(256), 0, st, (const uint32_t*)bits_in, shifts, (uint32_t*)bits_out, n);
+    AMDS_LAUNCH_CHECK("vary_precision_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_mean_pool(const void* x, float* out, int B, int T, int F, int in_dtype, void* stream) {
+    AMDS_REQUIRE(x && out, "amds_mean_pool: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && F > 0, "amds_mean_pool: bad shape B=%d T=%d F=%d (empty bags have no mean)", B, T, F);
+    if (B == 0) return AMDS_OK;
+    const dim3 grid(cdiv(F, 256), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == AMDS_F32) hipLaunchKernelGGL((mean_pool_kernel<float>), grid, block, 0, st, (const float*)x, out, T, F);
+    else if (in_dtype == AMDS_F16) hipLaunchKernelGGL((mean_pool_kernel<f16>), grid, block, 0, st, (const f16*)x, out, T, F);
+    else { set_error("amds_mean_pool: bad dtype %d", in_dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("mean_pool_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_linear_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int relu, void* stream) {
+    AMDS_REQUIRE(x && w && out, "amds_linear_f32: null pointer");
+    AMDS_REQUIRE(M >= 0 && N > 0 && K > 0, "amds_linear_f32: bad shape");
+    if (M == 0) return AMDS_OK;
+    return gemm_f32(x, K, w, K, bias, out, N, M, N, K, relu, (hipStream_t)stream);
+}

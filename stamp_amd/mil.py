@@ -133,3 +133,76 @@ class VisionTransformer(nn.Module):
         cls = ops.layernorm_rows(x, Bb, D, S * D, *pk["norm"], 1e-5, torch.float16)          # final LN, class token only
         logits = ops.gemm(cls, pk["head"][0], _lib.EPI_BIAS_F32, bias=pk["head"][1])
         return logits[:, : self.dim_output].contiguous()
+
+
+# ---- bag building (reference src/stamp/modeling/data.py:811-862) ------------------------------------------------
+def fixed_size_bag_indices(n_tiles: int, bag_size: int, deterministic: bool = False,
+                           generator: torch.Generator | None = None) -> torch.Tensor:
+    """The reference's sampling rule; drawn on the host exactly like the reference (torch.randperm on its CPU RNG)."""
+    if n_tiles <= bag_size:
+        return torch.arange(n_tiles)
+    if deterministic:
+        return torch.linspace(0, n_tiles - 1, steps=bag_size).round().long()
+    return torch.randperm(n_tiles, generator=generator)[:bag_size]
+
+
+def to_fixed_size_bag(feats: torch.Tensor, coords: torch.Tensor, bag_size: int, deterministic: bool = False,
+                      generator: torch.Generator | None = None):
+    """feats [N,F] f16/f32 + coords [N,2] f32 on the GPU -> (bag f32 [bag_size,F], coords [bag_size,2], n) via the HIP gather."""
+    idx = fixed_size_bag_indices(feats.shape[0], bag_size, deterministic, generator).to(feats.device)
+    bag = ops.gather_rows(feats.contiguous(), idx, bag_size, torch.float32)       # ".float()" of data.py:617 fused in
+    c = ops.gather_rows(coords.contiguous().float(), idx, bag_size, torch.float32)
+    return bag, c, min(bag_size, feats.shape[0])
+
+
+def vary_precision(data: torch.Tensor, *, min_fraction_bits: int, generator: torch.Generator | None = None) -> torch.Tensor:
+    """reference src/stamp/modeling/transforms.py:5-29; the shift draw stays torch.randint on the host RNG."""
+    if min_fraction_bits < 1:
+        raise ValueError("min_fraction bits has to be at least 1")
+    frac = {torch.float32: 23, torch.float16: 10, torch.bfloat16: 7}.get(data.dtype)
+    if frac is None:
+        raise NotImplementedError(f"precision variation not implemented for {data.dtype}")
+    shifts = torch.randint(0, frac - min_fraction_bits, data.shape, generator=generator).to(torch.uint8).to(data.device)
+    return ops.vary_precision(data.contiguous(), shifts)
+
+
+class MLP(nn.Module):
+    """reference src/stamp/modeling/models/mlp.py:6-44 (state_dict keys `mlp.{0,3,...}`); eval forward on the HIP path."""
+
+    def __init__(self, dim_input: int, dim_hidden: int, dim_output: int, num_layers: int, dropout: float):
+        super().__init__()
+        layers, d = [], dim_input
+        for _ in range(num_layers - 1):
+            layers += [nn.Linear(d, dim_hidden), nn.ReLU(), nn.Dropout(dropout)]
+            d = dim_hidden
+        layers.append(nn.Linear(d, dim_output))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training through the HIP MLP head is not implemented")
+        if x.ndim == 3:
+            x = ops.mean_pool(x.contiguous())
+        elif x.ndim != 2:
+            raise ValueError(f"Expected 2D or 3D input, got {x.shape}")
+        x = x.float().contiguous()
+        lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        for i, m in enumerate(lin):
+            x = ops.linear_f32(x, m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), relu=i < len(lin) - 1)
+        return x
+
+
+class Linear(nn.Module):
+    """reference src/stamp/modeling/models/mlp.py:47-62."""
+
+    def __init__(self, dim_input: int, dim_output: int):
+        super().__init__()
+        self.fc = nn.Linear(dim_input, dim_output)
+
+    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        if x.ndim == 3:
+            x = ops.mean_pool(x.contiguous())
+        elif x.ndim != 2:
+            raise ValueError(f"Expected 2D or 3D input, got {x.shape}")
+        return ops.linear_f32(x.float().contiguous(), self.fc.weight.detach().float().contiguous(),
+                              self.fc.bias.detach().float().contiguous())

@@ -149,3 +149,42 @@ def gated_attn_pool(x: torch.Tensor, weights: dict[str, torch.Tensor], return_at
     _lib.check(lib.amds_gated_attn_pool(_p(x), C.byref(gw), _p(out), _p(araw), N, F, L, D, _p(ws), nbytes, _stream()),
                "gated_attn_pool")
     return (out, araw) if return_attn else out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, n_out: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """dst[i] = src[idx[i]] (cast to out_dtype) for i < len(idx), zero rows up to n_out."""
+    _dev(src, idx)
+    assert src.dim() == 2 and src.is_contiguous() and idx.dtype == torch.int64
+    dst = torch.empty(n_out, src.shape[1], dtype=out_dtype, device=src.device)
+    _lib.check(_lib.lib().amds_gather_rows(_p(src), src.shape[1], _p(idx), idx.numel(), _p(dst), src.shape[1], n_out,
+                                           src.shape[1], _DT[src.dtype], _DT[out_dtype], _stream()), "gather_rows")
+    return dst
+
+
+def vary_precision(data: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
+    """data: f32 / f16 / bf16 tensor; shifts: uint8, same shape = number of low mantissa bits to clear per element."""
+    _dev(data, shifts)
+    assert data.is_contiguous() and shifts.is_contiguous() and shifts.dtype == torch.uint8 and shifts.shape == data.shape
+    out = torch.empty_like(data)
+    _lib.check(_lib.lib().amds_vary_precision(_p(data), _p(shifts), _p(out), data.numel(), data.element_size(), _stream()),
+               "vary_precision")
+    return out
+
+
+def mean_pool(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    assert x.dim() == 3 and x.is_contiguous()
+    B, T, F = x.shape
+    out = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_mean_pool(_p(x), _p(out), B, T, F, _DT[x.dtype], _stream()), "mean_pool")
+    return out
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
+    _dev(x, w, b)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_linear_f32(_p(x), _p(w), _p(b), _p(out), M, N, K, 1 if relu else 0, _stream()), "linear_f32")
+    return out

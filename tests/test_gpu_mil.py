@@ -54,3 +54,65 @@ def test_mil_vit_state_dict_roundtrip_and_guards(gpu):
     with pytest.raises(RuntimeError, match="GPU"):
         with torch.no_grad():
             m1.eval()(bags.cpu(), coords=None, mask=None)
+
+
+def test_fixed_size_bag_matches_reference_golden(gpu):
+    """bit-exact against the fixtures captured from the reference's _to_fixed_size_bag (same RNG stream)."""
+    from pathlib import Path
+
+    import numpy as np
+
+    from stamp_amd.mil import to_fixed_size_bag
+
+    z = np.load(Path(__file__).parent / "golden" / "fixed_size_bag.npz")
+    for n, bs in ((10, 16), (100, 16), (16, 16), (1000, 512), (1, 4)):
+        bag, coords = torch.from_numpy(z[f"bag_{n}_{bs}"]).to(gpu), torch.from_numpy(z[f"coords_{n}_{bs}"]).to(gpu)
+        b, c, l = to_fixed_size_bag(bag, coords, bs, deterministic=True)
+        assert np.array_equal(b.cpu().numpy(), z[f"det_bag_{n}_{bs}"]) and np.array_equal(c.cpu().numpy(), z[f"det_coords_{n}_{bs}"])
+        assert l == int(z[f"det_len_{n}_{bs}"])
+        torch.manual_seed(1234)
+        b, c, l = to_fixed_size_bag(bag, coords, bs, deterministic=False)
+        assert np.array_equal(b.cpu().numpy(), z[f"rand_bag_{n}_{bs}"]) and np.array_equal(c.cpu().numpy(), z[f"rand_coords_{n}_{bs}"])
+    # fp16 features on disk -> fp32 bag (".float()"), zero padding
+    f16 = torch.randn(5, 64).half().to(gpu)
+    b, _, l = to_fixed_size_bag(f16, torch.zeros(5, 2, device=gpu), 8, deterministic=True)
+    assert b.dtype == torch.float32 and torch.equal(b[:5], f16.float()) and (b[5:] == 0).all() and l == 5
+
+
+@pytest.mark.parametrize("name,tdt,idt", [("f32", torch.float32, torch.int32), ("f16", torch.float16, torch.int16), ("bf16", torch.bfloat16, torch.int16)])
+def test_vary_precision_bit_exact_vs_reference_golden(gpu, name, tdt, idt):
+    from pathlib import Path
+
+    import numpy as np
+
+    from stamp_amd.mil import vary_precision
+
+    z = np.load(Path(__file__).parent / "golden" / "vary_precision.npz")
+    data = torch.from_numpy(z[f"in_{name}"]).view(tdt).to(gpu)
+    torch.manual_seed(22)                   # the draw the reference made (global CPU generator)
+    out = vary_precision(data, min_fraction_bits=2)
+    assert np.array_equal(out.cpu().view(idt).numpy(), z[f"out_{name}"])
+    with pytest.raises(ValueError):
+        vary_precision(data, min_fraction_bits=0)
+
+
+def test_mlp_linear_heads_match_reference_golden(gpu):
+    from pathlib import Path
+
+    import numpy as np
+
+    from stamp_amd.mil import MLP, Linear
+
+    z = np.load(Path(__file__).parent / "golden" / "mlp.npz")
+    m = MLP(dim_input=20, dim_hidden=16, dim_output=3, num_layers=3, dropout=0.0).eval()
+    m.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mlp:")})
+    lin = Linear(dim_input=20, dim_output=2).eval()
+    lin.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("lin:")})
+    m, lin = m.to(gpu), lin.to(gpu)
+    with torch.no_grad():
+        for key in ("3", "2"):
+            x = torch.from_numpy(z[f"x{key}"]).to(gpu)
+            np.testing.assert_allclose(m(x).cpu().numpy(), z[f"mlp_y{key}"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(lin(x).cpu().numpy(), z[f"lin_y{key}"], rtol=1e-5, atol=1e-6)
+        with pytest.raises(ValueError):
+            m(torch.zeros(2, device=gpu))
