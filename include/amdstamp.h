@@ -124,6 +124,13 @@ int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtyp
  * of src/stamp/modeling/models/__init__.py:286-313). */
 int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
 
+/* ALiBi variant of the reference's MultiHeadALiBi (src/stamp/modeling/models/vision_tranformer.py:42-74, eval mode):
+ *   out = softmax(q k^T / 8) v  -  head_scale[h] * cdist(coords_q, coords_k) v        (bias applied AFTER the softmax)
+ * coords: fp32 [B][T][2] (class token at (0,0), :349-351); head_scale[h] = bias_scale_h / running_mean_h, fp32 [H].
+ * `out` is ALWAYS bf16 (the un-normalised distance term can exceed the fp16 range on long bags). */
+int amds_attention_alibi(const void* qkv, const float* coords, const float* head_scale, void* out, int B, int T, int H,
+                         int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tile encoder (ViT) -- the model behind Extractor.model (reference
  * src/stamp/preprocessing/extractor/__init__.py:17-28; called at src/stamp/preprocessing/__init__.py:324-325)

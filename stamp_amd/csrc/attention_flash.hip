@@ -17,12 +17,19 @@ constexpr int FA_KT = 64;                       // keys per tile
 constexpr int FA_VS = 192;                      // V^T row stride in bytes (12 slots) + 16 B skew per 8 rows: conflict-free
 constexpr int FA_K_BYTES = FA_KT * 128;         // 8 KB
 constexpr int FA_V_BYTES = 64 * FA_VS + 8 * 16; // 12.1 KB
-constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES;
+constexpr int FA_C_BYTES = FA_KT * 8;            // key coordinates (float2) of a tile, ALiBi variant only
+constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES + FA_C_BYTES;
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+// ALIBI: the reference's MultiHeadALiBi (src/stamp/modeling/models/vision_tranformer.py:42-74): the distance bias is
+// SUBTRACTED FROM THE PROBABILITIES (after the softmax):  out = softmax(q k^T/8) v  -  s_h * cdist(c_q, c_k) v,
+// s_h = bias_scale_h / running_mean_h.  The second product is accumulated by a third MFMA chain on the same V^T
+// fragments; distances are evaluated in fp32 from the token coordinates in registers (no T x T tensor).
+// TO: output element type.  The ALiBi variant always writes bf16: its second term sums |V| over ALL keys with weights
+// of order 1-10 (no softmax normalisation), which overflows fp16 (65504) on long bags; bf16 has the fp32 range.
+template <typename T, bool ALIBI, typename TO = T>
+__global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int Tn, int H,
+                                                            const float* __restrict__ coords, const float* __restrict__ head_scale) {
     typedef typename Act<T>::vec8 vec8;
-    typedef typename Act<T>::vec4 vec4;
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -37,6 +44,8 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     // staging registers (global -> regs -> LDS so the next tile's loads fly during this tile's MFMAs)
     u32x4 kreg[2];
     vec8 v0reg, v1reg;
+    float cxreg = 0.f, cyreg = 0.f;
+    const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
     const int k_key[2] = {tid >> 3, (tid >> 3) + 32};
     const int k_ch = tid & 7;
     const int v_kp = tid >> 3, v_ch = tid & 7;            // key pair 0..31, d chunk 0..7
@@ -53,6 +62,10 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) { v0reg[e] = (T)0.f; v1reg[e] = (T)0.f; }
         if (vk < Tn) v0reg = *reinterpret_cast<const vec8*>(base + (long)vk * ld + 2 * Dm + v_ch * 8);
         if (vk + 1 < Tn) v1reg = *reinterpret_cast<const vec8*>(base + (long)(vk + 1) * ld + 2 * Dm + v_ch * 8);
+        if constexpr (ALIBI) {
+            cxreg = cyreg = 0.f;
+            if (tid < FA_KT && key0 + tid < Tn) { cxreg = cbase[(long)(key0 + tid) * 2]; cyreg = cbase[(long)(key0 + tid) * 2 + 1]; }
+        }
     };
     auto stage_store = [&](int buf) {
         char* sK = smem + buf * FA_STAGE;
@@ -71,6 +84,9 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
             w[0] = v0reg[e]; w[1] = v1reg[e];
             *reinterpret_cast<vec2*>(sV + (v_ch * 8 + e) * FA_VS + v_ch * 16 + pos * 2) = w;
         }
+        if constexpr (ALIBI) {
+            if (tid < FA_KT) { float* sC = reinterpret_cast<float*>(sV + FA_V_BYTES); sC[tid * 2] = cxreg; sC[tid * 2 + 1] = cyreg; }
+        }
     };
 
     // this wave's 32 queries
@@ -80,12 +96,14 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const vec8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
 
-    f32x16 o[2];
+    f32x16 o[2], o2[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { o[dt][r] = 0.f; o2[dt][r] = 0.f; }
     float mrun = -INFINITY, l = 0.f;
+    float xq = 0.f, yq = 0.f, sh = 0.f;
+    if constexpr (ALIBI) { xq = cbase[(long)qc * 2]; yq = cbase[(long)qc * 2 + 1]; sh = head_scale[h]; }
     const float sc = 0.125f * 1.44269504088896340736f;
     const int swz = (l31 >> 1) & 7;
 
@@ -147,11 +165,25 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[t][ks * 8 + e]);
                 const int pos = t * 32 + ks * 16 + hi * 8;
+                vec8 bf;
+                if constexpr (ALIBI) {
+                    const float* sC = reinterpret_cast<const float*>(sV + FA_V_BYTES);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = ks * 8 + e;
+                        const int kl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float dx = xq - sC[kl * 2], dy = yq - sC[kl * 2 + 1];
+                        float dist = sqrtf(dx * dx + dy * dy) * sh;
+                        if (ragged && key0 + kl >= Tn) dist = 0.f;
+                        bf[e] = Act<T>::from_f32(dist);
+                    }
+                }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const int d = dt * 32 + l31;
                     const vec8 vf = *reinterpret_cast<const vec8*>(sV + d * FA_VS + (d >> 3) * 16 + pos * 2);
                     o[dt] = Act<T>::mfma32(vf, pf, o[dt]);
+                    if constexpr (ALIBI) o2[dt] = Act<T>::mfma32(vf, bf, o2[dt]);
                 }
             }
         if (j + 1 < ntile) stage_store(buf ^ 1);
@@ -160,15 +192,15 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     l += __shfl_xor(l, 32, 64);
     if (q < Tn) {
         const float inv = 1.0f / l;
-        T* orow = out + ((long)b * Tn + q) * Dm + h * 64;
+        TO* orow = out + ((long)b * Tn + q) * Dm + h * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                vec4 w;
+                typename Act<TO>::vec4 w;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
-                *reinterpret_cast<vec4*>(orow + dt * 32 + 8 * g + 4 * hi) = w;
+                for (int e = 0; e < 4; ++e) w[e] = Act<TO>::from_f32(o[dt][4 * g + e] * inv - (ALIBI ? o2[dt][4 * g + e] : 0.f));
+                *reinterpret_cast<typename Act<TO>::vec4*>(orow + dt * 32 + 8 * g + 4 * hi) = w;
             }
     }
 }
@@ -184,9 +216,24 @@ extern "C" int amds_attention(const void* qkv, void* out, int B, int T, int H, i
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
     ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
-    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H);
-    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr);
     else { set_error("amds_attention: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_alibi(const void* qkv, const float* coords, const float* head_scale, void* out, int B, int T,
+                                    int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && out && coords && head_scale, "amds_attention_alibi: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 6.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, true, bf16>), grid, block, 0, st, (const f16*)qkv, (bf16*)out, T, H, coords, head_scale);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, true, bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, coords, head_scale);
+    else { set_error("amds_attention_alibi: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<alibi>");
     return AMDS_OK;
 }

@@ -8,7 +8,8 @@
 
 Round-1 coverage: the ``mask=None`` forward the Lightning wrappers actually use for validation / predict
 (src/stamp/modeling/models/__init__.py:286-313), without ALiBi, in ``torch.no_grad`` / eval.  Training (backward),
-``mask != None`` and ``use_alibi=True`` raise NotImplementedError -- loudly, there is no torch fallback.
+and ``mask != None`` raise NotImplementedError -- loudly, there is no torch fallback.  ``use_alibi=True`` runs the
+reference's MultiHeadALiBi in eval mode (distance bias subtracted after the softmax, frozen running mean).
 
 Arithmetic plan: bags are fp16 on disk (preprocessing/__init__.py:325), so the projection GEMM consumes them
 exactly; MFMA operands fp16, fp32 accumulate, fp32 residual stream and LayerNorm, exact-erf GELU on the fp32
@@ -31,8 +32,7 @@ class VisionTransformer(nn.Module):
     def __init__(self, *, dim_output: int, dim_input: int, dim_model: int, n_layers: int, n_heads: int,
                  dim_feedforward: int, dropout: float, use_alibi: bool) -> None:
         super().__init__()
-        if use_alibi:
-            raise NotImplementedError("use_alibi=True is not on the HIP path yet (oracle/mil_vit.py restates it)")
+        self.use_alibi = bool(use_alibi)
         if n_heads * 64 != dim_model or dim_model % 128 or dim_feedforward % 128:
             raise NotImplementedError(f"HIP MIL vit needs head_dim 64 and dims that are multiples of 128 "
                                       f"(dim_model={dim_model}, n_heads={n_heads}, dim_feedforward={dim_feedforward})")
@@ -49,8 +49,17 @@ class VisionTransformer(nn.Module):
         for l in range(n_layers):
             p = f"transformer.layers.{l}."
             add(p + "0.norm.weight", D, ones=True); add(p + "0.norm.bias", D, zeros=True)
-            add(p + "0.mhsa.in_proj_weight", 3 * D, D); add(p + "0.mhsa.in_proj_bias", 3 * D, zeros=True)
-            add(p + "0.mhsa.out_proj.weight", D, D); add(p + "0.mhsa.out_proj.bias", D, zeros=True)
+            if use_alibi:       # MultiHeadALiBi: one Linear(D, 64) per head for q, k, v (+ running-mean scaler, bias_scale), fc
+                for h in range(n_heads):
+                    for enc in ("query_encoders", "key_encoders", "value_encoders"):
+                        add(p + f"0.mhsa.{enc}.{h}.weight", 64, D); add(p + f"0.mhsa.{enc}.{h}.bias", 64, zeros=True)
+                    add(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean", 1, ones=True)
+                    add(p + f"0.mhsa.attentions.{h}.scale_distance.items_so_far", 1, ones=True)
+                    P[(p + f"0.mhsa.attentions.{h}.bias_scale").replace(".", "/")] = nn.Parameter(torch.rand(1))
+                add(p + "0.mhsa.fc.weight", D, D); add(p + "0.mhsa.fc.bias", D, zeros=True)
+            else:
+                add(p + "0.mhsa.in_proj_weight", 3 * D, D); add(p + "0.mhsa.in_proj_bias", 3 * D, zeros=True)
+                add(p + "0.mhsa.out_proj.weight", D, D); add(p + "0.mhsa.out_proj.bias", D, zeros=True)
             add(p + "1.0.weight", D, ones=True); add(p + "1.0.bias", D, zeros=True)
             add(p + "1.1.weight", dim_feedforward, D); add(p + "1.1.bias", dim_feedforward, zeros=True)
             add(p + "1.4.weight", D, dim_feedforward); add(p + "1.4.bias", D, zeros=True)
@@ -86,10 +95,23 @@ class VisionTransformer(nn.Module):
               "proj_w": h16(g("project_features.0.weight")), "proj_b": g("project_features.0.bias"), "layers": []}
         for l in range(self.n_layers):
             p = f"transformer.layers.{l}."
+            if self.use_alibi:      # per-head encoders are just a row-blocked in_proj: [q heads | k heads | v heads]
+                H = self.n_heads
+                cat = lambda enc, what: torch.cat([g(p + f"0.mhsa.{enc}.{h}.{what}") for h in range(H)])  # noqa: E731
+                w_in = torch.cat([cat(e, "weight") for e in ("query_encoders", "key_encoders", "value_encoders")])
+                b_in = torch.cat([cat(e, "bias") for e in ("query_encoders", "key_encoders", "value_encoders")])
+                w_out, b_out = g(p + "0.mhsa.fc.weight"), g(p + "0.mhsa.fc.bias")
+                scale = torch.cat([g(p + f"0.mhsa.attentions.{h}.bias_scale") / g(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean")
+                                   for h in range(H)]).contiguous()
+            else:
+                w_in, b_in = g(p + "0.mhsa.in_proj_weight"), g(p + "0.mhsa.in_proj_bias")
+                w_out, b_out = g(p + "0.mhsa.out_proj.weight"), g(p + "0.mhsa.out_proj.bias")
+                scale = None
+            # ALiBi: the attention output is bf16 (range), so its output projection runs on bf16 operands
+            w_out_p = ops.cast_pad(_pad_rows(w_out, 128), w_out.shape[1], torch.bfloat16) if self.use_alibi else h16(w_out)
             pk["layers"].append(dict(
                 ln1=(g(p + "0.norm.weight"), g(p + "0.norm.bias")),
-                qkv=(h16(g(p + "0.mhsa.in_proj_weight")), g(p + "0.mhsa.in_proj_bias")),
-                out=(h16(g(p + "0.mhsa.out_proj.weight")), g(p + "0.mhsa.out_proj.bias")),
+                qkv=(h16(w_in), b_in), out=(w_out_p, b_out), alibi_scale=scale,
                 ln2=(g(p + "1.0.weight"), g(p + "1.0.bias")),
                 fc1=(h16(g(p + "1.1.weight")), g(p + "1.1.bias")),
                 fc2=(h16(g(p + "1.4.weight")), g(p + "1.4.bias"))))
@@ -122,10 +144,14 @@ class VisionTransformer(nn.Module):
         x[:, 0] = pk["cls"]                                                                  # vision_tranformer.py:347-348
         x[:, 1:] = proj.view(Bb, T, D)
         x = x.view(Bb * S, D)
+        if self.use_alibi:
+            if coords is None:
+                raise ValueError("use_alibi=True needs coords")
+            c = torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1).to(dev, torch.float32).contiguous()   # :349-351
         for L in pk["layers"]:
             h = ops.layernorm(x, *L["ln1"], 1e-5, torch.float16)
             qkv = ops.gemm(h, L["qkv"][0], _lib.EPI_BIAS, bias=L["qkv"][1])
-            att = ops.attention(qkv, Bb, S, H)
+            att = ops.attention_alibi(qkv, c, L["alibi_scale"], Bb, S, H) if self.use_alibi else ops.attention(qkv, Bb, S, H)
             ops.gemm(att, L["out"][0], _lib.EPI_RESIDUAL, bias=L["out"][1], out=x)           # x = attn(x) + x   (:291-292)
             h = ops.layernorm(x, *L["ln2"], 1e-5, torch.float16)
             u = ops.gemm(h, L["fc1"][0], _lib.EPI_BIAS_GELU, bias=L["fc1"][1])

@@ -102,6 +102,18 @@ def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     return out
 
 
+def attention_alibi(qkv: torch.Tensor, coords: torch.Tensor, head_scale: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+    """softmax(q k^T/8) v - head_scale[h] * cdist(coords, coords) v; coords fp32 [B,T,2], head_scale fp32 [H]."""
+    _dev(qkv, coords, head_scale)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
+    assert coords.dtype == torch.float32 and coords.is_contiguous() and coords.shape == (B, T, 2)
+    assert head_scale.dtype == torch.float32 and head_scale.numel() == H
+    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device=qkv.device)     # bf16: see include/amdstamp.h
+    _lib.check(_lib.lib().amds_attention_alibi(_p(qkv), _p(coords), _p(head_scale), _p(out), B, T, H, act_code(qkv.dtype),
+                                               _stream()), "attention_alibi")
+    return out
+
+
 def pack_swiglu_rows(w: torch.Tensor) -> torch.Tensor:
     """[2H, cols] fp32 (gate rows then value rows) -> 32-row block-interleaved layout."""
     _dev(w)

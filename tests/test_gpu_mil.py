@@ -48,8 +48,6 @@ def test_mil_vit_state_dict_roundtrip_and_guards(gpu):
     with pytest.raises(NotImplementedError):
         m1(bags, coords=None, mask=torch.zeros(2, 50, dtype=torch.bool, device=gpu))
     with pytest.raises(NotImplementedError):
-        VisionTransformer(**{**kw, "use_alibi": True})
-    with pytest.raises(NotImplementedError):
         m1.train()(bags, coords=None, mask=None)
     with pytest.raises(RuntimeError, match="GPU"):
         with torch.no_grad():
@@ -116,3 +114,29 @@ def test_mlp_linear_heads_match_reference_golden(gpu):
             np.testing.assert_allclose(lin(x).cpu().numpy(), z[f"lin_y{key}"], rtol=1e-5, atol=1e-6)
         with pytest.raises(ValueError):
             m(torch.zeros(2, device=gpu))
+
+
+@pytest.mark.parametrize("Bb,T", [(2, 1024), (1, 333)])
+def test_mil_vit_alibi_forward_matches_oracle(gpu, Bb, T):
+    """ALiBi-after-softmax (reference vision_tranformer.py:42-74), eval mode, post-training running means."""
+    torch.manual_seed(T)
+    F, C = 1024, 2
+    model = VisionTransformer(dim_output=C, dim_input=F, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512,
+                              dropout=0.0, use_alibi=True).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "running_mean" in n:
+                p.fill_(900.0 + 200 * torch.rand(1).item())      # mean tile distance seen in training
+            elif "items_so_far" in n:
+                p.fill_(41.0)
+            elif p.dim() == 1 and "class_token" not in n and "bias_scale" not in n:
+                p.add_(0.1 * torch.randn_like(p))
+    sd = model.state_dict()
+    assert "transformer.layers.0.0.mhsa.query_encoders.3.weight" in sd and "transformer.layers.1.0.mhsa.attentions.7.bias_scale" in sd
+    bags = torch.randn(Bb, T, F).half()
+    coords = (torch.rand(Bb, T, 2) * 40000 / 256).round() * 256          # tile grid in um
+    ref = mil_vit_forward(bags.float(), coords, None, sd, n_heads=8, use_alibi=True)
+    with torch.no_grad():
+        out = model(bags.to(gpu), coords=coords.to(gpu), mask=None)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 1e-2 * max(1.0, ref.abs().max().item()), (err, ref, out)
