@@ -128,27 +128,30 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         }
         const int key0 = j * FA_KT;
         const bool ragged = key0 + FA_KT > Tn;
+        if (ragged) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Tn) s[t][r] = -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v = s[t][r] * sc;
-                if (ragged && key >= Tn) v = -INFINITY;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = exp2f(mrun - mnew);
+        const float mnew = fmaxf(mrun, mx * sc);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         mrun = mnew;
         float ls = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[t][r] - mnew);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -mnew));
                 s[t][r] = p;
                 ls += p;
             }

@@ -40,30 +40,44 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ 
     const long ld = 3L * Dm;
     const T* base = qkv + (long)b * Tn * ld + h * ATT_D;
 
-    // ---- stage K (row-major, 16-byte chunks XOR-swizzled by (key>>1)&7) --------------------------
-    for (int c = tid; c < KP * 8; c += 256) {
-        const int key = c >> 3, ch = c & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (key < Tn) v = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
-        *reinterpret_cast<u32x4*>(sK + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = v;
+    // ---- stage K and V^T: ALL global loads are issued first (one L2/HBM round trip for the whole head instead of
+    //      one per loop iteration), then the LDS writes ----------------------------------------------------------
+    constexpr int K_IT = NKT;                 // KP*8 chunks / 256 threads
+    constexpr int V_IT = (NKT + 1) / 2;       // (KP/2)*8 key-pair items / 256 threads
+    u32x4 kv[K_IT];
+    vec8 v0[V_IT], v1[V_IT];
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) {
+        const int c = it * 256 + tid, key = c >> 3, ch = c & 7;
+        kv[it] = u32x4{0u, 0u, 0u, 0u};
+        if (key < Tn) kv[it] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
     }
-    // ---- stage V transposed: item = (key pair, 8-wide d chunk) ------------------------------------
-    for (int c = tid; c < (KP / 2) * 8; c += 256) {
-        const int kp2 = c >> 3, ch = c & 7;
-        const int k0 = kp2 * 2;
-        vec8 v0, v1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v0[e] = (T)0.f; v1[e] = (T)0.f; }
-        if (k0 < Tn) v0 = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
-        if (k0 + 1 < Tn) v1 = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
-        // position of key k0 inside the permuted image: swap bits 2 and 3 of the key index
-        const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);
+    for (int it = 0; it < V_IT; ++it) {
+        const int c = it * 256 + tid, k0 = (c >> 3) * 2, ch = c & 7;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            vec2 w;
-            w[0] = v0[e]; w[1] = v1[e];
-            *reinterpret_cast<vec2*>(sVt + (ch * 8 + e) * VS + ch * 16 + pos * 2) = w;
+        for (int e = 0; e < 8; ++e) { v0[it][e] = (T)0.f; v1[it][e] = (T)0.f; }
+        if (k0 < Tn) v0[it] = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
+        if (k0 + 1 < Tn) v1[it] = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) {
+        const int c = it * 256 + tid, key = c >> 3, ch = c & 7;
+        *reinterpret_cast<u32x4*>(sK + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[it];
+    }
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) {
+        const int c = it * 256 + tid, k0 = (c >> 3) * 2, ch = c & 7;
+        if (k0 < KP) {
+            // position of key k0 inside the permuted image: swap bits 2 and 3 of the key index
+            const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                typedef T vec2 __attribute__((ext_vector_type(2)));
+                vec2 w;
+                w[0] = v0[it][e]; w[1] = v1[it][e];
+                *reinterpret_cast<vec2*>(sVt + (ch * 8 + e) * VS + ch * 16 + pos * 2) = w;
+            }
         }
     }
     __syncthreads();
@@ -100,27 +114,32 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ 
                     s[t] = Act<T>::mfma32(kf, qf[ks], s[t]);
                 }
             }
+            // raw (unscaled) scores: only a ragged last tile needs masking -- one wave-uniform test per TILE, not per element
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) {
+                if ((t0 + t + 1) * 32 > Tn) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = (t0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= Tn) s[t][r] = -INFINITY;
+                    }
+                }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < NTC; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = (t0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float v = s[t][r] * sc;
-                    if ((t0 + t + 1) * 32 > Tn && key >= Tn) v = -INFINITY;
-                    s[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrun, mx);
-            const float alpha = exp2f(mrun - mnew);  // first chunk: exp2(-inf) = 0
+            const float mnew = fmaxf(mrun, mx * sc);            // running max of the SCALED (log2-domain) scores
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // first chunk: exp2(-inf) = 0
             mrun = mnew;
             float ls = 0.f;
 #pragma unroll
             for (int t = 0; t < NTC; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(s[t][r] - mnew);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -mnew));   // v_exp_f32; exp2(-inf) = 0
                     s[t][r] = p;
                     ls += p;
                 }
