@@ -237,6 +237,31 @@ int amds_mean_pool(const void* x, float* out, int B, int T, int F, int in_dtype,
 /* out[M][N] = (relu?)(x[M][K] w[N][K]^T + bias) in exact fp32 (fp32-input MFMA); MLP / Linear heads, mlp.py:24-33. */
 int amds_linear_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int relu, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * TransMIL building blocks (reference src/stamp/modeling/models/trans_mil.py), fp32 throughout
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Batched fp32 GEMM on the exact-fp32 MFMA: for z = (o, i), o < outer, i < inner:
+ *   C[o,i] (+)= diag*I + alpha * A[o,i] * op(B[o,i]) + bias[n];  op(B) = B^T if transb (B stored [N][K]) else B ([K][N]).
+ * Operand z starts at base + o*s?o + i*s?i (elements), so head slices of a packed qkv tensor are addressed in place. */
+int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
+                   float* C, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
+                   float diag, const float* bias, int accumulate, void* stream);
+/* In-place softmax over the last dim of a contiguous [rows][cols] fp32 matrix (trans_mil.py:145). */
+int amds_softmax_rows(float* x, long rows, int cols, void* stream);
+/* Landmarks: out[z][j][c] = scale * sum_{t<l} x[z][j*l + t][c] (trans_mil.py:114-124, mask=None). */
+int amds_landmark_mean(const float* x, long sxo, long sxi, int ld, float* out, int outer, int inner, int m, int l, int d,
+                       float scale, void* stream);
+/* z0 = x^T / (max row-abs-sum * max col-abs-sum), maxima over ALL nmat matrices (trans_mil.py:23-28). scratch8: 8 B. */
+int amds_pinv_init(const float* x, float* z, int nmat, int n, void* scratch8, void* stream);
+/* out[z][t][c] += sum_k w[i][k] v[z][t+k-taps/2][c]: per-head depth-wise conv along the sequence (trans_mil.py:71-78,150-151). */
+int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w, float* out, long soo, long soi, int ldo,
+                    int outer, int inner, int n, int d, int taps, void* stream);
+/* PPEG: y = x + dw7x7(x) + dw5x5(x) + dw3x3(x) on the H x W token grid, class token passed through (trans_mil.py:274-283).
+ * x, y: [B][1+H*W][C]; w7 [C][49], w5 [C][25], w3 [C][9], biases [C]. */
+int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
+              const float* b3, int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

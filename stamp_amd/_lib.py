@@ -67,6 +67,12 @@ PROTOTYPES = {
     "amds_vary_precision": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "amds_mean_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_linear_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_bgemm_f32": (_i, [_vp, _i, _l, _l, _vp, _i, _l, _l, _i, _vp, _i, _l, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp]),
+    "amds_softmax_rows": (_i, [_vp, _l, _i, _vp]),
+    "amds_landmark_mean": (_i, [_vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "amds_pinv_init": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "amds_dwconv_seq": (_i, [_vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "amds_ppeg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_gated_attn_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amds_gated_attn_pool": (_i, [_vp, C.POINTER(GapWeights), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }

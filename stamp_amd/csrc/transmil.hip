@@ -1,0 +1,247 @@
+// transmil.hip -- building blocks of the TransMIL head, all in fp32 like the reference:
+// reference src/stamp/modeling/models/trans_mil.py -- NystromAttention.forward :81-163, moore_penrose_iter_pinv :23-37,
+// PPEG.forward :274-283.  The Nystrom pseudo-inverse iteration is numerically touchy (6 cubic iterations on softmax
+// matrices), so every matmul here runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).
+//   amds_bgemm_f32        C[z] = diag*I + alpha * A[z] op(B[z])   batched over (outer, inner) with separate strides,
+//                         op(B) = B^T (B stored [N][K], "x y^T" products) or B (stored [K][N])
+//   amds_softmax_rows     in-place row softmax, any row length
+//   amds_landmark_mean    segment sums of l consecutive tokens divided by l  (:114-124)
+//   amds_pinv_init        z0 = x^T / (max_j sum_i |x_ij| * max_i sum_j |x_ij|), maxima over ALL batches and heads (:26-28)
+//   amds_dwconv_seq       depth-wise (per head) 33-tap convolution along the sequence, added in place (:150-151)
+//   amds_ppeg             x + dw7x7(x) + dw5x5(x) + dw3x3(x) on the sqrt(T) x sqrt(T) token grid (:274-283)
+#include "common.h"
+
+namespace amds {
+
+template <int TRANSB>
+__global__ void __launch_bounds__(256) bgemm_f32_kernel(const float* __restrict__ A, int lda, long sAo, long sAi,
+                                                        const float* __restrict__ B, int ldb, long sBo, long sBi,
+                                                        float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
+                                                        int M, int N, int K, float alpha, float diag,
+                                                        const float* __restrict__ bias, int accumulate) {
+    constexpr int BK = 32, LDT = BK + 1;
+    __shared__ float sA[64 * LDT];
+    __shared__ float sB[64 * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int zo = blockIdx.z / inner, zi = blockIdx.z - zo * inner;
+    A += zo * sAo + zi * sAi;
+    B += zo * sBo + zi * sBi;
+    Cm += zo * sCo + zi * sCi;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = it * 256 + tid, row = c >> 3, c4 = (c & 7) * 4;
+            const int gm = m0 + row;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + c4 + e;
+                sA[row * LDT + c4 + e] = (gm < M && k < K) ? A[(long)gm * lda + k] : 0.f;
+            }
+        }
+        if (TRANSB) {     // B stored [N][K]
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int c = it * 256 + tid, row = c >> 3, c4 = (c & 7) * 4;
+                const int gn = n0 + row;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + c4 + e;
+                    sB[row * LDT + c4 + e] = (gn < N && k < K) ? B[(long)gn * ldb + k] : 0.f;
+                }
+            }
+        } else {          // B stored [K][N]: coalesced along n, transposed into the [n][k] LDS image
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = it * 256 + tid, k = c >> 6, n = c & 63;
+                const int gk = k0 + k, gn = n0 + n;
+                sB[n * LDT + k] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = sA[(wm * 32 + l31) * LDT + kk + hi];
+            const float b = sB[(wn * 32 + l31) * LDT + kk + hi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < M) {
+                float v = alpha * acc[r] + (m == n ? diag : 0.f) + (bias ? bias[n] : 0.f);
+                if (accumulate) v += Cm[(long)m * ldc + n];
+                Cm[(long)m * ldc + n] = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long rows, int cols) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    if (row >= rows) return;
+    float* p = x + row * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int c = tid; c < cols; c += 256) m = fmaxf(m, p[c]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < cols; c += 256) { const float e = expf(p[c] - m); p[c] = e; s += e; }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = tid; c < cols; c += 256) p[c] *= inv;
+}
+
+// x: [outer][n][ld] view (head slice of width d at a column offset baked into the pointer); out [outer][inner][m][d]
+__global__ void landmark_mean_kernel(const float* __restrict__ x, long sxo, long sxi, int ld, float* __restrict__ out, int inner,
+                                     int m, int l, int d, float scale) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * d) return;
+    const int j = idx / d, c = idx - j * d;
+    const float* p = x + zo * sxo + zi * sxi + (long)j * l * ld + c;
+    float s = 0.f;
+    for (int t = 0; t < l; ++t) s += p[(long)t * ld];
+    out[((long)z * m + j) * d + c] = s * scale;
+}
+
+// per matrix: max over rows of sum_j |x_ij| and max over cols of sum_i |x_ij|; combined across matrices with integer
+// atomicMax on the (non-negative) float bit patterns -> order independent, deterministic
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int n, unsigned* __restrict__ out2) {
+    const float* p = x + (long)blockIdx.x * n * n;
+    float rmax = 0.f, cmax = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float rs = 0.f, cs = 0.f;
+        for (int j = 0; j < n; ++j) { rs += fabsf(p[(long)i * n + j]); cs += fabsf(p[(long)j * n + i]); }
+        rmax = fmaxf(rmax, rs); cmax = fmaxf(cmax, cs);
+    }
+    rmax = wave_max(rmax); cmax = wave_max(cmax);
+    if ((threadIdx.x & 63) == 0) { atomicMax(out2, __float_as_uint(rmax)); atomicMax(out2 + 1, __float_as_uint(cmax)); }
+}
+__global__ void transpose_scale_kernel(const float* __restrict__ x, float* __restrict__ z, int n, const unsigned* __restrict__ mx) {
+    const float inv = 1.0f / (__uint_as_float(mx[0]) * __uint_as_float(mx[1]));
+    const long base = (long)blockIdx.z * n * n;
+    const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
+    if (i < n && j < n) z[base + (long)i * n + j] = x[base + (long)j * n + i] * inv;
+}
+
+// out[z][t][c] += sum_k w[head][k] * v[z][t + k - pad][c]   (z = b*H + head; v strided view with row stride ldv)
+__global__ void dwconv_seq_kernel(const float* __restrict__ v, long svo, long svi, int ldv, const float* __restrict__ w,
+                                  float* __restrict__ out, long soo, long soi, int ldo, int inner, int n, int d, int taps) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const int t = idx / d, c = idx - t * d;
+    const float* p = v + zo * svo + zi * svi + c;
+    const float* wk = w + (long)zi * taps;
+    const int pad = taps / 2;
+    float s = 0.f;
+    for (int k = 0; k < taps; ++k) {
+        const int tt = t + k - pad;
+        if (tt >= 0 && tt < n) s += wk[k] * p[(long)tt * ldv];
+    }
+    out[zo * soo + zi * soi + (long)t * ldo + c] += s;
+}
+
+// x: [B][1 + H*W][C] tokens (row 0 = class token, untouched); y same shape
+__global__ void ppeg_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w7, const float* __restrict__ b7,
+                            const float* __restrict__ w5, const float* __restrict__ b5, const float* __restrict__ w3,
+                            const float* __restrict__ b3, int Hh, int Ww, int C) {
+    const int b = blockIdx.z, tok = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long base = ((long)b * (1 + Hh * Ww)) * C;
+    if (tok == 0) { y[base + c] = x[base + c]; return; }
+    const int i = (tok - 1) / Ww, j = (tok - 1) - i * Ww;
+    float s = x[base + (long)tok * C + c] + b7[c] + b5[c] + b3[c];
+    for (int di = -3; di <= 3; ++di)
+        for (int dj = -3; dj <= 3; ++dj) {
+            const int ii = i + di, jj = j + dj;
+            if (ii < 0 || ii >= Hh || jj < 0 || jj >= Ww) continue;
+            const float xv = x[base + (long)(1 + ii * Ww + jj) * C + c];
+            float wsum = w7[c * 49 + (di + 3) * 7 + (dj + 3)];
+            if (di >= -2 && di <= 2 && dj >= -2 && dj <= 2) wsum += w5[c * 25 + (di + 2) * 5 + (dj + 2)];
+            if (di >= -1 && di <= 1 && dj >= -1 && dj <= 1) wsum += w3[c * 9 + (di + 1) * 3 + (dj + 1)];
+            s += wsum * xv;
+        }
+    y[base + (long)tok * C + c] = s;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
+                              float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
+                              float diag, const float* bias, int accumulate, void* stream) {
+    AMDS_REQUIRE(A && B && Cm, "amds_bgemm_f32: null pointer");
+    AMDS_REQUIRE(outer > 0 && inner > 0 && (long)outer * inner <= 65535 && M > 0 && N > 0 && K > 0, "amds_bgemm_f32: bad sizes");
+    const dim3 grid(cdiv(N, 64), cdiv(M, 64), outer * inner);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM_F32, 2.0 * outer * inner * (double)M * N * K, st);
+    if (transb) hipLaunchKernelGGL((bgemm_f32_kernel<1>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
+    else hipLaunchKernelGGL((bgemm_f32_kernel<0>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
+    AMDS_LAUNCH_CHECK("bgemm_f32_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_softmax_rows(float* x, long rows, int cols, void* stream) {
+    AMDS_REQUIRE(x && rows >= 0 && cols > 0 && rows < (1L << 31), "amds_softmax_rows: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, rows, cols);
+    AMDS_LAUNCH_CHECK("softmax_rows_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_landmark_mean(const float* x, long sxo, long sxi, int ld, float* out, int outer, int inner, int m, int l, int d,
+                                  float scale, void* stream) {
+    AMDS_REQUIRE(x && out && outer > 0 && inner > 0 && m > 0 && l > 0 && d > 0, "amds_landmark_mean: bad arguments");
+    hipLaunchKernelGGL(landmark_mean_kernel, dim3(cdiv((long)m * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, x, sxo, sxi, ld,
+                       out, inner, m, l, d, scale);
+    AMDS_LAUNCH_CHECK("landmark_mean_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_pinv_init(const float* x, float* z, int nmat, int n, void* scratch8, void* stream) {
+    AMDS_REQUIRE(x && z && scratch8 && nmat > 0 && nmat <= 65535 && n > 0, "amds_pinv_init: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    AMDS_HIP(hipMemsetAsync(scratch8, 0, 8, st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(nmat), dim3(256), 0, st, x, n, (unsigned*)scratch8);
+    AMDS_LAUNCH_CHECK("absmax_kernel");
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3(cdiv(n, 16), cdiv(n, 16), nmat), dim3(16, 16), 0, st, x, z, n, (const unsigned*)scratch8);
+    AMDS_LAUNCH_CHECK("transpose_scale_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w, float* out, long soo, long soi, int ldo,
+                               int outer, int inner, int n, int d, int taps, void* stream) {
+    AMDS_REQUIRE(v && w && out && outer > 0 && inner > 0 && n > 0 && d > 0 && taps > 0 && (taps & 1), "amds_dwconv_seq: bad arguments");
+    hipLaunchKernelGGL(dwconv_seq_kernel, dim3(cdiv((long)n * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, v, svo, svi, ldv, w,
+                       out, soo, soi, ldo, inner, n, d, taps);
+    AMDS_LAUNCH_CHECK("dwconv_seq_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
+                         const float* b3, int B, int Hh, int Ww, int C, void* stream) {
+    AMDS_REQUIRE(x && y && x != y && w7 && b7 && w5 && b5 && w3 && b3, "amds_ppeg: null/aliased pointer");
+    AMDS_REQUIRE(B > 0 && B <= 65535 && Hh > 0 && Ww > 0 && (long)Hh * Ww + 1 <= 65535 && C > 0, "amds_ppeg: bad shape");
+    hipLaunchKernelGGL(ppeg_kernel, dim3(cdiv(C, 256), 1 + Hh * Ww, B), dim3(256), 0, (hipStream_t)stream, x, y, w7, b7, w5, b5, w3, b3, Hh, Ww, C);
+    AMDS_LAUNCH_CHECK("ppeg_kernel");
+    return AMDS_OK;
+}

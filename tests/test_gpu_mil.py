@@ -140,3 +140,37 @@ def test_mil_vit_alibi_forward_matches_oracle(gpu, Bb, T):
         out = model(bags.to(gpu), coords=coords.to(gpu), mask=None)
     err = (out.cpu() - ref).abs().max().item()
     assert err < 1e-2 * max(1.0, ref.abs().max().item()), (err, ref, out)
+
+
+@pytest.mark.parametrize("tag", ["t50", "t300"])
+def test_transmil_matches_reference_golden(gpu, tag):
+    """logits against the fixture captured from the reference TransMIL (same state_dict, same bags)."""
+    from pathlib import Path
+
+    import numpy as np
+
+    from stamp_amd.mil import TransMIL
+
+    z = np.load(Path(__file__).parent / "golden" / f"transmil_{tag}.npz")
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    dim_out, dim_in, dim_h = (int(v) for v in z["hparams"])
+    model = TransMIL(dim_output=dim_out, dim_input=dim_in, dim_hidden=dim_h).eval()
+    model.load_state_dict(sd, strict=True)                   # identical keys to the reference
+    model = model.to(gpu)
+    with torch.no_grad():
+        out = model(torch.from_numpy(z["bags"]).to(gpu))
+    np.testing.assert_allclose(out.cpu().numpy(), z["logits"], rtol=2e-3, atol=2e-3)
+
+
+def test_transmil_bag_1024_vs_oracle(gpu):
+    from oracle.transmil import transmil_forward
+    from stamp_amd.mil import TransMIL
+
+    torch.manual_seed(3)
+    model = TransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval()
+    bags = torch.randn(2, 1024, 1024).half().float()
+    ref = transmil_forward(bags, {k: v.detach() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        out = model.to(gpu)(bags.to(gpu))
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), (err, ref, out)
