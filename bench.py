@@ -36,9 +36,10 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=1020, help="tiles per step per GPU (one virtual slide)")
-    ap.add_argument("--chunk", type=int, default=255, help="tiles per internal forward chunk")
+    ap.add_argument("--chunk", type=int, default=510, help="tiles per internal forward chunk")
     ap.add_argument("--model", default="vit_large_patch14_224")
     ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--overlap", type=int, default=0, help="1 = two chunks in flight on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -79,6 +80,7 @@ def main() -> None:
     act = torch.float16 if a.act == "f16" else torch.bfloat16
     sd = random_vit_state_dict(cfg, seed=0, init="moderate")
     model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk)
+    model.overlap = bool(a.overlap)
     g = torch.Generator().manual_seed(1234 + ctx.rank)
     tiles = torch.randint(0, 256, (a.tiles, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g).to(ctx.device)
     slide_ids = torch.tensor([ctx.rank], device=ctx.device)

@@ -189,6 +189,12 @@ int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_vit_weights
                             const uint8_t* tiles, void* feats_f16, float* tokens_f32, int B, int chunk,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* Same result as amds_vit_forward, with consecutive chunks alternating between `stream` and one library-owned side
+ * stream so that two chunks are in flight (ws must hold 2 x amds_vit_workspace_bytes(chunk)); `stream` waits for the
+ * side stream before the call's work is considered complete. */
+int amds_vit_forward_overlapped(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
+                                void* feats_f16, int B, int chunk, void* ws, size_t ws_bytes, void* stream);
+
 /* u8 HWC tiles -> im2col patch matrix [B*np][kp] (act dtype, raw 0..255 values, zero padded).
  * Exposed for tests; amds_vit_forward calls it internally. */
 int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int patch, int kp,

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "amds_attention_alibi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_vit_workspace_bytes": (_sz, [C.POINTER(VitCfg), _i]),
     "amds_vit_forward": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_vit_forward_overlapped": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_vit_forward_tokens": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),

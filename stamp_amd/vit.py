@@ -92,13 +92,14 @@ class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
-                 act_dtype: torch.dtype = torch.float16, chunk: int = 255) -> None:
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 510) -> None:
         super().__init__()
         if cfg.heads * 64 != cfg.dim:
             raise ValueError(f"head_dim must be 64 (dim={cfg.dim}, heads={cfg.heads})")
         self.cfg = cfg
         self.act_dtype = act_dtype
         self.chunk = int(chunk)
+        self.overlap = False            # two chunks in flight on two streams (amds_vit_forward_overlapped)
         self.device_ = torch.device(device)
         if self.device_.type != "cuda":
             raise RuntimeError("HipViT runs on the GPU only (no CPU fallback)")
@@ -228,6 +229,15 @@ class HipViT(nn.Module):
         if B == 0:
             return (feats, toks) if return_tokens else feats
         chunk = min(self.chunk, B)
+        if self.overlap and not return_tokens and B > chunk:
+            need = 2 * _lib.lib().amds_vit_workspace_bytes(C.byref(self._cfg_c), chunk)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
+            rc = _lib.lib().amds_vit_forward_overlapped(C.byref(self._cfg_c), C.byref(self._w_c), tiles.data_ptr(), feats.data_ptr(),
+                                                        B, chunk, self._ws.data_ptr(), self._ws.numel(),
+                                                        torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "vit_forward_overlapped")
+            return feats
         ws = self._workspace(chunk)
         rc = _lib.lib().amds_vit_forward_tokens(
             C.byref(self._cfg_c), C.byref(self._w_c), tiles.data_ptr(), feats.data_ptr(),
