@@ -120,7 +120,7 @@ def main() -> None:
     total_tiles = a.tiles * a.steps * ctx.world
     value = total_tiles / elapsed
     line = {
-        "metric": "tiles/sec encoded (224x224, ViT-L/14)", "value": round(value, 2), "unit": "tiles/s",
+        "metric": "tiles/sec encoded (224x224, ViT-L/14)" if a.model == "vit_large_patch14_224" else f"tiles/sec encoded (224x224, {a.model})", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.act, "data": "synthetic",

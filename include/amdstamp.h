@@ -118,6 +118,10 @@ int amds_pack_swiglu_rows(const float* src, float* dst, int H, int cols, void* s
  * head_dim is fixed at 64; T <= 288 (whole K/V of a head staged in LDS). softmax(q k^T / 8) v. */
 int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
 
+/* Same with an explicit head_dim: 64 (above) or 80 (ViT-H/14, e.g. Virchow2: dim 1280, 16 heads); qkv thirds are
+ * [H][head_dim]. */
+int amds_attention_vit_hd(const void* qkv, void* out, int B, int T, int H, int head_dim, int dtype, void* stream);
+
 /* Same contract for ANY T (K/V streamed through LDS in 64-key tiles, online softmax; the T x T matrix is never
  * materialised).  Used by the MIL heads: bags of 1024 tiles in training, whole slides (tens of thousands of
  * tiles) at deploy time (reference src/stamp/modeling/models/vision_tranformer.py:191, 217-227, mask=None path
@@ -141,7 +145,7 @@ typedef struct {
     int patch;        /* 14 or 16 */
     int dim;          /* 1024 / 1280 / 1536 */
     int depth;        /* 24 / 32 */
-    int heads;        /* dim / 64 */
+    int heads;        /* dim / 64 or dim / 80 */
     int hidden;       /* MLP hidden width (input width of fc2) */
     int n_prefix;     /* cls + register tokens */
     int mlp_kind;     /* 0 = Linear-GELU-Linear, 1 = SwiGLUPacked (fc1 out = 2*hidden) */

@@ -24,7 +24,8 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     AMDS_REQUIRE(c != nullptr, "vit: null cfg");
     AMDS_REQUIRE(c->img > 0 && c->patch > 0 && c->img % c->patch == 0, "vit: img=%d not divisible by patch=%d", c->img, c->patch);
-    AMDS_REQUIRE(c->dim % 128 == 0 && c->heads * 64 == c->dim, "vit: dim=%d must be heads*64 and a multiple of 128", c->dim);
+    AMDS_REQUIRE(c->dim % 128 == 0 && c->heads > 0 && (c->heads * 64 == c->dim || c->heads * 80 == c->dim),
+                 "vit: dim=%d must be a multiple of 128 and heads*64 or heads*80", c->dim);
     AMDS_REQUIRE(c->hidden % 64 == 0 && c->hidden > 0, "vit: hidden=%d must be a multiple of 64 (zero-pad)", c->hidden);
     AMDS_REQUIRE(c->mlp_kind == 0 || c->mlp_kind == 1, "vit: bad mlp_kind");
     AMDS_REQUIRE(c->mlp_kind == 1 || c->hidden % 128 == 0, "vit: GELU hidden=%d must be a multiple of 128", c->hidden);
@@ -66,7 +67,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         const amds_vit_block& b = w->blocks_host[l];
         AMDS_TRY(amds_layernorm(x, D, b.ln1_w, b.ln1_b, h, D, M, D, c->ln_eps, dt, st));
         AMDS_TRY(amds_gemm(h, D, b.qkv_w, D, M, 3 * D, D, dt, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
-        AMDS_TRY(amds_attention_vit(qkv, h, Bc, T, c->heads, dt, st));
+        AMDS_TRY(amds_attention_vit_hd(qkv, h, Bc, T, c->heads, D / c->heads, dt, st));
         AMDS_TRY(amds_gemm(h, D, b.proj_w, D, M, D, D, dt, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr, nullptr, 0, 0, 0, 1.0f, st));
         AMDS_TRY(amds_layernorm(x, D, b.ln2_w, b.ln2_b, h, D, M, D, c->ln_eps, dt, st));
         if (c->mlp_kind == 0)

@@ -85,11 +85,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, *, bias=None, scale=None, o
     return out
 
 
-def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64) -> torch.Tensor:
     _dev(qkv)
-    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
-    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
-    _lib.check(_lib.lib().amds_attention_vit(_p(qkv), _p(out), B, T, H, act_code(qkv.dtype), _stream()), "attention_vit")
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * head_dim)
+    out = torch.empty(B * T, H * head_dim, dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_vit_hd(_p(qkv), _p(out), B, T, H, head_dim, act_code(qkv.dtype), _stream()), "attention_vit")
     return out
 
 

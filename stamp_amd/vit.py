@@ -74,6 +74,10 @@ PRESETS: dict[str, ViTConfig] = {
     "vit_large_patch14_224": ViTConfig(),
     # UNI2-h, fully specified in-tree (reference uni2.py:17-31)
     "uni2_h": ViTConfig(dim=1536, depth=24, heads=24, hidden=4096, mlp="swiglu", reg_tokens=8, no_embed_class=True),
+    # Virchow2 = ViT-H/14, SwiGLUPacked, 4 register tokens (reference virchow2.py:34-39; D=1280 pinned by
+    # tests/test_encoders.py:31, the other hyper-parameters are the public model card's: SURVEY.md F4)
+    "virchow2": ViTConfig(dim=1280, depth=32, heads=16, hidden=3416, mlp="swiglu", reg_tokens=4, no_embed_class=False),
+    "test_tiny_hd80": ViTConfig(dim=640, depth=2, heads=8, hidden=696, mlp="swiglu", reg_tokens=4, no_embed_class=False),
     # ViT-L/16 (reference UNI, uni.py:26-31)
     "vit_large_patch16_224": ViTConfig(patch=16),
     # small shapes for tests
@@ -94,8 +98,8 @@ class HipViT(nn.Module):
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
                  act_dtype: torch.dtype = torch.float16, chunk: int = 510) -> None:
         super().__init__()
-        if cfg.heads * 64 != cfg.dim:
-            raise ValueError(f"head_dim must be 64 (dim={cfg.dim}, heads={cfg.heads})")
+        if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
+            raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
         self.cfg = cfg
         self.act_dtype = act_dtype
         self.chunk = int(chunk)

@@ -48,6 +48,7 @@ def test_flops_per_tile_matches_survey():
 
     assert abs(PRESETS["vit_large_patch14_224"].matmul_flops_per_tile() / 1e9 - 162.02) < 0.01
     assert abs(PRESETS["uni2_h"].matmul_flops_per_tile() / 1e9 - 370.94) < 0.01
+    assert abs(PRESETS["virchow2"].matmul_flops_per_tile() / 1e9 - 340.13) < 0.01
 
 
 def test_shard_slides_lpt():

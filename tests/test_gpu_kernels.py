@@ -181,6 +181,19 @@ def test_attention_streaming_any_length(gpu, dt, B, T, H):
         assert (out.double() - o2.double()).abs().max().item() < 4 * _eps(dt) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,H", [(2, 261, 16), (1, 257, 2), (3, 100, 1), (1, 288, 3), (2, 33, 2)])
+def test_attention_vit_head_dim_80(gpu, dt, B, T, H):
+    g = torch.Generator().manual_seed(B * 31 + T + H)
+    D = H * 80
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(gpu, dt)
+    out = ops.attention_vit(qkv, B, T, H, head_dim=80)
+    q, k, v = qkv.double().reshape(B, T, 3, H, 80).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 80 ** 0.5, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 4 * _eps(dt) * max(1.0, ref.abs().max().item()), err
+
+
 def test_attention_softmax_spike(gpu):
     """one key dominating a row / large logits: exercises the running-max rescale across chunks"""
     B, T, H = 1, 257, 1

@@ -12,7 +12,7 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
 
-@pytest.mark.parametrize("name", ["test_tiny", "test_tiny_swiglu"])
+@pytest.mark.parametrize("name", ["test_tiny", "test_tiny_swiglu", "test_tiny_hd80"])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_tiny_vit_matches_oracle(gpu, name, dt):
     cfg = PRESETS[name]
