@@ -101,8 +101,8 @@ int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, in
               int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
               const float* pos, int np, int T, int P, float acc_scale, void* stream);
 
-/* Tuning hook: same as amds_gemm with an explicit block-tile configuration
- * (0 = 128x128, 1 = 256x128, 2 = 256x256; -1 = library default). */
+/* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default; 0 = 128x128 tile, 8 = 256x256x64
+ * staggered two-group pipeline (production), 3 = its BK=32 variant, 7 = four-wave 128x128-wave-tile variant). */
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                  int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
                  const float* pos, int np, int T, int P, float acc_scale, void* stream);

@@ -135,7 +135,7 @@ extern "C" int amds_gemm(const void* A, long lda, const void* W, long ldw, int M
     return gemm_impl(-1, A, lda, W, ldw, M, N, K, dtype, epi, out, ldo, bias, scale, pos, np, T, P, acc_scale, stream);
 }
 
-// tuning hook: explicit tile configuration (0 = 128x128, 1 = 256x128, 2 = 256x256)
+// tuning hook: explicit kernel id (see gemm_kernel.h)
 extern "C" int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype,
                             int epi, void* out, long ldo, const float* bias, const float* scale, const float* pos,
                             int np, int T, int P, float acc_scale, void* stream) {

@@ -268,8 +268,9 @@ template <typename T, int EPI, int VARIANT>
 static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                           hipStream_t st);   // gemm_8p.h
 
-// tile configuration ids (amds_gemm_ex): 0 = 128x128 (2x2 waves), 1 = 256x128 (4x2), 2 = 256x256 (2x4),
-// 3 = 256x256 staggered 8-wave pipeline (gemm_8p.h; needs N % 256 == 0 and K >= 128, else falls back to 0)
+// kernel ids (amds_gemm_ex): 0 = 128x128 tile, one barrier per K step (small problems, any N % 128 == 0)
+//   8 = 256x256x64 staggered two-group pipeline (gemm_8p64.h, PRODUCTION; N % 256 == 0, else falls back to 0)
+//   3 = its BK = 32 / 4-stage variant (gemm_8p.h)      7 = four waves, 128x128 wave tiles, AGPR accumulators (gemm_4w.h)
 template <typename T, int EPI>
 static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                        const EpiArgs& ep, hipStream_t st) {
@@ -277,21 +278,12 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
     if (cfg == 8) cfg = 0;
     if (cfg == 7 && N % 256 == 0 && K >= 128) return launch_gemm_4w<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 7) cfg = 0;
-    if (cfg >= 3 && cfg <= 6) {   // 8-phase kernel; 4..6 are A/B variants kept for tuning
-        if (N % 256 == 0 && K >= 128) {
-            if (cfg == 3) return launch_gemm_8p<T, EPI, 0>(A, lda, W, ldw, M, N, K, ep, st);
-            if (cfg == 4) return launch_gemm_8p<T, EPI, 256>(A, lda, W, ldw, M, N, K, ep, st);        // direct epilogue
-            if (cfg == 5) return launch_gemm_8p<T, EPI, 128 + 64>(A, lda, W, ldw, M, N, K, ep, st);   // AGPR acc + loader prio
-            return launch_gemm_8p<T, EPI, 128 + 64 + 256>(A, lda, W, ldw, M, N, K, ep, st);           // both
-        }
+    if (cfg == 3) {   // BK = 32 four-stage variant of the staggered kernel (kept for A/B and for the ablation tools)
+        if (N % 256 == 0 && K >= 128) return launch_gemm_8p<T, EPI, 0>(A, lda, W, ldw, M, N, K, ep, st);
         cfg = 0;
     }
     switch (cfg) {
         case 0: return launch_gemm_cfg<T, 128, 128, 2, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
-        case 1: return launch_gemm_cfg<T, 256, 128, 4, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
-        case 2:
-            if (N % 256 == 0) return launch_gemm_cfg<T, 256, 256, 2, 4, EPI>(A, lda, W, ldw, M, N, K, ep, st);
-            return launch_gemm_cfg<T, 256, 128, 4, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     }
     set_error("amds_gemm: unknown tile config %d", cfg);
     return AMDS_ERR_INVALID;

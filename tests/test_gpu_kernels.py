@@ -34,7 +34,7 @@ def _gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 3, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
 def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)

@@ -58,3 +58,30 @@ def test_vit_large_chaotic_weights(gpu):
     ref_f = extract_features(tiles, sd, cfg)
     f = HipViT(cfg, sd, device=gpu, act_dtype=torch.float16, chunk=2)(tiles.to(gpu))
     assert _rel(f.cpu().float(), ref_f.float()) < 2.5e-2
+
+
+def test_vit_large_batch_invariance_at_bench_size(gpu):
+    """Size-independent properties at the bench shape (ViT-L/14, 1 100 tiles = 2 chunks of 510 + an 80-tile tail):
+    a tile's feature does not depend on which batch / chunk it travels in (bit-exact), on the chunk size, or on the
+    two-stream overlapped schedule; permuting tiles permutes features; every feature is finite."""
+    cfg = PRESETS["vit_large_patch14_224"]
+    sd = random_vit_state_dict(cfg, seed=0, init="moderate")
+    g = torch.Generator().manual_seed(11)
+    tiles = torch.randint(0, 256, (1100, 224, 224, 3), dtype=torch.uint8, generator=g).to(gpu)
+    model = HipViT(cfg, sd, device=gpu, chunk=510)
+    f = model(tiles)
+    assert f.shape == (1100, cfg.dim) and torch.isfinite(f.float()).all()
+    assert torch.equal(model(tiles[:37]), f[:37])                       # prefix batch
+    assert torch.equal(model(tiles[600:700]), f[600:700])               # tiles that crossed a chunk boundary
+    assert torch.equal(model.with_chunk(255)(tiles), f)                 # chunk size
+    model.with_chunk(510).overlap = True
+    assert torch.equal(model(tiles), f)                                 # two chunks in flight on two streams
+    model.overlap = False
+    perm = torch.randperm(1100, generator=g).to(gpu)
+    assert torch.equal(model(tiles[perm].contiguous()), f[perm])        # permutation equivariance
+    assert model(tiles[:0]).shape == (0, cfg.dim)                       # empty slide
+    # distinct tiles give distinct features, identical tiles identical features
+    assert not torch.equal(f[0], f[1])
+    dup = tiles[:2].clone(); dup[1] = dup[0]
+    fd = model(dup)
+    assert torch.equal(fd[0], fd[1])

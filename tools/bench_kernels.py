@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--dtype", default="f16")
-    ap.add_argument("--cfgs", default="0,2,3")
+    ap.add_argument("--cfgs", default="0,3,7,8")
     ap.add_argument("--rounds", type=int, default=1)
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
