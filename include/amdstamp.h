@@ -272,6 +272,42 @@ int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w,
 int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
               const float* b3, int B, int H, int W, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * MIL training step (reference src/stamp/modeling/models/__init__.py:133-141, 239-279): bf16 MFMA operands,
+ * fp32 accumulate / residual / master weights / optimizer state
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Batched / split-K amds_gemm on the production kernel: batch b uses A + b*bsA, W + b*bsW, out + b*bsOut (elements).
+ * Weight gradients dW[N][K] = dy^T x contract over the token dimension: split it (bsA = bsW = chunk, K = chunk) into
+ * nbatch fp32 partials and sum them with amds_colsum.  epi: AMDS_EPI_BIAS or AMDS_EPI_BIAS_F32. */
+int amds_gemm_batched(const void* A, long lda, long bsA, const void* W, long ldw, long bsW, int M, int N, int K,
+                      int nbatch, int dtype, int epi, void* out, long ldo, long bsOut, const float* bias,
+                      float acc_scale, void* stream);
+/* dst[c][r] = src[r][c] for 16-bit elements (dst leading dimension ld_dst >= R). */
+int amds_transpose16(const void* src, long ld_src, void* dst, long ld_dst, int R, int C, void* stream);
+/* out[n] (+)= sum_m x[m][n]; deterministic two-stage reduction (bias gradients, split-K partial sums). */
+size_t amds_colsum_workspace_bytes(int M, int N);
+int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* LayerNorm forward that also stores mean / rstd per row (fp32), and its backward:
+ *   dx = (add_skip ? dx : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma (+)= sum dy*xhat; dbeta (+)= sum dy */
+int amds_layernorm_train(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
+                         float* mean, float* rstd, int rows, int cols, float eps, int out_dtype, void* stream);
+size_t amds_layernorm_bwd_workspace_bytes(int rows, int cols);
+int amds_layernorm_bwd(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                       const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
+                       int rows, int cols, void* ws, size_t ws_bytes, void* stream);
+/* exact-erf GELU on a stored pre-activation and its derivative (dz = du * gelu'(z)). */
+int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, void* stream);
+int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, void* stream);
+/* Attention forward that also stores the log2-domain log-sum-exp per query, lse fp32 [B][H][T], and the flash-style
+ * backward: dqkv (same layout as qkv) from qkv, out, dout; dq_sum_ws: fp32 [B][H][T] scratch. */
+int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, void* stream);
+int amds_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dq_sum_ws, void* dqkv,
+                       int B, int T, int H, int dtype, void* stream);
+/* torch.optim.AdamW step (amsgrad=False) on flat fp32 buffers; `step` is the 1-based step count (bias correction). */
+int amds_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,18 @@ PROTOTYPES = {
     "amds_pinv_init": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "amds_dwconv_seq": (_i, [_vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_ppeg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_gemm_batched": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp]),
+    "amds_transpose16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
+    "amds_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "amds_colsum": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_layernorm_train": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "amds_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "amds_layernorm_bwd": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_gelu_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    "amds_gelu_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "amds_attention_fwd_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_adamw": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp]),
     "amds_gated_attn_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amds_gated_attn_pool": (_i, [_vp, C.POINTER(GapWeights), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }

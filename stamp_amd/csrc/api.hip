@@ -135,6 +135,27 @@ extern "C" int amds_gemm(const void* A, long lda, const void* W, long ldw, int M
     return gemm_impl(-1, A, lda, W, ldw, M, N, K, dtype, epi, out, ldo, bias, scale, pos, np, T, P, acc_scale, stream);
 }
 
+// Batched / split-K form of amds_gemm on the production kernel: batch b uses A + b*bsA, W + b*bsW, out + b*bsOut
+// (element strides).  Split-K for weight gradients: bsA = bsW = K (advance along the contraction), bsOut = M*N partials.
+extern "C" int amds_gemm_batched(const void* A, long lda, long bsA, const void* W, long ldw, long bsW, int M, int N, int K,
+                                 int nbatch, int dtype, int epi, void* out, long ldo, long bsOut, const float* bias,
+                                 float acc_scale, void* stream) {
+    AMDS_REQUIRE(A && W && out, "amds_gemm_batched: null pointer");
+    AMDS_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0 && nbatch <= 65535, "amds_gemm_batched: bad shape");
+    AMDS_REQUIRE(K % 64 == 0 && N % 256 == 0, "amds_gemm_batched: needs K %% 64 == 0 and N %% 256 == 0 (K=%d N=%d)", K, N);
+    AMDS_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && bsA % 8 == 0 && bsW % 8 == 0 && ldo % 4 == 0 && bsOut % 8 == 0, "amds_gemm_batched: strides must keep 16-byte alignment");
+    AMDS_REQUIRE(epi == AMDS_EPI_BIAS || epi == AMDS_EPI_BIAS_F32, "amds_gemm_batched: only the BIAS / BIAS_F32 epilogues");
+    EpiArgs ep;
+    ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; ep.pos = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = acc_scale;
+    ep.bsA = bsA; ep.bsW = bsW; ep.bsOut = bsOut; ep.nbatch = nbatch;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, 2.0 * nbatch * M * (double)N * K, st);
+    if (dtype == AMDS_F16) return gemm_dispatch<f16>(8, epi, A, lda, W, ldw, M, N, K, ep, st);
+    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(8, epi, A, lda, W, ldw, M, N, K, ep, st);
+    set_error("amds_gemm_batched: bad dtype %d", dtype);
+    return AMDS_ERR_INVALID;
+}
+
 // tuning hook: explicit kernel id (see gemm_kernel.h)
 extern "C" int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype,
                             int epi, void* out, long ldo, const float* bias, const float* scale, const float* pos,

@@ -28,7 +28,8 @@ constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES + FA_C_BYTES;
 // of order 1-10 (no softmax normalisation), which overflows fp16 (65504) on long bags; bf16 has the fp32 range.
 template <typename T, bool ALIBI, typename TO = T>
 __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int Tn, int H,
-                                                            const float* __restrict__ coords, const float* __restrict__ head_scale) {
+                                                            const float* __restrict__ coords, const float* __restrict__ head_scale,
+                                                            float* __restrict__ lse_out) {
     typedef typename Act<T>::vec8 vec8;
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
 
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         __syncthreads();
     }
     l += __shfl_xor(l, 32, 64);
+    if (lse_out && q < Tn && hi == 0) lse_out[((long)b * H + h) * Tn + q] = mrun + log2f(l);   // log2-domain log-sum-exp
     if (q < Tn) {
         const float inv = 1.0f / l;
         TO* orow = out + ((long)b * Tn + q) * Dm + h * 64;
@@ -219,8 +221,8 @@ extern "C" int amds_attention(const void* qkv, void* out, int B, int T, int H, i
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
     ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
-    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr);
-    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr, nullptr);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, nullptr);
     else { set_error("amds_attention: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel");
     return AMDS_OK;
@@ -234,9 +236,24 @@ extern "C" int amds_attention_alibi(const void* qkv, const float* coords, const 
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
     ProfScope prof(PROF_ATTN, 6.0 * B * H * (double)T * T * 64, st);
-    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, true, bf16>), grid, block, 0, st, (const f16*)qkv, (bf16*)out, T, H, coords, head_scale);
-    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, true, bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, coords, head_scale);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, true, bf16>), grid, block, 0, st, (const f16*)qkv, (bf16*)out, T, H, coords, head_scale, nullptr);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, true, bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, coords, head_scale, nullptr);
     else { set_error("amds_attention_alibi: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel<alibi>");
+    return AMDS_OK;
+}
+
+// forward that also stores L[b][h][q] = log2(sum_k exp2(s_qk * log2(e)/8)) for amds_attention_bwd
+extern "C" int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && out && lse, "amds_attention_fwd_lse: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_fwd_lse: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr, lse);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, lse);
+    else { set_error("amds_attention_fwd_lse: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<lse>");
     return AMDS_OK;
 }

@@ -79,7 +79,9 @@ __global__ void __launch_bounds__(256, 1) attn_vit80_kernel(const T* __restrict_
     const float sc = 0.11180339887498948f * 1.44269504088896340736f;  // 80^-0.5 * log2(e)
     const int nqb = (Tn + 31) >> 5;
 
-    for (int qb = wave; qb < nqb; qb += 4) {
+    // 9 query blocks over 4 waves leaves one wave with 3: rotate which wave (= which SIMD) that is from block to block, so
+    // the two (or more) workgroups sharing a CU do not pile their heavy waves on the same SIMD
+    for (int qb = (wave + blockIdx.x) & 3; qb < nqb; qb += 4) {
         const int q = qb * 32 + l31;
         const int qc = min(q, Tn - 1);
         vec8 qf[5];

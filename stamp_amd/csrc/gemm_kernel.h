@@ -32,6 +32,9 @@ struct EpiArgs {
     const float* pos;
     int np, T, P;
     float acc_scale;
+    // batched / split-K launches (gridDim.y = batch count): element strides added per batch index
+    long bsA = 0, bsW = 0, bsOut = 0;
+    int nbatch = 1;
 };
 
 template <int EPI, typename T>

@@ -1,0 +1,305 @@
+// train.hip -- the HBM-bound kernels of the MIL training step: everything around
+// the GEMMs and the attention of `stamp train` on the `vit` head -- reference
+// src/stamp/modeling/models/__init__.py:239-279 (LitTileClassifier._step: forward, loss, backward) and :133-141
+// (AdamW + OneCycleLR).  Mixed precision as usual for training: bf16 MFMA operands (activations AND gradients: bf16
+// keeps the fp32 exponent range, so no loss scaling), fp32 accumulation, fp32 residual stream / LayerNorm / master
+// weights / optimizer state.
+//   amds_transpose16          [R][C] 16-bit -> [C][ld] (weight-gradient GEMMs contract over the token dimension)
+//   amds_colsum               bias gradients: deterministic two-stage column sums
+//   amds_layernorm_train      LayerNorm forward that also stores mean / rstd
+//   amds_layernorm_bwd        dx (+ skip gradient), per-block partial d(gamma), d(beta)  -> amds_colsum finishes them
+//   amds_gelu_fwd / _bwd      exact-erf GELU on a stored pre-activation
+//   amds_adamw                fused decoupled-weight-decay Adam on one flat fp32 parameter buffer
+#include "common.h"
+
+namespace amds {
+
+// ---- 16-bit transpose through LDS (64 x 64 tiles, +1 padding) -------------------------------------------------------
+__global__ void __launch_bounds__(256) transpose16_kernel(const uint16_t* __restrict__ src, long ld_src, uint16_t* __restrict__ dst,
+                                                          long ld_dst, int R, int Cc) {
+    __shared__ uint16_t t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        t[r][c] = (r0 + r < R && c0 + c < Cc) ? src[(long)(r0 + r) * ld_src + c0 + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < Cc && r0 + r < R) dst[(long)(c0 + c) * ld_dst + r0 + r] = t[r][c];
+    }
+}
+
+// ---- column sums: stage 1 = per 256-row chunk partials, stage 2 = reduce partials ---------------------------------------
+template <typename TI>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const TI* __restrict__ x, long ld, float* __restrict__ partial, int M, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += (float)x[(long)r * ld + n];
+    partial[(long)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunk, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += partial[(long)c * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// ---- LayerNorm forward with saved statistics ---------------------------------------------------------------------------
+template <typename TO, int MAXV>
+__global__ void __launch_bounds__(256) ln_train_kernel(const float* __restrict__ x, long xs, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, TO* __restrict__ y, long ys,
+                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * xs;
+    const int nv = cols >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) { v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    TO* yr = y + (long)row * ys;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+            typedef TO vec4 __attribute__((ext_vector_type(4)));
+            vec4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (TO)((v[i][e] - mean) * rstd * g[e] + b[e]);
+            *reinterpret_cast<vec4*>(yr + c * 4) = w;
+        }
+    }
+}
+
+// ---- LayerNorm backward: one wave per row; 64 rows per block; per-block partial d(gamma), d(beta) ----------------------------
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dx_io = (add_skip ? dx_io : 0) + dx
+template <int MAXV>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, long dys, const float* __restrict__ x, long xs,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx, long dxs, int add_skip,
+                                                     float* __restrict__ dgp, float* __restrict__ dbp, int rows, int cols) {
+    extern __shared__ float red[];        // [2][4][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = cols >> 2;
+    f32x4 ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int r0 = blockIdx.x * 64;
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 gv[MAXV], xh[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (long)row * dys + c * 4);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)row * xs + c * 4);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    gv[i][e] = d[e] * gm[e];
+                    s1 += gv[i][e];
+                    s2 += gv[i][e] * xh[i][e];
+                    ag[i][e] += d[e] * xh[i][e];
+                    ab[i][e] += d[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4* p = reinterpret_cast<f32x4*>(dx + (long)row * dxs + c * 4);
+                f32x4 o = add_skip ? *p : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rs * (gv[i][e] - s1 - xh[i][e] * s2);
+                *p = o;
+            }
+        }
+    }
+    // block reduction of the 4 waves' d(gamma) / d(beta) partials
+    float* rg = red + wave * cols;
+    float* rb = red + (4 + wave) * cols;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rg[c * 4 + e] = ag[i][e]; rb[c * 4 + e] = ab[i][e]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        dgp[(long)blockIdx.x * cols + c] = (red[c] + red[cols + c]) + (red[2 * cols + c] + red[3 * cols + c]);
+        dbp[(long)blockIdx.x * cols + c] = (red[4 * cols + c] + red[5 * cols + c]) + (red[6 * cols + c] + red[7 * cols + c]);
+    }
+}
+
+// ---- GELU on a stored pre-activation ---------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void gelu_fwd_kernel(const TI* __restrict__ z, TO* __restrict__ u, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) u[i] = (TO)gelu_erf((float)z[i]);
+}
+template <typename TZ, typename TG, typename TO>
+__global__ void gelu_bwd_kernel(const TZ* __restrict__ z, const TG* __restrict__ du, TO* __restrict__ dz, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float x = (float)z[i];
+        const float d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+        dz[i] = (TO)((float)du[i] * d);
+    }
+}
+
+// ---- AdamW (torch.optim.AdamW semantics, amsgrad=False) -----------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float pi = p[i] * (1.0f - lr * wd);
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+        p[i] = pi;
+    }
+}
+
+static inline int grid1d(long n) { return (int)min((long)4096, (n + 255) / 256); }
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_transpose16(const void* src, long ld_src, void* dst, long ld_dst, int R, int Cc, void* stream) {
+    AMDS_REQUIRE(src && dst && src != dst, "amds_transpose16: null/aliased pointer");
+    AMDS_REQUIRE(R > 0 && Cc > 0 && ld_src >= Cc && ld_dst >= R, "amds_transpose16: bad shape");
+    hipLaunchKernelGGL(transpose16_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, ld_src,
+                       (uint16_t*)dst, ld_dst, R, Cc);
+    AMDS_LAUNCH_CHECK("transpose16_kernel");
+    return AMDS_OK;
+}
+
+extern "C" size_t amds_colsum_workspace_bytes(int M, int N) { return (size_t)cdiv(M, 256) * N * 4; }
+extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(x && out && ws, "amds_colsum: null pointer");
+    AMDS_REQUIRE(M > 0 && N > 0, "amds_colsum: bad shape");
+    const int nchunk = cdiv(M, 256);
+    if (ws_bytes < (size_t)nchunk * N * 4) { set_error("amds_colsum: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const dim3 grid(cdiv(N, 256), nchunk);
+    if (in_dtype == AMDS_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, ld, part, M, N);
+    else if (in_dtype == AMDS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, ld, part, M, N);
+    else if (in_dtype == AMDS_F16) hipLaunchKernelGGL((colsum_partial_kernel<f16>), grid, dim3(256), 0, st, (const f16*)x, ld, part, M, N);
+    else { set_error("amds_colsum: bad dtype"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("colsum_partial_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, out, nchunk, N, accumulate);
+    AMDS_LAUNCH_CHECK("colsum_final_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_layernorm_train(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
+                                    float* mean, float* rstd, int rows, int cols, float eps, int out_dtype, void* stream) {
+    AMDS_REQUIRE(x && gamma && beta && y && mean && rstd, "amds_layernorm_train: null pointer");
+    AMDS_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "amds_layernorm_train: cols=%d must be a multiple of 4 and <= 2048", cols);
+    if (rows == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    if (out_dtype == AMDS_BF16) hipLaunchKernelGGL((ln_train_kernel<bf16, 8>), grid, block, 0, st, x, x_row_stride, gamma, beta, (bf16*)y, y_row_stride, mean, rstd, rows, cols, eps);
+    else if (out_dtype == AMDS_F16) hipLaunchKernelGGL((ln_train_kernel<f16, 8>), grid, block, 0, st, x, x_row_stride, gamma, beta, (f16*)y, y_row_stride, mean, rstd, rows, cols, eps);
+    else if (out_dtype == AMDS_F32) hipLaunchKernelGGL((ln_train_kernel<float, 8>), grid, block, 0, st, x, x_row_stride, gamma, beta, (float*)y, y_row_stride, mean, rstd, rows, cols, eps);
+    else { set_error("amds_layernorm_train: bad dtype"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("ln_train_kernel");
+    return AMDS_OK;
+}
+
+extern "C" size_t amds_layernorm_bwd_workspace_bytes(int rows, int cols) { return (size_t)cdiv(rows, 64) * cols * 4 * 2 + amds_colsum_workspace_bytes(cdiv(rows, 64), cols); }
+extern "C" int amds_layernorm_bwd(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                                  const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
+                                  int rows, int cols, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "amds_layernorm_bwd: null pointer");
+    AMDS_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "amds_layernorm_bwd: bad shape");
+    if (ws_bytes < amds_layernorm_bwd_workspace_bytes(rows, cols)) { set_error("amds_layernorm_bwd: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = cdiv(rows, 64);
+    float* dgp = (float*)ws;
+    float* dbp = dgp + (size_t)nblk * cols;
+    char* cws = (char*)(dbp + (size_t)nblk * cols);
+    const size_t cws_bytes = amds_colsum_workspace_bytes(nblk, cols);
+    hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx,
+                       dx_stride, add_skip, dgp, dbp, rows, cols);
+    AMDS_LAUNCH_CHECK("ln_bwd_kernel");
+    int rc = amds_colsum(dgp, cols, dgamma, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
+    if (rc != AMDS_OK) return rc;
+    return amds_colsum(dbp, cols, dbeta, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
+}
+
+extern "C" int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, void* stream) {
+    AMDS_REQUIRE(z && u && n >= 0, "amds_gelu_fwd: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n);
+    else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_fwd_kernel<bf16, float>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (float*)u, n);
+    else if (in_dtype == AMDS_F32 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_fwd_kernel<float, float>), dim3(grid1d(n)), dim3(256), 0, st, (const float*)z, (float*)u, n);
+    else { set_error("amds_gelu_fwd: unsupported dtype pair"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("gelu_fwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, void* stream) {
+    AMDS_REQUIRE(z && du && dz && n >= 0, "amds_gelu_bwd: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16)
+        hipLaunchKernelGGL((gelu_bwd_kernel<bf16, bf16, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n);
+    else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_BF16)
+        hipLaunchKernelGGL((gelu_bwd_kernel<bf16, float, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (const float*)du, (bf16*)dz, n);
+    else if (z_dtype == AMDS_F32 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F32)
+        hipLaunchKernelGGL((gelu_bwd_kernel<float, float, float>), dim3(grid1d(n)), dim3(256), 0, st, (const float*)z, (const float*)du, (float*)dz, n);
+    else { set_error("amds_gelu_bwd: unsupported dtype combination"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("gelu_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, void* stream) {
+    AMDS_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "amds_adamw: bad arguments");
+    if (n == 0) return AMDS_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    AMDS_LAUNCH_CHECK("adamw_kernel");
+    return AMDS_OK;
+}

@@ -1,0 +1,107 @@
+"""torch-tensor wrappers over the training entry points of the C ABI (see include/amdstamp.h, "MIL training step")."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ops import _DT, _dev, _p, _stream, act_code
+
+
+def transpose16(src: torch.Tensor, ld_dst: int | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """[R, C] 16-bit -> [C, ld_dst] (columns R..ld_dst of a fresh output are zero)."""
+    _dev(src)
+    assert src.dim() == 2 and src.element_size() == 2 and src.stride(1) == 1
+    R, Cc = src.shape
+    ld = ld_dst or R
+    if out is None:
+        out = torch.zeros(Cc, ld, dtype=src.dtype, device=src.device)
+    _lib.check(_lib.lib().amds_transpose16(_p(src), src.stride(0), _p(out), out.stride(0), R, Cc, _stream()), "transpose16")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    _dev(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    lib = _lib.lib()
+    nb = lib.amds_colsum_workspace_bytes(M, N)
+    ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    _lib.check(lib.amds_colsum(_p(x), x.stride(0), _p(out), M, N, _DT[x.dtype], 1 if accumulate else 0, _p(ws), nb, _stream()), "colsum")
+    return out
+
+
+def layernorm_train(x: torch.Tensor, gamma, beta, eps: float, out_dtype=torch.bfloat16, rows=None, row_stride=None):
+    _dev(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    cols = gamma.numel()
+    rows = rows if rows is not None else x.numel() // cols
+    xs = row_stride if row_stride is not None else cols
+    y = torch.empty(rows, cols, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_layernorm_train(_p(x), xs, _p(gamma), _p(beta), _p(y), cols, _p(mean), _p(rstd), rows, cols, eps,
+                                               _DT[out_dtype], _stream()), "layernorm_train")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, add_skip: bool, dgamma, dbeta, accumulate_params: bool = False,
+                  rows=None, dy_stride=None, x_stride=None, dx_stride=None):
+    _dev(dy, x, mean, rstd, gamma, dx, dgamma, dbeta)
+    cols = gamma.numel()
+    rows = rows if rows is not None else dy.numel() // cols
+    lib = _lib.lib()
+    nb = lib.amds_layernorm_bwd_workspace_bytes(rows, cols)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.amds_layernorm_bwd(_p(dy), dy_stride or cols, _p(x), x_stride or cols, _p(mean), _p(rstd), _p(gamma), _p(dx),
+                                      dx_stride or cols, 1 if add_skip else 0, _p(dgamma), _p(dbeta), 1 if accumulate_params else 0,
+                                      rows, cols, _p(ws), nb, _stream()), "layernorm_bwd")
+    return dx
+
+
+def gelu_fwd(z: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    _dev(z)
+    u = torch.empty(z.shape, dtype=out_dtype or z.dtype, device=z.device)
+    _lib.check(_lib.lib().amds_gelu_fwd(_p(z), _p(u), z.numel(), _DT[z.dtype], _DT[u.dtype], _stream()), "gelu_fwd")
+    return u
+
+
+def gelu_bwd(z: torch.Tensor, du: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    _dev(z, du)
+    assert z.is_contiguous() and du.is_contiguous() and z.shape == du.shape
+    dz = torch.empty(z.shape, dtype=out_dtype or z.dtype, device=z.device)
+    _lib.check(_lib.lib().amds_gelu_bwd(_p(z), _p(du), _p(dz), z.numel(), _DT[z.dtype], _DT[du.dtype], _DT[dz.dtype], _stream()), "gelu_bwd")
+    return dz
+
+
+def attention_fwd_lse(qkv: torch.Tensor, B: int, T: int, H: int):
+    _dev(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
+    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_fwd_lse(_p(qkv), _p(out), _p(lse), B, T, H, act_code(qkv.dtype), _stream()), "attention_fwd_lse")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B: int, T: int, H: int) -> torch.Tensor:
+    _dev(qkv, out, dout, lse)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype == out.dtype
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(ws), _p(dqkv), B, T, H, act_code(qkv.dtype), _stream()),
+               "attention_bwd")
+    return dqkv
+
+
+def gemm_batched(a, lda, bsA, w, ldw, bsW, M, N, K, nbatch, dtype, out, ldo, bsOut, f32_out: bool, bias=None, acc_scale=1.0):
+    _lib.check(_lib.lib().amds_gemm_batched(_p(a), lda, bsA, _p(w), ldw, bsW, M, N, K, nbatch, act_code(dtype),
+                                            _lib.EPI_BIAS_F32 if f32_out else _lib.EPI_BIAS, _p(out), ldo, bsOut, _p(bias), acc_scale,
+                                            _stream()), "gemm_batched")
+    return out
+
+
+def adamw(p, g, m, v, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01) -> None:
+    _dev(p, g, m, v)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (p, g, m, v)) and p.numel() == g.numel() == m.numel() == v.numel()
+    _lib.check(_lib.lib().amds_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _stream()), "adamw")

@@ -1,0 +1,108 @@
+"""Training-step kernels (through the C ABI) against torch autograd / torch.optim on the CPU in fp64/fp32."""
+import pytest
+import torch
+
+from stamp_amd import _lib, ops, train_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def test_transpose_colsum(gpu):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(777, 300, generator=g).to(gpu, torch.bfloat16)
+    t = T.transpose16(x, ld_dst=832)
+    assert torch.equal(t[:, :777], x.t()) and (t[:, 777:] == 0).all()
+    s = T.colsum(x)
+    assert (s.cpu() - x.float().sum(0).cpu()).abs().max() < 1e-2
+    s2 = T.colsum(x.float(), out=s.clone(), accumulate=True)
+    assert torch.allclose(s2, 2 * s, rtol=1e-3, atol=2e-2)
+    assert torch.equal(T.colsum(x), s)                # deterministic
+
+
+@pytest.mark.parametrize("rows,cols", [(1025, 512), (70, 128), (4100, 1024)])
+def test_layernorm_train_and_bwd(gpu, rows, cols):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.5)
+    gamma, beta = 1 + 0.2 * torch.randn(cols, generator=g), 0.1 * torch.randn(cols, generator=g)
+    dy = torch.randn(rows, cols, generator=g)
+    skip = torch.randn(rows, cols, generator=g)
+    xd = x.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xd, (cols,), gd, bd, 1e-5)
+    y.backward(dy.double())
+    yh, mean, rstd = T.layernorm_train(x.to(gpu), gamma.to(gpu), beta.to(gpu), 1e-5, torch.float32)
+    assert (yh.cpu().double() - y.detach()).abs().max() < 1e-5
+    dx = skip.clone().to(gpu)
+    dgam, dbet = torch.zeros(cols, device=gpu), torch.zeros(cols, device=gpu)
+    T.layernorm_bwd(dy.to(gpu), x.to(gpu), mean, rstd, gamma.to(gpu), dx, True, dgam, dbet)
+    assert (dx.cpu().double() - (skip.double() + xd.grad)).abs().max() < 2e-5
+    assert (dgam.cpu().double() - gd.grad).abs().max() < 1e-3 * max(1.0, gd.grad.abs().max().item())
+    assert (dbet.cpu().double() - bd.grad).abs().max() < 1e-3 * max(1.0, bd.grad.abs().max().item())
+    dx2 = torch.empty(rows, cols, device=gpu)
+    T.layernorm_bwd(dy.to(gpu), x.to(gpu), mean, rstd, gamma.to(gpu), dx2, False, dgam, dbet, accumulate_params=True)
+    assert (dx2.cpu().double() - xd.grad).abs().max() < 2e-5
+    assert (dgam.cpu().double() - 2 * gd.grad).abs().max() < 2e-3 * max(1.0, gd.grad.abs().max().item())
+
+
+def test_gelu_fwd_bwd(gpu):
+    z = torch.linspace(-8, 8, 100001)
+    du = torch.randn(100001, generator=torch.Generator().manual_seed(1))
+    zd = z.double().requires_grad_(True)
+    u = torch.nn.functional.gelu(zd)
+    u.backward(du.double())
+    assert (T.gelu_fwd(z.to(gpu)).cpu().double() - u.detach()).abs().max() < 1e-6
+    assert (T.gelu_bwd(z.to(gpu), du.to(gpu)).cpu().double() - zd.grad).abs().max() < 1e-5
+    zb = z.to(gpu, torch.bfloat16)
+    dzb = T.gelu_bwd(zb, du.to(gpu, torch.bfloat16))
+    ref = torch.autograd.grad(torch.nn.functional.gelu(zb.cpu().double().requires_grad_(True)).sum(), [], allow_unused=True) if False else None
+    assert torch.isfinite(dzb.float()).all() and dzb.dtype == torch.bfloat16
+
+
+def test_adamw_matches_torch(gpu):
+    torch.manual_seed(0)
+    p0 = torch.randn(10007)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone().to(gpu), torch.zeros(10007, device=gpu), torch.zeros(10007, device=gpu)
+    for step in range(1, 6):
+        gcpu = torch.randn(10007)
+        ref.grad = gcpu.clone()
+        opt.step()
+        T.adamw(p, gcpu.to(gpu), m, v, 3e-4, step)
+        assert (p.cpu() - ref.detach()).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Tn,H", [(2, 1025, 8), (1, 200, 2), (1, 64, 1), (2, 129, 3), (1, 65, 1)])
+def test_attention_backward_vs_autograd(gpu, dt, B, Tn, H):
+    g = torch.Generator().manual_seed(B * 100 + Tn + H)
+    D = H * 64
+    qkv = torch.randn(B * Tn, 3 * D, generator=g).to(dt)
+    dout = torch.randn(B * Tn, D, generator=g).to(dt)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x.reshape(B, Tn, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * Tn, D)
+    o.backward(dout.double())
+    out, lse = T.attention_fwd_lse(qkv.to(gpu), B, Tn, H)
+    eps = 2 ** -7 if dt == torch.bfloat16 else 2 ** -10
+    assert (out.cpu().double() - o.detach()).abs().max() < 4 * eps * max(1.0, o.abs().max().item())
+    lref = torch.logsumexp((q @ k.transpose(-1, -2) / 8.0).detach(), -1) / torch.log(torch.tensor(2.0, dtype=torch.float64))
+    assert (lse.cpu().double() - lref).abs().max() < 1e-2
+    dqkv = T.attention_bwd(qkv.to(gpu), out, dout.to(gpu), lse, B, Tn, H)
+    gref = x.grad
+    err = (dqkv.cpu().double() - gref).abs().max().item()
+    assert err < 8 * eps * max(1.0, gref.abs().max().item()), (err, gref.abs().max().item())
+    assert torch.equal(dqkv, T.attention_bwd(qkv.to(gpu), out, dout.to(gpu), lse, B, Tn, H))
+
+
+def test_gemm_batched_split_k(gpu):
+    """weight-gradient shape: dW[N=256][K'=512] = dy^T[256][M] . x^T[512][M]^T, contraction over M split in 8 chunks"""
+    g = torch.Generator().manual_seed(2)
+    M, Nn, Kk, S = 8 * 1024, 256, 512, 8
+    dyT = torch.randn(Nn, M, generator=g).to(gpu, torch.bfloat16)
+    xT = torch.randn(Kk, M, generator=g).to(gpu, torch.bfloat16)
+    part = torch.empty(S, Nn, Kk, dtype=torch.float32, device=gpu)
+    # out[n][k] = sum_m dyT[n][m] xT[k][m]: A = dyT (rows n), W = xT (rows k)  ->  "N" of the GEMM is Kk
+    T.gemm_batched(dyT, M, M // S, xT, M, M // S, Nn, Kk, M // S, S, torch.bfloat16, part, Kk, Nn * Kk, True)
+    dW = T.colsum(part.view(S, Nn * Kk)).view(Nn, Kk)
+    ref = dyT.double() @ xT.double().t()
+    assert (dW.cpu().double() - ref.cpu()).abs().max() < 1e-3 * ref.abs().max().item()
