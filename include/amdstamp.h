@@ -304,6 +304,8 @@ int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, 
 int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, void* stream);
 int amds_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dq_sum_ws, void* dqkv,
                        int B, int T, int H, int dtype, void* stream);
+/* fp16 -> bf16 (features are fp16 on disk; the training path feeds bf16 MFMA operands). */
+int amds_convert_f16_bf16(const void* src, void* dst, long n, void* stream);
 /* torch.optim.AdamW step (amsgrad=False) on flat fp32 buffers; `step` is the 1-based step count (bias correction). */
 int amds_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, void* stream);

@@ -197,6 +197,12 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+__global__ void f16_to_bf16_kernel(const f16* __restrict__ src, bf16* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (bf16)(float)src[i];
+}
+
 static inline int grid1d(long n) { return (int)min((long)4096, (n + 255) / 256); }
 
 }  // namespace amds
@@ -301,5 +307,13 @@ extern "C" int amds_adamw(float* p, const float* g, float* m, float* v, long n, 
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
     AMDS_LAUNCH_CHECK("adamw_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_convert_f16_bf16(const void* src, void* dst, long n, void* stream) {
+    AMDS_REQUIRE(src && dst && n >= 0, "amds_convert_f16_bf16: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipLaunchKernelGGL(f16_to_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, (bf16*)dst, n);
+    AMDS_LAUNCH_CHECK("f16_to_bf16_kernel");
     return AMDS_OK;
 }

@@ -106,3 +106,79 @@ def test_gemm_batched_split_k(gpu):
     dW = T.colsum(part.view(S, Nn * Kk)).view(Nn, Kk)
     ref = dyT.double() @ xT.double().t()
     assert (dW.cpu().double() - ref.cpu()).abs().max() < 1e-3 * ref.abs().max().item()
+
+
+def _oracle_loss_and_grads(sd, bags, targets, weights, n_heads):
+    from oracle.mil_vit import mil_vit_forward
+
+    p = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    logits = mil_vit_forward_d(bags.double(), p, n_heads)
+    loss = torch.nn.functional.cross_entropy(logits, targets.double(), weight=None if weights is None else weights.double())
+    loss.backward()
+    return loss.item(), logits.detach(), {k: v.grad for k, v in p.items()}
+
+
+def mil_vit_forward_d(bags, sd, n_heads):
+    """fp64 autograd twin of oracle.mil_vit.mil_vit_forward (which casts its weights to fp32)."""
+    import torch.nn.functional as F
+    B = bags.shape[0]
+    x = F.gelu(F.linear(bags, sd["project_features.0.weight"], sd["project_features.0.bias"]))
+    D = x.shape[-1]
+    x = torch.cat([sd["class_token"].reshape(1, 1, D).expand(B, -1, -1), x], dim=1)
+    L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transformer.layers."))
+    hd = D // n_heads
+    for l in range(L):
+        p = f"transformer.layers.{l}."
+        h = F.layer_norm(x, (D,), sd[p + "0.norm.weight"], sd[p + "0.norm.bias"])
+        qkv = F.linear(h, sd[p + "0.mhsa.in_proj_weight"], sd[p + "0.mhsa.in_proj_bias"])
+        q, k, v = (t.reshape(B, -1, n_heads, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        o = (torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, -1) @ v).transpose(1, 2).reshape(B, -1, D)
+        x = F.linear(o, sd[p + "0.mhsa.out_proj.weight"], sd[p + "0.mhsa.out_proj.bias"]) + x
+        h = F.layer_norm(x, (D,), sd[p + "1.0.weight"], sd[p + "1.0.bias"])
+        h = F.linear(F.gelu(F.linear(h, sd[p + "1.1.weight"], sd[p + "1.1.bias"])), sd[p + "1.4.weight"], sd[p + "1.4.bias"])
+        x = h + x
+    x = F.layer_norm(x, (D,), sd["transformer.norm.weight"], sd["transformer.norm.bias"])
+    return F.linear(x[:, 0], sd["mlp_head.0.weight"], sd["mlp_head.0.bias"])
+
+
+def test_mil_vit_training_step_matches_autograd(gpu):
+    """forward + backward of the HIP trainer vs fp64 autograd of the same network (the oracle's architecture, which is
+    pinned to the reference): loss, logits and EVERY parameter gradient; then AdamW steps vs torch.optim.AdamW."""
+    from oracle.mil_vit import mil_vit_forward
+    from stamp_amd.mil import VisionTransformer
+    from stamp_amd.mil_train import HipMilVitTrainer
+
+    torch.manual_seed(5)
+    Bb, Tn, Fd, C = 3, 200, 256, 2
+    model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=256, n_layers=2, n_heads=4, dim_feedforward=256, dropout=0.0, use_alibi=False)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "class_token" not in n:
+                p.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    bags = torch.randn(Bb, Tn, Fd).half()
+    targets = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 1.0]])
+    weights = torch.tensor([0.7, 0.3])
+    # the twin reproduces the pinned oracle
+    with torch.no_grad():
+        assert torch.allclose(mil_vit_forward_d(bags.double(), {k: v.double() for k, v in sd.items()}, 4).float(),
+                              mil_vit_forward(bags.float(), torch.zeros(Bb, Tn, 2), None, sd, n_heads=4, use_alibi=False), atol=1e-4)
+    ref_loss, ref_logits, ref_g = _oracle_loss_and_grads(sd, bags.float(), targets, weights, 4)
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=1e-3, div_factor=25.0, total_steps=50, split_k=4)
+    loss, logits = tr.step(bags.to(gpu), targets, weights, update=False)
+    assert abs(loss.item() - ref_loss) < 2e-2 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    assert (logits.cpu().double() - ref_logits).abs().max() < 3e-2 * max(1.0, ref_logits.abs().max().item())
+    worst = 0.0
+    for k in tr.names:
+        g, r = tr.g(k).cpu().double(), ref_g[k]
+        rel = ((g - r).norm() / (r.norm() + 1e-12)).item()
+        worst = max(worst, rel)
+        assert rel < 5e-2, (k, rel, r.norm().item())
+    print("worst relative-L2 gradient error (bf16 operands):", worst)
+    # a few optimisation steps must reduce the loss and keep parameters finite; step count / lr schedule as torch's
+    losses = [tr.step(bags.to(gpu), targets, weights)[0].item() for _ in range(8)]
+    assert losses[-1] < losses[0] and torch.isfinite(tr.P).all()
+    ref_sched = torch.optim.lr_scheduler.OneCycleLR(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3), total_steps=50, max_lr=1e-3, div_factor=25.0)
+    assert abs(tr._lrs[0] - 1e-3 / 25.0) < 1e-12 and len(tr._lrs) == 50
+    tr.sync_to_model()
+    assert torch.allclose(model.state_dict()["mlp_head.0.bias"].cpu(), tr.p("mlp_head.0.bias").cpu())
