@@ -158,6 +158,22 @@ def main() -> None:
         line["secondary"] = {"metric": "MIL bags/s (vit head forward, bags of 1024 x 1024-d fp16, batch 64, no mask)",
                              "value": round(64 * ctx.world / dt_mil, 1), "unit": "bags/s", "gflop_per_bag_fwd": 11.83,
                              "finite": bool(torch.isfinite(lg).all())}
+        # training step (fwd + bwd + AdamW) of the same head, batch 64 (reference default, modeling/config.py:153)
+        from stamp_amd.mil_train import HipMilVitTrainer
+        trn = HipMilVitTrainer(mil, device=ctx.device, total_steps=100)
+        tg = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
+        cw = torch.tensor([0.5, 0.5])
+        for _ in range(2):
+            trn.step(bags, tg, cw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            ltr, _ = trn.step(bags, tg, cw)
+        torch.cuda.synchronize()
+        dt_tr = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 4)
+        line["secondary"]["train"] = {"metric": "MIL bags/s (vit head, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands)",
+                                      "value": round(64 * ctx.world / dt_tr, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltr))}
+        del trn
         from stamp_amd.mil import TransMIL as HipTransMIL
         tm = HipTransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().to(ctx.device)
         bags8 = bags[:8].float()

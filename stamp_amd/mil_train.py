@@ -102,8 +102,13 @@ class HipMilVitTrainer:
         return (M + unit - 1) // unit * unit
 
     # ---- one optimisation step ------------------------------------------------------------------------------------------------
-    def step(self, bags: torch.Tensor, targets: torch.Tensor, class_weights: torch.Tensor | None = None, *, update: bool = True):
-        """bags [Bb,T,F] fp16/bf16/fp32 on the GPU, targets float one-hot [Bb,C]. Returns (loss, logits)."""
+    def step(self, bags: torch.Tensor, targets: torch.Tensor, class_weights: torch.Tensor | None = None, *, update: bool = True,
+             data_parallel: bool = False):
+        """bags [Bb,T,F] fp16/bf16/fp32 on the GPU, targets float one-hot [Bb,C]. Returns (loss, logits).
+
+        data_parallel=True: every rank of the initialised process group holds a replica and its own bags; the flat
+        fp32 gradient buffer (14.7 MB for the default head) is averaged with ONE RCCL all-reduce before AdamW
+        (the reference itself is single-device, src/stamp/modeling/train.py:541-547)."""
         dev, D, H, FF, Fd, C = self.dev, self.D, self.H, self.FF, self.F, self.C
         Bb, Tn, _ = bags.shape
         S = Tn + 1
@@ -207,6 +212,8 @@ class HipMilVitTrainer:
         T.colsum(part, out=self.g(pn + "weight").view(-1))
         T.colsum(dzp, out=self.g(pn + "bias"))
         # ---- AdamW + OneCycleLR ---------------------------------------------------------------------------------------------------
+        if data_parallel and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(self.G, op=torch.distributed.ReduceOp.AVG)
         if update:
             self.step_count += 1
             lr = self._lrs[min(self.step_count - 1, len(self._lrs) - 1)]
