@@ -107,3 +107,22 @@ def test_fixed_size_bag():
         torch.manual_seed(1234)
         b, c, l = misc.to_fixed_size_bag(bag, coords, bs, deterministic=False)
         assert np.array_equal(b.numpy(), z[f"rand_bag_{n}_{bs}"]) and l == int(z[f"rand_len_{n}_{bs}"])
+
+
+@pytest.mark.parametrize("tag,preset", [("tiny", "test_swin_tiny"), ("swin_t", "ctranspath")])
+def test_ctranspath_swin(tag, preset):
+    """The Swin/ConvStem restatement against the reference's own `_SwinTransformer` (ctranspath.py), stage by stage.
+    The weights are the seeded `random_swin_state_dict` that tools/make_golden.py loaded into the reference module
+    with strict=True (so names and shapes are the reference's)."""
+    from oracle import swin_ctranspath
+    from stamp_amd.swin import SWIN_PRESETS, random_swin_state_dict
+
+    z = np.load(G / f"ctranspath_{tag}.npz")
+    cfg = SWIN_PRESETS[preset]
+    sd = random_swin_state_dict(cfg, int(z["seed"]))
+    taps = {}
+    feats = swin_ctranspath.swin_features(torch.from_numpy(z["tiles"]), sd, cfg, taps=taps)
+    for k, v in taps.items():
+        np.testing.assert_allclose(v[:, z["tap_idx_" + k]].numpy(), z["tap_" + k], rtol=0, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(feats.numpy(), z["feats"], rtol=0, atol=5e-6)
+    assert feats.shape == (z["tiles"].shape[0], cfg.out_dim)

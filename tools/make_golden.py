@@ -239,6 +239,89 @@ def golden_bag() -> None:
     save("fixed_size_bag.npz", **out)
 
 
+def he_like_tiles(n: int, size: int, seed: int) -> np.ndarray:
+    """Synthetic H&E-looking u8 tiles (smooth mixtures of two stain colours on white) -- smoother statistics than
+    uniform noise, so the conv stem and the shifted-window masks see structured input."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    out = np.empty((n, size, size, 3), np.uint8)
+    hema, eos = np.array([0.65, 0.70, 0.29], np.float32), np.array([0.07, 0.99, 0.11], np.float32)
+    for i in range(n):
+        f = rng.uniform(1.0, 6.0, size=4)
+        ph = rng.uniform(0, 6.28, size=4)
+        a = 0.5 + 0.5 * np.sin(6.28 * f[0] * xx + ph[0]) * np.cos(6.28 * f[1] * yy + ph[1])
+        b = 0.5 + 0.5 * np.sin(6.28 * f[2] * (xx + yy) + ph[2]) * np.cos(6.28 * f[3] * (xx - yy) + ph[3])
+        od = a[..., None] * 1.2 * hema + b[..., None] * 0.8 * eos
+        img = 255.0 * np.exp(-od) + rng.normal(0, 4.0, size=od.shape)
+        out[i] = np.clip(img, 0, 255).astype(np.uint8)
+    return out
+
+
+def golden_ctranspath() -> None:
+    """Reference `_SwinTransformer` + `_ConvStem` (preprocessing/extractor/ctranspath.py) on seeded weights.
+    The module top imports gdown / torchvision / stamp.utils.cache; only its model definitions are executed."""
+    import math
+    import warnings
+    from collections.abc import Iterable
+    from itertools import repeat
+    from typing import Optional, TypeVar, cast
+
+    import torch.nn as nn
+    import torch.utils.checkpoint as checkpoint
+    from torch import _assert
+    from torch.nn.init import _calculate_fan_in_and_fan_out
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from stamp_amd.swin import SWIN_PRESETS, random_swin_state_dict
+
+    glb = {"torch": torch, "nn": nn, "math": math, "warnings": warnings, "Iterable": Iterable, "repeat": repeat,
+           "Optional": Optional, "TypeVar": TypeVar, "cast": cast, "checkpoint": checkpoint, "_assert": _assert,
+           "_calculate_fan_in_and_fan_out": _calculate_fan_in_and_fan_out, "Tensor": torch.Tensor,
+           "_T": TypeVar("_T"), "__name__": "ref_ctranspath"}
+    names = {"_to_2tuple", "_no_grad_trunc_normal_", "_trunc_normal_tf_", "_variance_scaling_", "_trunc_normal_",
+             "_lecun_normal_", "_init_vit_weights", "_window_partition", "_window_reverse", "_drop_path", "_DropPath",
+             "_PatchEmbed", "_Mlp", "_ConvStem", "_WindowAttention", "_SwinTransformerBlock", "_PatchMerging",
+             "_BasicLayer", "_SwinTransformer", "_swin_tiny_patch4_window7_224"}
+    exec_defs(REF / "preprocessing" / "extractor" / "ctranspath.py", names, glb)
+
+    def run(tag: str, model: torch.nn.Module, cfg, seed: int, n: int, tap_rows: int):
+        model.head = nn.Identity()                       # ctranspath.py:51
+        sd = random_swin_state_dict(cfg, seed)
+        ref_sd = model.state_dict()
+        float_keys = {k for k, v in ref_sd.items() if v.is_floating_point() and not k.endswith("attn_mask")}
+        assert float_keys == set(sd), (float_keys ^ set(sd))
+        for k in float_keys:
+            assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+        model.load_state_dict({**ref_sd, **sd}, strict=True)     # buffers (rel-pos index, attn_mask, counters) stay
+        model.eval()
+        rng = np.random.default_rng(seed + 77)
+        tiles = np.concatenate([rng.integers(0, 256, size=(n - n // 2, cfg.img, cfg.img, 3), dtype=np.uint8),
+                                he_like_tiles(n // 2, cfg.img, seed + 78)])
+        x = torch.from_numpy(tiles).permute(0, 3, 1, 2).float() / 255.0
+        x = (x - torch.tensor(cfg.mean).view(1, 3, 1, 1)) / torch.tensor(cfg.std).view(1, 3, 1, 1)   # ctranspath.py:56-64
+        taps = {}
+        with torch.no_grad():
+            t = model.patch_embed(x)
+            taps["stem"] = t
+            for s, layer in enumerate(model.layers):
+                t = layer(t)
+                taps[f"stage{s}"] = t
+            feats = model(x)
+        arrs = {"tiles": tiles, "feats": feats.numpy(), "seed": np.array(seed)}
+        for k, v in taps.items():      # a strided sample of token rows keeps the fixture small
+            L = v.shape[1]
+            idx = np.unique(np.linspace(0, L - 1, min(L, tap_rows)).round().astype(np.int64))
+            arrs["tap_idx_" + k] = idx
+            arrs["tap_" + k] = v[:, idx].numpy()
+        save(f"ctranspath_{tag}.npz", **arrs)
+
+    full = SWIN_PRESETS["ctranspath"]
+    run("swin_t", glb["_swin_tiny_patch4_window7_224"](embed_layer=glb["_ConvStem"], pretrained=False), full, 0, 4, 40)
+    tiny = SWIN_PRESETS["test_swin_tiny"]
+    run("tiny", glb["_SwinTransformer"](img_size=tiny.img, embed_dim=tiny.embed, depths=tiny.depths, num_heads=tiny.heads,
+                                        window_size=7, embed_layer=glb["_ConvStem"]), tiny, 1, 6, 64)
+
+
 def main() -> None:
     install_shims()
     golden_chief()
@@ -246,6 +329,7 @@ def main() -> None:
     golden_transmil()
     golden_mlp_cox_transforms()
     golden_bag()
+    golden_ctranspath()
 
 
 if __name__ == "__main__":
