@@ -91,8 +91,8 @@ int amds_layernorm(const float* x, long x_row_stride, const float* gamma, const 
                    void* stream);
 
 /* C = A[M,K] * W[N,K]^T with a fused epilogue (nn.Linear + activation + residual).
- * A, W: act dtype, K-contiguous, lda/ldw in elements (multiples of 8); K % 64 == 0; N % 128 == 0
- * (pad weights with amds_cast_pad). M arbitrary. `out` is act dtype or fp32 depending on `epi`;
+ * A, W: act dtype, K-contiguous, lda/ldw in elements (multiples of 8); K % 64 == 0; N % 128 == 0 or
+ * N % 96 == 0 (pad weights with amds_cast_pad). M arbitrary. `out` is act dtype or fp32 depending on `epi`;
  * ldo in elements. bias/scale/pos are fp32 (scale may be NULL = 1; bias may be NULL = 0).
  * np/T/P only for AMDS_EPI_PATCH. acc_scale multiplies the accumulator before bias (1.0f normally).
  * Replaces nn.Linear on the path: timm Attention.qkv/proj, Mlp.fc1/fc2; reference
@@ -101,7 +101,7 @@ int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, in
               int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
               const float* pos, int np, int T, int P, float acc_scale, void* stream);
 
-/* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default; 0 = 128x128 tile, 8 = 256x256x64
+/* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default; 0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64
  * staggered two-group pipeline (production), 3 = its BK=32 variant, 7 = four-wave 128x128-wave-tile variant). */
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                  int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
@@ -209,6 +209,72 @@ int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int pat
  * src/stamp/preprocessing/extractor/h_optimus_0.py:22-30, mstar.py:19-25). */
 int amds_tile_normalize_u8(const uint8_t* hwc, float* chw, int B, int H, int W,
                            const float mean_host[3], const float std_host[3], void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CTransPath tile encoder = ConvStem + Swin-T, the reference's in-tree network
+ * (src/stamp/preprocessing/extractor/ctranspath.py; factories ctranspath.py:34-70, chief_ctranspath.py:20-57)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int img;          /* 224 (multiple of 28 * 2^(n_stages-1)) */
+    int embed;        /* 96 */
+    int n_stages;     /* 4 */
+    int depths[4];    /* 2,2,6,2 */
+    int heads[4];     /* 3,6,12,24 (dim/32) */
+    int dtype;        /* AMDS_F16 / AMDS_BF16: MFMA operand type; the residual stream is fp32 */
+    float ln_eps;     /* 1e-5 (nn.LayerNorm / BatchNorm2d defaults) */
+} amds_swin_cfg;
+
+typedef struct {
+    const float* ln1_w; const float* ln1_b;
+    const void*  qkv_w; const float* qkv_b;     /* [3C][Kp] act dtype (Kp = max(C,128), zero padded), [3C] */
+    const float* bias_lane;                     /* [heads][2][2][64][16] fp32: rel-pos bias * log2e in MFMA lane order, -30000 on pad keys */
+    const void*  proj_w; const float* proj_b;   /* [C][Kp] */
+    const float* ln2_w; const float* ln2_b;
+    const void*  fc1_w; const float* fc1_b;     /* [4C][Kp] */
+    const void*  fc2_w; const float* fc2_b;     /* [C][4C] */
+} amds_swin_block;
+
+typedef struct {
+    const float* ln_w; const float* ln_b;       /* [4C] */
+    const void*  red_w;                         /* [2C][4C] act dtype, no bias */
+} amds_swin_merge;
+
+typedef struct {
+    const float* stem;                          /* packed ConvStem parameters, see amds_swin_stem */
+    const amds_swin_block* blocks_host;         /* HOST array of sum(depths) structs holding device pointers */
+    int n_blocks;
+    amds_swin_merge merges[3];
+    const float* norm_w; const float* norm_b;
+    const float* mask_lane;                     /* [4][2][2][64][16] fp32 shifted-window masks (-100 * log2e) by window type */
+} amds_swin_weights;
+
+size_t amds_swin_workspace_bytes(const amds_swin_cfg* cfg_host, int batch);
+
+/* tiles: u8 [B][img][img][3] -> feats = model(tiles) with model.head = Identity (ctranspath.py:50-51, 975-988):
+ * feats_f16 [B][8*embed] is `.half()` of it (src/stamp/preprocessing/__init__.py:324-325), feats_f32 the unrounded
+ * value; either may be NULL.  The (u8/255 - mean)/std transform (ctranspath.py:56-64) is folded into the stem. */
+int amds_swin_forward(const amds_swin_cfg* cfg_host, const amds_swin_weights* w_host, const uint8_t* tiles,
+                      void* feats_f16, float* feats_f32, int B, int chunk, void* ws, size_t ws_bytes, void* stream);
+
+/* ConvStem + patch LayerNorm (ctranspath.py:386-444, 905-911): u8 tiles -> fp32 tokens x [B][(img/4)^2][embed].
+ * params (fp32, BatchNorm folded): a[3]=1/(255 std), b[3]=-mean/std, 2 pad, w1[27][C/8], b1[C/8], w2[9*C/8][C/4],
+ * b2[C/4], w3[C/4][C], b3[C], ln_w[C], ln_b[C]; conv weights are stored [ci][ky][kx][co]. */
+int amds_swin_stem(const uint8_t* tiles, float* x, const float* params, int B, int img, int embed, float eps, void* stream);
+
+/* (Shifted-)window multi-head attention with relative-position bias (ctranspath.py:510-547, 654-690): tokens stay in
+ * raster order, windows of 7x7 are addressed by index arithmetic (roll by -shift), head_dim 32.
+ * qkv: act dtype [B*grid^2][ldq] = [q|k|v] x [heads][32]; out: act dtype [B*grid^2][ldo]. */
+int amds_window_attention(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane, const float* mask_lane,
+                          int B, int grid, int dim, int heads, int shift, int dtype, void* stream);
+
+/* PatchMerging up to the Linear (ctranspath.py:717-736): x fp32 [B][grid^2][dim] -> LayerNorm(concat of the 2x2 cell
+ * members (0,0),(1,0),(0,1),(1,1)) as act dtype [B][(grid/2)^2][4*dim]. */
+int amds_patch_merge_ln(const float* x, void* y, const float* gamma, const float* beta, int B, int grid, int dim, float eps,
+                        int dtype, void* stream);
+
+/* Final LayerNorm + AdaptiveAvgPool1d(1) over tokens (ctranspath.py:981-984): x fp32 [B][L][dim] -> [B][dim]. */
+int amds_layernorm_meanpool(const float* x, void* out_f16, float* out_f32, const float* gamma, const float* beta, int B,
+                            int L, int dim, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gated-attention pooling (CHIEF slide encoder; reference

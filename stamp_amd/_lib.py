@@ -36,6 +36,26 @@ class VitWeights(C.Structure):
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
 
 
+class SwinCfg(C.Structure):
+    _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
+                ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
+
+
+class SwinBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_w", "ln1_b", "qkv_w", "qkv_b", "bias_lane", "proj_w", "proj_b",
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class SwinMerge(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_w", "ln_b", "red_w")]
+
+
+class SwinWeights(C.Structure):
+    _fields_ = [("stem", C.c_void_p), ("blocks_host", C.POINTER(SwinBlock)), ("n_blocks", C.c_int),
+                ("merges", SwinMerge * 3), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("mask_lane", C.c_void_p)]
+
+
 class GapWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b")]
 
@@ -63,6 +83,12 @@ PROTOTYPES = {
     "amds_vit_forward": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_vit_forward_overlapped": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_vit_forward_tokens": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_swin_workspace_bytes": (_sz, [C.POINTER(SwinCfg), _i]),
+    "amds_swin_forward": (_i, [C.POINTER(SwinCfg), C.POINTER(SwinWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_swin_stem": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "amds_window_attention": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amds_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "amds_layernorm_meanpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),
     "amds_gather_rows": (_i, [_vp, _l, _vp, _i, _vp, _l, _i, _i, _i, _i, _vp]),

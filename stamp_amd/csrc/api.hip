@@ -110,7 +110,7 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
     AMDS_REQUIRE(A && W && out, "amds_gemm: null pointer");
     AMDS_REQUIRE(M >= 0 && N > 0 && K > 0, "amds_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     AMDS_REQUIRE(K % 64 == 0, "amds_gemm: K=%d must be a multiple of 64 (zero-pad with amds_cast_pad)", K);
-    AMDS_REQUIRE(N % 128 == 0, "amds_gemm: N=%d must be a multiple of 128 (zero-pad the weight rows)", N);
+    AMDS_REQUIRE(N % 128 == 0 || N % 96 == 0, "amds_gemm: N=%d must be a multiple of 128 or of 96 (zero-pad the weight rows)", N);
     AMDS_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "amds_gemm: lda=%ld/ldw=%ld must be >= K and multiples of 8", lda, ldw);
     AMDS_REQUIRE(ldo % 4 == 0, "amds_gemm: ldo=%ld must be a multiple of 4", ldo);
     AMDS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0, "amds_gemm: pointers must be 16-byte aligned");

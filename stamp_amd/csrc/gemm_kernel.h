@@ -99,6 +99,7 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
     constexpr int GROUP_M = 8;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
     static_assert(EPI != AMDS_EPI_SWIGLU || (FN % 2 == 0), "swiglu needs gate/value fragment pairs");
+    constexpr int PAIRS = FM * FN < FM + FN ? FM * FN : FM + FN;     // MFMA/ds_read pairs interleaved per k-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -190,11 +191,12 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
             if (ks + 1 < 4) {
                 // interleave: one ds_read per MFMA for the first FM+FN MFMAs of this k-step
 #pragma unroll
-                for (int r = 0; r < FM + FN; ++r) {
+                for (int r = 0; r < PAIRS; ++r) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
+                if constexpr (FM * FN > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - PAIRS, 0);
+                if constexpr (FM + FN > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN - PAIRS, 0);
             }
         }
     }
@@ -272,6 +274,7 @@ static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int 
                           hipStream_t st);   // gemm_8p.h
 
 // kernel ids (amds_gemm_ex): 0 = 128x128 tile, one barrier per K step (small problems, any N % 128 == 0)
+//   1 = 128x96 tile, four waves stacked along M (N % 96 == 0: the Swin widths 96/192/288/576 that 128 does not divide)
 //   8 = 256x256x64 staggered two-group pipeline (gemm_8p64.h, PRODUCTION; N % 256 == 0, else falls back to 0)
 //   3 = its BK = 32 / 4-stage variant (gemm_8p.h)      7 = four waves, 128x128 wave tiles, AGPR accumulators (gemm_4w.h)
 template <typename T, int EPI>
@@ -285,8 +288,17 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
         if (N % 256 == 0 && K >= 128) return launch_gemm_8p<T, EPI, 0>(A, lda, W, ldw, M, N, K, ep, st);
         cfg = 0;
     }
+    if (cfg == 0 && N % 128 != 0) cfg = 1;
     switch (cfg) {
         case 0: return launch_gemm_cfg<T, 128, 128, 2, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+        case 1:
+            if constexpr (EPI == AMDS_EPI_SWIGLU || EPI == AMDS_EPI_PATCH) {
+                set_error("amds_gemm: the 128x96 tile has no SWIGLU / PATCH epilogue");
+                return AMDS_ERR_INVALID;
+            } else {
+                if (N % 96 != 0) { set_error("amds_gemm: kernel 1 needs N %% 96 == 0 (N=%d)", N); return AMDS_ERR_INVALID; }
+                return launch_gemm_cfg<T, 128, 96, 4, 1, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+            }
     }
     set_error("amds_gemm: unknown tile config %d", cfg);
     return AMDS_ERR_INVALID;

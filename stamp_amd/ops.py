@@ -200,3 +200,51 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, relu: b
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().amds_linear_f32(_p(x), _p(w), _p(b), _p(out), M, N, K, 1 if relu else 0, _stream()), "linear_f32")
     return out
+
+
+# ---- CTransPath / Swin building blocks (include/amdstamp.h, "CTransPath tile encoder") --------------------------
+def swin_stem(tiles: torch.Tensor, params: torch.Tensor, embed: int = 96, eps: float = 1e-5) -> torch.Tensor:
+    """u8 [B,S,S,3] -> fp32 tokens [B,(S/4)^2,embed] (ConvStem + patch LayerNorm)."""
+    _dev(tiles, params)
+    assert tiles.dtype == torch.uint8 and tiles.is_contiguous() and tiles.shape[-1] == 3
+    B, S = tiles.shape[0], tiles.shape[1]
+    x = torch.empty(B, (S // 4) ** 2, embed, dtype=torch.float32, device=tiles.device)
+    _lib.check(_lib.lib().amds_swin_stem(_p(tiles), _p(x), _p(params), B, S, embed, eps, _stream()), "swin_stem")
+    return x
+
+
+def window_attention(qkv: torch.Tensor, bias_lane: torch.Tensor, mask_lane: torch.Tensor, B: int, grid: int, heads: int,
+                     shift: int) -> torch.Tensor:
+    """qkv [B*grid^2, 3*heads*32] (raster token order) -> [B*grid^2, heads*32]."""
+    _dev(qkv, bias_lane, mask_lane)
+    dim = heads * 32
+    assert qkv.is_contiguous() and qkv.shape == (B * grid * grid, 3 * dim)
+    out = torch.empty(B * grid * grid, dim, dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.lib().amds_window_attention(_p(qkv), 3 * dim, _p(out), dim, _p(bias_lane), _p(mask_lane), B, grid, dim,
+                                                heads, shift, act_code(qkv.dtype), _stream()), "window_attention")
+    return out
+
+
+def patch_merge_ln(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, grid: int, eps: float = 1e-5,
+                   out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """x fp32 [B, grid^2, C] -> LayerNorm(2x2 concat) [B, (grid/2)^2, 4C]."""
+    _dev(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, L, Cd = x.shape
+    assert L == grid * grid
+    y = torch.empty(B, L // 4, 4 * Cd, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().amds_patch_merge_ln(_p(x), _p(y), _p(gamma), _p(beta), B, grid, Cd, eps, act_code(out_dtype),
+                                              _stream()), "patch_merge_ln")
+    return y
+
+
+def layernorm_meanpool(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> tuple[torch.Tensor, torch.Tensor]:
+    """x fp32 [B,L,C] -> (fp16 [B,C], fp32 [B,C]) = mean over tokens of LayerNorm(x)."""
+    _dev(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, L, Cd = x.shape
+    o16 = torch.empty(B, Cd, dtype=torch.float16, device=x.device)
+    o32 = torch.empty(B, Cd, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_layernorm_meanpool(_p(x), _p(o16), _p(o32), _p(gamma), _p(beta), B, L, Cd, eps, _stream()),
+               "layernorm_meanpool")
+    return o16, o32

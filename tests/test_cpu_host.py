@@ -6,6 +6,7 @@ import subprocess
 import sys
 from pathlib import Path
 
+import numpy as np
 import pytest
 import torch
 
@@ -99,3 +100,42 @@ def test_gather_single_rank():
     ctx = DistCtx(0, 1, 0, torch.device("cpu"))
     t = gather_slide_embeddings(ctx, torch.ones(2, 3), torch.tensor([2, 0]), 4)
     assert t[0].sum() == 3 and t[2].sum() == 3 and t[1].sum() == 0
+
+
+def test_swin_lane_tables_reproduce_dense_bias_and_mask():
+    """The MFMA-lane-ordered relative-position-bias and shifted-window-mask tables (host packing for
+    amds_window_attention) must be a pure re-indexing of the dense tensors the reference builds
+    (ctranspath.py:478-496, 620-645), which the oracle restates."""
+    from oracle import swin_ctranspath as osw
+    from stamp_amd.swin import LOG2E, _lane_key_query, rel_bias_lane_table, shift_mask_lane_table
+
+    table = torch.randn(169, 6, generator=torch.Generator().manual_seed(0))
+    dense = table[osw.rel_pos_index().reshape(-1)].reshape(49, 49, 6).permute(2, 0, 1)       # [h][q][k]
+    lane = rel_bias_lane_table(table)
+    key, query = _lane_key_query()
+    ok = (key < 49) & (query < 49)
+    got = lane[:, ok] / LOG2E
+    want = dense[:, query[ok], key[ok]]
+    assert torch.allclose(got, want, atol=1e-6)
+    assert (lane[:, key >= 49] <= -20000).all()
+    # every (query, key) pair of the window is covered exactly once
+    assert torch.unique(query[ok] * 49 + key[ok]).numel() == 49 * 49 == int(ok.sum())
+    masks = shift_mask_lane_table()
+    for grid in (56, 14):
+        lab = osw.window_region_labels(grid, grid, 3)
+        n = grid // 7
+        for wh, ww in ((0, 0), (n - 1, 0), (0, n - 1), (n - 1, n - 1)):
+            typ = 2 * (wh == n - 1) + (ww == n - 1)
+            l = lab[wh * n + ww]
+            want = torch.where(l[:, None] != l[None, :], -100.0, 0.0)                          # [q][k]
+            assert torch.allclose(masks[typ][ok] / LOG2E, want[query[ok], key[ok]], atol=1e-5)
+    assert (masks[0] == 0).all()
+
+
+def test_swin_flops_and_state_dict_shapes():
+    from stamp_amd.swin import SWIN_PRESETS, random_swin_state_dict, swin_param_shapes
+    cfg = SWIN_PRESETS["ctranspath"]
+    assert abs(cfg.matmul_flops_per_tile() / 1e9 - 8.99) < 0.01          # Swin-T: 4.5 GMAC (the published figure)
+    sd = random_swin_state_dict(cfg, 0)
+    assert sum(v.numel() for v in sd.values()) == sum(int(np.prod(s)) for _, s in swin_param_shapes(cfg))
+    assert cfg.out_dim == 768 and sd["layers.3.blocks.1.attn.qkv.weight"].shape == (2304, 768)
