@@ -45,10 +45,13 @@ def parse() -> argparse.Namespace:
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, seconds: float) -> dict:
+def cpu_baseline(cfg, sd, seconds: float, swin: bool = False) -> dict:
     """The oracle (= the reference's algorithm on torch CPU fp32 kernels, batch 64 like the reference's
     DataLoader, src/stamp/preprocessing/__init__.py:317) timed on this box's host cores on a bounded sample."""
-    from oracle.vit_tile_encoder import extract_features
+    if swin:
+        from oracle.swin_ctranspath import swin_encode_f16 as extract_features
+    else:
+        from oracle.vit_tile_encoder import extract_features
 
     threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(1234)
@@ -63,7 +66,7 @@ def cpu_baseline(cfg, sd, seconds: float) -> dict:
         if el >= seconds or n >= 512:
             break
     return {"value": round(n / el, 3), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": f"{n} synthetic 224x224 tiles, ViT-L/14 fp32 oracle (torch CPU), batches of {batch}, {el:.1f}s"}
+            "sample": f"{n} synthetic 224x224 tiles, {'CTransPath (Swin-T)' if swin else 'ViT'} fp32 oracle (torch CPU), batches of {batch}, {el:.1f}s"}
 
 
 def main() -> None:
@@ -76,11 +79,18 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if a.gpus != ctx.world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
-    cfg = PRESETS[a.model]
+    from stamp_amd.swin import SWIN_PRESETS, HipSwin, random_swin_state_dict
     act = torch.float16 if a.act == "f16" else torch.bfloat16
-    sd = random_vit_state_dict(cfg, seed=0, init="moderate")
-    model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk)
-    model.overlap = bool(a.overlap)
+    is_swin = a.model in SWIN_PRESETS
+    if is_swin:       # the reference's in-tree tile encoder (ctranspath.py): ConvStem + Swin-T
+        cfg = SWIN_PRESETS[a.model]
+        sd = random_swin_state_dict(cfg, seed=0)
+        model = HipSwin(cfg, sd, device=ctx.device, act_dtype=act, chunk=min(a.chunk, 256))
+    else:
+        cfg = PRESETS[a.model]
+        sd = random_vit_state_dict(cfg, seed=0, init="moderate")
+        model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk)
+        model.overlap = bool(a.overlap)
     g = torch.Generator().manual_seed(1234 + ctx.rank)
     tiles = torch.randint(0, 256, (a.tiles, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g).to(ctx.device)
     slide_ids = torch.tensor([ctx.rank], device=ctx.device)
@@ -112,7 +122,7 @@ def main() -> None:
     # roofline of the dominant kernel (the MFMA GEMM), from HIP events recorded around every launch of it
     ms, n, work = C.c_double(), C.c_long(), C.c_double()
     kinds = {}
-    for kind, name in ((0, "gemm"), (1, "attention"), (2, "layernorm"), (3, "im2col")):
+    for kind, name in ((0, "gemm"), (1, "attention"), (2, "layernorm"), (3, "im2col_or_stem")):
         _lib.check(lib.amds_profile_read(kind, C.byref(ms), C.byref(n), C.byref(work)), "profile_read")
         kinds[name] = (ms.value, n.value, work.value)
     gms, gn, gflop = kinds["gemm"]
@@ -124,15 +134,18 @@ def main() -> None:
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.act, "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: ViT-L/14 (dim 1024, depth 24, 16 heads, 257 tokens, GELU MLP, "
-                               "LayerScale) tile extraction on synthetic 224x224x3 u8 tiles resident in HBM, "
-                               "random-init weights, fp16 CLS features out",
+        "config": {"workload": ("CTransPath (ConvStem + Swin-T 96/(2,2,6,2)/window 7, the reference's in-tree tile encoder) on "
+                                "synthetic 224x224x3 u8 tiles resident in HBM, seeded weights, fp16 768-d features out") if is_swin else
+                               ("BASELINE.json configs[1]: ViT-L/14 (dim 1024, depth 24, 16 heads, 257 tokens, GELU MLP, "
+                                "LayerScale) tile extraction on synthetic 224x224x3 u8 tiles resident in HBM, "
+                                "random-init weights, fp16 CLS features out"),
                    "model": a.model, "tiles_per_step_per_gpu": a.tiles, "chunk": a.chunk,
                    "operands": a.act, "accumulate": "f32", "residual_stream": "f32",
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-        "roofline": {"kernel": "gemm_8p64_kernel (256x256x64 staggered two-group 8-wave MFMA 32x32x16 pipeline, fused LDS-staged epilogues)", "bound": "mfma",
+        "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles in stages 1-2, gemm_8p64_kernel in stages 3-4)" if is_swin else
+                               "gemm_8p64_kernel (256x256x64 staggered two-group 8-wave MFMA 32x32x16 pipeline, fused LDS-staged epilogues)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),
@@ -187,10 +200,26 @@ def main() -> None:
         dt_tm = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 3)
         line["secondary"]["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 8, exact-fp32 MFMA)",
                                          "value": round(8 * ctx.world / dt_tm, 1), "finite": bool(torch.isfinite(lg2).all())}
+        if not is_swin:     # the reference's in-tree tile encoder, same tile shape
+            scfg = SWIN_PRESETS["ctranspath"]
+            sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=256)
+            st_tiles = tiles[:1024] if tiles.shape[0] >= 1024 else tiles
+            sw(st_tiles)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                sf = sw(st_tiles)
+            torch.cuda.synchronize()
+            dt_sw = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 3)
+            line["secondary"]["ctranspath"] = {"metric": "tiles/sec encoded (224x224, CTransPath = ConvStem + Swin-T)",
+                                               "value": round(st_tiles.shape[0] * ctx.world / dt_sw, 1), "unit": "tiles/s",
+                                               "gflop_per_tile": round(scfg.matmul_flops_per_tile() / 1e9, 3),
+                                               "finite": bool(torch.isfinite(sf.float()).all())}
+            del sw
     except Exception as e:      # the headline metric must still be printed
         line.setdefault("secondary", {})["error"] = repr(e)[:200]
     if ctx.is_main and ctx.world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds, swin=is_swin)
     elif ctx.is_main:
         line["cpu_baseline"] = None
     if ctx.is_main:

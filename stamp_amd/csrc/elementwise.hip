@@ -67,12 +67,83 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     }
 }
 
+// Narrow rows (cols <= 512): a full wave per row would idle most lanes (96 columns = 24 float4 of 64 lanes), so a row
+// is owned by a group of G = 8/16/32 lanes (64/G rows per wave); statistics reduce inside the group.
+template <typename TO, int G, int MAXV>
+__global__ void __launch_bounds__(256) layernorm_narrow_kernel(const float* __restrict__ x, long xs,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, TO* __restrict__ y,
+                                                               long ys, int rows, int cols, float eps) {
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int row = blockIdx.x * RPB + threadIdx.x / G;
+    const bool live = row < rows;
+    const float* xr = x + (long)(live ? row : rows - 1) * xs;
+    const int nv = cols >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * G + sub;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i * G + sub < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)cols + eps);
+    if (!live) return;
+    TO* yr = y + (long)row * ys;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * G + sub;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if constexpr (sizeof(TO) == 4) {
+                f32x4 w = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(yr + c * 4) = w;
+            } else {
+                typedef TO vec4 __attribute__((ext_vector_type(4)));
+                vec4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (TO)o[e];
+                *reinterpret_cast<vec4*>(yr + c * 4) = w;
+            }
+        }
+    }
+}
+
 template <typename TO>
 static int launch_ln(const float* x, long xs, const float* g, const float* b, void* y, long ys, int rows,
                      int cols, float eps, hipStream_t st) {
     const int nv = cols / 4;
     const int grid = cdiv(rows, 4);
-    if (nv <= 64 * 4)
+    if (nv <= 32)
+        hipLaunchKernelGGL((layernorm_narrow_kernel<TO, 8, 4>), dim3(cdiv(rows, 32)), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
+    else if (nv <= 64)
+        hipLaunchKernelGGL((layernorm_narrow_kernel<TO, 16, 4>), dim3(cdiv(rows, 16)), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
+    else if (nv <= 128)
+        hipLaunchKernelGGL((layernorm_narrow_kernel<TO, 32, 4>), dim3(cdiv(rows, 8)), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
+    else if (nv <= 64 * 4)
         hipLaunchKernelGGL((layernorm_kernel<TO, 4>), dim3(grid), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);
     else if (nv <= 64 * 8)
         hipLaunchKernelGGL((layernorm_kernel<TO, 8>), dim3(grid), dim3(256), 0, st, x, xs, g, b, (TO*)y, ys, rows, cols, eps);

@@ -14,35 +14,6 @@
 
 namespace amds {
 
-template <int EPI>
-constexpr bool epi_is_staged() {
-    return EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU || EPI == AMDS_EPI_RESIDUAL ||
-           EPI == AMDS_EPI_BIAS_F32 || EPI == AMDS_EPI_BIAS_GELU_F32 || EPI == AMDS_EPI_BIAS_RELU_F32;
-}
-
-// value transform shared by all staged epilogues: bias, activation, LayerScale (residual)
-template <int EPI>
-__device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, int n, f32x4 v) {
-    if (ep.acc_scale != 1.0f) v *= ep.acc_scale;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
-    if constexpr (EPI == AMDS_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
-    }
-    if constexpr (EPI == AMDS_EPI_BIAS_GELU_F32) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-    }
-    if constexpr (EPI == AMDS_EPI_BIAS_RELU || EPI == AMDS_EPI_BIAS_RELU_F32) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    if constexpr (EPI == AMDS_EPI_RESIDUAL) {
-        if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + n);
-    }
-    return v;
-}
-
 // Caller guarantees: every wave has finished reading the K-loop stages (a barrier has been passed).
 template <int EPI, typename T>
 __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const EpiArgs& ep, char* smem, int m0, int n0, int M,

@@ -37,6 +37,35 @@ struct EpiArgs {
     int nbatch = 1;
 };
 
+template <int EPI>
+constexpr bool epi_is_staged() {
+    return EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU || EPI == AMDS_EPI_RESIDUAL ||
+           EPI == AMDS_EPI_BIAS_F32 || EPI == AMDS_EPI_BIAS_GELU_F32 || EPI == AMDS_EPI_BIAS_RELU_F32;
+}
+
+// value transform shared by all staged epilogues: bias, activation, LayerScale (residual)
+template <int EPI>
+__device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, int n, f32x4 v) {
+    if (ep.acc_scale != 1.0f) v *= ep.acc_scale;
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+    if constexpr (EPI == AMDS_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+    }
+    if constexpr (EPI == AMDS_EPI_BIAS_GELU_F32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if constexpr (EPI == AMDS_EPI_BIAS_RELU || EPI == AMDS_EPI_BIAS_RELU_F32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (EPI == AMDS_EPI_RESIDUAL) {
+        if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + n);
+    }
+    return v;
+}
+
 template <int EPI, typename T>
 __device__ __forceinline__ void epilogue4(const EpiArgs& ep, int m, int n, float v0, float v1, float v2,
                                           float v3) {
@@ -202,6 +231,49 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
+    if constexpr (epi_is_staged<EPI>()) {
+        // LDS-staged: the accumulator layout gives every lane a different row (8/16-byte pieces, 32 partial lines
+        // per store instruction: ~2 TB/s); bounce the tile through LDS (odd chunk pitch -> conflict-free column
+        // writes) and store whole rows, 16 bytes per lane.
+        constexpr bool F16OUT = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU);
+        constexpr int CPR = BN * (F16OUT ? 2 : 4) / 16, PITCH = (CPR | 1) * 16;     // 16-byte chunks per row; row pitch in bytes
+        __syncthreads();                                   // every wave is done with the K-loop stages
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = wm * WTM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wn * WTN + j * 32 + 8 * g + 4 * hi;
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    v = epi_value<EPI>(ep, n0 + nl, v);
+                    if constexpr (F16OUT) {
+                        vec4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = Act<T>::from_f32(v[e]);
+                        *reinterpret_cast<vec4*>(smem + row * PITCH + nl * 2) = o;
+                    } else {
+                        *reinterpret_cast<f32x4*>(smem + row * PITCH + nl * 4) = v;
+                    }
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
+            const int row = idx / CPR, c = idx - row * CPR;
+            if (m0 + row < M) {
+                if constexpr (F16OUT) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PITCH + c * 16);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + c * 8) = v;
+                } else {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PITCH + c * 16);
+                    f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + c * 4);
+                    if constexpr (EPI == AMDS_EPI_RESIDUAL) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WTM + i * 32 + l31;
@@ -241,13 +313,15 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
             }
         }
     }
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 static int launch_gemm_cfg(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                            const EpiArgs& ep, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * 64 * 2;
-    constexpr int LDS = 2 * STAGE;
+    constexpr int EPI_LDS = BM * ((BN * 4 / 16) | 1) * 16;            // fp32 tile at its odd chunk pitch
+    constexpr int LDS = 2 * STAGE > EPI_LDS ? 2 * STAGE : EPI_LDS;
     auto kern = gemm_tn_kernel<T, BM, BN, WM, WN, EPI>;
     static bool attr_set = false;
     if (!attr_set) {

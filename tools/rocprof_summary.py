@@ -27,5 +27,20 @@ def main(path: str) -> None:
     print(f"{'TOTAL':110s} {sum(a[0] for a in agg.values()):7d} {tot:12.1f}")
 
 
+def sequence(path: str, last: int) -> None:
+    """print the last `last` dispatches in start order (one forward = a fixed launch chain)"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = db.execute(f"select {namecol}, start, end from kernels order by start").fetchall()[-last:]
+    t0 = rows[0][1]
+    for i, (n, s, e) in enumerate(rows):
+        print(f"{i:4d} {(s - t0) / 1e3:10.1f} {(e - s) / 1e3:9.2f} us  {short(n)}")
+    print(f"span {(rows[-1][2] - t0) / 1e3:.1f} us, busy {sum(e - s for _, s, e in rows) / 1e3:.1f} us")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == "--seq":
+        sequence(sys.argv[1], int(sys.argv[3]))
+    else:
+        main(sys.argv[1])
