@@ -101,6 +101,17 @@ int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, in
               int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
               const float* pos, int np, int T, int P, float acc_scale, void* stream);
 
+/* Weights-stationary GEMM for narrow layers (K = 96, 192 or 384; N % 32 == 0): out = epi([LayerNorm](A) W^T + bias).
+ * The W slice of a workgroup lives in LDS for the whole launch and row groups stream through it from global memory
+ * straight into MFMA operand registers.  If ln_gamma/ln_beta are given, A is the fp32 residual stream [M][lda] and
+ * LayerNorm over its K columns (nn.LayerNorm, biased variance) is applied on the fly -- the `norm1`/`norm2` +
+ * `qkv`/`fc1` pairs of a Swin block (reference ctranspath.py:659, 693-695) in one pass; otherwise A is act dtype.
+ * epi: AMDS_EPI_BIAS, AMDS_EPI_BIAS_GELU (act dtype out), AMDS_EPI_RESIDUAL (fp32 out += ...), AMDS_EPI_BIAS_F32.
+ * Supported (K, epi, LN) combinations are those the Swin stages need; others return AMDS_ERR_INVALID. */
+int amds_gemm_rowstream(const void* A, long lda, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const void* W, long ldw, int M, int N, int K, int dtype, int epi, void* out, long ldo,
+                        const float* bias, void* stream);
+
 /* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default; 0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64
  * staggered two-group pipeline (production), 3 = its BK=32 variant, 7 = four-wave 128x128-wave-tile variant). */
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
@@ -226,11 +237,11 @@ typedef struct {
 
 typedef struct {
     const float* ln1_w; const float* ln1_b;
-    const void*  qkv_w; const float* qkv_b;     /* [3C][Kp] act dtype (Kp = max(C,128), zero padded), [3C] */
+    const void*  qkv_w; const float* qkv_b;     /* [3C][C] act dtype, [3C] */
     const float* bias_lane;                     /* [heads][2][2][64][16] fp32: rel-pos bias * log2e in MFMA lane order, -30000 on pad keys */
-    const void*  proj_w; const float* proj_b;   /* [C][Kp] */
+    const void*  proj_w; const float* proj_b;   /* [C][C] */
     const float* ln2_w; const float* ln2_b;
-    const void*  fc1_w; const float* fc1_b;     /* [4C][Kp] */
+    const void*  fc1_w; const float* fc1_b;     /* [4C][C] */
     const void*  fc2_w; const float* fc2_b;     /* [C][4C] */
 } amds_swin_block;
 

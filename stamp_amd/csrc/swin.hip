@@ -388,7 +388,7 @@ static int swin_plan(const amds_swin_cfg* c, int batch, SwinPlan* p) {
         AMDS_REQUIRE(c->heads[s] * SW_HD == (c->embed << s), "swin: heads[%d]=%d must be dim/32", s, c->heads[s]);
     }
     p->G = c->img / 4; p->C0 = c->embed; p->nstage = c->n_stages;
-    p->ldh0 = 128;                                   // stage-0 rows are zero-padded 96 -> 128 (GEMM K granularity 64)
+    p->ldh0 = c->embed;
     const size_t rows = (size_t)batch * p->G * p->G;
     size_t o = 0;
     p->off_xa = o;  o += align256(rows * c->embed * 4);
@@ -502,28 +502,43 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
     int rc;
 #define AMDS_TRY(call) do { rc = (call); if (rc != AMDS_OK) return rc; } while (0)
     AMDS_TRY(amds_swin_stem(tiles, xa, w->stem, Bc, c->img, c->embed, c->ln_eps, st));
-    // stage-0 activations live in 128-wide rows; the 32 pad columns are never written by LN / attention: zero them once
-    AMDS_HIP(hipMemsetAsync(h, 0, (size_t)Bc * pl.G * pl.G * pl.ldh0 * 2, st));
     float* x = xa;
     float* xo = xb;
     int G = pl.G, blk = 0;
     for (int s = 0; s < c->n_stages; ++s) {
-        const int C = c->embed << s, M = Bc * G * G, ldh = s == 0 ? pl.ldh0 : C, Kp = ldh;
+        const int C = c->embed << s, M = Bc * G * G;
+        // C = 96 / 192: weights-stationary streaming GEMMs with LayerNorm fused into the operand load (gemm_rowstream.hip);
+        // wider stages: tiled MFMA GEMMs + stand-alone LayerNorm
+        const bool narrow = C <= 192;
         for (int d = 0; d < c->depths[s]; ++d, ++blk) {
             const amds_swin_block& b = w->blocks_host[blk];
             const int shift = (d % 2 == 1 && G > SW_WS) ? SW_WS / 2 : 0;
-            AMDS_TRY(amds_layernorm(x, C, b.ln1_w, b.ln1_b, h, ldh, M, C, c->ln_eps, dt, st));
-            AMDS_TRY(amds_gemm(h, ldh, b.qkv_w, Kp, M, 3 * C, Kp, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
-            AMDS_TRY(amds_window_attention(big, 3 * C, h, ldh, b.bias_lane, w->mask_lane, Bc, G, C, c->heads[s], shift, dt, st));
-            AMDS_TRY(amds_gemm(h, ldh, b.proj_w, Kp, M, C, Kp, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
-            AMDS_TRY(amds_layernorm(x, C, b.ln2_w, b.ln2_b, h, ldh, M, C, c->ln_eps, dt, st));
-            AMDS_TRY(amds_gemm(h, ldh, b.fc1_w, Kp, M, 4 * C, Kp, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
-            AMDS_TRY(amds_gemm(big, 4 * C, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+            if (narrow) {
+                AMDS_TRY(amds_gemm_rowstream(x, C, b.ln1_w, b.ln1_b, c->ln_eps, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, st));
+                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_lane, Bc, G, C, c->heads[s], shift, dt, st));
+                AMDS_TRY(amds_gemm_rowstream(h, C, nullptr, nullptr, 0.f, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, st));
+                AMDS_TRY(amds_gemm_rowstream(x, C, b.ln2_w, b.ln2_b, c->ln_eps, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, st));
+                if (4 * C == 384)
+                    AMDS_TRY(amds_gemm_rowstream(big, 4 * C, nullptr, nullptr, 0.f, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, st));
+                else
+                    AMDS_TRY(amds_gemm(big, 4 * C, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+            } else {
+                AMDS_TRY(amds_layernorm(x, C, b.ln1_w, b.ln1_b, h, C, M, C, c->ln_eps, dt, st));
+                AMDS_TRY(amds_gemm(h, C, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_lane, Bc, G, C, c->heads[s], shift, dt, st));
+                AMDS_TRY(amds_gemm(h, C, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+                AMDS_TRY(amds_layernorm(x, C, b.ln2_w, b.ln2_b, h, C, M, C, c->ln_eps, dt, st));
+                AMDS_TRY(amds_gemm(h, C, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+                AMDS_TRY(amds_gemm(big, 4 * C, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+            }
         }
         if (s + 1 < c->n_stages) {
             const amds_swin_merge& m = w->merges[s];
             AMDS_TRY(amds_patch_merge_ln(x, h, m.ln_w, m.ln_b, Bc, G, C, c->ln_eps, dt, st));
-            AMDS_TRY(amds_gemm(h, 4 * C, m.red_w, 4 * C, M / 4, 2 * C, 4 * C, dt, AMDS_EPI_BIAS_F32, xo, 2 * C, nullptr, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+            if (4 * C == 384)
+                AMDS_TRY(amds_gemm_rowstream(h, 4 * C, nullptr, nullptr, 0.f, m.red_w, 4 * C, M / 4, 2 * C, 4 * C, dt, AMDS_EPI_BIAS_F32, xo, 2 * C, nullptr, st));
+            else
+                AMDS_TRY(amds_gemm(h, 4 * C, m.red_w, 4 * C, M / 4, 2 * C, 4 * C, dt, AMDS_EPI_BIAS_F32, xo, 2 * C, nullptr, nullptr, nullptr, 0, 0, 0, 1.0f, st));
             float* t = x; x = xo; xo = t;
             G /= 2;
         }

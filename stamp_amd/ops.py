@@ -248,3 +248,17 @@ def layernorm_meanpool(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     _lib.check(_lib.lib().amds_layernorm_meanpool(_p(x), _p(o16), _p(o32), _p(gamma), _p(beta), B, L, Cd, eps, _stream()),
                "layernorm_meanpool")
     return o16, o32
+
+
+def gemm_rowstream(a: torch.Tensor, w: torch.Tensor, epi: int, *, bias=None, ln_gamma=None, ln_beta=None, eps: float = 1e-5,
+                   out=None) -> torch.Tensor:
+    """Weights-stationary narrow GEMM; `a` is fp32 (with ln_gamma/ln_beta: LayerNorm fused) or the dtype of `w`."""
+    _dev(a, w, bias, ln_gamma, ln_beta, out)
+    M, K = a.shape
+    N = w.shape[0]
+    f32_out = epi in (_lib.EPI_RESIDUAL, _lib.EPI_BIAS_F32)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if f32_out else w.dtype, device=a.device)
+    _lib.check(_lib.lib().amds_gemm_rowstream(_p(a), a.stride(0), _p(ln_gamma), _p(ln_beta), eps, _p(w), w.stride(0), M, N, K,
+                                              act_code(w.dtype), epi, _p(out), out.stride(0), _p(bias), _stream()), "gemm_rowstream")
+    return out

@@ -216,7 +216,7 @@ class HipSwin(torch.nn.Module):
         i = 0
         for s, depth in enumerate(cfg.depths):
             Cs = cfg.embed << s
-            kp = max(Cs, 128)
+            kp = Cs
             for d in range(depth):
                 g = lambda n: sd[f"layers.{s}.blocks.{d}.{n}"]  # noqa: E731
                 b = blocks[i]

@@ -163,3 +163,37 @@ def test_swin_errors(gpu):
     with pytest.raises(KeyError):
         HipSwin(cfg, bad, device=gpu)
     assert model(torch.zeros(0, 112, 112, 3, dtype=torch.uint8, device=gpu)).shape == (0, 192)
+
+
+@pytest.mark.parametrize("K,N,epi,ln", [(96, 288, "bias", True), (96, 384, "gelu", True), (96, 96, "res", False),
+                                        (192, 576, "bias", True), (192, 768, "gelu", True), (192, 192, "res", False),
+                                        (384, 96, "res", False), (384, 192, "f32", False)])
+@pytest.mark.parametrize("M", [77, 4096 + 33])
+def test_gemm_rowstream(gpu, K, N, epi, ln, M):
+    """Weights-stationary narrow GEMM (+ fused LayerNorm) against fp64 on the same inputs; ragged M exercises the
+    row clamp and the predicated stores, N > one LDS slice exercises the slicing."""
+    g = torch.Generator().manual_seed(K + N + M)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    b = torch.randn(N, generator=g) * 0.3
+    code = {"bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU, "res": _lib.EPI_RESIDUAL, "f32": _lib.EPI_BIAS_F32}[epi]
+    if ln:
+        x = torch.randn(M, K, generator=g) * 2 + 0.5
+        gam, bet = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+        a_ref = F.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-5)
+        y = a_ref @ w.double().t() + b.double()
+        got = ops.gemm_rowstream(x.to(gpu), w.to(gpu), code, bias=b.to(gpu), ln_gamma=gam.to(gpu), ln_beta=bet.to(gpu))
+        ref = F.gelu(y) if epi == "gelu" else y
+        assert got.dtype == torch.float16 and got.shape == (M, N)
+        assert _rel(got.cpu().float(), ref) < 1e-3           # operand (LN output) and result rounded to fp16
+    else:
+        a = torch.randn(M, K, generator=g).half()
+        y = a.double() @ w.double().t()
+        if epi == "res":
+            res = torch.randn(M, N, generator=g)
+            got = ops.gemm_rowstream(a.to(gpu), w.to(gpu), code, bias=b.to(gpu), out=res.clone().to(gpu))
+            ref = res.double() + y + b.double()
+        else:
+            got = ops.gemm_rowstream(a.to(gpu), w.to(gpu), code, bias=None)
+            ref = y
+        assert got.dtype == torch.float32
+        assert (got.cpu().double() - ref).abs().max().item() < 3e-5 * K ** 0.5
