@@ -49,8 +49,8 @@ __device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, int n, f32x4 v) {
     if (ep.acc_scale != 1.0f) v *= ep.acc_scale;
     if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
     if constexpr (EPI == AMDS_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+        const f32x2 a = gelu_erf_poly2(f32x2{v[0], v[1]}), b = gelu_erf_poly2(f32x2{v[2], v[3]});
+        v = f32x4{a[0], a[1], b[0], b[1]};
     }
     if constexpr (EPI == AMDS_EPI_BIAS_GELU_F32) {
 #pragma unroll

@@ -7,44 +7,100 @@
 // coalesced epilogue).  Here the roles are inverted:
 //   * a workgroup (8 waves) stages its slice of W ONCE into LDS, already in MFMA fragment order (1 KB per
 //     (n-fragment, k-step): lane l reads its 16 bytes at lane*16 -> linear, conflict-free ds_read_b128), and then
-//     streams row groups through it (persistent grid: ~one workgroup per CU);
-//   * the activation never touches LDS: a lane's 16-byte MFMA B fragment IS a contiguous piece of one row, so each
-//     wave loads its 32*FM rows straight from global memory into registers (whole K);
+//     streams row groups through it (persistent grid, one workgroup per CU); LDS holds nothing else;
+//   * the activation never touches LDS: a lane's 16-byte MFMA fragment IS a contiguous piece of one row, so each wave
+//     loads its 32*FM rows straight from global memory into registers (whole K);
 //   * optional fused LayerNorm: A is the fp32 residual stream; the two lanes (l31, hi=0/1) that share a row hold all
 //     K values of it between them -> statistics are an in-lane sum plus one cross-half shuffle; the normalised row
 //     is rounded to the operand type in registers.  The separate LayerNorm kernel and its round trip disappear;
-//   * epilogue through a wave-private LDS transpose so that global stores / residual read-modify-writes are
-//     128-byte row segments (16 bytes per lane) instead of 8-byte pieces on 32 different rows.
-// MFMA orientation as everywhere else: W is the A operand, the activation the B operand (lane = row).
+//   * MFMA orientation: x is the A operand and W the B operand, so an accumulator register holds ONE ROW and the 32
+//     lanes of a half-wave hold 32 CONSECUTIVE COLUMNS: every global access of the epilogue is a contiguous 128-byte
+//     row segment per half-wave with no LDS transpose.  For 16-bit outputs two n-fragments are staged with their W rows
+//     interleaved (fragment 2p holds the even, 2p+1 the odd columns of a 64-column block), so a lane owns two adjacent
+//     columns and stores them as one 32-bit word;
+//   * latency: the residual rows (fp32 read-modify-write epilogues) are requested right after the operand rows, before
+//     any MFMA, and become the accumulators' initial value; the next row group's operand rows are requested before
+//     the current group's epilogue.  Each wave keeps 24-48 KB in flight.
 #include "gemm_kernel.h"
 
 namespace amds {
 
 constexpr int RS_WAVES = 8;
-constexpr int RS_STG_PITCH = 144;                       // bytes per staged row: 128 data + 16 pad (2-way conflicts at most)
-constexpr int RS_STG_BYTES = 32 * RS_STG_PITCH;         // per 32-row fragment
 
-template <typename T, int KS, int FM, int EPI, bool LNF>
-__global__ void __launch_bounds__(64 * RS_WAVES) rowstream_kernel(const void* __restrict__ Aptr, long lda, const T* __restrict__ W,
-                                                                  long ldw, int M, int nf, EpiArgs ep, const float* __restrict__ ln_g,
-                                                                  const float* __restrict__ ln_b, float eps, int groups) {
-    typedef typename Act<T>::vec8 vec8;
-    typedef typename Act<T>::vec4 vec4;
+template <typename T, int KS>
+__device__ __forceinline__ void rs_load_f16(typename Act<T>::vec8 (&xf)[KS], const T* A, long lda, int row, int hi) {
+    const T* xr = A + (long)row * lda + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const typename Act<T>::vec8*>(xr + 16 * ks);
+}
+
+template <int KS>
+__device__ __forceinline__ void rs_load_raw(f32x4 (&raw)[KS][2], const float* A, long lda, int row, int hi) {
+    const float* xr = A + (long)row * lda + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        raw[ks][0] = *reinterpret_cast<const f32x4*>(xr + 16 * ks);
+        raw[ks][1] = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 4);
+    }
+}
+
+// LayerNorm of one row spread over the lane pair (l31, hi = 0/1): two-pass statistics in fp32, output in operand type
+template <typename T, int KS>
+__device__ __forceinline__ void rs_normalise(typename Act<T>::vec8 (&xf)[KS], const f32x4 (&raw)[KS][2], const float* s_ln, int hi,
+                                             float eps) {
     constexpr int K = KS * 16;
-    constexpr bool F16OUT = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU);
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        s += ((raw[ks][0][0] + raw[ks][0][1]) + (raw[ks][0][2] + raw[ks][0][3])) +
+             ((raw[ks][1][0] + raw[ks][1][1]) + (raw[ks][1][2] + raw[ks][1][3]));
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / K);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = raw[ks][h2][e] - mean; q = fmaf(d, d, q); }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / K) + eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(s_ln + 16 * ks + 8 * hi + 4 * h2);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_ln + K + 16 * ks + 8 * hi + 4 * h2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xf[ks][4 * h2 + e] = Act<T>::from_f32(fmaf((raw[ks][h2][e] - mean) * rstd, gg[e], bb[e]));
+            if (h2 == 1 && (ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // at most 8 gamma/beta fragments in flight
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-bit outputs: out = act(LN?(A) W^T + bias), optional GELU.  nf n-fragments per slice, processed in pairs.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int KS, int FM, int EPI, bool LNF>
+__global__ void __launch_bounds__(64 * RS_WAVES) rowstream_f16out_kernel(const void* __restrict__ Aptr, long lda, const T* __restrict__ W,
+                                                                         long ldw, int M, int nf, T* __restrict__ out, long ldo,
+                                                                         const float* __restrict__ bias, const float* __restrict__ ln_g,
+                                                                         const float* __restrict__ ln_b, float eps, int groups) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    constexpr int K = KS * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int n_base = blockIdx.y * nf * 32;            // first output column of this workgroup's slice
-
-    // ---- stage the W slice in fragment order (async global -> LDS, per-lane gather addresses) ----
+    const int n_base = blockIdx.y * nf * 32;
+    const int npair = nf >> 1;
     char* s_w = smem;
     float* s_ln = reinterpret_cast<float*>(smem + (size_t)nf * KS * 1024);
-    char* s_stg = reinterpret_cast<char*>(s_ln) + (LNF ? 2 * K * 4 : 0) + wave * (FM * RS_STG_BYTES);
+    // W slice -> LDS in fragment order; paired fragments take the even / odd rows of their 64-row block
     for (int blk = wave; blk < nf * KS; blk += RS_WAVES) {
         const int j = blk / KS, ks = blk - j * KS;
-        glds16(W + (long)(n_base + 32 * j + l31) * ldw + 16 * ks + 8 * hi, s_w + blk * 1024);
+        const int wrow = (j < 2 * npair) ? 64 * (j >> 1) + 2 * l31 + (j & 1) : 32 * j + l31;
+        glds16(W + (long)(n_base + wrow) * ldw + 16 * ks + 8 * hi, s_w + blk * 1024);
     }
     if constexpr (LNF) {
         for (int i = tid; i < K; i += 64 * RS_WAVES) { s_ln[i] = ln_g[i]; s_ln[K + i] = ln_b[i]; }
@@ -52,138 +108,242 @@ __global__ void __launch_bounds__(64 * RS_WAVES) rowstream_kernel(const void* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int g = blockIdx.x * RS_WAVES + wave; g < groups; g += gridDim.x * RS_WAVES) {
-        const int row0 = g * 32 * FM;
-        // ---- activation fragments: whole K of 32*FM rows, registers only ----
-        vec8 xf[FM][KS];
+    const int gstep = gridDim.x * RS_WAVES;
+    const int lane_off2 = 4 * hi * (int)ldo + 2 * l31, lane_off1 = 4 * hi * (int)ldo + l31;     // lane-dependent part (elements)
+    int g = __builtin_amdgcn_readfirstlane(blockIdx.x * RS_WAVES + wave);
+    constexpr bool RAW_PF = LNF && KS * FM <= 6;       // prefetch the next group's fp32 rows only while 2 x raw + xf fit the register file
+    f32x4 raw[LNF ? FM : 1][KS][2];
+    vec8 xf[FM][KS];
+    if (g < groups && (RAW_PF || !LNF)) {
 #pragma unroll
         for (int f = 0; f < FM; ++f) {
-            const int row = min(row0 + f * 32 + l31, M - 1);
-            if constexpr (LNF) {
-                const float* xr = reinterpret_cast<const float*>(Aptr) + (long)row * lda + 8 * hi;
-                f32x4 raw[KS][2];
-                float s = 0.f;
+            const int row = min(g * 32 * FM + f * 32 + l31, M - 1);
+            if constexpr (LNF) rs_load_raw<KS>(raw[f], reinterpret_cast<const float*>(Aptr), lda, row, hi);
+            else rs_load_f16<T, KS>(xf[f], reinterpret_cast<const T*>(Aptr), lda, row, hi);
+        }
+    }
+    for (; g < groups; g += gstep) {
+        const int row0 = g * 32 * FM;
+        // the W fragments are loop invariant: without an opaque per-iteration offset the compiler hoists all nf*KS
+        // ds_reads out of the group loop and spills them
+        int lds_lane = lane * 16;
+        asm volatile("" : "+v"(lds_lane));
+        if constexpr (LNF) {
+            if constexpr (!RAW_PF) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    raw[ks][0] = *reinterpret_cast<const f32x4*>(xr + 16 * ks);
-                    raw[ks][1] = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 4);
-                }
+                for (int f = 0; f < FM; ++f)
+                    rs_load_raw<KS>(raw[f], reinterpret_cast<const float*>(Aptr), lda, min(row0 + f * 32 + l31, M - 1), hi);
+            }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    s += ((raw[ks][0][0] + raw[ks][0][1]) + (raw[ks][0][2] + raw[ks][0][3])) +
-                         ((raw[ks][1][0] + raw[ks][1][1]) + (raw[ks][1][2] + raw[ks][1][3]));
-                s += __shfl_xor(s, 32, 64);
-                const float mean = s * (1.0f / K);
-                float q = 0.f;
+            for (int f = 0; f < FM; ++f) rs_normalise<T, KS>(xf[f], raw[f], s_ln, hi, eps);
+            // request the next group's rows now: they arrive under this group's MFMAs / GELU / stores
+            if (RAW_PF && g + gstep < groups) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float d = raw[ks][h2][e] - mean; q = fmaf(d, d, q); }
-                q += __shfl_xor(q, 32, 64);
-                const float rstd = rsqrtf(q * (1.0f / K) + eps);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const f32x4 gg = *reinterpret_cast<const f32x4*>(s_ln + 16 * ks + 8 * hi + 4 * h2);
-                        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_ln + K + 16 * ks + 8 * hi + 4 * h2);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            xf[f][ks][4 * h2 + e] = Act<T>::from_f32(fmaf((raw[ks][h2][e] - mean) * rstd, gg[e], bb[e]));
-                    }
-            } else {
-                const T* xr = reinterpret_cast<const T*>(Aptr) + (long)row * lda + 8 * hi;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xf[f][ks] = *reinterpret_cast<const vec8*>(xr + 16 * ks);
+                for (int f = 0; f < FM; ++f)
+                    rs_load_raw<KS>(raw[f], reinterpret_cast<const float*>(Aptr), lda, min((g + gstep) * 32 * FM + f * 32 + l31, M - 1), hi);
             }
         }
-        // ---- n fragments ----
-        for (int j = 0; j < nf; ++j) {
-            f32x16 acc[FM];
+        for (int p = 0; p < npair; ++p) {
+            f32x16 acc[FM][2];
+            const float b0 = bias ? bias[n_base + 64 * p + 2 * l31] : 0.f, b1 = bias ? bias[n_base + 64 * p + 2 * l31 + 1] : 0.f;
 #pragma unroll
             for (int f = 0; f < FM; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-            const char* wj = s_w + (size_t)j * KS * 1024 + lane * 16;
+                for (int r = 0; r < 16; ++r) { acc[f][0][r] = b0; acc[f][1][r] = b1; }
+            const char* wp = s_w + (size_t)(2 * p) * KS * 1024 + lds_lane;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const vec8 wf = *reinterpret_cast<const vec8*>(wj + ks * 1024);
+                const vec8 w0 = *reinterpret_cast<const vec8*>(wp + ks * 1024);
+                const vec8 w1 = *reinterpret_cast<const vec8*>(wp + (KS + ks) * 1024);
 #pragma unroll
-                for (int f = 0; f < FM; ++f) acc[f] = Act<T>::mfma32(wf, xf[f][ks], acc[f]);
-            }
-            const int n_frag = n_base + 32 * j;
-            if constexpr (F16OUT) {
-                // two fragments (64 columns = 128 bytes per row) are collected before a flush
-                const int half = j & 1;
-#pragma unroll
-                for (int f = 0; f < FM; ++f)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        f32x4 v = {acc[f][4 * g4], acc[f][4 * g4 + 1], acc[f][4 * g4 + 2], acc[f][4 * g4 + 3]};
-                        v = epi_value<EPI>(ep, n_frag + 8 * g4 + 4 * hi, v);
-                        vec4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = Act<T>::from_f32(v[e]);
-                        *reinterpret_cast<vec4*>(s_stg + f * RS_STG_BYTES + l31 * RS_STG_PITCH + half * 64 + 16 * g4 + 8 * hi) = o;
-                    }
-                if (half == 1 || j == nf - 1) {
-                    __builtin_amdgcn_wave_barrier();
-                    const int ncol0 = n_frag - half * 32;              // first column of the staged segment
-                    const int nchunk = (half + 1) * 4;                 // 16-byte chunks per row: 4 (one fragment) or 8
-#pragma unroll
-                    for (int f = 0; f < FM; ++f)
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int r = it * 8 + (lane >> 3), c = lane & 7;
-                            const int row = row0 + f * 32 + r;
-                            const u32x4 v = *reinterpret_cast<const u32x4*>(s_stg + f * RS_STG_BYTES + r * RS_STG_PITCH + c * 16);
-                            if (row < M && c < nchunk)
-                                *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(ep.out) + (long)row * ep.ldo + ncol0 + c * 8) = v;
-                        }
-                    __builtin_amdgcn_wave_barrier();
+                for (int f = 0; f < FM; ++f) {
+                    acc[f][0] = Act<T>::mfma32(xf[f][ks], w0, acc[f][0]);
+                    acc[f][1] = Act<T>::mfma32(xf[f][ks], w1, acc[f][1]);
                 }
-            } else {
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // bound how many W fragments are in flight
+            }
+#pragma unroll
+            for (int f = 0; f < FM; ++f) {
+                T* ub = out + (long)(row0 + f * 32) * ldo + n_base + 64 * p;          // wave-uniform part of the address
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f32x2 v = {acc[f][0][r], acc[f][1][r]};
+                    if constexpr (EPI == AMDS_EPI_BIAS_GELU) v = gelu_erf_poly2(v);
+                    const vec2 o = {Act<T>::from_f32(v[0]), Act<T>::from_f32(v[1])};
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + f * 32 + 4 * hi + rr < M) *reinterpret_cast<vec2*>(ub + (long)rr * ldo + lane_off2) = o;
+                }
+            }
+        }
+        if (nf & 1) {                      // trailing unpaired fragment: plain column order, 16-bit stores
+            const int j = nf - 1;
+            f32x16 acc[FM];
+            const float b0 = bias ? bias[n_base + 32 * j + l31] : 0.f;
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][r] = b0;
+            const char* wp = s_w + (size_t)j * KS * 1024 + lds_lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const vec8 w0 = *reinterpret_cast<const vec8*>(wp + ks * 1024);
+#pragma unroll
+                for (int f = 0; f < FM; ++f) acc[f] = Act<T>::mfma32(xf[f][ks], w0, acc[f]);
+            }
+#pragma unroll
+            for (int f = 0; f < FM; ++f) {
+                T* ub = out + (long)(row0 + f * 32) * ldo + n_base + 32 * j;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = {acc[f][r], acc[f][r + 1]};
+                    if constexpr (EPI == AMDS_EPI_BIAS_GELU) v = gelu_erf_poly2(v);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2);
+                        if (row0 + f * 32 + 4 * hi + rr < M) ub[(long)rr * ldo + lane_off1] = Act<T>::from_f32(v[e]);
+                    }
+                }
+            }
+        }
+        if constexpr (!LNF) {
+            if (g + gstep < groups) {
 #pragma unroll
                 for (int f = 0; f < FM; ++f)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        f32x4 v = {acc[f][4 * g4], acc[f][4 * g4 + 1], acc[f][4 * g4 + 2], acc[f][4 * g4 + 3]};
-                        v = epi_value<EPI>(ep, n_frag + 8 * g4 + 4 * hi, v);
-                        *reinterpret_cast<f32x4*>(s_stg + f * RS_STG_BYTES + l31 * RS_STG_PITCH + 32 * g4 + 16 * hi) = v;
-                    }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int f = 0; f < FM; ++f)
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int r = it * 8 + (lane >> 3), c = lane & 7;
-                        const int row = row0 + f * 32 + r;
-                        f32x4 v = *reinterpret_cast<const f32x4*>(s_stg + f * RS_STG_BYTES + r * RS_STG_PITCH + c * 16);
-                        if (row < M) {
-                            f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (long)row * ep.ldo + n_frag + c * 4);
-                            if constexpr (EPI == AMDS_EPI_RESIDUAL) v += *p;
-                            *p = v;
-                        }
-                    }
-                __builtin_amdgcn_wave_barrier();
+                    rs_load_f16<T, KS>(xf[f], reinterpret_cast<const T*>(Aptr), lda, min((g + gstep) * 32 * FM + f * 32 + l31, M - 1), hi);
             }
         }
     }
 }
 
-template <typename T, int KS, int FM, int EPI, bool LNF>
-static int launch_rowstream(const void* A, long lda, const void* W, long ldw, int M, int N, const EpiArgs& ep, const float* ln_g,
-                            const float* ln_b, float eps, hipStream_t st) {
-    constexpr int K = KS * 16;
-    // slice N so that the resident W slice stays <= 72 KB (staging + LN parameters take the rest of the 160 KB)
-    const int nfrag = N / 32;
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 outputs with all NF n-fragments of the slice live: out (+)= A W^T + bias.  RESIDUAL: the accumulators start
+// from the residual rows, requested before the MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int KS, int FM, int NF, int EPI, bool PREFETCH>
+__global__ void __launch_bounds__(64 * RS_WAVES) rowstream_f32out_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw,
+                                                                         int M, float* out, long ldo, const float* __restrict__ bias,
+                                                                         int groups) {
+    typedef typename Act<T>::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n_base = blockIdx.y * NF * 32;
+    for (int blk = wave; blk < NF * KS; blk += RS_WAVES) {
+        const int j = blk / KS, ks = blk - j * KS;
+        glds16(W + (long)(n_base + 32 * j + l31) * ldw + 16 * ks + 8 * hi, smem + blk * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float bv[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bv[j] = bias ? bias[n_base + 32 * j + l31] : 0.f;
+
+    const int gstep = gridDim.x * RS_WAVES;
+    int g = __builtin_amdgcn_readfirstlane(blockIdx.x * RS_WAVES + wave);
+    const int lane_off = 4 * hi * (int)ldo + l31;
+    vec8 xf[FM][KS], xn[PREFETCH ? FM : 1][KS];
+    if (g < groups) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) rs_load_f16<T, KS>(xf[f], A, lda, min(g * 32 * FM + f * 32 + l31, M - 1), hi);
+    }
+    for (; g < groups; g += gstep) {
+        const int row0 = g * 32 * FM;
+        const bool full = row0 + 32 * FM <= M;
+        int lds_lane = lane * 16;                         // opaque per iteration: keeps the W-fragment ds_reads inside the loop
+        asm volatile("" : "+v"(lds_lane));
+        f32x16 acc[FM][NF];
+        if constexpr (EPI == AMDS_EPI_RESIDUAL) {
+            // unconditional loads on the (usual) full group: a predicated load sits in its own basic block and gets a
+            // vmcnt(0) at the join, which serialises the 48-96 requests this kernel lives on
+            if (full) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float* ub = out + (long)(row0 + f * 32 + (r & 3) + 8 * (r >> 2)) * ldo + n_base + 32 * j;   // wave-uniform
+                            acc[f][j][r] = ub[lane_off];
+                        }
+            } else {
+#pragma unroll
+                for (int f = 0; f < FM; ++f)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = min(row0 + f * 32 + 4 * hi + (r & 3) + 8 * (r >> 2), M - 1);
+                            acc[f][j][r] = out[(long)row * ldo + n_base + 32 * j + l31];
+                        }
+            }
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[f][j][r] += bv[j];
+        } else {
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[f][j][r] = bv[j];
+        }
+        if constexpr (PREFETCH) {
+            if (g + gstep < groups) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) rs_load_f16<T, KS>(xn[f], A, lda, min((g + gstep) * 32 * FM + f * 32 + l31, M - 1), hi);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const vec8 wf = *reinterpret_cast<const vec8*>(smem + (size_t)(j * KS + ks) * 1024 + lds_lane);
+#pragma unroll
+                for (int f = 0; f < FM; ++f) acc[f][j] = Act<T>::mfma32(xf[f][ks], wf, acc[f][j]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    float* ub = out + (long)(row0 + f * 32 + rr) * ldo + n_base + 32 * j;
+                    if (full || row0 + f * 32 + 4 * hi + rr < M) ub[lane_off] = acc[f][j][r];
+                }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xf[f][ks] = xn[f][ks];
+        } else {
+            if (g + gstep < groups) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) rs_load_f16<T, KS>(xf[f], A, lda, min((g + gstep) * 32 * FM + f * 32 + l31, M - 1), hi);
+            }
+        }
+    }
+}
+
+static int rs_slices(int nfrag, int KS) {
     int slices = 1;
     while ((nfrag % slices) != 0 || (size_t)(nfrag / slices) * KS * 1024 > 73728) ++slices;
-    const int nf = nfrag / slices;
-    const size_t lds = (size_t)nf * KS * 1024 + (LNF ? 2 * K * 4 : 0) + (size_t)RS_WAVES * FM * RS_STG_BYTES;
-    auto kern = rowstream_kernel<T, KS, FM, EPI, LNF>;
+    return slices;
+}
+
+template <typename T, int KS, int FM, int EPI, bool LNF>
+static int launch_rs_f16(const void* A, long lda, const void* W, long ldw, int M, int N, void* out, long ldo, const float* bias,
+                         const float* ln_g, const float* ln_b, float eps, hipStream_t st) {
+    constexpr int K = KS * 16;
+    const int nfrag = N / 32, slices = rs_slices(nfrag, KS), nf = nfrag / slices;
+    const size_t lds = (size_t)nf * KS * 1024 + (LNF ? 2 * K * 4 : 0);
+    auto kern = rowstream_f16out_kernel<T, KS, FM, EPI, LNF>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -191,29 +351,57 @@ static int launch_rowstream(const void* A, long lda, const void* W, long ldw, in
     }
     const int groups = cdiv(M, 32 * FM);
     int gx = cdiv(groups, RS_WAVES);
-    const int cap = 256 / slices > 0 ? 256 / slices : 1;            // ~one resident workgroup per CU over all slices
+    const int cap = 256 / slices > 0 ? 256 / slices : 1;            // one resident workgroup per CU over all slices
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(64 * RS_WAVES), lds, st, A, lda, reinterpret_cast<const T*>(W), ldw, M, nf, ep,
-                       ln_g, ln_b, eps, groups);
-    AMDS_LAUNCH_CHECK("rowstream_kernel");
+    hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(64 * RS_WAVES), lds, st, A, lda, reinterpret_cast<const T*>(W), ldw, M, nf,
+                       reinterpret_cast<T*>(out), ldo, bias, ln_g, ln_b, eps, groups);
+    AMDS_LAUNCH_CHECK("rowstream_f16out_kernel");
+    return AMDS_OK;
+}
+
+template <typename T, int KS, int FM, int NF, int EPI, bool PREFETCH>
+static int launch_rs_f32(const void* A, long lda, const void* W, long ldw, int M, int N, void* out, long ldo, const float* bias,
+                         hipStream_t st) {
+    const int slices = N / (32 * NF);
+    const size_t lds = (size_t)NF * KS * 1024;
+    auto kern = rowstream_f32out_kernel<T, KS, FM, NF, EPI, PREFETCH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int groups = cdiv(M, 32 * FM);
+    int gx = cdiv(groups, RS_WAVES);
+    const int cap = 256 / slices > 0 ? 256 / slices : 1;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(64 * RS_WAVES), lds, st, reinterpret_cast<const T*>(A), lda,
+                       reinterpret_cast<const T*>(W), ldw, M, reinterpret_cast<float*>(out), ldo, bias, groups);
+    AMDS_LAUNCH_CHECK("rowstream_f32out_kernel");
     return AMDS_OK;
 }
 
 template <typename T>
-static int rowstream_dispatch(const void* A, long lda, bool lnf, const void* W, long ldw, int M, int N, int K, int epi, const EpiArgs& ep,
-                              const float* ln_g, const float* ln_b, float eps, hipStream_t st) {
-#define RS_CASE(KSV, FMV, EPIV, LNV) \
-    if (K == KSV * 16 && epi == EPIV && lnf == LNV) return launch_rowstream<T, KSV, FMV, EPIV, LNV>(A, lda, W, ldw, M, N, ep, ln_g, ln_b, eps, st);
-    RS_CASE(6, 2, AMDS_EPI_BIAS, true)
-    RS_CASE(6, 2, AMDS_EPI_BIAS_GELU, true)
-    RS_CASE(6, 2, AMDS_EPI_RESIDUAL, false)
-    RS_CASE(12, 1, AMDS_EPI_BIAS, true)
-    RS_CASE(12, 1, AMDS_EPI_BIAS_GELU, true)
-    RS_CASE(12, 2, AMDS_EPI_RESIDUAL, false)
-    RS_CASE(24, 1, AMDS_EPI_RESIDUAL, false)
-    RS_CASE(24, 1, AMDS_EPI_BIAS_F32, false)
-#undef RS_CASE
-    set_error("amds_gemm_rowstream: no kernel for K=%d epi=%d fused_ln=%d", K, epi, (int)lnf);
+static int rowstream_dispatch(const void* A, long lda, bool lnf, const void* W, long ldw, int M, int N, int K, int epi, void* out, long ldo,
+                              const float* bias, const float* ln_g, const float* ln_b, float eps, hipStream_t st) {
+    const bool f16out = epi == AMDS_EPI_BIAS || epi == AMDS_EPI_BIAS_GELU;
+    if (f16out && lnf) {
+        if (K == 96 && epi == AMDS_EPI_BIAS) return launch_rs_f16<T, 6, 1, AMDS_EPI_BIAS, true>(A, lda, W, ldw, M, N, out, ldo, bias, ln_g, ln_b, eps, st);
+        if (K == 96) return launch_rs_f16<T, 6, 1, AMDS_EPI_BIAS_GELU, true>(A, lda, W, ldw, M, N, out, ldo, bias, ln_g, ln_b, eps, st);
+        if (K == 192 && epi == AMDS_EPI_BIAS) return launch_rs_f16<T, 12, 1, AMDS_EPI_BIAS, true>(A, lda, W, ldw, M, N, out, ldo, bias, ln_g, ln_b, eps, st);
+        if (K == 192) return launch_rs_f16<T, 12, 1, AMDS_EPI_BIAS_GELU, true>(A, lda, W, ldw, M, N, out, ldo, bias, ln_g, ln_b, eps, st);
+    }
+    if (!lnf && (epi == AMDS_EPI_RESIDUAL || epi == AMDS_EPI_BIAS_F32)) {
+#define RS_F32(KV, KSV, FMV, NFV, PF)                                                                                               \
+    if (K == KV && N % (32 * NFV) == 0) {                                                                                           \
+        if (epi == AMDS_EPI_RESIDUAL) return launch_rs_f32<T, KSV, FMV, NFV, AMDS_EPI_RESIDUAL, PF>(A, lda, W, ldw, M, N, out, ldo, bias, st); \
+        return launch_rs_f32<T, KSV, FMV, NFV, AMDS_EPI_BIAS_F32, PF>(A, lda, W, ldw, M, N, out, ldo, bias, st);                    \
+    }
+        RS_F32(96, 6, 2, 3, true)          // stage-1 proj: N = 96
+        RS_F32(192, 12, 1, 3, true)        // stage-2 proj: N = 192, two slices
+        RS_F32(384, 24, 1, 3, false)       // stage-1 fc2 (N = 96) and the first patch-merging reduction (N = 192, two slices)
+#undef RS_F32
+    }
+    set_error("amds_gemm_rowstream: no kernel for K=%d N=%d epi=%d fused_ln=%d", K, N, epi, (int)lnf);
     return AMDS_ERR_INVALID;
 }
 
@@ -229,15 +417,13 @@ extern "C" int amds_gemm_rowstream(const void* A, long lda, const float* ln_gamm
     AMDS_REQUIRE(K == 96 || K == 192 || K == 384, "amds_gemm_rowstream: K=%d must be 96, 192 or 384", K);
     AMDS_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "amds_gemm_rowstream: gamma and beta go together");
     const bool lnf = ln_gamma != nullptr;
-    AMDS_REQUIRE(lda >= K && lda % (lnf ? 4 : 8) == 0 && ldw >= K && ldw % 8 == 0 && ldo % 4 == 0, "amds_gemm_rowstream: bad strides");
-    AMDS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0, "amds_gemm_rowstream: pointers must be 16-byte aligned");
+    AMDS_REQUIRE(lda >= K && lda % (lnf ? 4 : 8) == 0 && ldw >= K && ldw % 8 == 0 && ldo % 2 == 0, "amds_gemm_rowstream: bad strides");
+    AMDS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 3) == 0, "amds_gemm_rowstream: misaligned pointers");
     if (M == 0) return AMDS_OK;
-    EpiArgs ep;
-    ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; ep.pos = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.0f;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);
-    if (dtype == AMDS_F16) return rowstream_dispatch<f16>(A, lda, lnf, W, ldw, M, N, K, epi, ep, ln_gamma, ln_beta, ln_eps, st);
-    if (dtype == AMDS_BF16) return rowstream_dispatch<bf16>(A, lda, lnf, W, ldw, M, N, K, epi, ep, ln_gamma, ln_beta, ln_eps, st);
+    if (dtype == AMDS_F16) return rowstream_dispatch<f16>(A, lda, lnf, W, ldw, M, N, K, epi, out, ldo, bias, ln_gamma, ln_beta, ln_eps, st);
+    if (dtype == AMDS_BF16) return rowstream_dispatch<bf16>(A, lda, lnf, W, ldw, M, N, K, epi, out, ldo, bias, ln_gamma, ln_beta, ln_eps, st);
     set_error("amds_gemm_rowstream: bad dtype %d", dtype);
     return AMDS_ERR_INVALID;
 }
