@@ -256,7 +256,7 @@ typedef struct {
     int n_blocks;
     amds_swin_merge merges[3];
     const float* norm_w; const float* norm_b;
-    const float* mask_lane;                     /* [4][2][2][64][16] fp32 shifted-window masks (-100 * log2e) by window type */
+    const uint64_t* mask_bits;                  /* [4][64] shifted-window masks by window type: bit (kt*2+qt)*16 + r of lane's word = masked (-100) */
 } amds_swin_weights;
 
 size_t amds_swin_workspace_bytes(const amds_swin_cfg* cfg_host, int batch);
@@ -275,7 +275,7 @@ int amds_swin_stem(const uint8_t* tiles, float* x, const float* params, int B, i
 /* (Shifted-)window multi-head attention with relative-position bias (ctranspath.py:510-547, 654-690): tokens stay in
  * raster order, windows of 7x7 are addressed by index arithmetic (roll by -shift), head_dim 32.
  * qkv: act dtype [B*grid^2][ldq] = [q|k|v] x [heads][32]; out: act dtype [B*grid^2][ldo]. */
-int amds_window_attention(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane, const float* mask_lane,
+int amds_window_attention(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane, const uint64_t* mask_bits,
                           int B, int grid, int dim, int heads, int shift, int dtype, void* stream);
 
 /* PatchMerging up to the Linear (ctranspath.py:717-736): x fp32 [B][grid^2][dim] -> LayerNorm(concat of the 2x2 cell

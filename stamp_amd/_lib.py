@@ -53,7 +53,7 @@ class SwinMerge(C.Structure):
 
 class SwinWeights(C.Structure):
     _fields_ = [("stem", C.c_void_p), ("blocks_host", C.POINTER(SwinBlock)), ("n_blocks", C.c_int),
-                ("merges", SwinMerge * 3), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("mask_lane", C.c_void_p)]
+                ("merges", SwinMerge * 3), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("mask_bits", C.c_void_p)]
 
 
 class GapWeights(C.Structure):

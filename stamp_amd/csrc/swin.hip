@@ -11,6 +11,7 @@
 //   merge  : gather 2x2 cells + LayerNorm(4C) (one kernel) | x' = . Wred^T (GEMM, fp32 out)
 //   head   : LayerNorm + mean over tokens (one kernel) -> fp16 (".half()" of the reference loop) and/or fp32
 #include "common.h"
+#include <stdlib.h>
 
 namespace amds {
 
@@ -131,150 +132,182 @@ __global__ void __launch_bounds__(256) swin_stem_kernel(const uint8_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Window attention (ctranspath.py:510-547 inside :654-690).  One wave = one (tile, window, head): 49 tokens, head_dim 32.
+// Window attention (ctranspath.py:510-547 inside :654-690).  A wave owns ONE HEAD for the whole launch and walks over
+// (tile, window) pairs; per window: 49 tokens, head_dim 32.
 //   S^T = K Q^T by MFMA 32x32x16 with the K and Q fragments loaded straight from the packed qkv rows (the 16-byte
 //   fragment of a lane IS a contiguous piece of one token row) -> a lane owns one query column and 16 keys per tile;
-//   s*scale*log2e + bias (dense per-lane table: rel-pos bias*log2e, -30000 on the 15 pad keys) + shift mask (-100*log2e
-//   where the region labels differ, per-lane table by window type) -> exp2 softmax (row reductions = 16 in-lane values
-//   + one cross-half shuffle) -> P (already the MFMA B operand) times V^T staged through LDS.
+//   s*scale*log2e + bias (dense per-lane table of the wave's head, rel-pos bias*log2e with -30000 on the 15 pad keys,
+//   loaded ONCE into 64 registers) + shift mask (-100*log2e where the region labels differ: one 64-bit word per lane
+//   and window type, bit = tile*16 + r) -> exp2 softmax (row reductions = 16 in-lane values + one cross-half shuffle)
+//   -> P (already the MFMA B operand) times V^T staged through a wave-private LDS image.
+//   Output: the two half-waves exchange 8-byte pieces so that every lane stores 16 contiguous bytes.
 // qkv: [rows][ldq] act dtype, columns [q | k | v] x [head][32]; out: [rows][ldo], columns [head][32].
-// bias_lane: [heads][kt 2][qt 2][lane 64][r 16] fp32;  mask_lane: [type 4][2][2][64][16] fp32 (type 0 unused).
+// bias_lane: [heads][kt 2][qt 2][lane 64][r 16] fp32;  mask_bits: [type 4][lane 64] u64 (type 0 = no mask).
+// Measured steps on the one-(window,head)-per-wave first version (256 tiles, stage 1, 195 us): bias loads 59 us,
+// 8-byte output stores 39 us, V^T staging 23 us, everything else 76 us.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) swin_wattn_kernel(const T* __restrict__ qkv, long ldq, T* __restrict__ out, long ldo,
-                                                         const float* __restrict__ bias_lane, const float* __restrict__ mask_lane,
-                                                         int G, int C, int heads, int shift, float scale_l2, int nunits) {
+                                                         const float* __restrict__ bias_lane, const unsigned long long* __restrict__ mask_bits,
+                                                         int G, int C, int heads, int shift, float scale_l2, int nwin_total, int nslots) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     __shared__ __attribute__((aligned(16))) char smem[4 * SW_VT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    int unit = blockIdx.x * 4 + wave;
-    const bool live = unit < nunits;
-    if (!live) unit = nunits - 1;
+    const int wid = blockIdx.x * 4 + wave;
+    const int h = wid % heads, slot = wid / heads;
     const int nwin_side = G / SW_WS, nW = nwin_side * nwin_side;
-    const int h = unit % heads, wi = (unit / heads) % nW, b = unit / (heads * nW);
-    const int wh = wi / nwin_side, ww = wi - wh * nwin_side;
-    auto token_row = [&](int p) -> long {
-        const int i = p / SW_WS, j = p - i * SW_WS;
-        int hh = wh * SW_WS + i + shift, wc = ww * SW_WS + j + shift;
-        hh = hh >= G ? hh - G : hh;
-        wc = wc >= G ? wc - G : wc;
-        return (long)b * G * G + (long)hh * G + wc;
-    };
-    const long row0 = token_row(l31), row1 = token_row(min(32 + l31, SW_N - 1));
-    const T* r0p = qkv + row0 * ldq + h * SW_HD + hi * 8;
-    const T* r1p = qkv + row1 * ldq + h * SW_HD + hi * 8;
-    vec8 qf[2][2], kf[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        qf[0][ks] = *reinterpret_cast<const vec8*>(r0p + ks * 16);
-        qf[1][ks] = *reinterpret_cast<const vec8*>(r1p + ks * 16);
-        kf[0][ks] = *reinterpret_cast<const vec8*>(r0p + C + ks * 16);
-        kf[1][ks] = *reinterpret_cast<const vec8*>(r1p + C + ks * 16);
-    }
-    // V^T image: lane = key
+    char* vt = smem + wave * SW_VT_BYTES;
+    // the head's bias table, in accumulator order
+    f32x4 bl[4][4];
     {
-        char* vt = smem + wave * SW_VT_BYTES;
-        vec8 vv[4];
-        const bool kv = lane < SW_N;
-        const T* vp = qkv + token_row(kv ? lane : SW_N - 1) * ldq + 2 * C + h * SW_HD;
+        const float* bp = bias_lane + ((size_t)h * 4 * 64 + lane) * 16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) vv[c] = *reinterpret_cast<const vec8*>(vp + c * 8);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bl[t][g] = *reinterpret_cast<const f32x4*>(bp + (size_t)t * 64 * 16 + g * 4);
+    }
+    const int p0 = l31, p1 = min(32 + l31, SW_N - 1), pv = min(lane, SW_N - 1);
+    const int i0 = p0 / SW_WS, j0 = p0 - i0 * SW_WS, i1 = p1 / SW_WS, j1 = p1 - i1 * SW_WS, iv = pv / SW_WS, jv = pv - iv * SW_WS;
+    const bool kvalid = lane < SW_N;
+    for (int step = 0, base = 0; base < nwin_total; ++step, base += nslots) {
+        // every step covers the contiguous window range [base, base + nslots).  Shifted layers rotate the assignment inside
+        // it by 37 per step so that the (slower) masked border windows do not always hit the same waves: measured at
+        // 256 tiles, stage 1: 216 -> 202 us; un-shifted layers keep a fixed window position per wave (166 vs 185 us rotated)
+        int idx = slot + (shift > 0 ? step * 37 : 0);
+        idx -= (idx / nslots) * nslots;
+        const int win = base + idx;
+        if (win >= nwin_total) break;
+        const int b = win / nW, wi = win - b * nW;
+        const int wh = wi / nwin_side, ww = wi - wh * nwin_side;
+        auto token_row = [&](int i, int j) -> long {
+            int hh = wh * SW_WS + i + shift, wc = ww * SW_WS + j + shift;
+            hh = hh >= G ? hh - G : hh;
+            wc = wc >= G ? wc - G : wc;
+            return (long)b * G * G + (long)hh * G + wc;
+        };
+        const long row0 = token_row(i0, j0), row1 = token_row(i1, j1);
+        const T* r0p = qkv + row0 * ldq + h * SW_HD + hi * 8;
+        const T* r1p = qkv + row1 * ldq + h * SW_HD + hi * 8;
+        vec8 qf[2][2], kf[2][2], vv[4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[0][ks] = *reinterpret_cast<const vec8*>(r0p + ks * 16);
+            qf[1][ks] = *reinterpret_cast<const vec8*>(r1p + ks * 16);
+            kf[0][ks] = *reinterpret_cast<const vec8*>(r0p + C + ks * 16);
+            kf[1][ks] = *reinterpret_cast<const vec8*>(r1p + C + ks * 16);
+        }
+        {
+            const T* vp = qkv + token_row(iv, jv) * ldq + 2 * C + h * SW_HD;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vv[c] = *reinterpret_cast<const vec8*>(vp + c * 8);
+        }
+        const int wtype = shift > 0 ? ((wh == nwin_side - 1) ? 2 : 0) + ((ww == nwin_side - 1) ? 1 : 0) : 0;
+        const unsigned long long mb = mask_bits[wtype * 64 + lane];      // unconditional (type 0 = zeros): a predicated load would
+                                                                         // get a vmcnt(0) at its join and stall the q/k/v requests
+        f32x16 s[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][qt][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) s[kt][qt] = Act<T>::mfma32(kf[kt][ks], qf[qt][ks], s[kt][qt]);
+            }
+        // V^T image (lane = key); the previous window's reads of it are complete (LDS is in order per wave)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<T*>(vt + (c * 8 + e) * SW_VS + lane * 2) = kv ? vv[c][e] : (T)0.f;
-    }
-    f32x16 s[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][qt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) s[kt][qt] = Act<T>::mfma32(kf[kt][ks], qf[qt][ks], s[kt][qt]);
-        }
-    const int wtype = shift > 0 ? ((wh == nwin_side - 1) ? 2 : 0) + ((ww == nwin_side - 1) ? 1 : 0) : 0;
-    const float* bl = bias_lane + ((size_t)h * 4 * 64 + lane) * 16;
-    const float* ml = mask_lane + ((size_t)wtype * 4 * 64 + lane) * 16;
-    float mx[2] = {-3.0e38f, -3.0e38f};
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int tile = kt * 2 + qt;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + (size_t)tile * 64 * 16 + g * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[kt][qt][g * 4 + e] = fmaf(s[kt][qt][g * 4 + e], scale_l2, bv[e]);
-            }
-            if (wtype) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 mv = *reinterpret_cast<const f32x4*>(ml + (size_t)tile * 64 * 16 + g * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[kt][qt][g * 4 + e] += mv[e];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx[qt] = fmaxf(mx[qt], s[kt][qt][r]);
-        }
-    float sum[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
-        float a = 0.f;
+                *reinterpret_cast<T*>(vt + (c * 8 + e) * SW_VS + lane * 2) = kvalid ? vv[c][e] : (T)0.f;
+        float mx[2] = {-3.0e38f, -3.0e38f};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kt][qt][r] - mx[qt]);
-                s[kt][qt][r] = p;
-                a += p;
-            }
-        sum[qt] = a + __shfl_xor(a, 32, 64);
-    }
-    __syncthreads();      // V^T image visible (every wave of the block reaches this point)
-    f32x16 o[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[qt][r] = 0.f;
-    const char* vt = smem + wave * SW_VT_BYTES + l31 * SW_VS + hi * 8;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const vec4 va = *reinterpret_cast<const vec4*>(vt + (32 * kt + 16 * s2) * 2);
-            const vec4 vb = *reinterpret_cast<const vec4*>(vt + (32 * kt + 16 * s2 + 8) * 2);
-            vec8 vf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vf[e] = va[e]; vf[4 + e] = vb[e]; }
-#pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                vec8 pf;
+                const int tile = kt * 2 + qt;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[kt][qt][8 * s2 + e]);
-                o[qt] = Act<T>::mfma32(vf, pf, o[qt]);
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[kt][qt][g * 4 + e] = fmaf(s[kt][qt][g * 4 + e], scale_l2, bl[tile][g][e]);
+                if (wtype) {
+                    const unsigned bits = (unsigned)(mb >> (tile * 16)) & 0xffffu;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kt][qt][r] += ((bits >> r) & 1u) ? -144.26950408889634f : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[qt] = fmaxf(mx[qt], s[kt][qt][r]);
             }
-        }
-    if (!live) return;
+        float sum[2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        if (qt * 32 + l31 < SW_N) {
+        for (int qt = 0; qt < 2; ++qt) {
+            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+            float a = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kt][qt][r] - mx[qt]);
+                    s[kt][qt][r] = p;
+                    a += p;
+                }
+            sum[qt] = a + __shfl_xor(a, 32, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 o[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][r] = 0.f;
+        const char* vr = vt + l31 * SW_VS + hi * 8;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const vec4 va = *reinterpret_cast<const vec4*>(vr + (32 * kt + 16 * s2) * 2);
+                const vec4 vb = *reinterpret_cast<const vec4*>(vr + (32 * kt + 16 * s2 + 8) * 2);
+                vec8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = va[e]; vf[4 + e] = vb[e]; }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    vec8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[kt][qt][8 * s2 + e]);
+                    o[qt] = Act<T>::mfma32(vf, pf, o[qt]);
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        // lane (query l31, half hi) holds d = 8g + 4hi + (0..3).  Exchange so that hi = 0 owns d 0-7 and 16-23, hi = 1 owns
+        // d 8-15 and 24-31: it sends the pieces the other half needs (g = 1,3 from hi = 0; g = 0,2 from hi = 1).
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
             const float inv = 1.0f / sum[qt];
-            T* op = out + (qt ? row1 : row0) * ldo + h * SW_HD + 4 * hi;
+            u32x2 pk[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 vec4 ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = Act<T>::from_f32(o[qt][4 * g + e] * inv);
-                *reinterpret_cast<vec4*>(op + 8 * g) = ov;
+                pk[g] = *reinterpret_cast<u32x2*>(&ov);
+            }
+            u32x4 st[2];
+#pragma unroll
+            for (int pair = 0; pair < 2; ++pair) {
+                const u32x2 keep = hi ? pk[2 * pair + 1] : pk[2 * pair];
+                const u32x2 give = hi ? pk[2 * pair] : pk[2 * pair + 1];
+                u32x2 got;
+                got[0] = __shfl_xor(give[0], 32, 64);
+                got[1] = __shfl_xor(give[1], 32, 64);
+                st[pair] = hi ? u32x4{got[0], got[1], keep[0], keep[1]} : u32x4{keep[0], keep[1], got[0], got[1]};
+            }
+            if (qt * 32 + l31 < SW_N) {
+                T* op = out + (qt ? row1 : row0) * ldo + h * SW_HD + 8 * hi;
+                *reinterpret_cast<u32x4*>(op) = st[0];
+                *reinterpret_cast<u32x4*>(op + 16) = st[1];
             }
         }
     }
@@ -400,15 +433,19 @@ static int swin_plan(const amds_swin_cfg* c, int batch, SwinPlan* p) {
 }
 
 template <typename T>
-static int launch_wattn(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane, const float* mask_lane,
+static int launch_wattn(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane, const unsigned long long* mask_bits,
                         int B, int G, int C, int heads, int shift, hipStream_t st) {
     const int nW = (G / SW_WS) * (G / SW_WS);
-    const long nunits = (long)B * nW * heads;
-    AMDS_REQUIRE(nunits < (1L << 31), "window attention: too many windows");
+    const long nwin = (long)B * nW;
+    AMDS_REQUIRE(nwin * heads < (1L << 31), "window attention: too many windows");
     const float scale_l2 = 0.17677669529663687f * 1.4426950408889634f;    // 32^-0.5 * log2(e)
-    ProfScope prof(PROF_ATTN, 4.0 * nunits * SW_N * SW_N * SW_HD, st);
-    hipLaunchKernelGGL((swin_wattn_kernel<T>), dim3(cdiv(nunits, 4)), dim3(256), 0, st, (const T*)qkv, ldq, (T*)out, ldo,
-                       bias_lane, mask_lane, G, C, heads, shift, scale_l2, (int)nunits);
+    // persistent waves: every wave keeps one head's bias table in registers; ~12 waves per CU
+    int nslots = (256 * 12) / heads;
+    if (nslots > nwin) nslots = (int)nwin;
+    nslots = (nslots + 3) & ~3;                                            // whole workgroups of 4 waves
+    ProfScope prof(PROF_ATTN, 4.0 * nwin * heads * SW_N * SW_N * SW_HD, st);
+    hipLaunchKernelGGL((swin_wattn_kernel<T>), dim3(nslots * heads / 4), dim3(256), 0, st, (const T*)qkv, ldq, (T*)out, ldo,
+                       bias_lane, mask_bits, G, C, heads, shift, scale_l2, (int)nwin, nslots);
     AMDS_LAUNCH_CHECK("swin_wattn_kernel");
     return AMDS_OK;
 }
@@ -433,18 +470,18 @@ extern "C" int amds_swin_stem(const uint8_t* tiles, float* x, const float* param
 }
 
 extern "C" int amds_window_attention(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane,
-                                     const float* mask_lane, int B, int grid, int dim, int heads, int shift, int dtype,
+                                     const uint64_t* mask_bits, int B, int grid, int dim, int heads, int shift, int dtype,
                                      void* stream) {
-    AMDS_REQUIRE(qkv && out && bias_lane && mask_lane, "amds_window_attention: null pointer");
+    AMDS_REQUIRE(qkv && out && bias_lane && mask_bits, "amds_window_attention: null pointer");
     AMDS_REQUIRE(grid > 0 && grid % SW_WS == 0, "amds_window_attention: grid=%d must be a multiple of 7", grid);
     AMDS_REQUIRE(heads * SW_HD == dim, "amds_window_attention: dim=%d must be heads*32", dim);
     AMDS_REQUIRE(shift >= 0 && shift < SW_WS && (shift == 0 || grid > SW_WS), "amds_window_attention: bad shift=%d for grid=%d", shift, grid);
-    AMDS_REQUIRE(ldq >= 3L * dim && ldq % 8 == 0 && ldo >= dim && ldo % 4 == 0, "amds_window_attention: bad strides");
-    AMDS_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0, "amds_window_attention: misaligned pointers");
+    AMDS_REQUIRE(ldq >= 3L * dim && ldq % 8 == 0 && ldo >= dim && ldo % 8 == 0, "amds_window_attention: bad strides");
+    AMDS_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "amds_window_attention: misaligned pointers");
     if (B <= 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == AMDS_F16) return launch_wattn<f16>(qkv, ldq, out, ldo, bias_lane, mask_lane, B, grid, dim, heads, shift, st);
-    if (dtype == AMDS_BF16) return launch_wattn<bf16>(qkv, ldq, out, ldo, bias_lane, mask_lane, B, grid, dim, heads, shift, st);
+    if (dtype == AMDS_F16) return launch_wattn<f16>(qkv, ldq, out, ldo, bias_lane, reinterpret_cast<const unsigned long long*>(mask_bits), B, grid, dim, heads, shift, st);
+    if (dtype == AMDS_BF16) return launch_wattn<bf16>(qkv, ldq, out, ldo, bias_lane, reinterpret_cast<const unsigned long long*>(mask_bits), B, grid, dim, heads, shift, st);
     set_error("amds_window_attention: bad dtype %d", dtype);
     return AMDS_ERR_INVALID;
 }
@@ -515,7 +552,7 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
             const int shift = (d % 2 == 1 && G > SW_WS) ? SW_WS / 2 : 0;
             if (narrow) {
                 AMDS_TRY(amds_gemm_rowstream(x, C, b.ln1_w, b.ln1_b, c->ln_eps, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, st));
-                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_lane, Bc, G, C, c->heads[s], shift, dt, st));
+                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_bits, Bc, G, C, c->heads[s], shift, dt, st));
                 AMDS_TRY(amds_gemm_rowstream(h, C, nullptr, nullptr, 0.f, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, st));
                 AMDS_TRY(amds_gemm_rowstream(x, C, b.ln2_w, b.ln2_b, c->ln_eps, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, st));
                 if (4 * C == 384)
@@ -525,7 +562,7 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
             } else {
                 AMDS_TRY(amds_layernorm(x, C, b.ln1_w, b.ln1_b, h, C, M, C, c->ln_eps, dt, st));
                 AMDS_TRY(amds_gemm(h, C, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
-                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_lane, Bc, G, C, c->heads[s], shift, dt, st));
+                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_bits, Bc, G, C, c->heads[s], shift, dt, st));
                 AMDS_TRY(amds_gemm(h, C, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
                 AMDS_TRY(amds_layernorm(x, C, b.ln2_w, b.ln2_b, h, C, M, C, c->ln_eps, dt, st));
                 AMDS_TRY(amds_gemm(h, C, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
@@ -552,7 +589,7 @@ extern "C" int amds_swin_forward(const amds_swin_cfg* cfg_host, const amds_swin_
                                  void* feats_f16, float* feats_f32, int B, int chunk, void* ws, size_t ws_bytes, void* stream) {
     AMDS_REQUIRE(cfg_host && w_host && tiles && (feats_f16 || feats_f32) && ws, "amds_swin_forward: null pointer");
     AMDS_REQUIRE(B >= 0 && chunk > 0, "amds_swin_forward: bad B=%d chunk=%d", B, chunk);
-    AMDS_REQUIRE(w_host->stem && w_host->blocks_host && w_host->norm_w && w_host->norm_b && w_host->mask_lane, "amds_swin_forward: incomplete weights");
+    AMDS_REQUIRE(w_host->stem && w_host->blocks_host && w_host->norm_w && w_host->norm_b && w_host->mask_bits, "amds_swin_forward: incomplete weights");
     SwinPlan pl;
     int rc = swin_plan(cfg_host, chunk, &pl);
     if (rc != AMDS_OK) return rc;

@@ -213,14 +213,15 @@ def swin_stem(tiles: torch.Tensor, params: torch.Tensor, embed: int = 96, eps: f
     return x
 
 
-def window_attention(qkv: torch.Tensor, bias_lane: torch.Tensor, mask_lane: torch.Tensor, B: int, grid: int, heads: int,
+def window_attention(qkv: torch.Tensor, bias_lane: torch.Tensor, mask_bits: torch.Tensor, B: int, grid: int, heads: int,
                      shift: int) -> torch.Tensor:
     """qkv [B*grid^2, 3*heads*32] (raster token order) -> [B*grid^2, heads*32]."""
-    _dev(qkv, bias_lane, mask_lane)
+    _dev(qkv, bias_lane, mask_bits)
+    assert mask_bits.dtype == torch.int64 and mask_bits.shape == (4, 64)
     dim = heads * 32
     assert qkv.is_contiguous() and qkv.shape == (B * grid * grid, 3 * dim)
     out = torch.empty(B * grid * grid, dim, dtype=qkv.dtype, device=qkv.device)
-    _lib.check(_lib.lib().amds_window_attention(_p(qkv), 3 * dim, _p(out), dim, _p(bias_lane), _p(mask_lane), B, grid, dim,
+    _lib.check(_lib.lib().amds_window_attention(_p(qkv), 3 * dim, _p(out), dim, _p(bias_lane), _p(mask_bits), B, grid, dim,
                                                 heads, shift, act_code(qkv.dtype), _stream()), "window_attention")
     return out
 

@@ -144,19 +144,30 @@ def rel_bias_lane_table(table: torch.Tensor) -> torch.Tensor:
 
 
 def shift_mask_lane_table() -> torch.Tensor:
-    """[4][2][2][64][16] fp32: -100 * log2(e) where query and key of a shifted window carry different region labels
-    (ctranspath.py:620-645).  Window type = 2*(last window row) + (last window column); inside such a window the
-    label along an axis is 1 for in-window offsets 0..3 and 2 for 4..6 (the rows that were rolled around)."""
+    """[4][2][2][64][16] bool: True where query and key of a shifted window carry different region labels, i.e. where
+    the reference adds -100 (ctranspath.py:620-645).  Window type = 2*(last window row) + (last window column); inside
+    such a window the label along an axis is 1 for in-window offsets 0..3 and 2 for 4..6 (the rows rolled around)."""
     key, query = _lane_key_query()
     k, q = key.clamp(max=48), query.clamp(max=48)
-    out = torch.zeros(4, 2, 2, 64, 16, dtype=torch.float64)
+    out = torch.zeros(4, 2, 2, 64, 16, dtype=torch.bool)
     for typ in range(4):
         def lab(p):
             lh = (1 + (p // 7 >= 4).long()) if typ & 2 else torch.zeros_like(p)
             lw = (1 + (p % 7 >= 4).long()) if typ & 1 else torch.zeros_like(p)
             return 3 * lh + lw
-        out[typ] = torch.where(lab(q) != lab(k), -100.0 * LOG2E, 0.0)
-    return out.float().contiguous()
+        out[typ] = lab(q) != lab(k)
+    return out
+
+
+def shift_mask_bits() -> torch.Tensor:
+    """The same masks packed for `amds_window_attention`: int64 [4][64], bit (kt*2+qt)*16 + r of a lane's word."""
+    m = shift_mask_lane_table().long()                       # [4][kt][qt][lane][r]
+    w = (1 << torch.arange(16, dtype=torch.int64)).view(1, 1, 1, 1, 16)
+    per_tile = (m * w).sum(-1)                               # [4][2][2][64]
+    sh = (torch.arange(2).view(2, 1) * 2 + torch.arange(2).view(1, 2)) * 16
+    bits = (per_tile << sh.view(1, 2, 2, 1)).sum(dim=(1, 2))
+    # reinterpret as signed 64-bit (bit 63 may be set)
+    return bits.contiguous()
 
 
 def pack_stem_params(sd: dict[str, torch.Tensor], cfg: SwinConfig, eps_bn: float = 1e-5) -> torch.Tensor:
@@ -210,7 +221,7 @@ class HipSwin(torch.nn.Module):
 
         sd = state_dict
         self.stem = f32(pack_stem_params(sd, cfg))
-        self.mask_lane = f32(shift_mask_lane_table())
+        self.mask_bits = shift_mask_bits().to(dev)
         nblk = sum(cfg.depths)
         blocks = (_lib.SwinBlock * nblk)()
         i = 0
@@ -239,7 +250,7 @@ class HipSwin(torch.nn.Module):
         hds = (C.c_int * 4)(*(list(cfg.heads) + [0] * (4 - len(cfg.heads))))
         self._cfg_c = _lib.SwinCfg(cfg.img, cfg.embed, len(cfg.depths), dep, hds, ops.act_code(act_dtype), 1e-5)
         self._w_c = _lib.SwinWeights(self.stem.data_ptr(), C.cast(blocks, C.POINTER(_lib.SwinBlock)), nblk, merges,
-                                     self.norm_w.data_ptr(), self.norm_b.data_ptr(), self.mask_lane.data_ptr())
+                                     self.norm_w.data_ptr(), self.norm_b.data_ptr(), self.mask_bits.data_ptr())
         torch.cuda.synchronize(dev)
 
     def _as_u8_hwc(self, tiles: torch.Tensor) -> torch.Tensor:
@@ -287,4 +298,4 @@ class HipSwin(torch.nn.Module):
 
 
 __all__ = ["SwinConfig", "SWIN_PRESETS", "HipSwin", "random_swin_state_dict", "swin_param_shapes",
-           "rel_bias_lane_table", "shift_mask_lane_table", "pack_stem_params"]
+           "rel_bias_lane_table", "shift_mask_lane_table", "shift_mask_bits", "pack_stem_params"]

@@ -107,7 +107,7 @@ def test_swin_lane_tables_reproduce_dense_bias_and_mask():
     amds_window_attention) must be a pure re-indexing of the dense tensors the reference builds
     (ctranspath.py:478-496, 620-645), which the oracle restates."""
     from oracle import swin_ctranspath as osw
-    from stamp_amd.swin import LOG2E, _lane_key_query, rel_bias_lane_table, shift_mask_lane_table
+    from stamp_amd.swin import LOG2E, _lane_key_query, rel_bias_lane_table, shift_mask_bits, shift_mask_lane_table
 
     table = torch.randn(169, 6, generator=torch.Generator().manual_seed(0))
     dense = table[osw.rel_pos_index().reshape(-1)].reshape(49, 49, 6).permute(2, 0, 1)       # [h][q][k]
@@ -127,9 +127,18 @@ def test_swin_lane_tables_reproduce_dense_bias_and_mask():
         for wh, ww in ((0, 0), (n - 1, 0), (0, n - 1), (n - 1, n - 1)):
             typ = 2 * (wh == n - 1) + (ww == n - 1)
             l = lab[wh * n + ww]
-            want = torch.where(l[:, None] != l[None, :], -100.0, 0.0)                          # [q][k]
-            assert torch.allclose(masks[typ][ok] / LOG2E, want[query[ok], key[ok]], atol=1e-5)
-    assert (masks[0] == 0).all()
+            want = l[:, None] != l[None, :]                                                     # [q][k]: reference adds -100
+            assert torch.equal(masks[typ][ok], want[query[ok], key[ok]])
+    assert not masks[0].any()
+    # the packed words the kernel reads: bit (kt*2+qt)*16 + r of lane's 64-bit word
+    bits = shift_mask_bits()
+    assert bits.shape == (4, 64) and bits.dtype == torch.int64
+    for typ in range(4):
+        for kt in range(2):
+            for qt in range(2):
+                for r in (0, 5, 15):
+                    got = (bits[typ] >> ((kt * 2 + qt) * 16 + r)) & 1
+                    assert torch.equal(got.bool(), masks[typ, kt, qt, :, r])
 
 
 def test_swin_flops_and_state_dict_shapes():

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from oracle import swin_ctranspath as osw
 from stamp_amd import _lib, ops
 from stamp_amd.swin import (SWIN_PRESETS, HipSwin, pack_stem_params, random_swin_state_dict, rel_bias_lane_table,
-                            shift_mask_lane_table)
+                            shift_mask_bits)
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).parent / "golden"
@@ -66,7 +66,7 @@ def test_window_attention(gpu, grid, heads, shift, dt):
     qkv = (torch.randn(B * grid * grid, 3 * heads * 32, generator=g) * 1.5).to(dt)
     table = torch.randn(169, heads, generator=g)
     ref = _window_attention_ref(qkv.float(), table, B, grid, heads, shift)
-    got = ops.window_attention(qkv.to(gpu), rel_bias_lane_table(table).to(gpu), shift_mask_lane_table().to(gpu), B, grid,
+    got = ops.window_attention(qkv.to(gpu), rel_bias_lane_table(table).to(gpu), shift_mask_bits().to(gpu), B, grid,
                                heads, shift)
     tol = 2e-3 if dt == torch.float16 else 1.2e-2        # P and the output are rounded to the operand type
     assert _rel(got.cpu().float(), ref) < tol, _rel(got.cpu().float(), ref)
