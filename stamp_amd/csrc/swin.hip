@@ -30,23 +30,23 @@ constexpr int SW_VT_BYTES = SW_HD * SW_VS;       // per wave
 template <int C0>
 __global__ void __launch_bounds__(256) swin_stem_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ x,
                                                         const float* __restrict__ prm, int S, int G, float eps) {
+    // Work split: a lane owns a pixel, a wave owns a channel group, so every weight is wave-uniform and is fetched by
+    // scalar loads straight into SGPR operands of the FMAs (no LDS copy of the weights, one LDS read of the input per
+    // 6-24 FMAs).  v1 (weights in LDS, one output element per thread, 2 LDS reads per FMA): 536 us per 256 tiles.
     constexpr int C1 = C0 / 8, C2 = C0 / 4, R = 7, R1 = 2 * R + 1, R0 = 4 * R + 3;
     constexpr int N_W1 = 27 * C1, N_W2 = 9 * C1 * C2, N_W3 = C2 * C0;
+    constexpr int G1 = C1 / 4, G2 = C2 / 4, G3 = C0 / 4;       // channels per wave in conv1 / conv2 / conv1x1
     __shared__ float s_in[R0 * R0 * 3];
     __shared__ float s_c1[R1 * R1 * C1];
     __shared__ float s_c2[R * R * C2];
-    __shared__ float s_w1[N_W1 + C1];
-    __shared__ float s_w2[N_W2 + C2];
-    __shared__ float s_w3[N_W3 + C0];
-    const int tid = threadIdx.x;
+    __shared__ float s_red[2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
-    const float* p_w1 = prm + 8;
-    const float* p_w2 = p_w1 + N_W1 + C1;
-    const float* p_w3 = p_w2 + N_W2 + C2;
-    const float* p_ln = p_w3 + N_W3 + C0;
-    for (int i = tid; i < N_W1 + C1; i += 256) s_w1[i] = p_w1[i];
-    for (int i = tid; i < N_W2 + C2; i += 256) s_w2[i] = p_w2[i];
-    for (int i = tid; i < N_W3 + C0; i += 256) s_w3[i] = p_w3[i];
+    const float* __restrict__ p_w1 = prm + 8;
+    const float* __restrict__ p_w2 = p_w1 + N_W1 + C1;
+    const float* __restrict__ p_w3 = p_w2 + N_W2 + C2;
+    const float* __restrict__ p_ln = p_w3 + N_W3 + C0;
     const float na0 = prm[0], na1 = prm[1], na2 = prm[2], nb0 = prm[3], nb1 = prm[4], nb2 = prm[5];
     const uint8_t* tile = tiles + (size_t)b * S * S * 3;
     const int y00 = 4 * R * by - 3, x00 = 4 * R * bx - 3;
@@ -60,72 +60,87 @@ __global__ void __launch_bounds__(256) swin_stem_kernel(const uint8_t* __restric
         s_in[i * 3 + 0] = v0; s_in[i * 3 + 1] = v1; s_in[i * 3 + 2] = v2;
     }
     __syncthreads();
-    // conv1 + BN + ReLU on the (2R+1)^2 halo region
+    // conv1 + BN + ReLU on the (2R+1)^2 halo region: wave = 3 output channels, lane = pixel (4 passes of 64)
     const int S1 = S / 2;
-    for (int o = tid; o < R1 * R1 * C1; o += 256) {
-        const int co = o % C1, pix = o / C1, ly = pix / R1, lx = pix - ly * R1;
+    for (int pix = lane; pix < R1 * R1; pix += 64) {
+        const int ly = pix / R1, lx = pix - ly * R1;
         const int y1 = 2 * R * by - 1 + ly, x1 = 2 * R * bx - 1 + lx;
-        float acc = 0.f;
-        if (y1 >= 0 && y1 < S1 && x1 >= 0 && x1 < S1) {
-            acc = s_w1[N_W1 + co];
+        float acc[G1];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int c = 0; c < G1; ++c) acc[c] = p_w1[N_W1 + wave * G1 + c];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float* in = &s_in[((2 * ly + ky) * R0 + 2 * lx + kx) * 3];
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int ci = 0; ci < 3; ++ci) acc = fmaf(in[ci], s_w1[(ci * 9 + ky * 3 + kx) * C1 + co], acc);
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* in = &s_in[((2 * ly + ky) * R0 + 2 * lx + kx) * 3];
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float a = in[ci];
+#pragma unroll
+                    for (int c = 0; c < G1; ++c) acc[c] = fmaf(a, p_w1[(ci * 9 + ky * 3 + kx) * C1 + wave * G1 + c], acc[c]);
                 }
-            acc = fmaxf(acc, 0.f);
-        }
-        s_c1[pix * C1 + co] = acc;
+            }
+        const bool inside = y1 >= 0 && y1 < S1 && x1 >= 0 && x1 < S1;
+#pragma unroll
+        for (int c = 0; c < G1; ++c) s_c1[pix * C1 + wave * G1 + c] = inside ? fmaxf(acc[c], 0.f) : 0.f;
     }
     __syncthreads();
-    // conv2 + BN + ReLU
-    for (int o = tid; o < R * R * C2; o += 256) {
-        const int co = o % C2, pix = o / C2, oy = pix / R, ox = pix - oy * R;
-        float acc = s_w2[N_W2 + co];
+    // conv2 + BN + ReLU: wave = 6 output channels, lane = one of the 49 output pixels
+    {
+        const int pix = lane < R * R ? lane : R * R - 1;
+        const int oy = pix / R, ox = pix - oy * R;
+        float acc[G2];
+#pragma unroll
+        for (int c = 0; c < G2; ++c) acc[c] = p_w2[N_W2 + wave * G2 + c];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const float* in = &s_c1[((2 * oy + ky) * R1 + 2 * ox + kx) * C1];
 #pragma unroll
-                for (int ci = 0; ci < C1; ++ci) acc = fmaf(in[ci], s_w2[(ci * 9 + ky * 3 + kx) * C2 + co], acc);
+                for (int ci = 0; ci < C1; ++ci) {
+                    const float a = in[ci];
+#pragma unroll
+                    for (int c = 0; c < G2; ++c) acc[c] = fmaf(a, p_w2[(ci * 9 + ky * 3 + kx) * C2 + wave * G2 + c], acc[c]);
+                }
             }
-        s_c2[pix * C2 + co] = fmaxf(acc, 0.f);
+        if (lane < R * R) {
+#pragma unroll
+            for (int c = 0; c < G2; ++c) s_c2[pix * C2 + wave * G2 + c] = fmaxf(acc[c], 0.f);
+        }
     }
     __syncthreads();
-    // conv1x1 + bias, LayerNorm over C0: 4 lanes per token, C0/4 channels each
-    constexpr int PER = C0 / 4;
-    const int t = tid >> 2, q = tid & 3;
-    const int tt = t < R * R ? t : R * R - 1;
-    float v[PER];
+    // conv1x1 + bias: wave = 24 output channels, lane = token; LayerNorm statistics reduce across the 4 waves through LDS
+    const int t = lane < R * R ? lane : R * R - 1;
+    float v[G3];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) v[k] = s_w3[N_W3 + q * PER + k];
+    for (int k = 0; k < G3; ++k) v[k] = p_w3[N_W3 + wave * G3 + k];
+#pragma unroll 4
     for (int ci = 0; ci < C2; ++ci) {
-        const float a = s_c2[tt * C2 + ci];
+        const float a = s_c2[t * C2 + ci];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) v[k] = fmaf(a, s_w3[ci * C0 + q * PER + k], v[k]);
+        for (int k = 0; k < G3; ++k) v[k] = fmaf(a, p_w3[ci * C0 + wave * G3 + k], v[k]);
     }
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) s += v[k];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-    const float mean = s * (1.0f / C0);
+    for (int k = 0; k < G3; ++k) s += v[k];
+    s_red[0][wave][lane] = s;
+    __syncthreads();
+    const float mean = (s_red[0][0][lane] + s_red[0][1][lane] + s_red[0][2][lane] + s_red[0][3][lane]) * (1.0f / C0);
     float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { const float d = v[k] - mean; ss = fmaf(d, d, ss); }
-    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
-    const float rstd = rsqrtf(ss * (1.0f / C0) + eps);
-    if (t < R * R) {
+    for (int k = 0; k < G3; ++k) { const float d = v[k] - mean; ss = fmaf(d, d, ss); }
+    s_red[1][wave][lane] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((s_red[1][0][lane] + s_red[1][1][lane] + s_red[1][2][lane] + s_red[1][3][lane]) * (1.0f / C0) + eps);
+    if (lane < R * R) {
         const int oy = t / R, ox = t - oy * R;
-        float* dst = x + ((size_t)b * G * G + (size_t)(R * by + oy) * G + R * bx + ox) * C0 + q * PER;
+        float* dst = x + ((size_t)b * G * G + (size_t)(R * by + oy) * G + R * bx + ox) * C0 + wave * G3;
 #pragma unroll
-        for (int k = 0; k < PER; k += 4) {
+        for (int k = 0; k < G3; k += 4) {
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaf((v[k + e] - mean) * rstd, p_ln[q * PER + k + e], p_ln[C0 + q * PER + k + e]);
+            for (int e = 0; e < 4; ++e) o[e] = fmaf((v[k + e] - mean) * rstd, p_ln[wave * G3 + k + e], p_ln[C0 + wave * G3 + k + e]);
             *reinterpret_cast<f32x4*>(dst + k) = o;
         }
     }
