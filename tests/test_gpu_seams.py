@@ -76,3 +76,24 @@ def test_extractor_seam(gpu):
         u8_tile_transform(np.zeros((224, 224), dtype=np.uint8))
     with pytest.raises(ValueError):
         model(torch.zeros(2, 100, 100, 3, dtype=torch.uint8, device=gpu))      # wrong tile size: an exception, not abort()
+
+
+def test_ctranspath_extractor_seam(gpu):
+    """`hip_ctranspath_extractor` = the reference's ctranspath()/chief_ctranspath() factories with the HIP model."""
+    from oracle.swin_ctranspath import swin_encode_f16
+    from stamp_amd.extractor import Extractor, extract_tiles, hip_ctranspath_extractor
+    from stamp_amd.swin import SWIN_PRESETS, random_swin_state_dict
+
+    cfg = SWIN_PRESETS["test_swin_tiny"]
+    sd = random_swin_state_dict(cfg, seed=21)
+    ex = hip_ctranspath_extractor(sd, identifier="chief-ctranspath", cfg=cfg, device=gpu, chunk=4)
+    assert isinstance(ex, Extractor) and ex.identifier == "chief-ctranspath"
+    rng = np.random.default_rng(1)
+    tiles = torch.stack([ex.transform(rng.integers(0, 256, (cfg.img, cfg.img, 3), dtype=np.uint8)) for _ in range(9)])
+    model = ex.model.to(gpu).eval()
+    with torch.inference_mode():
+        feats = model(tiles.to(gpu)).detach().half().cpu()
+    ref = swin_encode_f16(tiles, sd, cfg)
+    assert feats.shape == (9, cfg.out_dim) and ((feats.float() - ref.float()).norm() / ref.float().norm()).item() < 1.5e-3
+    assert torch.equal(extract_tiles(ex, tiles, batch_size=5, device=gpu), feats)
+    assert extract_tiles(ex, tiles[:0], device=gpu).shape == (0, cfg.out_dim)
