@@ -112,6 +112,13 @@ int amds_gemm_rowstream(const void* A, long lda, const float* ln_gamma, const fl
                         const void* W, long ldw, int M, int N, int K, int dtype, int epi, void* out, long ldo,
                         const float* bias, void* stream);
 
+/* The whole MLP branch of a 96-channel Swin block in one pass over the fp32 residual stream x [M][96]:
+ *   x += fc2(gelu(fc1(LayerNorm(x))))        (reference ctranspath.py:693-695 with _Mlp :355-383; hidden width 384)
+ * fc1_w [384][96], fc2_w [96][384] act dtype (row-major, unpadded), biases and LayerNorm parameters fp32.  Both weight
+ * matrices stay in LDS; the hidden activation only ever exists in MFMA registers. */
+int amds_swin_mlp96(float* x, int M, const void* fc1_w, const float* fc1_b, const void* fc2_w, const float* fc2_b,
+                    const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream);
+
 /* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default; 0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64
  * staggered two-group pipeline (production), 3 = its BK=32 variant, 7 = four-wave 128x128-wave-tile variant). */
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_ex": (_i, [_i, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_rowstream": (_i, [_vp, _l, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp]),
+    "amds_swin_mlp96": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
     "amds_pack_swiglu_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "amds_attention_vit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

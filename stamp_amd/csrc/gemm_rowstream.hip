@@ -22,6 +22,7 @@
 //     any MFMA, and become the accumulators' initial value; the next row group's operand rows are requested before
 //     the current group's epilogue.  Each wave keeps 24-48 KB in flight.
 #include "gemm_kernel.h"
+#include <stdlib.h>
 
 namespace amds {
 
@@ -331,6 +332,122 @@ __global__ void __launch_bounds__(64 * RS_WAVES) rowstream_f32out_kernel(const T
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole MLP branch of a 96-channel Swin block in one pass over the residual stream (ctranspath.py:693-695, _Mlp :355-383):
+//     x += W2 gelu(W1 LN(x) + b1) + b2          x fp32 [M][96], hidden 384
+// Both weight matrices live in LDS in MFMA fragment order (72 KB each).  The 384-wide hidden activation never exists in
+// memory: GEMM 1 runs with W1 as the A operand, so its accumulator holds (lane = row, registers = 32 hidden units);
+// after bias + GELU the 16 registers, rounded to the operand type, ARE the A operand of GEMM 2 for two k-steps (the
+// contraction index of an MFMA may be permuted freely as long as both operands agree, and W2's fragments are staged
+// with that permutation) -- A and B operand layouts are symmetric, so GEMM 2 (h as A, W2 as B) ends with
+// (lane = output channel, register = row): coalesced 128-byte row segments for the residual read-modify-write.
+// HBM traffic: one read and one write of x (616 MB per 256 tiles) instead of 2.2 GB for LN / fc1 / fc2 kernels.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, bool PF>
+__global__ void __launch_bounds__(64 * RS_WAVES) swin_mlp96_kernel(float* x, int M, const T* __restrict__ W1, const float* __restrict__ b1,
+                                                                   const T* __restrict__ W2, const float* __restrict__ b2,
+                                                                   const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                                   float eps, int groups) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int C = 96, H = 384, KS = 6, NJ = H / 32, NC = C / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w1 = smem;                                   // [NJ][KS][1 KB]
+    char* s_w2 = smem + NJ * KS * 1024;                  // [NC][2*NJ][1 KB]
+    float* s_ln = reinterpret_cast<float*>(s_w2 + NC * 2 * NJ * 1024);   // gamma[96] beta[96]
+    float* s_b1 = s_ln + 2 * C;                          // [384]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    for (int blk = wave; blk < NJ * KS; blk += RS_WAVES) {
+        const int j = blk / KS, ks = blk - j * KS;
+        glds16(W1 + (long)(32 * j + l31) * C + 16 * ks + 8 * hi, s_w1 + blk * 1024);
+    }
+    for (int blk = wave; blk < NC * 2 * NJ; blk += RS_WAVES) {
+        const int cf = blk / (2 * NJ), hs = blk - cf * 2 * NJ;
+        const T* src = W2 + (long)(32 * cf + l31) * H + 16 * hs + 4 * hi;      // slots 0-3: hidden 16hs+4hi.., slots 4-7: +8
+        const vec4 lo = *reinterpret_cast<const vec4*>(src), hi4 = *reinterpret_cast<const vec4*>(src + 8);
+        vec8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi4[e]; }
+        *reinterpret_cast<vec8*>(s_w2 + blk * 1024 + lane * 16) = v;
+    }
+    for (int i = tid; i < C; i += 64 * RS_WAVES) { s_ln[i] = ln_g[i]; s_ln[C + i] = ln_b[i]; }
+    for (int i = tid; i < H; i += 64 * RS_WAVES) s_b1[i] = b1[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float bv[NC];
+#pragma unroll
+    for (int cf = 0; cf < NC; ++cf) bv[cf] = b2[32 * cf + l31];
+
+    const int gstep = gridDim.x * RS_WAVES;
+    const int lane_off = 4 * hi * C + l31;
+    int g = __builtin_amdgcn_readfirstlane(blockIdx.x * RS_WAVES + wave);
+    f32x4 raw[KS][2];
+    vec8 xf[KS];
+    if (PF && g < groups) rs_load_raw<KS>(raw, x, C, min(g * 32 + l31, M - 1), hi);
+    for (; g < groups; g += gstep) {
+        const int row0 = g * 32;
+        const bool full = row0 + 32 <= M;
+        int lds_lane = lane * 16;                         // opaque per iteration: keeps the weight-fragment ds_reads inside the loop
+        asm volatile("" : "+v"(lds_lane));
+        if (!PF) rs_load_raw<KS>(raw, x, C, min(row0 + l31, M - 1), hi);
+        rs_normalise<T, KS>(xf, raw, s_ln, hi, eps);
+        // the accumulators of GEMM 2 start from the residual rows (+ b2); requested before any MFMA
+        f32x16 acc2[NC];
+        if (full) {
+#pragma unroll
+            for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[cf][r] = (x + (long)(row0 + (r & 3) + 8 * (r >> 2)) * C + 32 * cf)[lane_off];
+        } else {
+#pragma unroll
+            for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[cf][r] = x[(long)min(row0 + 4 * hi + (r & 3) + 8 * (r >> 2), M - 1) * C + 32 * cf + l31];
+        }
+        if (PF && g + gstep < groups) rs_load_raw<KS>(raw, x, C, min((g + gstep) * 32 + l31, M - 1), hi);
+#pragma unroll
+        for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[cf][r] += bv[cf];
+#pragma unroll 1
+        for (int j = 0; j < NJ; ++j) {
+            f32x16 acc1;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 32 * j + 8 * g4 + 4 * hi + (lds_lane & 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[4 * g4 + e] = bb[e];
+            }
+            const char* w1p = s_w1 + (size_t)j * KS * 1024 + lds_lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc1 = Act<T>::mfma32(*reinterpret_cast<const vec8*>(w1p + ks * 1024), xf[ks], acc1);
+            vec8 hf[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = gelu_erf_poly2(f32x2{acc1[r], acc1[r + 1]});
+                hf[r >> 3][r & 7] = Act<T>::from_f32(v[0]);
+                hf[r >> 3][(r & 7) + 1] = Act<T>::from_f32(v[1]);
+            }
+            const char* w2p = s_w2 + (size_t)(2 * j) * 1024 + lds_lane;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int cf = 0; cf < NC; ++cf)
+                    acc2[cf] = Act<T>::mfma32(hf[s2], *reinterpret_cast<const vec8*>(w2p + (size_t)(cf * 2 * NJ + s2) * 1024), acc2[cf]);
+        }
+#pragma unroll
+        for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float* ub = x + (long)(row0 + rr) * C + 32 * cf;
+                if (full || row0 + 4 * hi + rr < M) ub[lane_off] = acc2[cf][r];
+            }
+    }
+}
+
 static int rs_slices(int nfrag, int KS) {
     int slices = 1;
     while ((nfrag % slices) != 0 || (size_t)(nfrag / slices) * KS * 1024 > 73728) ++slices;
@@ -426,4 +543,38 @@ extern "C" int amds_gemm_rowstream(const void* A, long lda, const float* ln_gamm
     if (dtype == AMDS_BF16) return rowstream_dispatch<bf16>(A, lda, lnf, W, ldw, M, N, K, epi, out, ldo, bias, ln_gamma, ln_beta, ln_eps, st);
     set_error("amds_gemm_rowstream: bad dtype %d", dtype);
     return AMDS_ERR_INVALID;
+}
+
+extern "C" int amds_swin_mlp96(float* x, int M, const void* fc1_w, const float* fc1_b, const void* fc2_w, const float* fc2_b,
+                               const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream) {
+    AMDS_REQUIRE(x && fc1_w && fc1_b && fc2_w && fc2_b && ln_gamma && ln_beta, "amds_swin_mlp96: null pointer");
+    AMDS_REQUIRE(M >= 0, "amds_swin_mlp96: bad M=%d", M);
+    AMDS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)fc1_w & 15) == 0 && ((uintptr_t)fc2_w & 15) == 0, "amds_swin_mlp96: misaligned pointers");
+    if (M == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(12 * 6 + 3 * 24) * 1024 + (2 * 96 + 384) * 4;
+    const int groups = cdiv(M, 32);
+    int gx = cdiv(groups, RS_WAVES);
+    if (gx > 256) gx = 256;
+    ProfScope prof(PROF_GEMM, 4.0 * M * 96.0 * 384.0, st);
+    static const bool pf = getenv("AMDS_MLP96_PF") ? atoi(getenv("AMDS_MLP96_PF")) != 0 : false;
+#define MLP96_LAUNCH(T)                                                                                                              \
+    do {                                                                                                                             \
+        static bool attr_set = false;                                                                                                \
+        if (!attr_set) {                                                                                                             \
+            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp96_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp96_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                                         \
+        }                                                                                                                            \
+        if (pf) hipLaunchKernelGGL((swin_mlp96_kernel<T, true>), dim3(gx), dim3(64 * RS_WAVES), lds, st, x, M, reinterpret_cast<const T*>(fc1_w), fc1_b, \
+                           reinterpret_cast<const T*>(fc2_w), fc2_b, ln_gamma, ln_beta, ln_eps, groups);                             \
+        else hipLaunchKernelGGL((swin_mlp96_kernel<T, false>), dim3(gx), dim3(64 * RS_WAVES), lds, st, x, M, reinterpret_cast<const T*>(fc1_w), fc1_b, \
+                           reinterpret_cast<const T*>(fc2_w), fc2_b, ln_gamma, ln_beta, ln_eps, groups);                             \
+    } while (0)
+    if (dtype == AMDS_F16) MLP96_LAUNCH(f16);
+    else if (dtype == AMDS_BF16) MLP96_LAUNCH(bf16);
+    else { set_error("amds_swin_mlp96: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+#undef MLP96_LAUNCH
+    AMDS_LAUNCH_CHECK("swin_mlp96_kernel");
+    return AMDS_OK;
 }

@@ -569,11 +569,12 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
                 AMDS_TRY(amds_gemm_rowstream(x, C, b.ln1_w, b.ln1_b, c->ln_eps, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, st));
                 AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_bits, Bc, G, C, c->heads[s], shift, dt, st));
                 AMDS_TRY(amds_gemm_rowstream(h, C, nullptr, nullptr, 0.f, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, st));
-                AMDS_TRY(amds_gemm_rowstream(x, C, b.ln2_w, b.ln2_b, c->ln_eps, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, st));
-                if (4 * C == 384)
-                    AMDS_TRY(amds_gemm_rowstream(big, 4 * C, nullptr, nullptr, 0.f, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, st));
-                else
+                if (C == 96) {        // LN2 + fc1 + GELU + fc2 + residual in one pass, hidden activation in registers only
+                    AMDS_TRY(amds_swin_mlp96(x, M, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, b.ln2_w, b.ln2_b, c->ln_eps, dt, st));
+                } else {
+                    AMDS_TRY(amds_gemm_rowstream(x, C, b.ln2_w, b.ln2_b, c->ln_eps, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, st));
                     AMDS_TRY(amds_gemm(big, 4 * C, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+                }
             } else {
                 AMDS_TRY(amds_layernorm(x, C, b.ln1_w, b.ln1_b, h, C, M, C, c->ln_eps, dt, st));
                 AMDS_TRY(amds_gemm(h, C, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));

@@ -263,3 +263,15 @@ def gemm_rowstream(a: torch.Tensor, w: torch.Tensor, epi: int, *, bias=None, ln_
     _lib.check(_lib.lib().amds_gemm_rowstream(_p(a), a.stride(0), _p(ln_gamma), _p(ln_beta), eps, _p(w), w.stride(0), M, N, K,
                                               act_code(w.dtype), epi, _p(out), out.stride(0), _p(bias), _stream()), "gemm_rowstream")
     return out
+
+
+def swin_mlp96(x: torch.Tensor, fc1_w: torch.Tensor, fc1_b: torch.Tensor, fc2_w: torch.Tensor, fc2_b: torch.Tensor,
+               ln_gamma: torch.Tensor, ln_beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """In place: x += fc2(gelu(fc1(LayerNorm(x)))) for x fp32 [M, 96]."""
+    _dev(x, fc1_w, fc1_b, fc2_w, fc2_b, ln_gamma, ln_beta)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 96
+    assert fc1_w.shape == (384, 96) and fc2_w.shape == (96, 384) and fc1_w.is_contiguous() and fc2_w.is_contiguous()
+    M = x.numel() // 96
+    _lib.check(_lib.lib().amds_swin_mlp96(_p(x), M, _p(fc1_w), _p(fc1_b), _p(fc2_w), _p(fc2_b), _p(ln_gamma), _p(ln_beta), eps,
+                                          act_code(fc1_w.dtype), _stream()), "swin_mlp96")
+    return x

@@ -197,3 +197,21 @@ def test_gemm_rowstream(gpu, K, N, epi, ln, M):
             ref = y
         assert got.dtype == torch.float32
         assert (got.cpu().double() - ref).abs().max().item() < 3e-5 * K ** 0.5
+
+
+@pytest.mark.parametrize("M", [64, 3136 * 3 + 17])
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-4), (torch.bfloat16, 5e-3)])
+def test_swin_mlp96_fused(gpu, M, dt, tol):
+    """x += fc2(gelu(fc1(LN(x)))) in one kernel (hidden activation in MFMA registers) vs fp64 on the same weights."""
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 96, generator=g) * 1.5 + 0.2
+    w1 = (torch.randn(384, 96, generator=g) / 96 ** 0.5).to(dt)
+    w2 = (torch.randn(96, 384, generator=g) * 0.5 / 384 ** 0.5).to(dt)
+    b1, b2 = torch.randn(384, generator=g) * 0.2, torch.randn(96, generator=g) * 0.2
+    gam, bet = 1 + 0.2 * torch.randn(96, generator=g), 0.1 * torch.randn(96, generator=g)
+    h = F.layer_norm(x.double(), (96,), gam.double(), bet.double(), 1e-5)
+    ref = x.double() + F.gelu(h @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    got = ops.swin_mlp96(x.clone().to(gpu), w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu), gam.to(gpu), bet.to(gpu))
+    assert _rel(got.cpu(), ref) < tol, _rel(got.cpu(), ref)
+    # the branch itself (result minus residual) to the same relative tolerance x10: catches a wrong k-permutation
+    assert _rel(got.cpu().double() - x.double(), ref - x.double()) < 10 * tol
