@@ -37,7 +37,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=1020, help="tiles per step per GPU (one virtual slide)")
     ap.add_argument("--chunk", type=int, default=510, help="tiles per internal forward chunk")
-    ap.add_argument("--model", default="vit_large_patch14_224")
+    ap.add_argument("--model", default="vit_large_patch14_224", help="a ViT preset, or ctranspath (ConvStem + Swin-T)")
+    ap.add_argument("--swin-chunk", type=int, default=1024, help="tiles per internal chunk of the CTransPath forward (5.2 MB of workspace per tile)")
     ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--overlap", type=int, default=0, help="1 = two chunks in flight on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +86,7 @@ def main() -> None:
     if is_swin:       # the reference's in-tree tile encoder (ctranspath.py): ConvStem + Swin-T
         cfg = SWIN_PRESETS[a.model]
         sd = random_swin_state_dict(cfg, seed=0)
-        model = HipSwin(cfg, sd, device=ctx.device, act_dtype=act, chunk=min(a.chunk, 256))
+        model = HipSwin(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.swin_chunk)
     else:
         cfg = PRESETS[a.model]
         sd = random_vit_state_dict(cfg, seed=0, init="moderate")
@@ -139,7 +140,7 @@ def main() -> None:
                                ("BASELINE.json configs[1]: ViT-L/14 (dim 1024, depth 24, 16 heads, 257 tokens, GELU MLP, "
                                 "LayerScale) tile extraction on synthetic 224x224x3 u8 tiles resident in HBM, "
                                 "random-init weights, fp16 CLS features out"),
-                   "model": a.model, "tiles_per_step_per_gpu": a.tiles, "chunk": a.chunk,
+                   "model": a.model, "tiles_per_step_per_gpu": a.tiles, "chunk": a.swin_chunk if is_swin else a.chunk,
                    "operands": a.act, "accumulate": "f32", "residual_stream": "f32",
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
@@ -202,7 +203,7 @@ def main() -> None:
                                          "value": round(8 * ctx.world / dt_tm, 1), "finite": bool(torch.isfinite(lg2).all())}
         if not is_swin:     # the reference's in-tree tile encoder, same tile shape
             scfg = SWIN_PRESETS["ctranspath"]
-            sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=256)
+            sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)
             st_tiles = tiles[:1024] if tiles.shape[0] >= 1024 else tiles
             sw(st_tiles)
             torch.cuda.synchronize()

@@ -47,7 +47,7 @@ def hip_vit_extractor(name: str, state_dict: dict[str, torch.Tensor], *, identif
 
 
 def hip_ctranspath_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "ctranspath", cfg: SwinConfig | None = None,
-                             device="cuda", act_dtype=torch.float16, chunk: int = 256) -> Extractor:
+                             device="cuda", act_dtype=torch.float16, chunk: int = 1024) -> Extractor:
     """The reference's `ctranspath()` / `chief_ctranspath()` factories (src/stamp/preprocessing/extractor/ctranspath.py:34-70,
     chief_ctranspath.py:20-57) with the HIP model: `state_dict` is what they pass to `model.load_state_dict`
     (`torch.load("ctranspath.pth")["model"]`, after the sha256 check they do), `identifier` the ExtractorName value

@@ -193,7 +193,7 @@ class HipSwin(torch.nn.Module):
     geometry and is rebuilt here in MFMA lane order."""
 
     def __init__(self, cfg: SwinConfig, state_dict: dict[str, torch.Tensor], device: str | torch.device = "cuda",
-                 act_dtype: torch.dtype = torch.float16, chunk: int = 128):
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 1024):
         super().__init__()
         from . import ops
         self.cfg, self.act_dtype, self.chunk = cfg, act_dtype, int(chunk)
