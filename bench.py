@@ -130,6 +130,15 @@ def main() -> None:
     achieved = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
     total_tiles = a.tiles * a.steps * ctx.world
     value = total_tiles / elapsed
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary of the
+    # two rocprofv3 --pmc passes over this same workload (profiles/r01_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
+    traffic = None
+    pmc_file = ROOT / "profiles" / "r01_pmc_gemm_traffic.json"
+    if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 510 and pmc_file.is_file():
+        try:
+            traffic = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
     line = {
         "metric": "tiles/sec encoded (224x224, ViT-L/14)" if a.model == "vit_large_patch14_224" else f"tiles/sec encoded (224x224, {a.model})", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -148,7 +157,8 @@ def main() -> None:
         "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles in stages 1-2, gemm_8p64_kernel in stages 3-4)" if is_swin else
                                "gemm_8p64_kernel (256x256x64 staggered two-group 8-wave MFMA 32x32x16 pipeline, fused LDS-staged epilogues)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_note": "HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_traffic.json); algorithmic 1.48e9 -> 1.43x (A panels re-fetched across N tiles, served by L2/MALL)" if traffic else None,
                      "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),
                      "avg_gflop_per_launch": round(gflop / max(gn, 1) / 1e9, 2),
                      "time_share": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kinds.items()}},
