@@ -78,6 +78,12 @@ PRESETS: dict[str, ViTConfig] = {
     # tests/test_encoders.py:31, the other hyper-parameters are the public model card's: SURVEY.md F4)
     "virchow2": ViTConfig(dim=1280, depth=32, heads=16, hidden=3416, mlp="swiglu", reg_tokens=4, no_embed_class=False),
     "test_tiny_hd80": ViTConfig(dim=640, depth=2, heads=8, hidden=696, mlp="swiglu", reg_tokens=4, no_embed_class=False),
+    # H-optimus-0 / H-optimus-1 = timm vit_giant_patch14_reg4_dinov2 (reference h_optimus_0.py:15-20, h_optimus_1.py:15-20: the
+    # factory only passes init_values / dynamic_img_size; width 1536, depth 40, 24 heads, SwiGLUPacked 8192 -> 4096, 4 register
+    # tokens, no_embed_class are the timm architecture's published hyper-parameters, checked against the state_dict shapes at
+    # pack time).  Mean / std are in-tree (h_optimus_0.py:26-28).
+    "h_optimus_0": ViTConfig(dim=1536, depth=40, heads=24, hidden=4096, mlp="swiglu", reg_tokens=4, no_embed_class=True,
+                             mean=(0.707223, 0.578729, 0.703617), std=(0.211883, 0.230117, 0.177517)),
     # ViT-L/16 (reference UNI, uni.py:26-31)
     "vit_large_patch16_224": ViTConfig(patch=16),
     # small shapes for tests
