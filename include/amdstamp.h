@@ -228,6 +228,13 @@ int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int pat
 int amds_tile_normalize_u8(const uint8_t* hwc, float* chw, int B, int H, int W,
                            const float mean_host[3], const float std_host[3], void* stream);
 
+/* Tile background filter (reference src/stamp/preprocessing/tiling.py:280-291 `_has_enough_texture`):
+ * frac[b] = mean(cv2.Canny(tile.convert("L"), low, high)) / 255 for u8 HWC tiles [B][S][S][3], S <= 224; the reference keeps
+ * a tile when frac >= canny_cutoff (0.02) with low = 40, high = 100.  edges (u8 [B][S][S], 0/255) and gray (u8 [B][S][S])
+ * are optional outputs for tests.  Grey = Pillow's fixed-point ITU-R 601; Canny = OpenCV aperture 3, L1 magnitude. */
+int amds_tile_edge_fraction_u8(const uint8_t* tiles, float* frac, uint8_t* edges, uint8_t* gray, int B, int S, int low, int high,
+                               void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * CTransPath tile encoder = ConvStem + Swin-T, the reference's in-tree network
  * (src/stamp/preprocessing/extractor/ctranspath.py; factories ctranspath.py:34-70, chief_ctranspath.py:20-57)

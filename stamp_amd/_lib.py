@@ -91,6 +91,7 @@ PROTOTYPES = {
     "amds_window_attention": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "amds_layernorm_meanpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),
     "amds_gather_rows": (_i, [_vp, _l, _vp, _i, _vp, _l, _i, _i, _i, _i, _vp]),

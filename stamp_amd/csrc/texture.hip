@@ -1,0 +1,135 @@
+// texture.hip -- the tile background filter of the reference, `_has_enough_texture`
+// (src/stamp/preprocessing/tiling.py:280-291): tile.convert("L") -> cv2.Canny(gray, 40, 100) -> edges.mean()/255 >= cutoff.
+// Upstream it runs per tile on one DataLoader worker (OpenCV on the host, SURVEY.md row H4: the likely host bottleneck of
+// the feed); here one workgroup owns one tile, the grey image and the edge map live in LDS, nothing but the u8 tile is read
+// and one float per tile is written.
+//   grey  : Pillow's ITU-R 601 fixed point, L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16           (pinned: Pillow is here)
+//   Canny : OpenCV's algorithm for aperture 3, L2gradient = false (third-party, opencv-python 4.13 in the reference's lock
+//           file, NOT installed here -> parity unpinned): Sobel 3x3 with replicated borders, magnitude |dx| + |dy|,
+//           non-maximum suppression with the fixed-point tan(22.5 deg) sector test (TG22 = 13573 / 2^15) and zero magnitude
+//           outside the image, double threshold (m > high: edge; low < m <= high: candidate), 8-connected hysteresis.
+//   The hysteresis fixed point (candidates connected to an edge) does not depend on visiting order, so the stack walk of
+//   the CPU code becomes an in-LDS relaxation that repeats until no pixel changes.
+#include "common.h"
+
+namespace amds {
+
+constexpr int TEX_MAX_S = 224;
+
+__device__ __forceinline__ int tex_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// |dx| + |dy| and the signed derivatives at (y, x), replicated borders
+__device__ __forceinline__ int tex_sobel(const uint8_t* g, int S, int y, int x, int& dx, int& dy) {
+    const int ym = tex_clamp(y - 1, S - 1), yp = tex_clamp(y + 1, S - 1), xm = tex_clamp(x - 1, S - 1), xp = tex_clamp(x + 1, S - 1);
+    const int a = g[ym * S + xm], b = g[ym * S + x], c = g[ym * S + xp];
+    const int d = g[y * S + xm], f = g[y * S + xp];
+    const int p = g[yp * S + xm], q = g[yp * S + x], r = g[yp * S + xp];
+    dx = (c + 2 * f + r) - (a + 2 * d + p);
+    dy = (p + 2 * q + r) - (a + 2 * b + c);
+    return abs(dx) + abs(dy);
+}
+
+__device__ __forceinline__ int tex_mag(const uint8_t* g, int S, int y, int x) {
+    if (y < 0 || y >= S || x < 0 || x >= S) return 0;          // the magnitude plane is zero outside the image
+    int dx, dy;
+    return tex_sobel(g, S, y, x, dx, dy);
+}
+
+__global__ void __launch_bounds__(256) tile_canny_kernel(const uint8_t* __restrict__ tiles, float* __restrict__ frac, uint8_t* __restrict__ edges_out,
+                                                         uint8_t* __restrict__ gray_out, int S, int low, int high) {
+    extern __shared__ uint8_t tex_smem[];
+    uint8_t* g = tex_smem;                 // [S][S] grey
+    uint8_t* m = tex_smem + S * S;         // [S][S] 0 = candidate, 1 = not an edge, 2 = edge
+    __shared__ int s_changed, s_count;
+    const int tid = threadIdx.x, b = blockIdx.x, n = S * S;
+    const uint8_t* t = tiles + (size_t)b * n * 3;
+    for (int i = tid; i < n; i += 256) {
+        const int R = t[3 * i], G = t[3 * i + 1], B = t[3 * i + 2];
+        g[i] = (uint8_t)((19595 * R + 38470 * G + 7471 * B + 0x8000) >> 16);
+    }
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    if (gray_out) for (int i = tid; i < n; i += 256) gray_out[(size_t)b * n + i] = g[i];
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / S, x = i - y * S;
+        int dx, dy;
+        const int mag = tex_sobel(g, S, y, x, dx, dy);
+        uint8_t state = 1;
+        if (mag > low) {
+            const int ax = abs(dx), ay = abs(dy) << 15;
+            const int tg22x = ax * 13573;
+            bool keep;
+            if (ay < tg22x) {
+                keep = mag > tex_mag(g, S, y, x - 1) && mag >= tex_mag(g, S, y, x + 1);
+            } else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) {
+                    keep = mag > tex_mag(g, S, y - 1, x) && mag >= tex_mag(g, S, y + 1, x);
+                } else {
+                    const int s = ((dx ^ dy) < 0) ? -1 : 1;
+                    keep = mag > tex_mag(g, S, y - 1, x - s) && mag > tex_mag(g, S, y + 1, x + s);
+                }
+            }
+            if (keep) state = mag > high ? 2 : 0;
+        }
+        m[i] = state;
+    }
+    __syncthreads();
+    // hysteresis: grow the edge set into 8-connected candidates until nothing changes
+    for (;;) {
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        bool any = false;
+        for (int i = tid; i < n; i += 256) {
+            if (m[i] != 0) continue;
+            const int y = i / S, x = i - y * S;
+            bool hit = false;
+#pragma unroll
+            for (int dyy = -1; dyy <= 1; ++dyy)
+#pragma unroll
+                for (int dxx = -1; dxx <= 1; ++dxx) {
+                    const int yy = y + dyy, xx = x + dxx;
+                    if (yy >= 0 && yy < S && xx >= 0 && xx < S && m[yy * S + xx] == 2) hit = true;
+                }
+            if (hit) { m[i] = 2; any = true; }
+        }
+        if (any) s_changed = 1;
+        __syncthreads();
+        const int ch = s_changed;
+        __syncthreads();
+        if (!ch) break;
+    }
+    int cnt = 0;
+    for (int i = tid; i < n; i += 256) {
+        const bool e = m[i] == 2;
+        cnt += e;
+        if (edges_out) edges_out[(size_t)b * n + i] = e ? 255 : 0;
+    }
+    cnt = (int)wave_sum((float)cnt);
+    if ((tid & 63) == 0) atomicAdd(&s_count, cnt);
+    __syncthreads();
+    if (tid == 0) frac[b] = (float)s_count / (float)n;       // == edges.mean() / 255
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+extern "C" int amds_tile_edge_fraction_u8(const uint8_t* tiles, float* frac, uint8_t* edges, uint8_t* gray, int B, int S, int low, int high,
+                                          void* stream) {
+    AMDS_REQUIRE(B >= 0 && S >= 3 && S <= TEX_MAX_S, "amds_tile_edge_fraction_u8: tile size %d unsupported (3..%d)", S, TEX_MAX_S);
+    AMDS_REQUIRE(low >= 0 && high >= low, "amds_tile_edge_fraction_u8: thresholds low=%d high=%d", low, high);
+    if (B == 0) return AMDS_OK;
+    AMDS_REQUIRE(tiles && frac, "amds_tile_edge_fraction_u8: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * S * S;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_canny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TEX_MAX_S * TEX_MAX_S));
+        attr_set = true;
+    }
+    ProfScope prof(PROF_OTHER, (double)B * S * S * 3, st);
+    hipLaunchKernelGGL(tile_canny_kernel, dim3(B), dim3(256), lds, st, tiles, frac, edges, gray, S, low, high);
+    AMDS_LAUNCH_CHECK("tile_canny_kernel");
+    return AMDS_OK;
+}

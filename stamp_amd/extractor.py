@@ -56,6 +56,13 @@ def hip_ctranspath_extractor(state_dict: dict[str, torch.Tensor], *, identifier:
     return Extractor(model=model, transform=u8_tile_transform, identifier=identifier)
 
 
+def has_enough_texture(tiles_u8: torch.Tensor, cutoff: float = 0.02) -> torch.Tensor:
+    """Batched `_has_enough_texture` (reference src/stamp/preprocessing/tiling.py:280-291) for decoded tiles already on
+    the GPU: bool [B], True = keep (Canny edge fraction >= canny_cutoff; 40 / 100 are the reference's hard-coded thresholds)."""
+    from . import ops
+    return ops.tile_edge_fraction(tiles_u8, 40, 100) >= cutoff
+
+
 @torch.inference_mode()
 def extract_tiles(extractor: Extractor, tiles_u8: torch.Tensor, batch_size: int = 1020, device="cuda") -> torch.Tensor:
     """The reference's per-slide hot loop (preprocessing/__init__.py:322-327) on an in-memory stack of decoded tiles:

@@ -275,3 +275,15 @@ def swin_mlp96(x: torch.Tensor, fc1_w: torch.Tensor, fc1_b: torch.Tensor, fc2_w:
     _lib.check(_lib.lib().amds_swin_mlp96(_p(x), M, _p(fc1_w), _p(fc1_b), _p(fc2_w), _p(fc2_b), _p(ln_gamma), _p(ln_beta), eps,
                                           act_code(fc1_w.dtype), _stream()), "swin_mlp96")
     return x
+
+
+def tile_edge_fraction(tiles: torch.Tensor, low: int = 40, high: int = 100, return_maps: bool = False):
+    """u8 [B,S,S,3] -> fp32 [B] = mean(Canny(grey(tile), low, high)) / 255 (reference tiling.py:280-291)."""
+    _dev(tiles)
+    assert tiles.dtype == torch.uint8 and tiles.is_contiguous() and tiles.dim() == 4 and tiles.shape[-1] == 3 and tiles.shape[1] == tiles.shape[2]
+    B, S = tiles.shape[0], tiles.shape[1]
+    frac = torch.empty(B, dtype=torch.float32, device=tiles.device)
+    edges = torch.empty(B, S, S, dtype=torch.uint8, device=tiles.device) if return_maps else None
+    gray = torch.empty(B, S, S, dtype=torch.uint8, device=tiles.device) if return_maps else None
+    _lib.check(_lib.lib().amds_tile_edge_fraction_u8(_p(tiles), _p(frac), _p(edges), _p(gray), B, S, low, high, _stream()), "tile_edge_fraction")
+    return (frac, edges, gray) if return_maps else frac

@@ -126,3 +126,32 @@ def test_ctranspath_swin(tag, preset):
         np.testing.assert_allclose(v[:, z["tap_idx_" + k]].numpy(), z["tap_" + k], rtol=0, atol=2e-5, err_msg=k)
     np.testing.assert_allclose(feats.numpy(), z["feats"], rtol=0, atol=5e-6)
     assert feats.shape == (z["tiles"].shape[0], cfg.out_dim)
+
+
+def test_texture_gray_matches_pillow_golden():
+    """`tile.convert("L")` (tiling.py:284): fixtures produced by the installed Pillow in tools/make_golden.py."""
+    from oracle import texture
+    z = np.load(G / "texture_gray.npz")
+    assert np.array_equal(texture.gray_L(z["tiles"]), z["gray"])
+
+
+def test_texture_canny_known_answers():
+    """The Canny restatement has no reference vectors (OpenCV is absent: parity unpinned); these are cases whose answer
+    follows from the published algorithm by hand."""
+    from oracle import texture
+    S = 32
+    flat = np.full((S, S), 77, np.uint8)
+    assert texture.canny_l1(flat).sum() == 0
+    step = np.zeros((S, S), np.uint8)
+    step[:, 16:] = 255                      # |dx| = 1020 on columns 15 and 16; NMS (m > left, m >= right) keeps column 15 only
+    e = texture.canny_l1(step)
+    assert (e[:, 15] == 255).all() and e.sum() == 255 * S
+    weak = np.zeros((S, S), np.uint8)
+    weak[:, 16:] = 20                       # |dx| = 80: above low (40), below high (100): candidates without a seed -> nothing
+    assert texture.canny_l1(weak).sum() == 0
+    mixed = weak.copy()
+    mixed[:8, 16:] = 255                    # a strong segment on top: hysteresis walks down the connected weak edge
+    e = texture.canny_l1(mixed)
+    assert (e[:, 15] == 255).sum() >= S - 2 and e[:, 15][-1] == 255
+    rgb = np.stack([step] * 3, -1)
+    assert abs(texture.edge_fraction(rgb) - 1 / S) < 1e-12 and texture.has_enough_texture(rgb, 0.02)

@@ -322,6 +322,18 @@ def golden_ctranspath() -> None:
                                         window_size=7, embed_layer=glb["_ConvStem"]), tiny, 1, 6, 64)
 
 
+def golden_texture_gray() -> None:
+    """`tile.convert("L")` of the reference's texture filter (tiling.py:284), executed with the installed Pillow."""
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    tiles = np.concatenate([rng.integers(0, 256, size=(1, 224, 224, 3), dtype=np.uint8), he_like_tiles(1, 224, 6),
+                            np.stack([np.stack(np.meshgrid(np.arange(224) % 256, (np.arange(224) * 3) % 256), -1).astype(np.uint8)[..., [0, 1, 0]]])])
+    tiles[2, ..., 2] = 255 - tiles[2, ..., 0]
+    gray = np.stack([np.array(Image.fromarray(t).convert("L")) for t in tiles])
+    save("texture_gray.npz", tiles=tiles, gray=gray)
+
+
 def main() -> None:
     install_shims()
     golden_chief()
@@ -330,6 +342,7 @@ def main() -> None:
     golden_mlp_cox_transforms()
     golden_bag()
     golden_ctranspath()
+    golden_texture_gray()
 
 
 if __name__ == "__main__":
