@@ -395,6 +395,21 @@ int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, 
 int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, void* stream);
 int amds_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dq_sum_ws, void* dqkv,
                        int B, int T, int H, int dtype, void* stream);
+
+/* ALiBi attention in TRAIN mode (reference MultiHeadALiBi / _ALiBi, src/stamp/modeling/models/vision_tranformer.py:34-74, with the
+ * running-mean scaler already updated by the caller, :24-29):  out = softmax(q k^T/8) v - bias_scale_h * U,
+ * U = sum_k cdist(c_q, c_k) * inv_running_mean_h * v.  out, U and Osm (the softmax part alone): bf16 [B*T][H*64];
+ * lse fp32 [B][H][T] (log2 domain). */
+int amds_attention_alibi_fwd_train(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale,
+                                   void* out_bf16, void* u_bf16, void* osm_bf16, float* lse, int B, int T, int H, int dtype, void* stream);
+/* Its backward (bf16 operands): dqkv as amds_attention_bwd, the value path carries the distance term (dV += (P - dist_scale_h D)^T dO,
+ * dist_scale_h = bias_scale_h * inv_running_mean_h), and dbs_part [B][H][T] holds -sum_d dO U per query: summed over (b, q) it is
+ * the gradient of bias_scale_h.  dq_sum_ws: fp32 [B][H][T] scratch. */
+int amds_attention_alibi_bwd(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords,
+                             const float* bias_scale, const float* dist_scale, float* dq_sum_ws, float* dbs_part, void* dqkv,
+                             int B, int T, int H, void* stream);
+/* rowsum[b*T + q] = sum_k |coords[b,q] - coords[b,k]|: the batch statistic `_RunningMeanScaler` needs (mean of torch.cdist). */
+int amds_cdist_rowsum(const float* coords, float* rowsum, int B, int T, void* stream);
 /* fp16 -> bf16 (features are fp16 on disk; the training path feeds bf16 MFMA operands). */
 int amds_convert_f16_bf16(const void* src, void* dst, long n, void* stream);
 /* torch.optim.AdamW step (amsgrad=False) on flat fp32 buffers; `step` is the 1-based step count (bias correction). */

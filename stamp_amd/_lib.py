@@ -115,6 +115,9 @@ PROTOTYPES = {
     "amds_gelu_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "amds_attention_fwd_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_alibi_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_alibi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "amds_cdist_rowsum": (_i, [_vp, _vp, _i, _i, _vp]),
     "amds_convert_f16_bf16": (_i, [_vp, _vp, _l, _vp]),
     "amds_adamw": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp]),
     "amds_gated_attn_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),

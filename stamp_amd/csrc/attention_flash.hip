@@ -29,7 +29,8 @@ constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES + FA_C_BYTES;
 template <typename T, bool ALIBI, typename TO = T>
 __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int Tn, int H,
                                                             const float* __restrict__ coords, const float* __restrict__ head_scale,
-                                                            float* __restrict__ lse_out) {
+                                                            float* __restrict__ lse_out, const float* __restrict__ out_scale = nullptr,
+                                                            TO* __restrict__ u_out = nullptr, TO* __restrict__ osm_out = nullptr) {
     typedef typename Act<T>::vec8 vec8;
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
 
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     if (lse_out && q < Tn && hi == 0) lse_out[((long)b * H + h) * Tn + q] = mrun + log2f(l);   // log2-domain log-sum-exp
     if (q < Tn) {
         const float inv = 1.0f / l;
+        const float osc = (ALIBI && out_scale) ? out_scale[h] : 1.0f;
         TO* orow = out + ((long)b * Tn + q) * Dm + h * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -204,8 +206,20 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
             for (int g = 0; g < 4; ++g) {
                 typename Act<TO>::vec4 w;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = Act<TO>::from_f32(o[dt][4 * g + e] * inv - (ALIBI ? o2[dt][4 * g + e] : 0.f));
+                for (int e = 0; e < 4; ++e) w[e] = Act<TO>::from_f32(o[dt][4 * g + e] * inv - (ALIBI ? osc * o2[dt][4 * g + e] : 0.f));
                 *reinterpret_cast<typename Act<TO>::vec4*>(orow + dt * 32 + 8 * g + 4 * hi) = w;
+                if constexpr (ALIBI) {
+                    if (u_out) {       // training: U = sum_k (dist / running_mean) v and the softmax part alone (out = Osm - bias_scale * U;
+                                       // Osm cannot be rebuilt from the rounded out and U: |U| >> |Osm| cancels catastrophically)
+                        const long off = ((long)b * Tn + q) * Dm + h * 64 + dt * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = Act<TO>::from_f32(o2[dt][4 * g + e]);
+                        *reinterpret_cast<typename Act<TO>::vec4*>(u_out + off) = w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = Act<TO>::from_f32(o[dt][4 * g + e] * inv);
+                        *reinterpret_cast<typename Act<TO>::vec4*>(osm_out + off) = w;
+                    }
+                }
             }
     }
 }
@@ -255,5 +269,23 @@ extern "C" int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, in
     else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, lse);
     else { set_error("amds_attention_fwd_lse: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel<lse>");
+    return AMDS_OK;
+}
+
+// Training forward of the ALiBi attention (reference vision_tranformer.py:42-74 in train mode): head_scale = 1 / running_mean
+// (already updated by the caller, :24-29), out = softmax(q k^T / 8) v - bias_scale_h * U with U = sum_k (dist / running_mean) v.
+// Saves what the backward needs: L = log2-sum-exp per query, U and the softmax part Osm (both bf16).
+extern "C" int amds_attention_alibi_fwd_train(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale,
+                                              void* out_bf16, void* u_bf16, void* osm_bf16, float* lse, int B, int T, int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && coords && inv_running_mean && bias_scale && out_bf16 && u_bf16 && osm_bf16 && lse, "amds_attention_alibi_fwd_train: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_fwd_train: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 6.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, true, bf16>), grid, block, 0, st, (const f16*)qkv, (bf16*)out_bf16, T, H, coords, inv_running_mean, lse, bias_scale, (bf16*)u_bf16, (bf16*)osm_bf16);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, true, bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out_bf16, T, H, coords, inv_running_mean, lse, bias_scale, (bf16*)u_bf16, (bf16*)osm_bf16);
+    else { set_error("amds_attention_alibi_fwd_train: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<alibi,train>");
     return AMDS_OK;
 }

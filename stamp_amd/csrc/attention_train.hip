@@ -21,22 +21,30 @@ constexpr int BT_TR_BYTES = 64 * BT_RS + 8 * 16;   // transposed image: 64 featu
 
 __device__ __forceinline__ int perm16(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
-// Dq[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]
+// Dq[b][h][q] = sum_d dO[q][h*64+d] * Osm[q][h*64+d], Osm = the softmax part of the output (`o`; for plain attention the output).
+// ALiBi (u != NULL): out = Osm - bias_scale_h U; dbs_part[b][h][q] = -sum_d dO U, whose sum over (b, q) is the gradient of
+// bias_scale_h.
 template <typename T>
 __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ dq_sum,
-                                                            int Tn, int H, long total) {
+                                                            int Tn, int H, long total, const T* __restrict__ u = nullptr,
+                                                            const float* __restrict__ bias_scale = nullptr, float* __restrict__ dbs_part = nullptr) {
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per (b, q, h)
     if (wv >= total) return;
     const int lane = threadIdx.x & 63;
     const long bq = wv / H;
     const int h = (int)(wv - bq * H);
     const long off = bq * (long)H * 64 + h * 64 + lane;
-    float s = Act<T>::to_f32(o[off]) * Act<T>::to_f32(dout[off]);
-    s = wave_sum(s);
+    const float g = Act<T>::to_f32(dout[off]);
+    const float osm = Act<T>::to_f32(o[off]);
+    float gu = 0.f;
+    if (u) gu = -g * Act<T>::to_f32(u[off]);
+    const float s = wave_sum(osm * g);
+    if (u) gu = wave_sum(gu);
     if (lane == 0) {
         const long b = bq / Tn;
         const int q = (int)(bq - b * Tn);
         dq_sum[(b * H + h) * (long)Tn + q] = s;
+        if (u) dbs_part[(b * H + h) * (long)Tn + q] = gu;
     }
 }
 
@@ -45,19 +53,23 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const T* __restrict_
 //   S[i=query][j=key]  = Q_rows . K^T(regs)        dP[i=query][j=key] = dO_rows . V^T(regs)
 //   dV^T[d][key] += dO^T[d][q] P[q][key]           dK^T[d][key] += Q^T[d][q] dS[q][key]
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// ALIBI: dV^T += dO^T (P - c_h D) with D = cdist(coords) and c_h = bias_scale_h / running_mean_h (the value path of the
+// post-softmax distance bias, vision_tranformer.py:60-72); dS, dK, dQ are those of the softmax part alone.
+template <typename T, bool ALIBI = false>
 __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ dq_sum,
-                                                               T* __restrict__ dqkv, int Tn, int H) {
+                                                               T* __restrict__ dqkv, int Tn, int H, const float* __restrict__ coords = nullptr,
+                                                               const float* __restrict__ dist_scale = nullptr) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
-    constexpr int STAGE = 2 * BT_ROW_BYTES + 2 * BT_TR_BYTES + 2 * BT_TILE * 4;
+    constexpr int STAGE = 2 * BT_ROW_BYTES + 2 * BT_TR_BYTES + 2 * BT_TILE * 4 + (ALIBI ? 2 * BT_TILE * 4 : 0);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
+    const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
     const int Dm = H * 64;
     const long ld = 3L * Dm;
     const T* base = qkv + (long)b * Tn * ld + h * 64;           // q at +0, k at +Dm, v at +2Dm
@@ -79,7 +91,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
     // staging: per tile 64 queries x (Q row 128 B + dO row 128 B); thread -> (token pair, 8-wide d chunk)
     const int pr = tid >> 3, ch = tid & 7;          // pair 0..31 -> tokens 2pr, 2pr+1
     vec8 q0, q1, g0, g1;
-    float lreg = 0.f, dreg = 0.f;
+    float lreg = 0.f, dreg = 0.f, cxreg = 0.f, cyreg = 0.f;
+    float xk = 0.f, yk = 0.f, ch_ = 0.f;
+    if constexpr (ALIBI) { xk = cbase[(long)keyc * 2]; yk = cbase[(long)keyc * 2 + 1]; ch_ = dist_scale[h]; }
     auto stage_load = [&](int j) {
         const int t0 = j * BT_TILE + pr * 2;
 #pragma unroll
@@ -88,6 +102,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
         if (t0 + 1 < Tn) { q1 = *reinterpret_cast<const vec8*>(base + (long)(t0 + 1) * ld + ch * 8); g1 = *reinterpret_cast<const vec8*>(dobase + (long)(t0 + 1) * Dm + ch * 8); }
         lreg = dreg = 0.f;
         if (tid < BT_TILE && j * BT_TILE + tid < Tn) { lreg = lrow[j * BT_TILE + tid]; dreg = drow[j * BT_TILE + tid]; }
+        if constexpr (ALIBI) {
+            cxreg = cyreg = 0.f;
+            if (tid < BT_TILE && j * BT_TILE + tid < Tn) { cxreg = cbase[(long)(j * BT_TILE + tid) * 2]; cyreg = cbase[(long)(j * BT_TILE + tid) * 2 + 1]; }
+        }
     };
     auto stage_store = [&](int buf) {
         char* sQ = smem + buf * STAGE;
@@ -111,6 +129,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
             *reinterpret_cast<vec2*>(sGt + (ch * 8 + e) * BT_RS + ch * 16 + pos * 2) = w;
         }
         if (tid < BT_TILE) { sL[tid] = lreg; sL[BT_TILE + tid] = dreg; }
+        if constexpr (ALIBI) {
+            if (tid < BT_TILE) { sL[2 * BT_TILE + tid] = cxreg; sL[3 * BT_TILE + tid] = cyreg; }
+        }
     };
 
     f32x16 dk[2], dv[2];
@@ -154,7 +175,12 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
                 float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -sL[ql]));
                 if (qg >= Tn || key >= Tn) p = 0.f;
                 const float dsv = p * (dp[r] - sL[BT_TILE + ql]);
-                pf[r >> 3][r & 7] = Act<T>::from_f32(p);
+                float pw = p;                                   // weight on v: P, minus the scaled distance for ALiBi
+                if constexpr (ALIBI) {
+                    const float ddx = sL[2 * BT_TILE + ql] - xk, ddy = sL[3 * BT_TILE + ql] - yk;
+                    if (qg < Tn && key < Tn) pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
+                }
+                pf[r >> 3][r & 7] = Act<T>::from_f32(pw);
                 df[r >> 3][r & 7] = Act<T>::from_f32(dsv);
             }
 #pragma unroll
@@ -320,16 +346,37 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
 
 template <typename T>
 static int launch_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* dq_sum, void* dqkv, int B, int T_, int H,
-                           hipStream_t st) {
+                           hipStream_t st, const void* u = nullptr, const float* coords = nullptr, const float* bias_scale = nullptr,
+                           const float* dist_scale = nullptr, float* dbs_part = nullptr) {
     const long total = (long)B * T_ * H;
-    hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, (const T*)o, (const T*)dout, dq_sum, T_, H, total);
+    hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, (const T*)o, (const T*)dout, dq_sum, T_, H, total,
+                       (const T*)u, bias_scale, dbs_part);
     AMDS_LAUNCH_CHECK("attn_bwd_prep_kernel");
     const dim3 grid((T_ + 127) / 128, H, B), block(256);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H);
+    if (u) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
+    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
     AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H);
     AMDS_LAUNCH_CHECK("attn_bwd_dq_kernel");
     return AMDS_OK;
+}
+
+// mean over b, q, k of |c[b,q] - c[b,k]| -- the statistic `_RunningMeanScaler` folds into its running mean in train mode
+// (vision_tranformer.py:24-29 applied to torch.cdist(coords, coords), :59-60).  One wave per (b, q); deterministic two-stage sum.
+__global__ void __launch_bounds__(256) cdist_rowsum_kernel(const float* __restrict__ coords, float* __restrict__ rowsum, int Tn, long rows) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const long b = r / Tn;
+    const float* cb = coords + b * (long)Tn * 2;
+    const float xq = coords[r * 2], yq = coords[r * 2 + 1];
+    float s = 0.f;
+    for (int k = lane; k < Tn; k += 64) {
+        const float dx = xq - cb[k * 2], dy = yq - cb[k * 2 + 1];
+        s += sqrtf(dx * dx + dy * dy);
+    }
+    s = wave_sum(s);
+    if (lane == 0) rowsum[r] = s;
 }
 
 }  // namespace amds
@@ -346,4 +393,23 @@ extern "C" int amds_attention_bwd(const void* qkv, const void* out, const void* 
     if (dtype == AMDS_F16) return launch_attn_bwd<f16>(qkv, out, dout, lse, dq_sum_ws, dqkv, B, T, H, st);
     set_error("amds_attention_bwd: bad dtype %d", dtype);
     return AMDS_ERR_INVALID;
+}
+
+extern "C" int amds_attention_alibi_bwd(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords,
+                                        const float* bias_scale, const float* dist_scale, float* dq_sum_ws, float* dbs_part, void* dqkv,
+                                        int B, int T, int H, void* stream) {
+    AMDS_REQUIRE(qkv && osm && u && dout && lse && coords && bias_scale && dist_scale && dq_sum_ws && dbs_part && dqkv, "amds_attention_alibi_bwd: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_bwd: bad shape B=%d T=%d H=%d", B, T, H);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_ATTN, 10.0 * B * H * (double)T * T * 64, st);
+    return launch_attn_bwd<bf16>(qkv, osm, dout, lse, dq_sum_ws, dqkv, B, T, H, st, u, coords, bias_scale, dist_scale, dbs_part);
+}
+
+extern "C" int amds_cdist_rowsum(const float* coords, float* rowsum, int B, int T, void* stream) {
+    AMDS_REQUIRE(coords && rowsum, "amds_cdist_rowsum: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0, "amds_cdist_rowsum: bad shape");
+    const long rows = (long)B * T;
+    hipLaunchKernelGGL(cdist_rowsum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, coords, rowsum, T, rows);
+    AMDS_LAUNCH_CHECK("cdist_rowsum_kernel");
+    return AMDS_OK;
 }

@@ -105,3 +105,38 @@ def adamw(p, g, m, v, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-
     _dev(p, g, m, v)
     assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (p, g, m, v)) and p.numel() == g.numel() == m.numel() == v.numel()
     _lib.check(_lib.lib().amds_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _stream()), "adamw")
+
+
+def attention_alibi_fwd_train(qkv: torch.Tensor, coords: torch.Tensor, inv_running_mean: torch.Tensor, bias_scale: torch.Tensor,
+                              B: int, T: int, H: int):
+    """ALiBi attention forward that saves what its backward needs: returns (out, U, Osm: bf16; lse fp32 [B,H,T])."""
+    _dev(qkv, coords, inv_running_mean, bias_scale)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64) and coords.shape == (B, T, 2) and coords.dtype == torch.float32
+    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device=qkv.device)
+    u, osm = torch.empty_like(out), torch.empty_like(out)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_alibi_fwd_train(_p(qkv), _p(coords.contiguous()), _p(inv_running_mean), _p(bias_scale), _p(out), _p(u),
+                                                         _p(osm), _p(lse), B, T, H, act_code(qkv.dtype), _stream()), "attention_alibi_fwd_train")
+    return out, u, osm, lse
+
+
+def attention_alibi_bwd(qkv, osm, u, dout, lse, coords, bias_scale, dist_scale, B: int, T: int, H: int):
+    """-> (dqkv bf16, d bias_scale [H] fp32)."""
+    _dev(qkv, osm, u, dout, lse, coords, bias_scale, dist_scale)
+    assert qkv.dtype == osm.dtype == u.dtype == dout.dtype == torch.bfloat16 and all(t.is_contiguous() for t in (qkv, osm, u, dout))
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    part = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_alibi_bwd(_p(qkv), _p(osm), _p(u), _p(dout), _p(lse), _p(coords.contiguous()), _p(bias_scale), _p(dist_scale),
+                                                   _p(ws), _p(part), _p(dqkv), B, T, H, _stream()), "attention_alibi_bwd")
+    dbs = colsum(part.permute(1, 0, 2).reshape(H, B * T).t().contiguous())        # [B*T, H] -> column sums = per-head gradient
+    return dqkv, dbs
+
+
+def cdist_mean(coords: torch.Tensor) -> torch.Tensor:
+    """mean of torch.cdist(coords, coords) over [B, T, T] as a 0-d device tensor (no host sync)."""
+    _dev(coords)
+    B, T, _ = coords.shape
+    rows = torch.empty(B * T, 1, dtype=torch.float32, device=coords.device)
+    _lib.check(_lib.lib().amds_cdist_rowsum(_p(coords.contiguous()), _p(rows), B, T, _stream()), "cdist_rowsum")
+    return colsum(rows).reshape(()) / float(B * T * T)

@@ -182,3 +182,41 @@ def test_mil_vit_training_step_matches_autograd(gpu):
     assert abs(tr._lrs[0] - 1e-3 / 25.0) < 1e-12 and len(tr._lrs) == 50
     tr.sync_to_model()
     assert torch.allclose(model.state_dict()["mlp_head.0.bias"].cpu(), tr.p("mlp_head.0.bias").cpu())
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("B,Tn,H", [(2, 200, 2), (1, 1025, 8)])
+def test_alibi_attention_fwd_bwd_vs_autograd(gpu, B, Tn, H):
+    """Post-softmax distance bias (reference _ALiBi.forward): out = softmax(qk^T/8) v - bs_h * (cdist/rm_h) v.
+    HIP forward + backward (dq, dk, dv, d bias_scale) against fp64 autograd on the same bf16-rounded q, k, v."""
+    g = torch.Generator().manual_seed(B * Tn)
+    D = H * 64
+    qkv = (torch.randn(B * Tn, 3 * D, generator=g) * 0.8).bfloat16()
+    coords = torch.rand(B, Tn, 2, generator=g) * 4000.0
+    coords[:, 0] = 0.0                                           # the class token sits at (0, 0) (vision_tranformer.py:349-351)
+    bs = torch.rand(H, generator=g) * 0.5 + 0.1
+    rm = torch.rand(H, generator=g) * 500.0 + 1800.0
+    dout = (torch.randn(B * Tn, D, generator=g) * 0.5).bfloat16()
+
+    q3 = qkv.double().reshape(B, Tn, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)      # [3,B,H,T,64]
+    bsd = bs.double().clone().requires_grad_(True)
+    dist = torch.cdist(coords.double(), coords.double())                                                  # [B,T,T]
+    w = torch.softmax(q3[0] @ q3[1].transpose(-2, -1) / 8.0, -1) - (dist[:, None] / rm.double().view(1, H, 1, 1)) * bsd.view(1, H, 1, 1)
+    ref = (w @ q3[2]).permute(0, 2, 1, 3).reshape(B * Tn, D)
+    ref.backward(dout.double())
+    ref_dqkv = q3.grad.permute(1, 3, 0, 2, 4).reshape(B * Tn, 3 * D)
+
+    inv_rm = (1.0 / rm).to(gpu)
+    out, u, osm, lse = T.attention_alibi_fwd_train(qkv.to(gpu), coords.to(gpu), inv_rm, bs.to(gpu), B, Tn, H)
+    assert _rel(out.float().cpu(), ref.detach()) < 8e-3                  # the distance operand is rounded to bf16
+    dqkv, dbs = T.attention_alibi_bwd(qkv.to(gpu), osm, u, dout.to(gpu), lse, coords.to(gpu), bs.to(gpu), (bs / rm).to(gpu), B, Tn, H)
+    d = dqkv.float().cpu().reshape(B * Tn, 3, D)
+    r = ref_dqkv.reshape(B * Tn, 3, D)
+    for i, name in enumerate("qkv"):
+        assert _rel(d[:, i], r[:, i]) < 1.5e-2, (name, _rel(d[:, i], r[:, i]))
+    assert _rel(dbs.cpu(), bsd.grad) < 1e-2, (dbs.cpu(), bsd.grad)
+    m = T.cdist_mean(coords.to(gpu))
+    assert abs(m.item() - dist.mean().item()) < 1e-3 * dist.mean().item()
