@@ -198,6 +198,21 @@ def main() -> None:
         line["secondary"]["train"] = {"metric": "MIL bags/s (vit head, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands)",
                                       "value": round(64 * ctx.world / dt_tr, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltr))}
         del trn
+        # the same head with use_alibi=True (MultiHeadALiBi: post-softmax distance bias, train-mode running-mean scalers)
+        mil_a = HipMil(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.0, use_alibi=True).eval()
+        crd = (torch.rand(64, 1024, 2, generator=torch.Generator().manual_seed(2)) * 4e4).to(ctx.device)
+        trn = HipMilVitTrainer(mil_a, device=ctx.device, total_steps=100)
+        for _ in range(2):
+            trn.step(bags, tg, cw, coords=crd)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            lta, _ = trn.step(bags, tg, cw, coords=crd)
+        torch.cuda.synchronize()
+        dt_ta = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 4)
+        line["secondary"]["train_alibi"] = {"metric": "MIL bags/s (vit head with ALiBi, fwd + bwd + AdamW, bags of 1024 x 1024-d + coords, batch 64, bf16 operands)",
+                                            "value": round(64 * ctx.world / dt_ta, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(lta))}
+        del trn, mil_a
         from stamp_amd.mil import TransMIL as HipTransMIL
         tm = HipTransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().to(ctx.device)
         bags8 = bags[:8].float()

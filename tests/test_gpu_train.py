@@ -220,3 +220,77 @@ def test_alibi_attention_fwd_bwd_vs_autograd(gpu, B, Tn, H):
     assert _rel(dbs.cpu(), bsd.grad) < 1e-2, (dbs.cpu(), bsd.grad)
     m = T.cdist_mean(coords.to(gpu))
     assert abs(m.item() - dist.mean().item()) < 1e-3 * dist.mean().item()
+
+
+def test_mil_vit_alibi_training_step_matches_autograd(gpu):
+    """use_alibi=True: forward + backward of the HIP trainer vs fp32 autograd through the pinned oracle
+    (oracle.mil_vit, golden-tested against the reference's MultiHeadALiBi): loss, logits, every parameter gradient incl.
+    bias_scale and the 3 x heads per-head encoders, and the train-mode running-mean update of every head."""
+    from oracle.mil_vit import mil_vit_forward, running_mean_update
+    from stamp_amd.mil import VisionTransformer
+    from stamp_amd.mil_train import HipMilVitTrainer
+
+    torch.manual_seed(7)
+    Bb, Tn, Fd, C, H = 3, 150, 256, 2, 4
+    model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=256, n_layers=2, n_heads=H, dim_feedforward=256, dropout=0.0, use_alibi=True)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "class_token" not in n and "scale_distance" not in n and "bias_scale" not in n:
+                p.add_(0.05 * torch.randn_like(p))
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    bags = torch.randn(Bb, Tn, Fd).half()
+    coords = torch.rand(Bb, Tn, 2) * 3000.0
+    targets = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 1.0]])
+    weights = torch.tensor([0.7, 0.3])
+    # reference semantics of a train-mode forward: every scaler folds this batch's distances in BEFORE it is used
+    cc = torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1)
+    dist = torch.cdist(cc, cc)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k in sd0:
+        if k.endswith("scale_distance.running_mean"):
+            rm, n = running_mean_update(sd0[k], sd0[k[: -len("running_mean")] + "items_so_far"], dist)
+            sd[k], sd[k[: -len("running_mean")] + "items_so_far"] = rm, n
+    params = {k: v.clone().requires_grad_(not k.endswith(("running_mean", "items_so_far"))) for k, v in sd.items()}
+    logits_ref = mil_vit_forward(bags.float(), coords, None, params, n_heads=H, use_alibi=True)
+    loss_ref = torch.nn.functional.cross_entropy(logits_ref, targets, weight=weights)
+    loss_ref.backward()
+
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=1e-3, div_factor=25.0, total_steps=50, split_k=4)
+    loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu))
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    assert (logits.cpu() - logits_ref.detach()).abs().max() < 3e-2 * max(1.0, logits_ref.abs().max().item())
+    worst, report = 0.0, []
+    for k in tr.names:
+        if k.endswith(("running_mean", "items_so_far")):
+            assert torch.allclose(tr.p(k).cpu(), sd[k], rtol=1e-5), (k, tr.p(k).cpu(), sd[k])       # buffers: updated, exactly as the reference
+            continue
+        g, r = tr.g(k).cpu().double(), params[k].grad.double()
+        if "key_encoders" in k and k.endswith(".bias"):
+            # softmax is invariant to a per-query constant, so the TRUE gradient of a key bias is 0 (autograd: 1e-10);
+            # hold the bf16 path to "small against the sibling value-bias gradient" instead of a relative error
+            sib = params[k.replace("key_encoders", "value_encoders")].grad.double().norm()
+            assert r.norm() < 1e-6 and g.norm() < 5e-2 * sib, (k, g.norm().item(), sib.item())
+            continue
+        # q / k encoders of the LAST layer only get gradient through the class token's single query row, and with ALiBi the
+        # softmax part is a small fraction of the attention output: their gradients are ~20x smaller than the value encoder's.
+        # Error is measured against max(|r|, 5 % of the sibling value-encoder gradient) -- what matters to the optimiser.
+        floor = 0.0
+        if "query_encoders" in k or "key_encoders" in k:
+            floor = 0.05 * params[k.replace("query_encoders", "value_encoders").replace("key_encoders", "value_encoders")].grad.double().norm().item()
+        rel = ((g - r).norm() / max(r.norm().item(), floor, 1e-12)).item()
+        worst = max(worst, rel)
+        report.append((rel, k, r.norm().item()))
+    report.sort(reverse=True)
+    print("largest gradient errors with ALiBi (bf16 operands):", [(round(a, 4), b, float(f"{c:.2e}")) for a, b, c in report[:8]])
+    for rel, k, rn in report:
+        # bias_scale is a scalar: its gradient is a signed sum over (in the last layer) only the class-token rows
+        assert rel < (0.12 if k.endswith("bias_scale") else 6e-2), (k, rel, rn)
+    losses = [tr.step(bags.to(gpu), targets, weights, coords=coords.to(gpu))[0].item() for _ in range(8)]
+    assert losses[-1] < losses[0] and torch.isfinite(tr.P).all()
+    n_key = next(k for k in tr.names if k.endswith("items_so_far"))
+    assert tr.p(n_key).item() == 1.0 + 9                                   # nine train-mode forwards, weight decay never touched it
+    tr.sync_to_model()
+    model.eval()
+    with torch.no_grad():
+        y = model(bags.to(gpu), coords=coords.to(gpu), mask=None)          # deploy-time forward of the trained head still runs
+    assert torch.isfinite(y).all()
