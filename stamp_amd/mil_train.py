@@ -136,8 +136,12 @@ class HipMilVitTrainer:
 
     # ---- one optimisation step ------------------------------------------------------------------------------------------------
     def step(self, bags: torch.Tensor, targets: torch.Tensor, class_weights: torch.Tensor | None = None, *, update: bool = True,
-             data_parallel: bool = False, coords: torch.Tensor | None = None):
+             data_parallel: bool = False, coords: torch.Tensor | None = None, loss_fn=None):
         """bags [Bb,T,F] fp16/bf16/fp32 on the GPU, targets float one-hot [Bb,C]. Returns (loss, logits).
+
+        loss_fn(logits, targets) -> scalar selects the task (stamp_amd.losses): default = the classifier's weighted
+        cross-entropy; `losses.l1_loss` = LitTileRegressor (dim_output 1); `losses.cox_survival_loss` = LitTileSurvival
+        (dim_output 1, targets [time, event]).
 
         data_parallel=True: every rank of the initialised process group holds a replica and its own bags; the flat
         fp32 gradient buffer (14.7 MB for the default head) is averaged with ONE RCCL all-reduce before AdamW
@@ -203,7 +207,10 @@ class HipMilVitTrainer:
         logits = ops.linear_f32(clsn, self.p("mlp_head.0.weight").contiguous(), self.p("mlp_head.0.bias").contiguous())
         # ---- loss on [Bb, C]: the reference's weighted CE with float one-hot targets (models/__init__.py:254-258) ---------------------
         lg = logits.detach().clone().requires_grad_(True)
-        loss = F.cross_entropy(lg, targets.to(dev, torch.float32), weight=None if class_weights is None else class_weights.to(dev, torch.float32))
+        if loss_fn is None:
+            loss = F.cross_entropy(lg, targets.to(dev, torch.float32), weight=None if class_weights is None else class_weights.to(dev, torch.float32))
+        else:
+            loss = loss_fn(lg, targets.to(dev))
         loss.backward()
         dlogits = lg.grad.contiguous()
         if not update and not torch.is_grad_enabled():

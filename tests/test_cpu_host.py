@@ -148,3 +148,27 @@ def test_swin_flops_and_state_dict_shapes():
     sd = random_swin_state_dict(cfg, 0)
     assert sum(v.numel() for v in sd.values()) == sum(int(np.prod(s)) for _, s in swin_param_shapes(cfg))
     assert cfg.out_dim == 768 and sd["layers.3.blocks.1.attn.qkv.weight"].shape == (2304, 768)
+
+
+def test_product_losses_match_oracle_and_reference_known_answers():
+    """stamp_amd.losses (product, differentiable torch on [batch] scalars) vs the pinned oracle and the known answers of the
+    reference's own docstring (src/stamp/modeling/models/cox.py:192-204)."""
+    from oracle import misc
+    from stamp_amd import losses
+    g = torch.Generator().manual_seed(0)
+    lh = torch.randn(40, generator=g)
+    ev = torch.rand(40, generator=g) < 0.6
+    t_notie = torch.randperm(40, generator=g).float()
+    t_tie = torch.randint(0, 8, (40,), generator=g).float()
+    for t, m in ((t_notie, "efron"), (t_tie, "efron"), (t_tie, "breslow")):
+        a = losses.neg_partial_log_likelihood(lh, t, ev, m)
+        b = misc.cox_neg_partial_log_likelihood(lh, t, ev, m)
+        assert abs(a.item() - b.item()) < 1e-5, (m, a.item(), b.item())
+    z = np.load(Path(__file__).parent / "golden" / "cox.npz")
+    lhz, tt, evz = torch.from_numpy(z["log_hz"]), torch.from_numpy(z["time"]), torch.from_numpy(z["event"])
+    assert abs(losses.neg_partial_log_likelihood(lhz, tt, evz, "efron").item() - float(z["efron"])) < 1e-4
+    # differentiable, and the survival wrapper reads [time, event] columns
+    p = lh.clone().requires_grad_(True)
+    losses.cox_survival_loss(p.unsqueeze(-1), torch.stack([t_tie, ev.float()], 1)).backward()
+    assert torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    assert abs(losses.l1_loss(torch.tensor([[1.0], [3.0]]), torch.tensor([2.0, 5.0])).item() - 1.5) < 1e-7

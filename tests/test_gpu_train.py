@@ -294,3 +294,39 @@ def test_mil_vit_alibi_training_step_matches_autograd(gpu):
     with torch.no_grad():
         y = model(bags.to(gpu), coords=coords.to(gpu), mask=None)          # deploy-time forward of the trained head still runs
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("task", ["regression", "survival"])
+def test_trainer_regression_and_survival_losses(gpu, task):
+    """dim_output = 1 heads trained with the reference's other two objectives (LitTileRegressor: L1, LitTileSurvival: Cox/Efron):
+    the step's loss equals the objective evaluated on the HIP predictions, d(loss)/d(head bias) matches autograd of the same
+    objective through the oracle network, and a few steps reduce it."""
+    from oracle.mil_vit import mil_vit_forward
+    from stamp_amd import losses
+    from stamp_amd.mil import VisionTransformer
+    from stamp_amd.mil_train import HipMilVitTrainer
+
+    torch.manual_seed(11)
+    Bb, Tn, Fd = 6, 120, 256
+    model = VisionTransformer(dim_output=1, dim_input=Fd, dim_model=256, n_layers=1, n_heads=4, dim_feedforward=256, dropout=0.0, use_alibi=False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    bags = torch.randn(Bb, Tn, Fd).half()
+    if task == "regression":
+        targets, fn = torch.randn(Bb, 1), losses.l1_loss
+    else:
+        targets = torch.stack([torch.tensor([5.0, 3.0, 3.0, 9.0, 1.0, 7.0]), torch.tensor([1.0, 1.0, 0.0, 1.0, 1.0, 0.0])], 1)   # a tie at t = 3
+        fn = losses.cox_survival_loss
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_pred = mil_vit_forward(bags.float(), torch.zeros(Bb, Tn, 2), None, params, n_heads=4, use_alibi=False)
+    ref_loss = fn(ref_pred, targets)
+    ref_loss.backward()
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=2e-3, div_factor=25.0, total_steps=50, split_k=4)
+    loss, pred = tr.step(bags.to(gpu), targets, update=False, loss_fn=fn)
+    assert pred.shape == (Bb, 1)
+    assert abs(loss.item() - fn(pred.cpu(), targets).item()) < 1e-5
+    assert abs(loss.item() - ref_loss.item()) < 3e-2 * max(1.0, abs(ref_loss.item()))
+    for k in ("mlp_head.0.bias", "mlp_head.0.weight", "transformer.norm.weight", "project_features.0.bias"):
+        g, r = tr.g(k).cpu().double(), params[k].grad.double()
+        assert ((g - r).norm() / (r.norm() + 1e-12)).item() < 6e-2, k
+    ls = [tr.step(bags.to(gpu), targets, loss_fn=fn)[0].item() for _ in range(10)]
+    assert ls[-1] < ls[0]
