@@ -292,6 +292,14 @@ int amds_swin_stem(const uint8_t* tiles, float* x, const float* params, int B, i
 int amds_window_attention(const void* qkv, long ldq, void* out, long ldo, const float* bias_lane, const uint64_t* mask_bits,
                           int B, int grid, int dim, int heads, int shift, int dtype, void* stream);
 
+/* The whole attention branch of a 96-channel Swin block in one pass over the fp32 residual stream x [B][grid^2][96]:
+ *   x += proj(window_attention(qkv(LayerNorm(x))))        (reference ctranspath.py:654-692; 3 heads x 32, window 7)
+ * qkv_w [288][96], proj_w [96][96] act dtype (row-major, unpadded); biases, LayerNorm parameters fp32; bias_lane / mask_bits as
+ * for amds_window_attention.  Weights and bias tables stay in LDS, q/k/v/probabilities/head outputs only exist in registers. */
+int amds_swin_attn96(float* x, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
+                     const float* ln_gamma, const float* ln_beta, const float* bias_lane, const uint64_t* mask_bits, int B,
+                     int grid, int shift, float ln_eps, int dtype, void* stream);
+
 /* PatchMerging up to the Linear (ctranspath.py:717-736): x fp32 [B][grid^2][dim] -> LayerNorm(concat of the 2x2 cell
  * members (0,0),(1,0),(0,1),(1,1)) as act dtype [B][(grid/2)^2][4*dim]. */
 int amds_patch_merge_ln(const float* x, void* y, const float* gamma, const float* beta, int B, int grid, int dim, float eps,

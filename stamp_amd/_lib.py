@@ -89,6 +89,7 @@ PROTOTYPES = {
     "amds_swin_forward": (_i, [C.POINTER(SwinCfg), C.POINTER(SwinWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_swin_stem": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_window_attention": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amds_swin_attn96": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "amds_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "amds_layernorm_meanpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -11,6 +11,7 @@
 //   merge  : gather 2x2 cells + LayerNorm(4C) (one kernel) | x' = . Wred^T (GEMM, fp32 out)
 //   head   : LayerNorm + mean over tokens (one kernel) -> fp16 (".half()" of the reference loop) and/or fp32
 #include "common.h"
+#include "rowstream.h"
 #include <stdlib.h>
 
 namespace amds {
@@ -329,6 +330,228 @@ __global__ void __launch_bounds__(256) swin_wattn_kernel(const T* __restrict__ q
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole attention branch of a 96-channel Swin block in ONE pass over the residual stream (ctranspath.py:654-692):
+//     x[window rows] += proj( window_attention( qkv( LayerNorm(x[window rows]) ) ) )
+// One wave owns one (tile, window) at a time (4 waves per workgroup, one workgroup per CU, 512 registers per lane);
+// Wqkv, Wproj, the three heads' relative-position-bias tables, LayerNorm parameters and biases live in LDS (122 KB) for the
+// whole launch.  Nothing but x is read or written: 2 x 384 B per token instead of the 2.9 KB of the unfused chain.
+// Register-level dataflow (all operands of every MFMA come from registers or the stationary LDS images):
+//   xf        = LayerNorm(x rows) as MFMA fragments (lane = token)                     [rowstream.h]
+//   K, Q      = W(A) x xf(B)        -> (lane = token, registers = the head's 32 dims)  = A / B operands of S^T = K Q^T
+//   V^T       = xf(A) x Wv(B)       -> (lane = dim, registers = tokens)                = A operand of P V, no LDS transpose
+//   S^T       -> softmax (+ bias table, + shift mask bits) -> P in registers            = B operand of P V
+//   O^T       = V^T(A) x P(B)       -> (lane = token, registers = dims)                = A operand of the projection
+//   out      += O(A) x Wproj(B)     -> (lane = output channel, registers = token rows)  coalesced read-modify-write of x
+// The contraction index of every chained MFMA pair is permuted consistently (accumulator register order = operand slot
+// order), and Wproj is staged in LDS with that permutation baked in.
+// ------------------------------------------------------------------------------------------------
+constexpr int SA_WQKV = 9 * 6 * 1024, SA_WPROJ = 3 * 6 * 1024, SA_BIAS = 3 * 4 * 64 * 16 * 4;
+constexpr int SA_LDS = SA_WQKV + SA_WPROJ + SA_BIAS + (2 * 96 + 288 + 96) * 4;
+
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+swin_attn96_kernel(float* x, const T* __restrict__ Wqkv, const float* __restrict__ bqkv, const T* __restrict__ Wproj,
+                   const float* __restrict__ bproj, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                   const float* __restrict__ bias_lane, const unsigned long long* __restrict__ mask_bits, int G, int shift, float eps,
+                   float scale_l2, int nwin_total) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int C = 96, KS = 6, NH = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_wqkv = smem;
+    char* s_wproj = smem + SA_WQKV;
+    float* s_bias = reinterpret_cast<float*>(s_wproj + SA_WPROJ);          // [head][tile][g][lane][4]
+    float* s_ln = s_bias + SA_BIAS / 4;                                    // gamma[96] beta[96]
+    float* s_bq = s_ln + 2 * C;                                            // qkv bias [288]
+    float* s_bp = s_bq + 3 * C;                                            // proj bias [96]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    for (int blk = wave; blk < 9 * KS; blk += 4) {
+        const int j = blk / KS, ks = blk - j * KS;
+        glds16(Wqkv + (long)(32 * j + l31) * C + 16 * ks + 8 * hi, s_wqkv + blk * 1024);
+    }
+    for (int blk = wave; blk < 3 * 6; blk += 4) {                          // (cf, hs): B operand of the projection, k-permuted
+        const int cf = blk / 6, hs = blk - cf * 6;
+        const T* src = Wproj + (long)(32 * cf + l31) * C + 16 * hs + 4 * hi;
+        const vec4 lo = *reinterpret_cast<const vec4*>(src), hi4 = *reinterpret_cast<const vec4*>(src + 8);
+        vec8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi4[e]; }
+        *reinterpret_cast<vec8*>(s_wproj + blk * 1024 + lane * 16) = v;
+    }
+    for (int i = tid; i < NH * 4 * 64 * 4; i += 256) {                     // bias table: [h][tile][lane][g*4..] -> [h][tile][g][lane][4]
+        const int g4 = i & 3, ln = (i >> 2) & 63, ht = i >> 8;
+        *reinterpret_cast<f32x4*>(s_bias + ((ht * 4 + g4) * 64 + ln) * 4) = *reinterpret_cast<const f32x4*>(bias_lane + ((size_t)ht * 64 + ln) * 16 + g4 * 4);
+    }
+    for (int i = tid; i < C; i += 256) { s_ln[i] = ln_g[i]; s_ln[C + i] = ln_b[i]; s_bp[i] = bproj[i]; }
+    for (int i = tid; i < 3 * C; i += 256) s_bq[i] = bqkv[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nwin_side = G / SW_WS, nW = nwin_side * nwin_side;
+    const int p0 = l31, p1 = min(32 + l31, SW_N - 1);
+    const int i0 = p0 / SW_WS, j0 = p0 - i0 * SW_WS, i1 = p1 / SW_WS, j1 = p1 - i1 * SW_WS;
+    const int wstep = gridDim.x * 4;
+    int win = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    auto token_row = [&](int w, int i, int j) -> int {
+        const int b = w / nW, wi = w - b * nW;
+        const int wh = wi / nwin_side, ww = wi - wh * nwin_side;
+        int hh = wh * SW_WS + i + shift, wc = ww * SW_WS + j + shift;
+        hh = hh >= G ? hh - G : hh;
+        wc = wc >= G ? wc - G : wc;
+        return (b * G + hh) * G + wc;
+    };
+    f32x4 raw[2][KS][2];
+    vec8 xf[2][KS];
+    if (win < nwin_total) {
+        rs_load_raw<KS>(raw[0], x, C, token_row(win, i0, j0), hi);
+        rs_load_raw<KS>(raw[1], x, C, token_row(win, i1, j1), hi);
+        rs_normalise<T, KS>(xf[0], raw[0], s_ln, hi, eps);
+        rs_normalise<T, KS>(xf[1], raw[1], s_ln, hi, eps);
+    }
+    for (; win < nwin_total; win += wstep) {
+        int lds_lane = lane * 16;                         // opaque per iteration: keeps the stationary-operand ds_reads inside the loop
+        asm volatile("" : "+v"(lds_lane));
+        const int wi = win % nW;
+        const int wh = wi / nwin_side, ww = wi - wh * nwin_side;
+        const int wtype = shift > 0 ? ((wh == nwin_side - 1) ? 2 : 0) + ((ww == nwin_side - 1) ? 1 : 0) : 0;
+        const unsigned long long mb = mask_bits[wtype * 64 + lane];
+        f32x16 acc_out[2][3];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int cf = 0; cf < 3; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_out[f][cf][r] = 0.f;
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) {
+            // ---- K (A operand of S^T), Q (B operand), V^T (A operand of P V): 3 x 2 x 6 MFMAs ----
+            vec8 kf[2][2], qf[2][2], vf[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                f32x16 aq, ak, av;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 bq4 = *reinterpret_cast<const f32x4*>(s_bq + 32 * h + 8 * g4 + 4 * hi + (lds_lane & 1));
+                    const f32x4 bk4 = *reinterpret_cast<const f32x4*>(s_bq + C + 32 * h + 8 * g4 + 4 * hi + (lds_lane & 1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { aq[4 * g4 + e] = bq4[e]; ak[4 * g4 + e] = bk4[e]; }
+                }
+                const float bvl = s_bq[2 * C + 32 * h + l31 + (lds_lane & 1)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = bvl;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const vec8 wq = *reinterpret_cast<const vec8*>(s_wqkv + ((h)*KS + ks) * 1024 + lds_lane);
+                    const vec8 wk = *reinterpret_cast<const vec8*>(s_wqkv + ((3 + h) * KS + ks) * 1024 + lds_lane);
+                    const vec8 wv = *reinterpret_cast<const vec8*>(s_wqkv + ((6 + h) * KS + ks) * 1024 + lds_lane);
+                    aq = Act<T>::mfma32(wq, xf[f][ks], aq);
+                    ak = Act<T>::mfma32(wk, xf[f][ks], ak);
+                    av = Act<T>::mfma32(xf[f][ks], wv, av);
+                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);          // at most 6 weight fragments in flight
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    qf[f][r >> 3][r & 7] = Act<T>::from_f32(aq[r]);
+                    kf[f][r >> 3][r & 7] = Act<T>::from_f32(ak[r]);
+                    vf[f][r >> 3][r & 7] = Act<T>::from_f32(av[r]);
+                }
+            }
+            // ---- attention of this head, one 32-query half at a time ----
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x16 sT[2];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sT[kt][r] = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) sT[kt] = Act<T>::mfma32(kf[kt][s2], qf[qt][s2], sT[kt]);
+                    const int tile = kt * 2 + qt;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bias) + (((h * 4 + tile) * 4 + g4) * 64) * 16 + lds_lane);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sT[kt][4 * g4 + e] = fmaf(sT[kt][4 * g4 + e], scale_l2, bv[e]);
+                    }
+                    if (wtype) {
+                        const unsigned bits = (unsigned)(mb >> (tile * 16)) & 0xffffu;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sT[kt][r] += ((bits >> r) & 1u) ? -144.26950408889634f : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kt][r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pexp = __builtin_amdgcn_exp2f(sT[kt][r] - mx);
+                        sT[kt][r] = pexp;
+                        sum += pexp;
+                    }
+                sum += __shfl_xor(sum, 32, 64);
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        vec8 pf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(sT[kt][8 * s2 + e]);
+                        o = Act<T>::mfma32(vf[kt][s2], pf, o);
+                    }
+                const float inv = 1.0f / sum;
+                vec8 of[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) of[r >> 3][r & 7] = Act<T>::from_f32(o[r] * inv);
+                // ---- projection: this head's 32 input channels = two k-steps ----
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int cf = 0; cf < 3; ++cf)
+                        acc_out[qt][cf] = Act<T>::mfma32(of[s2], *reinterpret_cast<const vec8*>(s_wproj + (cf * 6 + 2 * h + s2) * 1024 + lds_lane), acc_out[qt][cf]);
+            }
+        }
+        const bool more = win + wstep < nwin_total;
+        // ---- x rows += result + bias: register r of (half f) is token p = 32 f + (r&3) + 8 (r>>2) + 4 hi; lanes = channels.
+        // (Starting the accumulators from the residual rows instead, as the MLP kernel does, was measured: same time, 29 spills.)
+        const int b = win / nW;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int pc = min(p, SW_N - 1);
+                const int i = pc / SW_WS, j = pc - i * SW_WS;
+                int hh = wh * SW_WS + i + shift, wc = ww * SW_WS + j + shift;
+                hh = hh >= G ? hh - G : hh;
+                wc = wc >= G ? wc - G : wc;
+                float* row = x + ((long)(b * G + hh) * G + wc) * C + l31;
+                if (f == 0 || (r & 3) + 8 * (r >> 2) < 17) {                 // compile-time: registers that can hold a token < 49
+                    float v0 = row[0], v1 = row[32], v2 = row[64];             // unconditional loads (clamped row), predicated stores
+                    v0 += acc_out[f][0][r] + s_bp[l31];
+                    v1 += acc_out[f][1][r] + s_bp[32 + l31];
+                    v2 += acc_out[f][2][r] + s_bp[64 + l31];
+                    if (p < SW_N) { row[0] = v0; row[32] = v1; row[64] = v2; }
+                }
+            }
+        if (more) {
+            rs_load_raw<KS>(raw[0], x, C, token_row(win + wstep, i0, j0), hi);
+            rs_load_raw<KS>(raw[1], x, C, token_row(win + wstep, i1, j1), hi);
+            rs_normalise<T, KS>(xf[0], raw[0], s_ln + (lds_lane & 1), hi, eps);
+            rs_normalise<T, KS>(xf[1], raw[1], s_ln + (lds_lane & 1), hi, eps);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PatchMerging gather + LayerNorm(4C) (ctranspath.py:717-736).  One wave per output row; the four members of a 2x2
 // cell are concatenated in the reference's order (0,0),(1,0),(0,1),(1,1) [dh = k&1, dw = k>>1].
 // ------------------------------------------------------------------------------------------------
@@ -501,6 +724,40 @@ extern "C" int amds_window_attention(const void* qkv, long ldq, void* out, long 
     return AMDS_ERR_INVALID;
 }
 
+extern "C" int amds_swin_attn96(float* x, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
+                               const float* ln_gamma, const float* ln_beta, const float* bias_lane, const uint64_t* mask_bits, int B,
+                               int grid, int shift, float ln_eps, int dtype, void* stream) {
+    AMDS_REQUIRE(x && qkv_w && qkv_b && proj_w && proj_b && ln_gamma && ln_beta && bias_lane && mask_bits, "amds_swin_attn96: null pointer");
+    AMDS_REQUIRE(grid > 0 && grid % SW_WS == 0, "amds_swin_attn96: grid=%d must be a multiple of 7", grid);
+    AMDS_REQUIRE(shift >= 0 && shift < SW_WS && (shift == 0 || grid > SW_WS), "amds_swin_attn96: bad shift=%d for grid=%d", shift, grid);
+    AMDS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)qkv_w & 15) == 0 && ((uintptr_t)proj_w & 7) == 0, "amds_swin_attn96: misaligned pointers");
+    if (B <= 0) return AMDS_OK;
+    const long nwin = (long)B * (grid / SW_WS) * (grid / SW_WS);
+    AMDS_REQUIRE(nwin < (1L << 30) && (long)B * grid * grid * 96 < (1L << 31), "amds_swin_attn96: batch too large for 32-bit token indexing");
+    hipStream_t st = (hipStream_t)stream;
+    const float scale_l2 = 0.17677669529663687f * 1.4426950408889634f;
+    int gx = (int)((nwin + 3) / 4);
+    if (gx > 256) gx = 256;
+    ProfScope prof(PROF_ATTN, nwin * (2.0 * 49 * 96 * 384 + 4.0 * 3 * 49 * 49 * 32), st);
+#define ATTN96_LAUNCH(T)                                                                                                              \
+    do {                                                                                                                              \
+        static bool attr_set = false;                                                                                                 \
+        if (!attr_set) {                                                                                                              \
+            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_attn96_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS)); \
+            attr_set = true;                                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((swin_attn96_kernel<T>), dim3(gx), dim3(256), SA_LDS, st, x, reinterpret_cast<const T*>(qkv_w), qkv_b,     \
+                           reinterpret_cast<const T*>(proj_w), proj_b, ln_gamma, ln_beta, bias_lane,                                  \
+                           reinterpret_cast<const unsigned long long*>(mask_bits), grid, shift, ln_eps, scale_l2, (int)nwin);         \
+    } while (0)
+    if (dtype == AMDS_F16) ATTN96_LAUNCH(f16);
+    else if (dtype == AMDS_BF16) ATTN96_LAUNCH(bf16);
+    else { set_error("amds_swin_attn96: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+#undef ATTN96_LAUNCH
+    AMDS_LAUNCH_CHECK("swin_attn96_kernel");
+    return AMDS_OK;
+}
+
 extern "C" int amds_patch_merge_ln(const float* x, void* y, const float* gamma, const float* beta, int B, int grid, int dim,
                                    float eps, int dtype, void* stream) {
     AMDS_REQUIRE(x && y && gamma && beta, "amds_patch_merge_ln: null pointer");
@@ -565,10 +822,15 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
         for (int d = 0; d < c->depths[s]; ++d, ++blk) {
             const amds_swin_block& b = w->blocks_host[blk];
             const int shift = (d % 2 == 1 && G > SW_WS) ? SW_WS / 2 : 0;
+            static const bool fuse_attn = getenv("AMDS_SWIN_FUSE_ATTN") ? atoi(getenv("AMDS_SWIN_FUSE_ATTN")) != 0 : true;
             if (narrow) {
-                AMDS_TRY(amds_gemm_rowstream(x, C, b.ln1_w, b.ln1_b, c->ln_eps, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, st));
-                AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_bits, Bc, G, C, c->heads[s], shift, dt, st));
-                AMDS_TRY(amds_gemm_rowstream(h, C, nullptr, nullptr, 0.f, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, st));
+                if (C == 96 && fuse_attn) {     // LN1 + qkv + window attention + proj + residual in one pass over x
+                    AMDS_TRY(amds_swin_attn96(x, b.qkv_w, b.qkv_b, b.proj_w, b.proj_b, b.ln1_w, b.ln1_b, b.bias_lane, w->mask_bits, Bc, G, shift, c->ln_eps, dt, st));
+                } else {
+                    AMDS_TRY(amds_gemm_rowstream(x, C, b.ln1_w, b.ln1_b, c->ln_eps, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, st));
+                    AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_bits, Bc, G, C, c->heads[s], shift, dt, st));
+                    AMDS_TRY(amds_gemm_rowstream(h, C, nullptr, nullptr, 0.f, b.proj_w, C, M, C, C, dt, AMDS_EPI_RESIDUAL, x, C, b.proj_b, st));
+                }
                 if (C == 96) {        // LN2 + fc1 + GELU + fc2 + residual in one pass, hidden activation in registers only
                     AMDS_TRY(amds_swin_mlp96(x, M, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, b.ln2_w, b.ln2_b, c->ln_eps, dt, st));
                 } else {

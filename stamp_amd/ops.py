@@ -287,3 +287,14 @@ def tile_edge_fraction(tiles: torch.Tensor, low: int = 40, high: int = 100, retu
     gray = torch.empty(B, S, S, dtype=torch.uint8, device=tiles.device) if return_maps else None
     _lib.check(_lib.lib().amds_tile_edge_fraction_u8(_p(tiles), _p(frac), _p(edges), _p(gray), B, S, low, high, _stream()), "tile_edge_fraction")
     return (frac, edges, gray) if return_maps else frac
+
+
+def swin_attn96(x: torch.Tensor, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta, bias_lane, mask_bits, grid: int, shift: int,
+                eps: float = 1e-5) -> torch.Tensor:
+    """In place: x += proj(window_attention(qkv(LayerNorm(x)))) for x fp32 [B, grid^2, 96]."""
+    _dev(x, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta, bias_lane, mask_bits)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 96 and x.shape[1] == grid * grid
+    assert qkv_w.shape == (288, 96) and proj_w.shape == (96, 96) and qkv_w.is_contiguous() and proj_w.is_contiguous()
+    _lib.check(_lib.lib().amds_swin_attn96(_p(x), _p(qkv_w), _p(qkv_b), _p(proj_w), _p(proj_b), _p(ln_gamma), _p(ln_beta), _p(bias_lane),
+                                           _p(mask_bits), x.shape[0], grid, shift, eps, act_code(qkv_w.dtype), _stream()), "swin_attn96")
+    return x

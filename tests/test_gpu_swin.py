@@ -215,3 +215,28 @@ def test_swin_mlp96_fused(gpu, M, dt, tol):
     assert _rel(got.cpu(), ref) < tol, _rel(got.cpu(), ref)
     # the branch itself (result minus residual) to the same relative tolerance x10: catches a wrong k-permutation
     assert _rel(got.cpu().double() - x.double(), ref - x.double()) < 10 * tol
+
+
+@pytest.mark.parametrize("grid,shift,B", [(56, 0, 2), (56, 3, 2), (14, 3, 3), (7, 0, 5)])
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+def test_swin_attn96_fused(gpu, grid, shift, B, dt, tol):
+    """x += proj(window_attention(qkv(LN(x)))) in one kernel (q, k, v, P, head outputs only in registers) against the oracle's
+    block arithmetic in fp64 on the same weights (oracle.swin_ctranspath.swin_block, attention half)."""
+    g = torch.Generator().manual_seed(grid * 10 + shift)
+    C, H = 96, 3
+    x = torch.randn(B, grid * grid, C, generator=g) * 1.5 + 0.1
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).to(dt)
+    wproj = (torch.randn(C, C, generator=g) * 0.5 / C ** 0.5).to(dt)
+    bqkv, bproj = torch.randn(3 * C, generator=g) * 0.2, torch.randn(C, generator=g) * 0.2
+    gam, bet = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    table = torch.randn(169, H, generator=g) * 0.7
+    # reference: the oracle's swin_block with an identity MLP half (fc2 = 0) in fp64
+    sd = {"b.norm1.weight": gam, "b.norm1.bias": bet, "b.attn.qkv.weight": wqkv.float(), "b.attn.qkv.bias": bqkv,
+          "b.attn.proj.weight": wproj.float(), "b.attn.proj.bias": bproj, "b.attn.relative_position_bias_table": table,
+          "b.norm2.weight": torch.ones(C), "b.norm2.bias": torch.zeros(C), "b.mlp.fc1.weight": torch.zeros(4 * C, C),
+          "b.mlp.fc1.bias": torch.zeros(4 * C), "b.mlp.fc2.weight": torch.zeros(C, 4 * C), "b.mlp.fc2.bias": torch.zeros(C)}
+    ref = osw.swin_block(x.double(), {k: v.double() for k, v in sd.items()}, "b.", grid, grid, H, shift)
+    got = ops.swin_attn96(x.clone().to(gpu), wqkv.to(gpu), bqkv.to(gpu), wproj.to(gpu), bproj.to(gpu), gam.to(gpu), bet.to(gpu),
+                          rel_bias_lane_table(table).to(gpu), shift_mask_bits().to(gpu), grid, shift)
+    assert _rel(got.cpu(), ref) < tol, _rel(got.cpu(), ref)
+    assert _rel(got.cpu().double() - x.double(), ref - x.double()) < 10 * tol       # the branch alone
