@@ -119,6 +119,12 @@ int amds_gemm_rowstream(const void* A, long lda, const float* ln_gamma, const fl
 int amds_swin_mlp96(float* x, int M, const void* fc1_w, const float* fc1_b, const void* fc2_w, const float* fc2_b,
                     const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream);
 
+/* Same branch for 192-channel blocks (hidden 768), weights streamed through LDS in 12 chunks from an image pre-packed in MFMA
+ * fragment order: amds_swin_mlp192_pack(fc1_w [768][192], fc2_w [192][768], packed [768*192*2 elements]) once per weight set. */
+int amds_swin_mlp192_pack(const void* fc1_w, const void* fc2_w, void* packed, int dtype, void* stream);
+int amds_swin_mlp192(float* x, int M, const void* packed_w, const float* fc1_b, const float* fc2_b, const float* ln_gamma,
+                     const float* ln_beta, float ln_eps, int dtype, void* stream);
+
 /* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default; 0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64
  * staggered two-group pipeline (production), 3 = its BK=32 variant, 7 = four-wave 128x128-wave-tile variant). */
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
@@ -257,6 +263,7 @@ typedef struct {
     const float* ln2_w; const float* ln2_b;
     const void*  fc1_w; const float* fc1_b;     /* [4C][C] */
     const void*  fc2_w; const float* fc2_b;     /* [C][4C] */
+    const void*  mlp_pack;                      /* amds_swin_mlp192_pack image for C = 192 blocks, else NULL */
 } amds_swin_block;
 
 typedef struct {

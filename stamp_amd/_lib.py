@@ -44,7 +44,7 @@ class SwinCfg(C.Structure):
 class SwinBlock(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "bias_lane", "proj_w", "proj_b",
-        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "mlp_pack")]
 
 
 class SwinMerge(C.Structure):
@@ -76,6 +76,8 @@ PROTOTYPES = {
     "amds_gemm_ex": (_i, [_i, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_rowstream": (_i, [_vp, _l, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp]),
     "amds_swin_mlp96": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
+    "amds_swin_mlp192_pack": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "amds_swin_mlp192": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
     "amds_pack_swiglu_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "amds_attention_vit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

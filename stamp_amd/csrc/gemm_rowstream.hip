@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(64 * RS_WAVES) swin_mlp96_kernel(float* x, int
         int lds_lane = lane * 16;                         // opaque per iteration: keeps the weight-fragment ds_reads inside the loop
         asm volatile("" : "+v"(lds_lane));
         if (!PF) rs_load_raw<KS>(raw, x, C, min(row0 + l31, M - 1), hi);
-        rs_normalise<T, KS>(xf, raw, s_ln, hi, eps);
+        rs_normalise<T, KS>(xf, raw, s_ln + (lds_lane & 1), hi, eps);
         // the accumulators of GEMM 2 start from the residual rows (+ b2); requested before any MFMA
         f32x16 acc2[NC];
         if (full) {
@@ -396,6 +396,158 @@ __global__ void __launch_bounds__(64 * RS_WAVES) swin_mlp96_kernel(float* x, int
                 float* ub = x + (long)(row0 + rr) * C + 32 * cf;
                 if (full || row0 + 4 * hi + rr < M) ub[lane_off] = acc2[cf][r];
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MLP branch of a 192-channel Swin block (stage 2) in one pass over the residual stream, weights STREAMED through LDS:
+//     x += W2 gelu(W1 LN(x) + b1) + b2          x fp32 [M][192], hidden 768
+// Same register-level chaining as swin_mlp96_kernel (the GELU'd fc1 accumulator is the A operand of fc2), but the two
+// weight matrices (590 KB) do not fit LDS: a workgroup (4 waves x 32 rows = 128 rows) walks the hidden dimension in 12
+// chunks of 64 units; chunk c of both matrices is one contiguous 48 KB block of the pre-packed weight image
+// (amds_swin_mlp_pack: MFMA fragment order, fc2 with the k-permutation baked in), copied by LDS-DMA into a double buffer
+// two chunks ahead of its use (three buffers) -- one barrier per chunk.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MS_CHUNK_BYTES = 49152;      // 2 fc1 fragments x 12 k-steps + 6 channel fragments x 4 k-steps, 1 KB each
+
+constexpr int MS_WAVES = 4;                // one wave per SIMD: the 96 + 48 + 16 accumulator / operand registers of a row group need > 256
+
+template <typename T>
+__global__ void __launch_bounds__(64 * MS_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1)))
+swin_mlp192_kernel(float* x, int M, const char* __restrict__ wpack, const float* __restrict__ b1,
+                                                                    const float* __restrict__ b2, const float* __restrict__ ln_g,
+                                                                    const float* __restrict__ ln_b, float eps, int nblocks) {
+    typedef typename Act<T>::vec8 vec8;
+    constexpr int C = 192, H = 768, KS = 12, NC = 6, NCH = H / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;                                                    // [3][48 KB]
+    float* s_ln = reinterpret_cast<float*>(smem + 3 * MS_CHUNK_BYTES);   // gamma[192] beta[192]
+    float* s_b1 = s_ln + 2 * C;                                          // [768]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    for (int i = tid; i < C; i += 64 * MS_WAVES) { s_ln[i] = ln_g[i]; s_ln[C + i] = ln_b[i]; }
+    for (int i = tid; i < H; i += 64 * MS_WAVES) s_b1[i] = b1[i];
+    float bv[NC];
+#pragma unroll
+    for (int cf = 0; cf < NC; ++cf) bv[cf] = b2[32 * cf + l31];
+    // every wave copies 12 of the 48 1-KB pieces of a chunk
+    auto load_chunk = [&](int hc, int buf) {
+        const char* src = wpack + (size_t)hc * MS_CHUNK_BYTES;
+        char* dst = s_w + buf * MS_CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < 48 / MS_WAVES; ++i) {
+            const int piece = wave * (48 / MS_WAVES) + i;
+            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
+        }
+    };
+    const int lane_off = 4 * hi * C + l31;
+    // three LDS buffers: chunk c+2 is requested while chunk c is consumed (two chunks = ~4 us of latency cover)
+    int buf = 0;
+    load_chunk(0, 0);
+    load_chunk(1, 1);
+    for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        const int row0 = rb * (32 * MS_WAVES) + wave * 32;
+        const bool full = row0 + 32 <= M;
+        int lds_lane = lane * 16;
+        asm volatile("" : "+v"(lds_lane));
+        vec8 xf[KS];
+        {
+            f32x4 raw[KS][2];
+            rs_load_raw<KS>(raw, x, C, min(row0 + l31, M - 1), hi);
+            rs_normalise<T, KS>(xf, raw, s_ln + (lds_lane & 1), hi, eps);      // opaque 0: gamma / beta reads are loop invariant and
+                                                                               // would otherwise be hoisted (192 registers) and spilled
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the 96 raw registers are dead before the 96 residual loads are requested
+        f32x16 acc2[NC];
+        if (full) {
+#pragma unroll
+            for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[cf][r] = (x + (long)(row0 + (r & 3) + 8 * (r >> 2)) * C + 32 * cf)[lane_off];
+        } else {
+#pragma unroll
+            for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[cf][r] = x[(long)min(row0 + 4 * hi + (r & 3) + 8 * (r >> 2), M - 1) * C + 32 * cf + l31];
+        }
+#pragma unroll
+        for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[cf][r] += bv[cf];
+#pragma unroll 1
+        for (int hc = 0; hc < NCH; ++hc) {
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // this wave's 12 pieces of chunk hc have landed (chunk hc+1 may be in flight) ...
+            __syncthreads();                                     // ... and everybody's; every wave is done with the buffer of chunk hc-1
+            const int nxt = hc + 2 < NCH ? hc + 2 : hc + 2 - NCH;
+            const int b2 = buf == 0 ? 2 : buf - 1;               // (buf + 2) % 3 = the buffer chunk hc-1 occupied
+            if (hc + 2 < NCH || rb + gridDim.x < nblocks) load_chunk(nxt, b2);   // wraps into the next row block's first chunks
+            else asm volatile("s_nop 0");
+            const char* wb = s_w + buf * MS_CHUNK_BYTES + lds_lane;
+            // both hidden fragments of the chunk at once: two independent MFMA chains (one wave per SIMD: a single chain
+            // would expose the full MFMA latency at every k-step)
+            f32x16 acc1[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + 64 * hc + 32 * jj + 8 * g4 + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc1[jj][4 * g4 + e] = bb[e];
+                }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                acc1[0] = Act<T>::mfma32(*reinterpret_cast<const vec8*>(wb + ks * 1024), xf[ks], acc1[0]);
+                acc1[1] = Act<T>::mfma32(*reinterpret_cast<const vec8*>(wb + (KS + ks) * 1024), xf[ks], acc1[1]);
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            vec8 hf[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = gelu_erf_poly2(f32x2{acc1[jj][r], acc1[jj][r + 1]});
+                    hf[jj][r >> 3][r & 7] = Act<T>::from_f32(v[0]);
+                    hf[jj][r >> 3][(r & 7) + 1] = Act<T>::from_f32(v[1]);
+                }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int cf = 0; cf < NC; ++cf)
+                        acc2[cf] = Act<T>::mfma32(hf[jj][s2], *reinterpret_cast<const vec8*>(wb + 24576 + (cf * 4 + 2 * jj + s2) * 1024), acc2[cf]);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+#pragma unroll
+        for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float* ub = x + (long)(row0 + rr) * C + 32 * cf;
+                if (full || row0 + 4 * hi + rr < M) ub[lane_off] = acc2[cf][r];
+            }
+    }
+}
+
+// weight image for swin_mlp192_kernel: 12 chunks of 48 KB = [fc1: 2 fragments x 12 k-steps][fc2: 6 channel fragments x 4 k-steps],
+// every fragment 64 lanes x 8 elements in MFMA register order.
+template <typename T>
+__global__ void swin_mlp192_pack_kernel(const T* __restrict__ w1, const T* __restrict__ w2, T* __restrict__ out) {
+    constexpr int C = 192, H = 768;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // one 8-element lane slot
+    if (idx >= 12 * 48 * 64) return;
+    const int lane = idx & 63, piece = (idx >> 6) % 48, hc = idx / (48 * 64);
+    const int l31 = lane & 31, hi = lane >> 5;
+    T* dst = out + (size_t)idx * 8;
+    if (piece < 24) {                       // fc1: rows = hidden units, k = input channels
+        const int jj = piece / 12, ks = piece - jj * 12;
+        const T* src = w1 + (size_t)(64 * hc + 32 * jj + l31) * C + 16 * ks + 8 * hi;
+        for (int e = 0; e < 8; ++e) dst[e] = src[e];
+    } else {                                // fc2 as B operand: lane = output channel, slots = hidden units (permuted)
+        const int q = piece - 24, cf = q >> 2, s4 = q & 3;
+        const T* src = w2 + (size_t)(32 * cf + l31) * H + 64 * hc + 16 * s4 + 4 * hi;
+        for (int e = 0; e < 4; ++e) { dst[e] = src[e]; dst[4 + e] = src[8 + e]; }
     }
 }
 
@@ -527,5 +679,45 @@ extern "C" int amds_swin_mlp96(float* x, int M, const void* fc1_w, const float* 
     else { set_error("amds_swin_mlp96: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
 #undef MLP96_LAUNCH
     AMDS_LAUNCH_CHECK("swin_mlp96_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_swin_mlp192_pack(const void* fc1_w, const void* fc2_w, void* packed, int dtype, void* stream) {
+    AMDS_REQUIRE(fc1_w && fc2_w && packed, "amds_swin_mlp192_pack: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = 12 * 48 * 64;
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((swin_mlp192_pack_kernel<f16>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const f16*)fc1_w, (const f16*)fc2_w, (f16*)packed);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((swin_mlp192_pack_kernel<bf16>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16*)fc1_w, (const bf16*)fc2_w, (bf16*)packed);
+    else { set_error("amds_swin_mlp192_pack: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("swin_mlp192_pack_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_swin_mlp192(float* x, int M, const void* packed_w, const float* fc1_b, const float* fc2_b, const float* ln_gamma,
+                                const float* ln_beta, float ln_eps, int dtype, void* stream) {
+    AMDS_REQUIRE(x && packed_w && fc1_b && fc2_b && ln_gamma && ln_beta, "amds_swin_mlp192: null pointer");
+    AMDS_REQUIRE(M >= 0, "amds_swin_mlp192: bad M=%d", M);
+    AMDS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "amds_swin_mlp192: misaligned pointers");
+    if (M == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 3 * MS_CHUNK_BYTES + (2 * 192 + 768) * 4;
+    const int nblocks = cdiv(M, 32 * MS_WAVES);
+    const int gx = nblocks < 256 ? nblocks : 256;
+    ProfScope prof(PROF_GEMM, 4.0 * M * 192.0 * 768.0, st);
+#define MLP192_LAUNCH(T)                                                                                                              \
+    do {                                                                                                                              \
+        static bool attr_set = false;                                                                                                 \
+        if (!attr_set) {                                                                                                              \
+            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp192_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((swin_mlp192_kernel<T>), dim3(gx), dim3(64 * MS_WAVES), lds, st, x, M, reinterpret_cast<const char*>(packed_w), fc1_b, fc2_b, \
+                           ln_gamma, ln_beta, ln_eps, nblocks);                                                                       \
+    } while (0)
+    if (dtype == AMDS_F16) MLP192_LAUNCH(f16);
+    else if (dtype == AMDS_BF16) MLP192_LAUNCH(bf16);
+    else { set_error("amds_swin_mlp192: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+#undef MLP192_LAUNCH
+    AMDS_LAUNCH_CHECK("swin_mlp192_kernel");
     return AMDS_OK;
 }

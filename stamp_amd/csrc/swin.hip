@@ -833,6 +833,8 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
                 }
                 if (C == 96) {        // LN2 + fc1 + GELU + fc2 + residual in one pass, hidden activation in registers only
                     AMDS_TRY(amds_swin_mlp96(x, M, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, b.ln2_w, b.ln2_b, c->ln_eps, dt, st));
+                } else if (C == 192 && b.mlp_pack) {     // same fusion, weights streamed through LDS
+                    AMDS_TRY(amds_swin_mlp192(x, M, b.mlp_pack, b.fc1_b, b.fc2_b, b.ln2_w, b.ln2_b, c->ln_eps, dt, st));
                 } else {
                     AMDS_TRY(amds_gemm_rowstream(x, C, b.ln2_w, b.ln2_b, c->ln_eps, b.fc1_w, C, M, 4 * C, C, dt, AMDS_EPI_BIAS_GELU, big, 4 * C, b.fc1_b, st));
                     AMDS_TRY(amds_gemm(big, 4 * C, b.fc2_w, 4 * C, M, C, 4 * C, dt, AMDS_EPI_RESIDUAL, x, C, b.fc2_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));

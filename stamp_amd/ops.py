@@ -298,3 +298,21 @@ def swin_attn96(x: torch.Tensor, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta
     _lib.check(_lib.lib().amds_swin_attn96(_p(x), _p(qkv_w), _p(qkv_b), _p(proj_w), _p(proj_b), _p(ln_gamma), _p(ln_beta), _p(bias_lane),
                                            _p(mask_bits), x.shape[0], grid, shift, eps, act_code(qkv_w.dtype), _stream()), "swin_attn96")
     return x
+
+
+def swin_mlp192_pack(fc1_w: torch.Tensor, fc2_w: torch.Tensor) -> torch.Tensor:
+    """[768,192] and [192,768] (act dtype) -> the fragment-ordered weight image amds_swin_mlp192 streams through LDS."""
+    _dev(fc1_w, fc2_w)
+    assert fc1_w.shape == (768, 192) and fc2_w.shape == (192, 768) and fc1_w.is_contiguous() and fc2_w.is_contiguous() and fc1_w.dtype == fc2_w.dtype
+    out = torch.empty(2 * 768 * 192, dtype=fc1_w.dtype, device=fc1_w.device)
+    _lib.check(_lib.lib().amds_swin_mlp192_pack(_p(fc1_w), _p(fc2_w), _p(out), act_code(fc1_w.dtype), _stream()), "swin_mlp192_pack")
+    return out
+
+
+def swin_mlp192(x: torch.Tensor, packed_w: torch.Tensor, fc1_b, fc2_b, ln_gamma, ln_beta, eps: float = 1e-5) -> torch.Tensor:
+    """In place: x += fc2(gelu(fc1(LayerNorm(x)))) for x fp32 [M, 192]."""
+    _dev(x, packed_w, fc1_b, fc2_b, ln_gamma, ln_beta)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 192 and packed_w.numel() == 2 * 768 * 192
+    _lib.check(_lib.lib().amds_swin_mlp192(_p(x), x.numel() // 192, _p(packed_w), _p(fc1_b), _p(fc2_b), _p(ln_gamma), _p(ln_beta), eps,
+                                           act_code(packed_w.dtype), _stream()), "swin_mlp192")
+    return x

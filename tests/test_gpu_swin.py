@@ -240,3 +240,22 @@ def test_swin_attn96_fused(gpu, grid, shift, B, dt, tol):
                           rel_bias_lane_table(table).to(gpu), shift_mask_bits().to(gpu), grid, shift)
     assert _rel(got.cpu(), ref) < tol, _rel(got.cpu(), ref)
     assert _rel(got.cpu().double() - x.double(), ref - x.double()) < 10 * tol       # the branch alone
+
+
+@pytest.mark.parametrize("M", [128, 784 * 5 + 9])
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-4), (torch.bfloat16, 5e-3)])
+def test_swin_mlp192_streamed(gpu, M, dt, tol):
+    """Stage-2 MLP branch with weights streamed through LDS from the pre-packed fragment image, vs fp64."""
+    g = torch.Generator().manual_seed(M + 1)
+    C, Hd = 192, 768
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.2
+    w1 = (torch.randn(Hd, C, generator=g) / C ** 0.5).to(dt)
+    w2 = (torch.randn(C, Hd, generator=g) * 0.5 / Hd ** 0.5).to(dt)
+    b1, b2 = torch.randn(Hd, generator=g) * 0.2, torch.randn(C, generator=g) * 0.2
+    gam, bet = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    h = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    ref = x.double() + F.gelu(h @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    pk = ops.swin_mlp192_pack(w1.to(gpu), w2.to(gpu))
+    got = ops.swin_mlp192(x.clone().to(gpu), pk, b1.to(gpu), b2.to(gpu), gam.to(gpu), bet.to(gpu))
+    assert _rel(got.cpu(), ref) < tol, _rel(got.cpu(), ref)
+    assert _rel(got.cpu().double() - x.double(), ref - x.double()) < 10 * tol
