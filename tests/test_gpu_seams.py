@@ -97,3 +97,40 @@ def test_ctranspath_extractor_seam(gpu):
     assert feats.shape == (9, cfg.out_dim) and ((feats.float() - ref.float()).norm() / ref.float().norm()).item() < 1.5e-3
     assert torch.equal(extract_tiles(ex, tiles, batch_size=5, device=gpu), feats)
     assert extract_tiles(ex, tiles[:0], device=gpu).shape == (0, cfg.out_dim)
+
+
+def test_chief_pipeline_tiles_to_slide_embedding(gpu):
+    """The reference's `chief-ctranspath` chain end to end on the HIP path: decoded tiles -> background filter ->
+    CTransPath features (fp16, what the .h5 holds) -> CHIEF gated-attention pooling -> 768-d slide embedding, against the
+    same chain through the oracle (both halves pinned to the reference: ctranspath.py, chief.py)."""
+    from oracle.gated_attention import KEYS, gated_attention_pool
+    from oracle.swin_ctranspath import swin_encode_f16
+    from oracle import texture
+    from stamp_amd.encoder import HipGatedAttentionEncoder
+    from stamp_amd.extractor import extract_tiles, has_enough_texture, hip_ctranspath_extractor
+    from stamp_amd.swin import SWIN_PRESETS, random_swin_state_dict
+
+    cfg = SWIN_PRESETS["ctranspath"]
+    sd = random_swin_state_dict(cfg, seed=31)
+    rng = np.random.default_rng(3)
+    tiles = rng.integers(0, 256, (12, 224, 224, 3), dtype=np.uint8)
+    tiles[3] = 240                                           # two blank tiles: the filter must drop exactly these
+    tiles[7] = 255
+    tiles_t = torch.from_numpy(tiles)
+    keep = has_enough_texture(tiles_t.to(gpu), cutoff=0.02).cpu()
+    assert keep.tolist() == [texture.has_enough_texture(t, 0.02) for t in tiles] and keep.sum() == 10
+    ex = hip_ctranspath_extractor(sd, identifier="chief-ctranspath", device=gpu, chunk=4)
+    feats = extract_tiles(ex, tiles_t[keep], batch_size=6, device=gpu)               # fp16 [10, 768] on the host
+    ref_feats = swin_encode_f16(tiles_t[keep], sd, cfg)
+    assert ((feats.float() - ref_feats.float()).norm() / ref_feats.float().norm()).item() < 1.5e-3
+    g = torch.Generator().manual_seed(9)
+    F_, L, D = 768, 512, 256
+    csd = {KEYS["fc_w"]: torch.randn(L, F_, generator=g) / F_ ** 0.5, KEYS["fc_b"]: torch.randn(L, generator=g) * 0.1,
+           KEYS["a_w"]: torch.randn(D, L, generator=g) / L ** 0.5, KEYS["a_b"]: torch.randn(D, generator=g) * 0.1,
+           KEYS["b_w"]: torch.randn(D, L, generator=g) / L ** 0.5, KEYS["b_b"]: torch.randn(D, generator=g) * 0.1,
+           KEYS["c_w"]: torch.randn(1, D, generator=g), KEYS["c_b"]: torch.randn(1, generator=g)}
+    enc = HipGatedAttentionEncoder(csd, device=gpu)
+    assert "chief-ctranspath" in enc.required_extractors and ex.identifier in enc.required_extractors
+    emb = enc._generate_slide_embedding(feats.float(), device=gpu)                    # the reference reads the h5 as fp32 (chief.py:117)
+    ref_emb = gated_attention_pool(ref_feats.float(), csd)["WSI_feature"].reshape(-1).numpy()
+    assert emb.shape == (768,) and np.linalg.norm(emb - ref_emb) / np.linalg.norm(ref_emb) < 2e-3
