@@ -86,6 +86,123 @@ __global__ void __launch_bounds__(256) bgemm_f32_kernel(const float* __restrict_
     }
 }
 
+// 128 x 128 tile variant for the large batched products (Nystrom pinv iterations 256^3, q k_l^T, projections): each wave owns
+// 64 x 64 = 2 x 2 MFMA fragments, so one LDS operand read feeds two MFMAs; the LDS image is [row][k parity][k / 2] so that the
+// 8 values a lane needs per 16-deep k-tile (k = hi, hi + 2, ...) are two ds_read_b128; global loads are float4 and the next
+// k-tile is fetched into registers while the current one is multiplied.  Requires K, lda, ldb multiples of 4 and 16-byte
+// aligned operands; the 64 x 64 kernel above remains the fallback.
+template <int TRANSB>
+__global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restrict__ A, int lda, long sAo, long sAi,
+                                                            const float* __restrict__ B, int ldb, long sBo, long sBi,
+                                                            float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
+                                                            int M, int N, int K, float alpha, float diag,
+                                                            const float* __restrict__ bias, int accumulate) {
+    constexpr int BT = 128, BK = 16, LDT = 20;
+    __shared__ __attribute__((aligned(16))) float sA[BT * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[BT * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int zo = blockIdx.z / inner, zi = blockIdx.z - zo * inner;
+    A += zo * sAo + zi * sAi;
+    B += zo * sBo + zi * sBi;
+    Cm += zo * sCo + zi * sCi;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4;
+            const int gm = m0 + row;
+            ra[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gm < M && k0 + c4 < K) ra[it] = *reinterpret_cast<const f32x4*>(A + (long)gm * lda + k0 + c4);
+            rb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TRANSB) {
+                const int gn = n0 + row;
+                if (gn < N && k0 + c4 < K) rb[it] = *reinterpret_cast<const f32x4*>(B + (long)gn * ldb + k0 + c4);
+            } else {                                  // B stored [K][N]: float4 along n
+                const int k = c >> 5, n4 = (c & 31) * 4;
+                const int gk = k0 + k, gn = n0 + n4;
+                if (gk < K && gn + 3 < N) rb[it] = *reinterpret_cast<const f32x4*>(B + (long)gk * ldb + gn);
+                else if (gk < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gn + e < N) rb[it][e] = B[(long)gk * ldb + gn + e];
+                }
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = c4 + e;
+                sA[row * LDT + (k & 1) * 8 + (k >> 1)] = ra[it][e];
+            }
+            if (TRANSB) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c4 + e;
+                    sB[row * LDT + (k & 1) * 8 + (k >> 1)] = rb[it][e];
+                }
+            } else {
+                const int k = c >> 5, n4 = (c & 31) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sB[(n4 + e) * LDT + (k & 1) * 8 + (k >> 1)] = rb[it][e];
+            }
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* pa = sA + (wm * 64 + i * 32 + l31) * LDT + hi * 8;
+            fa[i][0] = *reinterpret_cast<const f32x4*>(pa);
+            fa[i][1] = *reinterpret_cast<const f32x4*>(pa + 4);
+            const float* pb = sB + (wn * 64 + i * 32 + l31) * LDT + hi * 8;
+            fb[i][0] = *reinterpret_cast<const f32x4*>(pb);
+            fb[i][1] = *reinterpret_cast<const f32x4*>(pb + 4);
+        }
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kp >> 2][kp & 3], fb[j][kp >> 2][kp & 3], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= N) continue;
+        const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < M) {
+                    float v = alpha * acc[i][j][r] + (m == n ? diag : 0.f) + bn;
+                    if (accumulate) v += Cm[(long)m * ldc + n];
+                    Cm[(long)m * ldc + n] = v;
+                }
+            }
+    }
+}
+
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long rows, int cols) {
     __shared__ float red[4];
     const long row = blockIdx.x;
@@ -191,9 +308,18 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
                               float diag, const float* bias, int accumulate, void* stream) {
     AMDS_REQUIRE(A && B && Cm, "amds_bgemm_f32: null pointer");
     AMDS_REQUIRE(outer > 0 && inner > 0 && (long)outer * inner <= 65535 && M > 0 && N > 0 && K > 0, "amds_bgemm_f32: bad sizes");
-    const dim3 grid(cdiv(N, 64), cdiv(M, 64), outer * inner);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM_F32, 2.0 * outer * inner * (double)M * N * K, st);
+    const bool vec_ok = K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && sAo % 4 == 0 && sAi % 4 == 0 && sBo % 4 == 0 && sBi % 4 == 0 &&
+                        ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+    if (vec_ok && M >= 96 && N >= 96) {
+        const dim3 gbig(cdiv(N, 128), cdiv(M, 128), outer * inner);
+        if (transb) hipLaunchKernelGGL((bgemm_f32_big_kernel<1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
+        else hipLaunchKernelGGL((bgemm_f32_big_kernel<0>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
+        AMDS_LAUNCH_CHECK("bgemm_f32_big_kernel");
+        return AMDS_OK;
+    }
+    const dim3 grid(cdiv(N, 64), cdiv(M, 64), outer * inner);
     if (transb) hipLaunchKernelGGL((bgemm_f32_kernel<1>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
     else hipLaunchKernelGGL((bgemm_f32_kernel<0>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
     AMDS_LAUNCH_CHECK("bgemm_f32_kernel");
