@@ -215,17 +215,18 @@ def main() -> None:
         del trn, mil_a
         from stamp_amd.mil import TransMIL as HipTransMIL
         tm = HipTransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().to(ctx.device)
-        bags8 = bags[:8].float()
+        bags_f = bags.float()
         with torch.no_grad():
-            tm(bags8)
+            tm(bags_f)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(3):
-                lg2 = tm(bags8)
+                lg2 = tm(bags_f)
             torch.cuda.synchronize()
         dt_tm = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 3)
-        line["secondary"]["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 8, exact-fp32 MFMA)",
-                                         "value": round(8 * ctx.world / dt_tm, 1), "finite": bool(torch.isfinite(lg2).all())}
+        line["secondary"]["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 64, exact-fp32 MFMA)",
+                                         "value": round(64 * ctx.world / dt_tm, 1), "finite": bool(torch.isfinite(lg2).all())}
+        del bags_f
         if not is_swin:     # the reference's in-tree tile encoder, same tile shape
             scfg = SWIN_PRESETS["ctranspath"]
             sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)
