@@ -12,6 +12,7 @@
 // order inside each 16-key group is permuted (bits 2<->3) in the LDS image so that a lane's 8 P values of
 // a K=16 step are exactly its accumulator registers 8*ks .. 8*ks+7 -- no cross-lane shuffles at all.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace amds {
@@ -22,15 +23,28 @@ constexpr int ATT_D = 64;
 // and the transposing ds_write_b32 of staging is at most 2-way (free) -- found by exhaustive search.
 __host__ __device__ constexpr int vt_row_bytes(int nkt) { return (nkt & 1) ? nkt * 64 : nkt * 64 + 64; }
 
-template <typename T, int NKT>  // NKT = ceil(T/32) key tiles
+// TAIL: T = 32 NKT + 1 -- the shape of every "class token + 16x16 patches" encoder (257).  Rounding 257 up to 9 query blocks and
+// 9 key tiles costs 12 % + 12 % padded MFMA work and, worse, 9 query blocks over 4 waves leave one wave with 3 of them (the
+// workgroup's critical path: 27 tile pairs where 16 would do).  With TAIL the MFMA path covers exactly 32 NKT queries x 32 NKT
+// keys (2 query blocks per wave), the odd KEY is folded into every query's online softmax as a rank-1 VALU update, and the odd
+// QUERY is a 257-key GEMV split over the four waves (lane = key for the scores, lane = dim for the output).
+template <typename T, int NKT, bool TAIL = false>  // NKT = key tiles of 32 on the MFMA path
 __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     constexpr int KP = NKT * 32;
     constexpr int VS = vt_row_bytes(NKT);
-    __shared__ __attribute__((aligned(16))) char smem[KP * 128 + ATT_D * VS + 8 * 16];
+    constexpr int MAIN = KP * 128 + ATT_D * VS + 8 * 16;
+    constexpr int XTRA = TAIL ? (3 * 64 + KP + 8 + 4 * 64) * 4 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[MAIN + XTRA];
     char* sK = smem;
     char* sVt = smem + KP * 128;
+    float* sKt = reinterpret_cast<float*>(smem + MAIN);     // tail key [64] | tail value [64] | tail query [64] | P [KP] | red [8] | part [4][64]
+    float* sVl = sKt + 64;
+    float* sQt = sVl + 64;
+    float* sP = sQt + 64;
+    float* sRed = sP + KP;
+    float* sPart = sRed + 8;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,15 +64,15 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ 
     for (int it = 0; it < K_IT; ++it) {
         const int c = it * 256 + tid, key = c >> 3, ch = c & 7;
         kv[it] = u32x4{0u, 0u, 0u, 0u};
-        if (key < Tn) kv[it] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
+        if (key < (TAIL ? KP : Tn)) kv[it] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < V_IT; ++it) {
         const int c = it * 256 + tid, k0 = (c >> 3) * 2, ch = c & 7;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v0[it][e] = (T)0.f; v1[it][e] = (T)0.f; }
-        if (k0 < Tn) v0[it] = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
-        if (k0 + 1 < Tn) v1[it] = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
+        if (k0 < (TAIL ? KP : Tn)) v0[it] = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
+        if (k0 + 1 < (TAIL ? KP : Tn)) v1[it] = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < K_IT; ++it) {
@@ -80,11 +94,19 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ 
             }
         }
     }
+    if constexpr (TAIL) {
+        if (tid < 64) {
+            const T* tr = base + (long)KP * ld + tid;                  // token KP = the odd one
+            sQt[tid] = Act<T>::to_f32(tr[0]);
+            sKt[tid] = Act<T>::to_f32(tr[Dm]);
+            sVl[tid] = Act<T>::to_f32(tr[2 * Dm]);
+        }
+    }
     __syncthreads();
 
     const float sc = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
     const int swz = (l31 >> 1) & 7;
-    const int nqb = (Tn + 31) >> 5;
+    const int nqb = TAIL ? NKT : (Tn + 31) >> 5;
 
     // 9 query blocks over 4 waves leaves one wave with 3: rotate which wave (= which SIMD) that is from block to block, so
     // the two (or more) workgroups sharing a CU do not pile their heavy waves on the same SIMD
@@ -170,6 +192,28 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ 
 #pragma unroll 1
         for (int c = 0; c < NKT / CH; ++c) chunk(std::integral_constant<int, CH>{}, c * CH);
         if constexpr (NKT % CH != 0) chunk(std::integral_constant<int, (NKT % CH == 0 ? 1 : NKT % CH)>{}, (NKT / CH) * CH);
+        if constexpr (TAIL) {      // the odd key: rank-1 update of this block's 32 queries (dot product split over the lane pair)
+            float dot = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8), k1 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot = fmaf(Act<T>::to_f32(qf[ks][e]), k0[e], fmaf(Act<T>::to_f32(qf[ks][4 + e]), k1[e], dot));
+            }
+            dot += __shfl_xor(dot, 32, 64);
+            const float st = dot * sc, mnew = fmaxf(mrun, st);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew), pt = __builtin_amdgcn_exp2f(st - mnew);
+            mrun = mnew;
+            l = l * alpha + (hi == 0 ? pt : 0.f);                     // l is a per-lane partial: count the key once per query
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(sVl + dt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[dt][4 * g + e] = fmaf(o[dt][4 * g + e], alpha, pt * vv[e]);
+                }
+        }
         l += __shfl_xor(l, 32, 64);
         if (q < Tn) {
             const float inv = 1.0f / l;
@@ -185,12 +229,75 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const T* __restrict__ 
                 }
         }
     }
+    if constexpr (TAIL) {
+        // ---- the odd query against all KP + 1 keys: scores with lane = key (wave w owns keys 64 w ..), output with lane = dim ----
+        const int key = tid;
+        float sv = -INFINITY;
+        if (key < KP) {
+            float dot = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const vec8 kk = *reinterpret_cast<const vec8*>(sK + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4));
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(sQt + ch * 8), q1 = *reinterpret_cast<const f32x4*>(sQt + ch * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot = fmaf(Act<T>::to_f32(kk[e]), q0[e], fmaf(Act<T>::to_f32(kk[4 + e]), q1[e], dot));
+            }
+            sv = dot * sc;
+        }
+        float st = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sQt + d4 * 4), bq = *reinterpret_cast<const f32x4*>(sKt + d4 * 4);
+            st += (a[0] * bq[0] + a[1] * bq[1]) + (a[2] * bq[2] + a[3] * bq[3]);
+        }
+        st *= sc;
+        const float wm = wave_max(sv);
+        if (lane == 0) sRed[wave] = wm;
+        __syncthreads();
+        const float m = fmaxf(fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3])), st);
+        const float pk = key < KP ? __builtin_amdgcn_exp2f(sv - m) : 0.f;
+        if (key < KP) sP[(key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1)] = pk;       // the V^T image's key order
+        const float ws = wave_sum(pk);
+        if (lane == 0) sRed[4 + wave] = ws;
+        __syncthreads();
+        const float ptl = __builtin_amdgcn_exp2f(st - m);
+        const float ltot = ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7])) + ptl;
+        const int d = lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const int pos0 = wave * 64 + c8 * 8;
+            if (pos0 < KP) {
+                const vec8 vv = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos0 * 2);
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sP + pos0), p1 = *reinterpret_cast<const f32x4*>(sP + pos0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fmaf(Act<T>::to_f32(vv[e]), p0[e], fmaf(Act<T>::to_f32(vv[4 + e]), p1[e], acc));
+            }
+        }
+        sPart[wave * 64 + d] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            const float ov = ((sPart[d] + sPart[64 + d]) + (sPart[128 + d] + sPart[192 + d])) + ptl * sVl[d];
+            out[((long)b * Tn + KP) * Dm + h * ATT_D + d] = Act<T>::from_f32(ov / ltot);
+        }
+    }
 }
 
 template <typename T>
 static int launch_attn(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
-    const int nkt = (Tn + 31) / 32;
     const dim3 grid(B * H), block(256);
+    static const bool tail_on = getenv("AMDS_ATTN_TAIL") ? atoi(getenv("AMDS_ATTN_TAIL")) != 0 : true;
+    if (tail_on && Tn % 32 == 1 && Tn > 32) {      // class token + a multiple of 32 patches: MFMA on the 32-multiple, VALU for the odd token
+        switch (Tn / 32) {
+#define AMDS_ATT_TAIL(N) \
+    case N: hipLaunchKernelGGL((attn_vit_kernel<T, N, true>), grid, block, 0, st, (const T*)qkv, (T*)out, Tn, H); break;
+            AMDS_ATT_TAIL(1) AMDS_ATT_TAIL(2) AMDS_ATT_TAIL(3) AMDS_ATT_TAIL(4) AMDS_ATT_TAIL(5) AMDS_ATT_TAIL(6) AMDS_ATT_TAIL(7) AMDS_ATT_TAIL(8)
+#undef AMDS_ATT_TAIL
+        }
+        AMDS_LAUNCH_CHECK("attn_vit_kernel<tail>");
+        return AMDS_OK;
+    }
+    const int nkt = (Tn + 31) / 32;
     switch (nkt) {
 #define AMDS_ATT_CASE(N) \
     case N: hipLaunchKernelGGL((attn_vit_kernel<T, N>), grid, block, 0, st, (const T*)qkv, (T*)out, Tn, H); break;
