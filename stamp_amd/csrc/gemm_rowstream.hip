@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(64 * RS_WAVES) rowstream_f32out_kernel(const T
 // (lane = output channel, register = row): coalesced 128-byte row segments for the residual read-modify-write.
 // HBM traffic: one read and one write of x (616 MB per 256 tiles) instead of 2.2 GB for LN / fc1 / fc2 kernels.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, bool PF>
+template <typename T>
 __global__ void __launch_bounds__(64 * RS_WAVES) swin_mlp96_kernel(float* x, int M, const T* __restrict__ W1, const float* __restrict__ b1,
                                                                    const T* __restrict__ W2, const float* __restrict__ b2,
                                                                    const float* __restrict__ ln_g, const float* __restrict__ ln_b,
@@ -336,13 +336,13 @@ __global__ void __launch_bounds__(64 * RS_WAVES) swin_mlp96_kernel(float* x, int
     int g = __builtin_amdgcn_readfirstlane(blockIdx.x * RS_WAVES + wave);
     f32x4 raw[KS][2];
     vec8 xf[KS];
-    if (PF && g < groups) rs_load_raw<KS>(raw, x, C, min(g * 32 + l31, M - 1), hi);
     for (; g < groups; g += gstep) {
         const int row0 = g * 32;
         const bool full = row0 + 32 <= M;
         int lds_lane = lane * 16;                         // opaque per iteration: keeps the weight-fragment ds_reads inside the loop
         asm volatile("" : "+v"(lds_lane));
-        if (!PF) rs_load_raw<KS>(raw, x, C, min(row0 + l31, M - 1), hi);
+        // (prefetching the next group's rows here was measured: the 48 extra live registers spill, 29.7 -> 30.8 ms per 1024 tiles)
+        rs_load_raw<KS>(raw, x, C, min(row0 + l31, M - 1), hi);
         rs_normalise<T, KS>(xf, raw, s_ln + (lds_lane & 1), hi, eps);
         // the accumulators of GEMM 2 start from the residual rows (+ b2); requested before any MFMA
         f32x16 acc2[NC];
@@ -357,7 +357,6 @@ __global__ void __launch_bounds__(64 * RS_WAVES) swin_mlp96_kernel(float* x, int
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[cf][r] = x[(long)min(row0 + 4 * hi + (r & 3) + 8 * (r >> 2), M - 1) * C + 32 * cf + l31];
         }
-        if (PF && g + gstep < groups) rs_load_raw<KS>(raw, x, C, min((g + gstep) * 32 + l31, M - 1), hi);
 #pragma unroll
         for (int cf = 0; cf < NC; ++cf)
 #pragma unroll
@@ -660,18 +659,14 @@ extern "C" int amds_swin_mlp96(float* x, int M, const void* fc1_w, const float* 
     int gx = cdiv(groups, RS_WAVES);
     if (gx > 256) gx = 256;
     ProfScope prof(PROF_GEMM, 4.0 * M * 96.0 * 384.0, st);
-    static const bool pf = getenv("AMDS_MLP96_PF") ? atoi(getenv("AMDS_MLP96_PF")) != 0 : false;
 #define MLP96_LAUNCH(T)                                                                                                              \
     do {                                                                                                                             \
         static bool attr_set = false;                                                                                                \
         if (!attr_set) {                                                                                                             \
-            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp96_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp96_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp96_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        if (pf) hipLaunchKernelGGL((swin_mlp96_kernel<T, true>), dim3(gx), dim3(64 * RS_WAVES), lds, st, x, M, reinterpret_cast<const T*>(fc1_w), fc1_b, \
-                           reinterpret_cast<const T*>(fc2_w), fc2_b, ln_gamma, ln_beta, ln_eps, groups);                             \
-        else hipLaunchKernelGGL((swin_mlp96_kernel<T, false>), dim3(gx), dim3(64 * RS_WAVES), lds, st, x, M, reinterpret_cast<const T*>(fc1_w), fc1_b, \
+        hipLaunchKernelGGL((swin_mlp96_kernel<T>), dim3(gx), dim3(64 * RS_WAVES), lds, st, x, M, reinterpret_cast<const T*>(fc1_w), fc1_b, \
                            reinterpret_cast<const T*>(fc2_w), fc2_b, ln_gamma, ln_beta, ln_eps, groups);                             \
     } while (0)
     if (dtype == AMDS_F16) MLP96_LAUNCH(f16);
