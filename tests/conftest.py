@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The shared library is git-ignored (built in-tree, it travels with the working copy): a fresh checkout builds it once
+    here, exactly as `__graft_entry__.build()` does (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = ROOT / "stamp_amd" / "lib" / "libamdstamp.so"
+    if not lib.is_file():
+        import subprocess
+        subprocess.run(["make", "-j", str(os.cpu_count() or 4)], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def gpu():
     import torch
