@@ -77,6 +77,9 @@ PRESETS: dict[str, ViTConfig] = {
     # Virchow2 = ViT-H/14, SwiGLUPacked, 4 register tokens (reference virchow2.py:34-39; D=1280 pinned by
     # tests/test_encoders.py:31, the other hyper-parameters are the public model card's: SURVEY.md F4)
     "virchow2": ViTConfig(dim=1280, depth=32, heads=16, hidden=3416, mlp="swiglu", reg_tokens=4, no_embed_class=False),
+    # Virchow (v1) = the same ViT-H/14 SwiGLU trunk without register tokens; used with `HipViTClsMean` (reference virchow_full.py,
+    # virchow.py: the factories pass mlp_layer=SwiGLUPacked, act_layer=SiLU; remaining hyper-parameters from the model card)
+    "virchow": ViTConfig(dim=1280, depth=32, heads=16, hidden=3416, mlp="swiglu", reg_tokens=0, no_embed_class=False),
     "test_tiny_hd80": ViTConfig(dim=640, depth=2, heads=8, hidden=696, mlp="swiglu", reg_tokens=4, no_embed_class=False),
     # H-optimus-0 / H-optimus-1 = timm vit_giant_patch14_reg4_dinov2 (reference h_optimus_0.py:15-20, h_optimus_1.py:15-20: the
     # factory only passes init_values / dynamic_img_size; width 1536, depth 40, 24 heads, SwiGLUPacked 8192 -> 4096, 4 register
@@ -265,6 +268,29 @@ class HipViT(nn.Module):
         return self
 
 
+class HipViTClsMean(nn.Module):
+    """`VirchowConcatenated` of the reference (src/stamp/preprocessing/extractor/virchow_full.py:25-35): the model output is the
+    final-LayerNorm'd token tensor; the tile embedding is cat(class token, mean of output[:, 1:]) -> [B, 2*dim] (2560 for Virchow).
+    The trunk and the token mean run in libamdstamp (`amds_vit_forward_tokens`, `amds_mean_pool`); slicing / concatenation are
+    data movement."""
+
+    def __init__(self, vit: "HipViT") -> None:
+        super().__init__()
+        self.vit = vit
+        self.cfg = vit.cfg
+
+    @torch.no_grad()
+    def forward(self, tiles: torch.Tensor) -> torch.Tensor:
+        _, toks = self.vit(tiles, return_tokens=True)                 # fp32 [B, T, D], final norm applied
+        if toks.shape[0] == 0:
+            return toks.new_zeros(0, 2 * self.cfg.dim, dtype=torch.float16)
+        mean = ops.mean_pool(toks[:, 1:].contiguous())                 # virchow_full.py:33-34: everything after the class token
+        return torch.cat([toks[:, 0], mean], dim=-1).half()
+
+    def to(self, *args, **kwargs):
+        return self
+
+
 def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate") -> dict[str, torch.Tensor]:
     """Random timm-named weights (no checkpoints are reachable offline).
 
@@ -316,4 +342,4 @@ def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate")
     return sd
 
 
-__all__ = ["ViTConfig", "PRESETS", "HipViT", "random_vit_state_dict", "packed_weight_bytes", "replace", "field"]
+__all__ = ["ViTConfig", "PRESETS", "HipViT", "HipViTClsMean", "random_vit_state_dict", "packed_weight_bytes", "replace", "field"]

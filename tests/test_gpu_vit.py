@@ -85,3 +85,18 @@ def test_vit_large_batch_invariance_at_bench_size(gpu):
     dup = tiles[:2].clone(); dup[1] = dup[0]
     fd = model(dup)
     assert torch.equal(fd[0], fd[1])
+
+
+def test_cls_plus_mean_patch_embedding(gpu):
+    """`VirchowConcatenated` (reference virchow_full.py:25-35): cat(class token, mean of the remaining tokens)."""
+    from stamp_amd.vit import HipViTClsMean
+    cfg = PRESETS["test_tiny_hd80"]
+    sd = random_vit_state_dict(cfg, seed=4, init="moderate")
+    tiles = torch.randint(0, 256, (5, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(8))
+    _, ref_t = extract_features(tiles, sd, cfg, return_tokens=True)
+    ref = torch.cat([ref_t[:, 0], ref_t[:, 1:].mean(1)], dim=-1)
+    model = HipViTClsMean(HipViT(cfg, sd, device=gpu, chunk=2))
+    out = model(tiles.to(gpu))
+    assert out.dtype == torch.float16 and out.shape == (5, 2 * cfg.dim)
+    assert _rel(out.cpu().float(), ref) < 2e-3
+    assert model(tiles[:0].to(gpu)).shape == (0, 2 * cfg.dim)
