@@ -2,6 +2,7 @@
 #include "gemm_8p.h"
 #include "gemm_4w.h"
 #include "gemm_8p64.h"
+#include "gemm_pp.h"
 namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(bf16)
 }

@@ -35,6 +35,9 @@ struct EpiArgs {
     // batched / split-K launches (gridDim.y = batch count): element strides added per batch index
     long bsA = 0, bsW = 0, bsOut = 0;
     int nbatch = 1;
+    // gemm_pp.h: per-CU arrival tickets and the start offset (10-ns ticks) of the second workgroup of a CU
+    int* pp_slots = nullptr;
+    int pp_delay = 0;
 };
 
 template <int EPI>
@@ -343,6 +346,9 @@ static int launch_gemm_8p64(const void* A, long lda, const void* W, long ldw, in
 template <typename T, int EPI>
 static int launch_gemm_4w(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                           hipStream_t st);   // gemm_4w.h
+template <typename T, int EPI>
+static int launch_gemm_pp(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                          hipStream_t st);   // gemm_pp.h
 template <typename T, int EPI, int VARIANT>
 static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                           hipStream_t st);   // gemm_8p.h
@@ -354,6 +360,10 @@ static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int 
 template <typename T, int EPI>
 static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                        const EpiArgs& ep, hipStream_t st) {
+    if constexpr (EPI != AMDS_EPI_SWIGLU) {
+        if (cfg == 9 && N % 128 == 0 && K >= 64 && ep.nbatch == 1) return launch_gemm_pp<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+    }
+    if (cfg == 9) cfg = 8;
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 8) cfg = 0;
     if (cfg == 7 && N % 256 == 0 && K >= 128) return launch_gemm_4w<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);

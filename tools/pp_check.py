@@ -1,0 +1,29 @@
+"""cfg 9 (ping-pong GEMM) against cfg 8 on every staged epilogue, ragged M.  python tools/pp_check.py"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from stamp_amd import _lib, ops  # noqa: E402
+
+torch.manual_seed(0)
+ok = True
+for dt in (torch.float16, torch.bfloat16):
+    for M, N, K in ((1000, 256, 64), (777, 1024, 1024), (4099, 512, 128), (256, 3072, 4096)):
+        a = torch.randn(M, K, device="cuda").to(dt)
+        w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(dt)
+        b = torch.randn(N, device="cuda")
+        sc = torch.rand(N, device="cuda")
+        for name, epi in (("bias", _lib.EPI_BIAS), ("gelu", _lib.EPI_BIAS_GELU), ("relu", _lib.EPI_BIAS_RELU),
+                          ("f32", _lib.EPI_BIAS_F32), ("gelu32", _lib.EPI_BIAS_GELU_F32), ("res", _lib.EPI_RESIDUAL)):
+            outs = []
+            for cfg in (8, 9):
+                out = torch.randn(M, N, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) if epi == _lib.EPI_RESIDUAL else None
+                outs.append(ops.gemm(a, w, epi, bias=b, scale=sc if epi == _lib.EPI_RESIDUAL else None, out=out, cfg=cfg).float())
+            d = (outs[0] - outs[1]).abs().max().item()
+            good = d == 0.0
+            ok &= good
+            if not good:
+                print(dt, M, N, K, name, "max diff", d)
+print("pp_check", "OK (bit-equal to cfg 8)" if ok else "MISMATCH")
