@@ -155,7 +155,7 @@ def main() -> None:
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
         "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles in stages 1-2, gemm_8p64_kernel in stages 3-4)" if is_swin else
-                               "gemm_8p64_kernel (256x256x64 staggered two-group 8-wave MFMA 32x32x16 pipeline, fused LDS-staged epilogues)", "bound": "mfma",
+                               "256x256x64 MFMA 32x32x16 GEMMs with fused LDS-staged epilogues: gemm_4w64_kernel (4 waves, 128x128 wave tiles; qkv / proj / fc2) + gemm_8p64_kernel (8 waves, staggered groups; fc1 + GELU)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_traffic.json); algorithmic 1.48e9 -> 1.43x (A panels re-fetched across N tiles, served by L2/MALL)" if traffic else None,

@@ -120,7 +120,12 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
     EpiArgs ep;
     ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = scale; ep.pos = pos;
     ep.np = np; ep.T = T; ep.P = P; ep.acc_scale = acc_scale;
-    if (cfg < 0) cfg = default_gemm_cfg(M, N, K);
+    if (cfg < 0) {
+        cfg = default_gemm_cfg(M, N, K);
+        // measured (profiles/r01_gemm_vendor_and_power.txt): the four-wave 128-byte-row kernel wins wherever the epilogue is not
+        // VALU-bound (bias only; fp32 outputs / residual read-modify-write), the eight-wave kernel keeps bias + GELU
+        if (cfg == 8 && epi != AMDS_EPI_BIAS_GELU && epi != AMDS_EPI_SWIGLU && epi != AMDS_EPI_PATCH && N % 256 == 0 && !getenv("AMDS_GEMM_CFG")) cfg = 10;
+    }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);
     if (dtype == AMDS_F16) return gemm_dispatch<f16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);

@@ -200,17 +200,19 @@ gemm_4w_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (pass) __syncthreads();
+            // fragment column j outermost: its 4 bias / LayerScale vectors are loaded once (16 registers), then used by 4 row blocks
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int row = wm * 128 + i * 32 + l31;
+            for (int jj = 0; jj < (F16OUT ? 4 : 2); ++jj) {
+                const int j = F16OUT ? jj : pass * 2 + jj;
+                EpiCols<4> cols;
+                epi_cols_load<EPI>(ep, cols, [&](int g) { return n0 + wn * 128 + j * 32 + 8 * g + 4 * hi; });
 #pragma unroll
-                for (int jj = 0; jj < (F16OUT ? 4 : 2); ++jj) {
-                    const int j = F16OUT ? jj : pass * 2 + jj;
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * 128 + i * 32 + l31;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int n = n0 + wn * 128 + j * 32 + 8 * g + 4 * hi;
                         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        v = epi_value<EPI>(ep, n, v);
+                        v = epi_value<EPI>(ep, cols.bias[g], cols.scale[g], v);
                         if constexpr (F16OUT) {
                             vec4 o;
 #pragma unroll

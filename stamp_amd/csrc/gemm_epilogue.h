@@ -21,6 +21,8 @@ __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const E
     typedef typename Act<T>::vec4 vec4;
     const int l31 = lane & 31, hi = lane >> 5;
     constexpr bool F16OUT = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU);
+    EpiCols<8> cols;      // [j * 4 + g]: columns n0 + wc * 64 + j * 32 + 8 g + 4 hi
+    epi_cols_load<EPI>(ep, cols, [&](int q) { return n0 + wc * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi; });
     if constexpr (F16OUT) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -29,9 +31,8 @@ __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const E
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    v = epi_value<EPI>(ep, n, v);
+                    v = epi_value<EPI>(ep, cols.bias[j * 4 + g], cols.scale[j * 4 + g], v);
                     vec4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = Act<T>::from_f32(v[e]);
@@ -57,9 +58,8 @@ __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const E
                 const int row = grp * 128 + i * 32 + l31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wc * 64 + pass * 32 + 8 * g + 4 * hi;
                     f32x4 v = {acc[i][pass][4 * g], acc[i][pass][4 * g + 1], acc[i][pass][4 * g + 2], acc[i][pass][4 * g + 3]};
-                    v = epi_value<EPI>(ep, n, v);
+                    v = epi_value<EPI>(ep, cols.bias[pass * 4 + g], cols.scale[pass * 4 + g], v);
                     const int chunk = wc * 8 + 2 * g + hi;
                     *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = v;
                 }

@@ -46,11 +46,32 @@ constexpr bool epi_is_staged() {
            EPI == AMDS_EPI_BIAS_F32 || EPI == AMDS_EPI_BIAS_GELU_F32 || EPI == AMDS_EPI_BIAS_RELU_F32;
 }
 
+// Per-column epilogue vectors (bias, LayerScale) of G groups of 4 consecutive columns, loaded ONCE and up front.  Loaded
+// inside the value loop, every one of these 16-byte loads is followed by its own s_waitcnt vmcnt(0): a serial L2 round
+// trip per 4 outputs, 32 per wave and 256 x 256 tile = 7-9 us of every tile's ~9 us epilogue.
+template <int G>
+struct EpiCols {
+    f32x4 bias[G], scale[G];
+};
+template <int EPI, int G, typename F>
+__device__ __forceinline__ void epi_cols_load(const EpiArgs& ep, EpiCols<G>& c, F col_of) {
+    if (ep.bias) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) c.bias[q] = *reinterpret_cast<const f32x4*>(ep.bias + col_of(q));
+    }
+    if constexpr (EPI == AMDS_EPI_RESIDUAL) {
+        if (ep.scale) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) c.scale[q] = *reinterpret_cast<const f32x4*>(ep.scale + col_of(q));
+        }
+    }
+}
+
 // value transform shared by all staged epilogues: bias, activation, LayerScale (residual)
 template <int EPI>
-__device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, int n, f32x4 v) {
+__device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, const f32x4& bias, const f32x4& scale, f32x4 v) {
     if (ep.acc_scale != 1.0f) v *= ep.acc_scale;
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+    if (ep.bias) v += bias;
     if constexpr (EPI == AMDS_EPI_BIAS_GELU) {
         const f32x2 a = gelu_erf_poly2(f32x2{v[0], v[1]}), b = gelu_erf_poly2(f32x2{v[2], v[3]});
         v = f32x4{a[0], a[1], b[0], b[1]};
@@ -64,7 +85,7 @@ __device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, int n, f32x4 v) {
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     if constexpr (EPI == AMDS_EPI_RESIDUAL) {
-        if (ep.scale) v *= *reinterpret_cast<const f32x4*>(ep.scale + n);
+        if (ep.scale) v *= scale;
     }
     return v;
 }
@@ -240,6 +261,8 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
         // writes) and store whole rows, 16 bytes per lane.
         constexpr bool F16OUT = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU);
         constexpr int CPR = BN * (F16OUT ? 2 : 4) / 16, PITCH = (CPR | 1) * 16;     // 16-byte chunks per row; row pitch in bytes
+        EpiCols<FN * 4> cols;
+        epi_cols_load<EPI>(ep, cols, [&](int q) { return n0 + wn * WTN + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi; });
         __syncthreads();                                   // every wave is done with the K-loop stages
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -250,7 +273,7 @@ gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
                 for (int g = 0; g < 4; ++g) {
                     const int nl = wn * WTN + j * 32 + 8 * g + 4 * hi;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    v = epi_value<EPI>(ep, n0 + nl, v);
+                    v = epi_value<EPI>(ep, cols.bias[j * 4 + g], cols.scale[j * 4 + g], v);
                     if constexpr (F16OUT) {
                         vec4 o;
 #pragma unroll
@@ -347,6 +370,9 @@ template <typename T, int EPI>
 static int launch_gemm_4w(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                           hipStream_t st);   // gemm_4w.h
 template <typename T, int EPI>
+static int launch_gemm_4w64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                            hipStream_t st);   // gemm_4w64.h
+template <typename T, int EPI>
 static int launch_gemm_pp(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                           hipStream_t st);   // gemm_pp.h
 template <typename T, int EPI, int VARIANT>
@@ -364,6 +390,8 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
         if (cfg == 9 && N % 128 == 0 && K >= 64 && ep.nbatch == 1) return launch_gemm_pp<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     }
     if (cfg == 9) cfg = 8;
+    if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 10) cfg = 8;
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 8) cfg = 0;
     if (cfg == 7 && N % 256 == 0 && K >= 128) return launch_gemm_4w<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);

@@ -1,4 +1,5 @@
-"""cfg 9 (ping-pong GEMM) against cfg 8 on every staged epilogue, ragged M.  python tools/pp_check.py"""
+"""An alternative GEMM kernel (cfg 9 = ping-pong, 10 = four waves / 128-byte rows) against cfg 8 on every staged epilogue,
+ragged M.  python tools/pp_check.py [cfg]"""
 import sys
 from pathlib import Path
 
@@ -7,6 +8,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stamp_amd import _lib, ops  # noqa: E402
 
+ALT = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 torch.manual_seed(0)
 ok = True
 for dt in (torch.float16, torch.bfloat16):
@@ -18,7 +20,7 @@ for dt in (torch.float16, torch.bfloat16):
         for name, epi in (("bias", _lib.EPI_BIAS), ("gelu", _lib.EPI_BIAS_GELU), ("relu", _lib.EPI_BIAS_RELU),
                           ("f32", _lib.EPI_BIAS_F32), ("gelu32", _lib.EPI_BIAS_GELU_F32), ("res", _lib.EPI_RESIDUAL)):
             outs = []
-            for cfg in (8, 9):
+            for cfg in (8, ALT):
                 out = torch.randn(M, N, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) if epi == _lib.EPI_RESIDUAL else None
                 outs.append(ops.gemm(a, w, epi, bias=b, scale=sc if epi == _lib.EPI_RESIDUAL else None, out=out, cfg=cfg).float())
             d = (outs[0] - outs[1]).abs().max().item()
@@ -26,4 +28,4 @@ for dt in (torch.float16, torch.bfloat16):
             ok &= good
             if not good:
                 print(dt, M, N, K, name, "max diff", d)
-print("pp_check", "OK (bit-equal to cfg 8)" if ok else "MISMATCH")
+print(f"cfg {ALT}", "OK (bit-equal to cfg 8)" if ok else "MISMATCH")

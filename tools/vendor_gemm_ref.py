@@ -39,8 +39,9 @@ for name, N, K in (("fc1", 4096, 1024), ("qkv", 3072, 1024), ("proj", 1024, 1024
             ("amds cfg 8 bias f16", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=8)),
             ("amds cfg 8 bias+gelu", lambda: ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=b, cfg=8)),
             ("amds cfg 8 residual f32", lambda: ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=b, out=res, cfg=8)),
-            ("amds cfg 7 bias f16", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=7)),
-            ("amds cfg 9 bias f16", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=9))]
+            ("amds cfg 10 bias f16", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=10)),
+            ("amds cfg 10 bias+gelu", lambda: ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=b, cfg=10)),
+            ("amds cfg 10 residual f32", lambda: ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=b, out=res, cfg=10))]
     for label, fn in rows:
         us = timed(fn)
         print(f"{name:6s} {label:26s} {us:7.0f} us {flop / us / 1e6:6.0f} TF/s")
