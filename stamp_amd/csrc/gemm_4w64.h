@@ -19,7 +19,10 @@
 
 namespace amds {
 
-template <typename T, int EPI>
+// ABL: ablation bits (results WRONG when non-zero; only reachable through amds_gemm_ablate): 1 = no LDS-DMA after the first
+// two K tiles, 4 = no fragment ds_reads after the first, 8 = no barriers
+// P3 / P0: LDS-DMA pieces of the next K tile requested in k-step 3 of the previous tile / k-step 0 (the rest in k-step 1)
+template <typename T, int EPI, int ABL = 0, int P3 = 6, int P0 = 6>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
                  EpiArgs ep, int tiles_m, int tiles_n) {
@@ -68,6 +71,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         voff[it] = (int)(((long)row * (it < 8 ? lda : ldw) + sc * 8) * 2);
     }
     auto issue_pieces = [&](int kt, int lo, int hi_) {
+        if ((ABL & 1) && kt >= 2) return;
         char* st = smem + (kt & 1) * STAGE;
         const int koff = kt * BK * 2;
 #pragma unroll
@@ -92,6 +96,13 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     vec8 afA[FM], wfA[FN], afB[FM], wfB[FN];
     auto load_frags = [&](int kt, int ks, vec8 (&af)[FM], vec8 (&wf)[FN]) {
+        if ((ABL & 4) && (kt > 0 || ks > 1)) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(wf[j]));
+            return;
+        }
         const char* sb = smem + (kt & 1) * STAGE;
         const int co = ((ks * 2 + hi) ^ swz) << 4;
 #pragma unroll
@@ -107,6 +118,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     };
     // scheduling recipe of one k-step: 16 MFMAs with `reads` ds_reads and `copies` LDS-DMA requests in the gaps
     auto interleave = [&](auto reads_c, auto copies_c) {
+        if constexpr (ABL != 0) { __builtin_amdgcn_sched_barrier(0); return; }
         constexpr int READS = decltype(reads_c)::value, COPIES = decltype(copies_c)::value;
 #pragma unroll
         for (int r = 0; r < READS; ++r) {
@@ -122,14 +134,17 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         __builtin_amdgcn_sched_barrier(0);
     };
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 4> I4;
-    typedef std::integral_constant<int, 6> I6;
     typedef std::integral_constant<int, 8> I8;
+    constexpr int P1 = 16 - P3 - P0;
+    static_assert(P3 <= 8 && P0 <= 8 && P1 >= 0 && P1 <= 8, "at most 8 LDS-DMA pieces per k-step (16 MFMAs, 8 fragment reads)");
+    typedef std::integral_constant<int, P3> IP3;
+    typedef std::integral_constant<int, P0> IP0;
+    typedef std::integral_constant<int, P1> IP1;
 
 #define AMDS_BARRIER()                        \
     do {                                      \
         __builtin_amdgcn_sched_barrier(0);    \
-        __builtin_amdgcn_s_barrier();         \
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();         \
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
@@ -138,19 +153,19 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AMDS_BARRIER();
     load_frags(0, 0, afA, wfA);
-    if (nk > 1) issue_pieces(1, 0, 6);
+    if (nk > 1) issue_pieces(1, 0, P3);
     __builtin_amdgcn_sched_barrier(0);
 
     auto k_tile = [&](int kt, auto next_c, auto next2_c) {
         constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
         load_frags(kt, 1, afB, wfB);
-        if constexpr (NEXT) issue_pieces(kt + 1, 6, 12);
+        if constexpr (NEXT) issue_pieces(kt + 1, P3, P3 + P0);
         mfmas(afA, wfA);
-        if constexpr (NEXT) interleave(I8{}, I6{}); else interleave(I8{}, I0{});
+        if constexpr (NEXT) interleave(I8{}, IP0{}); else interleave(I8{}, I0{});
         load_frags(kt, 2, afA, wfA);
-        if constexpr (NEXT) issue_pieces(kt + 1, 12, 16);
+        if constexpr (NEXT) issue_pieces(kt + 1, P3 + P0, 16);
         mfmas(afB, wfB);
-        if constexpr (NEXT) interleave(I8{}, I4{}); else interleave(I8{}, I0{});
+        if constexpr (NEXT) interleave(I8{}, IP1{}); else interleave(I8{}, I0{});
         load_frags(kt, 3, afB, wfB);
         mfmas(afA, wfA);
         interleave(I8{}, I0{});
@@ -158,9 +173,9 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         AMDS_BARRIER();
         if constexpr (NEXT) load_frags(kt + 1, 0, afA, wfA);
-        if constexpr (NEXT2) issue_pieces(kt + 2, 0, 6);
+        if constexpr (NEXT2) issue_pieces(kt + 2, 0, P3);
         mfmas(afB, wfB);
-        if constexpr (NEXT2) interleave(I8{}, I6{});
+        if constexpr (NEXT2) interleave(I8{}, IP3{});
         else if constexpr (NEXT) interleave(I8{}, I0{});
         else __builtin_amdgcn_sched_barrier(0);
     };
@@ -287,6 +302,19 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     }
 }
 
+
+template <typename T, int EPI, int ABL, int P3 = 6, int P0 = 6>
+static int launch_gemm_4w64_abl(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                                hipStream_t st) {
+    constexpr int LDS = 2 * (256 + 256) * 128;
+    auto kern = gemm_4w64_kernel<T, EPI, ABL, P3, P0>;
+    AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    const int tiles_m = cdiv(M, 256), tiles_n = N / 256;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
+                       reinterpret_cast<const T*>(W), ldw, M, N, K, ep, tiles_m, tiles_n);
+    AMDS_LAUNCH_CHECK("gemm_4w64_kernel(abl)");
+    return AMDS_OK;
+}
 
 template <typename T, int EPI>
 static int launch_gemm_4w64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,

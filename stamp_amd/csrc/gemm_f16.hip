@@ -24,5 +24,10 @@ extern "C" int amds_gemm_ablate(int abl, const void* A, long lda, const void* W,
         D_(0) D_(1) D_(4) D_(5) D_(8) D_(9) D_(12) D_(13)
 #undef D_
     }
+    switch (abl - 2000) {     // 2000 + bits: the 4-wave / 128-byte-row kernel
+#define E_(x) case x: return launch_gemm_4w64_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
+        E_(0) E_(1) E_(4) E_(5) E_(8) E_(9) E_(12) E_(13)
+#undef E_
+    }
     return AMDS_ERR_INVALID;
 }

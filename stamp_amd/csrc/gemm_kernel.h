@@ -392,6 +392,7 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
     if (cfg == 9) cfg = 8;
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
+
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 8) cfg = 0;
     if (cfg == 7 && N % 256 == 0 && K >= 128) return launch_gemm_4w<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
