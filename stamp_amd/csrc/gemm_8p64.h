@@ -58,20 +58,28 @@ gemm_8p64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         else ep.out = reinterpret_cast<T*>(ep.out) + by * ep.bsOut;
     }
 
-    // ---- copy addressing: 4096 16-byte chunks per tile, 8 per thread; chunk index XOR (row>>1)&7 on the source ----
-    const T* src[8];
+    // ---- copy addressing: 4096 16-byte chunks per tile, 8 per thread; chunk index XOR (row>>1)&7 on the source.
+    // Buffer form (buffer_load_dwordx4 ... offen lds): a constant 32-bit byte offset per piece, the K advance in the scalar
+    // offset -> no 64-bit vector address arithmetic in the loop; rows past M are out of range and read as 0.
+    const int rows_a = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(A + (long)m0 * lda), 0, (int)((((long)rows_a - 1) * lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(W + (long)n0 * ldw), 0, (int)(((long)(BN - 1) * ldw + K) * 2), 0x00020000);
+    int voff[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int c = (it & 3) * NT + tid, row = c >> 3, cp = c & 7, sc = cp ^ ((row >> 1) & 7);
-        if (it < 4) src[it] = A + (long)min(m0 + row, M - 1) * lda + sc * 8;
-        else src[it] = W + (long)(n0 + row) * ldw + sc * 8;
+        voff[it] = (int)(((long)row * (it < 4 ? lda : ldw) + sc * 8) * 2);
     }
     auto issue_tile = [&](int kt) {
         char* st = smem + (kt & 1) * STAGE;
-        const int koff = kt * BK;
+        const int koff = kt * BK * 2;
 #pragma unroll
         for (int it = 0; it < 8; ++it)
-            glds16(src[it] + koff, st + (it >> 2) * A_BYTES + ((it & 3) * NT + wave * 64) * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(it < 4 ? rsrc_a : rsrc_w,
+                                                     (lptr_t)(st + (it >> 2) * A_BYTES + ((it & 3) * NT + wave * 64) * 16), 16, voff[it],
+                                                     koff, 0, 0);
     };
 
     const int swz = (l31 >> 1) & 7;
