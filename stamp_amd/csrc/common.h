@@ -134,6 +134,13 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// the same copy in buffer form (buffer_load_dwordx4 v, s[rsrc], soffset offen lds): byte offset = voffset (per lane) + soffset
+// (wave-uniform); out-of-range offsets read as 0.  Wrapped in a __device__ function: called directly inside some kernel
+// templates the builtin makes the HOST-side instantiation silently invalid (no stub emitted, undefined symbol at load time).
+__device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
 // ---- live per-kernel timing (HIP events on the launch stream; off unless amds_profile_enable(1)) ----
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_GEMM_F32 = 4, PROF_NKINDS = 5 };
 extern bool g_prof_on;
