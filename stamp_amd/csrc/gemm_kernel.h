@@ -388,8 +388,9 @@ static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int 
 
 // kernel ids (amds_gemm_ex): 0 = 128x128 tile, one barrier per K step (small problems, any N % 128 == 0)
 //   1 = 128x96 tile, four waves stacked along M (N % 96 == 0: the Swin widths 96/192/288/576 that 128 does not divide)
-//   8 = 256x256x64 staggered two-group pipeline (gemm_8p64.h, PRODUCTION; N % 256 == 0, else falls back to 0)
-//   3 = its BK = 32 / 4-stage variant (gemm_8p.h)      7 = four waves, 128x128 wave tiles, AGPR accumulators (gemm_4w.h)
+//   8 = 256x256x64 eight-wave staggered two-group pipeline (gemm_8p64.h, PRODUCTION for bias + GELU; N % 256 == 0, else 0)
+//  10 = 256x256x64 four waves, 128x128 wave tiles, AGPR accumulators (gemm_4w64.h, PRODUCTION for the other epilogues)
+//   3 / 7 = their BK = 32 (64-byte LDS row) predecessors (gemm_8p.h, gemm_4w.h)      9 = ping-pong experiment (gemm_pp.h)
 template <typename T, int EPI>
 static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                        const EpiArgs& ep, hipStream_t st) {
