@@ -55,22 +55,27 @@ gemm_4w_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long 
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- copy addressing: 2048 16-byte chunks per tile, 8 per thread (4 of A, 4 of W) ---------------------
-    const T* src[8];
+    // ---- copy addressing: 2048 16-byte chunks per tile, 8 per thread (4 of A, 4 of W); buffer-form LDS-DMA (common.h) ----
+    const int rows_a = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(A + (long)m0 * lda), 0, (int)((((long)rows_a - 1) * lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(W + (long)n0 * ldw), 0, (int)(((long)(BN - 1) * ldw + K) * 2), 0x00020000);
+    int voff[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int c = (it & 3) * NT + tid, row = c >> 2, cp = c & 3, sc = cp ^ ((row >> 2) & 3);
-        if (it < 4) src[it] = A + (long)min(m0 + row, M - 1) * lda + sc * 8;
-        else src[it] = W + (long)(n0 + row) * ldw + sc * 8;
+        voff[it] = (int)(((long)row * (it < 4 ? lda : ldw) + sc * 8) * 2);
     }
     // pieces [lo, hi) of tile kt
     auto issue_pieces = [&](int kt, int lo, int hi_) {
         if ((ABL & 1) && kt >= 3) return;
         char* st = smem + (kt & (NSTAGE - 1)) * STAGE;
-        const int koff = kt * BK;
+        const int koff = kt * BK * 2;
 #pragma unroll
         for (int it = 0; it < 8; ++it)
-            if (it >= lo && it < hi_) glds16(src[it] + koff, st + (it >> 2) * A_BYTES + ((it & 3) * NT + wave * 64) * 16);
+            if (it >= lo && it < hi_)
+                bufl16(it < 4 ? rsrc_a : rsrc_w, st + (it >> 2) * A_BYTES + ((it & 3) * NT + wave * 64) * 16, voff[it], koff);
     };
 
     const int swz = (l31 >> 2) & 3;
