@@ -30,6 +30,35 @@ __global__ void __launch_bounds__(256) transpose16_kernel(const uint16_t* __rest
     }
 }
 
+// Fast path (R, Cc multiples of 64; 16-byte aligned rows on both sides): 16-byte global loads and stores, 4-byte LDS writes,
+// rows pitched 33 dwords so that the 8 rows a lane gathers for one output chunk sit in 8 different banks.  The 2-byte-per-
+// lane kernel above moved 3.2 TB/s (13 % of a MIL training step went into it).
+__global__ void __launch_bounds__(256) transpose16_vec_kernel(const uint16_t* __restrict__ src, long ld_src, uint16_t* __restrict__ dst,
+                                                              long ld_dst) {
+    __shared__ uint32_t t[64 * 33];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u, r = i >> 3, ch = i & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)(r0 + r) * ld_src + c0 + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[r * 33 + ch * 4 + e] = v[e];
+    }
+    __syncthreads();
+    const uint16_t* th = reinterpret_cast<const uint16_t*>(t);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u, c = i >> 3, rg = i & 7;     // output row c, its elements r = rg*8 .. rg*8+7
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = th[(rg * 8 + 2 * e) * 66 + c], hi = th[(rg * 8 + 2 * e + 1) * 66 + c];
+            o[e] = lo | (hi << 16);
+        }
+        *reinterpret_cast<u32x4*>(dst + (long)(c0 + c) * ld_dst + r0 + rg * 8) = o;
+    }
+}
+
 // ---- column sums: stage 1 = per 256-row chunk partials, stage 2 = reduce partials ---------------------------------------
 // Stage 1: a block owns 64 columns x CS_ROWS rows; 16 column groups of 4 (one 8/16-byte load per row) x 16 row lanes, four
 // independent accumulator sets per thread so that 4 loads are in flight; the 16 row lanes reduce through LDS in a fixed
@@ -256,8 +285,13 @@ using namespace amds;
 extern "C" int amds_transpose16(const void* src, long ld_src, void* dst, long ld_dst, int R, int Cc, void* stream) {
     AMDS_REQUIRE(src && dst && src != dst, "amds_transpose16: null/aliased pointer");
     AMDS_REQUIRE(R > 0 && Cc > 0 && ld_src >= Cc && ld_dst >= R, "amds_transpose16: bad shape");
-    hipLaunchKernelGGL(transpose16_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, ld_src,
-                       (uint16_t*)dst, ld_dst, R, Cc);
+    const bool vec = R % 64 == 0 && Cc % 64 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(transpose16_vec_kernel, dim3(Cc / 64, R / 64), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, ld_src,
+                           (uint16_t*)dst, ld_dst);
+    else
+        hipLaunchKernelGGL(transpose16_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, ld_src,
+                           (uint16_t*)dst, ld_dst, R, Cc);
     AMDS_LAUNCH_CHECK("transpose16_kernel");
     return AMDS_OK;
 }

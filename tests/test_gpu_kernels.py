@@ -34,7 +34,7 @@ def _gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 3, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
 def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
@@ -54,10 +54,11 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1, 256, 128), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
                                    (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
-@pytest.mark.parametrize("cfg", [3, 7, 8])
+@pytest.mark.parametrize("cfg", [3, 7, 8, 9, 10])
 def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
-    """cfg 3 (staggered 4-stage LDS ring, counted vmcnt): exact-shape sweep incl. the minimum K (4 phases), ragged M,
-    and a race screen -- 6 launches must be bitwise identical and match an fp64 reference."""
+    """The pipelined kernels (3 / 8: staggered two-group 8-wave; 7 / 10: four waves, 128x128 wave tiles; 9: ping-pong):
+    exact-shape sweep incl. the minimum K, ragged M (rows past M are out of range of the LDS-DMA buffer descriptor), and a
+    race screen -- 6 launches must be bitwise identical and match an fp64 reference."""
     g = torch.Generator().manual_seed(M * 3 + N + K)
     a = torch.randn(M, K, generator=g).to(gpu, dt)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
@@ -72,7 +73,7 @@ def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 3, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10])
 def test_gemm_epilogues(gpu, dt, cfg):
     M, N, K = 771, 512, 256
     _g = ops.gemm
@@ -112,6 +113,21 @@ def test_gemm_epilogues(gpu, dt, cfg):
     # acc_scale
     out = ops_.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, acc_scale=0.25)
     assert (out.double() - (0.25 * _gemm_ref(a, w, None) + bias.double())).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_kernels_bit_identical(gpu, dt):
+    """Every 256-wide kernel id accumulates k in the same order with the same MFMA: outputs are bit-identical, so the library's
+    per-epilogue choice of kernel (amds_gemm default) never changes a result."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1500, 768, 320
+    a = torch.randn(M, K, generator=g).to(gpu, dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
+    bias = torch.randn(N, generator=g).to(gpu)
+    for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_BIAS_F32):
+        ref = ops.gemm(a, w, epi, bias=bias, cfg=8)
+        for cfg in (3, 7, 9, 10, -1):
+            assert torch.equal(ops.gemm(a, w, epi, bias=bias, cfg=cfg), ref), (epi, cfg)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

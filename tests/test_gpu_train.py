@@ -19,6 +19,17 @@ def test_transpose_colsum(gpu):
     assert torch.equal(T.colsum(x), s)                # deterministic
 
 
+@pytest.mark.parametrize("R,C,ld", [(128, 64, None), (1024, 512, None), (640, 2048, 704), (64 * 1025, 512, None)])
+def test_transpose_vector_path(gpu, R, C, ld):
+    """R and C multiples of 64 take the 16-byte-per-lane kernel; `ld` = a padded destination pitch."""
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).to(gpu, torch.bfloat16)
+    t = T.transpose16(x) if ld is None else T.transpose16(x, ld_dst=ld)
+    assert torch.equal(t[:, :R], x.t())
+    xs = torch.randn(R, C + 64, generator=g).to(gpu, torch.bfloat16)[:, 64:]      # a view: source pitch != columns
+    assert torch.equal(T.transpose16(xs), xs.t())
+
+
 @pytest.mark.parametrize("rows,cols", [(1025, 512), (70, 128), (4100, 1024)])
 def test_layernorm_train_and_bwd(gpu, rows, cols):
     g = torch.Generator().manual_seed(rows)
