@@ -53,7 +53,7 @@ int default_gemm_cfg(int M, int N, int K) {
     static int env = -2;
     if (env == -2) {
         const char* s = getenv("AMDS_GEMM_CFG");
-        env = s ? atoi(s) : -1;
+        env = (s && *s) ? atoi(s) : -1;          // set-but-empty counts as unset
     }
     if (env >= 0) return env;
     // the staggered 256x256 pipeline wins whenever the grid fills the chip; small problems keep 128x128 tiles
@@ -124,7 +124,7 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
         cfg = default_gemm_cfg(M, N, K);
         // measured (profiles/r01_gemm_vendor_and_power.txt): the four-wave 128-byte-row kernel wins wherever the epilogue is not
         // VALU-bound (bias only; fp32 outputs / residual read-modify-write), the eight-wave kernel keeps bias + GELU
-        if (cfg == 8 && epi != AMDS_EPI_BIAS_GELU && epi != AMDS_EPI_SWIGLU && epi != AMDS_EPI_PATCH && N % 256 == 0 && !getenv("AMDS_GEMM_CFG")) cfg = 10;
+        if (cfg == 8 && epi != AMDS_EPI_BIAS_GELU && epi != AMDS_EPI_SWIGLU && epi != AMDS_EPI_PATCH && N % 256 == 0 && !(getenv("AMDS_GEMM_CFG") && *getenv("AMDS_GEMM_CFG"))) cfg = 10;
     }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);

@@ -114,6 +114,32 @@ __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
     const f32x2 h = x * 0.5f;
     return h * (z * p) + h;
 }
+// the same polynomial on NC independent 2-vectors, Horner steps interleaved across them: one wave per SIMD (4-wave GEMM) has
+// nobody to hide the dependent v_pk_fma latency behind, so a single chain runs at a fraction of the VALU rate
+template <int NC>
+__device__ __forceinline__ void gelu_erf_poly2_n(f32x2 (&x)[NC]) {
+    constexpr float Z = 3.25f;
+    constexpr float c[12] = {4.346401949e-01f, -2.144501162e-01f, 1.532795055e-01f, -1.143948891e-01f, 8.225328539e-02f,
+                             -5.548698805e-02f, 3.551052708e-02f, -2.022940554e-02f, 8.718888393e-03f, -4.313286983e-03f,
+                             3.632394905e-03f, -1.469356506e-03f};
+    f32x2 z[NC], u[NC], p[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        z[k] = x[k] * 0.70710678118654752440f;
+        z[k] = __builtin_elementwise_min(__builtin_elementwise_max(z[k], f32x2{-Z, -Z}), f32x2{Z, Z});
+        u[k] = z[k] * z[k] * (2.0f / (Z * Z)) - 1.0f;
+        p[k] = f32x2{c[11], c[11]};
+    }
+#pragma unroll
+    for (int i = 10; i >= 0; --i)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) p[k] = p[k] * u[k] + c[i];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const f32x2 h = x[k] * 0.5f;
+        x[k] = h * (z[k] * p[k]) + h;
+    }
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -196,31 +196,38 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         for (int pass = 0; pass < NPASS; ++pass) {
             if (pass) __syncthreads();
             // fragment column j outermost: its 4 bias / LayerScale vectors are loaded once (16 registers), then used by 4 row blocks
+            auto values = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-            for (int jj = 0; jj < (F16OUT ? 4 : 2); ++jj) {
-                const int j = F16OUT ? jj : pass * 2 + jj;
-                EpiCols<4> cols;
-                epi_cols_load<EPI>(ep, cols, [&](int g) { return n0 + wn * 128 + j * 32 + 8 * g + 4 * hi; });
+                for (int jj = 0; jj < (F16OUT ? 4 : 2); ++jj) {
+                    const int j = F16OUT ? jj : pass * 2 + jj;
+                    EpiCols<4> cols;
+                    epi_cols_load<EPI>(ep, cols, [&](int g) { return n0 + wn * 128 + j * 32 + 8 * g + 4 * hi; });
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int row = wm * 128 + i * 32 + l31;
+                    for (int i = 0; i < FM; ++i) {
+                        const int row = wm * 128 + i * 32 + l31;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        v = epi_value<EPI>(ep, cols.bias[g], cols.scale[g], v);
-                        if constexpr (F16OUT) {
-                            vec4 o;
+                        for (int g = 0; g < 4; g += 2) {
+                            f32x4 v0 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            f32x4 v1 = {acc[i][j][4 * g + 4], acc[i][j][4 * g + 5], acc[i][j][4 * g + 6], acc[i][j][4 * g + 7]};
+                            epi_value_pair<EPI, FAST>(ep, cols.bias[g], cols.scale[g], cols.bias[g + 1], cols.scale[g + 1], v0, v1);
+                            if constexpr (F16OUT) {
+                                vec4 o0, o1;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = Act<T>::from_f32(v[e]);
-                            const int chunk = wn * 16 + j * 4 + g;
-                            *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + hi * 8) = o;
-                        } else {
-                            const int chunk = wn * 16 + jj * 8 + 2 * g + hi;
-                            *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = v;
+                                for (int e = 0; e < 4; ++e) { o0[e] = Act<T>::from_f32(v0[e]); o1[e] = Act<T>::from_f32(v1[e]); }
+                                const int chunk = wn * 16 + j * 4 + g;
+                                *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + hi * 8) = o0;
+                                *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 1) ^ (row & 31)) << 4) + hi * 8) = o1;
+                            } else {
+                                const int chunk = wn * 16 + jj * 8 + 2 * g + hi;
+                                *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = v0;
+                                *reinterpret_cast<f32x4*>(smem + row * 512 + (((chunk + 2) ^ (row & 31)) << 4)) = v1;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (F16OUT && ep.bias != nullptr && ep.acc_scale == 1.0f) values(std::true_type{}); else values(std::false_type{});
             __syncthreads();
             // one wave per SIMD: batch 8 rows (reads first, then the stores) so the LDS / L2 latencies overlap
 #pragma unroll 1

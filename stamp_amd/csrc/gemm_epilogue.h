@@ -24,22 +24,29 @@ __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const E
     EpiCols<8> cols;      // [j * 4 + g]: columns n0 + wc * 64 + j * 32 + 8 g + 4 hi
     epi_cols_load<EPI>(ep, cols, [&](int q) { return n0 + wc * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi; });
     if constexpr (F16OUT) {
+        auto values = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = grp * 128 + i * 32 + l31;
+            for (int i = 0; i < 4; ++i) {
+                const int row = grp * 128 + i * 32 + l31;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    v = epi_value<EPI>(ep, cols.bias[j * 4 + g], cols.scale[j * 4 + g], v);
-                    vec4 o;
+                    for (int g = 0; g < 4; g += 2) {
+                        f32x4 v0 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        f32x4 v1 = {acc[i][j][4 * g + 4], acc[i][j][4 * g + 5], acc[i][j][4 * g + 6], acc[i][j][4 * g + 7]};
+                        epi_value_pair<EPI, FAST>(ep, cols.bias[j * 4 + g], cols.scale[j * 4 + g], cols.bias[j * 4 + g + 1],
+                                                  cols.scale[j * 4 + g + 1], v0, v1);
+                        vec4 o0, o1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = Act<T>::from_f32(v[e]);
-                    const int chunk = wc * 8 + j * 4 + g;
-                    *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + hi * 8) = o;
-                }
-        }
+                        for (int e = 0; e < 4; ++e) { o0[e] = Act<T>::from_f32(v0[e]); o1[e] = Act<T>::from_f32(v1[e]); }
+                        const int chunk = wc * 8 + j * 4 + g;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + hi * 8) = o0;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 1) ^ (row & 31)) << 4) + hi * 8) = o1;
+                    }
+            }
+        };
+        if (ep.bias != nullptr && ep.acc_scale == 1.0f) values(std::true_type{}); else values(std::false_type{});
         __syncthreads();
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
