@@ -216,8 +216,9 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { o0[e] = Act<T>::from_f32(v0[e]); o1[e] = Act<T>::from_f32(v1[e]); }
                                 const int chunk = wn * 16 + j * 4 + g;
-                                *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + hi * 8) = o0;
-                                *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 1) ^ (row & 31)) << 4) + hi * 8) = o1;
+                                const int half = (hi ^ ((l31 >> 3) & 1)) * 8;      // see gemm_epilogue.h: conflict-free 8-byte stores
+                                *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + half) = o0;
+                                *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 1) ^ (row & 31)) << 4) + half) = o1;
                             } else {
                                 const int chunk = wn * 16 + jj * 8 + 2 * g + hi;
                                 *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = v0;
@@ -238,6 +239,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                     for (int u = 0; u < 8; ++u) {
                         const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
                         v[u] = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
+                        if ((u >> 2) & 1) v[u] = u32x4{v[u][2], v[u][3], v[u][0], v[u][1]};      // row bit 3 set: halves stored swapped
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {

@@ -41,17 +41,21 @@ __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const E
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { o0[e] = Act<T>::from_f32(v0[e]); o1[e] = Act<T>::from_f32(v1[e]); }
                         const int chunk = wc * 8 + j * 4 + g;
-                        *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + hi * 8) = o0;
-                        *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 1) ^ (row & 31)) << 4) + hi * 8) = o1;
+                        // the 8-byte half inside the 16-byte chunk is XOR-ed with row bit 3: the 16 lanes of one LDS cycle then
+                        // hit 32 distinct banks (without it rows r and r+8 collide 2-way: SQ_LDS_BANK_CONFLICT = 4 cycles per store)
+                        const int half = (hi ^ ((l31 >> 3) & 1)) * 8;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + half) = o0;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 1) ^ (row & 31)) << 4) + half) = o1;
                     }
             }
         };
         if (ep.bias != nullptr && ep.acc_scale == 1.0f) values(std::true_type{}); else values(std::false_type{});
         __syncthreads();
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = wave * 32 + it * 2 + hi;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
+            if ((it >> 2) & 1) v = u32x4{v[2], v[3], v[0], v[1]};       // row bit 3 set: the halves were stored swapped
             const int chunk = l31 ^ (row & 31);
             if (m0 + row < M)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + chunk * 8) = v;

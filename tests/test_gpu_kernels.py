@@ -52,7 +52,7 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(1, 256, 128), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
+@pytest.mark.parametrize("M,N,K", [(1, 256, 128), (300, 256, 64), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
                                    (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
 @pytest.mark.parametrize("cfg", [3, 7, 8, 9, 10])
 def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
