@@ -57,6 +57,8 @@ template <> struct Act<f16> {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
+    // two v_cvt_pk_f16_f32 (element-wise conversion loops compile to v_cvt_f16_f32 + v_pack / v_alignbit: 2.5x the instructions)
+    static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
     static __device__ __forceinline__ float to_f32(f16 x) { return (float)x; }
 };
 template <> struct Act<bf16> {
@@ -72,6 +74,7 @@ template <> struct Act<bf16> {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
+    static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
     static __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
 };
 

@@ -118,7 +118,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     };
     // scheduling recipe of one k-step: 16 MFMAs with `reads` ds_reads and `copies` LDS-DMA requests in the gaps
     auto interleave = [&](auto reads_c, auto copies_c) {
-        if constexpr (ABL != 0) { __builtin_amdgcn_sched_barrier(0); return; }
+        if constexpr ((ABL & 15) != 0) { __builtin_amdgcn_sched_barrier(0); return; }
         constexpr int READS = decltype(reads_c)::value, COPIES = decltype(copies_c)::value;
 #pragma unroll
         for (int r = 0; r < READS; ++r) {
@@ -148,10 +148,28 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
+    // ABL & 16: thread 0 of every workgroup logs {s_memrealtime at start, s_memtime at 5 points, HW_ID, XCC_ID} into ep.pos (debug)
+    unsigned long long* tlog = nullptr;
+    if constexpr ((ABL & 16) != 0) {
+        if (tid == 0) {
+            tlog = reinterpret_cast<unsigned long long*>(const_cast<float*>(ep.pos)) + (long)blockIdx.x * 8;
+            tlog[0] = __builtin_amdgcn_s_memrealtime();
+            tlog[1] = __builtin_amdgcn_s_memtime();
+            tlog[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            tlog[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+    }
+#define AMDS_STAMP(k)                                                              \
+    do {                                                                           \
+        if constexpr ((ABL & 16) != 0) {                                           \
+            if (tlog) tlog[k] = __builtin_amdgcn_s_memtime();                      \
+        }                                                                          \
+    } while (0)
     const int nk = K / BK;   // >= 1
     issue_pieces(0, 0, 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AMDS_BARRIER();
+    AMDS_STAMP(2);                  // first K tile landed
     load_frags(0, 0, afA, wfA);
     if (nk > 1) issue_pieces(1, 0, P3);
     __builtin_amdgcn_sched_barrier(0);
@@ -184,6 +202,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     if (nk >= 2) k_tile(kt++, std::true_type{}, std::false_type{});
     k_tile(kt, std::false_type{}, std::false_type{});
     AMDS_BARRIER();                 // every wave is done with the LDS stages
+    AMDS_STAMP(3);                  // K loop done
 #undef AMDS_BARRIER
 
     // ---- epilogue: LDS-staged, coalesced (wave tile 128 x 128) -----------------------------------------------
@@ -192,19 +211,32 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                             EPI == AMDS_EPI_BIAS_GELU_F32 || EPI == AMDS_EPI_BIAS_RELU_F32;
     if constexpr (STAGED) {
         constexpr int NPASS = F16OUT ? 1 : 2;
+        // (staging and storing the fp16 tile in two halves, so that the first half's stores drain under the second half's VALU
+        //  work, measured 4 % slower per launch: one more barrier, shorter store batches)
+        constexpr int NH = 1, FMH = FM / NH;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
             if (pass) __syncthreads();
             // fragment column j outermost: its 4 bias / LayerScale vectors are loaded once (16 registers), then used by 4 row blocks
             auto values = [&](auto fast_c) {
                 constexpr bool FAST = decltype(fast_c)::value;
+                // bias / LayerScale vectors of fragment column jj + 1 are requested before column jj is processed: one exposed L2
+                // round trip per pass instead of one per column (one wave per SIMD: nothing else would hide them)
+                constexpr int NJ = F16OUT ? 4 : 2;
+                auto load_cols = [&](EpiCols<4>& c, int j) {
+                    epi_cols_load<EPI>(ep, c, [&](int g) { return n0 + wn * 128 + j * 32 + 8 * g + 4 * hi; });
+                };
+                EpiCols<4> cols, cols_next;
+                load_cols(cols, F16OUT ? 0 : pass * 2);
 #pragma unroll
-                for (int jj = 0; jj < (F16OUT ? 4 : 2); ++jj) {
+                for (int jj = 0; jj < NJ; ++jj) {
                     const int j = F16OUT ? jj : pass * 2 + jj;
-                    EpiCols<4> cols;
-                    epi_cols_load<EPI>(ep, cols, [&](int g) { return n0 + wn * 128 + j * 32 + 8 * g + 4 * hi; });
+                    if (jj + 1 < NJ) load_cols(cols_next, j + 1);
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) {
+                    for (int ii = 0; ii < FMH; ++ii) {
+                        const int i = h * FMH + ii;
                         const int row = wm * 128 + i * 32 + l31;
 #pragma unroll
                         for (int g = 0; g < 4; g += 2) {
@@ -212,9 +244,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                             f32x4 v1 = {acc[i][j][4 * g + 4], acc[i][j][4 * g + 5], acc[i][j][4 * g + 6], acc[i][j][4 * g + 7]};
                             epi_value_pair<EPI, FAST>(ep, cols.bias[g], cols.scale[g], cols.bias[g + 1], cols.scale[g + 1], v0, v1);
                             if constexpr (F16OUT) {
-                                vec4 o0, o1;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { o0[e] = Act<T>::from_f32(v0[e]); o1[e] = Act<T>::from_f32(v1[e]); }
+                                const vec4 o0 = Act<T>::from_f32x4(v0), o1 = Act<T>::from_f32x4(v1);
                                 const int chunk = wn * 16 + j * 4 + g;
                                 const int half = (hi ^ ((l31 >> 3) & 1)) * 8;      // see gemm_epilogue.h: conflict-free 8-byte stores
                                 *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + half) = o0;
@@ -226,24 +256,26 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                             }
                         }
                     }
+                    cols = cols_next;
                 }
             };
             if (F16OUT && ep.bias != nullptr && ep.acc_scale == 1.0f) values(std::true_type{}); else values(std::false_type{});
             __syncthreads();
+            if (h == NH - 1) AMDS_STAMP(4);              // values staged
             // one wave per SIMD: batch 8 rows (reads first, then the stores) so the LDS / L2 latencies overlap
 #pragma unroll 1
-            for (int b8 = 0; b8 < 4; ++b8) {
+            for (int b8 = 0; b8 < 4 / NH; ++b8) {
                 if constexpr (F16OUT) {
                     u32x4 v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                        const int rr = wave * (64 / NH) + (b8 * 8 + u) * 2 + hi, row = NH == 2 ? (rr >> 6) * 128 + h * 64 + (rr & 63) : rr;
                         v[u] = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
                         if ((u >> 2) & 1) v[u] = u32x4{v[u][2], v[u][3], v[u][0], v[u][1]};      // row bit 3 set: halves stored swapped
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                        const int rr = wave * (64 / NH) + (b8 * 8 + u) * 2 + hi, row = NH == 2 ? (rr >> 6) * 128 + h * 64 + (rr & 63) : rr;
                         const int chunk = l31 ^ (row & 31);
                         if (m0 + row < M)
                             *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + chunk * 8) = v[u];
@@ -271,6 +303,7 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                     }
                 }
             }
+          }
         }
     } else {
 #pragma unroll
@@ -309,8 +342,9 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
             }
         }
     }
+    AMDS_STAMP(5);                      // all global stores issued
+#undef AMDS_STAMP
 }
-
 
 template <typename T, int EPI, int ABL, int P3 = 6, int P0 = 6>
 static int launch_gemm_4w64_abl(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,

@@ -37,9 +37,7 @@ __device__ __forceinline__ void epilogue_staged_256(f32x16 (&acc)[4][2], const E
                         f32x4 v1 = {acc[i][j][4 * g + 4], acc[i][j][4 * g + 5], acc[i][j][4 * g + 6], acc[i][j][4 * g + 7]};
                         epi_value_pair<EPI, FAST>(ep, cols.bias[j * 4 + g], cols.scale[j * 4 + g], cols.bias[j * 4 + g + 1],
                                                   cols.scale[j * 4 + g + 1], v0, v1);
-                        vec4 o0, o1;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { o0[e] = Act<T>::from_f32(v0[e]); o1[e] = Act<T>::from_f32(v1[e]); }
+                        const vec4 o0 = Act<T>::from_f32x4(v0), o1 = Act<T>::from_f32x4(v1);
                         const int chunk = wc * 8 + j * 4 + g;
                         // the 8-byte half inside the 16-byte chunk is XOR-ed with row bit 3: the 16 lanes of one LDS cycle then
                         // hit 32 distinct banks (without it rows r and r+8 collide 2-way: SQ_LDS_BANK_CONFLICT = 4 cycles per store)

@@ -8,11 +8,15 @@ namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(f16)
 }
 
+// log buffer for the timeline bit (16) of the 2000-range ablation ids: set it, then call amds_gemm_ablate(2016, ...) with a real bias
+static void* g_gemm_debug_log = nullptr;
+extern "C" void amds_gemm_debug_log(void* p) { g_gemm_debug_log = p; }
+
 // performance-archaeology entry (f16, EPI_BIAS only): ablated variants of the 8-phase kernel; results are wrong by design
 extern "C" int amds_gemm_ablate(int abl, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                                 void* out, long ldo, const float* bias, void* stream) {
     using namespace amds;
-    EpiArgs ep; ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; ep.pos = (abl & 16) ? bias : nullptr; if (abl & 16) ep.bias = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.f;
+    EpiArgs ep; ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; const int bits = abl >= 2000 ? abl - 2000 : (abl >= 1000 ? abl - 1000 : abl); ep.pos = (bits & 16) ? bias : nullptr; if (bits & 16) ep.bias = nullptr; if (abl >= 2000 && (bits & 16)) { if (!g_gemm_debug_log) return AMDS_ERR_INVALID; ep.pos = (const float*)g_gemm_debug_log; ep.bias = bias; } ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.f;
     hipStream_t st = (hipStream_t)stream;
     switch (abl) {
 #define C_(x) case x: return launch_gemm_8p_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
@@ -26,7 +30,7 @@ extern "C" int amds_gemm_ablate(int abl, const void* A, long lda, const void* W,
     }
     switch (abl - 2000) {     // 2000 + bits: the 4-wave / 128-byte-row kernel
 #define E_(x) case x: return launch_gemm_4w64_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
-        E_(0) E_(1) E_(4) E_(5) E_(8) E_(9) E_(12) E_(13)
+        E_(0) E_(1) E_(4) E_(5) E_(8) E_(9) E_(12) E_(13) E_(16)
 #undef E_
     }
     return AMDS_ERR_INVALID;
