@@ -22,7 +22,9 @@ namespace amds {
 // ABL: ablation bits (results WRONG when non-zero; only reachable through amds_gemm_ablate): 1 = no LDS-DMA after the first
 // two K tiles, 4 = no fragment ds_reads after the first, 8 = no barriers
 // P3 / P0: LDS-DMA pieces of the next K tile requested in k-step 3 of the previous tile / k-step 0 (the rest in k-step 1)
-template <typename T, int EPI, int ABL = 0, int P3 = 6, int P0 = 6>
+// AUXA / AUXW: cache-policy bits of the LDS-DMA loads of the A / W tiles (0 = default, 1 = sc0, 2 = nt, 3 = sc0 nt); measured at the
+// power cap: sc0 no change, nt on W -6...-12 %, nt on A 0...-5 %
+template <typename T, int EPI, int ABL = 0, int P3 = 6, int P0 = 6, int AUXA = 0, int AUXW = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
                  EpiArgs ep, int tiles_m, int tiles_n) {
@@ -76,10 +78,14 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         const int koff = kt * BK * 2;
 #pragma unroll
         for (int it = 0; it < 16; ++it)
-            if (it >= lo && it < hi_)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(it < 8 ? rsrc_a : rsrc_w,
-                                                         (lptr_t)(st + (it >> 3) * A_BYTES + ((it & 7) * NT + wave * 64) * 16), 16,
-                                                         voff[it], koff, 0, 0);
+            if (it >= lo && it < hi_) {
+                if (it < 8) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(st + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff, 0, AUXA);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(st + A_BYTES + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff,
+                                                             0, AUXW);
+                }
+            }
     };
 
     const int swz = (l31 >> 1) & 7;
@@ -346,11 +352,11 @@ gemm_4w64_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #undef AMDS_STAMP
 }
 
-template <typename T, int EPI, int ABL, int P3 = 6, int P0 = 6>
+template <typename T, int EPI, int ABL, int P3 = 6, int P0 = 6, int AUXA = 0, int AUXW = 0>
 static int launch_gemm_4w64_abl(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                                 hipStream_t st) {
     constexpr int LDS = 2 * (256 + 256) * 128;
-    auto kern = gemm_4w64_kernel<T, EPI, ABL, P3, P0>;
+    auto kern = gemm_4w64_kernel<T, EPI, ABL, P3, P0, AUXA, AUXW>;
     AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int tiles_m = cdiv(M, 256), tiles_n = N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,

@@ -16,7 +16,7 @@ extern "C" void amds_gemm_debug_log(void* p) { g_gemm_debug_log = p; }
 extern "C" int amds_gemm_ablate(int abl, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                                 void* out, long ldo, const float* bias, void* stream) {
     using namespace amds;
-    EpiArgs ep; ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; const int bits = abl >= 2000 ? abl - 2000 : (abl >= 1000 ? abl - 1000 : abl); ep.pos = (bits & 16) ? bias : nullptr; if (bits & 16) ep.bias = nullptr; if (abl >= 2000 && (bits & 16)) { if (!g_gemm_debug_log) return AMDS_ERR_INVALID; ep.pos = (const float*)g_gemm_debug_log; ep.bias = bias; } ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.f;
+    EpiArgs ep; ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = nullptr; const int bits = abl >= 3000 ? 0 : (abl >= 2000 ? abl - 2000 : (abl >= 1000 ? abl - 1000 : abl)); ep.pos = (bits & 16) ? bias : nullptr; if (bits & 16) ep.bias = nullptr; if (abl >= 2000 && (bits & 16)) { if (!g_gemm_debug_log) return AMDS_ERR_INVALID; ep.pos = (const float*)g_gemm_debug_log; ep.bias = bias; } ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.f;
     hipStream_t st = (hipStream_t)stream;
     switch (abl) {
 #define C_(x) case x: return launch_gemm_8p_abl<f16, AMDS_EPI_BIAS, x>(A, lda, W, ldw, M, N, K, ep, st);
