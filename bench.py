@@ -154,8 +154,8 @@ def main() -> None:
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-        "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles where N is not a multiple of 256, gemm_4w64_kernel / gemm_8p64_kernel in stage 4 and the stage-3 MLP)" if is_swin else
-                               "256x256x64 MFMA 32x32x16 GEMMs with fused LDS-staged epilogues: gemm_4w64_kernel (4 waves, 128x128 wave tiles; qkv / proj / fc2) + gemm_8p64_kernel (8 waves, staggered groups; fc1 + GELU)", "bound": "mfma",
+        "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles where N is not a multiple of 256, gemm_4w16_kernel in stage 4 and the stage-3 MLP)" if is_swin else
+                               "gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_traffic.json); algorithmic 1.48e9 -> 1.43x (A panels re-fetched across N tiles, served by L2/MALL)" if traffic else None,

@@ -56,6 +56,9 @@ template <> struct Act<f16> {
     static __device__ __forceinline__ void mfma32_agpr(vec8 a, vec8 b, f32x16& c) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
+    static __device__ __forceinline__ void mfma16_agpr(vec8 a, vec8 b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
     // two v_cvt_pk_f16_f32 (element-wise conversion loops compile to v_cvt_f16_f32 + v_pack / v_alignbit: 2.5x the instructions)
     static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
@@ -72,6 +75,9 @@ template <> struct Act<bf16> {
     }
     static __device__ __forceinline__ void mfma32_agpr(vec8 a, vec8 b, f32x16& c) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma16_agpr(vec8 a, vec8 b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
     static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }

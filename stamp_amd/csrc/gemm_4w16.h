@@ -1,0 +1,287 @@
+// gemm_4w16.h -- gemm_4w64.h (256 x 256 x 64 tiles, four waves, 128 x 128 wave tiles, two 64 KB LDS stages, buffer-form LDS-DMA)
+// on v_mfma_f32_16x16x32 instead of v_mfma_f32_32x32x16.
+//
+// Why: under the socket power cap the matrix pipe's own draw sets the clock, and the 16x16x32 instruction is the cheaper one
+// per flop -- tools/ubench/mfma_rate.hip, bare MFMA streams on pseudo-random operands, 2.5 s sustained: 32x32x16 1.74 PFLOP/s at
+// 1.82 GHz / 1310 W, 16x16x32 2.05 PFLOP/s at 2.13 GHz / 1355 W (profiles/r01_gemm_vendor_and_power.txt).  The vendor kernel
+// for these shapes uses it too (MI16x16x1).
+//
+// Same LDS image as gemm_4w64.h (128-byte rows, 16-byte chunk index XOR (row>>1)&7): a 16x16x32 operand fragment is 16 rows x
+// 4 chunks (lane = row l15, chunk kb = lane>>4), and with that swizzle the 16 lanes of every ds_read_b128 cycle still fall into
+// 16 distinct 16-byte bank slots.  Accumulators: 8 x 8 blocks of 16 x 16 (f32x4 per lane: row m = l15, columns 4 kb .. 4 kb + 3
+// -- W is again the MFMA "A" operand).  A K tile is four units of 32 MFMAs (512 cycles each, like a k-step of gemm_4w64.h):
+//     u0  MFMA(set 0, row blocks 0-3) | 8 reads of set 1 <- (kt, k 32..63) | LDS-DMA pieces P3 .. P3+P0 of tile kt+1
+//     u1  MFMA(set 0, row blocks 4-7) | 8 reads of set 1                    | the remaining pieces of tile kt+1
+//     u2  MFMA(set 1, row blocks 0-3)
+//     lgkmcnt(0), vmcnt(0), s_barrier
+//     u3  MFMA(set 1, row blocks 4-7) | 16 reads of set 0 <- (kt+1, k 0..31) | pieces 0 .. P3 of tile kt+2
+// Results differ from the 32x32x16 kernels in the last bits (32 products are summed per instruction instead of 16).
+#pragma once
+#include <type_traits>
+#include "gemm_kernel.h"
+
+namespace amds {
+
+template <typename T, int EPI, int P3 = 6, int P0 = 6>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
+                 EpiArgs ep, int tiles_m, int tiles_n) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int BM = 256, BN = 256, BK = 64, NT = 256;
+    constexpr int ROWB = BK * 2;                                   // 128 bytes per LDS row
+    constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;   // 32 KB, 64 KB
+    constexpr int FI = 8, FJ = 8;                                  // 16 x 16 blocks per wave tile
+    constexpr int GROUP_M = 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kb = lane >> 4;
+    const int l31 = lane & 31, hi = lane >> 5;      // read-back of the staged tile (row-wise, as in gemm_4w64.h)
+
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int group = GROUP_M * tiles_n;
+        const int g = t / group, first_m = g * GROUP_M;
+        const int gm = min(tiles_m - first_m, GROUP_M);
+        const int rr = t - g * group;
+        tm = first_m + rr % gm;
+        tn = rr / gm;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- copy addressing: 4096 16-byte chunks per K tile, 16 per thread (8 of A, 8 of W); chunk ^= (row>>1)&7 on the source.
+    // Buffer form (buffer_load_dwordx4 ... offen lds): one 32-bit byte offset per piece, constant over the K loop, the K
+    // advance in the scalar offset, no vector address arithmetic in the loop; rows past M are out of range and read as 0.
+    const int rows_a = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(A + (long)m0 * lda), 0, (int)((((long)rows_a - 1) * lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(W + (long)n0 * ldw), 0, (int)(((long)(BN - 1) * ldw + K) * 2), 0x00020000);
+    int voff[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int c = (it & 7) * NT + tid, row = c >> 3, cp = c & 7, sc = cp ^ ((row >> 1) & 7);
+        voff[it] = (int)(((long)row * (it < 8 ? lda : ldw) + sc * 8) * 2);
+    }
+    auto issue_pieces = [&](int kt, int lo, int hi_) {
+        char* st = smem + (kt & 1) * STAGE;
+        const int koff = kt * BK * 2;
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            if (it >= lo && it < hi_) {
+                if (it < 8) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(st + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(st + A_BYTES + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff,
+                                                             0, 0);
+                }
+            }
+    };
+
+    const int swz = (l15 >> 1) & 7;
+    const int a_off = (wm * 128 + l15) * ROWB;
+    const int w_off = A_BYTES + (wn * 128 + l15) * ROWB;
+
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    vec8 af[2][FI], wf[2][FJ];
+    // fragments [lo, hi) of the 16 (8 A then 8 W) of k-half ks of tile kt into set s
+    auto load_frags = [&](int kt, int ks, int s, int lo, int hi_) {
+        const char* sb = smem + (kt & 1) * STAGE;
+        const int co = ((ks * 4 + kb) ^ swz) << 4;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q >= lo && q < hi_) {
+                if (q < 8) af[s][q] = *reinterpret_cast<const vec8*>(sb + a_off + q * 16 * ROWB + co);
+                else wf[s][q - 8] = *reinterpret_cast<const vec8*>(sb + w_off + (q - 8) * 16 * ROWB + co);
+            }
+    };
+    // one LDS-DMA piece / one fragment read (the fillers of a unit)
+    auto issue_piece = [&](int kt, int it) { issue_pieces(kt, it, it + 1); };
+    // A unit = 32 MFMAs (set s, row blocks 4 ih .. 4 ih + 3, all 8 column blocks) with, behind the first NR of them, one fragment
+    // read each (fragments rlo .. rlo + NR - 1 of k-half rks of tile rkt into set rs) and behind the next NC one LDS-DMA piece each
+    // (pieces clo .. of tile ckt).  The MFMAs are inline asm with the accumulators pinned to AGPRs: with the builtin, the register
+    // allocator keeps part of the 64 f32x4 accumulators in VGPRs and shuffles them through AGPRs (380 v_accvgpr moves per K tile).
+    // Inline asm is invisible to the sched_group_barrier masks, so the order is pinned with a scheduling barrier after every slot.
+    auto unit = [&](int s, int ih, auto nr_c, int rkt, int rks, int rs, int rlo, auto nc_c, int ckt, int clo) {
+        constexpr int NR = decltype(nr_c)::value, NC = decltype(nc_c)::value;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            Act<T>::mfma16_agpr(wf[s][m & 7], af[s][ih * 4 + (m >> 3)], acc[ih * 4 + (m >> 3)][m & 7]);
+            if (m < NR) load_frags(rkt, rks, rs, rlo + m, rlo + m + 1);
+            else if (m - NR < NC) issue_piece(ckt, clo + m - NR);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 8> I8;
+    typedef std::integral_constant<int, 16> I16;
+    constexpr int P1 = 16 - P3 - P0;
+    static_assert(P3 <= 8 && P0 <= 8 && P1 >= 0 && P1 <= 8, "LDS-DMA piece split");
+    typedef std::integral_constant<int, P3> IP3;
+    typedef std::integral_constant<int, P0> IP0;
+    typedef std::integral_constant<int, P1> IP1;
+
+#define AMDS_BARRIER()                        \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
+    const int nk = K / BK;   // >= 1
+    issue_pieces(0, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMDS_BARRIER();
+    load_frags(0, 0, 0, 0, 16);
+    if (nk > 1) issue_pieces(1, 0, P3);
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto k_tile = [&](int kt, auto next_c, auto next2_c) {
+        constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
+        if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, P3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
+        if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, P3 + P0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
+        unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AMDS_BARRIER();
+        if constexpr (NEXT2) unit(1, 1, I16{}, kt + 1, 0, 0, 0, IP3{}, kt + 2, 0);
+        else if constexpr (NEXT) unit(1, 1, I16{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
+        else unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+    };
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
+    if (nk >= 2) k_tile(kt++, std::true_type{}, std::false_type{});
+    k_tile(kt, std::false_type{}, std::false_type{});
+    AMDS_BARRIER();                 // every wave is done with the LDS stages
+#undef AMDS_BARRIER
+    // MFMA result -> accumulator read hazard: the compiler does not know the inline asm is an MFMA, so it neither pads the read of
+    // a result nor keeps it away -- left alone it copies an accumulator to VGPRs right behind the asm that last wrote it (one
+    // s_nop later: the copy returns the value from BEFORE that MFMA).  Passing every accumulator through these asm statements as
+    // an AGPR operand keeps all of them in AGPRs until the nops have been executed.
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        if (i == 0)
+            asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]),
+                         "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+        else
+            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]),
+                         "+a"(acc[i][6]), "+a"(acc[i][7]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: LDS-staged, coalesced.  Block (i, j): row = wm*128 + 16 i + l15, columns wn*128 + 16 j + 4 kb .. + 3 ----
+    constexpr bool F16OUT = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU);
+    static_assert(epi_is_staged<EPI>(), "gemm_4w16 has staged epilogues only");
+    constexpr int NPASS = F16OUT ? 1 : 2;
+    constexpr int JP = FJ / NPASS;                 // column blocks per pass
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass) __syncthreads();
+        EpiCols<JP> cols;                           // [jj]: columns n0 + wn*128 + 16 (pass*JP + jj) + 4 kb
+        epi_cols_load<EPI>(ep, cols, [&](int jj) { return n0 + wn * 128 + (pass * JP + jj) * 16 + 4 * kb; });
+        auto values = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int row = wm * 128 + i * 16 + l15;
+#pragma unroll
+                for (int jj = 0; jj < JP; jj += 2) {
+                    const int j = pass * JP + jj;
+                    f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
+                    epi_value_pair<EPI, FAST>(ep, cols.bias[jj], cols.scale[jj], cols.bias[jj + 1], cols.scale[jj + 1], v0, v1);
+                    if constexpr (F16OUT) {
+                        const vec4 o0 = Act<T>::from_f32x4(v0), o1 = Act<T>::from_f32x4(v1);
+                        // 16-byte chunk of the 512-byte row: wn*16 + 2 j + (kb>>1); the 8-byte half (kb & 1) is XOR-ed with row bit 3
+                        const int chunk = wn * 16 + j * 2 + (kb >> 1);
+                        const int half = ((kb & 1) ^ ((l15 >> 3) & 1)) * 8;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + half) = o0;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 2) ^ (row & 31)) << 4) + half) = o1;
+                    } else {
+                        const int chunk = wn * 16 + jj * 4 + kb;       // 16-byte chunk = 4 fp32 columns of this pass's 128
+                        *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = v0;
+                        *reinterpret_cast<f32x4*>(smem + row * 512 + (((chunk + 4) ^ (row & 31)) << 4)) = v1;
+                    }
+                }
+            }
+        };
+        if (F16OUT && ep.bias != nullptr && ep.acc_scale == 1.0f) values(std::true_type{}); else values(std::false_type{});
+        __syncthreads();
+        // one wave per SIMD: batch 8 rows (reads first, then the stores) so the LDS / L2 latencies overlap
+#pragma unroll 1
+        for (int b8 = 0; b8 < 4; ++b8) {
+            if constexpr (F16OUT) {
+                u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                    v[u] = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
+                    if ((u >> 2) & 1) v[u] = u32x4{v[u][2], v[u][3], v[u][0], v[u][1]};      // row bit 3 set: halves stored swapped
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                    const int chunk = l31 ^ (row & 31);
+                    if (m0 + row < M)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + chunk * 8) = v[u];
+                }
+            } else {
+                f32x4 v[8], o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                    const int chunk = l31 ^ (row & 31);
+                    const int n = n0 + (chunk >> 4) * 128 + pass * 64 + (chunk & 15) * 4;
+                    v[u] = *reinterpret_cast<const f32x4*>(smem + row * 512 + l31 * 16);
+                    if constexpr (EPI == AMDS_EPI_RESIDUAL)
+                        o[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.out) +
+                                                               (long)min(m0 + row, M - 1) * ep.ldo + n);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                    const int chunk = l31 ^ (row & 31);
+                    const int n = n0 + (chunk >> 4) * 128 + pass * 64 + (chunk & 15) * 4;
+                    if constexpr (EPI == AMDS_EPI_RESIDUAL) v[u] += o[u];
+                    if (m0 + row < M)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (long)(m0 + row) * ep.ldo + n) = v[u];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int EPI>
+static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
+                            hipStream_t st) {
+    if constexpr (!epi_is_staged<EPI>()) {
+        return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
+    } else {
+        constexpr int LDS = 2 * (256 + 256) * 128;
+        auto kern = gemm_4w16_kernel<T, EPI>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_set = true;
+        }
+        const int tiles_m = cdiv(M, 256), tiles_n = N / 256;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
+                           reinterpret_cast<const T*>(W), ldw, M, N, K, ep, tiles_m, tiles_n);
+        AMDS_LAUNCH_CHECK("gemm_4w16_kernel");
+        return AMDS_OK;
+    }
+}
+
+}  // namespace amds

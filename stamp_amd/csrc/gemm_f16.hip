@@ -4,6 +4,7 @@
 #include "gemm_8p64.h"
 #include "gemm_pp.h"
 #include "gemm_4w64.h"
+#include "gemm_4w16.h"
 namespace amds {
 AMDS_GEMM_DISPATCH_IMPL(f16)
 }

@@ -34,7 +34,7 @@ def _gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10, 12])
 @pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
 def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
@@ -54,7 +54,7 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1, 256, 128), (300, 256, 64), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
                                    (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
-@pytest.mark.parametrize("cfg", [3, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [3, 7, 8, 9, 10, 12])
 def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
     """The pipelined kernels (3 / 8: staggered two-group 8-wave; 7 / 10: four waves, 128x128 wave tiles; 9: ping-pong):
     exact-shape sweep incl. the minimum K, ragged M (rows past M are out of range of the LDS-DMA buffer descriptor), and a
@@ -73,7 +73,7 @@ def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10, 12])
 def test_gemm_epilogues(gpu, dt, cfg):
     M, N, K = 771, 512, 256
     _g = ops.gemm
@@ -117,8 +117,9 @@ def test_gemm_epilogues(gpu, dt, cfg):
 
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_kernels_bit_identical(gpu, dt):
-    """Every 256-wide kernel id accumulates k in the same order with the same MFMA: outputs are bit-identical, so the library's
-    per-epilogue choice of kernel (amds_gemm default) never changes a result."""
+    """The 256-wide kernels built on v_mfma 32x32x16 (ids 3, 7, 8, 9, 10) accumulate k in the same order: bit-identical outputs.
+    Id 12 (v_mfma 16x16x32, the library default) sums 32 products per instruction: last-bit differences only, and it is the
+    kernel the default dispatch picks for this shape."""
     g = torch.Generator().manual_seed(11)
     M, N, K = 1500, 768, 320
     a = torch.randn(M, K, generator=g).to(gpu, dt)
@@ -126,8 +127,11 @@ def test_gemm_kernels_bit_identical(gpu, dt):
     bias = torch.randn(N, generator=g).to(gpu)
     for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_BIAS_F32):
         ref = ops.gemm(a, w, epi, bias=bias, cfg=8)
-        for cfg in (3, 7, 9, 10, -1):
+        for cfg in (3, 7, 9, 10):
             assert torch.equal(ops.gemm(a, w, epi, bias=bias, cfg=cfg), ref), (epi, cfg)
+        o12 = ops.gemm(a, w, epi, bias=bias, cfg=12)
+        assert torch.equal(ops.gemm(a, w, epi, bias=bias), o12), epi          # default dispatch = id 12 here
+        assert (o12.float() - ref.float()).abs().max().item() <= 4e-3 * ref.float().abs().max().item(), epi
 
 
 @pytest.mark.parametrize("dt", DTYPES)

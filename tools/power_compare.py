@@ -34,9 +34,12 @@ def sampler():
 
 cases = [("vendor matmul", lambda: torch.matmul(a, w.t())),
          ("amds cfg 10 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=10)),
+         ("amds cfg 12 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=12)),
          ("amds cfg 8 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=8)),
          ("amds cfg 10 residual", lambda: ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=b, out=res, cfg=10)),
-         ("amds cfg 10 gelu", lambda: ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=b, cfg=10))]
+         ("amds cfg 12 residual", lambda: ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=b, out=res, cfg=12)),
+         ("amds cfg 10 gelu", lambda: ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=b, cfg=10)),
+         ("amds cfg 12 gelu", lambda: ops.gemm(a, w, _lib.EPI_BIAS_GELU, bias=b, cfg=12))]
 for name, fn in cases:
     stop = False
     samples.clear()
