@@ -35,6 +35,9 @@ def sampler():
 cases = [("vendor matmul", lambda: torch.matmul(a, w.t())),
          ("amds cfg 10 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=10)),
          ("amds cfg 12 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=12)),
+         ("amds cfg 13 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=13)),
+         ("amds cfg 12 bias (2)", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=12)),
+         ("amds cfg 13 bias (2)", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=13)),
          ("amds cfg 8 bias", lambda: ops.gemm(a, w, _lib.EPI_BIAS, bias=b, cfg=8)),
          ("amds cfg 10 residual", lambda: ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=b, out=res, cfg=10)),
          ("amds cfg 12 residual", lambda: ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=b, out=res, cfg=12)),
