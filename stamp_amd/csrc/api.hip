@@ -155,8 +155,13 @@ extern "C" int amds_gemm_batched(const void* A, long lda, long bsA, const void* 
     ep.bsA = bsA; ep.bsW = bsW; ep.bsOut = bsOut; ep.nbatch = nbatch;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, 2.0 * nbatch * M * (double)N * K, st);
-    if (dtype == AMDS_F16) return gemm_dispatch<f16>(8, epi, A, lda, W, ldw, M, N, K, ep, st);
-    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(8, epi, A, lda, W, ldw, M, N, K, ep, st);
+    static int bcfg = -1;
+    if (bcfg < 0) {
+        const char* e = getenv("AMDS_GEMM_CFG");
+        bcfg = (e && *e && atoi(e) == 8) ? 8 : 12;          // AMDS_GEMM_CFG=8: the eight-wave kernel (A/B)
+    }
+    if (dtype == AMDS_F16) return gemm_dispatch<f16>(bcfg, epi, A, lda, W, ldw, M, N, K, ep, st);
+    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(bcfg, epi, A, lda, W, ldw, M, N, K, ep, st);
     set_error("amds_gemm_batched: bad dtype %d", dtype);
     return AMDS_ERR_INVALID;
 }

@@ -56,6 +56,14 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         tn = rr / gm;
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    if (ep.nbatch > 1) {       // batched / split-K: operands and output of batch blockIdx.y (element strides)
+        const long by = blockIdx.y;
+        A += by * ep.bsA;
+        W += by * ep.bsW;
+        constexpr bool F32O = (EPI == AMDS_EPI_RESIDUAL || EPI == AMDS_EPI_BIAS_F32 || EPI == AMDS_EPI_BIAS_GELU_F32 || EPI == AMDS_EPI_BIAS_RELU_F32);
+        if (F32O) ep.out = reinterpret_cast<float*>(ep.out) + by * ep.bsOut;
+        else ep.out = reinterpret_cast<T*>(ep.out) + by * ep.bsOut;
+    }
 
     // ---- copy addressing: 4096 16-byte chunks per K tile, 16 per thread (8 of A, 8 of W); chunk ^= (row>>1)&7 on the source.
     // Buffer form (buffer_load_dwordx4 ... offen lds): one 32-bit byte offset per piece, constant over the K loop, the K
@@ -287,7 +295,7 @@ static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, in
             attr_set = true;
         }
         const int tiles_m = cdiv(M, 256), tiles_n = N / 256;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, ep.nbatch), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
                            reinterpret_cast<const T*>(W), ldw, M, N, K, ep, tiles_m, tiles_n);
         AMDS_LAUNCH_CHECK("gemm_4w16_kernel");
         return AMDS_OK;

@@ -430,7 +430,7 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
     if (cfg == 9) cfg = 8;
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
-    if (cfg == 12 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w16<T, EPI, true>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 13 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w16<T, EPI, false>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 12 || cfg == 13) cfg = 8;
 
