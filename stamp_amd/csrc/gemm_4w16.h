@@ -98,11 +98,36 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     const int a_off = (wm * 128 + l15) * ROWB;
     const int w_off = A_BYTES + (wn * 128 + l15) * ROWB;
 
+    // The accumulators start from the bias (when there is one and acc_scale == 1): the epilogue then has no bias add (128 packed
+    // adds per tile) and no bias loads to wait for; the 8 vectors are requested here and land under the first K tile's DMA.
+    const bool bias_in_acc = ep.bias != nullptr && ep.acc_scale == 1.0f;
     f32x4 acc[FI][FJ];
+    {
+        f32x4 b0[FJ];
 #pragma unroll
-    for (int i = 0; i < FI; ++i)
+        for (int j = 0; j < FJ; ++j) b0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias_in_acc) {
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < FJ; ++j) b0[j] = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + j * 16 + 4 * kb);
+        }
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = b0[j];
+    }
+    // The initial values must BE in their AGPRs well before the first inline-asm MFMA reads them: left alone, the compiler sinks
+    // the v_accvgpr_write of an accumulator right in front of the asm that first uses it, and -- not knowing that asm is an MFMA --
+    // without the wait states the hardware needs (wrong sums in single 16 x 16 blocks).
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        if (i == FI - 1)
+            asm volatile("s_nop 7" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]),
+                         "+a"(acc[i][6]), "+a"(acc[i][7]));
+        else
+            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]),
+                         "+a"(acc[i][6]), "+a"(acc[i][7]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     vec8 af[2][FI], wf[2][FJ];
     // fragments [lo, hi) of the 16 (8 A then 8 W) of k-half ks of tile kt into set s
@@ -208,8 +233,10 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         if (pass) __syncthreads();
+        EpiArgs epv = ep;                           // what the value transform still has to apply
+        if (bias_in_acc) epv.bias = nullptr;
         EpiCols<JP> cols;                           // [jj]: columns n0 + wn*128 + 16 (pass*JP + jj) + 4 kb
-        epi_cols_load<EPI>(ep, cols, [&](int jj) { return n0 + wn * 128 + (pass * JP + jj) * 16 + 4 * kb; });
+        epi_cols_load<EPI>(epv, cols, [&](int jj) { return n0 + wn * 128 + (pass * JP + jj) * 16 + 4 * kb; });
         auto values = [&](auto fast_c) {
             constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
@@ -219,7 +246,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                 for (int jj = 0; jj < JP; jj += 2) {
                     const int j = pass * JP + jj;
                     f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
-                    epi_value_pair<EPI, FAST>(ep, cols.bias[jj], cols.scale[jj], cols.bias[jj + 1], cols.scale[jj + 1], v0, v1);
+                    epi_value_pair<EPI, FAST, true>(epv, cols.bias[jj], cols.scale[jj], cols.bias[jj + 1], cols.scale[jj + 1], v0, v1);
                     if constexpr (F16OUT) {
                         const vec4 o0 = Act<T>::from_f32x4(v0), o1 = Act<T>::from_f32x4(v1);
                         // 16-byte chunk of the 512-byte row: wn*16 + 2 j + (kb>>1); the 8-byte half (kb & 1) is XOR-ed with row bit 3
@@ -235,7 +262,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                 }
             }
         };
-        if (F16OUT && ep.bias != nullptr && ep.acc_scale == 1.0f) values(std::true_type{}); else values(std::false_type{});
+        if (F16OUT && (bias_in_acc || (ep.bias == nullptr && ep.acc_scale == 1.0f))) values(std::true_type{}); else values(std::false_type{});
         __syncthreads();
         // one wave per SIMD: batch 8 rows (reads first, then the stores) so the LDS / L2 latencies overlap
 #pragma unroll 1

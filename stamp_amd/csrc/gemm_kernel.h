@@ -94,19 +94,24 @@ __device__ __forceinline__ f32x4 epi_value(const EpiArgs& ep, const f32x4& bias,
 // Two column groups at once for the 16-bit-output epilogues: the GELU polynomial runs as four interleaved chains.
 // FAST = (bias present, acc_scale == 1): decided once per kernel by a uniform branch around the value loop; left inside it the
 // two tests become v_cndmask selects (12 of ~70 VALU instructions per 4 outputs).
-template <int EPI, bool FAST>
+// NOBIAS (with FAST): the bias is already in the accumulators (gemm_4w16.h initialises them with it).
+template <int EPI, bool FAST, bool NOBIAS = false>
 __device__ __forceinline__ void epi_value_pair(const EpiArgs& ep, const f32x4& b0, const f32x4& s0, const f32x4& b1, const f32x4& s1,
                                                f32x4& v0, f32x4& v1) {
     if constexpr (FAST && EPI == AMDS_EPI_BIAS_GELU) {
-        v0 += b0;
-        v1 += b1;
+        if constexpr (!NOBIAS) {
+            v0 += b0;
+            v1 += b1;
+        }
         f32x2 q[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
         gelu_erf_poly2_n<4>(q);
         v0 = f32x4{q[0][0], q[0][1], q[1][0], q[1][1]};
         v1 = f32x4{q[2][0], q[2][1], q[3][0], q[3][1]};
     } else if constexpr (FAST && (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_RELU)) {
-        v0 += b0;
-        v1 += b1;
+        if constexpr (!NOBIAS) {
+            v0 += b0;
+            v1 += b1;
+        }
         if constexpr (EPI == AMDS_EPI_BIAS_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }

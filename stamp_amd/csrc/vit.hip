@@ -58,6 +58,15 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     const int D = c->dim, T = pl.T, M = Bc * T, dt = c->dtype;
     int rc;
 #define AMDS_TRY(call) do { rc = (call); if (rc != AMDS_OK) return rc; } while (0)
+    // One kernel family per GEMM whatever the batch: a tile's features must not depend on which chunk it travels in (bit-exact,
+    // tests/test_gpu_vit.py).  The library default switches from 128x128 tiles (v_mfma 32x32x16) to the 16x16x32 kernel once the
+    // grid fills the chip, and those two differ in the last bits -- so the encoder names the kernel id itself.  AMDS_GEMM_CFG
+    // (tuning) still overrides.
+    static const int kcfg = (getenv("AMDS_GEMM_CFG") && *getenv("AMDS_GEMM_CFG")) ? -1 : 12;
+    auto enc_gemm = [&](const void* A, long lda, const void* Wt, long ldw, int Mr, int N, int K, int epi, void* out, long ldo, const float* bias,
+                        const float* scale) {
+        return amds_gemm_ex(N % 256 == 0 ? kcfg : -1, A, lda, Wt, ldw, Mr, N, K, dt, epi, out, ldo, bias, scale, nullptr, 0, 0, 0, 1.0f, st);
+    };
     // patch embedding: im2col (raw 0..255 values) -> GEMM with folded normalisation, + pos-embed
     AMDS_TRY(amds_tile_im2col_u8(tiles, mlp, Bc, c->img, c->patch, pl.kp, dt, st));
     if (c->n_prefix > 0) AMDS_TRY(prefix_init(w->prefix, x, Bc, T, c->n_prefix, D, st));
@@ -66,15 +75,15 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     for (int l = 0; l < c->depth; ++l) {
         const amds_vit_block& b = w->blocks_host[l];
         AMDS_TRY(amds_layernorm(x, D, b.ln1_w, b.ln1_b, h, D, M, D, c->ln_eps, dt, st));
-        AMDS_TRY(amds_gemm(h, D, b.qkv_w, D, M, 3 * D, D, dt, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        AMDS_TRY(enc_gemm(h, D, b.qkv_w, D, M, 3 * D, D, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr));
         AMDS_TRY(amds_attention_vit_hd(qkv, h, Bc, T, c->heads, D / c->heads, dt, st));
-        AMDS_TRY(amds_gemm(h, D, b.proj_w, D, M, D, D, dt, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        AMDS_TRY(enc_gemm(h, D, b.proj_w, D, M, D, D, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr));
         AMDS_TRY(amds_layernorm(x, D, b.ln2_w, b.ln2_b, h, D, M, D, c->ln_eps, dt, st));
         if (c->mlp_kind == 0)
-            AMDS_TRY(amds_gemm(h, D, b.fc1_w, D, M, c->hidden, D, dt, AMDS_EPI_BIAS_GELU, mlp, c->hidden, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+            AMDS_TRY(enc_gemm(h, D, b.fc1_w, D, M, c->hidden, D, AMDS_EPI_BIAS_GELU, mlp, c->hidden, b.fc1_b, nullptr));
         else
             AMDS_TRY(amds_gemm(h, D, b.fc1_w, D, M, 2 * c->hidden, D, dt, AMDS_EPI_SWIGLU, mlp, c->hidden, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
-        AMDS_TRY(amds_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, dt, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr, nullptr, 0, 0, 0, 1.0f, st));
+        AMDS_TRY(enc_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr));
     }
     // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32
     AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));

@@ -130,8 +130,14 @@ def test_gemm_kernels_bit_identical(gpu, dt):
         for cfg in (3, 7, 9, 10):
             assert torch.equal(ops.gemm(a, w, epi, bias=bias, cfg=cfg), ref), (epi, cfg)
         o12 = ops.gemm(a, w, epi, bias=bias, cfg=12)
-        assert torch.equal(ops.gemm(a, w, epi, bias=bias), o12), epi          # default dispatch = id 12 here
-        assert (o12.float() - ref.float()).abs().max().item() <= 4e-3 * ref.float().abs().max().item(), epi
+        ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10          # one unit in the last place at the top of the output range
+        assert (o12.float() - ref.float()).abs().max().item() <= ulp * ref.float().abs().max().item(), epi
+    # a grid that fills the chip (>= 192 tiles of 256 x 256): the default dispatch is id 12
+    M2, N2 = 4099, 3072
+    a2 = torch.randn(M2, K, generator=g).to(gpu, dt)
+    w2 = (torch.randn(N2, K, generator=g) / K ** 0.5).to(gpu, dt)
+    b2 = torch.randn(N2, generator=g).to(gpu)
+    assert torch.equal(ops.gemm(a2, w2, _lib.EPI_BIAS_F32, bias=b2), ops.gemm(a2, w2, _lib.EPI_BIAS_F32, bias=b2, cfg=12))
 
 
 @pytest.mark.parametrize("dt", DTYPES)

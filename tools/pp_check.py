@@ -24,7 +24,7 @@ for dt in (torch.float16, torch.bfloat16):
                 out = torch.randn(M, N, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) if epi == _lib.EPI_RESIDUAL else None
                 outs.append(ops.gemm(a, w, epi, bias=b, scale=sc if epi == _lib.EPI_RESIDUAL else None, out=out, cfg=cfg).float())
             d = (outs[0] - outs[1]).abs().max().item()
-            good = d == 0.0 if ALT != 12 else d <= 2e-3 * outs[0].abs().max().item()     # 16x16x32 MFMAs: last-bit differences
+            good = d == 0.0 if ALT != 12 else d <= 4e-3 * outs[0].abs().max().item()     # 16x16x32 MFMAs, bias summed first: last-bit differences (one bf16 ulp)
             ok &= good
             if not good:
                 print(dt, M, N, K, name, "max diff", d)
