@@ -109,45 +109,36 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // ulp of fp16/bf16).  Written on 2-vectors so that it compiles to v_pk_fma_f32 / v_pk_mul_f32: 9.5 instructions per
 // element against ~22 issue slots for the rcp/exp form above (quarter-rate transcendentals counted as four).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
-    constexpr float Z = 3.25f;
-    f32x2 z = x * 0.70710678118654752440f;
-    z = __builtin_elementwise_min(__builtin_elementwise_max(z, f32x2{-Z, -Z}), f32x2{Z, Z});
-    const f32x2 u = z * z * (2.0f / (Z * Z)) - 1.0f;
-    constexpr float c[12] = {4.346401949e-01f, -2.144501162e-01f, 1.532795055e-01f, -1.143948891e-01f, 8.225328539e-02f,
-                             -5.548698805e-02f, 3.551052708e-02f, -2.022940554e-02f, 8.718888393e-03f, -4.313286983e-03f,
-                             3.632394905e-03f, -1.469356506e-03f};
-    f32x2 p = {c[11], c[11]};
-#pragma unroll
-    for (int i = 10; i >= 0; --i) p = p * u + c[i];
-    const f32x2 h = x * 0.5f;
-    return h * (z * p) + h;
-}
+// The scaling by 1/sqrt2 is folded into the clamp bound, the argument map and the coefficients (three packed operations fewer
+// per 2 outputs than clamping z = x/sqrt2):  xc = clamp(x, +-3.25 sqrt2),  u = xc^2 / 3.25^2 - 1,  gelu = h + h (xc Q(u)),  h = x/2.
+constexpr float GELU_XMAX = 4.59619407771256f, GELU_USCALE = 0.09467455621301775f;
+constexpr float GELU_Q[12] = {3.073371250e-01f, -1.516402814e-01f, 1.083792275e-01f, -8.086256723e-02f, 5.821552511e-02f, -3.940696708e-02f,
+                              2.493799295e-02f, -1.386272869e-02f, 6.385995681e-03f, -3.540644640e-03f, 2.470353036e-03f, -8.427158838e-04f};
 // the same polynomial on NC independent 2-vectors, Horner steps interleaved across them: one wave per SIMD (4-wave GEMM) has
 // nobody to hide the dependent v_pk_fma latency behind, so a single chain runs at a fraction of the VALU rate
 template <int NC>
 __device__ __forceinline__ void gelu_erf_poly2_n(f32x2 (&x)[NC]) {
-    constexpr float Z = 3.25f;
-    constexpr float c[12] = {4.346401949e-01f, -2.144501162e-01f, 1.532795055e-01f, -1.143948891e-01f, 8.225328539e-02f,
-                             -5.548698805e-02f, 3.551052708e-02f, -2.022940554e-02f, 8.718888393e-03f, -4.313286983e-03f,
-                             3.632394905e-03f, -1.469356506e-03f};
-    f32x2 z[NC], u[NC], p[NC];
+    f32x2 xc[NC], u[NC], p[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        z[k] = x[k] * 0.70710678118654752440f;
-        z[k] = __builtin_elementwise_min(__builtin_elementwise_max(z[k], f32x2{-Z, -Z}), f32x2{Z, Z});
-        u[k] = z[k] * z[k] * (2.0f / (Z * Z)) - 1.0f;
-        p[k] = f32x2{c[11], c[11]};
+        xc[k] = __builtin_elementwise_min(__builtin_elementwise_max(x[k], f32x2{-GELU_XMAX, -GELU_XMAX}), f32x2{GELU_XMAX, GELU_XMAX});
+        u[k] = xc[k] * xc[k] * GELU_USCALE - 1.0f;
+        p[k] = f32x2{GELU_Q[11], GELU_Q[11]};
     }
 #pragma unroll
     for (int i = 10; i >= 0; --i)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) p[k] = p[k] * u[k] + c[i];
+        for (int k = 0; k < NC; ++k) p[k] = p[k] * u[k] + GELU_Q[i];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         const f32x2 h = x[k] * 0.5f;
-        x[k] = h * (z[k] * p[k]) + h;
+        x[k] = h * (xc[k] * p[k]) + h;
     }
+}
+__device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
+    f32x2 q[1] = {x};
+    gelu_erf_poly2_n<1>(q);
+    return q[0];
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
