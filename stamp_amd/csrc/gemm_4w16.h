@@ -308,14 +308,14 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     }
 }
 
-template <typename T, int EPI, bool SPREAD = true>
+template <typename T, int EPI, bool SPREAD = true, int P3 = 6, int P0 = 6>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st) {
     if constexpr (!epi_is_staged<EPI>()) {
         return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     } else {
         constexpr int LDS = 2 * (256 + 256) * 128;
-        auto kern = gemm_4w16_kernel<T, EPI, 6, 6, SPREAD>;
+        auto kern = gemm_4w16_kernel<T, EPI, P3, P0, SPREAD>;
         static bool attr_set = false;
         if (!attr_set) {
             AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));

@@ -411,7 +411,7 @@ static int launch_gemm_4w(const void* A, long lda, const void* W, long ldw, int 
 template <typename T, int EPI>
 static int launch_gemm_4w64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w64.h
-template <typename T, int EPI, bool SPREAD>
+template <typename T, int EPI, bool SPREAD, int P3, int P0>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w16.h
 template <typename T, int EPI>
@@ -435,8 +435,8 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
     if (cfg == 9) cfg = 8;
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
-    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true>(A, lda, W, ldw, M, N, K, ep, st);
-    if (cfg == 13 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w16<T, EPI, false>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 13 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w16<T, EPI, true, 8, 8>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 12 || cfg == 13) cfg = 8;
 
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
