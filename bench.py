@@ -36,7 +36,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=1020, help="tiles per step per GPU (one virtual slide)")
-    ap.add_argument("--chunk", type=int, default=510, help="tiles per internal forward chunk")
+    ap.add_argument("--chunk", type=int, default=1020, help="tiles per internal forward chunk")
     ap.add_argument("--model", default="vit_large_patch14_224", help="a ViT preset, or ctranspath (ConvStem + Swin-T)")
     ap.add_argument("--swin-chunk", type=int, default=1024, help="tiles per internal chunk of the CTransPath forward (5.2 MB of workspace per tile)")
     ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
@@ -134,7 +134,7 @@ def main() -> None:
     # two rocprofv3 --pmc passes over this same workload (profiles/r01_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
     traffic = None
     pmc_file = ROOT / "profiles" / "r01_pmc_gemm_traffic.json"
-    if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 510 and pmc_file.is_file():
+    if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 1020 and pmc_file.is_file():
         try:
             traffic = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"]
         except Exception:
@@ -158,7 +158,7 @@ def main() -> None:
                                "gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_traffic.json); algorithmic 1.48e9 -> 1.43x (A panels re-fetched across N tiles, served by L2/MALL)" if traffic else None,
+                     "traffic_note": "HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_traffic.json); algorithmic 2.97e9 at this chunk (1020 tiles, M = 262140) -> 1.43x (A panels re-fetched across N tiles, served by L2/MALL)" if traffic else None,
                      "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),
                      "avg_gflop_per_launch": round(gflop / max(gn, 1) / 1e9, 2),
                      "time_share": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kinds.items()}},

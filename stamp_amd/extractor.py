@@ -38,7 +38,7 @@ def u8_tile_transform(img) -> torch.Tensor:
 
 
 def hip_vit_extractor(name: str, state_dict: dict[str, torch.Tensor], *, identifier: str | None = None,
-                      cfg: ViTConfig | None = None, device="cuda", act_dtype=torch.float16, chunk: int = 510) -> Extractor:
+                      cfg: ViTConfig | None = None, device="cuda", act_dtype=torch.float16, chunk: int = 1020) -> Extractor:
     """Extractor whose model is the HIP tile encoder.  `name` is a key of `stamp_amd.vit.PRESETS`; `state_dict`
     uses timm VisionTransformer names (what the reference's factories load, e.g. uni2.py:32-34)."""
     cfg = cfg or PRESETS[name]

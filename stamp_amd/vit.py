@@ -105,7 +105,7 @@ class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
-                 act_dtype: torch.dtype = torch.float16, chunk: int = 510) -> None:
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 1020) -> None:
         super().__init__()
         if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
             raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
