@@ -140,6 +140,29 @@ def test_gemm_kernels_bit_identical(gpu, dt):
     assert torch.equal(ops.gemm(a2, w2, _lib.EPI_BIAS_F32, bias=b2), ops.gemm(a2, w2, _lib.EPI_BIAS_F32, bias=b2, cfg=12))
 
 
+def test_gemm_bench_size_sampled_rows(gpu):
+    """The four GEMMs of one ViT-L block at the bench chunk (M = 262 140, library-default kernel): 96 sampled rows -- the first
+    and the last row tile included -- against an fp64 reference; the residual epilogue read-modify-writes its output."""
+    g = torch.Generator().manual_seed(3)
+    M = 262140
+    rows = torch.cat([torch.arange(0, 32), torch.randint(0, M, (32,), generator=g), torch.arange(M - 32, M)]).to(gpu)
+    for N, K, epi in ((3072, 1024, _lib.EPI_BIAS), (1024, 1024, _lib.EPI_RESIDUAL), (4096, 1024, _lib.EPI_BIAS_GELU), (1024, 4096, _lib.EPI_RESIDUAL)):
+        a = torch.randn(M, K, device=gpu).half()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu).half()
+        bias = torch.randn(N, generator=g).to(gpu)
+        x0 = torch.randn(M, N, device=gpu) if epi == _lib.EPI_RESIDUAL else None
+        out = ops.gemm(a, w, epi, bias=bias, out=x0.clone() if x0 is not None else None)
+        ref = a[rows].double() @ w.double().t() + bias.double()
+        if epi == _lib.EPI_BIAS_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        if epi == _lib.EPI_RESIDUAL:
+            ref = ref + x0[rows].double()
+        tol = 2e-5 * (K / 1024) if epi == _lib.EPI_RESIDUAL else 1.5e-3
+        err = (out[rows].double() - ref).abs().max().item()
+        assert err < tol * max(1.0, ref.abs().max().item()), (N, K, epi, err)
+        del a, w, out, x0
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_swiglu(gpu, dt):
     M, H, K = 300, 192, 128
