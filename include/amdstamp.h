@@ -126,7 +126,7 @@ int amds_swin_mlp192(float* x, int M, const void* packed_w, const float* fc1_b, 
                      const float* ln_beta, float ln_eps, int dtype, void* stream);
 
 /* Tuning hook: same as amds_gemm with an explicit kernel (-1 = library default: 12 when N % 256 == 0 and the grid fills the chip
- * (SWIGLU / PATCH epilogues: 8), else 0 / 1).  0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64 eight-wave staggered two-group
+ * (PATCH epilogue: 8), else 0 / 1).  0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64 eight-wave staggered two-group
  * pipeline, 10 = 256x256x64 four-wave kernel (128x128 wave tiles), 12 = the same on v_mfma 16x16x32 (13: its A/B schedule),
  * 3 / 7 = BK = 32 predecessors, 9 = ping-pong experiment (two 256x128 workgroups per CU).  Ids other than 12 / 13 give
  * bit-identical results; 12 / 13 sum the bias first and 32 products per MFMA: they differ from the others in the last bits. */

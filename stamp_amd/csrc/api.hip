@@ -123,8 +123,8 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
     if (cfg < 0) {
         cfg = default_gemm_cfg(M, N, K);
         // measured (profiles/r01_gemm_vendor_and_power.txt): at the socket power cap the four-wave kernel on 16x16x32 MFMAs (the cheaper
-        // instruction per flop) wins on every staged epilogue; SWIGLU / PATCH keep the eight-wave kernel
-        if (cfg == 8 && epi != AMDS_EPI_SWIGLU && epi != AMDS_EPI_PATCH && N % 256 == 0 && !(getenv("AMDS_GEMM_CFG") && *getenv("AMDS_GEMM_CFG"))) cfg = 12;
+        // instruction per flop) wins on every staged epilogue and on SWIGLU; PATCH keeps the eight-wave kernel
+        if (cfg == 8 && epi != AMDS_EPI_PATCH && N % 256 == 0 && !(getenv("AMDS_GEMM_CFG") && *getenv("AMDS_GEMM_CFG"))) cfg = 12;
     }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);

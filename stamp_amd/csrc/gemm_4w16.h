@@ -227,7 +227,47 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     // ---- epilogue: LDS-staged, coalesced.  Block (i, j): row = wm*128 + 16 i + l15, columns wn*128 + 16 j + 4 kb .. + 3 ----
     constexpr bool F16OUT = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_BIAS_RELU);
-    static_assert(epi_is_staged<EPI>(), "gemm_4w16 has staged epilogues only");
+    static_assert(epi_is_staged<EPI>() || EPI == AMDS_EPI_SWIGLU, "gemm_4w16: staged epilogues and SWIGLU");
+    if constexpr (EPI == AMDS_EPI_SWIGLU) {
+        // Packed fc1 of a SwiGLU MLP (ops.pack_swiglu_rows): columns [64 q, 64 q + 32) are the gates and [64 q + 32, 64 q + 64) the values
+        // of hidden units [32 q, 32 q + 32).  In 16 x 16 blocks: gate block 4 q + t pairs with value block 4 q + 2 + t (t = 0, 1) in the
+        // SAME lane, hidden unit 32 q + 16 t + 4 kb + r.  out [M, N/2] (16-bit): 128 hidden units per tile and row = 256 B, staged as
+        // 256 rows x 256 B (16-byte chunk index XOR row & 15) and stored row-wise.  The bias is in the accumulators (host requires one).
+        const float as = ep.acc_scale;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int row = wm * 128 + i * 16 + l15;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 gt = acc[i][4 * q + t], vl = acc[i][4 * q + 2 + t];
+                    if (!bias_in_acc) {
+                        const f32x4 bg = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + (4 * q + t) * 16 + 4 * kb);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + (4 * q + 2 + t) * 16 + 4 * kb);
+                        gt = gt * as + bg;
+                        vl = vl * as + bv;
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = silu(gt[e]) * vl[e];
+                    const int hcol = wn * 64 + q * 32 + t * 16 + 4 * kb;          // hidden column inside the tile (0..127)
+                    const int chunk = hcol >> 3, half = ((hcol >> 2) & 1) * 8;
+                    *reinterpret_cast<vec4*>(smem + row * 256 + ((chunk ^ (row & 15)) << 4) + half) = Act<T>::from_f32x4(o);
+                }
+        }
+        __syncthreads();
+        const int l15r = lane & 15, rsub = lane >> 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = wave * 64 + it * 4 + rsub;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * 256 + l15r * 16);
+            const int chunk = l15r ^ (row & 15);
+            if (m0 + row < M)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 / 2 + chunk * 8) = v;
+        }
+        return;
+    }
     constexpr int NPASS = F16OUT ? 1 : 2;
     constexpr int JP = FJ / NPASS;                 // column blocks per pass
 #pragma unroll
@@ -311,7 +351,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 template <typename T, int EPI, bool SPREAD = true, int P3 = 6, int P0 = 6>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st) {
-    if constexpr (!epi_is_staged<EPI>()) {
+    if constexpr (!epi_is_staged<EPI>() && EPI != AMDS_EPI_SWIGLU) {
         return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     } else {
         constexpr int LDS = 2 * (256 + 256) * 128;

@@ -82,7 +82,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         if (c->mlp_kind == 0)
             AMDS_TRY(enc_gemm(h, D, b.fc1_w, D, M, c->hidden, D, AMDS_EPI_BIAS_GELU, mlp, c->hidden, b.fc1_b, nullptr));
         else
-            AMDS_TRY(amds_gemm(h, D, b.fc1_w, D, M, 2 * c->hidden, D, dt, AMDS_EPI_SWIGLU, mlp, c->hidden, b.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f, st));
+            AMDS_TRY(enc_gemm(h, D, b.fc1_w, D, M, 2 * c->hidden, D, AMDS_EPI_SWIGLU, mlp, c->hidden, b.fc1_b, nullptr));
         AMDS_TRY(enc_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr));
     }
     // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32

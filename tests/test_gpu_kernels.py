@@ -164,8 +164,8 @@ def test_gemm_bench_size_sampled_rows(gpu):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_swiglu(gpu, dt):
-    M, H, K = 300, 192, 128
+@pytest.mark.parametrize("cfg,M,H,K", [(-1, 300, 192, 128), (12, 777, 256, 192), (8, 777, 256, 192), (12, 5000, 1024, 64)])
+def test_gemm_swiglu(gpu, dt, cfg, M, H, K):
     g = torch.Generator().manual_seed(9)
     a = torch.randn(M, K, generator=g).to(gpu, dt)
     w = (torch.randn(2 * H, K, generator=g) / K ** 0.5).to(gpu)
@@ -173,7 +173,7 @@ def test_gemm_swiglu(gpu, dt):
     wp = ops.pack_swiglu_rows(w).to(dt)
     bp = ops.pack_swiglu_rows(bias.reshape(-1, 1)).reshape(-1)
     # padded N must be a multiple of 128: 384 ok
-    out = ops.gemm(a, wp, _lib.EPI_SWIGLU, bias=bp)
+    out = ops.gemm(a, wp, _lib.EPI_SWIGLU, bias=bp, cfg=cfg)
     full = a.double() @ w.to(dt).double().t() + bias.double()
     x1, x2 = full[:, :H], full[:, H:]
     ref = torch.nn.functional.silu(x1) * x2
