@@ -1,12 +1,15 @@
 """Oracle for the tile-encoder path: u8 tile -> transform -> timm-style
 VisionTransformer -> CLS feature -> fp16.
 
-PARITY STATUS: **unpinned against timm** -- the ViT trunk's arithmetic lives in the third-party package
+PARITY STATUS: **unpinned against timm itself** -- the ViT trunk's arithmetic lives in the third-party package
 ``timm==1.0.25`` (reference uv.lock), which is neither under /root/reference nor installed here; the reference's
 own tests only smoke-test this boundary (tests/test_feature_extractors.py:20-80).  The restatement follows timm's
 published ``VisionTransformer`` semantics (pre-LN blocks, LayerScale, SwiGLUPacked = fc1 -> chunk(2) ->
-SiLU(x1)*x2 -> fc2, register tokens after CLS, ``no_embed_class``) and is cross-checked against an independent
-third-party implementation that IS installed (HF ``transformers.Dinov2Model``) in tests/test_oracle_vit.py.
+SiLU(x1)*x2 -> fc2, register tokens after CLS, ``no_embed_class``) and EVERY branch of it is cross-checked against
+independent third-party implementations that ARE installed (HF ``transformers`` ``Dinov2Model`` and
+``Dinov2WithRegistersModel``: GELU and SwiGLU FFN, 0/4/8 register tokens, both ``no_embed_class`` settings, head_dim
+64 and 80, and the full-size 24-block ViT-L/14) in tests/test_oracle_vit.py.  This is test infrastructure: only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it.
 Call sites restated: reference src/stamp/preprocessing/extractor/virchow2.py:29-45 (CLS select),
 uni2.py:17-37, reddino.py:40-57, h_optimus_0.py:22-30 (transform), src/stamp/preprocessing/__init__.py:324-325
 (``model(tiles).half()``).

@@ -48,6 +48,36 @@ def test_vit_large_matches_oracle(gpu):
     assert r_f < 1e-3 and r_t < 1e-3 and mx < 2e-3
 
 
+@pytest.mark.parametrize("name,tol_f16", [("uni2_h", 1e-3), ("virchow2", 1e-3), ("h_optimus_0", 1e-3), ("vit_large_patch16_224", 1e-3)])
+def test_full_size_presets_match_oracle(gpu, name, tol_f16):
+    """Full-size parity for every preset DESIGN quotes a throughput for (reference uni2.py:17-37, virchow2.py:24-54 -- ViT-H/14
+    with head_dim 80 --, h_optimus_0.py:15-30, uni.py:26-31): 2 tiles, fp16 operands / fp32 accumulate / fp32 residual stream.
+    Stated tolerance: relative L2 error of the fp16 CLS features and of the final tokens <= 1e-3 (BASELINE.json north_star)."""
+    cfg = PRESETS[name]
+    sd = random_vit_state_dict(cfg, seed=5, init="moderate")
+    tiles = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
+    ref_f, ref_t = extract_features(tiles, sd, cfg, return_tokens=True)
+    model = HipViT(cfg, sd, device=gpu, act_dtype=torch.float16, chunk=2)
+    f, t = model(tiles.to(gpu), return_tokens=True)
+    r_t, r_f = _rel(t.cpu(), ref_t), _rel(f.cpu().float(), ref_f.float())
+    print(f"{name} fp16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e}")
+    assert torch.isfinite(f.float()).all() and r_f < tol_f16 and r_t < tol_f16, (r_f, r_t)
+
+
+def test_vit_large_bf16_matches_oracle(gpu):
+    """BASELINE.json configs[1] says "bf16".  bf16 operands carry 8 mantissa bits (eps 3.9e-3): the 1e-3 feature bar of
+    north_star is NOT reachable with them, which is why the product default is fp16 operands (same MFMA rate).
+    Honest bf16 tolerance, stated: relative L2 <= 1e-2 on the CLS features and tokens of the full ViT-L/14 trunk."""
+    cfg = PRESETS["vit_large_patch14_224"]
+    sd = random_vit_state_dict(cfg, seed=0, init="moderate")
+    tiles = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    ref_f, ref_t = extract_features(tiles, sd, cfg, return_tokens=True)
+    f, t = HipViT(cfg, sd, device=gpu, act_dtype=torch.bfloat16, chunk=2)(tiles.to(gpu), return_tokens=True)
+    r_t, r_f = _rel(t.cpu(), ref_t), _rel(f.cpu().float(), ref_f.float())
+    print(f"ViT-L/14 bf16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e}")
+    assert r_f < 1e-2 and r_t < 1e-2, (r_f, r_t)
+
+
 def test_vit_large_chaotic_weights(gpu):
     """Ill-conditioned control ("stress" init: the fp32 and fp64 oracles already disagree by 1.1e-5, 180x the fp32
     epsilon).  fp16 operand rounding (2^-11) is amplified the same way; the bound below is that amplification with

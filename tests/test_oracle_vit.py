@@ -1,6 +1,10 @@
-"""Cross-check of the ViT oracle (timm semantics restated from knowledge; timm itself is absent) against an
-independent third-party implementation that is installed: HF transformers.Dinov2Model (ViT with CLS token,
-pos-embed on CLS+patches, pre-LN blocks, LayerScale, exact GELU).  CPU only."""
+"""Cross-check of the ViT oracle (timm semantics restated from knowledge; timm itself is absent) against independent
+third-party implementations that ARE installed: HF transformers `Dinov2Model` (CLS token, pos-embed on CLS+patches, pre-LN
+blocks, LayerScale, exact GELU or SwiGLU FFN) and `Dinov2WithRegistersModel` (register tokens inserted behind the class
+token after the position embedding).  Every branch the reference's extractors reach is covered: GELU Mlp (ViT-L/14: RedDino,
+UNI), SwiGLUPacked (UNI2-h uni2.py:17-31, Virchow2 virchow2.py:34-39, H-optimus h_optimus_0.py:15-20), register tokens with
+`no_embed_class=True` (UNI2-h, H-optimus: position embedding on patches only) and `no_embed_class=False` (Virchow2: one
+position row per prefix token), head_dim 80 (Virchow2), and the full-size ViT-L/14 trunk.  CPU only."""
 import pytest
 import torch
 
@@ -10,11 +14,27 @@ from stamp_amd.vit import ViTConfig
 transformers = pytest.importorskip("transformers")
 
 
-def _hf_to_timm(hf_sd, depth):
+def _hf_to_timm(hf_sd, depth, *, swiglu: bool, regs: int, no_embed_class: bool):
+    """HF Dinov2(+Registers) state_dict -> timm VisionTransformer names.  Only re-labelling, except for the position
+    embedding, where the two libraries place the class-token row differently (this is what timm's own checkpoint filter
+    does for the reg4_dinov2 models): HF adds pos[0] to the class token and pos[1:] to the patches BEFORE inserting the
+    registers.  timm `no_embed_class=True`: pos_embed covers patches only -> fold pos[0] into cls_token.  timm
+    `no_embed_class=False` with registers: pos_embed has 1 + regs + n_patches rows added AFTER the concat -> register
+    rows are zero."""
+    pos = hf_sd["embeddings.position_embeddings"]
+    cls = hf_sd["embeddings.cls_token"]
     sd = {"patch_embed.proj.weight": hf_sd["embeddings.patch_embeddings.projection.weight"],
           "patch_embed.proj.bias": hf_sd["embeddings.patch_embeddings.projection.bias"],
-          "cls_token": hf_sd["embeddings.cls_token"], "pos_embed": hf_sd["embeddings.position_embeddings"],
           "norm.weight": hf_sd["layernorm.weight"], "norm.bias": hf_sd["layernorm.bias"]}
+    if regs:
+        sd["reg_token"] = hf_sd["embeddings.register_tokens"]
+    if no_embed_class:
+        sd["cls_token"], sd["pos_embed"] = cls + pos[:, :1], pos[:, 1:]
+    elif regs:
+        sd["cls_token"] = cls
+        sd["pos_embed"] = torch.cat([pos[:, :1], pos.new_zeros(1, regs, pos.shape[-1]), pos[:, 1:]], dim=1)
+    else:
+        sd["cls_token"], sd["pos_embed"] = cls, pos
     for i in range(depth):
         h, t = f"encoder.layer.{i}.", f"blocks.{i}."
         for n in ("norm1", "norm2"):
@@ -24,28 +44,68 @@ def _hf_to_timm(hf_sd, depth):
         sd[t + "attn.qkv.bias"] = torch.cat([hf_sd[a + "query.bias"], hf_sd[a + "key.bias"], hf_sd[a + "value.bias"]])
         sd[t + "attn.proj.weight"], sd[t + "attn.proj.bias"] = hf_sd[h + "attention.output.dense.weight"], hf_sd[h + "attention.output.dense.bias"]
         sd[t + "ls1.gamma"], sd[t + "ls2.gamma"] = hf_sd[h + "layer_scale1.lambda1"], hf_sd[h + "layer_scale2.lambda1"]
-        sd[t + "mlp.fc1.weight"], sd[t + "mlp.fc1.bias"] = hf_sd[h + "mlp.fc1.weight"], hf_sd[h + "mlp.fc1.bias"]
-        sd[t + "mlp.fc2.weight"], sd[t + "mlp.fc2.bias"] = hf_sd[h + "mlp.fc2.weight"], hf_sd[h + "mlp.fc2.bias"]
+        f1, f2 = ("mlp.weights_in", "mlp.weights_out") if swiglu else ("mlp.fc1", "mlp.fc2")
+        sd[t + "mlp.fc1.weight"], sd[t + "mlp.fc1.bias"] = hf_sd[h + f1 + ".weight"], hf_sd[h + f1 + ".bias"]
+        sd[t + "mlp.fc2.weight"], sd[t + "mlp.fc2.bias"] = hf_sd[h + f2 + ".weight"], hf_sd[h + f2 + ".bias"]
     return sd
 
 
-def test_oracle_matches_hf_dinov2():
-    from transformers import Dinov2Config, Dinov2Model
-
-    torch.manual_seed(0)
-    hc = Dinov2Config(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, mlp_ratio=2, image_size=224,
-                      patch_size=14, layerscale_value=0.7, layer_norm_eps=1e-6, hidden_act="gelu",
-                      use_swiglu_ffn=False, qkv_bias=True)
-    model = Dinov2Model(hc).eval()
-    with torch.no_grad():      # HF zero-inits several tensors; make every parameter matter
+def _hf_model(dim, depth, heads, mlp_ratio, swiglu, regs, seed=0, perturb=0.05):
+    torch.manual_seed(seed)
+    kw = dict(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads, mlp_ratio=mlp_ratio, image_size=224,
+              patch_size=14, layerscale_value=0.7, layer_norm_eps=1e-6, hidden_act="gelu", use_swiglu_ffn=swiglu, qkv_bias=True)
+    if regs:
+        from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+        model = Dinov2WithRegistersModel(Dinov2WithRegistersConfig(num_register_tokens=regs, **kw)).eval()
+    else:
+        from transformers import Dinov2Config, Dinov2Model
+        model = Dinov2Model(Dinov2Config(**kw)).eval()
+    with torch.no_grad():      # HF zero-inits several tensors (biases, registers); make every parameter matter
         for p in model.parameters():
-            p.add_(0.05 * torch.randn_like(p))
-    cfg = ViTConfig(dim=128, depth=3, heads=2, hidden=256, mlp="gelu", layerscale=True, ln_eps=1e-6)
-    sd = _hf_to_timm({k: v.detach() for k, v in model.state_dict().items()}, 3)
+            p.add_(perturb * torch.randn_like(p))
+    return model
+
+
+def _swiglu_hidden(dim, mlp_ratio):      # HF Dinov2SwiGLUFFN and timm's SwiGLUPacked users size the FFN the same way
+    return (int(int(dim * mlp_ratio) * 2 / 3) + 7) // 8 * 8
+
+
+CASES = {
+    # name: (dim, depth, heads, mlp_ratio, swiglu, regs, no_embed_class)
+    "gelu": (128, 3, 2, 2, False, 0, False),                     # ViT-L/14 family (RedDino, UNI)
+    "swiglu": (128, 3, 2, 4, True, 0, False),                    # Virchow v1 branch
+    "swiglu_reg8_noembedclass": (192, 2, 3, 4, True, 8, True),   # UNI2-h / H-optimus branch
+    "swiglu_reg4_embedclass_hd80": (160, 2, 2, 4, True, 4, False),   # Virchow2 branch, head_dim 80
+    "gelu_reg4_noembedclass": (128, 2, 2, 2, False, 4, True),    # timm vit_*_reg4_dinov2 with the plain Mlp
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_hf_dinov2(name):
+    dim, depth, heads, mlp_ratio, swiglu, regs, nec = CASES[name]
+    model = _hf_model(dim, depth, heads, mlp_ratio, swiglu, regs)
+    hidden = _swiglu_hidden(dim, mlp_ratio) if swiglu else dim * mlp_ratio
+    cfg = ViTConfig(dim=dim, depth=depth, heads=heads, hidden=hidden, mlp="swiglu" if swiglu else "gelu", reg_tokens=regs,
+                    no_embed_class=nec, layerscale=True, ln_eps=1e-6)
+    sd = _hf_to_timm({k: v.detach() for k, v in model.state_dict().items()}, depth, swiglu=swiglu, regs=regs, no_embed_class=nec)
     tiles = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
     x = tile_transform(tiles, cfg.mean, cfg.std)
     with torch.no_grad():
         ref = model(pixel_values=x).last_hidden_state
         got = vit_tokens(x, sd, cfg)
-    assert got.shape == ref.shape == (2, 257, 128)
+    assert got.shape == ref.shape == (2, 257 + regs, dim)
     torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4)
+
+
+def test_oracle_matches_hf_dinov2_full_size_vit_large():
+    """The headline trunk at its real size: ViT-L/14, 24 blocks, 16 heads, 257 tokens, 303 M parameters, one tile."""
+    model = _hf_model(1024, 24, 16, 4, False, 0, seed=3, perturb=0.02)
+    cfg = ViTConfig()       # vit_large_patch14_224
+    sd = _hf_to_timm({k: v.detach() for k, v in model.state_dict().items()}, 24, swiglu=False, regs=0, no_embed_class=False)
+    tiles = torch.randint(0, 256, (1, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    x = tile_transform(tiles, cfg.mean, cfg.std)
+    with torch.no_grad():
+        ref = model(pixel_values=x).last_hidden_state
+        got = vit_tokens(x, sd, cfg)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert got.shape == ref.shape == (1, 257, 1024) and rel < 2e-5, rel
