@@ -42,6 +42,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--overlap", type=int, default=0, help="1 = two chunks in flight on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline workload only (for a ViT-only rocprofv3 kernel trace)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -167,8 +168,8 @@ def main() -> None:
     # Single-GPU line only: these blocks contain rank collectives (max_over_ranks) inside a try/except, and a rank that raised
     # while the others wait in a collective would hang the N-GPU scaling run, whose purpose is the headline value.
     try:
-        if ctx.world > 1:
-            raise RuntimeError("secondary metrics are reported on the single-GPU line")
+        if ctx.world > 1 or a.no_secondary:
+            raise RuntimeError("secondary metrics are reported on the single-GPU line" if ctx.world > 1 else "--no-secondary")
         from stamp_amd.mil import VisionTransformer as HipMil
         torch.manual_seed(1)
         mil = HipMil(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512,

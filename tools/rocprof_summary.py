@@ -27,6 +27,28 @@ def main(path: str) -> None:
     print(f"{'TOTAL':110s} {sum(a[0] for a in agg.values()):7d} {tot:12.1f}")
 
 
+def by_shape(path: str) -> None:
+    """per (kernel, grid) table: one row per launch SHAPE, so the dominant kernel's average per GEMM shape can be read off."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    gcols = [c for c in ("grid_x", "grid_y", "grid_z", "grid_size_x", "grid_size_y", "grid_size_z", "grid_size") if c in cols]
+    wcols = [c for c in ("workgroup_x", "workgroup_size_x", "workgroup_size") if c in cols]
+    sel = ", ".join([namecol, "start", "end"] + gcols + wcols[:1])
+    agg = {}
+    for row in db.execute(f"select {sel} from kernels").fetchall():
+        n, s, e = row[:3]
+        a = agg.setdefault((short(n), tuple(row[3:])), [0, 0.0, 1e30, 0.0])
+        d = (e - s) / 1e3
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    print(f"columns after the name: {gcols + wcols[:1]} (grid in work-items, workgroup size)")
+    print(f"{'kernel':96s} {'grid/wg':>26s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for (k, g), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k[:96]:96s} {str(g):>26s} {a[0]:7d} {a[1]:12.1f} {a[1]/a[0]:10.2f} {a[2]:10.2f} {a[3]:10.2f} {100*a[1]/tot:6.2f}")
+    print(f"{'TOTAL':96s} {'':>26s} {sum(a[0] for a in agg.values()):7d} {tot:12.1f}")
+
+
 def sequence(path: str, last: int) -> None:
     """print the last `last` dispatches in start order (one forward = a fixed launch chain)"""
     db = sqlite3.connect(path)
@@ -42,5 +64,7 @@ def sequence(path: str, last: int) -> None:
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[2] == "--seq":
         sequence(sys.argv[1], int(sys.argv[3]))
+    elif len(sys.argv) > 2 and sys.argv[2] == "--by-shape":
+        by_shape(sys.argv[1])
     else:
         main(sys.argv[1])
