@@ -162,6 +162,17 @@ int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, v
 int amds_attention_alibi(const void* qkv, const float* coords, const float* head_scale, void* out, int B, int T, int H,
                          int dtype, void* stream);
 
+/* The reference's `mask != None` forward (src/stamp/modeling/models/vision_tranformer.py:355-381; pinned by the reference's
+ * tests/test_model.py:28-32).  pad: u8 [B][T], 1 = padded tile, class token included at t = 0 (never padded).
+ * blocked(q, k) = (pad[q] & pad[k]) | (q > 0 & k == 0)  -- the outer-product mask of :363-367, restated literally.
+ * amds_attention_masked (nn.MultiheadAttention branch): blocked scores are -inf before the softmax; the reference passes
+ *   attn_mask.repeat(heads, 1, 1) (:224), so (bag b, head h) uses the pad row of bag (b*H + h) % B -- reproduced.
+ * amds_attention_alibi_masked (MultiHeadALiBi branch, :62-70): softmax over all keys, blocked products zeroed afterwards, no
+ *   distance term on the class-token row and column (:370-372); out bf16. */
+int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int dtype, void* stream);
+int amds_attention_alibi_masked(const void* qkv, const float* coords, const float* head_scale, const uint8_t* pad, void* out,
+                                int B, int T, int H, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tile encoder (ViT) -- the model behind Extractor.model (reference
  * src/stamp/preprocessing/extractor/__init__.py:17-28; called at src/stamp/preprocessing/__init__.py:324-325)
@@ -434,6 +445,33 @@ int amds_attention_alibi_fwd_train(const void* qkv, const float* coords, const f
 int amds_attention_alibi_bwd(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords,
                              const float* bias_scale, const float* dist_scale, float* dq_sum_ws, float* dbs_part, void* dqkv,
                              int B, int T, int H, void* stream);
+/* Training forward / backward of nn.MultiheadAttention WITH its dropout on the attention probabilities (the `dropout` constructor
+ * argument of the reference's VisionTransformer reaches nn.MultiheadAttention, vision_tranformer.py:191; active in train mode):
+ * out = drop(P) v, lse that of the undropped softmax.  The keep mask is a counter-based function of (seed, stream_id, b, h, q, k),
+ * regenerated by the backward (same p / seed / stream_id), never stored.  P(drop) = round(p * 65536) / 65536.  p = 0 is
+ * amds_attention_fwd_lse / amds_attention_bwd. */
+int amds_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, float p, uint64_t seed,
+                             uint32_t stream_id, void* stream);
+int amds_attention_bwd_train(const void* qkv, const void* out, const void* dout, const float* lse, float* dq_sum_ws, void* dqkv,
+                             int B, int T, int H, int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
+/* The other dropout sites of the reference's MIL `vit` (vision_tranformer.py:157-169, 314-318), same counter-based masks:
+ *   amds_gelu_dropout_fwd   u = drop(gelu_erf(z))              `Linear -> GELU -> Dropout` of project_features / feed_forward
+ *   amds_gelu_dropout_bwd   dz = gelu'(z) * drop'(du)
+ *   amds_dropout_add        x_out[r][c] = x_in[r][c] + drop(y[r][c])     feed_forward's trailing Dropout + the residual add
+ *   amds_dropout_cast_bwd   dy[r][c] = (out dtype) drop'(dx[r][c])       gradient entering the last Linear's backward
+ * Element index of [rows][cols] views = r * cols + c (row pitches ld* may be larger than cols).
+ * amds_dropout_keep_scale(p) = 65536 / (65536 - round(p*65536)), the factor kept values are multiplied by.
+ * amds_dropout_mask / amds_attention_dropout_mask write the keep masks themselves (u8 0/1; [n] resp. [B][H][T][T]) for tests. */
+float amds_dropout_keep_scale(float p);
+int amds_gelu_dropout_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
+int amds_gelu_dropout_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, float p, uint64_t seed,
+                          uint32_t stream_id, void* stream);
+int amds_dropout_add(const float* y, long ldy, const float* x_in, long ldx, float* x_out, long ldo, long rows, int cols, float p,
+                     uint64_t seed, uint32_t stream_id, void* stream);
+int amds_dropout_cast_bwd(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, int out_dtype, float p, uint64_t seed,
+                          uint32_t stream_id, void* stream);
+int amds_dropout_mask(uint8_t* mask, long n, float p, uint64_t seed, uint32_t stream_id, void* stream);
+int amds_attention_dropout_mask(uint8_t* mask, int B, int H, int T, float p, uint64_t seed, uint32_t stream_id, void* stream);
 /* rowsum[b*T + q] = sum_k |coords[b,q] - coords[b,k]|: the batch statistic `_RunningMeanScaler` needs (mean of torch.cdist). */
 int amds_cdist_rowsum(const float* coords, float* rowsum, int B, int T, void* stream);
 /* fp16 -> bf16 (features are fp16 on disk; the training path feeds bf16 MFMA operands). */

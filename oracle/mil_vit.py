@@ -2,8 +2,13 @@
 
 Restates reference src/stamp/modeling/models/vision_tranformer.py: VisionTransformer.forward :331-384,
 Transformer.forward :281-295, SelfAttention.forward :194-242 (nn.MultiheadAttention branch and MultiHeadALiBi
-branch), feed_forward :157-169, _ALiBi.forward :42-74, _RunningMeanScaler :15-31 -- eval mode, dropout = 0.
-Pinned by tests/golden/mil_vit_{plain,alibi}.npz captured from the imported reference module.
+branch), feed_forward :157-169, _ALiBi.forward :42-74, _RunningMeanScaler :15-31.  Eval mode by default; the TRAIN-mode dropout
+sites are restated as explicit multiplier masks (`drop`): `project_features.2` = Dropout(dropout) after the GELU (:314-318),
+nn.MultiheadAttention's dropout on the attention probabilities (:191; torch semantics), and the two Dropout(0.5) of feed_forward
+(:157-169 -- `Transformer` calls `feed_forward(dim, mlp_dim)` WITHOUT a rate, :268-271, so 0.5 whatever the config says).
+Pinned by tests/golden/mil_vit_{plain,alibi}.npz (eval, +-mask) and tests/golden/mil_vit_train_{plain,alibi}.npz (train mode: the
+masks the reference's own nn.Dropout modules drew, its logits, loss, parameter gradients and updated scaler buffers), all captured
+from the imported reference module by tools/make_golden.py.  Test infrastructure: only tests/ and smoke() import this.
 State-dict keys are the reference's (project_features.0, class_token, transformer.layers.{l}.0.{norm,mhsa...},
 transformer.layers.{l}.1.{0,1,4}, transformer.norm, mlp_head.0).
 """
@@ -13,8 +18,9 @@ import torch
 import torch.nn.functional as F
 
 
-def _mha(x, sd, pre, heads, attn_mask):
-    """nn.MultiheadAttention(batch_first=True) self-attention, need_weights=False; attn_mask True = blocked."""
+def _mha(x, sd, pre, heads, attn_mask, drop=None):
+    """nn.MultiheadAttention(batch_first=True) self-attention, need_weights=False; attn_mask True = blocked.
+    drop: multiplier [B, heads, T, T] applied to the softmax weights (train-mode attention dropout, already scaled by 1/(1-p))."""
     B, T, D = x.shape
     hd = D // heads
     qkv = F.linear(x, sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"])
@@ -26,7 +32,10 @@ def _mha(x, sd, pre, heads, attn_mask):
         # (b, h) is masked with the mask of batch (b*heads + h) % B.
         idx = (torch.arange(B)[:, None] * heads + torch.arange(heads)[None, :]) % B
         s = s.masked_fill(attn_mask[idx], float("-inf"))
-    o = torch.softmax(s, dim=-1) @ v
+    w = torch.softmax(s, dim=-1)
+    if drop is not None:
+        w = w * drop
+    o = w @ v
     o = o.transpose(1, 2).reshape(B, T, D)
     return F.linear(o, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
 
@@ -50,11 +59,15 @@ def _alibi_mha(x, coords, sd, pre, heads, attn_mask, alibi_mask):
     return F.linear(torch.cat(outs, dim=-1), sd[pre + "fc.weight"], sd[pre + "fc.bias"])
 
 
-def mil_vit_forward(bags, coords, mask, sd, *, n_heads: int, use_alibi: bool):
-    """bags [B,T,F], coords [B,T,2], mask bool [B,T] or None -> logits [B,C]."""
-    sd = {k: v.float() for k, v in sd.items()}
+def mil_vit_forward(bags, coords, mask, sd, *, n_heads: int, use_alibi: bool, drop: dict | None = None, dtype=torch.float32):
+    """bags [B,T,F], coords [B,T,2], mask bool [B,T] or None -> logits [B,C].
+    drop (train mode): multipliers keyed "proj" [B,T,D], f"attn{l}" [B,H,T+1,T+1], f"ff1_{l}" [B,T+1,FF], f"ff2_{l}" [B,T+1,D]."""
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    drop = drop or {}
     B = bags.shape[0]
     x = F.gelu(F.linear(bags, sd["project_features.0.weight"], sd["project_features.0.bias"]))
+    if "proj" in drop:
+        x = x * drop["proj"]
     D = x.shape[-1]
     x = torch.cat([sd["class_token"].reshape(1, 1, D).expand(B, -1, -1), x], dim=1)
     coords = torch.cat([coords.new_zeros(B, 1, 2), coords], dim=1)
@@ -73,11 +86,15 @@ def mil_vit_forward(bags, coords, mask, sd, *, n_heads: int, use_alibi: bool):
         if use_alibi:
             a = _alibi_mha(h, coords, sd, p + "0.mhsa.", n_heads, attn_mask, alibi_mask)
         else:
-            a = _mha(h, sd, p + "0.mhsa.", n_heads, attn_mask)
+            a = _mha(h, sd, p + "0.mhsa.", n_heads, attn_mask, drop.get(f"attn{l}"))
         x = a + x
         h = F.layer_norm(x, (D,), sd[p + "1.0.weight"], sd[p + "1.0.bias"])
         h = F.gelu(F.linear(h, sd[p + "1.1.weight"], sd[p + "1.1.bias"]))
+        if f"ff1_{l}" in drop:
+            h = h * drop[f"ff1_{l}"]
         h = F.linear(h, sd[p + "1.4.weight"], sd[p + "1.4.bias"])
+        if f"ff2_{l}" in drop:
+            h = h * drop[f"ff2_{l}"]
         x = h + x
     x = F.layer_norm(x, (D,), sd["transformer.norm.weight"], sd["transformer.norm.bias"])
     return F.linear(x[:, 0], sd["mlp_head.0.weight"], sd["mlp_head.0.bias"])

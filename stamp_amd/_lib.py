@@ -61,6 +61,7 @@ class GapWeights(C.Structure):
 
 
 _vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+_u64, _u32 = C.c_uint64, C.c_uint32
 
 # name -> (restype, argtypes); must list every symbol include/amdstamp.h declares
 PROTOTYPES = {
@@ -123,6 +124,17 @@ PROTOTYPES = {
     "amds_attention_alibi_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_alibi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "amds_cdist_rowsum": (_i, [_vp, _vp, _i, _i, _vp]),
+    "amds_attention_masked": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_alibi_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_fwd_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u32, _vp]),
+    "amds_attention_bwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u32, _vp]),
+    "amds_dropout_keep_scale": (_f, [_f]),
+    "amds_gelu_dropout_fwd": (_i, [_vp, _vp, _l, _i, _i, _f, _u64, _u32, _vp]),
+    "amds_gelu_dropout_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _f, _u64, _u32, _vp]),
+    "amds_dropout_add": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _f, _u64, _u32, _vp]),
+    "amds_dropout_cast_bwd": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _f, _u64, _u32, _vp]),
+    "amds_dropout_mask": (_i, [_vp, _l, _f, _u64, _u32, _vp]),
+    "amds_attention_dropout_mask": (_i, [_vp, _i, _i, _i, _f, _u64, _u32, _vp]),
     "amds_convert_f16_bf16": (_i, [_vp, _vp, _l, _vp]),
     "amds_adamw": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp]),
     "amds_gated_attn_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -26,13 +26,25 @@ constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES + FA_C_BYTES;
 // fragments; distances are evaluated in fp32 from the token coordinates in registers (no T x T tensor).
 // TO: output element type.  The ALiBi variant always writes bf16: its second term sums |V| over ALL keys with weights
 // of order 1-10 (no softmax normalisation), which overflows fp16 (65504) on long bags; bf16 has the fp32 range.
-template <typename T, bool ALIBI, typename TO = T>
+//
+// MASK: the reference's `mask != None` path (vision_tranformer.py:355-381), restated literally.  pad[b][t] (u8, class token
+// included at t = 0 and never padded) marks padded tiles; blocked(q, k) = (pad[q] & pad[k]) | (q > 0 & k == 0): padded queries
+// do not see padded keys, tiles never see the class token (:363-367) -- an UNpadded query still attends to every key, padded or
+// not, exactly as the reference's outer-product mask does.  nn.MultiheadAttention branch: blocked scores are -inf before the
+// softmax, and because the reference hands MultiheadAttention `attn_mask.repeat(heads, 1, 1)` (:224), (bag b, head h) is masked
+// with the pad row of bag (b*H + h) % B.  ALiBi branch (:62-70): the softmax runs over ALL keys, blocked products are zeroed
+// afterwards, and the distance term is dropped on the class-token row and column (alibi_mask, :370-372); mask row = bag b.
+// DROP (plain attention, training): nn.MultiheadAttention's dropout on the attention probabilities: out = drop(P) v with the
+// normaliser and the saved log-sum-exp those of the undropped P; mask bits from (seed, stream, (b,h,q), k) -- common.h drop_*.
+template <typename T, bool ALIBI, typename TO = T, bool MASK = false, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int Tn, int H,
                                                             const float* __restrict__ coords, const float* __restrict__ head_scale,
                                                             float* __restrict__ lse_out, const float* __restrict__ out_scale = nullptr,
-                                                            TO* __restrict__ u_out = nullptr, TO* __restrict__ osm_out = nullptr) {
+                                                            TO* __restrict__ u_out = nullptr, TO* __restrict__ osm_out = nullptr,
+                                                            const uint8_t* __restrict__ pad = nullptr, uint64_t seed = 0, uint32_t drop_stream = 0,
+                                                            uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE + (MASK ? 2 * FA_KT : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,6 +59,9 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     u32x4 kreg[2];
     vec8 v0reg, v1reg;
     float cxreg = 0.f, cyreg = 0.f;
+    uint8_t mreg = 0;
+    const uint8_t* prow = nullptr;
+    if constexpr (MASK) prow = pad + (long)(ALIBI ? b : (int)(((long)b * H + h) % gridDim.z)) * Tn;
     const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
     const int k_key[2] = {tid >> 3, (tid >> 3) + 32};
     const int k_ch = tid & 7;
@@ -67,6 +82,10 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         if constexpr (ALIBI) {
             cxreg = cyreg = 0.f;
             if (tid < FA_KT && key0 + tid < Tn) { cxreg = cbase[(long)(key0 + tid) * 2]; cyreg = cbase[(long)(key0 + tid) * 2 + 1]; }
+        }
+        if constexpr (MASK) {
+            mreg = 1;
+            if (tid < FA_KT && key0 + tid < Tn) mreg = prow[key0 + tid];
         }
     };
     auto stage_store = [&](int buf) {
@@ -89,6 +108,9 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         if constexpr (ALIBI) {
             if (tid < FA_KT) { float* sC = reinterpret_cast<float*>(sV + FA_V_BYTES); sC[tid * 2] = cxreg; sC[tid * 2 + 1] = cyreg; }
         }
+        if constexpr (MASK) {
+            if (tid < FA_KT) (smem + 2 * FA_STAGE + buf * FA_KT)[tid] = (char)mreg;
+        }
     };
 
     // this wave's 32 queries
@@ -108,6 +130,10 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     if constexpr (ALIBI) { xq = cbase[(long)qc * 2]; yq = cbase[(long)qc * 2 + 1]; sh = head_scale[h]; }
     const float sc = 0.125f * 1.44269504088896340736f;
     const int swz = (l31 >> 1) & 7;
+    bool qpad = false;
+    if constexpr (MASK) qpad = prow[qc] != 0;
+    uint32_t rowkey = 0;
+    if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qc));
 
     stage_load(0);
     stage_store(0);
@@ -117,6 +143,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         if (j + 1 < ntile) stage_load(j + 1);
         const char* sK = smem + buf * FA_STAGE;
         const char* sV = sK + FA_K_BYTES;
+        const char* sM = smem + 2 * FA_STAGE + buf * FA_KT;
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -139,15 +166,30 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                     if (key >= Tn) s[t][r] = -INFINITY;
                 }
         }
+        uint32_t blocked = 0;            // bit t*16 + r: this (query, key) product is masked out
+        if constexpr (MASK) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool bl = (qpad && sM[kl] != 0) || (q > 0 && key0 + kl == 0);
+                    blocked |= (bl ? 1u : 0u) << (t * 16 + r);
+                    if (!ALIBI && bl) s[t][r] = -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx * sc);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        float mnew = fmaxf(mrun, mx * sc);
+        float msafe = mnew;
+        if constexpr (MASK) msafe = (mnew == -INFINITY) ? 0.f : mnew;       // a query whose keys so far are all blocked
+        const float alpha = __builtin_amdgcn_exp2f(mrun - msafe);
         mrun = mnew;
+        mnew = msafe;
         float ls = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -158,6 +200,24 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                 ls += p;
             }
         l = l * alpha + ls;
+        if constexpr (MASK && ALIBI) {       // softmax over all keys, blocked products zeroed afterwards (:66-68)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((blocked >> (t * 16 + r)) & 1u) s[t][r] = 0.f;
+        }
+        if constexpr (DROP) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int k = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;      // even key, its partner k + 1 sits in register r + 1
+                    const uint32_t bits = drop_pair_bits(rowkey, (uint32_t)k >> 1);
+                    s[t][r] = drop_keep(bits, 0, thr16) ? s[t][r] * keep_scale : 0.f;
+                    s[t][r + 1] = drop_keep(bits, 1, thr16) ? s[t][r + 1] * keep_scale : 0.f;
+                }
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -180,6 +240,9 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                         const float dx = xq - sC[kl * 2], dy = yq - sC[kl * 2 + 1];
                         float dist = sqrtf(dx * dx + dy * dy) * sh;
                         if (ragged && key0 + kl >= Tn) dist = 0.f;
+                        if constexpr (MASK) {
+                            if (((blocked >> (t * 16 + r)) & 1u) || q == 0 || key0 + kl == 0) dist = 0.f;
+                        }
                         bf[e] = Act<T>::from_f32(dist);
                     }
                 }
@@ -287,5 +350,56 @@ extern "C" int amds_attention_alibi_fwd_train(const void* qkv, const float* coor
     else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, true, bf16>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out_bf16, T, H, coords, inv_running_mean, lse, bias_scale, (bf16*)u_bf16, (bf16*)osm_bf16);
     else { set_error("amds_attention_alibi_fwd_train: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel<alibi,train>");
+    return AMDS_OK;
+}
+
+// `mask != None` forward of the reference (vision_tranformer.py:355-381; pinned by the reference's tests/test_model.py:28-32): pad u8 [B][T]
+// with the class token included at t = 0 (never padded).  See the kernel comment for the literal blocking rule.
+extern "C" int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && out && pad, "amds_attention_masked: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_masked: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false, f16, true>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false, bf16, true>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f);
+    else { set_error("amds_attention_masked: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<mask>");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_alibi_masked(const void* qkv, const float* coords, const float* head_scale, const uint8_t* pad, void* out, int B, int T,
+                                           int H, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && out && coords && head_scale && pad, "amds_attention_alibi_masked: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_masked: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 6.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, true, bf16, true>), grid, block, 0, st, (const f16*)qkv, (bf16*)out, T, H, coords, head_scale, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, true, bf16, true>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, coords, head_scale, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f);
+    else { set_error("amds_attention_alibi_masked: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<alibi,mask>");
+    return AMDS_OK;
+}
+
+// Training forward of nn.MultiheadAttention with dropout p on the attention probabilities (vision_tranformer.py:191: the `dropout`
+// constructor argument reaches MultiheadAttention; train mode): out = drop(P) v; lse as amds_attention_fwd_lse.  p = 0 is that call.
+extern "C" int amds_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, float p, uint64_t seed,
+                                        uint32_t stream_id, void* stream) {
+    if (p == 0.f) return amds_attention_fwd_lse(qkv, out, lse, B, T, H, dtype, stream);
+    AMDS_REQUIRE(qkv && out && lse, "amds_attention_fwd_train: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && p > 0.f && p < 1.f, "amds_attention_fwd_train: bad arguments B=%d T=%d H=%d p=%f", B, T, H, p);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    const uint32_t thr = drop_thr16(p);
+    const float ks = drop_scale(thr);
+    ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false, f16, false, true>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr, lse, nullptr, nullptr, nullptr, nullptr, seed, stream_id, thr, ks);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false, bf16, false, true>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, lse, nullptr, nullptr, nullptr, nullptr, seed, stream_id, thr, ks);
+    else { set_error("amds_attention_fwd_train: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<drop>");
     return AMDS_OK;
 }

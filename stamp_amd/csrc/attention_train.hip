@@ -55,14 +55,17 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // ALIBI: dV^T += dO^T (P - c_h D) with D = cdist(coords) and c_h = bias_scale_h / running_mean_h (the value path of the
 // post-softmax distance bias, vision_tranformer.py:60-72); dS, dK, dQ are those of the softmax part alone.
-template <typename T, bool ALIBI = false>
+// DROP: dropout on the attention probabilities (amds_attention_fwd_train): with M = keep-mask * 1/(1-p) regenerated from the same
+// counters, dV = (M o P)^T dO, dP = M o (dO V^T), dS = P o (dP - Dq) where Dq = rowsum(dO o O) still holds for O = (M o P) V.
+template <typename T, bool ALIBI = false, bool DROP = false>
 __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ dq_sum,
                                                                T* __restrict__ dqkv, int Tn, int H, const float* __restrict__ coords = nullptr,
-                                                               const float* __restrict__ dist_scale = nullptr) {
+                                                               const float* __restrict__ dist_scale = nullptr, uint64_t seed = 0,
+                                                               uint32_t drop_stream = 0, uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
-    constexpr int STAGE = 2 * BT_ROW_BYTES + 2 * BT_TR_BYTES + 2 * BT_TILE * 4 + (ALIBI ? 2 * BT_TILE * 4 : 0);
+    constexpr int STAGE = 2 * BT_ROW_BYTES + 2 * BT_TR_BYTES + 2 * BT_TILE * 4 + ((ALIBI || DROP) ? 2 * BT_TILE * 4 : 0);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,6 +95,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
     const int pr = tid >> 3, ch = tid & 7;          // pair 0..31 -> tokens 2pr, 2pr+1
     vec8 q0, q1, g0, g1;
     float lreg = 0.f, dreg = 0.f, cxreg = 0.f, cyreg = 0.f;
+    uint32_t rkreg = 0;
     float xk = 0.f, yk = 0.f, ch_ = 0.f;
     if constexpr (ALIBI) { xk = cbase[(long)keyc * 2]; yk = cbase[(long)keyc * 2 + 1]; ch_ = dist_scale[h]; }
     auto stage_load = [&](int j) {
@@ -106,6 +110,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
             cxreg = cyreg = 0.f;
             if (tid < BT_TILE && j * BT_TILE + tid < Tn) { cxreg = cbase[(long)(j * BT_TILE + tid) * 2]; cyreg = cbase[(long)(j * BT_TILE + tid) * 2 + 1]; }
         }
+        if constexpr (DROP) {      // per-query row keys of this tile (ALiBi has no attention dropout: the slot is free)
+            if (tid < BT_TILE) rkreg = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + min(j * BT_TILE + tid, Tn - 1)));
+        }
     };
     auto stage_store = [&](int buf) {
         char* sQ = smem + buf * STAGE;
@@ -113,6 +120,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
         char* sQt = sG + BT_ROW_BYTES;
         char* sGt = sQt + BT_TR_BYTES;
         float* sL = reinterpret_cast<float*>(sGt + BT_TR_BYTES);
+        if constexpr (DROP) {
+            if (tid < BT_TILE) reinterpret_cast<uint32_t*>(sL)[2 * BT_TILE + tid] = rkreg;
+        }
         const int t0 = pr * 2;
         *reinterpret_cast<vec8*>(sQ + t0 * 128 + ((ch ^ ((t0 >> 1) & 7)) << 4)) = q0;
         *reinterpret_cast<vec8*>(sQ + (t0 + 1) * 128 + ((ch ^ (((t0 + 1) >> 1) & 7)) << 4)) = q1;
@@ -174,8 +184,15 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
                 const int qg = j * BT_TILE + ql;
                 float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -sL[ql]));
                 if (qg >= Tn || key >= Tn) p = 0.f;
-                const float dsv = p * (dp[r] - sL[BT_TILE + ql]);
-                float pw = p;                                   // weight on v: P, minus the scaled distance for ALiBi
+                float dpr = dp[r];
+                float pw = p;                                   // weight on v: P (dropped: M o P), minus the scaled distance for ALiBi
+                if constexpr (DROP) {
+                    const uint32_t bits = drop_pair_bits(reinterpret_cast<const uint32_t*>(sL)[2 * BT_TILE + ql], (uint32_t)key >> 1);
+                    const float mk = drop_keep(bits, key & 1, thr16) ? keep_scale : 0.f;
+                    dpr *= mk;
+                    pw *= mk;
+                }
+                const float dsv = p * (dpr - sL[BT_TILE + ql]);
                 if constexpr (ALIBI) {
                     const float ddx = sL[2 * BT_TILE + ql] - xk, ddy = sL[3 * BT_TILE + ql] - yk;
                     if (qg < Tn && key < Tn) pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
@@ -221,10 +238,11 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
 //   S^T[i=key][j=query] = K_rows . Q^T(regs)      dP^T[i=key][j=query] = V_rows . dO^T(regs)
 //   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ dq_sum,
-                                                             T* __restrict__ dqkv, int Tn, int H) {
+                                                             T* __restrict__ dqkv, int Tn, int H, uint64_t seed = 0, uint32_t drop_stream = 0,
+                                                             uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     constexpr int STAGE = 2 * BT_ROW_BYTES + BT_TR_BYTES;
@@ -249,6 +267,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
         gf[ks] = *reinterpret_cast<const vec8*>(dobase + (long)qc * Dm + (ks * 2 + hi) * 8);
     }
     const float Lq = lse[((long)b * H + h) * Tn + qc], Dq = dq_sum[((long)b * H + h) * Tn + qc];
+    uint32_t rowkey = 0;
+    if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qc));
 
     const int pr = tid >> 3, ch = tid & 7;
     vec8 k0, k1, v0, v1;
@@ -314,7 +334,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
                 const int kg = j * BT_TILE + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -Lq));
                 if (kg >= Tn) p = 0.f;
-                df[r >> 3][r & 7] = Act<T>::from_f32(p * (dp[r] - Dq));
+                float dpr = dp[r];
+                if constexpr (DROP) dpr *= drop_keep(drop_pair_bits(rowkey, (uint32_t)kg >> 1), kg & 1, thr16) ? keep_scale : 0.f;
+                df[r >> 3][r & 7] = Act<T>::from_f32(p * (dpr - Dq));
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -347,12 +369,21 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
 template <typename T>
 static int launch_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* dq_sum, void* dqkv, int B, int T_, int H,
                            hipStream_t st, const void* u = nullptr, const float* coords = nullptr, const float* bias_scale = nullptr,
-                           const float* dist_scale = nullptr, float* dbs_part = nullptr) {
+                           const float* dist_scale = nullptr, float* dbs_part = nullptr, float p_drop = 0.f, uint64_t seed = 0, uint32_t drop_stream = 0) {
     const long total = (long)B * T_ * H;
     hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, (const T*)o, (const T*)dout, dq_sum, T_, H, total,
                        (const T*)u, bias_scale, dbs_part);
     AMDS_LAUNCH_CHECK("attn_bwd_prep_kernel");
     const dim3 grid((T_ + 127) / 128, H, B), block(256);
+    if (!u && p_drop > 0.f) {
+        const uint32_t thr = drop_thr16(p_drop);
+        const float ks = drop_scale(thr);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
+        AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel<drop>");
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, seed, drop_stream, thr, ks);
+        AMDS_LAUNCH_CHECK("attn_bwd_dq_kernel<drop>");
+        return AMDS_OK;
+    }
     if (u) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
     AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
@@ -392,6 +423,19 @@ extern "C" int amds_attention_bwd(const void* qkv, const void* out, const void* 
     if (dtype == AMDS_BF16) return launch_attn_bwd<bf16>(qkv, out, dout, lse, dq_sum_ws, dqkv, B, T, H, st);
     if (dtype == AMDS_F16) return launch_attn_bwd<f16>(qkv, out, dout, lse, dq_sum_ws, dqkv, B, T, H, st);
     set_error("amds_attention_bwd: bad dtype %d", dtype);
+    return AMDS_ERR_INVALID;
+}
+
+// backward of amds_attention_fwd_train (same p, seed, stream_id as the forward)
+extern "C" int amds_attention_bwd_train(const void* qkv, const void* out, const void* dout, const float* lse, float* dq_sum_ws, void* dqkv,
+                                        int B, int T, int H, int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(qkv && out && dout && lse && dq_sum_ws && dqkv, "amds_attention_bwd_train: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && p >= 0.f && p < 1.f, "amds_attention_bwd_train: bad arguments B=%d T=%d H=%d p=%f", B, T, H, p);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_ATTN, 10.0 * B * H * (double)T * T * 64, st);
+    if (dtype == AMDS_BF16) return launch_attn_bwd<bf16>(qkv, out, dout, lse, dq_sum_ws, dqkv, B, T, H, st, nullptr, nullptr, nullptr, nullptr, nullptr, p, seed, stream_id);
+    if (dtype == AMDS_F16) return launch_attn_bwd<f16>(qkv, out, dout, lse, dq_sum_ws, dqkv, B, T, H, st, nullptr, nullptr, nullptr, nullptr, nullptr, p, seed, stream_id);
+    set_error("amds_attention_bwd_train: bad dtype %d", dtype);
     return AMDS_ERR_INVALID;
 }
 

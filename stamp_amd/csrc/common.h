@@ -153,6 +153,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- dropout bits (training) --------------------------------------------------------------------
+// Counter-based, so forward and backward regenerate the SAME mask from (seed, stream, element index) and nothing T x T or
+// M x FF is stored.  One 32-bit hash (murmur3 finaliser over a per-row key) serves the element PAIR (2j, 2j+1) of a row, 16
+// bits each:  keep  <=>  bits16 >= thr16,  thr16 = round(p * 65536)  ->  P(drop) = thr16 / 65536 (p = 0.5, 0.25 exact),
+// kept values are scaled by 65536 / (65536 - thr16).  `stream` separates the dropout sites of one training step.
+__device__ __host__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __host__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint32_t stream, uint64_t row) {
+    const uint32_t a = fmix32((uint32_t)seed ^ (uint32_t)row ^ (stream * 0x9E3779B1u));
+    return fmix32(a + (uint32_t)(seed >> 32) + (uint32_t)(row >> 32) * 0x7FEB352Du);
+}
+__device__ __host__ __forceinline__ uint32_t drop_pair_bits(uint32_t rowkey, uint32_t pair) { return fmix32(rowkey ^ (pair * 0x9E3779B1u)); }
+__device__ __host__ __forceinline__ bool drop_keep(uint32_t pair_bits, int odd, uint32_t thr16) {
+    return ((pair_bits >> (odd ? 16 : 0)) & 0xFFFFu) >= thr16;
+}
+// elementwise sites: the flat tensor is cut into rows of 65536 elements
+__device__ __forceinline__ bool drop_keep_flat(uint64_t seed, uint32_t stream, long idx, uint32_t thr16) {
+    const uint32_t key = drop_rowkey(seed, stream, (uint64_t)(idx >> 16));
+    return drop_keep(drop_pair_bits(key, (uint32_t)(idx & 0xFFFF) >> 1), (int)(idx & 1), thr16);
+}
+static inline uint32_t drop_thr16(float p) { const long t = lroundf(p * 65536.0f); return (uint32_t)(t < 0 ? 0 : (t > 65535 ? 65535 : t)); }
+static inline float drop_scale(uint32_t thr16) { return 65536.0f / (float)(65536u - thr16); }
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 // async 16-byte global -> LDS copy; LDS destination = wave-uniform base + lane*16

@@ -1,0 +1,154 @@
+// dropout.hip -- the dropout sites of the MIL `vit` training step outside the attention kernels (reference
+// src/stamp/modeling/models/vision_tranformer.py): `project_features` = Linear -> GELU -> Dropout(p) (:314-318) and
+// `feed_forward` = LayerNorm -> Linear -> GELU -> Dropout(0.5) -> Linear -> Dropout(0.5) (:157-169; the factory is called
+// WITHOUT a dropout argument at :268-271, so the feed-forward rate is the hard-coded 0.5 whatever the config says).
+// Masks are regenerated from (seed, stream, element index) in the backward (common.h: drop_*), never stored.
+//   amds_gelu_dropout_fwd / _bwd   u = drop(gelu(z)) ;  dz = gelu'(z) * drop'(du)
+//   amds_dropout_add               x_out = x_in + drop(y)          (second feed-forward dropout + residual add)
+//   amds_dropout_cast_bwd          dy16 = (16-bit) drop'(dx)       (gradient entering fc2's backward GEMMs)
+//   amds_dropout_mask / amds_attention_dropout_mask   the masks themselves as u8, for the parity tests
+#include "common.h"
+
+namespace amds {
+
+template <typename TI, typename TO>
+__global__ void gelu_dropout_fwd_kernel(const TI* __restrict__ z, TO* __restrict__ u, long n, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float g = gelu_erf((float)z[i]);
+        u[i] = (TO)(drop_keep_flat(seed, stream, i, thr) ? g * scale : 0.f);
+    }
+}
+template <typename TZ, typename TG, typename TO>
+__global__ void gelu_dropout_bwd_kernel(const TZ* __restrict__ z, const TG* __restrict__ du, TO* __restrict__ dz, long n, uint64_t seed,
+                                        uint32_t stream, uint32_t thr, float scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float x = (float)z[i];
+        const float d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+        dz[i] = (TO)(drop_keep_flat(seed, stream, i, thr) ? (float)du[i] * d * scale : 0.f);
+    }
+}
+// rows x cols view with row pitches (the residual stream may be padded): element index = r * cols + c
+__global__ void dropout_add_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ xin, long ldx, float* __restrict__ xout, long ldo,
+                                   long rows, int cols, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
+    const long n = rows * cols;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = y[r * ldy + c];
+        xout[r * ldo + c] = xin[r * ldx + c] + (drop_keep_flat(seed, stream, i, thr) ? v * scale : 0.f);
+    }
+}
+template <typename TO>
+__global__ void dropout_cast_bwd_kernel(const float* __restrict__ dx, long ldx, TO* __restrict__ dy, long ldy, long rows, int cols, uint64_t seed,
+                                        uint32_t stream, uint32_t thr, float scale) {
+    const long n = rows * cols;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        dy[r * ldy + c] = (TO)(drop_keep_flat(seed, stream, i, thr) ? dx[r * ldx + c] * scale : 0.f);
+    }
+}
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ m, long n, uint64_t seed, uint32_t stream, uint32_t thr) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) m[i] = drop_keep_flat(seed, stream, i, thr) ? 1 : 0;
+}
+// attention probabilities: row = (b*H + h)*T + q, pair = k >> 1 (attention_flash.hip / attention_train.hip use the same rule)
+__global__ void attn_dropout_mask_kernel(uint8_t* __restrict__ m, int H, int Tn, long rows, uint64_t seed, uint32_t stream, uint32_t thr) {
+    const long row = blockIdx.x;
+    if (row >= rows) return;
+    const uint32_t key = drop_rowkey(seed, stream, (uint64_t)row);
+    for (int k = threadIdx.x; k < Tn; k += blockDim.x) m[row * Tn + k] = drop_keep(drop_pair_bits(key, (uint32_t)k >> 1), k & 1, thr) ? 1 : 0;
+}
+
+static inline int grid1d_(long n) { return (int)min((long)8192, (n + 255) / 256); }
+
+}  // namespace amds
+
+using namespace amds;
+
+#define DROP_ARGS_OK(p) ((p) >= 0.f && (p) < 1.f)
+
+extern "C" float amds_dropout_keep_scale(float p) { return drop_scale(drop_thr16(p)); }
+
+extern "C" int amds_gelu_dropout_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(z && u && n >= 0 && DROP_ARGS_OK(p), "amds_gelu_dropout_fwd: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t thr = drop_thr16(p);
+    const float sc = drop_scale(thr);
+    if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (float*)u, n, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_F32 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<float, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const float*)z, (float*)u, n, seed, stream_id, thr, sc);
+    else { set_error("amds_gelu_dropout_fwd: unsupported dtype pair"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("gelu_dropout_fwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_gelu_dropout_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, float p, uint64_t seed,
+                                     uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(z && du && dz && n >= 0 && DROP_ARGS_OK(p), "amds_gelu_dropout_bwd: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t thr = drop_thr16(p);
+    const float sc = drop_scale(thr);
+    if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16)
+        hipLaunchKernelGGL((gelu_dropout_bwd_kernel<bf16, bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_BF16)
+        hipLaunchKernelGGL((gelu_dropout_bwd_kernel<bf16, float, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (const float*)du, (bf16*)dz, n, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_F32 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F32)
+        hipLaunchKernelGGL((gelu_dropout_bwd_kernel<float, float, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const float*)z, (const float*)du, (float*)dz, n, seed, stream_id, thr, sc);
+    else { set_error("amds_gelu_dropout_bwd: unsupported dtype combination"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("gelu_dropout_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_dropout_add(const float* y, long ldy, const float* x_in, long ldx, float* x_out, long ldo, long rows, int cols, float p,
+                                uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(y && x_in && x_out && rows >= 0 && cols > 0 && ldy >= cols && ldx >= cols && ldo >= cols && DROP_ARGS_OK(p), "amds_dropout_add: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = drop_thr16(p);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1d_(rows * cols)), dim3(256), 0, (hipStream_t)stream, y, ldy, x_in, ldx, x_out, ldo, rows, cols, seed,
+                       stream_id, thr, drop_scale(thr));
+    AMDS_LAUNCH_CHECK("dropout_add_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_dropout_cast_bwd(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, int out_dtype, float p, uint64_t seed,
+                                     uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(dx && dy && rows >= 0 && cols > 0 && ldx >= cols && ldy >= cols && DROP_ARGS_OK(p), "amds_dropout_cast_bwd: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = drop_thr16(p);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == AMDS_BF16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<bf16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (bf16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
+    else if (out_dtype == AMDS_F16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<f16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (f16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
+    else if (out_dtype == AMDS_F32) hipLaunchKernelGGL((dropout_cast_bwd_kernel<float>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (float*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
+    else { set_error("amds_dropout_cast_bwd: bad dtype"); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("dropout_cast_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_dropout_mask(uint8_t* mask, long n, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(mask && n >= 0 && DROP_ARGS_OK(p), "amds_dropout_mask: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid1d_(n)), dim3(256), 0, (hipStream_t)stream, mask, n, seed, stream_id, drop_thr16(p));
+    AMDS_LAUNCH_CHECK("dropout_mask_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_dropout_mask(uint8_t* mask, int B, int H, int T, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(mask && B > 0 && H > 0 && T > 0 && DROP_ARGS_OK(p), "amds_attention_dropout_mask: bad arguments");
+    const long rows = (long)B * H * T;
+    AMDS_REQUIRE(rows < (1L << 31), "amds_attention_dropout_mask: too many rows");
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, mask, H, T, rows, seed, stream_id, drop_thr16(p));
+    AMDS_LAUNCH_CHECK("attn_dropout_mask_kernel");
+    return AMDS_OK;
+}

@@ -25,6 +25,8 @@ def l1_loss(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
 def neg_partial_log_likelihood(log_hz: torch.Tensor, time: torch.Tensor, event: torch.Tensor, ties_method: str = "efron",
                                reduction: str = "mean") -> torch.Tensor:
     """Cox partial likelihood; `log_hz` [B] or [B,1] (differentiable), `time` [B], `event` [B] (bool / 0-1)."""
+    if event.sum().item() == 0 or log_hz.dim() == 0:       # cox.py:219-224: "No events OR single sample. Returning zero loss"
+        return torch.tensor(0.0, requires_grad=True, device=log_hz.device)
     lh = log_hz.reshape(-1)
     time = time.to(lh.device)
     order = torch.argsort(time)

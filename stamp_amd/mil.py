@@ -1,164 +1,208 @@
-"""MIL heads on the HIP path -- inference forward (deploy / validation), reference state_dict keys.
+"""MIL heads on the HIP path: model classes with the reference's constructors, parameter trees (state_dict keys) and
+``forward`` signatures, whose arithmetic runs in libamdstamp.
 
-`VisionTransformer` here mirrors the reference's MIL model class of the same name
-(src/stamp/modeling/models/vision_tranformer.py:298-384): same keyword-only constructor, same parameter names
-(`class_token`, `project_features.0.*`, `transformer.layers.{l}.0.{norm,mhsa.in_proj_*,mhsa.out_proj.*}`,
-`transformer.layers.{l}.1.{0,1,4}.*`, `transformer.norm.*`, `mlp_head.0.*`), so checkpoints interchange through
-`load_state_dict`; ``forward(bags, *, coords, mask)`` has the reference signature (pinned by tests/test_model.py:28-32).
+`VisionTransformer` mirrors the reference's MIL model class of the same name
+(src/stamp/modeling/models/vision_tranformer.py:298-384): same keyword-only constructor, the same module tree -- hence the same
+state_dict keys WITH prefix / nesting semantics (`class_token`, `project_features.0.*`,
+`transformer.layers.{l}.0.{norm,mhsa.in_proj_*,mhsa.out_proj.*}` or the MultiHeadALiBi tree with its `running_mean` /
+`items_so_far` BUFFERS, `transformer.layers.{l}.1.{0,1,4}.*`, `transformer.norm.*`, `mlp_head.0.*`) -- so Lightning checkpoints
+of the reference's `Lit*` wrappers load into it and vice versa; ``forward(bags, *, coords, mask)`` is pinned by the reference's
+tests/test_model.py:28-32.  The submodules are parameter containers only; ``forward`` never calls them.
 
-Round-1 coverage: the ``mask=None`` forward the Lightning wrappers actually use for validation / predict
-(src/stamp/modeling/models/__init__.py:286-313), without ALiBi, in ``torch.no_grad`` / eval.  Training (backward),
-and ``mask != None`` raise NotImplementedError -- loudly, there is no torch fallback.  ``use_alibi=True`` runs the
-reference's MultiHeadALiBi in eval mode (distance bias subtracted after the softmax, frozen running mean).
-
-Arithmetic plan: bags are fp16 on disk (preprocessing/__init__.py:325), so the projection GEMM consumes them
-exactly; MFMA operands fp16, fp32 accumulate, fp32 residual stream and LayerNorm, exact-erf GELU on the fp32
-projection output, streaming attention (never materialises T x T, so whole-slide bags fit).
+The forward is DIFFERENTIABLE: one torch.autograd.Function over (bags, parameters) whose forward / backward are the HIP
+training kernels (stamp_amd/mil_core.py), so ``loss.backward()`` fills ``.grad`` of the nn.Parameters and any torch optimiser /
+Lightning drives it (reference models/__init__.py:133-141, 239-279), and ``torch.func.jacrev`` w.r.t. the bag works
+(heatmaps/__init__.py:36-56).  Modes:
+  * ``.eval()`` under ``torch.no_grad()`` / ``inference_mode()``: inference kernels, fp16 MFMA operands, any bag length, ``mask``
+    supported (restated literally from :355-381).
+  * gradient needed, or ``.train()``: training kernels, bf16 operands, fp32 accumulate / residual stream / statistics.  In
+    ``.train()`` mode the reference's dropout sites are live (project_features and nn.MultiheadAttention: `dropout`; both
+    feed-forward Dropouts: the hard-coded 0.5 of :160) with counter-based masks seeded from torch's CPU generator, and every
+    ALiBi `_RunningMeanScaler` buffer is updated before use (:24-29).  ``mask`` is not available on this path.
+There is no CPU / torch fallback: CPU tensors raise.
 """
 from __future__ import annotations
 
 import torch
 from torch import nn
 
-from . import _lib, ops
+from . import _lib, mil_core, ops
+from .mil_core import PackedVit, VitDims
 
 
-def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
-    r = (-w.shape[0]) % mult
-    return w if r == 0 else torch.cat([w, w.new_zeros(r, *w.shape[1:])])
+# ---- parameter containers with the reference's names (never called) ----------------------------------------------------------------
+class _RunningMeanScalerParams(nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self.register_buffer("running_mean", torch.ones(1))
+        self.register_buffer("items_so_far", torch.ones(1))
+
+
+class _ALiBiParams(nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self.scale_distance = _RunningMeanScalerParams()
+        self.bias_scale = nn.Parameter(torch.rand(1))
+
+
+class _MultiHeadALiBiParams(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int) -> None:
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError(f"{embed_dim=} has to be divisible by {num_heads=}")
+        hd = embed_dim // num_heads
+        self.query_encoders = nn.ModuleList([nn.Linear(embed_dim, hd) for _ in range(num_heads)])
+        self.key_encoders = nn.ModuleList([nn.Linear(embed_dim, hd) for _ in range(num_heads)])
+        self.value_encoders = nn.ModuleList([nn.Linear(embed_dim, hd) for _ in range(num_heads)])
+        self.attentions = nn.ModuleList([_ALiBiParams() for _ in range(num_heads)])
+        self.fc = nn.Linear(embed_dim, embed_dim)
+
+
+class _SelfAttentionParams(nn.Module):
+    def __init__(self, dim: int, num_heads: int, dropout: float, use_alibi: bool) -> None:
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.mhsa = _MultiHeadALiBiParams(dim, num_heads) if use_alibi else nn.MultiheadAttention(dim, num_heads, dropout, batch_first=True)
+
+
+class _TransformerParams(nn.Module):
+    def __init__(self, dim: int, depth: int, heads: int, mlp_dim: int, dropout: float, use_alibi: bool) -> None:
+        super().__init__()
+        ff = lambda: nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, mlp_dim), nn.GELU(), nn.Dropout(0.5), nn.Linear(mlp_dim, dim), nn.Dropout(0.5))  # noqa: E731
+        self.layers = nn.ModuleList([nn.ModuleList([_SelfAttentionParams(dim, heads, dropout, use_alibi), ff()]) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim)
+
+
+class _Saved:
+    """Carrier of the forward's saved activations between the two autograd Functions (a non-tensor input)."""
+    saved = None
+    pk = None
+
+
+def _unwrap_batched(t: torch.Tensor):
+    """(plain tensor, batch dim or None, vmap level) of a functorch BatchedTensor; plain tensors pass through."""
+    F_ = torch._C._functorch
+    if F_.is_batchedtensor(t):
+        return F_.get_unwrapped(t), F_.maybe_get_bdim(t), F_.maybe_get_level(t)
+    return t, None, None
+
+
+class _MilVitBackward(torch.autograd.Function):
+    """The HIP backward as its own Function so that torch.func.jacrev (= vmap over the backward, heatmaps/__init__.py:45-52) has a
+    vmap rule to call: one HIP backward per basis vector of the logits."""
+
+    @staticmethod
+    def forward(dlogits, holder, need_params, need_bags, names):
+        G, dbags = mil_core.backward(holder.pk, holder.saved, dlogits, need_params=need_params, need_bags=need_bags)
+        outs = [dbags if need_bags else dlogits.new_zeros(())]
+        outs += [G[n].contiguous() for n in names] if need_params else []
+        return tuple(outs)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        pass
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("double backward through the HIP MIL head is not implemented")
+
+    @staticmethod
+    def vmap(info, in_dims, dlogits, holder, need_params, need_bags, names):
+        bd = in_dims[0]
+        if bd is None:
+            outs = _MilVitBackward.apply(dlogits, holder, need_params, need_bags, names)
+            return outs, tuple(None for _ in outs)
+        rows = [_MilVitBackward.apply(dlogits.select(bd, i), holder, need_params, need_bags, names) for i in range(info.batch_size)]
+        outs = tuple(torch.stack([r[j] for r in rows]) for j in range(len(rows[0])))
+        return outs, tuple(0 for _ in outs)
+
+
+class _MilVitFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(bags, coords, holder, model, training, seed, *params):
+        names = model._param_names
+        P = dict(zip(names, params))
+        dev = bags.device
+
+        def get(name):
+            t = P[name] if name in P else model.get_buffer(name)
+            return t.detach().to(dev, torch.float32)
+
+        pk = PackedVit(model.dims, get, torch.bfloat16, train=True)
+        logits, saved = mil_core.forward_train(pk, bags.detach(), None if coords is None else coords.detach(), training=training, seed=seed)
+        holder.pk, holder.saved = pk, saved
+        return logits
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.holder, ctx.names = inputs[2], inputs[3]._param_names
+        ctx.bags_dtype = inputs[0].dtype
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        need_bags = ctx.needs_input_grad[0]
+        need_params = any(ctx.needs_input_grad[6:])
+        outs = _MilVitBackward.apply(dlogits, ctx.holder, need_params, need_bags, tuple(ctx.names))
+        dbags = outs[0].to(ctx.bags_dtype) if need_bags else None
+        gp = list(outs[1:]) if need_params else [None] * len(ctx.names)
+        return (dbags, None, None, None, None, None, *gp)
 
 
 class VisionTransformer(nn.Module):
     def __init__(self, *, dim_output: int, dim_input: int, dim_model: int, n_layers: int, n_heads: int,
                  dim_feedforward: int, dropout: float, use_alibi: bool) -> None:
         super().__init__()
+        self.dims = VitDims(F=dim_input, D=dim_model, H=n_heads, FF=dim_feedforward, C=dim_output, L=n_layers, alibi=bool(use_alibi),
+                            p_drop=float(dropout))
         self.use_alibi = bool(use_alibi)
-        if n_heads * 64 != dim_model or dim_model % 128 or dim_feedforward % 128:
-            raise NotImplementedError(f"HIP MIL vit needs head_dim 64 and dims that are multiples of 128 "
-                                      f"(dim_model={dim_model}, n_heads={n_heads}, dim_feedforward={dim_feedforward})")
         self.dim_output, self.dim_input, self.dim_model = dim_output, dim_input, dim_model
-        self.n_layers, self.n_heads, self.dim_feedforward = n_layers, n_heads, dim_feedforward
-        D = dim_model
-        # parameters with the reference's names and shapes (registered flat; state_dict keys match the reference)
-        self.class_token = nn.Parameter(torch.randn(D))
-        P = nn.ParameterDict()
-        def add(name, *shape, ones=False, zeros=False):
-            t = torch.ones(*shape) if ones else torch.zeros(*shape) if zeros else torch.randn(*shape) / (shape[-1] ** 0.5)
-            P[name.replace(".", "/")] = nn.Parameter(t)
-        add("project_features.0.weight", D, dim_input); add("project_features.0.bias", D, zeros=True)
-        for l in range(n_layers):
-            p = f"transformer.layers.{l}."
-            add(p + "0.norm.weight", D, ones=True); add(p + "0.norm.bias", D, zeros=True)
-            if use_alibi:       # MultiHeadALiBi: one Linear(D, 64) per head for q, k, v (+ running-mean scaler, bias_scale), fc
-                for h in range(n_heads):
-                    for enc in ("query_encoders", "key_encoders", "value_encoders"):
-                        add(p + f"0.mhsa.{enc}.{h}.weight", 64, D); add(p + f"0.mhsa.{enc}.{h}.bias", 64, zeros=True)
-                    add(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean", 1, ones=True)
-                    add(p + f"0.mhsa.attentions.{h}.scale_distance.items_so_far", 1, ones=True)
-                    P[(p + f"0.mhsa.attentions.{h}.bias_scale").replace(".", "/")] = nn.Parameter(torch.rand(1))
-                add(p + "0.mhsa.fc.weight", D, D); add(p + "0.mhsa.fc.bias", D, zeros=True)
-            else:
-                add(p + "0.mhsa.in_proj_weight", 3 * D, D); add(p + "0.mhsa.in_proj_bias", 3 * D, zeros=True)
-                add(p + "0.mhsa.out_proj.weight", D, D); add(p + "0.mhsa.out_proj.bias", D, zeros=True)
-            add(p + "1.0.weight", D, ones=True); add(p + "1.0.bias", D, zeros=True)
-            add(p + "1.1.weight", dim_feedforward, D); add(p + "1.1.bias", dim_feedforward, zeros=True)
-            add(p + "1.4.weight", D, dim_feedforward); add(p + "1.4.bias", D, zeros=True)
-        add("transformer.norm.weight", D, ones=True); add("transformer.norm.bias", D, zeros=True)
-        add("mlp_head.0.weight", dim_output, D); add("mlp_head.0.bias", dim_output, zeros=True)
-        self._p = P
-        self._packed = None
+        self.n_layers, self.n_heads, self.dim_feedforward, self.dropout = n_layers, n_heads, dim_feedforward, float(dropout)
+        # the reference's module tree (vision_tranformer.py:312-329): parameter containers, initialised like the reference's
+        self.class_token = nn.Parameter(torch.randn(dim_model))
+        self.project_features = nn.Sequential(nn.Linear(dim_input, dim_model, bias=True), nn.GELU(), nn.Dropout(dropout))
+        self.transformer = _TransformerParams(dim_model, n_layers, n_heads, dim_feedforward, dropout, use_alibi)
+        self.mlp_head = nn.Sequential(nn.Linear(dim_model, dim_output))
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._packed: PackedVit | None = None
+        self._packed_key = None
 
-    # ---- reference-compatible state_dict ---------------------------------------------------------------------
-    def state_dict(self, *a, **k):   # type: ignore[override]
-        sd = {"class_token": self.class_token.detach()}
-        sd.update({n.replace("/", "."): p.detach() for n, p in self._p.items()})
-        return sd
-
-    def load_state_dict(self, sd, strict: bool = True):   # type: ignore[override]
-        own = self.state_dict()
-        missing, unexpected = [k for k in own if k not in sd], [k for k in sd if k not in own]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f"state_dict mismatch: missing {missing}, unexpected {unexpected}")
-        with torch.no_grad():
-            for k, v in sd.items():
-                if k == "class_token":
-                    self.class_token.copy_(v)
-                elif k in own:
-                    self._p[k.replace(".", "/")].copy_(v)
-        self._packed = None
-        return self
-
-    def _pack(self, dev):
-        g = lambda n: self._p[n.replace(".", "/")].detach().to(dev, torch.float32).contiguous()  # noqa: E731
-        h16 = lambda w: ops.cast_pad(_pad_rows(w, 128), (w.shape[1] + 63) // 64 * 64, torch.float16)  # noqa: E731
-        pk = {"cls": self.class_token.detach().to(dev, torch.float32),
-              "proj_w": h16(g("project_features.0.weight")), "proj_b": g("project_features.0.bias"), "layers": []}
-        for l in range(self.n_layers):
-            p = f"transformer.layers.{l}."
-            if self.use_alibi:      # per-head encoders are just a row-blocked in_proj: [q heads | k heads | v heads]
-                H = self.n_heads
-                cat = lambda enc, what: torch.cat([g(p + f"0.mhsa.{enc}.{h}.{what}") for h in range(H)])  # noqa: E731
-                w_in = torch.cat([cat(e, "weight") for e in ("query_encoders", "key_encoders", "value_encoders")])
-                b_in = torch.cat([cat(e, "bias") for e in ("query_encoders", "key_encoders", "value_encoders")])
-                w_out, b_out = g(p + "0.mhsa.fc.weight"), g(p + "0.mhsa.fc.bias")
-                scale = torch.cat([g(p + f"0.mhsa.attentions.{h}.bias_scale") / g(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean")
-                                   for h in range(H)]).contiguous()
-            else:
-                w_in, b_in = g(p + "0.mhsa.in_proj_weight"), g(p + "0.mhsa.in_proj_bias")
-                w_out, b_out = g(p + "0.mhsa.out_proj.weight"), g(p + "0.mhsa.out_proj.bias")
-                scale = None
-            # ALiBi: the attention output is bf16 (range), so its output projection runs on bf16 operands
-            w_out_p = ops.cast_pad(_pad_rows(w_out, 128), w_out.shape[1], torch.bfloat16) if self.use_alibi else h16(w_out)
-            pk["layers"].append(dict(
-                ln1=(g(p + "0.norm.weight"), g(p + "0.norm.bias")),
-                qkv=(h16(w_in), b_in), out=(w_out_p, b_out), alibi_scale=scale,
-                ln2=(g(p + "1.0.weight"), g(p + "1.0.bias")),
-                fc1=(h16(g(p + "1.1.weight")), g(p + "1.1.bias")),
-                fc2=(h16(g(p + "1.4.weight")), g(p + "1.4.bias"))))
-        pk["norm"] = (g("transformer.norm.weight"), g("transformer.norm.bias"))
-        hb = g("mlp_head.0.bias")
-        pk["head"] = (h16(g("mlp_head.0.weight")), torch.cat([hb, hb.new_zeros((-hb.shape[0]) % 128)]))
-        return pk
+    # ---- inference weights, re-packed only when a parameter / buffer changed ---------------------------------------------------------
+    def _infer_pack(self, dev) -> PackedVit:
+        tensors = dict(self.named_parameters())
+        tensors.update(dict(self.named_buffers()))
+        key = (str(dev), tuple((t.data_ptr(), t._version) for t in tensors.values()))
+        if self._packed is None or self._packed_key != key:
+            self._packed = PackedVit(self.dims, lambda n: tensors[n].detach().to(dev, torch.float32), torch.float16, train=False)
+            self._packed_key = key
+        return self._packed
 
     def forward(self, bags: torch.Tensor, *, coords: torch.Tensor | None = None, mask: torch.Tensor | None = None):
-        if mask is not None:
-            raise NotImplementedError("mask != None is not on the HIP path (the reference's Lit wrappers always pass None)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("training (backward) through the HIP MIL head is not implemented; call under "
-                                      "torch.no_grad() / .eval() for deploy-time forward")
         if not bags.is_cuda:
             raise RuntimeError("HIP MIL head needs bags on the GPU (no CPU fallback)")
-        Bb, T, F = bags.shape
-        if F != self.dim_input:
-            raise ValueError(f"bags have {F} features, model expects {self.dim_input}")
-        dev, D, H = bags.device, self.dim_model, self.n_heads
-        if self._packed is None or self._packed["cls"].device != dev:
-            self._packed = self._pack(dev)
-        pk = self._packed
-        Kp = (F + 63) // 64 * 64
-        a = bags.reshape(Bb * T, F)
-        a = a.contiguous() if (a.dtype == torch.float16 and Kp == F) else ops.cast_pad(a.float(), Kp, torch.float16)
-        proj = ops.gemm(a, pk["proj_w"], _lib.EPI_BIAS_GELU_F32, bias=pk["proj_b"])          # [Bb*T, D] fp32
-        S = T + 1
-        x = torch.empty(Bb, S, D, dtype=torch.float32, device=dev)
-        x[:, 0] = pk["cls"]                                                                  # vision_tranformer.py:347-348
-        x[:, 1:] = proj.view(Bb, T, D)
-        x = x.view(Bb * S, D)
-        if self.use_alibi:
-            if coords is None:
-                raise ValueError("use_alibi=True needs coords")
-            c = torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1).to(dev, torch.float32).contiguous()   # :349-351
-        for L in pk["layers"]:
-            h = ops.layernorm(x, *L["ln1"], 1e-5, torch.float16)
-            qkv = ops.gemm(h, L["qkv"][0], _lib.EPI_BIAS, bias=L["qkv"][1])
-            att = ops.attention_alibi(qkv, c, L["alibi_scale"], Bb, S, H) if self.use_alibi else ops.attention(qkv, Bb, S, H)
-            ops.gemm(att, L["out"][0], _lib.EPI_RESIDUAL, bias=L["out"][1], out=x)           # x = attn(x) + x   (:291-292)
-            h = ops.layernorm(x, *L["ln2"], 1e-5, torch.float16)
-            u = ops.gemm(h, L["fc1"][0], _lib.EPI_BIAS_GELU, bias=L["fc1"][1])
-            ops.gemm(u, L["fc2"][0], _lib.EPI_RESIDUAL, bias=L["fc2"][1], out=x)             # x = ff(x) + x     (:293)
-        cls = ops.layernorm_rows(x, Bb, D, S * D, *pk["norm"], 1e-5, torch.float16)          # final LN, class token only
-        logits = ops.gemm(cls, pk["head"][0], _lib.EPI_BIAS_F32, bias=pk["head"][1])
-        return logits[:, : self.dim_output].contiguous()
+        if bags.dim() != 3 or bags.shape[-1] != self.dim_input:
+            raise ValueError(f"bags must be [batch, tile, {self.dim_input}], got {tuple(bags.shape)}")
+        need_grad = torch.is_grad_enabled() and (bags.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not (self.training or need_grad):
+            return mil_core.forward_infer(self._infer_pack(bags.device), bags, coords, mask)
+        if mask is not None:
+            raise NotImplementedError("mask != None is available on the inference path only (eval + no_grad); the reference's "
+                                      "Lightning wrappers never pass one (models/__init__.py:286-313)")
+        seed = 0
+        if self.training:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())            # torch's CPU generator: reproducible under torch.manual_seed
+            if self.use_alibi:
+                if coords is None:
+                    raise ValueError("use_alibi=True needs coords")
+                bufs = dict(self.named_buffers())
+                Bb = bags.shape[0]
+                cc = mil_core._coords_with_cls(coords.detach(), Bb, bags.device)
+                mil_core.update_running_means(lambda n: bufs[n], self.dims, cc)
+        holder = _Saved()
+        params = [p for _, p in self.named_parameters()]
+        if need_grad:
+            return _MilVitFunction.apply(bags, coords, holder, self, self.training, seed, *params)
+        with torch.no_grad():
+            return _MilVitFunction.forward(bags, coords, holder, self, self.training, seed, *params)
 
 
 # ---- bag building (reference src/stamp/modeling/data.py:811-862) ------------------------------------------------

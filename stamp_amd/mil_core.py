@@ -1,0 +1,492 @@
+"""Functional core of the MIL `vit` head on the HIP path: weight packing, inference forward, training forward and backward.
+
+Everything with a token dimension runs in libamdstamp (GEMMs, LayerNorm, attention, GELU / dropout, reductions); this file is
+the launch sequence and the bookkeeping around it.  The two front ends are `stamp_amd.mil.VisionTransformer` (an nn.Module with
+the reference's constructor, parameter tree and ``forward(bags, coords=, mask=)``; differentiable through one
+torch.autograd.Function) and `stamp_amd.mil_train.HipMilVitTrainer` (flat fp32 master buffer + fused AdamW).
+
+Reference: src/stamp/modeling/models/vision_tranformer.py -- VisionTransformer.forward :331-384, Transformer.forward :281-295,
+SelfAttention :172-242, feed_forward :157-169, MultiHeadALiBi / _ALiBi / _RunningMeanScaler :15-154.
+
+Shapes.  The kernels want GEMM dimensions in multiples of 128 and attention heads of 64 channels.  Models that do not have them
+(the reference's own tests use dim_input 456, dim_model 4 x 33, dim_feedforward 135; tests/test_model.py:9-32) are run on a
+ZERO-PADDED copy of the weights: input / model / feed-forward widths padded to multiples of 128, every head padded from
+head_dim to 64 channels with `sqrt(64 / head_dim)` folded into the query rows (the kernels scale scores by 1/8), an all-zero head
+appended when the head count is odd.  Padding channels stay exactly zero through the whole network (zero weights and biases;
+LayerNorm is evaluated over the true `dim_model` columns only), so the padded model computes the same function; gradients are
+sliced back to the reference shapes.  Restrictions that remain: head_dim <= 64 and dim_model % 4 == 0 (LayerNorm kernels read
+float4).  When nothing needs padding (the defaults: 512 / 8 heads / 512) the packed tensors are plain views / casts.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from . import train_ops as T
+
+BF = torch.bfloat16
+_ENC = ("query_encoders", "key_encoders", "value_encoders")
+
+
+def _up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+@dataclass(frozen=True)
+class VitDims:
+    F: int
+    D: int
+    H: int
+    FF: int
+    C: int
+    L: int
+    alibi: bool
+    p_drop: float = 0.0          # `dropout` of the constructor: project_features' Dropout and nn.MultiheadAttention's dropout
+    p_ff: float = 0.5            # feed_forward's two Dropouts: the reference never forwards `dropout` to them (:268-271 -> :160)
+
+    def __post_init__(self):
+        if self.D % self.H:
+            raise ValueError(f"dim_model={self.D} has to be divisible by n_heads={self.H}")
+        if self.hd > 64 or self.D % 4:
+            raise NotImplementedError(f"HIP MIL vit needs head_dim <= 64 and dim_model % 4 == 0 (dim_model={self.D}, n_heads={self.H})")
+
+    @property
+    def hd(self) -> int:
+        return self.D // self.H
+
+    @property
+    def Fp(self) -> int:
+        return _up(self.F, 128)
+
+    @property
+    def Dp(self) -> int:
+        return _up(self.D, 128)
+
+    @property
+    def FFp(self) -> int:
+        return _up(self.FF, 128)
+
+    @property
+    def Ha(self) -> int:
+        return self.H + (self.H & 1)
+
+    @property
+    def Da(self) -> int:
+        return 64 * self.Ha
+
+    @property
+    def qscale(self) -> float:
+        return 8.0 / math.sqrt(self.hd)
+
+
+# ---- reference parameter names ------------------------------------------------------------------------------------------------
+def layer_prefix(l: int) -> str:
+    return f"transformer.layers.{l}."
+
+
+def param_names(d: VitDims) -> list[str]:
+    """state_dict order of the reference module (parameters and the ALiBi scaler buffers)."""
+    names = ["class_token", "project_features.0.weight", "project_features.0.bias"]
+    for l in range(d.L):
+        p = layer_prefix(l)
+        names += [p + "0.norm.weight", p + "0.norm.bias"]
+        if d.alibi:
+            for e in _ENC:
+                for h in range(d.H):
+                    names += [p + f"0.mhsa.{e}.{h}.weight", p + f"0.mhsa.{e}.{h}.bias"]
+            for h in range(d.H):
+                names += [p + f"0.mhsa.attentions.{h}.bias_scale", p + f"0.mhsa.attentions.{h}.scale_distance.running_mean",
+                          p + f"0.mhsa.attentions.{h}.scale_distance.items_so_far"]
+            names += [p + "0.mhsa.fc.weight", p + "0.mhsa.fc.bias"]
+        else:
+            names += [p + "0.mhsa.in_proj_weight", p + "0.mhsa.in_proj_bias", p + "0.mhsa.out_proj.weight", p + "0.mhsa.out_proj.bias"]
+        names += [p + "1.0.weight", p + "1.0.bias", p + "1.1.weight", p + "1.1.bias", p + "1.4.weight", p + "1.4.bias"]
+    names += ["transformer.norm.weight", "transformer.norm.bias", "mlp_head.0.weight", "mlp_head.0.bias"]
+    return names
+
+
+def is_buffer(name: str) -> bool:
+    return name.endswith("scale_distance.running_mean") or name.endswith("scale_distance.items_so_far")
+
+
+# ---- zero padding of the weights (data movement only) --------------------------------------------------------------------------
+def _pad2(w: torch.Tensor, R: int, Cc: int) -> torch.Tensor:
+    if w.shape == (R, Cc):
+        return w.contiguous()
+    return F.pad(w, (0, Cc - w.shape[1], 0, R - w.shape[0])).contiguous()
+
+
+def _pad1(v: torch.Tensor, n: int) -> torch.Tensor:
+    return v.contiguous() if v.numel() == n else F.pad(v, (0, n - v.numel())).contiguous()
+
+
+class PackedVit:
+    """fp32 padded master copies (`m`), 16-bit MFMA operand copies W [N][K] (`w`) and, for training, W^T [K][N] (`wt`)."""
+
+    def __init__(self, dims: VitDims, get, act: torch.dtype, train: bool) -> None:
+        self.dims, self.act, self.train = dims, act, train
+        self.refresh(get)
+
+    # in-projection [3][H][hd][D] <-> padded [3*Da][Dp]; q rows carry sqrt(64/hd)
+    def _pad_in(self, w3: torch.Tensor) -> torch.Tensor:
+        d = self.dims
+        if d.hd == 64 and d.Ha == d.H and (w3.dim() == 3 or d.D == d.Dp):
+            return w3.reshape(3 * d.Da, -1).contiguous() if w3.dim() == 4 else w3.reshape(3 * d.Da).contiguous()
+        if w3.dim() == 4:       # weight [3, H, hd, D]
+            out = F.pad(w3, (0, d.Dp - d.D, 0, 64 - d.hd, 0, d.Ha - d.H))
+            out[0] *= d.qscale
+            return out.reshape(3 * d.Da, d.Dp).contiguous()
+        out = F.pad(w3, (0, 64 - d.hd, 0, d.Ha - d.H))      # bias [3, H, hd]
+        out[0] *= d.qscale
+        return out.reshape(3 * d.Da).contiguous()
+
+    def unpad_in_w(self, g: torch.Tensor) -> torch.Tensor:
+        d = self.dims
+        g4 = g.view(3, d.Ha, 64, d.Dp)[:, : d.H, : d.hd, : d.D]
+        if d.hd != 64:
+            g4 = g4.clone()
+            g4[0] *= d.qscale
+        return g4
+
+    def unpad_in_b(self, g: torch.Tensor) -> torch.Tensor:
+        d = self.dims
+        g3 = g.view(3, d.Ha, 64)[:, : d.H, : d.hd]
+        if d.hd != 64:
+            g3 = g3.clone()
+            g3[0] *= d.qscale
+        return g3
+
+    def _pad_out(self, w: torch.Tensor) -> torch.Tensor:      # [D, H*hd] -> [Dp, Da]
+        d = self.dims
+        if w.shape == (d.Dp, d.Da):
+            return w.contiguous()
+        return F.pad(w.reshape(d.D, d.H, d.hd), (0, 64 - d.hd, 0, d.Ha - d.H, 0, d.Dp - d.D)).reshape(d.Dp, d.Da).contiguous()
+
+    def unpad_out_w(self, g: torch.Tensor) -> torch.Tensor:
+        d = self.dims
+        return g.view(d.Dp, d.Ha, 64)[: d.D, : d.H, : d.hd].reshape(d.D, d.D)
+
+    def refresh(self, get) -> None:
+        d = self.dims
+        m: dict = {"cls": _pad1(get("class_token"), d.Dp), "proj_w": _pad2(get("project_features.0.weight"), d.Dp, d.Fp),
+                   "proj_b": _pad1(get("project_features.0.bias"), d.Dp), "layers": []}
+        for l in range(d.L):
+            p = layer_prefix(l)
+            Lm: dict = {"ln1": (get(p + "0.norm.weight").contiguous(), get(p + "0.norm.bias").contiguous()),
+                        "ln2": (get(p + "1.0.weight").contiguous(), get(p + "1.0.bias").contiguous())}
+            if d.alibi:     # per-head Linear(D, hd) encoders = a row-blocked in-projection [q heads | k heads | v heads]
+                w3 = torch.stack([torch.stack([get(p + f"0.mhsa.{e}.{h}.weight") for h in range(d.H)]) for e in _ENC])
+                b3 = torch.stack([torch.stack([get(p + f"0.mhsa.{e}.{h}.bias") for h in range(d.H)]) for e in _ENC])
+                Lm["out_w"], Lm["out_b"] = self._pad_out(get(p + "0.mhsa.fc.weight")), _pad1(get(p + "0.mhsa.fc.bias"), d.Dp)
+                bs = torch.cat([get(p + f"0.mhsa.attentions.{h}.bias_scale").reshape(1) for h in range(d.H)])
+                rm = torch.cat([get(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean").reshape(1) for h in range(d.H)])
+                Lm["bias_scale"] = _pad1(bs, d.Ha)
+                Lm["inv_rm"] = F.pad(1.0 / rm, (0, d.Ha - d.H), value=1.0).contiguous()
+            else:
+                w3 = get(p + "0.mhsa.in_proj_weight").view(3, d.H, d.hd, d.D)
+                b3 = get(p + "0.mhsa.in_proj_bias").view(3, d.H, d.hd)
+                Lm["out_w"], Lm["out_b"] = self._pad_out(get(p + "0.mhsa.out_proj.weight")), _pad1(get(p + "0.mhsa.out_proj.bias"), d.Dp)
+            Lm["in_w"], Lm["in_b"] = self._pad_in(w3), self._pad_in(b3)
+            Lm["fc1_w"], Lm["fc1_b"] = _pad2(get(p + "1.1.weight"), d.FFp, d.Dp), _pad1(get(p + "1.1.bias"), d.FFp)
+            Lm["fc2_w"], Lm["fc2_b"] = _pad2(get(p + "1.4.weight"), d.Dp, d.FFp), _pad1(get(p + "1.4.bias"), d.Dp)
+            m["layers"].append(Lm)
+        m["norm"] = (get("transformer.norm.weight").contiguous(), get("transformer.norm.bias").contiguous())
+        m["head_w"], m["head_b"] = get("mlp_head.0.weight").contiguous(), get("mlp_head.0.bias").contiguous()
+        self.m = m
+        cast = lambda w, dt=None: ops.cast_pad(w, w.shape[1], dt or self.act)  # noqa: E731
+        self.w: dict = {"proj_w": cast(m["proj_w"]), "layers": []}
+        self.wt: dict = {"layers": []}
+        if self.train:
+            self.wt["proj_w"] = T.transpose16(self.w["proj_w"])
+        for Lm in m["layers"]:
+            # ALiBi: the attention output is bf16 (range, see amds_attention_alibi), so its output projection runs on bf16 operands
+            Lw = {"in_w": cast(Lm["in_w"]), "out_w": cast(Lm["out_w"], BF if d.alibi else None), "fc1_w": cast(Lm["fc1_w"]),
+                  "fc2_w": cast(Lm["fc2_w"])}
+            self.w["layers"].append(Lw)
+            if self.train:
+                self.wt["layers"].append({k: T.transpose16(v) for k, v in Lw.items()})
+
+
+def _coords_with_cls(coords: torch.Tensor, Bb: int, dev) -> torch.Tensor:
+    return torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1).to(dev, torch.float32).contiguous()      # class token at (0, 0), :349-351
+
+
+def _ln(x, rows, cols, ld_in, gamma, beta, out_dtype, ld_out, buf=None):
+    """LayerNorm over the first `cols` columns of rows pitched ld_in; output pitched ld_out, padding columns zero."""
+    if buf is None:
+        buf = (torch.zeros if ld_out != cols else torch.empty)(rows, ld_out, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().amds_layernorm(x.data_ptr(), ld_in, gamma.data_ptr(), beta.data_ptr(), buf.data_ptr(), ld_out, rows, cols, 1e-5,
+                                         ops._DT[out_dtype], ops._stream()), "layernorm")
+    return buf
+
+
+# ---- inference forward (fp16 operands; deploy / validation / the reference's `mask` path) -----------------------------------------
+def forward_infer(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, mask: torch.Tensor | None) -> torch.Tensor:
+    d = pk.dims
+    Bb, Tn, Fd = bags.shape
+    dev = bags.device
+    act = pk.act
+    a = bags.reshape(Bb * Tn, Fd)
+    a = a.contiguous() if (a.dtype == act and d.Fp == Fd) else ops.cast_pad(a.float(), d.Fp, act)
+    proj = ops.gemm(a, pk.w["proj_w"], _lib.EPI_BIAS_GELU_F32, bias=pk.m["proj_b"])                  # [Bb*T, Dp] fp32, eval: Dropout = identity
+    S = Tn + 1
+    M = Bb * S
+    x = torch.empty(Bb, S, d.Dp, dtype=torch.float32, device=dev)
+    x[:, 0] = pk.m["cls"]                                                                            # :347-348
+    x[:, 1:] = proj.view(Bb, Tn, d.Dp)
+    x = x.view(M, d.Dp)
+    c = pad = None
+    if d.alibi:
+        if coords is None:
+            raise ValueError("use_alibi=True needs coords")
+        c = _coords_with_cls(coords, Bb, dev)
+    if mask is not None:
+        if mask.shape != (Bb, Tn):
+            raise ValueError(f"mask must be [batch, tile] = {(Bb, Tn)}, got {tuple(mask.shape)}")
+        pad = torch.cat([mask.new_zeros(Bb, 1), mask], dim=1).to(dev, torch.uint8).contiguous()      # class token never padded (:356-358)
+    hbuf = torch.zeros(M, d.Dp, dtype=act, device=dev) if d.Dp != d.D else None
+    lib, st = _lib.lib(), ops._stream()
+    for Lm, Lw in zip(pk.m["layers"], pk.w["layers"]):
+        h = _ln(x, M, d.D, d.Dp, *Lm["ln1"], act, d.Dp, hbuf)
+        qkv = ops.gemm(h, Lw["in_w"], _lib.EPI_BIAS, bias=Lm["in_b"])
+        if d.alibi:
+            scale = (Lm["bias_scale"] * Lm["inv_rm"]).contiguous()
+            if pad is None:
+                att = ops.attention_alibi(qkv, c, scale, Bb, S, d.Ha)
+            else:
+                att = torch.empty(M, d.Da, dtype=BF, device=dev)
+                _lib.check(lib.amds_attention_alibi_masked(qkv.data_ptr(), c.data_ptr(), scale.data_ptr(), pad.data_ptr(), att.data_ptr(), Bb, S,
+                                                           d.Ha, ops.act_code(act), st), "attention_alibi_masked")
+        elif pad is None:
+            att = ops.attention(qkv, Bb, S, d.Ha)
+        else:
+            if d.Ha != d.H:
+                raise NotImplementedError("mask with an odd head count: the reference's head-repeated mask indexing (b*H + h) % B "
+                                          "changes with the padded head")
+            att = torch.empty(M, d.Da, dtype=act, device=dev)
+            _lib.check(lib.amds_attention_masked(qkv.data_ptr(), pad.data_ptr(), att.data_ptr(), Bb, S, d.Ha, ops.act_code(act), st), "attention_masked")
+        ops.gemm(att, Lw["out_w"], _lib.EPI_RESIDUAL, bias=Lm["out_b"], out=x)                       # x = attn(x) + x   (:291-292)
+        h = _ln(x, M, d.D, d.Dp, *Lm["ln2"], act, d.Dp, hbuf)
+        u = ops.gemm(h, Lw["fc1_w"], _lib.EPI_BIAS_GELU, bias=Lm["fc1_b"])
+        ops.gemm(u, Lw["fc2_w"], _lib.EPI_RESIDUAL, bias=Lm["fc2_b"], out=x)                         # x = ff(x) + x     (:293)
+    cls = _ln(x, Bb, d.D, S * d.Dp, *pk.m["norm"], torch.float32, d.D)                               # final LN, class token only
+    return ops.linear_f32(cls, pk.m["head_w"], pk.m["head_b"])
+
+
+# ---- training forward / backward (bf16 operands, saved statistics) ----------------------------------------------------------------
+def _gelu_drop_fwd(z, out_dtype, p, seed, sid):
+    if p <= 0.0:
+        return T.gelu_fwd(z, out_dtype)
+    u = torch.empty(z.shape, dtype=out_dtype or z.dtype, device=z.device)
+    _lib.check(_lib.lib().amds_gelu_dropout_fwd(z.data_ptr(), u.data_ptr(), z.numel(), ops._DT[z.dtype], ops._DT[u.dtype], p, seed, sid, ops._stream()),
+               "gelu_dropout_fwd")
+    return u
+
+
+def _gelu_drop_bwd(z, du, p, seed, sid):
+    if p <= 0.0:
+        return T.gelu_bwd(z, du)
+    dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    _lib.check(_lib.lib().amds_gelu_dropout_bwd(z.data_ptr(), du.data_ptr(), dz.data_ptr(), z.numel(), ops._DT[z.dtype], ops._DT[du.dtype],
+                                                ops._DT[dz.dtype], p, seed, sid, ops._stream()), "gelu_dropout_bwd")
+    return dz
+
+
+def update_running_means(get, d: VitDims, cc: torch.Tensor) -> None:
+    """Train-mode `_RunningMeanScaler` of every head and layer, BEFORE use (:24-29): rm <- rm + (mean(dist) - rm) / n ; n <- n + 1.
+    Every scaler sees the same distance matrix, so one mean serves all of them (buffers updated in place)."""
+    md = T.cdist_mean(cc)
+    rms = [get(layer_prefix(l) + f"0.mhsa.attentions.{h}.scale_distance.running_mean") for l in range(d.L) for h in range(d.H)]
+    ns = [get(layer_prefix(l) + f"0.mhsa.attentions.{h}.scale_distance.items_so_far") for l in range(d.L) for h in range(d.H)]
+    with torch.no_grad():
+        delta = torch._foreach_neg(rms)
+        torch._foreach_add_(delta, md)
+        torch._foreach_div_(delta, ns)
+        torch._foreach_add_(rms, delta)
+        torch._foreach_add_(ns, 1.0)
+
+
+def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, *, training: bool, seed: int = 0):
+    """-> (logits fp32 [Bb, C], saved).  `training` switches the dropout sites on (the running means are the caller's job)."""
+    d = pk.dims
+    dev = bags.device
+    Bb, Tn, Fd = bags.shape
+    S = Tn + 1
+    Mt, M = Bb * Tn, Bb * S
+    Dp, Da, Ha = d.Dp, d.Da, d.Ha
+    p_proj = d.p_drop if training else 0.0
+    p_att = d.p_drop if (training and not d.alibi) else 0.0
+    p_ff = d.p_ff if training else 0.0
+    lib, st = _lib.lib(), ops._stream()
+    src = bags.reshape(Mt, Fd).contiguous()
+    if src.dtype == torch.float16 and d.Fp == Fd:
+        a = torch.empty(Mt, Fd, dtype=BF, device=dev)
+        _lib.check(lib.amds_convert_f16_bf16(src.data_ptr(), a.data_ptr(), src.numel(), st), "convert")
+    elif src.dtype == BF and d.Fp == Fd:
+        a = src
+    else:
+        a = ops.cast_pad(src.float(), d.Fp, BF)
+    zp = ops.gemm(a, pk.w["proj_w"], _lib.EPI_BIAS, bias=pk.m["proj_b"])                             # bf16 [Mt, Dp]
+    xp = _gelu_drop_fwd(zp, torch.float32, p_proj, seed, 1000)
+    x = torch.empty(Bb, S, Dp, dtype=torch.float32, device=dev)
+    x[:, 0] = pk.m["cls"]
+    x[:, 1:] = xp.view(Bb, Tn, Dp)
+    x = x.view(M, Dp)
+    cc = None
+    if d.alibi:
+        if coords is None:
+            raise ValueError("use_alibi=True needs coords")
+        cc = _coords_with_cls(coords, Bb, dev)
+    layers = []
+    zbuf = (lambda: torch.zeros(M, Dp, dtype=BF, device=dev)) if Dp != d.D else (lambda: None)
+    for l, (Lm, Lw) in enumerate(zip(pk.m["layers"], pk.w["layers"])):
+        h1, mu1, rs1 = T.layernorm_train(x, *Lm["ln1"], 1e-5, BF, rows=M, row_stride=Dp, out=zbuf(), ld_out=Dp)
+        qkv = ops.gemm(h1, Lw["in_w"], _lib.EPI_BIAS, bias=Lm["in_b"])
+        x_mid = x.clone()
+        if d.alibi:
+            att, u_al, osm, lse = T.attention_alibi_fwd_train(qkv, cc, Lm["inv_rm"], Lm["bias_scale"], Bb, S, Ha)
+            lse = (lse, u_al, osm)
+        else:
+            att, lse = T.attention_fwd_train(qkv, Bb, S, Ha, p_att, seed, 10 * l + 1)
+        ops.gemm(att, Lw["out_w"], _lib.EPI_RESIDUAL, bias=Lm["out_b"], out=x_mid)
+        h2, mu2, rs2 = T.layernorm_train(x_mid, *Lm["ln2"], 1e-5, BF, rows=M, row_stride=Dp, out=zbuf(), ld_out=Dp)
+        z = ops.gemm(h2, Lw["fc1_w"], _lib.EPI_BIAS, bias=Lm["fc1_b"])
+        u = _gelu_drop_fwd(z, None, p_ff, seed, 10 * l + 2)
+        if p_ff > 0.0:          # x_out = x_mid + Dropout(fc2(u))   (:167-168)
+            y = ops.gemm(u, Lw["fc2_w"], _lib.EPI_BIAS_F32, bias=Lm["fc2_b"])
+            x_out = torch.empty_like(x_mid)
+            _lib.check(lib.amds_dropout_add(y.data_ptr(), Dp, x_mid.data_ptr(), Dp, x_out.data_ptr(), Dp, M, Dp, p_ff, seed, 10 * l + 3, st), "dropout_add")
+        else:
+            x_out = x_mid.clone()
+            ops.gemm(u, Lw["fc2_w"], _lib.EPI_RESIDUAL, bias=Lm["fc2_b"], out=x_out)
+        layers.append((x, h1, mu1, rs1, qkv, att, lse, x_mid, h2, mu2, rs2, z, u))
+        x = x_out
+    clsn, muf, rsf = T.layernorm_train(x, *pk.m["norm"], 1e-5, torch.float32, rows=Bb, row_stride=S * Dp)
+    logits = ops.linear_f32(clsn, pk.m["head_w"], pk.m["head_b"])
+    saved = dict(a=a, zp=zp, x=x, clsn=clsn, muf=muf, rsf=rsf, layers=layers, cc=cc, shape=(Bb, Tn, Fd), p=(p_proj, p_att, p_ff), seed=seed)
+    return logits, saved
+
+
+def _bgemm(A, lda, B, ldb, transb, Cm, ldc, M, N, K):
+    _lib.check(_lib.lib().amds_bgemm_f32(A.data_ptr(), lda, 0, 0, B.data_ptr(), ldb, 0, 0, 1 if transb else 0, Cm.data_ptr(), ldc, 0, 0, 1, 1,
+                                         M, N, K, 1.0, 0.0, None, 0, ops._stream()), "bgemm_f32")
+
+
+def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False, split_k: int = 32):
+    """-> (grads: reference-named, reference-shaped fp32 tensors (empty dict if not need_params), dbags fp32 [Bb,T,F] or None)."""
+    d = pk.dims
+    dev = dlogits.device
+    Bb, Tn, Fd = saved["shape"]
+    S = Tn + 1
+    Mt, M = Bb * Tn, Bb * S
+    D, Dp, Da, Ha, FFp, Fp, C = d.D, d.Dp, d.Da, d.Ha, d.FFp, d.Fp, d.C
+    p_proj, p_att, p_ff = saved["p"]
+    seed = saved["seed"]
+    lib, st = _lib.lib(), ops._stream()
+    G: dict[str, torch.Tensor] = {}
+    unit = 64 * split_k
+    Mp, Mtp = _up(M, unit), _up(Mt, unit)
+    tbuf: dict = {}
+
+    def tr(t: torch.Tensor, key: str) -> torch.Tensor:      # [M, cols] bf16 -> [cols, Mp], zero-padded scratch reused per width
+        k = (key, t.shape[1])
+        if k not in tbuf:
+            tbuf[k] = torch.zeros(t.shape[1], Mp, dtype=BF, device=dev)
+        return T.transpose16(t, out=tbuf[k])
+
+    def wgrad(dyT: torch.Tensor, xT: torch.Tensor, Nn: int, Kk: int, Mpad: int) -> torch.Tensor:
+        """dW[N][K] = dy^T x, contraction over the (padded) token dimension split into split_k fp32 partials."""
+        chunk = Mpad // split_k
+        part = torch.empty(split_k, Nn * Kk, dtype=torch.float32, device=dev)
+        T.gemm_batched(dyT, Mpad, chunk, xT, Mpad, chunk, Nn, Kk, chunk, split_k, BF, part, Kk, Nn * Kk, True)
+        return T.colsum(part).view(Nn, Kk)
+
+    dlogits = dlogits.contiguous().float()
+    clsn, x = saved["clsn"], saved["x"]
+    if need_params:
+        gW = torch.empty(C, D, dtype=torch.float32, device=dev)
+        _bgemm(dlogits.t().contiguous(), Bb, clsn, D, False, gW, D, C, D, Bb)                           # dW_head = dlogits^T clsn
+        G["mlp_head.0.weight"], G["mlp_head.0.bias"] = gW, T.colsum(dlogits)
+    dcls = torch.empty(Bb, D, dtype=torch.float32, device=dev)
+    _bgemm(dlogits, C, pk.m["head_w"], D, False, dcls, D, Bb, D, C)                                      # dclsn = dlogits W_head
+    dx = torch.zeros(M, Dp, dtype=torch.float32, device=dev)
+    gn_w, gn_b = torch.empty(D, device=dev), torch.empty(D, device=dev)
+    T.layernorm_bwd(dcls, x, saved["muf"], saved["rsf"], pk.m["norm"][0], dx, False, gn_w, gn_b, rows=Bb, dy_stride=D, x_stride=S * Dp, dx_stride=S * Dp)
+    G["transformer.norm.weight"], G["transformer.norm.bias"] = gn_w, gn_b
+    for l in reversed(range(d.L)):
+        p = layer_prefix(l)
+        Lm, Lw, Lt = pk.m["layers"][l], pk.w["layers"][l], pk.wt["layers"][l]
+        x_in, h1, mu1, rs1, qkv, att, lse, x_mid, h2, mu2, rs2, z, u = saved["layers"][l]
+        # ---- feed-forward branch: x_out = x_mid + drop(fc2(drop(gelu(fc1(LN(x_mid))))))
+        if p_ff > 0.0:
+            dyb = torch.empty(M, Dp, dtype=BF, device=dev)
+            _lib.check(lib.amds_dropout_cast_bwd(dx.data_ptr(), Dp, dyb.data_ptr(), Dp, M, Dp, _lib.BF16, p_ff, seed, 10 * l + 3, st), "dropout_cast_bwd")
+        else:
+            dyb = ops.cast_pad(dx, Dp, BF)
+        du = ops.gemm(dyb, Lt["fc2_w"], _lib.EPI_BIAS)                                                   # [M, FFp] = dy W2
+        if need_params:
+            G[p + "1.4.weight"] = wgrad(tr(dyb, "g"), tr(u, "a"), Dp, FFp, Mp)[:D, : d.FF]
+            G[p + "1.4.bias"] = (T.colsum(dyb) if p_ff > 0.0 else T.colsum(dx))[:D]
+        dz = _gelu_drop_bwd(z, du, p_ff, seed, 10 * l + 2)
+        dh2 = ops.gemm(dz, Lt["fc1_w"], _lib.EPI_BIAS_F32)                                               # [M, Dp] fp32
+        if need_params:
+            G[p + "1.1.weight"] = wgrad(tr(dz, "g"), tr(h2, "a"), FFp, Dp, Mp)[: d.FF, :D]
+            G[p + "1.1.bias"] = T.colsum(dz)[: d.FF]
+        g_w, g_b = torch.empty(D, device=dev), torch.empty(D, device=dev)
+        T.layernorm_bwd(dh2, x_mid, mu2, rs2, Lm["ln2"][0], dx, True, g_w, g_b, rows=M, dy_stride=Dp, x_stride=Dp, dx_stride=Dp)
+        G[p + "1.0.weight"], G[p + "1.0.bias"] = g_w, g_b
+        # ---- attention branch: x_mid = x_in + out_proj(attention(in_proj(LN(x_in))))
+        dxb = ops.cast_pad(dx, Dp, BF)                                                                   # d(x_mid)
+        datt = ops.gemm(dxb, Lt["out_w"], _lib.EPI_BIAS)                                                 # [M, Da]
+        out_name = "0.mhsa.fc." if d.alibi else "0.mhsa.out_proj."
+        if need_params:
+            G[p + out_name + "weight"] = pk.unpad_out_w(wgrad(tr(dxb, "g"), tr(att, "a"), Dp, Da, Mp))
+            G[p + out_name + "bias"] = T.colsum(dx)[:D]
+        if d.alibi:
+            lse_, u_al, osm = lse
+            dqkv, dbs = T.attention_alibi_bwd(qkv, osm, u_al, datt, lse_, saved["cc"], Lm["bias_scale"], (Lm["bias_scale"] * Lm["inv_rm"]).contiguous(),
+                                              Bb, S, Ha)
+            if need_params:
+                for h in range(d.H):
+                    G[p + f"0.mhsa.attentions.{h}.bias_scale"] = dbs[h:h + 1].clone()
+        else:
+            dqkv = T.attention_bwd_train(qkv, att, datt, lse, Bb, S, Ha, p_att, seed, 10 * l + 1)
+        if need_params:
+            gw = pk.unpad_in_w(wgrad(tr(dqkv, "g"), tr(h1, "a"), 3 * Da, Dp, Mp))                          # [3, H, hd, D]
+            gb = pk.unpad_in_b(T.colsum(dqkv))                                                           # [3, H, hd]
+            if d.alibi:
+                for i, e in enumerate(_ENC):
+                    for h in range(d.H):
+                        G[p + f"0.mhsa.{e}.{h}.weight"], G[p + f"0.mhsa.{e}.{h}.bias"] = gw[i, h], gb[i, h]
+            else:
+                G[p + "0.mhsa.in_proj_weight"], G[p + "0.mhsa.in_proj_bias"] = gw.reshape(3 * D, D), gb.reshape(3 * D)
+        dh1 = ops.gemm(dqkv, Lt["in_w"], _lib.EPI_BIAS_F32)
+        g_w, g_b = torch.empty(D, device=dev), torch.empty(D, device=dev)
+        T.layernorm_bwd(dh1, x_in, mu1, rs1, Lm["ln1"][0], dx, True, g_w, g_b, rows=M, dy_stride=Dp, x_stride=Dp, dx_stride=Dp)
+        G[p + "0.norm.weight"], G[p + "0.norm.bias"] = g_w, g_b
+    dx3 = dx.view(Bb, S, Dp)
+    if need_params:
+        G["class_token"] = T.colsum(dx3[:, 0, :])[:D]                                                    # rows at stride S*Dp
+    dxp = dx3[:, 1:, :].reshape(Mt, Dp)                                                                  # contiguous copy (data movement)
+    dzp = _gelu_drop_bwd(saved["zp"], dxp, p_proj, seed, 1000)                                           # bf16
+    if need_params:
+        dzpT = T.transpose16(dzp, ld_dst=Mtp)
+        aT = T.transpose16(saved["a"], ld_dst=Mtp)
+        G["project_features.0.weight"] = wgrad(dzpT, aT, Dp, Fp, Mtp)[:D, :Fd]
+        G["project_features.0.bias"] = T.colsum(dzp)[:D]
+    dbags = None
+    if need_bags:
+        dbags = ops.gemm(dzp, pk.wt["proj_w"], _lib.EPI_BIAS_F32)[:, :Fd].reshape(Bb, Tn, Fd)
+    if not need_params:
+        G = {}
+    return G, dbags
+
+
+def flops_per_bag(T_: int = 1024, Fd: int = 1024, D: int = 512, FF: int = 512, L: int = 2) -> float:
+    """matmul FLOPs of one forward (2 per MAC): projection + L x (qkv, attention, out, fc1, fc2); training ~ 3x."""
+    S = T_ + 1
+    return 2 * T_ * Fd * D + L * (2 * S * D * 3 * D + 4 * S * S * D + 2 * S * D * D + 2 * S * D * FF + 2 * S * FF * D)

@@ -32,16 +32,19 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = 
     return out
 
 
-def layernorm_train(x: torch.Tensor, gamma, beta, eps: float, out_dtype=torch.bfloat16, rows=None, row_stride=None):
-    _dev(x, gamma, beta)
+def layernorm_train(x: torch.Tensor, gamma, beta, eps: float, out_dtype=torch.bfloat16, rows=None, row_stride=None, out=None, ld_out=None):
+    """LayerNorm over the first gamma.numel() columns of rows pitched `row_stride`; `out` / `ld_out`: a wider, zero-padded destination."""
+    _dev(x, gamma, beta, out)
     assert x.dtype == torch.float32 and x.is_contiguous()
     cols = gamma.numel()
     rows = rows if rows is not None else x.numel() // cols
     xs = row_stride if row_stride is not None else cols
-    y = torch.empty(rows, cols, dtype=out_dtype, device=x.device)
+    ld = ld_out if ld_out is not None else cols
+    y = out if out is not None else torch.empty(rows, ld, dtype=out_dtype, device=x.device)
+    assert y.dtype == out_dtype and y.shape == (rows, ld) and (out is not None or ld == cols)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().amds_layernorm_train(_p(x), xs, _p(gamma), _p(beta), _p(y), cols, _p(mean), _p(rstd), rows, cols, eps,
+    _lib.check(_lib.lib().amds_layernorm_train(_p(x), xs, _p(gamma), _p(beta), _p(y), ld, _p(mean), _p(rstd), rows, cols, eps,
                                                _DT[out_dtype], _stream()), "layernorm_train")
     return y, mean, rstd
 
@@ -92,6 +95,40 @@ def attention_bwd(qkv, out, dout, lse, B: int, T: int, H: int) -> torch.Tensor:
     _lib.check(_lib.lib().amds_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(ws), _p(dqkv), B, T, H, act_code(qkv.dtype), _stream()),
                "attention_bwd")
     return dqkv
+
+
+def attention_fwd_train(qkv: torch.Tensor, B: int, T: int, H: int, p: float = 0.0, seed: int = 0, stream_id: int = 0):
+    """nn.MultiheadAttention forward in train mode: dropout p on the attention probabilities (counter-based mask), + lse."""
+    _dev(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64)
+    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_fwd_train(_p(qkv), _p(out), _p(lse), B, T, H, act_code(qkv.dtype), float(p), int(seed), int(stream_id),
+                                                   _stream()), "attention_fwd_train")
+    return out, lse
+
+
+def attention_bwd_train(qkv, out, dout, lse, B: int, T: int, H: int, p: float = 0.0, seed: int = 0, stream_id: int = 0) -> torch.Tensor:
+    _dev(qkv, out, dout, lse)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype == out.dtype
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_bwd_train(_p(qkv), _p(out), _p(dout), _p(lse), _p(ws), _p(dqkv), B, T, H, act_code(qkv.dtype), float(p),
+                                                   int(seed), int(stream_id), _stream()), "attention_bwd_train")
+    return dqkv
+
+
+def dropout_mask(n: int, p: float, seed: int, stream_id: int, device) -> torch.Tensor:
+    """The keep mask (u8) an elementwise dropout site draws for (seed, stream_id) -- for tests."""
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().amds_dropout_mask(_p(m), n, float(p), int(seed), int(stream_id), _stream()), "dropout_mask")
+    return m
+
+
+def attention_dropout_mask(B: int, H: int, T: int, p: float, seed: int, stream_id: int, device) -> torch.Tensor:
+    m = torch.empty(B, H, T, T, dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().amds_attention_dropout_mask(_p(m), B, H, T, float(p), int(seed), int(stream_id), _stream()), "attention_dropout_mask")
+    return m
 
 
 def gemm_batched(a, lda, bsA, w, ldw, bsW, M, N, K, nbatch, dtype, out, ldo, bsOut, f32_out: bool, bias=None, acc_scale=1.0):

@@ -45,10 +45,9 @@ def test_mil_vit_state_dict_roundtrip_and_guards(gpu):
     bags = torch.randn(2, 50, 256).to(gpu)           # fp32 bags are accepted too (cast on the device)
     with torch.no_grad():
         assert torch.equal(m1(bags, coords=None, mask=None), m2(bags, coords=None, mask=None))
-    with pytest.raises(NotImplementedError):
-        m1(bags, coords=None, mask=torch.zeros(2, 50, dtype=torch.bool, device=gpu))
-    with pytest.raises(NotImplementedError):
-        m1.train()(bags, coords=None, mask=None)
+    with pytest.raises(NotImplementedError):      # mask is an inference-path feature
+        m1.train()(bags, coords=None, mask=torch.zeros(2, 50, dtype=torch.bool, device=gpu))
+    m1.eval()
     with pytest.raises(RuntimeError, match="GPU"):
         with torch.no_grad():
             m1.eval()(bags.cpu(), coords=None, mask=None)
@@ -124,7 +123,7 @@ def test_mil_vit_alibi_forward_matches_oracle(gpu, Bb, T):
     model = VisionTransformer(dim_output=C, dim_input=F, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512,
                               dropout=0.0, use_alibi=True).eval()
     with torch.no_grad():
-        for n, p in model.named_parameters():
+        for n, p in list(model.named_parameters()) + list(model.named_buffers()):
             if "running_mean" in n:
                 p.fill_(900.0 + 200 * torch.rand(1).item())      # mean tile distance seen in training
             elif "items_so_far" in n:

@@ -1,0 +1,385 @@
+"""The MIL `vit` seam on the GPU: the reference's own fixtures loaded into the HIP model class (eval, with and without `mask`), the
+reference's test shapes, the differentiable module (autograd / torch optimisers / jacrev), train-mode dropout against the oracle
+fed with the very masks the kernels drew, bench-size and configs[0]-shaped training parity, and the epoch loop."""
+import dataclasses
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.mil_vit import mil_vit_forward, running_mean_update
+from stamp_amd import _lib, mil_core
+from stamp_amd import train_ops as T
+from stamp_amd.mil import VisionTransformer
+from stamp_amd.mil_train import HipMilVitTrainer, fit
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def _perturb(model, scale=0.05):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "class_token" not in n and "bias_scale" not in n:
+                p.add_(scale * torch.randn_like(p))
+
+
+# ---- eval forward against the REFERENCE's fixtures (head_dim 32 / 16 -> zero-padded heads) ---------------------------------------------
+@pytest.mark.parametrize("tag,alibi", [("plain", False), ("alibi", True)])
+def test_eval_forward_matches_reference_fixture_with_and_without_mask(gpu, tag, alibi):
+    """State dict, bags, coords, mask and logits captured from the reference module (tools/make_golden.py): the HIP model class
+    loads the reference's state_dict as is and reproduces `logits_nomask` and `logits_mask` (vision_tranformer.py:355-381;
+    the reference's tests/test_model.py:28-32 pins this call).  Tolerance: 5e-3 absolute on O(1) logits (fp16 MFMA operands)."""
+    z = np.load(G / f"mil_vit_{tag}.npz")
+    C, F, D, L, H, FF = (int(v) for v in z["hparams"])
+    model = VisionTransformer(dim_output=C, dim_input=F, dim_model=D, n_layers=L, n_heads=H, dim_feedforward=FF, dropout=0.0, use_alibi=alibi).eval()
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    model = model.to(gpu)
+    bags, coords, mask = (torch.from_numpy(z[k]).to(gpu) for k in ("bags", "coords", "mask"))
+    with torch.inference_mode():
+        y0 = model(bags, coords=coords, mask=None)
+        y1 = model(bags, coords=coords, mask=mask)
+        assert torch.equal(y1, model(bags, coords=coords, mask=mask))        # test_inference_reproducibility of the reference
+    tol = 5e-3 * max(1.0, float(np.abs(z["logits_nomask"]).max()))
+    assert np.abs(y0.cpu().numpy() - z["logits_nomask"]).max() < tol, (y0.cpu().numpy(), z["logits_nomask"])
+    assert np.abs(y1.cpu().numpy() - z["logits_mask"]).max() < tol, (y1.cpu().numpy(), z["logits_mask"])
+    assert np.abs(z["logits_mask"] - z["logits_nomask"]).max() > 10 * tol      # the mask matters in this fixture
+
+
+@pytest.mark.parametrize("alibi", [False, True])
+def test_reference_test_shapes_with_random_mask(gpu, alibi):
+    """The shapes of the reference's tests/test_model.py:9-32 (456-d input, 4 heads x 33, feed-forward 135, 3 layers, 75 tiles, random
+    mask): nothing is a multiple of anything, everything runs on the zero-padded copy.  Against the oracle."""
+    torch.manual_seed(3)
+    H = 4
+    model = VisionTransformer(dim_output=3, dim_input=456, dim_model=H * 33, n_layers=3, n_heads=H, dim_feedforward=135, dropout=0.12, use_alibi=alibi).eval()
+    _perturb(model)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    bags, coords = torch.rand(6, 75, 456), torch.rand(6, 75, 2) * 2000
+    mask = torch.rand(6, 75) > 0.5
+    for m in (None, mask):
+        ref = mil_vit_forward(bags, coords, m, sd, n_heads=H, use_alibi=alibi)
+        with torch.no_grad():
+            out = model(bags.to(gpu), coords=coords.to(gpu), mask=None if m is None else m.to(gpu))
+        assert out.shape == (6, 3)
+        assert (out.cpu() - ref).abs().max() < 6e-3 * max(1.0, ref.abs().max().item()), (m is None, out.cpu(), ref)
+
+
+# ---- the differentiable module ------------------------------------------------------------------------------------------------------
+def _no_dropout(model):
+    model.dims = dataclasses.replace(model.dims, p_drop=0.0, p_ff=0.0)
+    return model
+
+
+@pytest.mark.parametrize("alibi", [False, True])
+def test_module_backward_fills_param_grads_like_the_trainer(gpu, alibi):
+    """loss.backward() through the nn.Module (torch.autograd.Function over the HIP forward / backward) gives the gradients the
+    bespoke trainer computes -- same kernels, so equal to rounding of the split-K order -- and they match the oracle's autograd."""
+    torch.manual_seed(5)
+    Bb, Tn, Fd, C, H = 3, 130, 256, 2, 4
+    kw = dict(dim_output=C, dim_input=Fd, dim_model=256, n_layers=2, n_heads=H, dim_feedforward=256, dropout=0.0, use_alibi=alibi)
+    model = _no_dropout(VisionTransformer(**kw))
+    _perturb(model)
+    twin = _no_dropout(VisionTransformer(**kw))
+    twin.load_state_dict(model.state_dict())
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    bags, coords = torch.randn(Bb, Tn, Fd).half(), torch.rand(Bb, Tn, 2) * 3000
+    targets, weights = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 1.0]]), torch.tensor([0.7, 0.3])
+    model = model.to(gpu).train()
+    logits = model(bags.to(gpu), coords=coords.to(gpu), mask=None)
+    loss = torch.nn.functional.cross_entropy(logits, targets.to(gpu), weight=weights.to(gpu))
+    loss.backward()
+    tr = HipMilVitTrainer(twin, device=gpu, split_k=32, dropout=False)
+    loss_t, logits_t = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu))
+    assert torch.equal(logits.detach(), logits_t) and abs(loss.item() - loss_t.item()) < 1e-6
+    for n, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+        assert _rel(p.grad.cpu(), tr.g(n).cpu()) < 1e-5 or p.grad.abs().max() < 1e-7, (n, _rel(p.grad.cpu(), tr.g(n).cpu()))
+    # oracle (train-mode semantics: scalers updated before use)
+    sd = dict(sd0)
+    if alibi:
+        cc = torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1)
+        dist = torch.cdist(cc, cc)
+        for k in sd0:
+            if k.endswith("running_mean"):
+                n = k[: -len("running_mean")] + "items_so_far"
+                sd[k], sd[n] = running_mean_update(sd0[k], sd0[n], dist)
+                assert torch.allclose(model.get_buffer(k).cpu(), sd[k], rtol=1e-5)          # module buffers updated in place, like the reference
+                assert model.get_buffer(n).item() == 2.0
+    params = {k: v.clone().double().requires_grad_(not mil_core.is_buffer(k)) for k, v in sd.items()}
+    ref = mil_vit_forward(bags.double(), coords.double(), None, params, n_heads=H, use_alibi=alibi, dtype=torch.float64)
+    torch.nn.functional.cross_entropy(ref, targets.double(), weight=weights.double()).backward()
+    for n in ("mlp_head.0.weight", "transformer.norm.weight", "transformer.layers.1.1.1.weight", "transformer.layers.0.1.4.weight",
+              "project_features.0.weight", "class_token"):
+        assert _rel(dict(model.named_parameters())[n].grad.cpu(), params[n].grad) < 5e-2, n
+
+
+def test_module_trains_with_torch_adamw_and_onecycle_like_the_trainer(gpu):
+    """`configure_optimizers` of the reference (models/__init__.py:133-141) driving the HIP module: AdamW(lr=1e-3) + OneCycleLR stepped
+    per batch, against HipMilVitTrainer (fused AdamW fed torch's own lr AND beta1 schedule).  Same loss curve."""
+    torch.manual_seed(9)
+    Bb, Tn, Fd, C = 4, 100, 256, 2
+    kw = dict(dim_output=C, dim_input=Fd, dim_model=256, n_layers=1, n_heads=4, dim_feedforward=256, dropout=0.0, use_alibi=False)
+    model = _no_dropout(VisionTransformer(**kw))
+    twin = _no_dropout(VisionTransformer(**kw))
+    twin.load_state_dict(model.state_dict())
+    bags = torch.randn(Bb, Tn, Fd).half().to(gpu)
+    targets = torch.nn.functional.one_hot(torch.arange(Bb) % 2, 2).float().to(gpu)
+    model = model.to(gpu).train()
+    steps = 12
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, total_steps=steps, max_lr=2e-3, div_factor=25.0)
+    tr = HipMilVitTrainer(twin, device=gpu, max_lr=2e-3, div_factor=25.0, total_steps=steps, dropout=False)
+    la, lb = [], []
+    for i in range(steps):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(bags, coords=None, mask=None), targets)
+        loss.backward()
+        opt.step()
+        if i + 1 < steps:
+            sched.step()
+        la.append(loss.item())
+        lb.append(tr.step(bags, targets.cpu())[0].item())
+    print("torch AdamW on the module:", [round(v, 5) for v in la])
+    print("fused trainer:            ", [round(v, 5) for v in lb])
+    assert la[-1] < la[0] * 0.9
+    assert max(abs(a - b) / max(abs(b), 1e-3) for a, b in zip(la, lb)) < 5e-3
+    tr.sync_to_model()
+    for (n, p), (_, q) in zip(model.state_dict().items(), twin.state_dict().items()):
+        assert (p.cpu() - q.cpu()).abs().max() < 2e-3 * max(1.0, q.abs().max().item()), n
+
+
+def test_jacrev_wrt_bag_features(gpu):
+    """The reference's heatmaps take d(logits)/d(features) with torch.func.jacrev (heatmaps/__init__.py:36-56)."""
+    from torch.func import jacrev
+
+    torch.manual_seed(2)
+    Tn, Fd, C, H = 90, 256, 3, 4
+    model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=256, n_layers=2, n_heads=H, dim_feedforward=256, dropout=0.3, use_alibi=False).eval()
+    _perturb(model)
+    sd = {k: v.clone().double() for k, v in model.state_dict().items()}
+    feats = torch.randn(Tn, Fd).half().float()
+    model = model.to(gpu)
+    fg, cg = feats.to(gpu), torch.zeros(Tn, 2, device=gpu)
+    jac = jacrev(lambda b: model.forward(b.unsqueeze(0), coords=cg.unsqueeze(0), mask=None).squeeze(0))(fg)
+    assert jac.shape == (C, Tn, Fd)
+    x = feats.double().requires_grad_(True)
+    ref = torch.autograd.functional.jacobian(
+        lambda b: mil_vit_forward(b.unsqueeze(0), torch.zeros(1, Tn, 2).double(), None, sd, n_heads=H, use_alibi=False, dtype=torch.float64).squeeze(0), x)
+    assert _rel(jac.cpu(), ref) < 4e-2, _rel(jac.cpu(), ref)
+    cam = (fg * jac).mean(-1).abs()                     # _gradcam_per_category's next line runs on the result
+    assert torch.isfinite(torch.softmax(cam, dim=-1)).all()
+
+
+# ---- dropout --------------------------------------------------------------------------------------------------------------------------
+def test_dropout_masks_statistics_and_determinism(gpu):
+    for p in (0.5, 0.25, 0.1):
+        m = T.dropout_mask(1 << 20, p, 1234, 7, gpu)
+        assert abs(m.float().mean().item() - (1 - p)) < 3e-3
+        assert torch.equal(m, T.dropout_mask(1 << 20, p, 1234, 7, gpu))
+        assert not torch.equal(m, T.dropout_mask(1 << 20, p, 1235, 7, gpu)) and not torch.equal(m, T.dropout_mask(1 << 20, p, 1234, 8, gpu))
+        assert abs(_lib.lib().amds_dropout_keep_scale(p) - 1 / (1 - round(p * 65536) / 65536)) < 1e-6
+        # neighbouring elements share one hash: they must still be independent
+        mm = m.float().view(-1, 2)
+        cov = ((mm[:, 0] - (1 - p)) * (mm[:, 1] - (1 - p))).mean().item()
+        assert abs(cov) < 2e-3
+    a = T.attention_dropout_mask(2, 4, 193, 0.25, 99, 11, gpu)
+    assert a.shape == (2, 4, 193, 193) and abs(a.float().mean().item() - 0.75) < 5e-3
+    rows = a.float().mean(-1)
+    assert rows.min() > 0.55 and rows.max() < 0.95           # no (b, h, q) row is degenerate
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_attention_dropout_fwd_bwd_vs_autograd(gpu, dt):
+    """nn.MultiheadAttention's dropout on the probabilities: the HIP forward / backward with p > 0 against fp64 autograd using the
+    mask the kernels regenerate from (seed, stream) -- dropped entries zero, kept ones scaled by 1/(1-p), softmax normaliser untouched."""
+    B, Tn, H, p, seed, sid = 2, 257, 3, 0.25, 4242, 21
+    g = torch.Generator().manual_seed(8)
+    D = H * 64
+    qkv = torch.randn(B * Tn, 3 * D, generator=g).to(dt)
+    dout = torch.randn(B * Tn, D, generator=g).to(dt)
+    mask = T.attention_dropout_mask(B, H, Tn, p, seed, sid, gpu).cpu().double() * _lib.lib().amds_dropout_keep_scale(p)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x.reshape(B, Tn, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o = ((torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) * mask) @ v).transpose(1, 2).reshape(B * Tn, D)
+    o.backward(dout.double())
+    out, lse = T.attention_fwd_train(qkv.to(gpu), B, Tn, H, p, seed, sid)
+    eps = 2 ** -7 if dt == torch.bfloat16 else 2 ** -10
+    assert (out.cpu().double() - o.detach()).abs().max() < 4 * eps * max(1.0, o.abs().max().item())
+    out0, lse0 = T.attention_fwd_train(qkv.to(gpu), B, Tn, H, 0.0, seed, sid)
+    assert torch.equal(lse, lse0) and not torch.equal(out, out0)         # the saved statistic is that of the undropped softmax
+    dqkv = T.attention_bwd_train(qkv.to(gpu), out, dout.to(gpu), lse, B, Tn, H, p, seed, sid)
+    err = (dqkv.cpu().double() - x.grad).abs().max().item()
+    assert err < 8 * eps * max(1.0, x.grad.abs().max().item()), (err, x.grad.abs().max().item())
+
+
+def _hip_drop_multipliers(tr_dims, Bb, Tn, seed, dev, training_alibi):
+    """The multipliers every dropout site of one step used, rebuilt from the kernels' own mask generators."""
+    d = tr_dims
+    S = Tn + 1
+    ks = lambda p: _lib.lib().amds_dropout_keep_scale(p)  # noqa: E731
+    drop = {}
+    if d.p_drop > 0:
+        drop["proj"] = (T.dropout_mask(Bb * Tn * d.Dp, d.p_drop, seed, 1000, dev).view(Bb, Tn, d.Dp)[..., : d.D].cpu().double() * ks(d.p_drop))
+    for l in range(d.L):
+        if d.p_drop > 0 and not training_alibi:
+            drop[f"attn{l}"] = T.attention_dropout_mask(Bb, d.Ha, S, d.p_drop, seed, 10 * l + 1, dev)[:, : d.H].cpu().double() * ks(d.p_drop)
+        drop[f"ff1_{l}"] = T.dropout_mask(Bb * S * d.FFp, d.p_ff, seed, 10 * l + 2, dev).view(Bb, S, d.FFp)[..., : d.FF].cpu().double() * ks(d.p_ff)
+        drop[f"ff2_{l}"] = T.dropout_mask(Bb * S * d.Dp, d.p_ff, seed, 10 * l + 3, dev).view(Bb, S, d.Dp)[..., : d.D].cpu().double() * ks(d.p_ff)
+    return drop
+
+
+@pytest.mark.parametrize("alibi", [False, True])
+def test_training_step_with_dropout_matches_oracle_given_the_same_masks(gpu, alibi):
+    """Train mode as `stamp train` runs it: dropout 0.25 on project_features and inside nn.MultiheadAttention, the hard-coded 0.5 on both
+    feed-forward Dropouts (the oracle's placement of these sites is pinned to the reference by tests/golden/mil_vit_train_*.npz).
+    The oracle is fed the masks the kernels drew; loss, logits and every gradient must agree."""
+    torch.manual_seed(13)
+    Bb, Tn, Fd, C, H = 3, 140, 256, 2, 4
+    model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=256, n_layers=2, n_heads=H, dim_feedforward=256, dropout=0.25, use_alibi=alibi)
+    _perturb(model)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    bags, coords = torch.randn(Bb, Tn, Fd).half(), torch.rand(Bb, Tn, 2) * 3000
+    targets, weights = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 1.0]]), torch.tensor([0.7, 0.3])
+    tr = HipMilVitTrainer(model, device=gpu, split_k=8)            # dropout=None: as the reference's train mode
+    seed = 777123
+    loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu), seed=seed)
+    loss2, logits2 = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu), seed=seed + 1)
+    assert not torch.equal(logits, logits2)                         # a different seed draws different masks
+    drop = _hip_drop_multipliers(model.dims, Bb, Tn, seed, gpu, alibi)
+    sd = dict(sd0)
+    if alibi:
+        cc = torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1)
+        dist = torch.cdist(cc, cc)
+        for k in sd0:
+            if k.endswith("running_mean"):
+                n = k[: -len("running_mean")] + "items_so_far"
+                sd[k], sd[n] = running_mean_update(sd0[k], sd0[n], dist)
+    params = {k: v.clone().double().requires_grad_(not mil_core.is_buffer(k)) for k, v in sd.items()}
+    ref = mil_vit_forward(bags.double(), coords.double(), None, params, n_heads=H, use_alibi=alibi, drop=drop, dtype=torch.float64)
+    ref_loss = torch.nn.functional.cross_entropy(ref, targets.double(), weight=weights.double())
+    ref_loss.backward()
+    # (gradients in tr.G are those of the SECOND call; redo the first)
+    loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu), seed=seed)
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    assert (logits.cpu().double() - ref.detach()).abs().max() < 3e-2 * max(1.0, ref.abs().max().item())
+    worst = 0.0
+    for k in tr.names:
+        if mil_core.is_buffer(k) or ("key_encoders" in k and k.endswith(".bias")) or k.endswith("in_proj_bias"):
+            continue                       # (key biases have a zero true gradient; in_proj_bias mixes that third in)
+        g, r = tr.g(k).cpu().double(), params[k].grad.double()
+        floor = 0.0
+        if "query_encoders" in k or "key_encoders" in k:
+            floor = 0.05 * params[k.replace("query_encoders", "value_encoders").replace("key_encoders", "value_encoders")].grad.double().norm().item()
+        rel = ((g - r).norm() / max(r.norm().item(), floor, 1e-12)).item()
+        worst = max(worst, rel)
+        assert rel < (0.12 if k.endswith("bias_scale") else 6e-2), (k, rel, r.norm().item())
+    print(f"dropout on, alibi={alibi}: worst relative-L2 gradient error {worst:.4f}")
+    losses = [tr.step(bags.to(gpu), targets, weights, coords=coords.to(gpu))[0].item() for _ in range(30)]
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) and torch.isfinite(tr.P).all()
+
+
+# ---- bench-size and configs[0]-shaped training parity -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("alibi", [False, True])
+def test_bench_size_training_step_matches_autograd(gpu, alibi):
+    """BASELINE.json configs[2] geometry: bags of 1024 tiles x 1024-d, dim_model 512, 8 heads, feed-forward 512, 2 layers, split-K 32
+    (the bench's settings; batch 4 so that the fp64 oracle finishes in seconds).  Loss, logits and EVERY parameter gradient against
+    fp64 autograd through the pinned oracle.  Stated bars (bf16 MFMA operands): loss / logits 1e-2, each gradient <= 3e-2 relative
+    L2 (<= 5e-2 with ALiBi; scalar bias_scale <= 0.12; q/k encoders measured against 5 % of the sibling value-encoder gradient)."""
+    torch.manual_seed(21)
+    Bb, Tn, Fd, C, H = 4, 1024, 1024, 2, 8
+    model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=512, n_layers=2, n_heads=H, dim_feedforward=512, dropout=0.0, use_alibi=alibi)
+    _perturb(model)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    bags = torch.randn(Bb, Tn, Fd).half()
+    coords = (torch.rand(Bb, Tn, 2) * 4e4 / 256).round() * 256
+    targets = torch.nn.functional.one_hot(torch.arange(Bb) % 2, 2).float()
+    weights = torch.tensor([0.6, 0.4])
+    tr = HipMilVitTrainer(model, device=gpu, split_k=32, dropout=False)
+    loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu))
+    sd = dict(sd0)
+    if alibi:
+        cc = torch.cat([coords.new_zeros(Bb, 1, 2), coords], dim=1)
+        dist = torch.cdist(cc, cc)
+        for k in sd0:
+            if k.endswith("running_mean"):
+                n = k[: -len("running_mean")] + "items_so_far"
+                sd[k], sd[n] = running_mean_update(sd0[k], sd0[n], dist)
+    params = {k: v.clone().double().requires_grad_(not mil_core.is_buffer(k)) for k, v in sd.items()}
+    ref = mil_vit_forward(bags.double(), coords.double(), None, params, n_heads=H, use_alibi=alibi, dtype=torch.float64)
+    ref_loss = torch.nn.functional.cross_entropy(ref, targets.double(), weight=weights.double())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-2 * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    assert (logits.cpu().double() - ref.detach()).abs().max() < 1e-2 * max(1.0, ref.abs().max().item())
+    report = []
+    for k in tr.names:
+        if mil_core.is_buffer(k) or ("key_encoders" in k and k.endswith(".bias")):
+            continue
+        g, r = tr.g(k).cpu().double(), params[k].grad.double()
+        if k.endswith("in_proj_bias"):         # the key third has a zero true gradient: compare q and v thirds
+            g, r = torch.cat([g[:512], g[1024:]]), torch.cat([r[:512], r[1024:]])
+        floor = 0.0
+        if "query_encoders" in k or "key_encoders" in k:
+            floor = 0.05 * params[k.replace("query_encoders", "value_encoders").replace("key_encoders", "value_encoders")].grad.double().norm().item()
+        report.append((((g - r).norm() / max(r.norm().item(), floor, 1e-12)).item(), k))
+    report.sort(reverse=True)
+    print(f"bench-size step, alibi={alibi}: largest gradient errors", [(round(a, 4), b) for a, b in report[:6]])
+    for rel, k in report:
+        bar = 0.12 if k.endswith("bias_scale") else (5e-2 if alibi else 3e-2)
+        assert rel < bar, (k, rel)
+
+
+def test_config0_shape_training_step(gpu):
+    """BASELINE.json configs[0]: tests/random_data.py-shaped data -- 64 bags x 256 tiles x 2048-d (resnet50 width), 2 classes, `vit` head with
+    the reference's defaults (512 / 2 layers / 8 heads / 512, modeling/config.py:92-100).  The whole batch runs one HIP step; an 8-bag slice
+    is checked against fp64 autograd through the oracle."""
+    torch.manual_seed(33)
+    Bb, Tn, Fd = 64, 256, 2048
+    model = VisionTransformer(dim_output=2, dim_input=Fd, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.0, use_alibi=False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    bags = torch.rand(Bb, Tn, Fd).half()                             # random_data.py draws uniform features
+    targets = torch.nn.functional.one_hot(torch.arange(Bb) % 2, 2).float()
+    tr = HipMilVitTrainer(model, device=gpu, dropout=False)
+    loss, logits = tr.step(bags.to(gpu), targets, update=False)
+    assert logits.shape == (Bb, 2) and torch.isfinite(loss)
+    ref = mil_vit_forward(bags[:8].double(), torch.zeros(8, Tn, 2).double(), None, {k: v.double() for k, v in sd.items()}, n_heads=8, use_alibi=False,
+                          dtype=torch.float64)
+    assert (logits[:8].cpu().double() - ref).abs().max() < 1e-2 * max(1.0, ref.abs().max().item())
+    loss8, _ = tr.step(bags[:8].to(gpu), targets[:8], update=False)
+    params = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    r8 = mil_vit_forward(bags[:8].double(), torch.zeros(8, Tn, 2).double(), None, params, n_heads=8, use_alibi=False, dtype=torch.float64)
+    torch.nn.functional.cross_entropy(r8, targets[:8].double()).backward()
+    for k in ("project_features.0.weight", "transformer.layers.0.1.1.weight", "transformer.layers.1.0.mhsa.out_proj.weight", "mlp_head.0.weight", "class_token"):
+        assert _rel(tr.g(k).cpu(), params[k].grad) < 3e-2, (k, _rel(tr.g(k).cpu(), params[k].grad))
+    l0 = tr.step(bags.to(gpu), targets)[0].item()
+    for _ in range(15):
+        l1 = tr.step(bags.to(gpu), targets)[0].item()
+    assert l1 < l0
+
+
+def test_fit_loop_trains_validates_and_restores_the_best_epoch(gpu):
+    """`train_model_` semantics end to end on a separable toy problem: per-epoch validation on FULL bags of different lengths (batch 1),
+    early stopping, best weights restored into the nn.Module, which then predicts with the inference kernels."""
+    torch.manual_seed(4)
+    Fd = 256
+    model = VisionTransformer(dim_output=2, dim_input=Fd, dim_model=128, n_layers=1, n_heads=2, dim_feedforward=128, dropout=0.1, use_alibi=False)
+    direction = torch.randn(Fd)
+
+    def make(n, tiles, label):
+        return (torch.randn(n, tiles, Fd) + (0.35 if label else -0.35) * direction).half()
+
+    train = [(torch.cat([make(8, 64, 0), make(8, 64, 1)]), None, None, torch.nn.functional.one_hot(torch.tensor([0] * 8 + [1] * 8), 2).float())] * 4
+    valid = [(make(1, t, lab), None, None, torch.nn.functional.one_hot(torch.tensor([lab]), 2).float()) for t, lab in ((50, 0), (300, 1), (77, 1), (129, 0))]
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=2e-3, total_steps=4 * 12)
+    hist = fit(tr, lambda: train, lambda: valid, max_epochs=12, patience=4)
+    assert len(hist["validation_loss"]) >= 2 and hist["best_epoch"] >= 0
+    assert min(hist["validation_loss"]) < hist["validation_loss"][0] and hist["validation_loss"][hist["best_epoch"]] == min(hist["validation_loss"])
+    model.eval()
+    with torch.no_grad():
+        pred = torch.cat([model.to(gpu)(b.to(gpu), coords=None, mask=None) for b, *_ in valid]).argmax(-1).cpu()
+    assert torch.equal(pred, torch.tensor([0, 1, 1, 0]))

@@ -155,3 +155,45 @@ def test_texture_canny_known_answers():
     assert (e[:, 15] == 255).sum() >= S - 2 and e[:, 15][-1] == 255
     rgb = np.stack([step] * 3, -1)
     assert abs(texture.edge_fraction(rgb) - 1 / S) < 1e-12 and texture.has_enough_texture(rgb, 0.02)
+
+
+def _train_fixture(tag):
+    z = np.load(G / f"mil_vit_train_{tag}.npz")
+    sd0 = {k[len("w_before:"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_before:")}
+    sd1 = {k[len("w_after:"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_after:")}
+    grads = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g:")}
+    L = int(z["hparams"][3])
+    mult = lambda name: torch.from_numpy(z["mask:" + name]).float() / (1.0 - float(z["rate:" + name]))  # noqa: E731
+    drop = {"proj": mult("project_features.2")}
+    for l in range(L):
+        drop[f"ff1_{l}"], drop[f"ff2_{l}"] = mult(f"transformer.layers.{l}.1.3"), mult(f"transformer.layers.{l}.1.5")
+    return z, sd0, sd1, grads, drop
+
+
+@pytest.mark.parametrize("tag,alibi", [("plain", False), ("alibi", True)])
+def test_mil_vit_train_mode_matches_reference(tag, alibi):
+    """TRAIN mode of the reference module (dropout sites + ALiBi scaler update), pinned by what the reference itself produced:
+    with the keep masks its nn.Dropout modules drew, the oracle reproduces its logits, loss and every parameter gradient."""
+    z, sd0, sd1, grads, drop = _train_fixture(tag)
+    heads = int(z["hparams"][4])
+    assert float(z["rate:transformer.layers.0.1.3"]) == 0.5 and float(z["rate:transformer.layers.0.1.5"]) == 0.5     # hard-coded (:160)
+    assert abs(float(z["rate:project_features.2"]) - float(z["dropout"])) < 1e-7
+    bags, coords = torch.from_numpy(z["bags"]), torch.from_numpy(z["coords"])
+    sd = dict(sd0)
+    if alibi:       # every scaler folds the batch's distances in BEFORE use
+        cc = torch.cat([coords.new_zeros(3, 1, 2), coords], dim=1)
+        dist = torch.cdist(cc, cc)
+        for k in sd0:
+            if k.endswith("running_mean"):
+                n = k[: -len("running_mean")] + "items_so_far"
+                sd[k], sd[n] = mil_vit.running_mean_update(sd0[k], sd0[n], dist)
+                np.testing.assert_allclose(sd[k].numpy(), sd1[k].numpy(), rtol=1e-6)
+                np.testing.assert_allclose(sd[n].numpy(), sd1[n].numpy())
+    params = {k: v.clone().requires_grad_(k in grads) for k, v in sd.items()}
+    logits = mil_vit.mil_vit_forward(bags, coords, None, params, n_heads=heads, use_alibi=alibi, drop=drop)
+    np.testing.assert_allclose(logits.detach().numpy(), z["logits"], rtol=2e-5, atol=2e-5)
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(z["targets"]), weight=torch.from_numpy(z["class_weights"]))
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-5)
+    loss.backward()
+    for k, g in grads.items():
+        np.testing.assert_allclose(params[k].grad.numpy(), g.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)

@@ -89,7 +89,7 @@ def exec_defs(path: Path, names: set[str], glb: dict) -> dict:
 
 
 def sd_np(module: torch.nn.Module, prefix: str = "w:") -> dict[str, np.ndarray]:
-    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}      # copy: buffers are updated in place later
 
 
 def save(name: str, **arrs) -> None:
@@ -151,6 +151,49 @@ def golden_mil_vit() -> None:
             arrs["logits_mask"] = model(bags, coords=coords, mask=mask).numpy()
         arrs["hparams"] = np.array([kw[k] for k in ("dim_output", "dim_input", "dim_model", "n_layers", "n_heads", "dim_feedforward")])
         save(f"mil_vit_{tag}.npz", **arrs)
+
+
+def golden_mil_vit_train() -> None:
+    """TRAIN-mode fixtures: one forward + backward of the reference module in .train(), with the keep masks its own nn.Dropout
+    modules drew captured by forward hooks (project_features.2, transformer.layers.{l}.1.3 and .1.5).  nn.MultiheadAttention's
+    internal dropout cannot be observed from outside, so the plain variant uses dropout=0.0 (its feed-forward Dropouts are live
+    regardless: hard-coded 0.5) and the ALiBi variant -- which has no attention dropout -- uses dropout=0.3."""
+    vt = sys.modules.get("stamp.modeling.models.vision_tranformer") or load_by_path(
+        "stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
+    for tag, use_alibi, p_drop, kw in (
+        ("plain", False, 0.0, dict(dim_output=3, dim_input=48, dim_model=64, n_layers=2, n_heads=2, dim_feedforward=96)),
+        ("alibi", True, 0.3, dict(dim_output=2, dim_input=40, dim_model=64, n_layers=2, n_heads=4, dim_feedforward=64)),
+    ):
+        torch.manual_seed(17 if use_alibi else 16)
+        model = vt.VisionTransformer(dropout=p_drop, use_alibi=use_alibi, **kw).train()
+        bags = torch.randn(3, 37, kw["dim_input"])
+        coords = torch.rand(3, 37, 2) * 4000
+        targets = torch.nn.functional.one_hot(torch.tensor([0, 1, 1]), kw["dim_output"]).float()
+        weights = torch.rand(kw["dim_output"]) + 0.5
+        arrs = dict(bags=bags.numpy(), coords=coords.numpy(), targets=targets.numpy(), class_weights=weights.numpy(),
+                    **sd_np(model, "w_before:"))
+        masks, rates = {}, {}
+
+        def hook(name):
+            def fn(mod, inp, out):
+                masks[name] = ((out != 0) | (inp[0] == 0)).to(torch.uint8).numpy()
+                rates[name] = mod.p
+            return fn
+        handles = [m.register_forward_hook(hook(n)) for n, m in model.named_modules() if isinstance(m, torch.nn.Dropout)]
+        logits = model(bags, coords=coords, mask=None)
+        loss = torch.nn.functional.cross_entropy(logits, targets, weight=weights)      # LitTileClassifier._step, models/__init__.py:254-258
+        loss.backward()
+        for h in handles:
+            h.remove()
+        assert set(masks) == {"project_features.2"} | {f"transformer.layers.{l}.1.{i}" for l in range(kw["n_layers"]) for i in (3, 5)}, set(masks)
+        arrs.update({"mask:" + k: v for k, v in masks.items()})
+        arrs.update({"rate:" + k: np.float32(v) for k, v in rates.items()})
+        arrs["logits"], arrs["loss"] = logits.detach().numpy(), loss.detach().numpy()
+        arrs.update({"g:" + n: p.grad.numpy() for n, p in model.named_parameters()})
+        arrs.update(sd_np(model, "w_after:"))            # ALiBi: scaler buffers after the train-mode forward
+        arrs["hparams"] = np.array([kw[k] for k in ("dim_output", "dim_input", "dim_model", "n_layers", "n_heads", "dim_feedforward")])
+        arrs["dropout"] = np.float32(p_drop)
+        save(f"mil_vit_train_{tag}.npz", **arrs)
 
 
 def golden_transmil() -> None:
@@ -338,6 +381,7 @@ def main() -> None:
     install_shims()
     golden_chief()
     golden_mil_vit()
+    golden_mil_vit_train()
     golden_transmil()
     golden_mlp_cox_transforms()
     golden_bag()

@@ -27,7 +27,7 @@ def main(path: str) -> None:
     print(f"{'TOTAL':110s} {sum(a[0] for a in agg.values()):7d} {tot:12.1f}")
 
 
-def by_shape(path: str) -> None:
+def by_shape(path: str, alternate: int = 1) -> None:
     """per (kernel, grid) table: one row per launch SHAPE, so the dominant kernel's average per GEMM shape can be read off."""
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
@@ -36,9 +36,14 @@ def by_shape(path: str) -> None:
     wcols = [c for c in ("workgroup_x", "workgroup_size_x", "workgroup_size") if c in cols]
     sel = ", ".join([namecol, "start", "end"] + gcols + wcols[:1])
     agg = {}
-    for row in db.execute(f"select {sel} from kernels").fetchall():
+    seen = {}
+    for row in db.execute(f"select {sel} from kernels order by start").fetchall():
         n, s, e = row[:3]
-        a = agg.setdefault((short(n), tuple(row[3:])), [0, 0.0, 1e30, 0.0])
+        key = (short(n), tuple(row[3:]))
+        if alternate > 1:       # launches of one (kernel, grid) that alternate between GEMM shapes differing only in K (proj / fc2)
+            i = seen[key] = seen.get(key, -1) + 1
+            key = (key[0], key[1] + (f"#{i % alternate}",))
+        a = agg.setdefault(key, [0, 0.0, 1e30, 0.0])
         d = (e - s) / 1e3
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     tot = sum(a[1] for a in agg.values())
@@ -65,6 +70,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[2] == "--seq":
         sequence(sys.argv[1], int(sys.argv[3]))
     elif len(sys.argv) > 2 and sys.argv[2] == "--by-shape":
-        by_shape(sys.argv[1])
+        by_shape(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     else:
         main(sys.argv[1])
