@@ -10,7 +10,14 @@ A "step" is one pass of the hot path over one virtual slide of `--tiles` u8 tile
 im2col -> patch-embed GEMM -> 24 x {LN, QKV GEMM, attention, proj GEMM(+residual), LN, fc1 GEMM(+GELU),
 fc2 GEMM(+residual)} -> final LN on CLS -> fp16 features in HBM.  Slides shard across ranks (weak scaling: every
 rank encodes its own slide per step); for N>1 every step ends with the path's one collective, an RCCL all-gather
-of the slide-level embeddings.  Rank 0 prints ONE JSON line.
+of the slide-level embeddings.  Rank 0 prints ONE JSON line.  Beside `value` (HBM-resident, the contract's metric) the
+single-GPU line carries:
+  end_to_end   SURVEY.md 8d's M1: a pinned host pool of --e2e-tiles DISTINCT tiles -> double-buffered H2D -> encode -> fp16
+               features D2H, wall clock from the first H2D enqueue to the last feature row on the host (PCIe-inclusive)
+  drop_in_b64  what an unmodified `extract_` gets: `model(tiles.to(device)).detach().half().cpu()` on batches of 64
+               (reference src/stamp/preprocessing/__init__.py:315-327)
+  secondary    MIL bags/s (vit head deploy / train / +ALiBi, TransMIL), CTransPath tiles/s
+  cpu_baseline the oracle on the host cores (ViT-L/14, batch 64) + the MIL / pooling CPU baselines of BASELINE.md section 3
 """
 from __future__ import annotations
 
@@ -43,37 +50,245 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--overlap", type=int, default=0, help="1 = two chunks in flight on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (for a ViT-only rocprofv3 kernel trace)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--e2e-tiles", type=int, default=100_000, help="distinct tiles of the end-to-end (M1) leg; 0 = skip")
+    ap.add_argument("--e2e-warmup", type=int, default=2, help="batches of the end-to-end leg run before its clock starts")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle = the reference's algorithm on torch CPU fp32 kernels), rank 0 at N = 1 only, bounded samples
+# ---------------------------------------------------------------------------------------------------------------------------
+def _pick_threads(fn, candidates) -> int:
+    """Untimed calibration: the host has 2 sockets x 64 cores x SMT; torch's default (all hardware threads) is far from the
+    fastest setting for GEMM-bound fp32 work.  Try a few, keep the best."""
+    best, best_t = candidates[0], float("inf")
+    for n in candidates:
+        torch.set_num_threads(n)
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = n, dt
+    torch.set_num_threads(best)
+    return best
+
+
 def cpu_baseline(cfg, sd, seconds: float, swin: bool = False) -> dict:
-    """The oracle (= the reference's algorithm on torch CPU fp32 kernels, batch 64 like the reference's
-    DataLoader, src/stamp/preprocessing/__init__.py:317) timed on this box's host cores on a bounded sample."""
+    """C1 of BASELINE.md section 3: u8 tiles -> transform -> ViT forward (fp32, batch 64 like the reference's DataLoader,
+    src/stamp/preprocessing/__init__.py:317, attention through F.scaled_dot_product_attention as timm does) -> fp16."""
     if swin:
-        from oracle.swin_ctranspath import swin_encode_f16 as extract_features
+        from oracle.swin_ctranspath import swin_encode_f16 as run
     else:
         from oracle.vit_tile_encoder import extract_features
 
-    threads = torch.get_num_threads()
+        def run(t, s, c):
+            return extract_features(t, s, c, sdpa=True)
+    hw = os.cpu_count() or 8
     g = torch.Generator().manual_seed(1234)
-    batch = 16
+    batch = 64
     tiles = torch.randint(0, 256, (batch, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g)
-    extract_features(tiles[:2], sd, cfg)           # warm
+    cands = sorted({n for n in (16, 32, 64, 96, 128, hw) if n <= hw}) or [hw]
+    threads = _pick_threads(lambda: run(tiles[:8], sd, cfg), cands)
+    run(tiles[:8], sd, cfg)           # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        extract_features(tiles, sd, cfg)
+        run(tiles, sd, cfg)
         n += batch
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 512:
+        if el >= seconds or n >= 1024:
             break
     return {"value": round(n / el, 3), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": f"{n} synthetic 224x224 tiles, {'CTransPath (Swin-T)' if swin else 'ViT'} fp32 oracle (torch CPU), batches of {batch}, {el:.1f}s"}
+            "sample": (f"{n} synthetic 224x224 tiles (batches of {batch}, the reference's DataLoader batch), "
+                       f"{'CTransPath (Swin-T)' if swin else 'ViT'} fp32 oracle on torch CPU kernels with SDPA attention, {el:.1f}s; "
+                       f"thread count chosen by an untimed calibration over {cands} of {hw} hardware threads")}
+
+
+def cpu_baseline_mil(seconds_each: float = 4.0) -> dict:
+    """C2-C4 of BASELINE.md section 3 on the host: MIL `vit` train step (fwd + bwd + AdamW through torch autograd on the
+    oracle network, dropout sites live as in the reference's train mode), MIL forward (deploy: batch 1, full bag), gated-attention
+    pooling.  Bags of 1024 x 1024-d.  Bounded: a few steps each."""
+    from oracle.gated_attention import KEYS, gated_attention_pool
+    from oracle.mil_vit import mil_vit_forward
+    from stamp_amd.mil import VisionTransformer
+
+    out = {}
+    torch.manual_seed(1)
+    model = VisionTransformer(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.25, use_alibi=False)
+    params = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-4)
+    Bb, Tn, D, H = 8, 1024, 512, 8
+    bags = torch.randn(Bb, Tn, 1024).half().float()
+    coords = torch.zeros(Bb, Tn, 2)
+    targets = torch.nn.functional.one_hot(torch.arange(Bb) % 2, 2).float()
+
+    def drop_masks():
+        def m(shape, p):
+            return (torch.rand(shape) >= p).float() / (1 - p)
+        d = {"proj": m((Bb, Tn, D), 0.25)}
+        for l in range(2):
+            d[f"attn{l}"], d[f"ff1_{l}"], d[f"ff2_{l}"] = m((Bb, H, Tn + 1, Tn + 1), 0.25), m((Bb, Tn + 1, D), 0.5), m((Bb, Tn + 1, D), 0.5)
+        return d
+
+    def train_step():
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(mil_vit_forward(bags, coords, None, params, n_heads=H, use_alibi=False, drop=drop_masks()), targets)
+        loss.backward()
+        opt.step()
+
+    hw = os.cpu_count() or 8
+    threads = _pick_threads(train_step, sorted({n for n in (16, 32, 64, hw) if n <= hw}))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_each and n < 40:
+        train_step()
+        n += 1
+    el = time.perf_counter() - t0
+    out["mil_vit_train"] = {"value": round(n * Bb / el, 2), "unit": "bags/s", "cores": threads,
+                            "sample": f"{n} steps of batch {Bb}, bags of 1024 x 1024-d, fwd + bwd + AdamW, train-mode dropout, {el:.1f}s"}
+    sdp = {k: v.detach() for k, v in params.items()}
+    with torch.no_grad():
+        mil_vit_forward(bags[:1], coords[:1], None, sdp, n_heads=H, use_alibi=False)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds_each and n < 200:
+            mil_vit_forward(bags[n % Bb:n % Bb + 1], coords[:1], None, sdp, n_heads=H, use_alibi=False)
+            n += 1
+        el = time.perf_counter() - t0
+    out["mil_vit_deploy"] = {"value": round(n / el, 2), "unit": "bags/s", "cores": threads, "sample": f"{n} forwards of batch 1, bag 1024 x 1024-d, {el:.1f}s"}
+    g = torch.Generator().manual_seed(5)
+    N, F_, L, Dd = 1024, 768, 512, 256
+    sdg = {KEYS["fc_w"]: torch.randn(L, F_, generator=g) / F_ ** 0.5, KEYS["fc_b"]: torch.zeros(L), KEYS["a_w"]: torch.randn(Dd, L, generator=g) / L ** 0.5,
+           KEYS["a_b"]: torch.zeros(Dd), KEYS["b_w"]: torch.randn(Dd, L, generator=g) / L ** 0.5, KEYS["b_b"]: torch.zeros(Dd),
+           KEYS["c_w"]: torch.randn(1, Dd, generator=g) / Dd ** 0.5, KEYS["c_b"]: torch.zeros(1)}
+    x = torch.randn(N, F_, generator=g)
+    with torch.no_grad():
+        gated_attention_pool(x, sdg)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(seconds_each, 2.0) and n < 2000:
+            gated_attention_pool(x, sdg)
+            n += 1
+        el = time.perf_counter() - t0
+    out["gated_attention_pool"] = {"value": round(n / el, 1), "unit": "bags/s", "cores": threads, "sample": f"{n} bags of 1024 x 768, {el:.1f}s"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def end_to_end_leg(model, cfg, dev, n_tiles: int, batch: int, warm_batches: int) -> dict:
+    """SURVEY.md 8d M1.  The pool is generated ON the GPU with a seeded generator (distinct tiles, 150 KB each) and parked in
+    pinned host memory; then pinned host -> H2D -> encode -> fp16 D2H through stamp_amd.extractor.TilePipeline."""
+    from stamp_amd.extractor import TilePipeline
+
+    n_tiles = (n_tiles // batch) * batch
+    pool = torch.empty(n_tiles, cfg.img, cfg.img, 3, dtype=torch.uint8).pin_memory()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    for i in range(0, n_tiles, 4 * batch):
+        j = min(n_tiles, i + 4 * batch)
+        pool[i:j].copy_(torch.randint(0, 256, (j - i, cfg.img, cfg.img, 3), dtype=torch.uint8, device=dev, generator=gen))
+    dim = getattr(cfg, "out_dim", None) or cfg.dim
+    feats = torch.empty(n_tiles, dim, dtype=torch.float16).pin_memory()
+    pipe = TilePipeline(model, batch_size=batch, device=dev, tile_shape=(cfg.img, cfg.img, 3), feat_dim=dim)
+    for i in range(warm_batches):                     # steady state: the first batches are discarded (SURVEY.md 8d)
+        pipe.submit(pool[i * batch:(i + 1) * batch], feats[i * batch:(i + 1) * batch])
+    pipe.finish()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(0, n_tiles, batch):
+        pipe.submit(pool[i:i + batch], feats[i:i + batch])
+    pipe.finish()
+    el = time.perf_counter() - t0
+    ok = bool(torch.isfinite(feats[::997].float()).all()) and not bool((feats[-1] == 0).all())
+    # spot check: a pipelined feature row equals the one the plain call gives for the same tile
+    same = bool(torch.equal(model(pool[-batch:].to(dev))[-1].cpu(), feats[-1]))
+    return {"metric": "tiles/s end to end (M1: pinned host u8 -> H2D -> encode -> fp16 features on the host)", "value": round(n_tiles / el, 1),
+            "unit": "tiles/s", "tiles": n_tiles, "distinct": True, "batch": batch, "seconds": round(el, 2), "finite": ok, "matches_plain_call": same,
+            "h2d_gbytes": round(n_tiles * cfg.img * cfg.img * 3 / 1e9, 2), "d2h_mbytes": round(n_tiles * dim * 2 / 1e6, 1)}
+
+
+def drop_in_b64_leg(model, cfg, dev, n_batches: int = 48) -> dict:
+    """The reference's own loop, literally (preprocessing/__init__.py:315-327): batches of 64 from host memory,
+    ``model(tiles.to(device)).detach().half().cpu()``, one synchronous round trip per batch."""
+    g = torch.Generator().manual_seed(77)
+    host = torch.randint(0, 256, (64 * 8, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g)
+    batches = [host[i * 64:(i + 1) * 64] for i in range(8)]
+    with torch.inference_mode():
+        for b in batches[:3]:
+            model(b.to(dev)).detach().half().cpu()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_batches):
+            f = model(batches[i % 8].to(dev)).detach().half().cpu()
+        el = time.perf_counter() - t0
+        # the same batches with the tiles already on the device (kernel path at M = 64 x tokens)
+        dbat = [b.to(dev) for b in batches]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_batches):
+            model(dbat[i % 8])
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+    return {"metric": "tiles/s of an unmodified extract_ loop: model(batch_of_64.to(device)).half().cpu() per batch", "value": round(64 * n_batches / el, 1),
+            "unit": "tiles/s", "batches": n_batches, "hbm_resident_b64": round(64 * n_batches / el2, 1), "finite": bool(torch.isfinite(f.float()).all())}
+
+
+def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
+    """BASELINE.json's secondary metric, MIL bags/s (bags of 1024 x 1024-d, batch 64), and the in-tree tile encoder."""
+    from stamp_amd.mil import TransMIL as HipTransMIL
+    from stamp_amd.mil import VisionTransformer as HipMil
+    from stamp_amd.mil_train import HipMilVitTrainer
+    from stamp_amd.swin import SWIN_PRESETS, HipSwin, random_swin_state_dict
+
+    sec = {}
+    torch.manual_seed(1)
+    kw = dict(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512)
+    mil = HipMil(dropout=0.25, use_alibi=False, **kw).eval()            # template default dropout (config.yaml:343)
+    bags = torch.randn(64, 1024, 1024, generator=torch.Generator().manual_seed(1)).half().to(ctx.device)
+
+    def timeit(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n, r
+
+    with torch.no_grad():
+        dt, lg = timeit(lambda: mil(bags, coords=None, mask=None), 5)
+    sec.update({"metric": "MIL bags/s (vit head forward, bags of 1024 x 1024-d fp16, batch 64, no mask)", "value": round(64 / dt, 1), "unit": "bags/s",
+                "gflop_per_bag_fwd": 11.83, "finite": bool(torch.isfinite(lg).all())})
+    tg = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
+    cw = torch.tensor([0.5, 0.5])
+    for key, alibi, drop in (("train", False, None), ("train_no_dropout", False, False), ("train_alibi", True, None)):
+        model = mil if not alibi else HipMil(dropout=0.25, use_alibi=True, **kw).eval()
+        crd = (torch.rand(64, 1024, 2, generator=torch.Generator().manual_seed(2)) * 4e4).to(ctx.device) if alibi else None
+        trn = HipMilVitTrainer(model, device=ctx.device, total_steps=100, dropout=drop)
+        dt, (ltr, _) = timeit(lambda: trn.step(bags, tg, cw, coords=crd), 4)
+        sec[key] = {"metric": f"MIL bags/s (vit head{' with ALiBi' if alibi else ''}, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands, "
+                              + ("all dropout sites off)" if drop is False else "train-mode dropout as the reference: 0.25 / 0.25 / 0.5 / 0.5)"),
+                    "value": round(64 / dt, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltr))}
+        del trn
+    tm = HipTransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().to(ctx.device)
+    bags_f = bags.float()
+    with torch.no_grad():
+        dt, lg2 = timeit(lambda: tm(bags_f), 3, warm=1)
+    sec["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 64, exact-fp32 MFMA)", "value": round(64 / dt, 1),
+                       "finite": bool(torch.isfinite(lg2).all())}
+    del bags_f
+    if not is_swin:     # the reference's in-tree tile encoder, same tile shape (SURVEY.md 8a row H8)
+        scfg = SWIN_PRESETS["ctranspath"]
+        sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)
+        st_tiles = tiles[:1024] if tiles.shape[0] >= 1024 else tiles
+        dt, sf = timeit(lambda: sw(st_tiles), 3, warm=1)
+        sec["ctranspath"] = {"metric": "tiles/sec encoded (224x224, CTransPath = ConvStem + Swin-T)", "value": round(st_tiles.shape[0] / dt, 1),
+                             "unit": "tiles/s", "gflop_per_tile": round(scfg.matmul_flops_per_tile() / 1e9, 3), "finite": bool(torch.isfinite(sf.float()).all())}
+    return sec
 
 
 def main() -> None:
     a = parse()
-    from stamp_amd import _lib, distributed as D, ops
+    from stamp_amd import _lib, distributed as D
+    from stamp_amd.swin import SWIN_PRESETS, HipSwin, random_swin_state_dict
     from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
 
     ctx = D.init_from_env()
@@ -81,7 +296,6 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if a.gpus != ctx.world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
-    from stamp_amd.swin import SWIN_PRESETS, HipSwin, random_swin_state_dict
     act = torch.float16 if a.act == "f16" else torch.bfloat16
     is_swin = a.model in SWIN_PRESETS
     if is_swin:       # the reference's in-tree tile encoder (ctranspath.py): ConvStem + Swin-T
@@ -105,10 +319,11 @@ def main() -> None:
         return feats
 
     lib = _lib.lib()
+    actx = _lib.ctx(ctx.device.index or 0)
     for _ in range(a.warmup):
         step()
-    lib.amds_profile_reset()
-    lib.amds_profile_enable(1)
+    lib.amds_profile_reset(actx)
+    lib.amds_profile_enable(actx, 1)
     D.barrier(ctx)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -117,7 +332,7 @@ def main() -> None:
     torch.cuda.synchronize()
     D.barrier(ctx)
     elapsed = time.perf_counter() - t0
-    lib.amds_profile_enable(0)
+    lib.amds_profile_enable(actx, 0)
     elapsed = D.max_over_ranks(ctx, elapsed)
     assert torch.isfinite(out.float()).all()
 
@@ -125,21 +340,22 @@ def main() -> None:
     ms, n, work = C.c_double(), C.c_long(), C.c_double()
     kinds = {}
     for kind, name in ((0, "gemm"), (1, "attention"), (2, "layernorm"), (3, "im2col_or_stem")):
-        _lib.check(lib.amds_profile_read(kind, C.byref(ms), C.byref(n), C.byref(work)), "profile_read")
+        _lib.check(lib.amds_profile_read(actx, kind, C.byref(ms), C.byref(n), C.byref(work)), "profile_read")
         kinds[name] = (ms.value, n.value, work.value)
     gms, gn, gflop = kinds["gemm"]
     achieved = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
     total_tiles = a.tiles * a.steps * ctx.world
     value = total_tiles / elapsed
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary of the
-    # two rocprofv3 --pmc passes over this same workload (profiles/r01_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
-    traffic = None
-    pmc_file = ROOT / "profiles" / "r01_pmc_gemm_traffic.json"
-    if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 1020 and pmc_file.is_file():
-        try:
-            traffic = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    # two rocprofv3 --pmc passes over this same workload (profiles/*_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
+    traffic, pmc_name = None, None
+    for pmc_file in (ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
+        if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 1020 and pmc_file.is_file():
+            try:
+                traffic, pmc_name = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"], pmc_file.name
+                break
+            except Exception:
+                traffic = None
     line = {
         "metric": "tiles/sec encoded (224x224, ViT-L/14)" if a.model == "vit_large_patch14_224" else f"tiles/sec encoded (224x224, {a.model})", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -159,99 +375,36 @@ def main() -> None:
                                "gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_traffic.json); algorithmic 2.97e9 at this chunk (1020 tiles, M = 262140) -> 1.43x (A panels re-fetched across N tiles, served by L2/MALL)" if traffic else None,
+                     "traffic_note": (f"HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/{pmc_name}); "
+                                      "algorithmic 2.97e9 at this chunk (1020 tiles, M = 262140)") if traffic else None,
                      "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),
                      "avg_gflop_per_launch": round(gflop / max(gn, 1) / 1e9, 2),
                      "time_share": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kinds.items()}},
     }
-    # secondary metric of BASELINE.json: MIL bags/s (vit head, deploy-time forward, bags of 1024 x 1024-d, batch 64).
-    # Single-GPU line only: these blocks contain rank collectives (max_over_ranks) inside a try/except, and a rank that raised
-    # while the others wait in a collective would hang the N-GPU scaling run, whose purpose is the headline value.
-    try:
-        if ctx.world > 1 or a.no_secondary:
-            raise RuntimeError("secondary metrics are reported on the single-GPU line" if ctx.world > 1 else "--no-secondary")
-        from stamp_amd.mil import VisionTransformer as HipMil
-        torch.manual_seed(1)
-        mil = HipMil(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512,
-                     dropout=0.0, use_alibi=False).eval()
-        bags = torch.randn(64, 1024, 1024, generator=torch.Generator().manual_seed(1)).half().to(ctx.device)
-        with torch.no_grad():
-            for _ in range(2):
-                mil(bags, coords=None, mask=None)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                lg = mil(bags, coords=None, mask=None)
-            torch.cuda.synchronize()
-        dt_mil = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 5)
-        line["secondary"] = {"metric": "MIL bags/s (vit head forward, bags of 1024 x 1024-d fp16, batch 64, no mask)",
-                             "value": round(64 * ctx.world / dt_mil, 1), "unit": "bags/s", "gflop_per_bag_fwd": 11.83,
-                             "finite": bool(torch.isfinite(lg).all())}
-        # training step (fwd + bwd + AdamW) of the same head, batch 64 (reference default, modeling/config.py:153)
-        from stamp_amd.mil_train import HipMilVitTrainer
-        trn = HipMilVitTrainer(mil, device=ctx.device, total_steps=100)
-        tg = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
-        cw = torch.tensor([0.5, 0.5])
-        for _ in range(2):
-            trn.step(bags, tg, cw)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(4):
-            ltr, _ = trn.step(bags, tg, cw)
-        torch.cuda.synchronize()
-        dt_tr = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 4)
-        line["secondary"]["train"] = {"metric": "MIL bags/s (vit head, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands)",
-                                      "value": round(64 * ctx.world / dt_tr, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltr))}
-        del trn
-        # the same head with use_alibi=True (MultiHeadALiBi: post-softmax distance bias, train-mode running-mean scalers)
-        mil_a = HipMil(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.0, use_alibi=True).eval()
-        crd = (torch.rand(64, 1024, 2, generator=torch.Generator().manual_seed(2)) * 4e4).to(ctx.device)
-        trn = HipMilVitTrainer(mil_a, device=ctx.device, total_steps=100)
-        for _ in range(2):
-            trn.step(bags, tg, cw, coords=crd)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(4):
-            lta, _ = trn.step(bags, tg, cw, coords=crd)
-        torch.cuda.synchronize()
-        dt_ta = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 4)
-        line["secondary"]["train_alibi"] = {"metric": "MIL bags/s (vit head with ALiBi, fwd + bwd + AdamW, bags of 1024 x 1024-d + coords, batch 64, bf16 operands)",
-                                            "value": round(64 * ctx.world / dt_ta, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(lta))}
-        del trn, mil_a
-        from stamp_amd.mil import TransMIL as HipTransMIL
-        tm = HipTransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().to(ctx.device)
-        bags_f = bags.float()
-        with torch.no_grad():
-            tm(bags_f)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                lg2 = tm(bags_f)
-            torch.cuda.synchronize()
-        dt_tm = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 3)
-        line["secondary"]["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 64, exact-fp32 MFMA)",
-                                         "value": round(64 * ctx.world / dt_tm, 1), "finite": bool(torch.isfinite(lg2).all())}
-        del bags_f
-        if not is_swin:     # the reference's in-tree tile encoder, same tile shape
-            scfg = SWIN_PRESETS["ctranspath"]
-            sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)
-            st_tiles = tiles[:1024] if tiles.shape[0] >= 1024 else tiles
-            sw(st_tiles)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                sf = sw(st_tiles)
-            torch.cuda.synchronize()
-            dt_sw = D.max_over_ranks(ctx, (time.perf_counter() - t1) / 3)
-            line["secondary"]["ctranspath"] = {"metric": "tiles/sec encoded (224x224, CTransPath = ConvStem + Swin-T)",
-                                               "value": round(st_tiles.shape[0] * ctx.world / dt_sw, 1), "unit": "tiles/s",
-                                               "gflop_per_tile": round(scfg.matmul_flops_per_tile() / 1e9, 3),
-                                               "finite": bool(torch.isfinite(sf.float()).all())}
-            del sw
-    except Exception as e:      # the headline metric must still be printed
-        line.setdefault("secondary", {})["error"] = repr(e)[:200]
+    # Everything below is single-GPU-line only: these blocks are wrapped in try/except, and a rank that raised while the others
+    # wait in a collective would hang the N-GPU scaling run, whose purpose is the headline value.
+    single = ctx.world == 1 and not a.no_secondary
+    if single and a.e2e_tiles > 0:
+        try:
+            line["end_to_end"] = end_to_end_leg(model, cfg, ctx.device, a.e2e_tiles, a.swin_chunk if is_swin else a.chunk, a.e2e_warmup)
+        except Exception as e:
+            line["end_to_end"] = {"error": repr(e)[:300]}
+    if single:
+        try:
+            line["drop_in_b64"] = drop_in_b64_leg(model, cfg, ctx.device)
+        except Exception as e:
+            line["drop_in_b64"] = {"error": repr(e)[:300]}
+        try:
+            line["secondary"] = secondary_metrics(ctx, a, tiles, is_swin)
+        except Exception as e:      # the headline metric must still be printed
+            line["secondary"] = {"error": repr(e)[:300]}
     if ctx.is_main and ctx.world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds, swin=is_swin)
+        if not a.no_secondary:
+            try:
+                line["cpu_baseline"]["mil"] = cpu_baseline_mil()
+            except Exception as e:
+                line["cpu_baseline"]["mil"] = {"error": repr(e)[:300]}
     elif ctx.is_main:
         line["cpu_baseline"] = None
     if ctx.is_main:

@@ -63,14 +63,25 @@ const char* amds_last_error(void);
 /* Fills name (<= n bytes) with the device's gcnArchName; AMDS_ERR_NODEVICE if none. */
 int amds_device_info(int device, char* name_host, int n, int* cu_count_host, size_t* hbm_bytes_host);
 
-/* Live per-kernel timing for bench.py's roofline line: while enabled, every launch made through this
- * library is bracketed by a pair of HIP events recorded on the launch stream.  kind: 0 = MFMA GEMM
+/* Per-device context: owns what would otherwise be hidden process state -- the live profiler and the side stream
+ * + fork/join events of the overlapped tile-encoder schedule.  One context per device and process: amds_create(device) returns the
+ * device's context (creating it on first call, sharing it afterwards); amds_destroy drops one reference and, with the last one,
+ * synchronises the device (the only synchronisation in the library) and frees events / stream.  Thread-safe: state is guarded by a
+ * mutex per context.  The compute entry points stay context-free -- they take every buffer and the stream from the caller and
+ * keep no state.  amds_create returns NULL on error (amds_last_error()). */
+typedef struct amds_ctx amds_ctx;
+amds_ctx* amds_create(int device);
+void amds_destroy(amds_ctx* ctx);
+int amds_ctx_device(const amds_ctx* ctx);
+
+/* Live per-kernel timing for bench.py's roofline line: while enabled on the context of the calling thread's current device, every
+ * launch made through this library is bracketed by a pair of HIP events recorded on the launch stream.  kind: 0 = MFMA GEMM
  * (work = 2*M*N*K flops), 1 = ViT attention (flops), 2 = LayerNorm (bytes), 3 = im2col (bytes),
  * 4 = fp32-MFMA GEMM (flops).  amds_profile_read waits for the recorded events and returns the summed
  * duration, launch count and summed work of one kind since the last reset (at most 32768 launches). */
-int amds_profile_enable(int on);
-int amds_profile_reset(void);
-int amds_profile_read(int kind, double* total_ms_host, long* launches_host, double* total_work_host);
+int amds_profile_enable(amds_ctx* ctx, int on);
+int amds_profile_reset(amds_ctx* ctx);
+int amds_profile_read(amds_ctx* ctx, int kind, double* total_ms_host, long* launches_host, double* total_work_host);
 
 /* ------------------------------------------------------------------------------------------------
  * Building blocks (also used by the MIL heads)
@@ -166,10 +177,11 @@ int amds_attention_alibi(const void* qkv, const float* coords, const float* head
  * tests/test_model.py:28-32).  pad: u8 [B][T], 1 = padded tile, class token included at t = 0 (never padded).
  * blocked(q, k) = (pad[q] & pad[k]) | (q > 0 & k == 0)  -- the outer-product mask of :363-367, restated literally.
  * amds_attention_masked (nn.MultiheadAttention branch): blocked scores are -inf before the softmax; the reference passes
- *   attn_mask.repeat(heads, 1, 1) (:224), so (bag b, head h) uses the pad row of bag (b*H + h) % B -- reproduced.
+ *   attn_mask.repeat(heads, 1, 1) (:224), so (bag b, head h) uses the pad row of bag (b*mask_heads + h) % B -- reproduced;
+ *   mask_heads = the model's real head count (<= H: heads h >= mask_heads are zero padding whose output is zero under any mask).
  * amds_attention_alibi_masked (MultiHeadALiBi branch, :62-70): softmax over all keys, blocked products zeroed afterwards, no
  *   distance term on the class-token row and column (:370-372); out bf16. */
-int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int dtype, void* stream);
+int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int mask_heads, int dtype, void* stream);
 int amds_attention_alibi_masked(const void* qkv, const float* coords, const float* head_scale, const uint8_t* pad, void* out,
                                 int B, int T, int H, int dtype, void* stream);
 
@@ -234,7 +246,7 @@ int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_vit_weights
 /* Same result as amds_vit_forward, with consecutive chunks alternating between `stream` and one library-owned side
  * stream so that two chunks are in flight (ws must hold 2 x amds_vit_workspace_bytes(chunk)); `stream` waits for the
  * side stream before the call's work is considered complete. */
-int amds_vit_forward_overlapped(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
+int amds_vit_forward_overlapped(amds_ctx* ctx, const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
                                 void* feats_f16, int B, int chunk, void* ws, size_t ws_bytes, void* stream);
 
 /* u8 HWC tiles -> im2col patch matrix [B*np][kp] (act dtype, raw 0..255 values, zero padded).

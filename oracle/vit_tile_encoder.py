@@ -29,8 +29,10 @@ def tile_transform(tiles_u8_hwc: torch.Tensor, mean, std) -> torch.Tensor:
     return (x - m) / s
 
 
-def vit_tokens(x_chw: torch.Tensor, sd: dict, cfg) -> torch.Tensor:
-    """timm VisionTransformer.forward_features on normalised float input -> final-LayerNorm'd tokens [B,T,D]."""
+def vit_tokens(x_chw: torch.Tensor, sd: dict, cfg, sdpa: bool = False) -> torch.Tensor:
+    """timm VisionTransformer.forward_features on normalised float input -> final-LayerNorm'd tokens [B,T,D].
+    sdpa=True evaluates the attention through F.scaled_dot_product_attention (what timm's fused_attn path calls; same
+    arithmetic, torch's blocked CPU kernel) -- used by bench.py's cpu_baseline leg; the parity tests use the explicit form."""
     D, p = cfg.dim, cfg.patch
     B = x_chw.shape[0]
     x = F.conv2d(x_chw, sd["patch_embed.proj.weight"].float(), sd["patch_embed.proj.bias"].float(), stride=p)
@@ -50,7 +52,10 @@ def vit_tokens(x_chw: torch.Tensor, sd: dict, cfg) -> torch.Tensor:
         qkv = F.linear(h, g("attn.qkv.weight"), g("attn.qkv.bias"))
         qkv = qkv.reshape(B, -1, 3, H, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
-        att = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1) @ v
+        if sdpa:
+            att = F.scaled_dot_product_attention(q, k, v)
+        else:
+            att = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1) @ v
         att = att.transpose(1, 2).reshape(B, -1, D)
         att = F.linear(att, g("attn.proj.weight"), g("attn.proj.bias"))
         if cfg.layerscale:
@@ -70,10 +75,10 @@ def vit_tokens(x_chw: torch.Tensor, sd: dict, cfg) -> torch.Tensor:
     return F.layer_norm(x, (D,), sd["norm.weight"].float(), sd["norm.bias"].float(), cfg.ln_eps)
 
 
-def extract_features(tiles_u8_hwc: torch.Tensor, sd: dict, cfg, return_tokens: bool = False):
+def extract_features(tiles_u8_hwc: torch.Tensor, sd: dict, cfg, return_tokens: bool = False, sdpa: bool = False):
     """The reference's per-batch step: model(transform(tiles))[:, 0].half()
     (src/stamp/preprocessing/__init__.py:324-325 + virchow2.py:29-30)."""
     with torch.no_grad():
-        toks = vit_tokens(tile_transform(tiles_u8_hwc, cfg.mean, cfg.std), sd, cfg)
+        toks = vit_tokens(tile_transform(tiles_u8_hwc, cfg.mean, cfg.std), sd, cfg, sdpa=sdpa)
     feats = toks[:, 0].half()
     return (feats, toks) if return_tokens else feats

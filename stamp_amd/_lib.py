@@ -68,9 +68,12 @@ PROTOTYPES = {
     "amds_version": (_i, []),
     "amds_last_error": (C.c_char_p, []),
     "amds_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_sz)]),
-    "amds_profile_enable": (_i, [_i]),
-    "amds_profile_reset": (_i, []),
-    "amds_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "amds_create": (_vp, [_i]),
+    "amds_destroy": (None, [_vp]),
+    "amds_ctx_device": (_i, [_vp]),
+    "amds_profile_enable": (_i, [_vp, _i]),
+    "amds_profile_reset": (_i, [_vp]),
+    "amds_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "amds_cast_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "amds_layernorm": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp]),
     "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
@@ -86,7 +89,7 @@ PROTOTYPES = {
     "amds_attention_alibi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_vit_workspace_bytes": (_sz, [C.POINTER(VitCfg), _i]),
     "amds_vit_forward": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "amds_vit_forward_overlapped": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_vit_forward_overlapped": (_i, [_vp, C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_vit_forward_tokens": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_swin_workspace_bytes": (_sz, [C.POINTER(SwinCfg), _i]),
     "amds_swin_forward": (_i, [C.POINTER(SwinCfg), C.POINTER(SwinWeights), _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -124,7 +127,7 @@ PROTOTYPES = {
     "amds_attention_alibi_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_alibi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "amds_cdist_rowsum": (_i, [_vp, _vp, _i, _i, _vp]),
-    "amds_attention_masked": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_masked": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_attention_alibi_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_fwd_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u32, _vp]),
     "amds_attention_bwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u32, _vp]),
@@ -163,6 +166,25 @@ def lib() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     _lib = handle
     return handle
+
+
+_ctx: dict[int, int] = {}
+
+
+def ctx(device: int = 0) -> int:
+    """The library context of a device (amds_create): owns the live profiler and the overlapped schedule's side stream."""
+    if device not in _ctx:
+        h = lib().amds_create(int(device))
+        if not h:
+            raise RuntimeError("libamdstamp amds_create failed: " + lib().amds_last_error().decode("utf-8", "replace"))
+        _ctx[device] = h
+    return _ctx[device]
+
+
+def destroy_contexts() -> None:
+    for h in _ctx.values():
+        lib().amds_destroy(h)
+    _ctx.clear()
 
 
 def check(rc: int, what: str = "") -> None:

@@ -1,6 +1,8 @@
 // api.hip -- error plumbing, device query and the GEMM entry points of libamdstamp.
 #include "gemm_kernel.h"
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 namespace amds {
 
@@ -18,34 +20,60 @@ int hip_fail(hipError_t e, const char* what) {
     return AMDS_ERR_HIP;
 }
 
-// ---- profiler ------------------------------------------------------------------------------------
-bool g_prof_on = false;
+// ---- per-device context: owns the live profiler and the side stream of the overlapped tile-encoder schedule -------------------------
+}  // namespace amds
+struct amds_ctx {
+    int device = -1;
+    int refs = 0;
+    std::mutex mu;
+    bool prof_on = false;
+    amds::ProfRec* recs = nullptr;
+    int nrec = 0, nalloc = 0;
+    long dropped = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+};
+namespace amds {
+std::atomic<int> g_prof_any{0};
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double work; };
-constexpr int PROF_MAX = 1 << 15;
-ProfRec* g_recs = nullptr;
-int g_nrec = 0, g_nalloc = 0;
-long g_dropped = 0;
-bool g_open = false;
-}  // namespace
-void prof_begin(int kind, double work, hipStream_t st) {
-    g_open = false;
-    if (g_nrec >= PROF_MAX) { ++g_dropped; return; }
-    if (!g_recs) g_recs = (ProfRec*)calloc(PROF_MAX, sizeof(ProfRec));
-    if (g_nrec >= g_nalloc) {
-        if (hipEventCreate(&g_recs[g_nrec].a) != hipSuccess || hipEventCreate(&g_recs[g_nrec].b) != hipSuccess) { ++g_dropped; return; }
-        g_nalloc = g_nrec + 1;
-    }
-    g_recs[g_nrec].kind = kind;
-    g_recs[g_nrec].work = work;
-    (void)hipEventRecord(g_recs[g_nrec].a, st);
-    g_open = true;
+constexpr int MAX_DEV = 64, PROF_MAX = 1 << 15;
+amds_ctx* g_ctx[MAX_DEV] = {};
+std::mutex g_tab;
+amds_ctx* current_ctx() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tab);
+    return g_ctx[dev];
 }
-void prof_end(hipStream_t st) {
-    if (!g_open) return;
-    (void)hipEventRecord(g_recs[g_nrec].b, st);
-    ++g_nrec;
-    g_open = false;
+}  // namespace
+// A launch is timed when the context of the CALLING THREAD'S CURRENT DEVICE has its profiler on.  Slots are handed out under the
+// context's mutex, so concurrent host threads cannot corrupt each other's records.
+int prof_begin(int kind, double work, hipStream_t st, amds_ctx** ctx_out) {
+    amds_ctx* c = current_ctx();
+    if (!c) return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->prof_on) return -1;
+    if (c->nrec >= PROF_MAX) { ++c->dropped; return -1; }
+    if (!c->recs) c->recs = (ProfRec*)calloc(PROF_MAX, sizeof(ProfRec));
+    if (!c->recs) return -1;
+    const int slot = c->nrec;
+    if (slot >= c->nalloc) {
+        if (hipEventCreate(&c->recs[slot].a) != hipSuccess || hipEventCreate(&c->recs[slot].b) != hipSuccess) { ++c->dropped; return -1; }
+        c->nalloc = slot + 1;
+    }
+    c->recs[slot].kind = kind;
+    c->recs[slot].work = work;
+    c->recs[slot].closed = false;
+    (void)hipEventRecord(c->recs[slot].a, st);
+    ++c->nrec;
+    *ctx_out = c;
+    return slot;
+}
+void prof_end(amds_ctx* c, int slot, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (slot >= c->nrec) return;          // the profiler was reset in between
+    (void)hipEventRecord(c->recs[slot].b, st);
+    c->recs[slot].closed = true;
 }
 
 // default tile configuration: AMDS_GEMM_CFG overrides (tuning), else by shape
@@ -85,18 +113,86 @@ extern "C" int amds_device_info(int device, char* name_host, int n, int* cu_coun
     return AMDS_OK;
 }
 
-extern "C" int amds_profile_enable(int on) { g_prof_on = on != 0; return AMDS_OK; }
-extern "C" int amds_profile_reset(void) { g_nrec = 0; g_dropped = 0; return AMDS_OK; }
-extern "C" int amds_profile_read(int kind, double* total_ms_host, long* launches_host, double* total_work_host) {
+extern "C" amds_ctx* amds_create(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt || device >= MAX_DEV) {
+        set_error("amds_create: no HIP device %d (count %d)", device, cnt);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_tab);
+    if (!g_ctx[device]) {
+        g_ctx[device] = new amds_ctx();
+        g_ctx[device]->device = device;
+    }
+    ++g_ctx[device]->refs;            // one context per device and process; further calls share it
+    return g_ctx[device];
+}
+
+extern "C" void amds_destroy(amds_ctx* c) {
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_tab);
+        if (--c->refs > 0) return;
+        if (c->device >= 0 && c->device < MAX_DEV && g_ctx[c->device] == c) g_ctx[c->device] = nullptr;
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();          // the only place the library synchronises the device
+    if (c->prof_on) g_prof_any.fetch_sub(1);
+    for (int i = 0; i < c->nalloc; ++i) { (void)hipEventDestroy(c->recs[i].a); (void)hipEventDestroy(c->recs[i].b); }
+    free(c->recs);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete c;
+}
+
+extern "C" int amds_ctx_device(const amds_ctx* c) { return c ? c->device : -1; }
+
+// side stream + fork / join events of the overlapped schedule, created on first use on the context's device
+int amds::ctx_side_stream(amds_ctx* c, hipStream_t* side, hipEvent_t* ev_in, hipEvent_t* ev_out) {
+    AMDS_REQUIRE(c, "null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->side) {
+        int dev = -1;
+        AMDS_HIP(hipGetDevice(&dev));
+        AMDS_REQUIRE(dev == c->device, "the calling thread's current device is %d, the context belongs to device %d", dev, c->device);
+        AMDS_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        AMDS_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        AMDS_HIP(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    }
+    *side = c->side; *ev_in = c->ev_in; *ev_out = c->ev_out;
+    return AMDS_OK;
+}
+
+extern "C" int amds_profile_enable(amds_ctx* c, int on) {
+    AMDS_REQUIRE(c, "amds_profile_enable: null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const bool want = on != 0;
+    if (want != c->prof_on) g_prof_any.fetch_add(want ? 1 : -1);
+    c->prof_on = want;
+    return AMDS_OK;
+}
+extern "C" int amds_profile_reset(amds_ctx* c) {
+    AMDS_REQUIRE(c, "amds_profile_reset: null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->nrec = 0; c->dropped = 0;
+    return AMDS_OK;
+}
+extern "C" int amds_profile_read(amds_ctx* c, int kind, double* total_ms_host, long* launches_host, double* total_work_host) {
+    AMDS_REQUIRE(c, "amds_profile_read: null context");
     AMDS_REQUIRE(kind >= 0 && kind < PROF_NKINDS, "amds_profile_read: bad kind %d", kind);
+    std::lock_guard<std::mutex> lk(c->mu);
     double ms = 0, work = 0;
     long n = 0;
-    for (int i = 0; i < g_nrec; ++i) {
-        if (g_recs[i].kind != kind) continue;
-        AMDS_HIP(hipEventSynchronize(g_recs[i].b));
+    for (int i = 0; i < c->nrec; ++i) {
+        if (c->recs[i].kind != kind || !c->recs[i].closed) continue;
+        AMDS_HIP(hipEventSynchronize(c->recs[i].b));
         float t = 0.f;
-        AMDS_HIP(hipEventElapsedTime(&t, g_recs[i].a, g_recs[i].b));
-        ms += t; work += g_recs[i].work; ++n;
+        AMDS_HIP(hipEventElapsedTime(&t, c->recs[i].a, c->recs[i].b));
+        ms += t; work += c->recs[i].work; ++n;
     }
     if (total_ms_host) *total_ms_host = ms;
     if (launches_host) *launches_host = n;

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                                                             float* __restrict__ lse_out, const float* __restrict__ out_scale = nullptr,
                                                             TO* __restrict__ u_out = nullptr, TO* __restrict__ osm_out = nullptr,
                                                             const uint8_t* __restrict__ pad = nullptr, uint64_t seed = 0, uint32_t drop_stream = 0,
-                                                            uint32_t thr16 = 0, float keep_scale = 1.f) {
+                                                            uint32_t thr16 = 0, float keep_scale = 1.f, int mask_heads = 0) {
     typedef typename Act<T>::vec8 vec8;
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE + (MASK ? 2 * FA_KT : 0)];
 
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     float cxreg = 0.f, cyreg = 0.f;
     uint8_t mreg = 0;
     const uint8_t* prow = nullptr;
-    if constexpr (MASK) prow = pad + (long)(ALIBI ? b : (int)(((long)b * H + h) % gridDim.z)) * Tn;
+    if constexpr (MASK) prow = pad + (long)(ALIBI ? b : (int)(((long)b * mask_heads + min(h, mask_heads - 1)) % gridDim.z)) * Tn;
     const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
     const int k_key[2] = {tid >> 3, (tid >> 3) + 32};
     const int k_ch = tid & 7;
@@ -355,15 +355,15 @@ extern "C" int amds_attention_alibi_fwd_train(const void* qkv, const float* coor
 
 // `mask != None` forward of the reference (vision_tranformer.py:355-381; pinned by the reference's tests/test_model.py:28-32): pad u8 [B][T]
 // with the class token included at t = 0 (never padded).  See the kernel comment for the literal blocking rule.
-extern "C" int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int dtype, void* stream) {
+extern "C" int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int mask_heads, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && out && pad, "amds_attention_masked: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_masked: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && mask_heads > 0 && mask_heads <= H, "amds_attention_masked: bad shape B=%d T=%d H=%d mask_heads=%d", B, T, H, mask_heads);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
     ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
-    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false, f16, true>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f);
-    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false, bf16, true>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((attn_flash_kernel<f16, false, f16, true>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f, mask_heads);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false, bf16, true>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pad, 0, 0, 0, 1.f, mask_heads);
     else { set_error("amds_attention_masked: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel<mask>");
     return AMDS_OK;

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
 #include "../../include/amdstamp.h"
 
 namespace amds {
@@ -192,15 +193,20 @@ __device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wa
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-// ---- live per-kernel timing (HIP events on the launch stream; off unless amds_profile_enable(1)) ----
+// ---- live per-kernel timing (HIP events on the launch stream; off unless amds_profile_enable(ctx, 1)) ----
+}  // namespace amds
+struct amds_ctx;
+namespace amds {
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_GEMM_F32 = 4, PROF_NKINDS = 5 };
-extern bool g_prof_on;
-void prof_begin(int kind, double work, hipStream_t st);
-void prof_end(hipStream_t st);
+struct ProfRec { hipEvent_t a, b; int kind; double work; bool closed; };
+extern std::atomic<int> g_prof_any;            // number of contexts whose profiler is on (fast path: one relaxed load per launch)
+int prof_begin(int kind, double work, hipStream_t st, amds_ctx** ctx_out);
+void prof_end(amds_ctx* ctx, int slot, hipStream_t st);
+int ctx_side_stream(amds_ctx* c, hipStream_t* side, hipEvent_t* ev_in, hipEvent_t* ev_out);
 struct ProfScope {
-    hipStream_t st; bool on;
-    ProfScope(int kind, double work, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(kind, work, s); }
-    ~ProfScope() { if (on) prof_end(st); }
+    hipStream_t st; amds_ctx* ctx = nullptr; int slot = -1;
+    ProfScope(int kind, double work, hipStream_t s) : st(s) { if (g_prof_any.load(std::memory_order_relaxed) > 0) slot = prof_begin(kind, work, s, &ctx); }
+    ~ProfScope() { if (slot >= 0) prof_end(ctx, slot, st); }
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

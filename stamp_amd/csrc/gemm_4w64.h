@@ -1,5 +1,5 @@
-// gemm_4w64.h -- 256 x 256 block tile, FOUR waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs) like gemm_4w.h,
-// but with the copy path of gemm_8p64.h: K tiles of 64 as 128-byte LDS rows (8 full lines per LDS-DMA instruction instead
+// gemm_4w64.h -- 256 x 256 block tile, FOUR waves (one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs)
+// with the copy path of gemm_8p64.h: K tiles of 64 as 128-byte LDS rows (8 full lines per LDS-DMA instruction instead
 // of 16 half lines) in TWO 64 KB stages, one barrier per K tile.
 //
 // This is the structure the vendor library picks for the tile-encoder shapes (profiles/r01_gemm_vendor_and_power.txt:
@@ -19,7 +19,7 @@
 
 namespace amds {
 
-// ABL: ablation bits (results WRONG when non-zero; only reachable through amds_gemm_ablate): 1 = no LDS-DMA after the first
+// ABL: ablation bits (results WRONG when non-zero; tuning instantiations only; the library instantiates ABL = 0): 1 = no LDS-DMA after the first
 // two K tiles, 4 = no fragment ds_reads after the first, 8 = no barriers
 // P3 / P0: LDS-DMA pieces of the next K tile requested in k-step 3 of the previous tile / k-step 0 (the rest in k-step 1)
 // AUXA / AUXW: cache-policy bits of the LDS-DMA loads of the A / W tiles (0 = default, 1 = sc0, 2 = nt, 3 = sc0 nt); measured at the

@@ -1,11 +1,18 @@
-// gemm_8p64.h -- variant of gemm_8p.h with 128-byte LDS rows: K tiles of 64 in a 2-deep ring of 64 KB stages.
+// gemm_8p64.h -- 256 x 256 x 64 block tile, EIGHT waves (2 x 4; wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16 fragments, fp32
+// accumulators) in two staggered groups: kernel id 8.  Dispatched for the PATCH epilogue (the patch-embedding GEMM) and as the
+// A/B baseline of the four-wave kernels (gemm_4w16.h = production, gemm_4w64.h).
 //
-// Why: tools/ubench/copy_bench.hip measures the global->LDS copy path with L2-resident panels at 15.5 TB/s for the
-// 64-byte row shape of gemm_8p.h (16 half lines per wave instruction) and 23.6 TB/s for 128-byte rows (8 full
-// lines per instruction) -- and the copy path, not the MFMA pipe, bounds the BK=32 kernel (ablation: copies alone
-// 415 us vs MFMA+barriers 394 us on the fc2 shape).  Same staggered two-group structure; a K tile now spans two
-// phases (k-steps {0,1} and {2,3}); all 8 copy pieces of tile kt+1 are issued in the first phase of tile kt and
-// must have landed (vmcnt(0): nothing else is in flight) before the barrier that ends tile kt.
+// Staggered two-group pipeline: waves w and w+4 share a SIMD.  The K loop is cut into phases `LOAD | s_barrier | COMPUTE |
+// s_barrier` (LOAD = fragment ds_read_b128 + LDS-DMA requests, COMPUTE = 16 MFMAs); group 1 runs one barrier behind group 0, so
+// every SIMD always has one wave computing while its partner loads.  W is the MFMA "A" operand and the activation the "B"
+// operand: a lane then holds one output row and 4 consecutive columns per register group (C-transposed fragments), so bias /
+// LayerScale are float4 loads and stores are 8-16 B per lane.  LDS rows are 128 bytes (K tile of 64) in a 2-deep ring of 64 KB
+// stages; 16-B chunks are XOR-swizzled on the SOURCE address of the LDS-DMA (it writes lane-linearly) and again on the read
+// (SQ_LDS_BANK_CONFLICT = 0 measured).  tools/ubench/copy_bench.hip: the global->LDS path moves 23.6 TB/s with 128-byte rows
+// (8 full lines per wave instruction) against 15.5 TB/s with 64-byte rows, and the copy path, not the MFMA pipe, bounded the
+// BK = 32 predecessor of this kernel.  A K tile spans two phases (k-steps {0,1} and {2,3}); all 8 copy pieces of tile kt+1 are
+// issued in the first phase of tile kt and must have landed (vmcnt(0): nothing else is in flight) before the barrier that ends
+// tile kt.
 //   RAW  tile kt+1 is first read in the slot after every wave executed vmcnt(0) + the closing barrier of tile kt.
 //   WAR  stage (kt+1)&1 held tile kt-1, whose last reads were retired (lgkmcnt(0)) before the barrier closing tile
 //        kt-1; the copies are issued after that barrier.

@@ -36,9 +36,6 @@ struct EpiArgs {
     // batched / split-K launches (gridDim.y = batch count): element strides added per batch index
     long bsA = 0, bsW = 0, bsOut = 0;
     int nbatch = 1;
-    // gemm_pp.h: per-CU arrival tickets and the start offset (10-ns ticks) of the second workgroup of a CU
-    int* pp_slots = nullptr;
-    int pp_delay = 0;
 };
 
 template <int EPI>
@@ -406,33 +403,22 @@ template <typename T, int EPI>
 static int launch_gemm_8p64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_8p64.h
 template <typename T, int EPI>
-static int launch_gemm_4w(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
-                          hipStream_t st);   // gemm_4w.h
-template <typename T, int EPI>
 static int launch_gemm_4w64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w64.h
 template <typename T, int EPI, bool SPREAD, int P3, int P0>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w16.h
-template <typename T, int EPI>
-static int launch_gemm_pp(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
-                          hipStream_t st);   // gemm_pp.h
-template <typename T, int EPI, int VARIANT>
-static int launch_gemm_8p(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
-                          hipStream_t st);   // gemm_8p.h
 
 // kernel ids (amds_gemm_ex): 0 = 128x128 tile, one barrier per K step (small problems, any N % 128 == 0)
 //   1 = 128x96 tile, four waves stacked along M (N % 96 == 0: the Swin widths 96/192/288/576 that 128 does not divide)
-//   8 = 256x256x64 eight-wave staggered two-group pipeline (gemm_8p64.h, PRODUCTION for bias + GELU; N % 256 == 0, else 0)
-//  10 = 256x256x64 four waves, 128x128 wave tiles, AGPR accumulators (gemm_4w64.h, PRODUCTION for the other epilogues)
-//   3 / 7 = their BK = 32 (64-byte LDS row) predecessors (gemm_8p.h, gemm_4w.h)      9 = ping-pong experiment (gemm_pp.h)
+//  12 = 256x256x64 four waves, 128x128 wave tiles on v_mfma 16x16x32, AGPR accumulators (gemm_4w16.h): PRODUCTION for every
+//       epilogue but PATCH whenever N % 256 == 0 and the grid fills the chip; 13 = its 8/8 LDS-DMA schedule (A/B)
+//   8 = 256x256x64 eight-wave staggered two-group pipeline (gemm_8p64.h): the PATCH epilogue, batched fallback
+//  10 = the four-wave structure on v_mfma 32x32x16 (gemm_4w64.h): the one A/B sibling kept
+// (the BK = 32 predecessors 3 / 7 and the ping-pong experiment 9 of round 1 were removed; their measurements stay in profiles/r01_*)
 template <typename T, int EPI>
 static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                        const EpiArgs& ep, hipStream_t st) {
-    if constexpr (EPI != AMDS_EPI_SWIGLU) {
-        if (cfg == 9 && N % 128 == 0 && K >= 64 && ep.nbatch == 1) return launch_gemm_pp<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
-    }
-    if (cfg == 9) cfg = 8;
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
     if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6>(A, lda, W, ldw, M, N, K, ep, st);
@@ -441,12 +427,6 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
 
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 8) cfg = 0;
-    if (cfg == 7 && N % 256 == 0 && K >= 128) return launch_gemm_4w<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
-    if (cfg == 7) cfg = 0;
-    if (cfg == 3) {   // BK = 32 four-stage variant of the staggered kernel (kept for A/B and for the ablation tools)
-        if (N % 256 == 0 && K >= 128) return launch_gemm_8p<T, EPI, 0>(A, lda, W, ldw, M, N, K, ep, st);
-        cfg = 0;
-    }
     if (cfg == 0 && N % 128 != 0) cfg = 1;
     switch (cfg) {
         case 0: return launch_gemm_cfg<T, 128, 128, 2, 2, EPI>(A, lda, W, ldw, M, N, K, ep, st);

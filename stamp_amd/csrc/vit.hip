@@ -132,10 +132,10 @@ extern "C" int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_
 
 // Two chunks in flight on two streams: the HBM-bound kernels of one chunk (LayerNorm, attention staging, epilogue
 // tails) run in the shadow of the other chunk's MFMA-bound GEMMs.  `ws` must hold 2 x amds_vit_workspace_bytes(chunk).
-// The side stream and its two events are created once per process (the only hidden state of the library).
-extern "C" int amds_vit_forward_overlapped(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
+// The side stream and its fork / join events belong to the context (created on first use on the context's device).
+extern "C" int amds_vit_forward_overlapped(amds_ctx* ctx, const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
                                            void* feats_f16, int B, int chunk, void* ws, size_t ws_bytes, void* stream) {
-    AMDS_REQUIRE(cfg_host && w_host && tiles && feats_f16 && ws, "amds_vit_forward_overlapped: null pointer");
+    AMDS_REQUIRE(ctx && cfg_host && w_host && tiles && feats_f16 && ws, "amds_vit_forward_overlapped: null pointer");
     AMDS_REQUIRE(B >= 0 && chunk > 0, "amds_vit_forward_overlapped: bad B=%d chunk=%d", B, chunk);
     VitPlan pl;
     int rc = make_plan(cfg_host, chunk, &pl);
@@ -144,27 +144,27 @@ extern "C" int amds_vit_forward_overlapped(const amds_vit_cfg* cfg_host, const a
         set_error("amds_vit_forward_overlapped: workspace %zu < required %zu bytes", ws_bytes, 2 * pl.total);
         return AMDS_ERR_WORKSPACE;
     }
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    if (!side) {
-        AMDS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        AMDS_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-        AMDS_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
-    }
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    rc = ctx_side_stream(ctx, &side, &ev_in, &ev_out);
+    if (rc != AMDS_OK) return rc;
     hipStream_t mainst = (hipStream_t)stream;
     AMDS_HIP(hipEventRecord(ev_in, mainst));
     AMDS_HIP(hipStreamWaitEvent(side, ev_in, 0));
     const size_t tile_bytes = (size_t)cfg_host->img * cfg_host->img * 3;
     int idx = 0;
-    for (int b0 = 0; b0 < B; b0 += chunk, ++idx) {
+    for (int b0 = 0; b0 < B && rc == AMDS_OK; b0 += chunk, ++idx) {
         const int bc = (B - b0 < chunk) ? B - b0 : chunk;
         rc = vit_chunk(cfg_host, w_host, pl, tiles + (size_t)b0 * tile_bytes,
                        reinterpret_cast<char*>(feats_f16) + (size_t)b0 * cfg_host->dim * 2, nullptr, bc,
                        reinterpret_cast<char*>(ws) + (idx & 1) * pl.total, (idx & 1) ? side : mainst);
-        if (rc != AMDS_OK) return rc;
     }
-    AMDS_HIP(hipEventRecord(ev_out, side));
-    AMDS_HIP(hipStreamWaitEvent(mainst, ev_out, 0));
+    // join the side stream back into the caller's stream on EVERY path: after an error nothing may still be running on it unordered
+    const hipError_t e1 = hipEventRecord(ev_out, side);
+    const hipError_t e2 = hipStreamWaitEvent(mainst, ev_out, 0);
+    if (rc != AMDS_OK) return rc;
+    if (e1 != hipSuccess) return hip_fail(e1, "hipEventRecord(join)");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamWaitEvent(join)");
     return AMDS_OK;
 }
 

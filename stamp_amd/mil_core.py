@@ -8,11 +8,11 @@ torch.autograd.Function) and `stamp_amd.mil_train.HipMilVitTrainer` (flat fp32 m
 Reference: src/stamp/modeling/models/vision_tranformer.py -- VisionTransformer.forward :331-384, Transformer.forward :281-295,
 SelfAttention :172-242, feed_forward :157-169, MultiHeadALiBi / _ALiBi / _RunningMeanScaler :15-154.
 
-Shapes.  The kernels want GEMM dimensions in multiples of 128 and attention heads of 64 channels.  Models that do not have them
+Shapes.  The kernels want GEMM dimensions in multiples of 256 (the split-K weight-gradient GEMMs) and attention heads of 64 channels.  Models that do not have them
 (the reference's own tests use dim_input 456, dim_model 4 x 33, dim_feedforward 135; tests/test_model.py:9-32) are run on a
-ZERO-PADDED copy of the weights: input / model / feed-forward widths padded to multiples of 128, every head padded from
-head_dim to 64 channels with `sqrt(64 / head_dim)` folded into the query rows (the kernels scale scores by 1/8), an all-zero head
-appended when the head count is odd.  Padding channels stay exactly zero through the whole network (zero weights and biases;
+ZERO-PADDED copy of the weights: input / model / feed-forward widths padded to multiples of 256, every head padded from
+head_dim to 64 channels with `sqrt(64 / head_dim)` folded into the query rows (the kernels scale scores by 1/8), all-zero heads
+appended up to a multiple of 4 heads.  Padding channels stay exactly zero through the whole network (zero weights and biases;
 LayerNorm is evaluated over the true `dim_model` columns only), so the padded model computes the same function; gradients are
 sliced back to the reference shapes.  Restrictions that remain: head_dim <= 64 and dim_model % 4 == 0 (LayerNorm kernels read
 float4).  When nothing needs padding (the defaults: 512 / 8 heads / 512) the packed tensors are plain views / casts.
@@ -60,19 +60,19 @@ class VitDims:
 
     @property
     def Fp(self) -> int:
-        return _up(self.F, 128)
+        return _up(self.F, 256)
 
     @property
     def Dp(self) -> int:
-        return _up(self.D, 128)
+        return _up(self.D, 256)
 
     @property
     def FFp(self) -> int:
-        return _up(self.FF, 128)
+        return _up(self.FF, 256)
 
     @property
     def Ha(self) -> int:
-        return self.H + (self.H & 1)
+        return _up(self.H, 4)
 
     @property
     def Da(self) -> int:
@@ -263,12 +263,9 @@ def forward_infer(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None
                                                            d.Ha, ops.act_code(act), st), "attention_alibi_masked")
         elif pad is None:
             att = ops.attention(qkv, Bb, S, d.Ha)
-        else:
-            if d.Ha != d.H:
-                raise NotImplementedError("mask with an odd head count: the reference's head-repeated mask indexing (b*H + h) % B "
-                                          "changes with the padded head")
+        else:       # d.H: the reference's head-repeated mask indexing (b*H + h) % B counts REAL heads; padded heads output zeros anyway
             att = torch.empty(M, d.Da, dtype=act, device=dev)
-            _lib.check(lib.amds_attention_masked(qkv.data_ptr(), pad.data_ptr(), att.data_ptr(), Bb, S, d.Ha, ops.act_code(act), st), "attention_masked")
+            _lib.check(lib.amds_attention_masked(qkv.data_ptr(), pad.data_ptr(), att.data_ptr(), Bb, S, d.Ha, d.H, ops.act_code(act), st), "attention_masked")
         ops.gemm(att, Lw["out_w"], _lib.EPI_RESIDUAL, bias=Lm["out_b"], out=x)                       # x = attn(x) + x   (:291-292)
         h = _ln(x, M, d.D, d.Dp, *Lm["ln2"], act, d.Dp, hbuf)
         u = ops.gemm(h, Lw["fc1_w"], _lib.EPI_BIAS_GELU, bias=Lm["fc1_b"])

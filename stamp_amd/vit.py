@@ -246,7 +246,7 @@ class HipViT(nn.Module):
             need = 2 * _lib.lib().amds_vit_workspace_bytes(C.byref(self._cfg_c), chunk)
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
-            rc = _lib.lib().amds_vit_forward_overlapped(C.byref(self._cfg_c), C.byref(self._w_c), tiles.data_ptr(), feats.data_ptr(),
+            rc = _lib.lib().amds_vit_forward_overlapped(_lib.ctx(tiles.device.index or 0), C.byref(self._cfg_c), C.byref(self._w_c), tiles.data_ptr(), feats.data_ptr(),
                                                         B, chunk, self._ws.data_ptr(), self._ws.numel(),
                                                         torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "vit_forward_overlapped")

@@ -73,7 +73,7 @@ def test_padding_is_a_no_op_on_aligned_shapes_and_invertible_on_odd_ones():
     for kw, alibi in ((dict(F=1024, D=512, H=8, FF=512, C=2, L=1), False), (dict(F=456, D=132, H=4, FF=135, C=3, L=1), False),
                       (dict(F=40, D=60, H=3, FF=64, C=2, L=1), True)):
         d = mil_core.VitDims(alibi=alibi, **kw)
-        assert d.Fp % 128 == 0 and d.Dp % 128 == 0 and d.FFp % 128 == 0 and d.Da % 128 == 0 and d.Ha % 2 == 0
+        assert d.Fp % 256 == 0 and d.Dp % 256 == 0 and d.FFp % 256 == 0 and d.Da % 256 == 0 and d.Ha % 4 == 0
         pk = mil_core.PackedVit.__new__(mil_core.PackedVit)
         pk.dims = d
         g = torch.Generator().manual_seed(0)

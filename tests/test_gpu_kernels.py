@@ -34,7 +34,7 @@ def _gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize("cfg", [0, 8, 10, 12])
 @pytest.mark.parametrize("M,N,K", [(257, 384, 128), (1000, 1024, 1024), (64, 128, 64), (513, 256, 640), (2570, 3072, 1024)])
 def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
@@ -54,9 +54,9 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1, 256, 128), (300, 256, 64), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
                                    (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
-@pytest.mark.parametrize("cfg", [3, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize("cfg", [8, 10, 12])
 def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
-    """The pipelined kernels (3 / 8: staggered two-group 8-wave; 7 / 10: four waves, 128x128 wave tiles; 9: ping-pong):
+    """The pipelined kernels (8: staggered two-group 8-wave; 10 / 12: four waves, 128x128 wave tiles):
     exact-shape sweep incl. the minimum K, ragged M (rows past M are out of range of the LDS-DMA buffer descriptor), and a
     race screen -- 6 launches must be bitwise identical and match an fp64 reference."""
     g = torch.Generator().manual_seed(M * 3 + N + K)
@@ -73,7 +73,7 @@ def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 3, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize("cfg", [0, 8, 10, 12])
 def test_gemm_epilogues(gpu, dt, cfg):
     M, N, K = 771, 512, 256
     _g = ops.gemm
@@ -117,7 +117,7 @@ def test_gemm_epilogues(gpu, dt, cfg):
 
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_kernels_bit_identical(gpu, dt):
-    """The 256-wide kernels built on v_mfma 32x32x16 (ids 3, 7, 8, 9, 10) accumulate k in the same order: bit-identical outputs.
+    """The 256-wide kernels built on v_mfma 32x32x16 (ids 8, 10) accumulate k in the same order: bit-identical outputs.
     Id 12 (v_mfma 16x16x32, the library default) sums 32 products per instruction: last-bit differences only, and it is the
     kernel the default dispatch picks for this shape."""
     g = torch.Generator().manual_seed(11)
@@ -127,7 +127,7 @@ def test_gemm_kernels_bit_identical(gpu, dt):
     bias = torch.randn(N, generator=g).to(gpu)
     for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_BIAS_F32):
         ref = ops.gemm(a, w, epi, bias=bias, cfg=8)
-        for cfg in (3, 7, 9, 10):
+        for cfg in (10,):
             assert torch.equal(ops.gemm(a, w, epi, bias=bias, cfg=cfg), ref), (epi, cfg)
         o12 = ops.gemm(a, w, epi, bias=bias, cfg=12)
         ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10          # one unit in the last place at the top of the output range

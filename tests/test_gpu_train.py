@@ -338,6 +338,9 @@ def test_trainer_regression_and_survival_losses(gpu, task):
     assert abs(loss.item() - ref_loss.item()) < 3e-2 * max(1.0, abs(ref_loss.item()))
     for k in ("mlp_head.0.bias", "mlp_head.0.weight", "transformer.norm.weight", "project_features.0.bias"):
         g, r = tr.g(k).cpu().double(), params[k].grad.double()
+        if task == "survival" and k == "mlp_head.0.bias":      # the Cox partial likelihood is invariant to a common shift: true gradient 0
+            assert r.norm() < 1e-6 and g.norm() < 1e-5
+            continue
         assert ((g - r).norm() / (r.norm() + 1e-12)).item() < 6e-2, k
     ls = [tr.step(bags.to(gpu), targets, loss_fn=fn)[0].item() for _ in range(10)]
     assert ls[-1] < ls[0]

@@ -109,3 +109,17 @@ def test_oracle_matches_hf_dinov2_full_size_vit_large():
         got = vit_tokens(x, sd, cfg)
     rel = ((got - ref).norm() / ref.norm()).item()
     assert got.shape == ref.shape == (1, 257, 1024) and rel < 2e-5, rel
+
+
+def test_oracle_sdpa_path_equals_explicit_attention():
+    """bench.py times the oracle with F.scaled_dot_product_attention; it must be the same function as the explicit form the parity
+    tests use."""
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+    from oracle.vit_tile_encoder import extract_features
+
+    cfg = PRESETS["test_tiny_swiglu"]
+    sd = random_vit_state_dict(cfg, seed=2, init="moderate")
+    tiles = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    _, a = extract_features(tiles, sd, cfg, return_tokens=True)
+    _, b = extract_features(tiles, sd, cfg, return_tokens=True, sdpa=True)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
