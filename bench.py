@@ -89,8 +89,8 @@ def cpu_baseline(cfg, sd, seconds: float, swin: bool = False) -> dict:
     g = torch.Generator().manual_seed(1234)
     batch = 64
     tiles = torch.randint(0, 256, (batch, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g)
-    cands = sorted({n for n in (16, 32, 64, 96, 128, hw) if n <= hw}) or [hw]
-    threads = _pick_threads(lambda: run(tiles[:8], sd, cfg), cands)
+    cands = sorted({n for n in (16, 32, 64, 128) if n <= hw}) or [hw]
+    threads = _pick_threads(lambda: run(tiles[:32], sd, cfg), cands)
     run(tiles[:8], sd, cfg)           # warm
     n, t0 = 0, time.perf_counter()
     while True:

@@ -412,6 +412,30 @@ int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w,
 int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
               const float* b3, int B, int H, int W, int C, void* stream);
 
+/* Backward pieces of the TransMIL head (training: the reference differentiates trans_mil.py with autograd inside
+ * LitTileClassifier._step, src/stamp/modeling/models/__init__.py:239-279); fp32 like the forward.  The matrix products of the
+ * backward are amds_bgemm_f32 calls.
+ *   amds_softmax_rows_bwd     dp <- p o (dp - rowsum(p o dp)), in place                              (three softmaxes, :145)
+ *   amds_landmark_mean_bwd    dx[z][j*l+t][c] (+)= scale * dout[z][j][c]                              (landmarks, :114-124)
+ *   amds_dwconv_seq_wgrad     dw[head][k] = sum_{bag,t,c} dout[t][c] * v[t+k-taps/2][c]               (res_conv, :150-151; its data gradient
+ *                             is amds_dwconv_seq with the taps reversed)
+ *   amds_ppeg_wgrad           dcorr[tap][c], tap = r*7+q < 49: sum dy[b,i,j,c] * x[b,i+r-3,j+q-3,c]; tap 49: sum dy.  The 7x7 kernel's
+ *                             gradient is taps 0..48, the 5x5 / 3x3 ones its central 25 / 9 taps, every bias tap 49 (:274-283; the data
+ *                             gradient is amds_ppeg with flipped kernels and zero biases)
+ *   amds_relu_bwd             dz = h > 0 ? dh : 0                                                       (_fc1, :290)
+ *   amds_pinv_init_bwd        dx += d/dx of z0 = x^T / (max row-abs-sum * max col-abs-sum), INCLUDING the path through the two global
+ *                             maxima (autograd differentiates them too, :26-28) */
+int amds_softmax_rows_bwd(const float* p, float* dp, long rows, int cols, void* stream);
+int amds_landmark_mean_bwd(const float* dout, float* dx, long sxo, long sxi, int ld, int outer, int inner, int m, int l, int d,
+                           float scale, int accumulate, void* stream);
+int amds_dwconv_seq_wgrad(const float* dout, long soo, long soi, int ldo, const float* v, long svo, long svi, int ldv, float* dw,
+                          int outer, int inner, int n, int d, int taps, void* stream);
+size_t amds_ppeg_wgrad_workspace_bytes(int B, int C);
+int amds_ppeg_wgrad(const float* x, const float* dy, float* dcorr, int B, int H, int W, int C, void* ws, size_t ws_bytes, void* stream);
+int amds_relu_bwd(const float* h, const float* dh, float* dz, long n, void* stream);
+size_t amds_pinv_init_bwd_workspace_bytes(int nmat);
+int amds_pinv_init_bwd(const float* x, const float* dz0, float* dx, int nmat, int n, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * MIL training step (reference src/stamp/modeling/models/__init__.py:133-141, 239-279): bf16 MFMA operands,
  * fp32 accumulate / residual / master weights / optimizer state

@@ -337,9 +337,212 @@ __global__ void __launch_bounds__(256) ppeg_kernel(const float* __restrict__ x, 
     }
 }
 
+
+// ---- backward pieces (TransMIL training; reference trans_mil.py differentiated by autograd in LitTileClassifier._step) ---------------
+// ds = p o (dp - rowsum(p o dp)), in place on dp
+__global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int cols) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    if (row >= rows) return;
+    const float* pr = p + row * cols;
+    float* dr = dp + row * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int c = tid; c < cols; c += 256) s += pr[c] * dr[c];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int c = tid; c < cols; c += 256) dr[c] = pr[c] * (dr[c] - s);
+}
+
+// dx[z][j*l + t][c] (+)= scale * dout[z][j][c]   (dx addressed like the forward's x: head slice of a packed qkv-shaped tensor)
+__global__ void landmark_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, long sxo, long sxi, int ld, int inner,
+                                         int m, int l, int d, float scale, int accumulate) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * l * d) return;
+    const int t = idx / d, c = idx - t * d;
+    const float g = scale * dout[((long)z * m + t / l) * d + c];
+    float* q = dx + zo * sxo + zi * sxi + (long)t * ld + c;
+    *q = accumulate ? *q + g : g;
+}
+
+// dw[zi][k] = sum over (zo, t, c) of dout[zo,zi][t][c] * v[zo,zi][t + k - taps/2][c]; one workgroup per (k, zi), fixed-order reduction
+__global__ void __launch_bounds__(256) dwconv_seq_wgrad_kernel(const float* __restrict__ dout, long soo, long soi, int ldo, const float* __restrict__ v,
+                                                               long svo, long svi, int ldv, float* __restrict__ dw, int outer, int n, int d, int taps) {
+    __shared__ float red[256];
+    const int k = blockIdx.x, zi = blockIdx.y;
+    const int pad = taps / 2;
+    const long per = (long)n * d;
+    float s = 0.f;
+    for (int zo = 0; zo < outer; ++zo) {
+        const float* po = dout + zo * soo + zi * soi;
+        const float* pv = v + zo * svo + zi * svi;
+        for (long idx = threadIdx.x; idx < per; idx += 256) {
+            const int t = (int)(idx / d), c = (int)(idx - (long)t * d);
+            const int tt = t + k - pad;
+            if (tt >= 0 && tt < n) s += po[(long)t * ldo + c] * pv[(long)tt * ldv + c];
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dw[(long)zi * taps + k] = red[0];
+}
+
+// PPEG weight gradients: part[chunk][tap][c] = sum over this chunk's bags and the whole grid of dy[b,i,j,c] * x[b,i+r-3,j+q-3,c] for
+// tap = r*7+q < 49; tap 49 = sum dy (the three biases share it).  The 5x5 / 3x3 kernels' gradients are the central taps.
+__global__ void __launch_bounds__(256) ppeg_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                         int B, int Hh, int Ww, int C, int bags_per_chunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x, tap = blockIdx.y, chunk = blockIdx.z;
+    if (c >= C) return;
+    const int r = tap / 7 - 3, q = tap % 7 - 3;
+    const int b0 = chunk * bags_per_chunk, b1 = min(B, b0 + bags_per_chunk);
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const long base = ((long)b * (1 + Hh * Ww)) * C + C + c;        // first grid token
+        for (int i = 0; i < Hh; ++i) {
+            const int ii = i + r;
+            if (tap < 49 && (ii < 0 || ii >= Hh)) continue;
+            for (int j = 0; j < Ww; ++j) {
+                const float g = dy[base + (long)(i * Ww + j) * C];
+                if (tap == 49) { s += g; continue; }
+                const int jj = j + q;
+                if (jj >= 0 && jj < Ww) s += g * x[base + (long)(ii * Ww + jj) * C];
+            }
+        }
+    }
+    part[((long)chunk * 50 + tap) * C + c] = s;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dh, float* __restrict__ dz, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dz[i] = h[i] > 0.f ? dh[i] : 0.f;
+}
+
+// pinv initialisation z0 = x^T / s, s = rmax * cmax (maxima over ALL matrices of the row sums / column sums of |x|): backward.
+// stage 1: per matrix, dot[z] = sum_ij dz0[z][j][i] * x[z][i][j]; and the arg-max of the row sums / column sums, packed as
+// (value bits << 32 | ~index) so that one 64-bit atomicMax gives the first index of the global maximum (deterministic).
+__global__ void __launch_bounds__(256) pinv_init_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dz0, int n,
+                                                                  float* __restrict__ dot, unsigned long long* __restrict__ arg2) {
+    __shared__ float red[256];
+    const long z = blockIdx.x;
+    const float* p = x + z * n * n;
+    const float* g = dz0 + z * n * n;
+    float s = 0.f;
+    unsigned long long best_r = 0, best_c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float rs = 0.f, cs = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float a = p[(long)i * n + j];
+            rs += fabsf(a); cs += fabsf(p[(long)j * n + i]);
+            s += g[(long)j * n + i] * a;
+        }
+        const unsigned idx = (unsigned)(z * n + i);
+        const unsigned long long kr = ((unsigned long long)__float_as_uint(rs) << 32) | (unsigned)(~idx);
+        const unsigned long long kc = ((unsigned long long)__float_as_uint(cs) << 32) | (unsigned)(~idx);
+        best_r = kr > best_r ? kr : best_r;
+        best_c = kc > best_c ? kc : best_c;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dot[z] = red[0];
+    atomicMax(arg2, best_r);
+    atomicMax(arg2 + 1, best_c);
+}
+// stage 2: dx[z][i][j] += dz0[z][j][i] / s  +  ds * (cmax on row i* of matrix z_r*  +  rmax on column j* of matrix z_c*),  ds = -sum(dot) / s^2
+__global__ void pinv_init_bwd_apply_kernel(const float* __restrict__ dz0, float* __restrict__ dx, int n, int nmat, const float* __restrict__ dot_sum,
+                                           const unsigned long long* __restrict__ arg2) {
+    const float rmax = __uint_as_float((unsigned)(arg2[0] >> 32)), cmax = __uint_as_float((unsigned)(arg2[1] >> 32));
+    const unsigned ridx = ~(unsigned)(arg2[0] & 0xFFFFFFFFull), cidx = ~(unsigned)(arg2[1] & 0xFFFFFFFFull);
+    const float s = rmax * cmax;
+    const float ds = -dot_sum[0] / (s * s);
+    const long z = blockIdx.z;
+    const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
+    if (i >= n || j >= n) return;
+    float g = dz0[z * n * n + (long)j * n + i] / s;
+    if ((unsigned)(z * n + i) == ridx) g += ds * cmax;         // d s / d (row sum i*) = cmax, spread over the row (x > 0: softmax output)
+    if ((unsigned)(z * n + j) == cidx) g += ds * rmax;
+    dx[z * n * n + (long)i * n + j] += g;
+}
+
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" int amds_softmax_rows_bwd(const float* p, float* dp, long rows, int cols, void* stream) {
+    AMDS_REQUIRE(p && dp && rows >= 0 && cols > 0 && rows < (1L << 31), "amds_softmax_rows_bwd: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, rows, cols);
+    AMDS_LAUNCH_CHECK("softmax_rows_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_landmark_mean_bwd(const float* dout, float* dx, long sxo, long sxi, int ld, int outer, int inner, int m, int l, int d,
+                                      float scale, int accumulate, void* stream) {
+    AMDS_REQUIRE(dout && dx && outer > 0 && inner > 0 && m > 0 && l > 0 && d > 0, "amds_landmark_mean_bwd: bad arguments");
+    hipLaunchKernelGGL(landmark_mean_bwd_kernel, dim3(cdiv((long)m * l * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, dout, dx, sxo,
+                       sxi, ld, inner, m, l, d, scale, accumulate);
+    AMDS_LAUNCH_CHECK("landmark_mean_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_dwconv_seq_wgrad(const float* dout, long soo, long soi, int ldo, const float* v, long svo, long svi, int ldv, float* dw,
+                                     int outer, int inner, int n, int d, int taps, void* stream) {
+    AMDS_REQUIRE(dout && v && dw && outer > 0 && inner > 0 && n > 0 && d > 0 && taps > 0 && (taps & 1), "amds_dwconv_seq_wgrad: bad arguments");
+    hipLaunchKernelGGL(dwconv_seq_wgrad_kernel, dim3(taps, inner), dim3(256), 0, (hipStream_t)stream, dout, soo, soi, ldo, v, svo, svi, ldv, dw, outer,
+                       n, d, taps);
+    AMDS_LAUNCH_CHECK("dwconv_seq_wgrad_kernel");
+    return AMDS_OK;
+}
+
+extern "C" size_t amds_ppeg_wgrad_workspace_bytes(int B, int C) { return (size_t)cdiv(B, 4) * 50 * C * 4 + amds_colsum_workspace_bytes(cdiv(B, 4), 50 * C); }
+extern "C" int amds_ppeg_wgrad(const float* x, const float* dy, float* dcorr, int B, int Hh, int Ww, int C, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(x && dy && dcorr && ws && B > 0 && Hh > 0 && Ww > 0 && C > 0, "amds_ppeg_wgrad: bad arguments");
+    if (ws_bytes < amds_ppeg_wgrad_workspace_bytes(B, C)) { set_error("amds_ppeg_wgrad: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    const int nchunk = cdiv(B, 4);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(ppeg_wgrad_kernel, dim3(cdiv(C, 256), 50, nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, 4);
+    AMDS_LAUNCH_CHECK("ppeg_wgrad_kernel");
+    char* cws = (char*)(part + (size_t)nchunk * 50 * C);
+    return amds_colsum(part, 50L * C, dcorr, nchunk, 50 * C, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(nchunk, 50 * C), stream);
+}
+
+extern "C" int amds_relu_bwd(const float* h, const float* dh, float* dz, long n, void* stream) {
+    AMDS_REQUIRE(h && dh && dz && n >= 0, "amds_relu_bwd: bad arguments");
+    if (n == 0) return AMDS_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)min((long)8192, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, dh, dz, n);
+    AMDS_LAUNCH_CHECK("relu_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" size_t amds_pinv_init_bwd_workspace_bytes(int nmat) { return 16 + (size_t)nmat * 4 + 16 + amds_colsum_workspace_bytes(nmat, 1) + 64; }
+extern "C" int amds_pinv_init_bwd(const float* x, const float* dz0, float* dx, int nmat, int n, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(x && dz0 && dx && ws && nmat > 0 && nmat <= 65535 && n > 0, "amds_pinv_init_bwd: bad arguments");
+    if (ws_bytes < amds_pinv_init_bwd_workspace_bytes(nmat)) { set_error("amds_pinv_init_bwd: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* arg2 = (unsigned long long*)ws;
+    float* dot = (float*)((char*)ws + 16);
+    float* dot_sum = dot + nmat;
+    char* cws = (char*)(dot_sum + 4);
+    AMDS_HIP(hipMemsetAsync(arg2, 0, 16, st));
+    hipLaunchKernelGGL(pinv_init_bwd_stats_kernel, dim3(nmat), dim3(256), 0, st, x, dz0, n, dot, arg2);
+    AMDS_LAUNCH_CHECK("pinv_init_bwd_stats_kernel");
+    int rc = amds_colsum(dot, 1, dot_sum, nmat, 1, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(nmat, 1), stream);
+    if (rc != AMDS_OK) return rc;
+    hipLaunchKernelGGL(pinv_init_bwd_apply_kernel, dim3(cdiv(n, 16), cdiv(n, 16), nmat), dim3(16, 16), 0, st, dz0, dx, n, nmat, dot_sum, arg2);
+    AMDS_LAUNCH_CHECK("pinv_init_bwd_apply_kernel");
+    return AMDS_OK;
+}
 
 extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                               float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,

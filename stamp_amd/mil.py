@@ -77,6 +77,7 @@ class _Saved:
     """Carrier of the forward's saved activations between the two autograd Functions (a non-tensor input)."""
     saved = None
     pk = None
+    shapes = None
 
 
 def _unwrap_batched(t: torch.Tensor):
@@ -312,7 +313,9 @@ def _bgemm(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer,
 
 
 class TransMIL(nn.Module):
-    """Same constructor and state_dict keys as the reference TransMIL; eval-mode forward on the HIP path (fp32)."""
+    """Same constructor and state_dict keys as the reference TransMIL (trans_mil.py:286-326); fp32 on the HIP path.  Inference forward
+    below; training (forward with saved intermediates + hand-derived backward) in stamp_amd/transmil_core.py, reached through one
+    torch.autograd.Function so that torch optimisers / Lightning drive it like the reference's module."""
 
     def __init__(self, dim_output: int, dim_input: int, dim_hidden: int):
         super().__init__()
@@ -396,16 +399,30 @@ class TransMIL(nn.Module):
         _bgemm(merged.data_ptr() + pad * Cd * e4, Cd, np_ * Cd, 0, wo.data_ptr(), Cd, 0, 0, True, x_res.data_ptr(), Cd, n * Cd, 0, b, 1, n, Cd, Cd,
                bias=bo.data_ptr(), accumulate=True)
 
+    def _get(self, dev):
+        tensors = dict(self.named_parameters())
+        return lambda n: tensors[n].detach().to(dev, torch.float32).contiguous()
+
     def forward(self, h: torch.Tensor, **kwargs) -> torch.Tensor:
+        """``forward(bags, coords=..., mask=...)`` like the reference (:299-303: coords and mask are accepted and ignored).
+        eval + no_grad: the inference path below.  Gradient needed or ``.train()``: the training kernels (transmil_core.py) behind a
+        torch.autograd.Function, with the reference's one dropout site (Dropout(0.1) on `to_out`) live in train mode."""
         import math
 
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training through the HIP TransMIL head is not implemented")
         if not h.is_cuda:
             raise RuntimeError("HIP TransMIL needs bags on the GPU (no CPU fallback)")
         Bb, T, F = h.shape
         if T < 1:
             raise ValueError("empty bag")
+        need_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if self.training or need_grad:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0
+            holder = _Saved()
+            params = [p for _, p in self.named_parameters()]
+            if need_grad:
+                return _TransMilFunction.apply(h, holder, self, self.training, seed, *params)
+            with torch.no_grad():
+                return _TransMilFunction.forward(h, holder, self, self.training, seed, *params)
         Cd = self.dim_hidden
         x = ops.linear_f32(h.reshape(Bb * T, F).float().contiguous(), self._f(self._fc1[0].weight), self._f(self._fc1[0].bias), relu=True)
         x = x.view(Bb, T, Cd)
@@ -428,3 +445,58 @@ class TransMIL(nn.Module):
             self._nystrom(y, layer, x)                                                           # x += attn(norm(x))
         cls = ops.layernorm_rows(x.view(-1), Bb, Cd, n * Cd, self._f(self.norm.weight), self._f(self.norm.bias), 1e-5, torch.float32)
         return ops.linear_f32(cls, self._f(self._fc2.weight), self._f(self._fc2.bias))
+
+
+class _TransMilBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(dlogits, holder, need_params, need_bags, names):
+        from . import transmil_core
+        G, dbags = transmil_core.backward(holder.saved, dlogits, need_params=need_params, need_bags=need_bags)
+        outs = [dbags if need_bags else dlogits.new_zeros(())]
+        outs += [G[n].reshape(holder.shapes[n]).contiguous() for n in names] if need_params else []
+        return tuple(outs)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        pass
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("double backward through the HIP TransMIL head is not implemented")
+
+    @staticmethod
+    def vmap(info, in_dims, dlogits, holder, need_params, need_bags, names):
+        bd = in_dims[0]
+        if bd is None:
+            outs = _TransMilBackward.apply(dlogits, holder, need_params, need_bags, names)
+            return outs, tuple(None for _ in outs)
+        rows = [_TransMilBackward.apply(dlogits.select(bd, i), holder, need_params, need_bags, names) for i in range(info.batch_size)]
+        outs = tuple(torch.stack([r[j] for r in rows]) for j in range(len(rows[0])))
+        return outs, tuple(0 for _ in outs)
+
+
+class _TransMilFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(bags, holder, model, training, seed, *params):
+        from . import transmil_core
+        names = [n for n, _ in model.named_parameters()]
+        P = dict(zip(names, params))
+        dev = bags.device
+        get = lambda n: P[n].detach().to(dev, torch.float32).contiguous()  # noqa: E731
+        logits, saved = transmil_core.forward_train(get, bags.detach(), (bags.shape[-1], model.dim_hidden, model.n_classes), training=training, seed=seed)
+        holder.saved, holder.shapes = saved, {n: tuple(p.shape) for n, p in P.items()}
+        return logits
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.holder, ctx.names = inputs[1], tuple(n for n, _ in inputs[2].named_parameters())
+        ctx.bags_dtype = inputs[0].dtype
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        need_bags = ctx.needs_input_grad[0]
+        need_params = any(ctx.needs_input_grad[5:])
+        outs = _TransMilBackward.apply(dlogits, ctx.holder, need_params, need_bags, ctx.names)
+        dbags = outs[0].to(ctx.bags_dtype) if need_bags else None
+        gp = list(outs[1:]) if need_params else [None] * len(ctx.names)
+        return (dbags, None, None, None, None, *gp)

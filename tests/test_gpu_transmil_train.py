@@ -1,0 +1,96 @@
+"""TransMIL training on the HIP path against autograd through the oracle (oracle/transmil.py, pinned to the reference's goldens):
+loss, logits, every parameter gradient, d/d(bags); the module under torch AdamW; the one dropout site with the kernels' own mask."""
+import pytest
+import torch
+
+from oracle.transmil import transmil_forward
+from stamp_amd import _lib
+from stamp_amd import train_ops as T
+from stamp_amd.mil import TransMIL
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def _setup(Bb, Tn, Fd, Cd, C, seed):
+    torch.manual_seed(seed)
+    model = TransMIL(dim_output=C, dim_input=Fd, dim_hidden=Cd)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    bags = torch.randn(Bb, Tn, Fd).half().float()
+    targets = torch.nn.functional.one_hot(torch.arange(Bb) % C, C).float()
+    return model, bags, targets
+
+
+def _oracle(model, bags, targets, drop=None):
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = bags.double().requires_grad_(True)
+    logits = transmil_forward(x, params, drop=drop, dtype=torch.float64)
+    loss = torch.nn.functional.cross_entropy(logits, targets.double())
+    loss.backward()
+    return loss.item(), logits.detach(), {k: v.grad for k, v in params.items()}, x.grad
+
+
+@pytest.mark.parametrize("Bb,Tn,Fd,Cd", [(2, 50, 96, 64), (3, 300, 128, 128), (2, 1024, 1024, 512)])
+def test_transmil_backward_matches_autograd(gpu, Bb, Tn, Fd, Cd):
+    """Shapes: 50 tiles (8 x 8 grid with 14 wrap-padded tiles, n = 65 < one landmark block), 300 tiles (18 x 18, wrap 24, front padding
+    59), and the bench geometry 1024 tiles x 1024-d, hidden 512 (32 x 32 grid, n = 1025 -> padded 1280, 5 tokens per landmark).
+    Stated tolerance (fp32 arithmetic on both sides, six cubic pinv iterations in between): every gradient <= 2e-3 relative L2."""
+    model, bags, targets = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn)
+    ref_loss, ref_logits, ref_g, ref_dx = _oracle(model, bags, targets)
+    model = model.to(gpu).eval()                       # eval: no dropout; gradients still flow (the heat-map use)
+    x = bags.to(gpu).requires_grad_(True)
+    logits = model(x)
+    loss = torch.nn.functional.cross_entropy(logits, targets.to(gpu))
+    loss.backward()
+    assert abs(loss.item() - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    assert (logits.detach().cpu().double() - ref_logits).abs().max() < 2e-3 * max(1.0, ref_logits.abs().max().item())
+    worst = []
+    for n, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+        worst.append((_rel(p.grad.cpu(), ref_g[n]), n))
+    worst.append((_rel(x.grad.cpu(), ref_dx), "bags"))
+    worst.sort(reverse=True)
+    print(f"TransMIL {Bb}x{Tn}x{Fd} hidden {Cd}: largest gradient errors", [(round(a, 6), b) for a, b in worst[:5]])
+    for rel, n in worst:
+        assert rel < 2e-3, (n, rel)
+    with torch.no_grad():                              # the inference path gives the same logits
+        assert (model(bags.to(gpu)) - logits.detach()).abs().max() < 1e-4
+
+
+def test_transmil_train_mode_dropout_and_optimizer(gpu):
+    """.train(): Dropout(0.1) on both `to_out` outputs, masks regenerated in the backward; against the oracle fed with the kernels' masks.
+    Then torch AdamW on the module's parameters reduces the loss."""
+    Bb, Tn, Fd, Cd, C = 3, 120, 128, 128, 2
+    model, bags, targets = _setup(Bb, Tn, Fd, Cd, C, seed=7)
+    model = model.to(gpu).train()
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # the draw the module will make
+    torch.manual_seed(123)
+    logits = model(bags.to(gpu))
+    loss = torch.nn.functional.cross_entropy(logits, targets.to(gpu))
+    loss.backward()
+    import math
+    n = 1 + math.ceil(math.sqrt(Tn)) ** 2
+    ks = _lib.lib().amds_dropout_keep_scale(0.1)
+    drop = {name: T.dropout_mask(Bb * n * Cd, 0.1, seed, sid, gpu).view(Bb, n, Cd).cpu().double() * ks for name, sid in (("layer1", 1), ("layer2", 2))}
+    assert abs(drop["layer1"].gt(0).double().mean().item() - 0.9) < 0.02
+    ref_loss, ref_logits, ref_g, _ = _oracle(model.cpu(), bags, targets, drop=drop)
+    model = model.to(gpu)
+    assert abs(loss.item() - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    for nme, p in model.named_parameters():
+        assert _rel(p.grad.cpu(), ref_g[nme]) < 2e-3, nme
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        l = torch.nn.functional.cross_entropy(model(bags.to(gpu)), targets.to(gpu))
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    assert sum(losses[-3:]) < sum(losses[:3])
