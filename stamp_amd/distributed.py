@@ -95,6 +95,24 @@ def gather_slide_embeddings(ctx: DistCtx, local_emb: torch.Tensor, local_ids: to
     return out
 
 
+def average_gradients(flat_grad: torch.Tensor) -> torch.Tensor:
+    """Data-parallel MIL training (the reference is single-device, src/stamp/modeling/train.py:541-547): every rank holds
+    a replica and its own bags; ONE all-reduce (RCCL over xGMI on the GPU box, 14.7 MB fp32 for the default `vit` head) averages the flat
+    gradient buffer before the optimiser step.  With equal per-rank batch sizes and a mean-reduced loss the average of the ranks'
+    gradients IS the gradient of the global batch, so N ranks x (B/N) bags train exactly like one rank with B bags."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad /= dist.get_world_size()
+    return flat_grad
+
+
+def average_buffers(values: torch.Tensor) -> torch.Tensor:
+    """Replicas see different bags, so the ALiBi `_RunningMeanScaler` buffers (updated from each rank's own distance matrix) would drift
+    apart: average them right after the update, before use (mean of the ranks' means = the mean over the global batch for equal
+    per-rank batches)."""
+    return average_gradients(values)
+
+
 def max_over_ranks(ctx: DistCtx, value: float) -> float:
     if ctx.world == 1:
         return value

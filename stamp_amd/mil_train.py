@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import mil_core
 from . import train_ops as T
+from .distributed import average_buffers, average_gradients
 from .mil import VisionTransformer
 from .mil_core import PackedVit
 
@@ -116,9 +117,7 @@ class HipMilVitTrainer:
             cc = mil_core._coords_with_cls(coords, bags.shape[0], dev)
             mil_core.update_running_means(self.p, self.dims, cc)
             if dist_on:      # replicas see different bags: keep the scaler buffers identical (mean of the ranks' updates)
-                stats = self.P[self._stat_idx]
-                torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.AVG)
-                self.P[self._stat_idx] = stats
+                self.P[self._stat_idx] = average_buffers(self.P[self._stat_idx])
             self.pk.refresh(self.p)
         logits, saved = mil_core.forward_train(self.pk, bags, coords, training=self.use_dropout, seed=seed)
         # ---- loss on [Bb, C]: the reference's weighted CE with float one-hot targets (models/__init__.py:254-258) ---------------------
@@ -138,7 +137,7 @@ class HipMilVitTrainer:
             self.g(k).copy_(gk)
         # ---- AdamW + OneCycleLR ---------------------------------------------------------------------------------------------------
         if dist_on:
-            torch.distributed.all_reduce(self.G, op=torch.distributed.ReduceOp.AVG)
+            average_gradients(self.G)
         if update:
             self.step_count += 1
             i = min(self.step_count - 1, len(self._lrs) - 1)

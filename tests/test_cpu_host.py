@@ -94,6 +94,52 @@ def test_gather_slide_embeddings_gloo_world2(tmp_path):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
 
 
+_DP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["REPO"])
+from oracle.mil_vit import mil_vit_forward
+from stamp_amd import distributed as D
+from stamp_amd.mil import VisionTransformer
+ctx = D.init_from_env(prefer_gpu=False)
+torch.manual_seed(0)                                   # every rank builds the same replica and the same GLOBAL batch
+model = VisionTransformer(dim_output=2, dim_input=32, dim_model=64, n_layers=1, n_heads=2, dim_feedforward=64, dropout=0.0, use_alibi=False)
+names = [n for n, _ in model.named_parameters()]
+bags, targets = torch.randn(8, 20, 32), torch.nn.functional.one_hot(torch.arange(8) % 2, 2).float()
+
+def flat_grad(b, t):                                   # the oracle network stands in for the HIP step on this CPU-only host
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    loss = torch.nn.functional.cross_entropy(mil_vit_forward(b, torch.zeros(b.shape[0], 20, 2), None, p, n_heads=2, use_alibi=False), t)
+    loss.backward()
+    return torch.cat([p[n].grad.reshape(-1) for n in names]), loss.detach()
+
+full, full_loss = flat_grad(bags, targets)             # one rank, whole batch
+per = 8 // ctx.world
+mine = slice(ctx.rank * per, (ctx.rank + 1) * per)
+g, l = flat_grad(bags[mine], targets[mine])            # this rank's shard
+g = D.average_gradients(g)
+l = D.average_gradients(l.reshape(1))
+assert torch.allclose(g, full, rtol=1e-5, atol=1e-7), (g - full).abs().max()
+assert abs(l.item() - full_loss.item()) < 1e-6
+stats = D.average_buffers(torch.tensor([float(ctx.rank + 1), 10.0 * (ctx.rank + 1)]))
+assert torch.allclose(stats, torch.tensor([1.5, 15.0])), stats
+D.barrier(ctx)
+print("rank", ctx.rank, "ok")
+"""
+
+
+def test_data_parallel_mil_gradients_equal_single_rank_gloo_world2(tmp_path):
+    """N-GPU DP-MIL must equal 1-GPU with the same global batch.  The reduction recipe the trainer uses
+    (stamp_amd.distributed.average_gradients / average_buffers: one all-reduce of the flat gradient buffer) on world-size-2 gloo."""
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, REPO=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
 def test_gather_single_rank():
     from stamp_amd.distributed import DistCtx, gather_slide_embeddings
 

@@ -40,7 +40,8 @@ def _oracle(model, bags, targets, drop=None):
 def test_transmil_backward_matches_autograd(gpu, Bb, Tn, Fd, Cd):
     """Shapes: 50 tiles (8 x 8 grid with 14 wrap-padded tiles, n = 65 < one landmark block), 300 tiles (18 x 18, wrap 24, front padding
     59), and the bench geometry 1024 tiles x 1024-d, hidden 512 (32 x 32 grid, n = 1025 -> padded 1280, 5 tokens per landmark).
-    Stated tolerance (fp32 arithmetic on both sides, six cubic pinv iterations in between): every gradient <= 2e-3 relative L2."""
+    Stated tolerance (fp32 arithmetic here, fp64 autograd there, six cubic pinv iterations in between): every gradient <= 1e-4 relative L2
+    (measured on the MI355X: <= 3e-6 at all three sizes)."""
     model, bags, targets = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn)
     ref_loss, ref_logits, ref_g, ref_dx = _oracle(model, bags, targets)
     model = model.to(gpu).eval()                       # eval: no dropout; gradients still flow (the heat-map use)
@@ -58,7 +59,7 @@ def test_transmil_backward_matches_autograd(gpu, Bb, Tn, Fd, Cd):
     worst.sort(reverse=True)
     print(f"TransMIL {Bb}x{Tn}x{Fd} hidden {Cd}: largest gradient errors", [(round(a, 6), b) for a, b in worst[:5]])
     for rel, n in worst:
-        assert rel < 2e-3, (n, rel)
+        assert rel < 1e-4, (n, rel)
     with torch.no_grad():                              # the inference path gives the same logits
         assert (model(bags.to(gpu)) - logits.detach()).abs().max() < 1e-4
 
@@ -84,7 +85,7 @@ def test_transmil_train_mode_dropout_and_optimizer(gpu):
     model = model.to(gpu)
     assert abs(loss.item() - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
     for nme, p in model.named_parameters():
-        assert _rel(p.grad.cpu(), ref_g[nme]) < 2e-3, nme
+        assert _rel(p.grad.cpu(), ref_g[nme]) < 1e-4, nme
     opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
     losses = []
     for _ in range(12):
