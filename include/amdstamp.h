@@ -350,6 +350,15 @@ int amds_patch_merge_ln(const float* x, void* y, const float* gamma, const float
 int amds_layernorm_meanpool(const float* x, void* out_f16, float* out_f32, const float* gamma, const float* beta, int B,
                             int L, int dim, float eps, void* stream);
 
+/* Supertile -> tiles (the resize + crop of the reference's WSI reader, src/stamp/preprocessing/tiling.py:326-343 and :225-246):
+ * rgba u8 [n][S][S][4] as `openslide.read_region` returns it -> PIL `Image.resize((k*t, k*t))` (bicubic on the premultiplied image, 8-bit
+ * two-pass resample with 22-bit fixed-point taps, un-premultiply) -> `.convert("RGB")` -> k x k tiles of t x t in row-major order:
+ * tiles u8 [n*k*k][t][t][3].  Bit-exact with Pillow (pinned in tests).  bounds int32 [k*t][2] = (first tap, tap count), coef int32
+ * [k*t][ksize]: Pillow's precompute_coeffs table for S -> k*t (stamp_amd.tiling.resize_coefficients); ws: n*S*k*t*4 bytes. */
+size_t amds_supertiles_to_tiles_workspace_bytes(int n, int S, int k, int t);
+int amds_supertiles_to_tiles_u8(const uint8_t* rgba, uint8_t* tiles, int n, int S, int k, int t, const int* bounds, const int* coef,
+                                int ksize, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Gated-attention pooling (CHIEF slide encoder; reference
  * src/stamp/encoding/encoder/chief.py:74-89 CHIEFModel.forward, :255-275 Attn_Net_Gated)

@@ -1,0 +1,121 @@
+"""Tiling of a whole-slide image on the step before the tile encoder: supertile geometry, background rejection on the thumbnail,
+supertile -> tiles on the GPU, tile coordinates.  Mirrors reference src/stamp/preprocessing/tiling.py (`_supertiles` :294-347,
+`_foreground_coords` :250-277, `_tiles` :196-247).  Reading pixels out of a slide file (openslide) and the thumbnail are host I/O
+and stay with the caller; what happens to the pixels afterwards runs here:
+
+    read_region RGBA [S, S, 4] u8  --amds_supertiles_to_tiles_u8-->  k x k tiles [224, 224, 3] u8  (+ micrometre coordinates)
+
+The GPU resize is PIL's `Image.resize` bit for bit (bicubic on the premultiplied image, 8-bit two-pass resample with 22-bit
+fixed-point taps; see csrc/resize.hip), so tiles equal the reference's `supertile.resize(...).convert("RGB").crop(...)`.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+@dataclass(frozen=True)
+class SupertileGeometry:
+    tile_size_slide_px: int          # one tile's side in level-0 pixels, ceil(tile_size_um / mpp)            (tiling.py:311)
+    tiles_per_side: int              # k = max(int(max_supertile_px * mpp // tile_size_um), 1)                 (:308-309)
+    supertile_size_slide_px: int     # the square read from the slide                                          (:312-314)
+    supertile_size_tile_px: int      # its side after the resize, k * tile_size_px                            (:315)
+    supertile_size_um: float         # (:317)
+
+
+def supertile_geometry(slide_mpp: float, tile_size_um: float = 256.0, tile_size_px: int = 224, max_supertile_size_slide_px: int = 4096) -> SupertileGeometry:
+    max_supertile_um = max_supertile_size_slide_px * slide_mpp
+    k = max(int(max_supertile_um // tile_size_um), 1)
+    tile_px_slide = int(np.ceil(tile_size_um / slide_mpp))
+    s = tile_px_slide * k
+    return SupertileGeometry(tile_px_slide, k, s, tile_size_px * k, s * slide_mpp)
+
+
+def thumbnail_size(dimensions: tuple[int, int], supertile_size_slide_px: int) -> tuple[int, int]:
+    """(width, height) of the one-cell-per-supertile grid; the reference asks the slide for a thumbnail of twice that (:254-261)."""
+    g = np.ceil(np.array(dimensions) / supertile_size_slide_px).astype(np.uint32)
+    return int(g[0]), int(g[1])
+
+
+def foreground_coords(dimensions: tuple[int, int], thumbnail_2x, supertile_size_slide_px: int, brightness_cutoff: int | None) -> list[tuple[int, int]]:
+    """Level-0 origins (x, y) of the supertiles that are not background, row-major -- `_foreground_coords` (:250-277).
+    `thumbnail_2x`: what `slide.get_thumbnail(2 * grid)` returned (a PIL image); like the reference it is resized to the grid and
+    converted to 32-bit luma with PIL (host glue on a few hundred pixels)."""
+    gw, gh = thumbnail_size(dimensions, supertile_size_slide_px)
+    gray = np.array(thumbnail_2x.resize((gw, gh)).convert("I"))
+    fg = gray < brightness_cutoff if brightness_cutoff is not None else np.ones_like(gray, dtype=bool)
+    return [(x, y) for y in range(0, dimensions[1], supertile_size_slide_px) for x in range(0, dimensions[0], supertile_size_slide_px)
+            if fg[y // supertile_size_slide_px, x // supertile_size_slide_px]]
+
+
+def tile_coords_um(origin_slide_px: tuple[int, int], slide_mpp: float, tiles_per_side: int, tile_size_um: float) -> np.ndarray:
+    """float64 [k*k, 2] top-left micrometre coordinates of a supertile's tiles in the reference's yield order (y outer, x inner; :237-246)."""
+    ox, oy = origin_slide_px[0] * slide_mpp, origin_slide_px[1] * slide_mpp
+    return np.array([(ox + x * tile_size_um, oy + y * tile_size_um) for y in range(tiles_per_side) for x in range(tiles_per_side)], dtype=np.float64)
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@lru_cache(maxsize=16)
+def resize_coefficients(in_size: int, out_size: int) -> tuple[np.ndarray, np.ndarray]:
+    """Pillow's tap table for a bicubic resize in_size -> out_size (Resample.c precompute_coeffs / normalize_coeffs_8bpc, evaluated in
+    double precision in the same operation order): bounds int32 [out, 2] = (first tap, tap count), taps int32 [out, ksize], 22
+    fraction bits.  Host-side set-up, once per (S, S') pair."""
+    scale = in_size / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    taps = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        n = min(int(center + support + 0.5), in_size) - xmin
+        k = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(n)]
+        ww = 0.0
+        for v in k:
+            ww += v
+        if ww != 0.0:
+            k = [v / ww for v in k]
+        for x, v in enumerate(k):
+            taps[xx, x] = int(v * (1 << 22) - 0.5) if v < 0 else int(v * (1 << 22) + 0.5)
+        bounds[xx] = (xmin, n)
+    return bounds, taps
+
+
+def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: int = 224) -> torch.Tensor:
+    """u8 [n, S, S, 4] (what `read_region` returns, on the GPU) -> u8 [n * k * k, tile_px, tile_px, 3]: resize to k * tile_px, drop alpha,
+    crop -- tiles of supertile i are rows i*k*k .. (i+1)*k*k - 1 in (y outer, x inner) order."""
+    if not rgba.is_cuda:
+        raise RuntimeError("supertiles_to_tiles needs the supertiles on the GPU (no CPU fallback)")
+    if rgba.dtype != torch.uint8 or rgba.dim() != 4 or rgba.shape[-1] != 4 or rgba.shape[1] != rgba.shape[2]:
+        raise ValueError(f"expected u8 [n, S, S, 4], got {rgba.dtype} {tuple(rgba.shape)}")
+    rgba = rgba.contiguous()
+    n, S = rgba.shape[0], rgba.shape[1]
+    k, t = int(tiles_per_side), int(tile_size_px)
+    bounds, taps = resize_coefficients(S, k * t)
+    dev = rgba.device
+    b_d, t_d = torch.from_numpy(bounds).to(dev), torch.from_numpy(taps).to(dev)
+    out = torch.empty(n * k * k, t, t, 3, dtype=torch.uint8, device=dev)
+    lib = _lib.lib()
+    nb = lib.amds_supertiles_to_tiles_workspace_bytes(n, S, k, t)
+    ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
+    _lib.check(lib.amds_supertiles_to_tiles_u8(rgba.data_ptr(), out.data_ptr(), n, S, k, t, b_d.data_ptr(), t_d.data_ptr(), taps.shape[1], ws.data_ptr(), nb,
+                                               ops._stream()), "supertiles_to_tiles")
+    return out

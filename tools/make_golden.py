@@ -282,6 +282,83 @@ def golden_bag() -> None:
     save("fixed_size_bag.npz", **out)
 
 
+from oracle.tiling import synthetic_slide  # noqa: E402  (seeded generator shared with the tests)
+
+
+class FakeSlide:
+    """The slice of openslide's AbstractSlide the reference's tiling code touches: `dimensions`, `read_region` (RGBA, transparent past
+    the edge like openslide), `get_thumbnail` (white background + PIL thumbnail, as openslide-python implements it)."""
+
+    def __init__(self, rgb: np.ndarray, mpp: float):
+        from PIL import Image
+        self._im = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]), "RGBA")
+        self.dimensions = (rgb.shape[1], rgb.shape[0])
+        self.properties = {"openslide.mpp-x": str(mpp)}
+
+    def read_region(self, location, level, size):
+        from PIL import Image
+        assert level == 0
+        x, y = location
+        out = Image.new("RGBA", size, (0, 0, 0, 0))
+        out.paste(self._im.crop((x, y, min(x + size[0], self.dimensions[0]), min(y + size[1], self.dimensions[1]))), (0, 0))
+        return out
+
+    def get_thumbnail(self, size):
+        from PIL import Image
+        bg = Image.new("RGB", self._im.size, "#ffffff")
+        thumb = Image.composite(self._im, bg, self._im)
+        thumb.thumbnail(tuple(int(v) for v in size), Image.Resampling.LANCZOS)
+        return thumb
+
+
+def golden_tiling() -> None:
+    """The reference's own `_foreground_coords`, `_supertiles` and `_tiles` (src/stamp/preprocessing/tiling.py:196-347) run on a synthetic
+    slide object.  Stored: the thumbnail the fake slide handed out, the foreground origins, every tile's coordinates and CRC32, and a
+    few tiles in full (an edge supertile that reads past the slide is among them)."""
+    import zlib
+    from concurrent import futures
+    from dataclasses import dataclass
+    from typing import Generic, NamedTuple, TypeVar, cast
+
+    from PIL import Image
+
+    glb = {"np": np, "futures": futures, "Image": Image, "cast": cast, "Iterator": typing.Iterator, "NamedTuple": NamedTuple, "Generic": Generic,
+           "TypeVar": TypeVar, "dataclass": dataclass, "_Unit": TypeVar("_Unit"), "Microns": float, "TilePixels": int, "SlidePixels": int, "SlideMPP": float,
+           "npt": types.SimpleNamespace(NDArray=typing.Any), "openslide": types.SimpleNamespace(AbstractSlide=object),
+           "get_slide_mpp_": lambda slide, default_mpp=None: float(slide.properties["openslide.mpp-x"])}
+    # `class _Tile(NamedTuple, Generic[_Unit])` needs Python >= 3.11: arithmetic-free stand-ins for the two record types (tiling.py:51-65)
+    import collections
+
+    class _XYCoords:
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+        def __class_getitem__(cls, item):
+            return cls
+
+    class _Tile(collections.namedtuple("_Tile", "image coordinates size")):
+        def __class_getitem__(cls, item):
+            return cls
+
+    glb.update(_XYCoords=_XYCoords, _Tile=_Tile)
+    exec_defs(REF / "preprocessing" / "tiling.py", {"_tiles", "_foreground_coords", "_supertiles"}, glb)
+    for tag, (w, h, mpp, seed) in {"mpp050": (3000, 2100, 0.5, 11), "mpp025": (2500, 1900, 0.25, 12)}.items():
+        slide = FakeSlide(synthetic_slide(w, h, seed), mpp)
+        kw = dict(tile_size_um=256.0, tile_size_px=224, max_supertile_size_slide_px=1024, max_workers=1, brightness_cutoff=224, default_slide_mpp=None)
+        ts_px = int(np.ceil(256.0 / mpp)) * max(int(1024 * mpp // 256.0), 1)
+        fg = [(c.x, c.y) for c in glb["_foreground_coords"](slide, ts_px, 224)]
+        grid = np.ceil(np.array(slide.dimensions) / ts_px).astype(np.uint32)
+        thumb = np.array(slide.get_thumbnail(tuple(grid * 2)))
+        tiles = list(glb["_tiles"](slide=slide, **kw))
+        tiles.sort(key=lambda t: (t.coordinates.y, t.coordinates.x))
+        coords = np.array([(t.coordinates.x, t.coordinates.y) for t in tiles], dtype=np.float64)
+        crc = np.array([zlib.crc32(np.array(t.image).tobytes()) for t in tiles], dtype=np.uint32)
+        keep = sorted({0, len(tiles) // 2, len(tiles) - 1})
+        full = np.stack([np.array(tiles[i].image) for i in keep])
+        save(f"tiling_{tag}.npz", slide=np.array([w, h, seed]), mpp=np.float64(mpp), thumb2x=thumb, foreground=np.array(fg, dtype=np.int64),
+             coords_um=coords, crc32=crc, full_idx=np.array(keep), full_tiles=full)
+
+
 def he_like_tiles(n: int, size: int, seed: int) -> np.ndarray:
     """Synthetic H&E-looking u8 tiles (smooth mixtures of two stain colours on white) -- smoother statistics than
     uniform noise, so the conv stem and the shifted-window masks see structured input."""
@@ -387,6 +464,7 @@ def main() -> None:
     golden_bag()
     golden_ctranspath()
     golden_texture_gray()
+    golden_tiling()
 
 
 if __name__ == "__main__":
