@@ -312,6 +312,8 @@ static int launch_attn(const void* qkv, void* out, int B, int Tn, int H, hipStre
     return AMDS_OK;
 }
 
+int attention_vit257(const void* qkv, void* out, int B, int H, int dtype, hipStream_t st);       // attention_vit257.hip
+
 }  // namespace amds
 
 using namespace amds;
@@ -322,6 +324,9 @@ extern "C" int amds_attention_vit(const void* qkv, void* out, int B, int T, int 
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_ATTN, 4.0 * B * H * (double)T * T * 64, st);
+    // T = 257 (class token + 16 x 16 patches): the persistent double-buffered kernel; AMDS_ATTN_257=0 selects the one-shot kernel (A/B)
+    static const bool use257 = getenv("AMDS_ATTN_257") ? atoi(getenv("AMDS_ATTN_257")) != 0 : true;
+    if (use257 && T == 257 && (dtype == AMDS_F16 || dtype == AMDS_BF16)) return attention_vit257(qkv, out, B, H, dtype, st);
     if (dtype == AMDS_F16) return launch_attn<f16>(qkv, out, B, T, H, st);
     if (dtype == AMDS_BF16) return launch_attn<bf16>(qkv, out, B, T, H, st);
     set_error("amds_attention_vit: bad dtype %d", dtype);

@@ -72,9 +72,9 @@ extern "C" size_t amds_supertiles_to_tiles_workspace_bytes(int n, int S, int k, 
 
 extern "C" int amds_supertiles_to_tiles_u8(const uint8_t* rgba, uint8_t* tiles, int n, int S, int k, int t, const int* bounds, const int* coef,
                                            int ksize, void* ws, size_t ws_bytes, void* stream) {
+    if (n == 0) return AMDS_OK;
     AMDS_REQUIRE(rgba && tiles && bounds && coef && ws, "amds_supertiles_to_tiles_u8: null pointer");
     AMDS_REQUIRE(n >= 0 && n <= 65535 && S > 0 && S <= 65535 && k > 0 && t > 0 && (long)k * t <= 65535 && ksize > 0, "amds_supertiles_to_tiles_u8: bad shape");
-    if (n == 0) return AMDS_OK;
     if (ws_bytes < amds_supertiles_to_tiles_workspace_bytes(n, S, k, t)) { set_error("amds_supertiles_to_tiles_u8: workspace too small"); return AMDS_ERR_WORKSPACE; }
     AMDS_REQUIRE(((uintptr_t)rgba & 3) == 0 && ((uintptr_t)ws & 3) == 0, "amds_supertiles_to_tiles_u8: 4-byte alignment");
     hipStream_t st = (hipStream_t)stream;
