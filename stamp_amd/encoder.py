@@ -9,10 +9,41 @@ chief.py:123-127).  Weights: the reference checkpoint's ``attention_net.*`` tens
 """
 from __future__ import annotations
 
+import hashlib
+import logging
+import os
+import re
+from pathlib import Path
+
 import numpy as np
 import torch
 
-from . import ops
+from . import h5io, ops
+
+_logger = logging.getLogger("stamp_amd")
+VERSION = "amdstamp-0.2"
+_HASH_RE = re.compile(r"^[0-9a-fA-F]{6,}$")
+
+
+def resolve_extractor_name(name: str) -> str:
+    """The reference's `_resolve_extractor_name` (encoder/__init__.py:235-250): strip a trailing `-<hex hash>` and nothing else."""
+    if not name:
+        raise ValueError("Empty extractor name")
+    name = str(name).strip()
+    if "-" not in name:
+        return name
+    base, suffix = name.rsplit("-", 1)
+    return base if _HASH_RE.match(suffix) else name
+
+
+def code_hash(directory: Path | None = None) -> str:
+    """`get_processing_code_hash` semantics (reference utils/cache.py:42-55): sha256 over the sha256 digests of the sorted *.py files of a
+    directory, here this package's (the reference's hash cannot be reproduced: different files); first 8 hex digits name output folders."""
+    d = Path(directory) if directory else Path(__file__).resolve().parent
+    h = hashlib.sha256()
+    for f in sorted(d.glob("*.py")):
+        h.update(hashlib.sha256(f.read_bytes()).hexdigest().encode())
+    return h.hexdigest()
 
 _KEYS = {"fc_w": "attention_net.0.weight", "fc_b": "attention_net.0.bias",
          "a_w": "attention_net.3.attention_a.0.weight", "a_b": "attention_net.3.attention_a.0.bias",
@@ -54,3 +85,64 @@ class HipGatedAttentionEncoder:
     @torch.no_grad()
     def _generate_patient_embedding(self, feats_list: list, device=None, **kwargs) -> np.ndarray:
         return self._generate_slide_embedding(torch.cat([f.to(self.device) for f in feats_list], dim=0))
+
+    # ---- the reference base class's file loops (encoder/__init__.py:42-229), on stamp_amd.h5io ---------------------------------------
+    def _read_h5(self, h5_path: str):
+        """-> (feats [N, F] in self.precision, CoordsInfo, extractor name with a hash suffix stripped)  (:182-201)."""
+        if not os.path.exists(h5_path):
+            raise FileNotFoundError(f"File does not exist: {h5_path}")
+        if not str(h5_path).endswith(".h5"):
+            raise ValueError(f"File is not of type .h5: {os.path.basename(h5_path)}")
+        d, attrs = h5io.read_file(h5_path)
+        feats = torch.from_numpy(np.ascontiguousarray(d["feats"])).to(dtype=self.precision)
+        coords = h5io.get_coords(d, attrs)
+        extractor = attrs.get("extractor", "")
+        if extractor == "":
+            raise ValueError(f"Feature file does not have extractor's name in the metadata: {os.path.basename(h5_path)}")
+        return feats, coords, resolve_extractor_name(extractor)
+
+    def _validate_and_read_features(self, h5_path: str):
+        feats, coords, extractor = self._read_h5(h5_path)
+        if extractor not in self.required_extractors:
+            raise ValueError(f"Features must be extracted with one of {self.required_extractors}. "
+                             f"Features located in {h5_path} are extracted with {extractor}")
+        return feats, coords
+
+    def _save_features_(self, output_path: Path, feats: np.ndarray, feat_type: str) -> None:
+        h5io.write_slide_features(output_path, feats, encoder=str(self.identifier), precision=str(self.precision), code_hash=code_hash()[:8],
+                                  stamp_version=VERSION, feat_type=feat_type)
+
+    def encode_slides_(self, output_dir: Path, feat_dir: Path, device=None, generate_hash: bool = True, **kwargs) -> None:
+        """One slide-level .h5 per tile-level .h5 under feat_dir, folder structure kept, existing outputs skipped, files whose extractor
+        is not accepted reported and skipped (:42-93)."""
+        encode_dir = Path(output_dir) / (f"{self.identifier}-slide-{code_hash()[:8]}" if generate_hash else f"{self.identifier}-slide")
+        os.makedirs(encode_dir, exist_ok=True)
+        feat_dir = Path(feat_dir)
+        for h5_path in sorted(feat_dir.rglob("*.h5")):
+            output_path = (encode_dir / h5_path.relative_to(feat_dir)).with_suffix(".h5")
+            if output_path.exists():
+                _logger.info(f"skipping {h5_path.stem} because {output_path} already exists")
+                continue
+            try:
+                feats, coords = self._validate_and_read_features(str(h5_path))
+            except ValueError as e:
+                _logger.warning(str(e))
+                continue
+            self._save_features_(output_path, self._generate_slide_embedding(feats, device, coords=coords), "slide")
+
+    def encode_patients_(self, output_dir: Path, feat_dir: Path, patient_to_files: dict[str, list[str]], device=None, generate_hash: bool = True,
+                         **kwargs) -> None:
+        """One patient-level .h5 per patient from all of the patient's tile-feature files (:95-162).  `patient_to_files` is the grouping the
+        reference derives from its slide table (`read_table(...).groupby(patient_label)[filename_label]`): table I/O stays with the caller."""
+        encode_dir = Path(output_dir) / (f"{self.identifier}-pat-{code_hash()[:8]}" if generate_hash else f"{self.identifier}-pat")
+        os.makedirs(encode_dir, exist_ok=True)
+        for patient_id, files in patient_to_files.items():
+            output_path = (encode_dir / str(patient_id)).with_suffix(".h5")
+            if output_path.exists():
+                _logger.info(f"skipping {patient_id} because {output_path} already exists")
+                continue
+            feats_list = [self._validate_and_read_features(os.path.join(feat_dir, f))[0] for f in files]
+            if not feats_list:
+                _logger.warning(f"No features found for patient {patient_id}, skipping.")
+                continue
+            self._save_features_(output_path, self._generate_patient_embedding(feats_list, device, **kwargs), "patient")

@@ -134,3 +134,47 @@ def test_chief_pipeline_tiles_to_slide_embedding(gpu):
     emb = enc._generate_slide_embedding(feats.float(), device=gpu)                    # the reference reads the h5 as fp32 (chief.py:117)
     ref_emb = gated_attention_pool(ref_feats.float(), csd)["WSI_feature"].reshape(-1).numpy()
     assert emb.shape == (768,) and np.linalg.norm(emb - ref_emb) / np.linalg.norm(ref_emb) < 2e-3
+
+
+def test_encoder_file_loop_on_h5_files(gpu, tmp_path):
+    """`Encoder.encode_slides_` / `encode_patients_` of the reference (encoding/encoder/__init__.py:42-162) on real .h5 files in STAMP's
+    schema: tile files in -> slide / patient files out, extractor validated after stripping the hash suffix, existing outputs skipped."""
+    import numpy as np
+    from oracle.gated_attention import KEYS, gated_attention_pool
+    from stamp_amd import h5io
+    from stamp_amd.encoder import HipGatedAttentionEncoder, resolve_extractor_name
+
+    if h5io._h5py is None:
+        try:
+            h5io._lib()
+        except RuntimeError:
+            pytest.skip("no HDF5 backend on this machine")
+    assert resolve_extractor_name("chief-ctranspath-0a1b2c3d") == "chief-ctranspath" and resolve_extractor_name("chief-ctranspath") == "chief-ctranspath"
+    g = torch.Generator().manual_seed(0)
+    F_, L, Dd = 768, 512, 256
+    sd = {KEYS["fc_w"]: torch.randn(L, F_, generator=g) / F_ ** 0.5, KEYS["fc_b"]: torch.randn(L, generator=g) * 0.1, KEYS["a_w"]: torch.randn(Dd, L, generator=g) / L ** 0.5,
+          KEYS["a_b"]: torch.zeros(Dd), KEYS["b_w"]: torch.randn(Dd, L, generator=g) / L ** 0.5, KEYS["b_b"]: torch.zeros(Dd),
+          KEYS["c_w"]: torch.randn(1, Dd, generator=g) / Dd ** 0.5, KEYS["c_b"]: torch.zeros(1)}
+    feat_dir, out_dir = tmp_path / "feats", tmp_path / "out"
+    slides = {}
+    for name, n, ext in (("a/s1", 300, "chief-ctranspath-deadbeef"), ("s2", 77, "chief-ctranspath"), ("s3", 10, "uni2")):
+        f = (torch.randn(n, F_, generator=g) * 0.5).half()
+        slides[name] = f
+        h5io.write_tile_features(feat_dir / f"{name}.h5", f, torch.zeros(n, 2), extractor=ext, tile_size_um=256.0, tile_size_px=224, code_hash="x", stamp_version="2.5.0")
+    enc = HipGatedAttentionEncoder(sd, device=gpu)
+    enc.encode_slides_(out_dir, feat_dir, gpu, generate_hash=False)
+    outs = sorted(p.relative_to(out_dir).as_posix() for p in out_dir.rglob("*.h5"))
+    assert outs == ["chief-slide/a/s1.h5", "chief-slide/s2.h5"]                      # s3 was extracted with a model this encoder does not accept
+    d, a = h5io.read_file(out_dir / "chief-slide" / "a" / "s1.h5")
+    ref = gated_attention_pool(slides["a/s1"].float(), sd)["WSI_feature"].reshape(-1)
+    assert a["feat_type"] == "slide" and a["encoder"] == "chief" and a["precision"] == "torch.float32" and d["feats"].shape == (F_,)
+    assert np.abs(d["feats"] - ref.numpy()).max() < 1e-4 * max(1.0, float(ref.abs().max()))
+    before = (out_dir / "chief-slide" / "s2.h5").stat().st_mtime_ns
+    enc.encode_slides_(out_dir, feat_dir, gpu, generate_hash=False)                    # second run: everything exists, nothing rewritten
+    assert (out_dir / "chief-slide" / "s2.h5").stat().st_mtime_ns == before
+    enc.encode_patients_(out_dir, feat_dir, {"P1": ["a/s1.h5", "s2.h5"]}, gpu, generate_hash=False)
+    d, a = h5io.read_file(out_dir / "chief-pat" / "P1.h5")
+    refp = gated_attention_pool(torch.cat([slides["a/s1"], slides["s2"]]).float(), sd)["WSI_feature"].reshape(-1)
+    assert a["feat_type"] == "patient" and np.abs(d["feats"] - refp.numpy()).max() < 1e-4 * max(1.0, float(refp.abs().max()))
+    with pytest.raises(ValueError):
+        enc.encode_patients_(out_dir, feat_dir, {"P2": ["s3.h5"]}, gpu, generate_hash=False)

@@ -59,3 +59,60 @@ def test_gpu_resize_random_rgba_vs_oracle(gpu, S, k):
     assert pt.supertiles_to_tiles(torch.from_numpy(a[:0]).to(gpu), k, t).shape == (0, t, t, 3)
     with pytest.raises(RuntimeError, match="GPU"):
         pt.supertiles_to_tiles(torch.from_numpy(a), k, t)
+
+
+def test_extract_slide_end_to_end_writes_stamp_h5(gpu, tmp_path):
+    """A synthetic slide object through the whole path (thumbnail rejection -> threaded read_region -> GPU resize / crop -> GPU Canny
+    filter -> tile encoder -> .h5 in STAMP's schema): tile coordinates are a subset of the reference fixture's, features equal the
+    encoder applied to the reference's own tiles, attributes follow the schema."""
+    from PIL import Image
+
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd import h5io
+    from stamp_amd.extractor import hip_vit_extractor
+    from stamp_amd.preprocess import extract_slide
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+
+    if h5io._h5py is None:
+        try:
+            h5io._lib()
+        except RuntimeError:
+            pytest.skip("no HDF5 backend on this machine")
+    z = np.load(G / "tiling_mpp050.npz")
+    w, h, seed = (int(v) for v in z["slide"])
+    rgb = ot.synthetic_slide(w, h, seed)
+
+    class Slide:                                   # openslide's surface, as tools/make_golden.py::FakeSlide
+        dimensions = (w, h)
+        _im = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]), "RGBA")
+
+        def read_region(self, loc, level, size):
+            out = Image.new("RGBA", size, (0, 0, 0, 0))
+            out.paste(self._im.crop((loc[0], loc[1], min(loc[0] + size[0], w), min(loc[1] + size[1], h))), (0, 0))
+            return out
+
+        def get_thumbnail(self, size):
+            bg = Image.new("RGB", self._im.size, "#ffffff")
+            t = Image.composite(self._im, bg, self._im)
+            t.thumbnail(tuple(int(v) for v in size), Image.Resampling.LANCZOS)
+            return t
+
+    cfg = PRESETS["test_tiny"]
+    sd = random_vit_state_dict(cfg, seed=3)
+    ex = hip_vit_extractor("test_tiny", sd, device=gpu, chunk=8, identifier="amdstamp-test")
+    out = tmp_path / "feats" / "slide.h5"
+    stats = extract_slide(Slide(), ex, out, slide_mpp=0.5, brightness_cutoff=224, canny_cutoff=None, supertiles_per_batch=3, device=gpu)
+    assert stats["supertiles"] == len(z["foreground"]) and stats["tiles_seen"] == stats["tiles_kept"] == len(z["coords_um"])
+    feats, ci, attrs = h5io.read_tile_features(out)
+    order = np.lexsort((ci.coords_um[:, 0], ci.coords_um[:, 1]))
+    assert np.array_equal(ci.coords_um[order].astype(np.float64), z["coords_um"]) and feats.dtype == np.float16
+    assert attrs["extractor"] == "amdstamp-test" and attrs["feat_type"] == "tile" and attrs["unit"] == "um" and attrs["tile_size_px"] == 224
+    # features of the three tiles the fixture stores in full == the oracle encoder on the REFERENCE's tiles
+    ref = extract_features(torch.from_numpy(z["full_tiles"]), sd, cfg).float().numpy()
+    got = feats[order][z["full_idx"]].astype(np.float32)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-3
+    # with the texture filter on, only a subset survives and every kept coordinate is one of the reference's
+    out2 = tmp_path / "feats" / "slide_canny.h5"
+    s2 = extract_slide(Slide(), ex, out2, slide_mpp=0.5, brightness_cutoff=224, canny_cutoff=0.02, device=gpu)
+    _, ci2, _ = h5io.read_tile_features(out2)
+    assert 0 < s2["tiles_kept"] <= s2["tiles_seen"] and {tuple(c) for c in ci2.coords_um.tolist()} <= {tuple(c) for c in z["coords_um"].astype(np.float32).tolist()}
