@@ -359,6 +359,49 @@ def golden_tiling() -> None:
              coords_um=coords, crc32=crc, full_idx=np.array(keep), full_tiles=full)
 
 
+def golden_tile_cache() -> None:
+    """Tile-cache zips (tiling.py:68-168, 380-406).  `tile_cache_amd.zip` is written by stamp_amd.tile_cache and must be readable by
+    the REFERENCE's `_tiles_from_cache_file`; `tile_cache_ref_style.zip` is assembled with the reference writer's own statements
+    (:121-151: json entry, f-string entry names, PIL save) in the legacy form without `tile_ext` and is what stamp_amd must read."""
+    import collections
+    import io
+    import json
+    import re
+    from zipfile import ZipFile
+
+    from PIL import Image
+
+    from stamp_amd import tile_cache as tc
+
+    class _XYCoords:
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+    _Tile = collections.namedtuple("_Tile", "image coordinates size")
+    glb = {"ZipFile": ZipFile, "json": json, "re": re, "Image": Image, "Path": Path, "Iterator": typing.Iterator, "_Tile": _Tile, "_XYCoords": _XYCoords,
+           "_TilerParams": dict, "Microns": float}
+    exec_defs(REF / "preprocessing" / "tiling.py", {"_tiles_from_cache_file"}, glb)
+    rng = np.random.default_rng(21)
+    tiles = rng.integers(0, 256, (5, 32, 32, 3), dtype=np.uint8)
+    coords = np.array([[0.0, 0.0], [256.0, 0.0], [512.5, 1024.0], [0.0, 1280.0], [123456.0, 7.25]])
+    params = tc.tiler_params("/data/slide_x.svs", tile_size_um=256.0, tile_size_px=32, max_supertile_size_slide_px=1024, brightness_cutoff=224,
+                             code_sha256="0" * 64, tile_ext="png")
+    OUT.mkdir(parents=True, exist_ok=True)
+    tc.write_tile_cache(OUT / "tile_cache_amd.zip", tiles, coords, params)
+    got = list(glb["_tiles_from_cache_file"](OUT / "tile_cache_amd.zip"))             # the reference reads what stamp_amd wrote
+    assert len(got) == 5 and all(np.array_equal(np.array(t.image), tiles[i]) for i, t in enumerate(got))
+    assert [(t.coordinates.x, t.coordinates.y) for t in got] == [tuple(c) for c in coords.tolist()] and got[0].size == 256.0
+    legacy = {k: v for k, v in params.items() if k != "tile_ext"}
+    with ZipFile(OUT / "tile_cache_ref_style.zip", "w") as zf:                           # the reference writer's statements, jpg, no tile_ext
+        with zf.open("tiler_params.json", "w") as fp:
+            fp.write(json.dumps(legacy).encode())
+        for t, (x, y) in zip(tiles, coords):
+            with zf.open(f"tile_({float(x)}, {float(y)}).jpg", "w") as fp:
+                Image.fromarray(t, "RGB").save(fp, format="jpeg")
+    ref = list(glb["_tiles_from_cache_file"](OUT / "tile_cache_ref_style.zip"))
+    save("tile_cache_expect.npz", tiles=tiles, coords=coords, jpeg_decoded=np.stack([np.array(t.image) for t in ref]))
+
+
 def he_like_tiles(n: int, size: int, seed: int) -> np.ndarray:
     """Synthetic H&E-looking u8 tiles (smooth mixtures of two stain colours on white) -- smoother statistics than
     uniform noise, so the conv stem and the shifted-window masks see structured input."""
@@ -465,6 +508,7 @@ def main() -> None:
     golden_ctranspath()
     golden_texture_gray()
     golden_tiling()
+    golden_tile_cache()
 
 
 if __name__ == "__main__":
