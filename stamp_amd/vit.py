@@ -95,6 +95,47 @@ PRESETS: dict[str, ViTConfig] = {
 }
 
 
+def expected_state_dict_shapes(cfg: ViTConfig) -> dict[str, tuple]:
+    """Parameter names and shapes of the timm `VisionTransformer` this config describes (num_classes = 0), i.e. what the reference's
+    factories hand to `load_state_dict` (uni2.py:32-34, virchow2.py:34-39, h_optimus_0.py:15-20, reddino.py:40-45)."""
+    D, p = cfg.dim, cfg.patch
+    fc1 = cfg.hidden * (2 if cfg.mlp == "swiglu" else 1)
+    sh: dict[str, tuple] = {"patch_embed.proj.weight": (D, 3, p, p), "patch_embed.proj.bias": (D,), "cls_token": (1, 1, D),
+                            "pos_embed": (1, cfg.n_patches + (0 if cfg.no_embed_class else cfg.n_prefix), D), "norm.weight": (D,), "norm.bias": (D,)}
+    if cfg.reg_tokens:
+        sh["reg_token"] = (1, cfg.reg_tokens, D)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        sh.update({b + "norm1.weight": (D,), b + "norm1.bias": (D,), b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
+                   b + "attn.proj.weight": (D, D), b + "attn.proj.bias": (D,), b + "norm2.weight": (D,), b + "norm2.bias": (D,),
+                   b + "mlp.fc1.weight": (fc1, D), b + "mlp.fc1.bias": (fc1,), b + "mlp.fc2.weight": (D, cfg.hidden), b + "mlp.fc2.bias": (D,)})
+        if cfg.layerscale:
+            sh.update({b + "ls1.gamma": (D,), b + "ls2.gamma": (D,)})
+    return sh
+
+
+# entries of real checkpoints that carry no arithmetic on this path (classifier head when num_classes > 0, DINOv2's mask token, pooling norm)
+_IGNORED_KEYS = ("head.", "fc_norm.", "mask_token", "head_drop", "attn_pool.")
+
+
+def validate_state_dict(cfg: ViTConfig, sd: dict[str, torch.Tensor]) -> None:
+    """Fail loudly, before any packing, when a checkpoint does not describe `cfg`: every expected key present with the expected shape, no
+    unexpected parameter (a stray key usually means a different architecture: qk-norm, a different MLP, an untied pos_embed layout)."""
+    want = expected_state_dict_shapes(cfg)
+    missing = [k for k in want if k not in sd]
+    wrong = [(k, tuple(sd[k].shape), v) for k, v in want.items() if k in sd and tuple(sd[k].shape) != v]
+    extra = [k for k in sd if k not in want and not k.startswith(_IGNORED_KEYS)]
+    if missing or wrong or extra:
+        msg = ["state_dict does not match the ViTConfig:"]
+        if missing:
+            msg.append(f"  missing ({len(missing)}): {missing[:6]}{' ...' if len(missing) > 6 else ''}")
+        if wrong:
+            msg.append("  wrong shape: " + "; ".join(f"{k} is {a}, expected {b}" for k, a, b in wrong[:6]) + (" ..." if len(wrong) > 6 else ""))
+        if extra:
+            msg.append(f"  unexpected ({len(extra)}): {extra[:6]}{' ...' if len(extra) > 6 else ''}")
+        raise ValueError("\n".join(msg))
+
+
 def packed_weight_bytes(cfg: ViTConfig) -> int:
     D = cfg.dim
     fc1 = cfg.hidden_pad * (2 if cfg.mlp == "swiglu" else 1)
@@ -138,6 +179,7 @@ class HipViT(nn.Module):
 
     def _pack(self, sd: dict[str, torch.Tensor]) -> None:
         c = self.cfg
+        validate_state_dict(c, sd)
         D, P, np_ = c.dim, c.n_prefix, c.n_patches
         dev = self.device_
         mean = torch.tensor(c.mean, dtype=torch.float64)
@@ -342,4 +384,5 @@ def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate")
     return sd
 
 
-__all__ = ["ViTConfig", "PRESETS", "HipViT", "HipViTClsMean", "random_vit_state_dict", "packed_weight_bytes", "replace", "field"]
+__all__ = ["ViTConfig", "PRESETS", "HipViT", "HipViTClsMean", "random_vit_state_dict", "packed_weight_bytes", "expected_state_dict_shapes",
+           "validate_state_dict", "replace", "field"]

@@ -218,3 +218,31 @@ def test_product_losses_match_oracle_and_reference_known_answers():
     losses.cox_survival_loss(p.unsqueeze(-1), torch.stack([t_tie, ev.float()], 1)).backward()
     assert torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
     assert abs(losses.l1_loss(torch.tensor([[1.0], [3.0]]), torch.tensor([2.0, 5.0])).item() - 1.5) < 1e-7
+
+
+def test_vit_state_dict_validation():
+    """Loader guard: a checkpoint must describe the preset -- names and shapes of timm's VisionTransformer."""
+    from stamp_amd.vit import PRESETS, expected_state_dict_shapes, random_vit_state_dict, validate_state_dict
+
+    for name in ("vit_large_patch14_224", "uni2_h", "virchow2", "h_optimus_0", "test_tiny_swiglu"):
+        cfg = PRESETS[name]
+        want = expected_state_dict_shapes(cfg)
+        n_par = sum(int(np.prod(s)) for s in want.values())
+        if name == "vit_large_patch14_224":
+            assert abs(n_par / 1e6 - 303.2) < 0.1                       # ViT-L/14 with LayerScale: 303.2 M parameters (the HF Dinov2 probe of SURVEY.md 8c)
+        if name == "uni2_h":
+            assert want["blocks.0.mlp.fc1.weight"] == (8192, 1536) and want["reg_token"] == (1, 8, 1536) and want["pos_embed"] == (1, 256, 1536)
+        if name == "virchow2":
+            assert want["pos_embed"] == (1, 261, 1280) and want["blocks.31.mlp.fc2.weight"] == (1280, 3416)
+    cfg = PRESETS["test_tiny_swiglu"]
+    sd = random_vit_state_dict(cfg, seed=0)
+    validate_state_dict(cfg, sd)
+    validate_state_dict(cfg, dict(sd, **{"head.weight": torch.zeros(3, cfg.dim), "mask_token": torch.zeros(1, cfg.dim)}))     # ignored extras
+    with pytest.raises(ValueError, match="missing"):
+        validate_state_dict(cfg, {k: v for k, v in sd.items() if k != "blocks.1.ls2.gamma"})
+    with pytest.raises(ValueError, match="wrong shape"):
+        validate_state_dict(cfg, dict(sd, pos_embed=torch.zeros(1, 257, cfg.dim)))
+    with pytest.raises(ValueError, match="unexpected"):
+        validate_state_dict(cfg, dict(sd, **{"blocks.0.attn.q_norm.weight": torch.ones(64)}))
+    with pytest.raises(ValueError):
+        validate_state_dict(PRESETS["test_tiny"], sd)                    # a SwiGLU / register-token checkpoint is not a plain ViT
