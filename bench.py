@@ -274,7 +274,21 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
         dt, lg2 = timeit(lambda: tm(bags_f), 3, warm=1)
     sec["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 64, exact-fp32 MFMA)", "value": round(64 / dt, 1),
                        "finite": bool(torch.isfinite(lg2).all())}
-    del bags_f
+    # TransMIL training (BASELINE.json configs[2]): fwd + hand-derived bwd + torch AdamW on the module's parameters, train mode (Dropout(0.1))
+    tm.train()
+    opt = torch.optim.AdamW(tm.parameters(), lr=1e-4)
+    tgd = tg.to(ctx.device)
+
+    def tm_step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(tm(bags_f), tgd)
+        loss.backward()
+        opt.step()
+        return loss
+    dt, ltm = timeit(tm_step, 3, warm=1)
+    sec["transmil_train"] = {"metric": "TransMIL bags/s (fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, fp32, Dropout(0.1) live)", "value": round(64 / dt, 1),
+                             "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltm))}
+    del bags_f, opt
     if not is_swin:     # the reference's in-tree tile encoder, same tile shape
         scfg = SWIN_PRESETS["ctranspath"]
         sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)

@@ -350,6 +350,14 @@ int amds_patch_merge_ln(const float* x, void* y, const float* gamma, const float
 int amds_layernorm_meanpool(const float* x, void* out_f16, float* out_f32, const float* gamma, const float* beta, int B,
                             int L, int dim, float eps, void* stream);
 
+/* Macenko stain normalisation of decoded RGB tiles (OPTIONAL stage, off by default: BASELINE.json's north_star names it, the reference
+ * KatherLab/STAMP v2.5.0 does not contain it -- SURVEY.md F1 -- so parity is UNPINNED; checked against oracle/macenko.py's restatement of
+ * Macenko et al., ISBI 2009).  tiles, out: u8 [B][H][W][3] (out != tiles); fit_out (may be NULL): fp32 [B][8] = haematoxylin vector (3),
+ * eosin vector (3), 99th-percentile concentrations (2), zeros for tiles with fewer than 16 stained pixels (those are copied through).
+ * Io = transmitted-light intensity (240), alpha = percentile of the stain angles (1), beta = optical-density threshold (0.15).
+ * One workgroup per tile, the tile staged once through LDS (H * W * 3 + 9 KB <= 160 KB: tiles up to 224 x 224). */
+int amds_macenko_normalize_u8(const uint8_t* tiles, uint8_t* out, float* fit_out, int B, int H, int W, float Io, float alpha, float beta, void* stream);
+
 /* Supertile -> tiles (the resize + crop of the reference's WSI reader, src/stamp/preprocessing/tiling.py:326-343 and :225-246):
  * rgba u8 [n][S][S][4] as `openslide.read_region` returns it -> PIL `Image.resize((k*t, k*t))` (bicubic on the premultiplied image, 8-bit
  * two-pass resample with 22-bit fixed-point taps, un-premultiply) -> `.convert("RGB")` -> k x k tiles of t x t in row-major order:

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),
+    "amds_macenko_normalize_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
     "amds_supertiles_to_tiles_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amds_supertiles_to_tiles_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "amds_gather_rows": (_i, [_vp, _l, _vp, _i, _vp, _l, _i, _i, _i, _i, _vp]),

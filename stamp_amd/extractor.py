@@ -63,6 +63,22 @@ def has_enough_texture(tiles_u8: torch.Tensor, cutoff: float = 0.02) -> torch.Te
     return ops.tile_edge_fraction(tiles_u8, 40, 100) >= cutoff
 
 
+def macenko_normalize(tiles_u8: torch.Tensor, *, Io: float = 240.0, alpha: float = 1.0, beta: float = 0.15, return_fit: bool = False):
+    """OPTIONAL Macenko stain normalisation of decoded tiles on the GPU: u8 [B, H, W, 3] -> u8 [B, H, W, 3] (+ per-tile fit [B, 8]).
+    Not part of the reference's pipeline -- named by BASELINE.json's north_star, off by default, parity unpinned."""
+    from . import _lib, ops
+    if not tiles_u8.is_cuda:
+        raise RuntimeError("macenko_normalize needs tiles on the GPU (no CPU fallback)")
+    if tiles_u8.dtype != torch.uint8 or tiles_u8.dim() != 4 or tiles_u8.shape[-1] != 3:
+        raise ValueError(f"expected u8 [B, H, W, 3], got {tiles_u8.dtype} {tuple(tiles_u8.shape)}")
+    t = tiles_u8.contiguous()
+    out = torch.empty_like(t)
+    fit = torch.empty(t.shape[0], 8, dtype=torch.float32, device=t.device) if return_fit else None
+    _lib.check(_lib.lib().amds_macenko_normalize_u8(t.data_ptr(), out.data_ptr(), None if fit is None else fit.data_ptr(), t.shape[0], t.shape[1], t.shape[2],
+                                                    Io, alpha, beta, ops._stream()), "macenko_normalize")
+    return (out, fit) if return_fit else out
+
+
 class TilePipeline:
     """The per-slide hot loop of the reference (src/stamp/preprocessing/__init__.py:315-327: batches from the DataLoader ->
     ``model(tiles.to(device))`` -> ``.detach().half().cpu()``) as a three-stage pipeline on three HIP streams:
