@@ -22,6 +22,18 @@
 
 namespace amds {
 
+// Accumulator block AGPR -> VGPR, explicitly and where it is used: left to the compiler, the copies of ALL 256 accumulators are
+// placed right behind the asm block that last defines them (another basic block than the epilogue's uses), which leaves the
+// epilogue no registers.
+__device__ __forceinline__ f32x4 agpr_read(const f32x4& a) {
+    f32x4 v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(a[0]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(a[1]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(a[2]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(a[3]));
+    return v;
+}
+
 template <typename T, int EPI, int P3 = 6, int P0 = 6, bool SPREAD = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
@@ -192,13 +204,50 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     if (nk > 1) issue_pieces(1, 0, P3);
     __builtin_amdgcn_sched_barrier(0);
 
+    // ---- residual epilogue state (see the epilogue): old values of pass 0, batches 0-1, are requested inside the second-to-last
+    // K tile (behind its last LDS-DMA piece, so the K loop's counted wait leaves them in flight), the rest right after the loop.
+    constexpr bool RMW = (EPI == AMDS_EPI_RESIDUAL);
+    const bool rmw_fast = RMW && (bias_in_acc || ep.bias == nullptr) && ep.acc_scale == 1.0f;
+    const bool rmw_early = rmw_fast && nk >= 2;
+    const int ldo4 = (int)ep.ldo * 4;
+    __amdgpu_buffer_rsrc_t rsrc_o = rsrc_a;
+    int offu[RMW ? 2 : 1][RMW ? 8 : 1];
+    f32x4 old[RMW ? 4 : 1][RMW ? 8 : 1];
+    if constexpr (RMW) {
+        const int rows_o = min(BM, M - m0);
+        rsrc_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(ep.out) + (long)m0 * ep.ldo + n0, 0,
+                                                   (int)((((long)rows_o - 1) * ep.ldo + BN) * 4), 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                offu[h][u] = (wave * 64 + 2 * u + hi) * ldo4 + (((l31 >> 4) ^ h) << 9) + (((l31 & 15) ^ (2 * u + hi)) << 4);
+    }
+    auto load_old = [&](int pass, int b8) {
+        if constexpr (RMW) {
+            int rowoff = b8 * 16 * ldo4 + pass * 256;
+            asm volatile("" : "+s"(rowoff));          // keep the 16 lane offsets, not 64 sums, in registers
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                old[b8][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_o, offu[b8 & 1][u] + rowoff, 0, 0));
+        }
+    };
+
     auto k_tile = [&](int kt, auto next_c, auto next2_c) {
         constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
         if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, P3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
         if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, P3 + P0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
+        if constexpr (RMW && NEXT && !NEXT2) {
+            if (rmw_early) load_old(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (RMW && NEXT && !NEXT2) {
+            if (rmw_early) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (NEXT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }                                           // (last tile: no LDS-DMA request is outstanding)
         AMDS_BARRIER();
         if constexpr (NEXT2) unit(1, 1, I16{}, kt + 1, 0, 0, 0, IP3{}, kt + 2, 0);
         else if constexpr (NEXT) unit(1, 1, I16{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
@@ -241,7 +290,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    f32x4 gt = acc[i][4 * q + t], vl = acc[i][4 * q + 2 + t];
+                    f32x4 gt = agpr_read(acc[i][4 * q + t]), vl = agpr_read(acc[i][4 * q + 2 + t]);
                     if (!bias_in_acc) {
                         const f32x4 bg = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + (4 * q + t) * 16 + 4 * kb);
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + (4 * q + 2 + t) * 16 + 4 * kb);
@@ -268,6 +317,80 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         }
         return;
     }
+    if constexpr (EPI == AMDS_EPI_RESIDUAL) {
+        // Fast read-modify-write (bias already in the accumulators or absent, acc_scale == 1 -- every call of the tile encoder).
+        // The OLD values of a whole pass (this wave's 64 rows x 128 columns = 32 x 16 bytes per lane) are requested BEFORE the
+        // accumulators are staged, and pass 1's as soon as pass 0 has consumed a batch of registers.  Requested batch by batch
+        // behind the LDS read-back (8 serial L2 / HBM round trips per tile) this epilogue cost ~20 us per tile against 31 us for
+        // proj's whole K loop.  Buffer addressing (32-bit offsets, no clamps): rows past M lie beyond num_records -- their loads
+        // return 0, their stores are dropped.  Row of (b8, u): wave*64 + 16 b8 + 2 u + hi; its 16-byte chunk l31 ^ (row & 31) splits
+        // bitwise into the 128-column half (l31 >> 4) ^ (b8 & 1) and the 4-column group (l31 & 15) ^ (2 u + hi).
+        // Raw s_barrier instead of __syncthreads(): the fence of the latter waits for the loads in flight (vmcnt(0)).
+        if (rmw_fast) {
+            auto run = [&](auto has_scale_c) {
+                constexpr bool HS = decltype(has_scale_c)::value;
+                f32x4 sc[4];
+                auto load_scale = [&](int pass) {
+                    if constexpr (HS) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            sc[jj] = *reinterpret_cast<const f32x4*>(ep.scale + n0 + wn * 128 + (pass * 4 + jj) * 16 + 4 * kb);
+                    }
+                };
+                load_scale(0);
+                if (!rmw_early) load_old(0, 0);
+                load_old(0, 1);
+                load_old(0, 2);
+                load_old(0, 3);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                    for (int i = 0; i < FI; ++i) {
+                        const int row = wm * 128 + i * 16 + l15;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            f32x4 v = agpr_read(acc[i][pass * 4 + jj]);
+                            if constexpr (HS) v *= sc[jj];
+                            const int chunk = wn * 16 + jj * 4 + kb;       // 16-byte chunk = 4 fp32 columns of this pass's 128
+                            *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = v;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pass == 0) load_scale(1);
+#pragma unroll
+                    for (int b8 = 0; b8 < 4; ++b8) {
+                        f32x4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                            v[u] = *reinterpret_cast<const f32x4*>(smem + row * 512 + l31 * 16);
+                        }
+                        int rowoff = b8 * 16 * ldo4 + pass * 256;
+                        asm volatile("" : "+s"(rowoff));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            v[u] += old[b8][u];
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rsrc_o, offu[b8 & 1][u] + rowoff, 0, 0);
+                        }
+                        if (pass == 0) load_old(1, b8);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (pass == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every wave has read pass 0 back before it is overwritten
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            if (ep.scale) run(std::true_type{}); else run(std::false_type{});
+            return;
+        }
+    }
     constexpr int NPASS = F16OUT ? 1 : 2;
     constexpr int JP = FJ / NPASS;                 // column blocks per pass
 #pragma unroll
@@ -285,7 +408,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #pragma unroll
                 for (int jj = 0; jj < JP; jj += 2) {
                     const int j = pass * JP + jj;
-                    f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
+                    f32x4 v0 = agpr_read(acc[i][j]), v1 = agpr_read(acc[i][j + 1]);
                     epi_value_pair<EPI, FAST, true>(epv, cols.bias[jj], cols.scale[jj], cols.bias[jj + 1], cols.scale[jj + 1], v0, v1);
                     if constexpr (F16OUT) {
                         const vec4 o0 = Act<T>::from_f32x4(v0), o1 = Act<T>::from_f32x4(v1);
