@@ -183,10 +183,19 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 8> I8;
     typedef std::integral_constant<int, 16> I16;
-    constexpr int P1 = 16 - P3 - P0;
-    static_assert(P3 <= 8 && P0 <= 8 && P1 >= 0 && P1 <= 8, "LDS-DMA piece split");
-    typedef std::integral_constant<int, P3> IP3;
-    typedef std::integral_constant<int, P0> IP0;
+    // SCHED 0 (P3 >= 0): tile kt+1 is requested while tile kt is consumed (P3 pieces in the last quarter of tile kt-1, P0 / P1 in the
+    //   first two quarters of kt) and waited for with vmcnt(0) at 3/4 of tile kt: the late pieces have a quarter to half a K tile
+    //   (~250-500 ns) to arrive -- enough for an L2 hit, not for an HBM miss, and a miss of one wave stalls all four at the barrier.
+    // SCHED 2 (P3 = -2, kernel id 13, A/B): a K tile's fragments (both k-halves) are in registers by mid-tile, so its stage is free
+    //   from there on: tile kt+2 is requested in the SECOND half of tile kt (behind a barrier at mid-tile) and tile kt+1's data
+    //   (requested in the second half of kt-1) is waited for at 3/4 with the first 8 pieces of kt+2 still in flight (vmcnt(8)):
+    //   0.75-1.25 tiles of flight time, as the vendor kernel does.  Measured +1 % on the K = 4096 / residual shapes, -0.5 % on qkv,
+    //   waiting at mid-tile with one barrier +-0.5 %: the K loop does not wait for its operands (profiles/r02_gemm_schedules.txt).
+    constexpr int SCHED = P3 < 0 ? -P3 : 0;
+    constexpr int Q3 = SCHED ? 0 : P3, Q0 = SCHED ? 0 : P0, P1 = SCHED ? 0 : 16 - Q3 - Q0;
+    static_assert((SCHED == 0 || SCHED == 2) && Q3 <= 8 && Q0 <= 8 && P1 >= 0 && P1 <= 8, "LDS-DMA piece split");
+    typedef std::integral_constant<int, Q3> IP3;
+    typedef std::integral_constant<int, Q0> IP0;
     typedef std::integral_constant<int, P1> IP1;
 
 #define AMDS_BARRIER()                        \
@@ -198,31 +207,30 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     const int nk = K / BK;   // >= 1
     issue_pieces(0, 0, 16);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (SCHED) {
+        if (nk > 1) {
+            issue_pieces(1, 0, 16);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     AMDS_BARRIER();
     load_frags(0, 0, 0, 0, 16);
-    if (nk > 1) issue_pieces(1, 0, P3);
+    if constexpr (!SCHED) {
+        if (nk > 1) issue_pieces(1, 0, Q3);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- residual epilogue state (see the epilogue): old values of pass 0, batches 0-1, are requested inside the second-to-last
-    // K tile (behind its last LDS-DMA piece, so the K loop's counted wait leaves them in flight), the rest right after the loop.
+    // ---- residual epilogue state (see the epilogue)
     constexpr bool RMW = (EPI == AMDS_EPI_RESIDUAL);
     const bool rmw_fast = RMW && (bias_in_acc || ep.bias == nullptr) && ep.acc_scale == 1.0f;
-    const bool rmw_early = rmw_fast && nk >= 2;
     const int ldo4 = (int)ep.ldo * 4;
     __amdgpu_buffer_rsrc_t rsrc_o = rsrc_a;
     int offu[RMW ? 2 : 1][RMW ? 8 : 1];
     f32x4 old[RMW ? 4 : 1][RMW ? 8 : 1];
-    if constexpr (RMW) {
-        const int rows_o = min(BM, M - m0);
-        rsrc_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(ep.out) + (long)m0 * ep.ldo + n0, 0,
-                                                   (int)((((long)rows_o - 1) * ep.ldo + BN) * 4), 0x00020000);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                offu[h][u] = (wave * 64 + 2 * u + hi) * ldo4 + (((l31 >> 4) ^ h) << 9) + (((l31 & 15) ^ (2 * u + hi)) << 4);
-    }
     auto load_old = [&](int pass, int b8) {
         if constexpr (RMW) {
             int rowoff = b8 * 16 * ldo4 + pass * 256;
@@ -235,23 +243,36 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     auto k_tile = [&](int kt, auto next_c, auto next2_c) {
         constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
-        if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, P3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
-        if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, P3 + P0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
-        if constexpr (RMW && NEXT && !NEXT2) {
-            if (rmw_early) load_old(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCHED == 0) {
+            if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, Q3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
+            if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, Q3 + Q0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
+            unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (last tile: no LDS-DMA request is outstanding)
+            AMDS_BARRIER();
+            if constexpr (NEXT2) unit(1, 1, I16{}, kt + 1, 0, 0, 0, IP3{}, kt + 2, 0);
+            else if constexpr (NEXT) unit(1, 1, I16{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
+            else unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+        } else {
+            unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
+            unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // this tile's fragments are all in registers
+            if constexpr (NEXT2) {
+                AMDS_BARRIER();                                                   // the stage of tile kt is free
+                unit(1, 0, I0{}, 0, 0, 0, 0, I8{}, kt + 2, 0);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  // tile kt+1 has landed, 8 pieces of kt+2 may fly
+                AMDS_BARRIER();
+                unit(1, 1, I16{}, kt + 1, 0, 0, 0, I8{}, kt + 2, 8);
+            } else if constexpr (NEXT) {
+                unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                AMDS_BARRIER();
+                unit(1, 1, I16{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
+            } else {
+                unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+                unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+            }
         }
-        unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (RMW && NEXT && !NEXT2) {
-            if (rmw_early) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if constexpr (NEXT) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }                                           // (last tile: no LDS-DMA request is outstanding)
-        AMDS_BARRIER();
-        if constexpr (NEXT2) unit(1, 1, I16{}, kt + 1, 0, 0, 0, IP3{}, kt + 2, 0);
-        else if constexpr (NEXT) unit(1, 1, I16{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
-        else unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
     };
     int kt = 0;
     for (; kt < nk - 2; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
@@ -327,6 +348,14 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         // bitwise into the 128-column half (l31 >> 4) ^ (b8 & 1) and the 4-column group (l31 & 15) ^ (2 u + hi).
         // Raw s_barrier instead of __syncthreads(): the fence of the latter waits for the loads in flight (vmcnt(0)).
         if (rmw_fast) {
+            const int rows_o = min(BM, M - m0);
+            rsrc_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(ep.out) + (long)m0 * ep.ldo + n0, 0,
+                                                       (int)((((long)rows_o - 1) * ep.ldo + BN) * 4), 0x00020000);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    offu[h][u] = (wave * 64 + 2 * u + hi) * ldo4 + (((l31 >> 4) ^ h) << 9) + (((l31 & 15) ^ (2 * u + hi)) << 4);
             auto run = [&](auto has_scale_c) {
                 constexpr bool HS = decltype(has_scale_c)::value;
                 f32x4 sc[4];
@@ -338,10 +367,8 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                     }
                 };
                 load_scale(0);
-                if (!rmw_early) load_old(0, 0);
-                load_old(0, 1);
-                load_old(0, 2);
-                load_old(0, 3);
+#pragma unroll
+                for (int b8 = 0; b8 < 4; ++b8) load_old(0, b8);
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll

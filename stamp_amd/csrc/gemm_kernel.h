@@ -412,7 +412,8 @@ static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, in
 // kernel ids (amds_gemm_ex): 0 = 128x128 tile, one barrier per K step (small problems, any N % 128 == 0)
 //   1 = 128x96 tile, four waves stacked along M (N % 96 == 0: the Swin widths 96/192/288/576 that 128 does not divide)
 //  12 = 256x256x64 four waves, 128x128 wave tiles on v_mfma 16x16x32, AGPR accumulators (gemm_4w16.h): PRODUCTION for every
-//       epilogue but PATCH whenever N % 256 == 0 and the grid fills the chip; 13 = its 8/8 LDS-DMA schedule (A/B)
+//       epilogue but PATCH whenever N % 256 == 0 and the grid fills the chip; 13 = the same kernel with tile kt+2 requested
+//       from mid-tile kt on (two barriers per K tile, gemm_4w16.h SCHED 2; A/B)
 //   8 = 256x256x64 eight-wave staggered two-group pipeline (gemm_8p64.h): the PATCH epilogue, batched fallback
 //  10 = the four-wave structure on v_mfma 32x32x16 (gemm_4w64.h): the one A/B sibling kept
 // (the BK = 32 predecessors 3 / 7 and the ping-pong experiment 9 of round 1 were removed; their measurements stay in profiles/r01_*)
@@ -422,7 +423,7 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
     if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6>(A, lda, W, ldw, M, N, K, ep, st);
-    if (cfg == 13 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w16<T, EPI, true, 8, 8>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 13 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, -2, 0>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 12 || cfg == 13) cfg = 8;
 
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);

@@ -54,7 +54,7 @@ def test_gemm_bias_asymmetric(gpu, dt, cfg, M, N, K):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1, 256, 128), (300, 256, 64), (255, 256, 192), (256, 512, 128), (257, 256, 256), (1000, 1024, 640),
                                    (4099, 768, 1024), (777, 256, 4096), (20000, 1024, 1024)])
-@pytest.mark.parametrize("cfg", [8, 10, 12])
+@pytest.mark.parametrize("cfg", [8, 10, 12, 13])
 def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
     """The pipelined kernels (8: staggered two-group 8-wave; 10 / 12: four waves, 128x128 wave tiles):
     exact-shape sweep incl. the minimum K, ragged M (rows past M are out of range of the LDS-DMA buffer descriptor), and a
@@ -73,7 +73,7 @@ def test_gemm_8phase_pipeline(gpu, dt, M, N, K, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 8, 10, 12])
+@pytest.mark.parametrize("cfg", [0, 8, 10, 12, 13])
 def test_gemm_epilogues(gpu, dt, cfg):
     M, N, K = 771, 512, 256
     _g = ops.gemm
@@ -132,6 +132,8 @@ def test_gemm_kernels_bit_identical(gpu, dt):
         o12 = ops.gemm(a, w, epi, bias=bias, cfg=12)
         ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10          # one unit in the last place at the top of the output range
         assert (o12.float() - ref.float()).abs().max().item() <= ulp * ref.float().abs().max().item(), epi
+        for cfg in (13,):                                               # the other LDS-DMA schedules of id 12: same arithmetic, same bits
+            assert torch.equal(ops.gemm(a, w, epi, bias=bias, cfg=cfg), o12), (epi, cfg)
     # a grid that fills the chip (>= 192 tiles of 256 x 256): the default dispatch is id 12
     M2, N2 = 4099, 3072
     a2 = torch.randn(M2, K, generator=g).to(gpu, dt)
