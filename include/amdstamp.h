@@ -145,6 +145,27 @@ int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int 
                  int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
                  const float* pos, int np, int T, int P, float acc_scale, void* stream);
 
+/* LayerNorm folded into the GEMMs around it (tile encoder, round 2).  timm's Block computes x += proj(attn(norm1(x))); x += fc2(act(fc1(
+ * norm2(x)))) (reference extractors virchow2.py:29-30, uni2.py:32-43 -> timm VisionTransformer.forward).  With
+ *   W'[n][k] = W[n][k] * gamma[k] (re-rounded to the act dtype), colsum[n] = sum_k W'[n][k], bias'[n] = bias[n] + sum_k W[n][k] * beta[k]:
+ *   Linear(LayerNorm(x))[m][n] = rstd[m] * (sum_k x[m][k] W'[n][k] - mean[m] * colsum[n]) + bias'[n]
+ * so the GEMM can read the UN-normalised rows and apply the row statistics in its epilogue, and the stand-alone LayerNorm (one
+ * read of the fp32 residual stream + one write, 7 % of the ViT-L step) disappears:
+ *   producer form (epi = AMDS_EPI_RESIDUAL; bias, if any, and scale as in amds_gemm; acc_scale 1): besides out += ..., writes
+ *       xh      act dtype [M][ldo]: a 16-bit copy of the updated rows (the A operand of the next GEMM), and
+ *       rowpart fp32 [M][N/128][2]: (sum, sum of squares) of the updated rows per 128-column slab (amds_ln_rowstat adds the slabs);
+ *   consumer form (epi = BIAS / BIAS_GELU / SWIGLU; A = the 16-bit copy, W = W', bias = bias'):
+ *       out = act(acc * rowstat[m][0] + (colsum[n] * rowstat[m][1] + bias[n])),   rowstat fp32 [M][2] = (rstd, -mean * rstd).
+ * N % 256 == 0, K % 64 == 0 (the production kernel only).  Same arithmetic as LayerNorm-then-GEMM up to where the 16-bit rounding
+ * happens (x instead of the normalised x; W * gamma instead of W): equal error against fp32 when |mean| << std over a row. */
+int amds_gemm_lnfold(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi, void* out,
+                     long ldo, const float* bias, const float* scale, void* xh, float* rowpart, const float* rowstat,
+                     const float* colsum, void* stream);
+/* rowpart [M][NP][2] (NP = N/128 of the producer) -> rowstat [M][2] = (rstd, -mean * rstd) with biased variance over D columns */
+int amds_ln_rowstat(const float* rowpart, int M, int NP, int D, float eps, float* rowstat, void* stream);
+/* the first LayerNorm of a stack: x fp32 [M][D] (pitch ldx) -> xh act dtype [M][D] (pitch ldxh) + rowstat [M][2] */
+int amds_ln_stats_cast(const float* x, long ldx, int M, int D, float eps, void* xh, long ldxh, float* rowstat, int dtype, void* stream);
+
 /* Reorders the 2H rows of a SwiGLUPacked fc1 weight/bias so that gate/value columns of one hidden
  * unit land in the same MFMA lane: dst blocks of 32 rows alternate [gate 32j..][value 32j..].
  * H % 32 == 0. src/dst fp32 [2H][cols] (bias: cols = 1). */
@@ -213,6 +234,11 @@ typedef struct {
     const void*  fc1_w; const float* fc1_b;     /* GELU: [hidden][dim]; SwiGLU: [2*hidden][dim] block-interleaved */
     const void*  fc2_w; const float* fc2_b;     /* [dim][hidden_pad] */
     const float* ls2;
+    /* LayerNorm folded into the GEMMs (amds_gemm_lnfold), set in all blocks or in none.  When set, qkv_w / fc1_w hold W * gamma
+     * (ln1 / ln2) rounded to the act dtype, qkv_b / fc1_b hold b + W beta, these hold sum_k of the rounded W * gamma per output row
+     * (same row order as the weight, i.e. block-interleaved for SwiGLU), and ln1_* / ln2_* are not read. */
+    const float* qkv_colsum;                    /* [3*dim] or NULL */
+    const float* fc1_colsum;                    /* [hidden] / [2*hidden] or NULL */
 } amds_vit_block;
 
 typedef struct {

@@ -27,7 +27,7 @@ class VitCfg(C.Structure):
 class VitBlock(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_colsum", "fc1_colsum")]
 
 
 class VitWeights(C.Structure):
@@ -78,6 +78,9 @@ PROTOTYPES = {
     "amds_layernorm": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp]),
     "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_ex": (_i, [_i, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "amds_gemm_lnfold": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amds_ln_rowstat": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
+    "amds_ln_stats_cast": (_i, [_vp, _l, _i, _i, _f, _vp, _l, _vp, _i, _vp]),
     "amds_gemm_rowstream": (_i, [_vp, _l, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp]),
     "amds_swin_mlp96": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
     "amds_swin_mlp192_pack": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -262,6 +262,35 @@ extern "C" int amds_gemm_batched(const void* A, long lda, long bsA, const void* 
     return AMDS_ERR_INVALID;
 }
 
+// LayerNorm folded into the GEMMs around it (production kernel only): see include/amdstamp.h
+extern "C" int amds_gemm_lnfold(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi, void* out,
+                                long ldo, const float* bias, const float* scale, void* xh, float* rowpart, const float* rowstat,
+                                const float* colsum, void* stream) {
+    AMDS_REQUIRE(A && W && out, "amds_gemm_lnfold: null pointer");
+    AMDS_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 256 == 0, "amds_gemm_lnfold: needs K %% 64 == 0 and N %% 256 == 0 (M=%d N=%d K=%d)", M, N, K);
+    AMDS_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ldo % 4 == 0, "amds_gemm_lnfold: bad pitches");
+    AMDS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)xh & 15) == 0,
+                 "amds_gemm_lnfold: pointers must be 16-byte aligned");
+    const bool producer = xh || rowpart, consumer = rowstat || colsum;
+    AMDS_REQUIRE(producer != consumer, "amds_gemm_lnfold: either (xh, rowpart) [RESIDUAL] or (rowstat, colsum) [BIAS / BIAS_GELU / SWIGLU]");
+    if (producer) {
+        AMDS_REQUIRE(epi == AMDS_EPI_RESIDUAL && xh && rowpart, "amds_gemm_lnfold: the producer form is the RESIDUAL epilogue with xh AND rowpart");
+    } else {
+        AMDS_REQUIRE((epi == AMDS_EPI_BIAS || epi == AMDS_EPI_BIAS_GELU || epi == AMDS_EPI_SWIGLU) && rowstat && colsum && bias,
+                     "amds_gemm_lnfold: the consumer form is BIAS / BIAS_GELU / SWIGLU with rowstat, colsum AND bias");
+    }
+    if (M == 0) return AMDS_OK;
+    EpiArgs ep;
+    ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = scale; ep.pos = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.0f;
+    ep.xh = xh; ep.rowpart = rowpart; ep.rowstat = rowstat; ep.colsum = colsum;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);
+    if (dtype == AMDS_F16) return gemm_dispatch<f16>(12, epi, A, lda, W, ldw, M, N, K, ep, st);
+    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(12, epi, A, lda, W, ldw, M, N, K, ep, st);
+    set_error("amds_gemm_lnfold: bad dtype %d", dtype);
+    return AMDS_ERR_INVALID;
+}
+
 // tuning hook: explicit kernel id (see gemm_kernel.h)
 extern "C" int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype,
                             int epi, void* out, long ldo, const float* bias, const float* scale, const float* pos,

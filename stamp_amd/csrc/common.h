@@ -143,6 +143,18 @@ __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// Sum over the 32 lanes that share lane >> 5; every lane gets the total.  Every step is an XOR butterfly (lane ^ 1, ^ 2, ^ 7, ^ 15, ^ 16:
+// quad_perm, row_half_mirror, row_mirror, ds_swizzle -- five independent masks), so the association tree is a fixed partition of the
+// lanes into cosets and the result does not change when the values are permuted by lane -> lane ^ c.  The GEMM epilogue needs that:
+// it holds a row's columns in lane l31 ^ (row & 31), and a row's statistics must not depend on where the row sits in its tile.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                      // lane ^ 16
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

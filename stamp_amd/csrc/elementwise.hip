@@ -154,6 +154,56 @@ static int launch_ln(const float* x, long xs, const float* g, const float* b, vo
 }
 
 // ---------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs (amds_gemm_lnfold): the two small kernels around them
+// ---------------------------------------------------------------------------------------------
+// partial (sum, sum of squares) per 128-column slab [M][NP][2] -> (rstd, -mean * rstd) per row, slabs added in index order
+__global__ void __launch_bounds__(256) ln_rowstat_kernel(const float* __restrict__ rowpart, int M, int NP, float inv_d, float eps,
+                                                         float* __restrict__ rowstat) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    const f32x2* p = reinterpret_cast<const f32x2*>(rowpart) + (long)r * NP;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < NP; ++i) {
+        const f32x2 v = p[i];
+        s1 += v[0];
+        s2 += v[1];
+    }
+    const float mean = s1 * inv_d, var = fmaxf(s2 * inv_d - mean * mean, 0.f), rstd = rsqrtf(var + eps);
+    reinterpret_cast<f32x2*>(rowstat)[r] = f32x2{rstd, -mean * rstd};
+}
+
+// the first LayerNorm of a stack (its input does not come out of a RESIDUAL GEMM): x fp32 -> 16-bit copy + (rstd, -mean * rstd)
+template <typename TO, int MAXV>
+__global__ void __launch_bounds__(256) ln_stats_cast_kernel(const float* __restrict__ x, long xs, TO* __restrict__ y, long ys, int rows,
+                                                            int cols, float eps, float* __restrict__ rowstat) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * xs;
+    TO* yr = y + (long)row * ys;
+    const int nv = cols >> 2;
+    typedef TO vec4 __attribute__((ext_vector_type(4)));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s1 += (v[0] + v[1]) + (v[2] + v[3]);
+            s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+            vec4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (TO)v[e];
+            *reinterpret_cast<vec4*>(yr + c * 4) = w;
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float mean = s1 / (float)cols, var = fmaxf(s2 / (float)cols - mean * mean, 0.f), rstd = rsqrtf(var + eps);
+    if (lane == 0) reinterpret_cast<f32x2*>(rowstat)[row] = f32x2{rstd, -mean * rstd};
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 -> act dtype cast with zero padding of the trailing columns (weight packing, one time)
 // ---------------------------------------------------------------------------------------------
 template <typename TO>
@@ -358,5 +408,34 @@ extern "C" int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int i
         hipLaunchKernelGGL((im2col_u8_kernel<bf16>), dim3(B * g), dim3(256), lds, st, tiles, (bf16*)out, img, patch, kp);
     else { set_error("amds_tile_im2col_u8: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("im2col_u8_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_ln_rowstat(const float* rowpart, int M, int NP, int D, float eps, float* rowstat, void* stream) {
+    AMDS_REQUIRE(rowpart && rowstat && M >= 0 && NP > 0 && D > 0, "amds_ln_rowstat: bad arguments");
+    if (M == 0) return AMDS_OK;
+    ProfScope prof(PROF_LN, (double)M * (NP * 8.0 + 8.0), (hipStream_t)stream);
+    hipLaunchKernelGGL(ln_rowstat_kernel, dim3(cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, rowpart, M, NP, 1.0f / (float)D, eps, rowstat);
+    AMDS_LAUNCH_CHECK("ln_rowstat_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_ln_stats_cast(const float* x, long ldx, int M, int D, float eps, void* xh, long ldxh, float* rowstat, int dtype,
+                                  void* stream) {
+    AMDS_REQUIRE(x && xh && rowstat && M >= 0, "amds_ln_stats_cast: bad arguments");
+    AMDS_REQUIRE(D > 0 && D % 4 == 0 && D <= 64 * 4 * 8 && ldx % 4 == 0 && ldxh % 4 == 0, "amds_ln_stats_cast: D=%d must be a multiple of 4, at most 2048", D);
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_ln_stats_cast: bad dtype %d", dtype);
+    if (M == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_LN, (double)M * D * 6.0, st);
+    const int grid = cdiv(M, 4);
+    if (dtype == AMDS_F16) {
+        if (D <= 1024) hipLaunchKernelGGL((ln_stats_cast_kernel<f16, 4>), dim3(grid), dim3(256), 0, st, x, ldx, (f16*)xh, ldxh, M, D, eps, rowstat);
+        else hipLaunchKernelGGL((ln_stats_cast_kernel<f16, 8>), dim3(grid), dim3(256), 0, st, x, ldx, (f16*)xh, ldxh, M, D, eps, rowstat);
+    } else {
+        if (D <= 1024) hipLaunchKernelGGL((ln_stats_cast_kernel<bf16, 4>), dim3(grid), dim3(256), 0, st, x, ldx, (bf16*)xh, ldxh, M, D, eps, rowstat);
+        else hipLaunchKernelGGL((ln_stats_cast_kernel<bf16, 8>), dim3(grid), dim3(256), 0, st, x, ldx, (bf16*)xh, ldxh, M, D, eps, rowstat);
+    }
+    AMDS_LAUNCH_CHECK("ln_stats_cast_kernel");
     return AMDS_OK;
 }

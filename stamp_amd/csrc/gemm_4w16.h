@@ -112,7 +112,8 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     // The accumulators start from the bias (when there is one and acc_scale == 1): the epilogue then has no bias add (128 packed
     // adds per tile) and no bias loads to wait for; the 8 vectors are requested here and land under the first K tile's DMA.
-    const bool bias_in_acc = ep.bias != nullptr && ep.acc_scale == 1.0f;
+    const bool lnf = ep.rowstat != nullptr;        // LayerNorm folded in: out = act(acc * rstd[m] + (colsum[n] * nmr[m] + bias[n]))
+    const bool bias_in_acc = ep.bias != nullptr && ep.acc_scale == 1.0f && !lnf;
     f32x4 acc[FI][FJ];
     {
         f32x4 b0[FJ];
@@ -277,6 +278,23 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     int kt = 0;
     for (; kt < nk - 2; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
     if (nk >= 2) k_tile(kt++, std::true_type{}, std::false_type{});
+    // LayerNorm-folded consumer: per-row (rstd, -mean*rstd) of this lane's 8 rows and the per-column (bias, colsum) vectors are
+    // requested before the last K tile (which issues no LDS-DMA and waits for none), so the epilogue finds them in registers.
+    constexpr bool LNC = (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_SWIGLU);
+    f32x2 rs[LNC ? FI : 1];
+    f32x4 cb[LNC ? FJ : 1], cs[LNC ? FJ : 1];
+    if constexpr (LNC) {
+        if (lnf) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+                rs[i] = *reinterpret_cast<const f32x2*>(ep.rowstat + 2 * (long)min(m0 + wm * 128 + i * 16 + l15, M - 1));
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                cb[j] = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + j * 16 + 4 * kb);
+                cs[j] = *reinterpret_cast<const f32x4*>(ep.colsum + n0 + wn * 128 + j * 16 + 4 * kb);
+            }
+        }
+    }
     k_tile(kt, std::false_type{}, std::false_type{});
     AMDS_BARRIER();                 // every wave is done with the LDS stages
 #undef AMDS_BARRIER
@@ -312,7 +330,10 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     f32x4 gt = agpr_read(acc[i][4 * q + t]), vl = agpr_read(acc[i][4 * q + 2 + t]);
-                    if (!bias_in_acc) {
+                    if (lnf) {
+                        gt = gt * rs[i][0] + (cs[4 * q + t] * rs[i][1] + cb[4 * q + t]);
+                        vl = vl * rs[i][0] + (cs[4 * q + 2 + t] * rs[i][1] + cb[4 * q + 2 + t]);
+                    } else if (!bias_in_acc) {
                         const f32x4 bg = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + (4 * q + t) * 16 + 4 * kb);
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + (4 * q + 2 + t) * 16 + 4 * kb);
                         gt = gt * as + bg;
@@ -356,8 +377,12 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     offu[h][u] = (wave * 64 + 2 * u + hi) * ldo4 + (((l31 >> 4) ^ h) << 9) + (((l31 & 15) ^ (2 * u + hi)) << 4);
-            auto run = [&](auto has_scale_c) {
-                constexpr bool HS = decltype(has_scale_c)::value;
+            const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(
+                ep.xh ? reinterpret_cast<T*>(ep.xh) + (long)m0 * ep.ldo + n0 : reinterpret_cast<T*>(ep.out), 0,
+                ep.xh ? (int)((((long)rows_o - 1) * ep.ldo + BN) * 2) : 0, 0x00020000);
+            const int np_part = N / 128;
+            auto run = [&](auto has_scale_c, auto lnp_c) {
+                constexpr bool HS = decltype(has_scale_c)::value, LNP = decltype(lnp_c)::value;
                 f32x4 sc[4];
                 auto load_scale = [&](int pass) {
                     if constexpr (HS) {
@@ -403,6 +428,27 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                             v[u] += old[b8][u];
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rsrc_o, offu[b8 & 1][u] + rowoff, 0, 0);
                         }
+                        if constexpr (LNP) {
+                            // 16-bit copy of the updated rows + this pass's partial row sums (the LayerNorm that follows is folded into
+                            // the next GEMM, which reads the copy as its A operand)
+                            float s1[8], s2[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const vec4 c = Act<T>::from_f32x4(v[u]);
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c), rsrc_h, (offu[b8 & 1][u] + rowoff) >> 1, 0, 0);
+                                s1[u] = half_wave_sum((v[u][0] + v[u][1]) + (v[u][2] + v[u][3]));
+                                s2[u] = half_wave_sum(fmaf(v[u][0], v[u][0], v[u][1] * v[u][1]) + fmaf(v[u][2], v[u][2], v[u][3] * v[u][3]));
+                            }
+                            float m1 = s1[0], m2 = s2[0];
+#pragma unroll
+                            for (int u = 1; u < 8; ++u) {
+                                m1 = (l31 == u) ? s1[u] : m1;
+                                m2 = (l31 == u) ? s2[u] : m2;
+                            }
+                            const int prow = m0 + wave * 64 + b8 * 16 + 2 * l31 + hi;           // lanes l31 < 8: row of (b8, u = l31, hi)
+                            if (l31 < 8 && prow < M)
+                                *reinterpret_cast<f32x2*>(ep.rowpart + ((long)prow * np_part + tn * 2 + pass) * 2) = f32x2{m1, m2};
+                        }
                         if (pass == 0) load_old(1, b8);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -414,7 +460,11 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                     }
                 }
             };
-            if (ep.scale) run(std::true_type{}); else run(std::false_type{});
+            if (ep.xh) {
+                if (ep.scale) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{});
+            } else {
+                if (ep.scale) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{});
+            }
             return;
         }
     }
@@ -424,7 +474,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     for (int pass = 0; pass < NPASS; ++pass) {
         if (pass) __syncthreads();
         EpiArgs epv = ep;                           // what the value transform still has to apply
-        if (bias_in_acc) epv.bias = nullptr;
+        if (bias_in_acc || lnf) epv.bias = nullptr;
         EpiCols<JP> cols;                           // [jj]: columns n0 + wn*128 + 16 (pass*JP + jj) + 4 kb
         epi_cols_load<EPI>(epv, cols, [&](int jj) { return n0 + wn * 128 + (pass * JP + jj) * 16 + 4 * kb; });
         auto values = [&](auto fast_c) {
@@ -452,7 +502,28 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                 }
             }
         };
-        if (F16OUT && (bias_in_acc || (ep.bias == nullptr && ep.acc_scale == 1.0f))) values(std::true_type{}); else values(std::false_type{});
+        auto values_ln = [&]() {
+            if constexpr (LNC && F16OUT) {
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    const int row = wm * 128 + i * 16 + l15;
+#pragma unroll
+                    for (int j = 0; j < FJ; j += 2) {
+                        f32x4 v0 = agpr_read(acc[i][j]), v1 = agpr_read(acc[i][j + 1]);
+                        v0 = v0 * rs[i][0] + (cs[j] * rs[i][1] + cb[j]);
+                        v1 = v1 * rs[i][0] + (cs[j + 1] * rs[i][1] + cb[j + 1]);
+                        epi_value_pair<EPI, true, true>(epv, cb[j], cb[j], cb[j + 1], cb[j + 1], v0, v1);      // activation only
+                        const vec4 o0 = Act<T>::from_f32x4(v0), o1 = Act<T>::from_f32x4(v1);
+                        const int chunk = wn * 16 + j * 2 + (kb >> 1);
+                        const int half = ((kb & 1) ^ ((l15 >> 3) & 1)) * 8;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + half) = o0;
+                        *reinterpret_cast<vec4*>(smem + row * 512 + (((chunk + 2) ^ (row & 31)) << 4) + half) = o1;
+                    }
+                }
+            }
+        };
+        if (LNC && F16OUT && lnf) values_ln();
+        else if (F16OUT && (bias_in_acc || (ep.bias == nullptr && ep.acc_scale == 1.0f))) values(std::true_type{}); else values(std::false_type{});
         __syncthreads();
         // one wave per SIMD: batch 8 rows (reads first, then the stores) so the LDS / L2 latencies overlap
 #pragma unroll 1

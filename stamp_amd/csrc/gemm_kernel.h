@@ -36,6 +36,14 @@ struct EpiArgs {
     // batched / split-K launches (gridDim.y = batch count): element strides added per batch index
     long bsA = 0, bsW = 0, bsOut = 0;
     int nbatch = 1;
+    // LayerNorm folded into the GEMMs around it (gemm_4w16.h only; amds_gemm_lnfold):
+    //   producer (RESIDUAL): xh = 16-bit copy of the updated rows (pitch ldo elements), rowpart = [M][N/128][2] partial (sum, sum of squares)
+    //   consumer (BIAS / BIAS_GELU / SWIGLU): rowstat = [M][2] (rstd, -mean*rstd), colsum = [N] sum_k W'[n][k]:
+    //       out = act( acc * rstd[m] + (colsum[n] * (-mean*rstd)[m] + bias[n]) )
+    void* xh = nullptr;
+    float* rowpart = nullptr;
+    const float* rowstat = nullptr;
+    const float* colsum = nullptr;
 };
 
 template <int EPI>

@@ -7,6 +7,11 @@
 //   h   = LN2(x)
 //   u   = gelu(h W1^T + b1) | silu(g)*v                         (MFMA GEMM, EPI_BIAS_GELU / EPI_SWIGLU)
 //   x  += ls2 * (u W2^T + b2)                                   (MFMA GEMM, EPI_RESIDUAL)
+// With LayerNorm folded into the GEMMs (blocks carry qkv_colsum / fc1_colsum; include/amdstamp.h, amds_gemm_lnfold) the two
+// layernorm launches of a block disappear: the proj / fc2 epilogues also write a 16-bit copy of the rows they update plus partial
+// row sums, amds_ln_rowstat turns those into (rstd, -mean*rstd) per row, and the qkv / fc1 GEMMs read the copy with W * gamma as
+// weights and apply the row statistics in their epilogues.  Only the first LayerNorm of the stack needs its own (statistics + cast)
+// launch, and the final norm stays a LayerNorm kernel.
 // The residual stream x stays fp32 in HBM for the whole depth (the reference computes in fp32,
 // src/stamp/preprocessing/__init__.py:324-325); only MFMA operands are rounded to the act dtype.
 #include "common.h"
@@ -16,7 +21,7 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
 
 struct VitPlan {
     int np, T, kp, dim, hidden;
-    size_t off_x, off_h, off_qkv, off_mlp, total;
+    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -45,6 +50,10 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     p->off_qkv = o; o += align256(rows * 3 * c->dim * 2);
     const size_t mlp_b = rows * c->hidden * 2, pm_b = (size_t)batch * p->np * p->kp * 2;
     p->off_mlp = o; o += align256(mlp_b > pm_b ? mlp_b : pm_b);
+    // LayerNorm-folded path: second 16-bit row buffer, partial row sums per 128-column slab, final row statistics
+    p->off_h2 = o;      o += align256(rows * c->dim * 2);
+    p->off_rowpart = o; o += align256(rows * (size_t)(c->dim / 128) * 2 * 4);
+    p->off_rowstat = o; o += align256(rows * 2 * 4);
     p->total = o;
     return AMDS_OK;
 }
@@ -72,7 +81,40 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     if (c->n_prefix > 0) AMDS_TRY(prefix_init(w->prefix, x, Bc, T, c->n_prefix, D, st));
     AMDS_TRY(amds_gemm(mlp, pl.kp, w->patch_w, pl.kp, Bc * pl.np, D, pl.kp, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
                        nullptr, w->pos_patch, pl.np, T, c->n_prefix, 1.0f / 255.0f, st));
+    // LayerNorm folded into the GEMMs: all blocks or none (a mixed stack would be a packing error)
+    bool fold = w->blocks_host[0].qkv_colsum != nullptr;
     for (int l = 0; l < c->depth; ++l) {
+        const amds_vit_block& b = w->blocks_host[l];
+        AMDS_REQUIRE((b.qkv_colsum != nullptr) == fold && (b.fc1_colsum != nullptr) == fold, "vit: block %d: qkv_colsum / fc1_colsum must be set in all blocks or in none", l);
+    }
+    if (fold) {
+        const int n_fc1 = c->mlp_kind == 0 ? c->hidden : 2 * c->hidden;
+        AMDS_REQUIRE(D % 256 == 0 && n_fc1 % 256 == 0, "vit: the LayerNorm-folded path needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", D, n_fc1);
+        void* h2 = ws + pl.off_h2;
+        float* rowpart = reinterpret_cast<float*>(ws + pl.off_rowpart);
+        float* rowstat = reinterpret_cast<float*>(ws + pl.off_rowstat);
+        const int NP = D / 128;
+        AMDS_TRY(amds_ln_stats_cast(x, D, M, D, c->ln_eps, h, D, rowstat, dt, st));
+        for (int l = 0; l < c->depth; ++l) {
+            const amds_vit_block& b = w->blocks_host[l];
+            AMDS_TRY(amds_gemm_lnfold(h, D, b.qkv_w, D, M, 3 * D, D, dt, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rowstat,
+                                      b.qkv_colsum, st));
+            AMDS_TRY(amds_attention_vit_hd(qkv, h, Bc, T, c->heads, D / c->heads, dt, st));
+            AMDS_TRY(amds_gemm_lnfold(h, D, b.proj_w, D, M, D, D, dt, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr, h2,
+                                      rowpart, nullptr, nullptr, st));
+            AMDS_TRY(amds_ln_rowstat(rowpart, M, NP, D, c->ln_eps, rowstat, st));
+            AMDS_TRY(amds_gemm_lnfold(h2, D, b.fc1_w, D, M, n_fc1, D, dt, c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU, mlp, c->hidden,
+                                      b.fc1_b, nullptr, nullptr, nullptr, rowstat, b.fc1_colsum, st));
+            if (l + 1 < c->depth) {
+                AMDS_TRY(amds_gemm_lnfold(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, dt, AMDS_EPI_RESIDUAL, x, D, b.fc2_b,
+                                          c->layerscale ? b.ls2 : nullptr, h, rowpart, nullptr, nullptr, st));
+                AMDS_TRY(amds_ln_rowstat(rowpart, M, NP, D, c->ln_eps, rowstat, st));
+            } else {
+                AMDS_TRY(enc_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr));
+            }
+        }
+    }
+    for (int l = 0; l < (fold ? 0 : c->depth); ++l) {
         const amds_vit_block& b = w->blocks_host[l];
         AMDS_TRY(amds_layernorm(x, D, b.ln1_w, b.ln1_b, h, D, M, D, c->ln_eps, dt, st));
         AMDS_TRY(enc_gemm(h, D, b.qkv_w, D, M, 3 * D, D, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr));

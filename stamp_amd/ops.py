@@ -85,6 +85,44 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, *, bias=None, scale=None, o
     return out
 
 
+def gemm_lnfold(a: torch.Tensor, w: torch.Tensor, epi: int, *, out=None, bias=None, scale=None, xh=None, rowpart=None, rowstat=None,
+                colsum=None) -> torch.Tensor:
+    """LayerNorm folded into the GEMMs around it (include/amdstamp.h, amds_gemm_lnfold): producer form (RESIDUAL: `xh`, `rowpart`
+    filled besides out += ...) or consumer form (BIAS / BIAS_GELU / SWIGLU with `rowstat`, `colsum`)."""
+    _dev(a, w, out, bias, scale, xh, rowpart, rowstat, colsum)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype
+    if out is None:
+        assert epi != _lib.EPI_RESIDUAL
+        out = torch.empty(M, N // 2 if epi == _lib.EPI_SWIGLU else N, dtype=a.dtype, device=a.device)
+    if xh is not None:
+        assert xh.dtype == a.dtype and xh.stride(0) == out.stride(0) and rowpart.shape == (M, N // 128, 2) and rowpart.is_contiguous()
+    _lib.check(_lib.lib().amds_gemm_lnfold(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, act_code(a.dtype), epi, _p(out), out.stride(0),
+                                           _p(bias), _p(scale), _p(xh), _p(rowpart), _p(rowstat), _p(colsum), _stream()), "gemm_lnfold")
+    return out
+
+
+def ln_rowstat(rowpart: torch.Tensor, D: int, eps: float) -> torch.Tensor:
+    """[M, NP, 2] partial (sum, sum of squares) -> [M, 2] (rstd, -mean * rstd)."""
+    _dev(rowpart)
+    assert rowpart.dtype == torch.float32 and rowpart.is_contiguous() and rowpart.dim() == 3 and rowpart.shape[2] == 2
+    out = torch.empty(rowpart.shape[0], 2, dtype=torch.float32, device=rowpart.device)
+    _lib.check(_lib.lib().amds_ln_rowstat(_p(rowpart), rowpart.shape[0], rowpart.shape[1], D, eps, _p(out), _stream()), "ln_rowstat")
+    return out
+
+
+def ln_stats_cast(x: torch.Tensor, eps: float, dtype: torch.dtype) -> tuple[torch.Tensor, torch.Tensor]:
+    """fp32 rows -> (16-bit copy, [M, 2] (rstd, -mean * rstd)): the first LayerNorm of a stack in the folded form."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, D = x.shape
+    xh = torch.empty(M, D, dtype=dtype, device=x.device)
+    rs = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_ln_stats_cast(_p(x), x.stride(0), M, D, eps, _p(xh), D, _p(rs), act_code(dtype), _stream()), "ln_stats_cast")
+    return xh, rs
+
+
 def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64) -> torch.Tensor:
     _dev(qkv)
     assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * head_dim)

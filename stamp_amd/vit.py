@@ -13,6 +13,7 @@ up with: virchow2.py:34-39, uni2.py:17-34, reddino.py:40-45, uni.py:26-31).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field, replace
 
 import torch
@@ -146,7 +147,7 @@ class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
-                 act_dtype: torch.dtype = torch.float16, chunk: int = 1020) -> None:
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None) -> None:
         super().__init__()
         if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
             raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
@@ -160,6 +161,15 @@ class HipViT(nn.Module):
         _lib.lib()  # fail early and loudly if the extension is missing
         self._keep: list[torch.Tensor] = []
         self._ws: torch.Tensor | None = None
+        # LayerNorm folded into the qkv / fc1 GEMMs (include/amdstamp.h, amds_gemm_lnfold): default on where the shapes allow it
+        # (every preset); AMDS_VIT_LNFOLD=0 or ln_fold=False packs the plain weights and runs the stand-alone LayerNorm kernels (A/B).
+        n_fc1 = cfg.hidden_pad * (2 if cfg.mlp == "swiglu" else 1)
+        can_fold = cfg.dim % 256 == 0 and n_fc1 % 256 == 0
+        if ln_fold is None:
+            ln_fold = can_fold and os.environ.get("AMDS_VIT_LNFOLD", "1") != "0"
+        if ln_fold and not can_fold:
+            raise ValueError(f"ln_fold needs dim % 256 == 0 and fc1 rows % 256 == 0 (dim={cfg.dim}, fc1 rows={n_fc1})")
+        self.ln_fold = bool(ln_fold)
         self._pack(state_dict)
 
     # -- weight packing (one time) ----------------------------------------------------------------
@@ -176,6 +186,15 @@ class HipViT(nn.Module):
         out = ops.cast_pad(w, ld or w.shape[1], self.act_dtype)
         self._keep.append(out)
         return out
+
+    def _folded(self, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+        """Linear(LayerNorm(x)) with the LayerNorm's affine part moved into the Linear: (W * gamma rounded to the act dtype, b + W beta,
+        row sums of the ROUNDED W * gamma) -- the row sums must describe the weights the MFMAs actually see."""
+        gamma, beta = gamma.detach().to(self.device_, torch.float64), beta.detach().to(self.device_, torch.float64)
+        w64 = w.detach().to(self.device_, torch.float64)
+        wf = ops.cast_pad((w64 * gamma[None, :]).float().contiguous(), w.shape[1], self.act_dtype)
+        bf = (b.detach().to(self.device_, torch.float64) + w64 @ beta).float()
+        return wf, bf, wf.double().sum(1).float()
 
     def _pack(self, sd: dict[str, torch.Tensor]) -> None:
         c = self.cfg
@@ -215,7 +234,13 @@ class HipViT(nn.Module):
             b = blocks[i]
             b.ln1_w, b.ln1_b = self._f32(g("norm1.weight")).data_ptr(), self._f32(g("norm1.bias")).data_ptr()
             b.ln2_w, b.ln2_b = self._f32(g("norm2.weight")).data_ptr(), self._f32(g("norm2.bias")).data_ptr()
-            b.qkv_w, b.qkv_b = self._act(g("attn.qkv.weight")).data_ptr(), self._f32(g("attn.qkv.bias")).data_ptr()
+            if self.ln_fold:
+                wq, bq, cq = self._folded(g("attn.qkv.weight"), g("attn.qkv.bias"), g("norm1.weight"), g("norm1.bias"))
+                self._keep.append(wq)
+                b.qkv_w, b.qkv_b, b.qkv_colsum = wq.data_ptr(), self._f32(bq).data_ptr(), self._f32(cq).data_ptr()
+            else:
+                b.qkv_w, b.qkv_b = self._act(g("attn.qkv.weight")).data_ptr(), self._f32(g("attn.qkv.bias")).data_ptr()
+                b.qkv_colsum = None
             b.proj_w, b.proj_b = self._act(g("attn.proj.weight")).data_ptr(), self._f32(g("attn.proj.bias")).data_ptr()
             w1, b1 = g("mlp.fc1.weight").detach().float().to(dev), g("mlp.fc1.bias").detach().float().to(dev)
             w2, b2 = g("mlp.fc2.weight").detach().float().to(dev), g("mlp.fc2.bias").detach().float().to(dev)
@@ -227,11 +252,20 @@ class HipViT(nn.Module):
                 w1p[:H], w1p[Hp:Hp + H] = w1[:H], w1[H:]
                 b1p = b1.new_zeros(2 * Hp)
                 b1p[:H], b1p[Hp:Hp + H] = b1[:H], b1[H:]
-                w1 = ops.pack_swiglu_rows(w1p)
-                b1 = ops.pack_swiglu_rows(b1p.reshape(-1, 1)).reshape(-1)
+                w1, b1 = w1p, b1p
             else:
                 assert w1.shape[0] == c.hidden and c.hidden % 128 == 0
+            c1 = None
+            if self.ln_fold:
+                w1, b1, c1 = self._folded(w1, b1, g("norm2.weight"), g("norm2.bias"))       # w1: act dtype from here on
+            if c.mlp == "swiglu":
+                # block-interleave gate / value rows in the library (fp32 round trip of 16-bit values is exact)
+                w1 = ops.pack_swiglu_rows(w1.float())
+                b1 = ops.pack_swiglu_rows(b1.reshape(-1, 1)).reshape(-1)
+                if c1 is not None:
+                    c1 = ops.pack_swiglu_rows(c1.reshape(-1, 1)).reshape(-1)
             b.fc1_w, b.fc1_b = self._act(w1).data_ptr(), self._f32(b1).data_ptr()
+            b.fc1_colsum = self._f32(c1).data_ptr() if c1 is not None else None
             b.fc2_w, b.fc2_b = self._act(w2, ld=Hp).data_ptr(), self._f32(b2).data_ptr()
             if c.layerscale:
                 b.ls1, b.ls2 = self._f32(g("ls1.gamma")).data_ptr(), self._f32(g("ls2.gamma")).data_ptr()

@@ -294,3 +294,74 @@ def test_errors_are_values(gpu):
         ops.attention_vit(torch.zeros(400, 192, dtype=torch.float16, device=gpu), 1, 400, 1)
     with pytest.raises(RuntimeError, match="GPU"):
         ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,use_scale", [(1000, 1024, 320, True), (515, 512, 1024, False), (256, 256, 64, True)])
+def test_gemm_lnfold_producer(gpu, dt, M, N, K, use_scale):
+    """amds_gemm_lnfold, producer form: the fp32 rows are updated exactly as by the plain RESIDUAL epilogue; xh is their 16-bit
+    rounding; rowpart holds (sum, sum of squares) per 128-column slab -- slab (tile tn, pass p) = columns tn*256 + {64p .. 64p+63} and
+    tn*256 + 128 + {64p .. 64p+63} -- and amds_ln_rowstat turns them into (rstd, -mean*rstd)."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(gpu, dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, dt)
+    bias = torch.randn(N, generator=g).to(gpu)
+    scale = (0.5 + torch.rand(N, generator=g)).to(gpu) if use_scale else None
+    x0 = torch.randn(M, N, generator=g).to(gpu)
+    ref = x0.clone()
+    ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=bias, scale=scale, out=ref, cfg=12)
+    x = x0.clone()
+    xh = torch.full((M, N), 7.0, dtype=dt, device=gpu)
+    rowpart = torch.full((M, N // 128, 2), -1.0, device=gpu)
+    ops.gemm_lnfold(a, w, _lib.EPI_RESIDUAL, out=x, bias=bias, scale=scale, xh=xh, rowpart=rowpart)
+    assert torch.equal(x, ref)
+    assert torch.equal(xh, ref.to(dt))
+    cols = ref.view(M, N // 256, 2, 2, 64)                       # [tile, 128-half, pass, 64]
+    slab = cols.permute(0, 1, 3, 2, 4).reshape(M, N // 128, 128).double()
+    want = torch.stack([slab.sum(-1), (slab * slab).sum(-1)], -1)
+    assert torch.allclose(rowpart.double(), want, rtol=2e-5, atol=1e-3)
+    rs = ops.ln_rowstat(rowpart, N, 1e-6)
+    mean = ref.double().mean(1)
+    rstd = 1.0 / torch.sqrt(ref.double().var(1, unbiased=False) + 1e-6)
+    assert torch.allclose(rs[:, 0].double(), rstd, rtol=1e-4)
+    assert torch.allclose(rs[:, 1].double(), -mean * rstd, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "swiglu"])
+def test_gemm_lnfold_consumer(gpu, dt, epi):
+    """amds_gemm_lnfold, consumer form, against Linear(LayerNorm(x)) in fp64: the folded GEMM reads the un-normalised 16-bit rows and
+    W * gamma; it must be as close to the exact result as the LayerNorm-then-GEMM chain it replaces (both round to 16 bits once)."""
+    g = torch.Generator().manual_seed(8)
+    M, D, N = 777, 512, 1024
+    x = (torch.randn(M, D, generator=g) * 3.0 + 0.4).to(gpu)
+    x[:, 7] *= 40.0                                                      # one massive channel, as real ViT residual streams have
+    gamma = (1.0 + 0.3 * torch.randn(D, generator=g)).to(gpu)
+    beta = (0.2 * torch.randn(D, generator=g)).to(gpu)
+    W = (torch.randn(N, D, generator=g) / D ** 0.5).to(gpu)
+    b = (0.1 * torch.randn(N, generator=g)).to(gpu)
+    y64 = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6) @ W.double().t() + b.double()
+    if epi == "swiglu":
+        H = N // 2
+        want = torch.nn.functional.silu(y64[:, :H]) * y64[:, H:]
+        Wp, bp = ops.pack_swiglu_rows(W), ops.pack_swiglu_rows(b.view(-1, 1)).view(-1)
+    else:
+        want = torch.nn.functional.gelu(y64) if epi == "gelu" else y64
+        Wp, bp = W, b
+    code = {"bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU, "swiglu": _lib.EPI_SWIGLU}[epi]
+    # the chain it replaces
+    h = ops.layernorm(x, gamma, beta, 1e-6, dt)
+    chain = ops.gemm(h, Wp.to(dt), code, bias=bp, cfg=12).double()
+    # folded
+    Wf = (Wp * gamma[None, :]).to(dt)
+    colsum = Wf.float().sum(1)
+    bf = bp + Wp @ beta
+    xh, rs = ops.ln_stats_cast(x, 1e-6, dt)
+    assert torch.equal(xh, x.to(dt))
+    got = ops.gemm_lnfold(xh, Wf, code, bias=bf, rowstat=rs, colsum=colsum).double()
+    e_chain = ((chain - want).norm() / want.norm()).item()
+    e_fold = ((got - want).norm() / want.norm()).item()
+    tol = 6e-3 if dt == torch.bfloat16 else 8e-4
+    assert e_fold < tol and e_fold < 1.5 * e_chain + 1e-4, (e_fold, e_chain)
