@@ -370,6 +370,16 @@ def main() -> None:
                 break
             except Exception:
                 traffic = None
+    alg_bytes = None
+    if not is_swin:
+        # algorithmic HBM bytes per GEMM launch, averaged over the four launches of a block (operands once, fp32 residual rows read +
+        # written, outputs once; with the LayerNorm folded in, proj / fc2 also write the 16-bit copy of the rows)
+        Mrows, Dm, Hd = min(a.chunk, a.tiles) * cfg.tokens, cfg.dim, cfg.hidden_pad
+        n1 = Hd * (2 if cfg.mlp == "swiglu" else 1)
+        fold = 2 * Mrows * Dm if getattr(model, "ln_fold", False) else 0
+        per = [2 * Mrows * Dm + 2 * 3 * Dm * Dm + 2 * Mrows * 3 * Dm, 2 * Mrows * Dm + 2 * Dm * Dm + 8 * Mrows * Dm + fold,
+               2 * Mrows * Dm + 2 * n1 * Dm + 2 * Mrows * Hd, 2 * Mrows * Hd + 2 * Dm * Hd + 8 * Mrows * Dm + fold]
+        alg_bytes = sum(per) / 4
     line = {
         "metric": "tiles/sec encoded (224x224, ViT-L/14)" if a.model == "vit_large_patch14_224" else f"tiles/sec encoded (224x224, {a.model})", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -386,11 +396,13 @@ def main() -> None:
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
         "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles where N is not a multiple of 256, gemm_4w16_kernel in stage 4 and the stage-3 MLP)" if is_swin else
-                               "gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues)", "bound": "mfma",
+                               ("gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues"
+                                + ("; LayerNorm folded in: proj / fc2 also emit a 16-bit row copy + row sums, qkv / fc1 apply the row statistics" if getattr(model, "ln_fold", False) else "") + ")"), "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": (f"HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/{pmc_name}); "
-                                      "algorithmic 2.97e9 at this chunk (1020 tiles, M = 262140)") if traffic else None,
+                                      f"algorithmic {alg_bytes:.3g} at this chunk ({min(a.chunk, a.tiles)} tiles)") if traffic else None,
+                     "algorithmic_bytes_per_launch": round(alg_bytes) if alg_bytes else None,
                      "launches": gn, "avg_launch_us": round(gms / max(gn, 1) * 1e3, 2),
                      "avg_gflop_per_launch": round(gflop / max(gn, 1) / 1e9, 2),
                      "time_share": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kinds.items()}},
