@@ -151,6 +151,9 @@ extern "C" void amds_destroy(amds_ctx* c) {
 
 extern "C" int amds_ctx_device(const amds_ctx* c) { return c ? c->device : -1; }
 
+// the context of the calling thread's current device, if the host created one (amds_create); nullptr otherwise
+amds_ctx* amds::ctx_of_current_device() { return current_ctx(); }
+
 // side stream + fork / join events of the overlapped schedule, created on first use on the context's device
 int amds::ctx_side_stream(amds_ctx* c, hipStream_t* side, hipEvent_t* ev_in, hipEvent_t* ev_out) {
     AMDS_REQUIRE(c, "null context");

@@ -215,6 +215,7 @@ extern std::atomic<int> g_prof_any;            // number of contexts whose profi
 int prof_begin(int kind, double work, hipStream_t st, amds_ctx** ctx_out);
 void prof_end(amds_ctx* ctx, int slot, hipStream_t st);
 int ctx_side_stream(amds_ctx* c, hipStream_t* side, hipEvent_t* ev_in, hipEvent_t* ev_out);
+amds_ctx* ctx_of_current_device();
 struct ProfScope {
     hipStream_t st; amds_ctx* ctx = nullptr; int slot = -1;
     ProfScope(int kind, double work, hipStream_t s) : st(s) { if (g_prof_any.load(std::memory_order_relaxed) > 0) slot = prof_begin(kind, work, s, &ctx); }

@@ -58,13 +58,23 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     return AMDS_OK;
 }
 
+// Side stream + fork / join events for the ragged-tail schedule below (nullptr side = single stream).
+struct VitSide {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
 static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const VitPlan& pl, const uint8_t* tiles,
-                     void* feats_f16, float* tokens_f32, int Bc, char* ws, hipStream_t st) {
+                     void* feats_f16, float* tokens_f32, int Bc, char* ws, hipStream_t st, const VitSide& sd = VitSide()) {
     float* x = reinterpret_cast<float*>(ws + pl.off_x);
-    void* h = ws + pl.off_h;
-    void* qkv = ws + pl.off_qkv;
-    void* mlp = ws + pl.off_mlp;
-    const int D = c->dim, T = pl.T, M = Bc * T, dt = c->dtype;
+    char* h = ws + pl.off_h;
+    char* qkv = ws + pl.off_qkv;
+    char* mlp = ws + pl.off_mlp;
+    char* h2 = ws + pl.off_h2;
+    float* rowpart = reinterpret_cast<float*>(ws + pl.off_rowpart);
+    float* rowstat = reinterpret_cast<float*>(ws + pl.off_rowstat);
+    const int D = c->dim, T = pl.T, M = Bc * T, dt = c->dtype, Hd = c->hidden, NP = D / 128;
+    const int n_fc1 = c->mlp_kind == 0 ? Hd : 2 * Hd;
     int rc;
 #define AMDS_TRY(call) do { rc = (call); if (rc != AMDS_OK) return rc; } while (0)
     // One kernel family per GEMM whatever the batch: a tile's features must not depend on which chunk it travels in (bit-exact,
@@ -73,59 +83,108 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     // (tuning) still overrides.
     static const int kcfg = (getenv("AMDS_GEMM_CFG") && *getenv("AMDS_GEMM_CFG")) ? -1 : 12;
     auto enc_gemm = [&](const void* A, long lda, const void* Wt, long ldw, int Mr, int N, int K, int epi, void* out, long ldo, const float* bias,
-                        const float* scale) {
-        return amds_gemm_ex(N % 256 == 0 ? kcfg : -1, A, lda, Wt, ldw, Mr, N, K, dt, epi, out, ldo, bias, scale, nullptr, 0, 0, 0, 1.0f, st);
+                        const float* scale, hipStream_t s) {
+        return amds_gemm_ex(N % 256 == 0 ? kcfg : -1, A, lda, Wt, ldw, Mr, N, K, dt, epi, out, ldo, bias, scale, nullptr, 0, 0, 0, 1.0f, s);
     };
+    // LayerNorm folded into the GEMMs: all blocks or none (a mixed stack would be a packing error)
+    const bool fold = w->blocks_host[0].qkv_colsum != nullptr;
+    for (int l = 0; l < c->depth; ++l) {
+        const amds_vit_block& b = w->blocks_host[l];
+        AMDS_REQUIRE((b.qkv_colsum != nullptr) == fold && (b.fc1_colsum != nullptr) == fold, "vit: block %d: qkv_colsum / fc1_colsum must be set in all blocks or in none", l);
+    }
+    if (fold)
+        AMDS_REQUIRE(D % 256 == 0 && n_fc1 % 256 == 0, "vit: the LayerNorm-folded path needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", D, n_fc1);
+
     // patch embedding: im2col (raw 0..255 values) -> GEMM with folded normalisation, + pos-embed
     AMDS_TRY(amds_tile_im2col_u8(tiles, mlp, Bc, c->img, c->patch, pl.kp, dt, st));
     if (c->n_prefix > 0) AMDS_TRY(prefix_init(w->prefix, x, Bc, T, c->n_prefix, D, st));
     AMDS_TRY(amds_gemm(mlp, pl.kp, w->patch_w, pl.kp, Bc * pl.np, D, pl.kp, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
                        nullptr, w->pos_patch, pl.np, T, c->n_prefix, 1.0f / 255.0f, st));
-    // LayerNorm folded into the GEMMs: all blocks or none (a mixed stack would be a packing error)
-    bool fold = w->blocks_host[0].qkv_colsum != nullptr;
-    for (int l = 0; l < c->depth; ++l) {
-        const amds_vit_block& b = w->blocks_host[l];
-        AMDS_REQUIRE((b.qkv_colsum != nullptr) == fold && (b.fc1_colsum != nullptr) == fold, "vit: block %d: qkv_colsum / fc1_colsum must be set in all blocks or in none", l);
-    }
-    if (fold) {
-        const int n_fc1 = c->mlp_kind == 0 ? c->hidden : 2 * c->hidden;
-        AMDS_REQUIRE(D % 256 == 0 && n_fc1 % 256 == 0, "vit: the LayerNorm-folded path needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", D, n_fc1);
-        void* h2 = ws + pl.off_h2;
-        float* rowpart = reinterpret_cast<float*>(ws + pl.off_rowpart);
-        float* rowstat = reinterpret_cast<float*>(ws + pl.off_rowstat);
-        const int NP = D / 128;
-        AMDS_TRY(amds_ln_stats_cast(x, D, M, D, c->ln_eps, h, D, rowstat, dt, st));
+
+    // ---- ragged tail on a side stream.  The GEMMs work on 256-row tiles, one workgroup per CU: M = 64 x 257 rows (the reference's
+    // DataLoader batch) is 64 full row tiles + 64 rows, and that 65th row tile costs every GEMM a whole extra wave of workgroups on a
+    // mostly idle chip (proj / fc2: 260 tiles on 256 CUs = two waves for the work of one).  Everything except attention is
+    // row-local, so the last M % 256 rows run as their own chain of launches on the side stream and meet the main rows only around
+    // attention: their few workgroups fill CUs while the main chain's next kernel ramps up.  Same kernels, same arithmetic, same
+    // bits -- only the launch geometry changes.  Used when the remainder is at most half a tile.
+    const int rem = M % 256;
+    const bool split = sd.side != nullptr && rem > 0 && rem <= 128 && M - rem >= 256;
+    struct Part { int r0, n; hipStream_t s; };
+    Part parts[2] = {{0, split ? M - rem : M, st}, {M - rem, rem, sd.side}};
+    const int nparts = split ? 2 : 1;
+    bool forked = false;
+    auto fork = [&]() -> int {
+        if (!split) return AMDS_OK;
+        AMDS_HIP(hipEventRecord(sd.ev_fork, st));
+        AMDS_HIP(hipStreamWaitEvent(sd.side, sd.ev_fork, 0));
+        forked = true;
+        return AMDS_OK;
+    };
+    auto join = [&]() -> int {
+        if (!split || !forked) return AMDS_OK;
+        forked = false;
+        AMDS_HIP(hipEventRecord(sd.ev_join, sd.side));
+        AMDS_HIP(hipStreamWaitEvent(st, sd.ev_join, 0));
+        return AMDS_OK;
+    };
+    auto rows16 = [&](char* base, int r0, long pitch_elems) { return base + (size_t)r0 * pitch_elems * 2; };   // 16-bit row buffers
+
+    auto body = [&]() -> int {
+        if (fold) AMDS_TRY(amds_ln_stats_cast(x, D, M, D, c->ln_eps, h, D, rowstat, dt, st));
+        AMDS_TRY(fork());
         for (int l = 0; l < c->depth; ++l) {
             const amds_vit_block& b = w->blocks_host[l];
-            AMDS_TRY(amds_gemm_lnfold(h, D, b.qkv_w, D, M, 3 * D, D, dt, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rowstat,
-                                      b.qkv_colsum, st));
+            const bool last = l + 1 == c->depth;
+            for (int p = 0; p < nparts; ++p) {
+                const Part& q = parts[p];
+                if (fold) {
+                    AMDS_TRY(amds_gemm_lnfold(rows16(h, q.r0, D), D, b.qkv_w, D, q.n, 3 * D, D, dt, AMDS_EPI_BIAS, rows16(qkv, q.r0, 3 * D), 3 * D,
+                                              b.qkv_b, nullptr, nullptr, nullptr, rowstat + 2 * (size_t)q.r0, b.qkv_colsum, q.s));
+                } else {
+                    AMDS_TRY(amds_layernorm(x + (size_t)q.r0 * D, D, b.ln1_w, b.ln1_b, rows16(h, q.r0, D), D, q.n, D, c->ln_eps, dt, q.s));
+                    AMDS_TRY(enc_gemm(rows16(h, q.r0, D), D, b.qkv_w, D, q.n, 3 * D, D, AMDS_EPI_BIAS, rows16(qkv, q.r0, 3 * D), 3 * D, b.qkv_b,
+                                      nullptr, q.s));
+                }
+            }
+            AMDS_TRY(join());
             AMDS_TRY(amds_attention_vit_hd(qkv, h, Bc, T, c->heads, D / c->heads, dt, st));
-            AMDS_TRY(amds_gemm_lnfold(h, D, b.proj_w, D, M, D, D, dt, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr, h2,
-                                      rowpart, nullptr, nullptr, st));
-            AMDS_TRY(amds_ln_rowstat(rowpart, M, NP, D, c->ln_eps, rowstat, st));
-            AMDS_TRY(amds_gemm_lnfold(h2, D, b.fc1_w, D, M, n_fc1, D, dt, c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU, mlp, c->hidden,
-                                      b.fc1_b, nullptr, nullptr, nullptr, rowstat, b.fc1_colsum, st));
-            if (l + 1 < c->depth) {
-                AMDS_TRY(amds_gemm_lnfold(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, dt, AMDS_EPI_RESIDUAL, x, D, b.fc2_b,
-                                          c->layerscale ? b.ls2 : nullptr, h, rowpart, nullptr, nullptr, st));
-                AMDS_TRY(amds_ln_rowstat(rowpart, M, NP, D, c->ln_eps, rowstat, st));
-            } else {
-                AMDS_TRY(enc_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr));
+            AMDS_TRY(fork());
+            for (int p = 0; p < nparts; ++p) {
+                const Part& q = parts[p];
+                float* xq = x + (size_t)q.r0 * D;
+                const float* ls1 = c->layerscale ? b.ls1 : nullptr;
+                const float* ls2 = c->layerscale ? b.ls2 : nullptr;
+                const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU;
+                if (fold) {
+                    float* rp = rowpart + (size_t)q.r0 * NP * 2;
+                    float* rs = rowstat + 2 * (size_t)q.r0;
+                    AMDS_TRY(amds_gemm_lnfold(rows16(h, q.r0, D), D, b.proj_w, D, q.n, D, D, dt, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1,
+                                              rows16(h2, q.r0, D), rp, nullptr, nullptr, q.s));
+                    AMDS_TRY(amds_ln_rowstat(rp, q.n, NP, D, c->ln_eps, rs, q.s));
+                    AMDS_TRY(amds_gemm_lnfold(rows16(h2, q.r0, D), D, b.fc1_w, D, q.n, n_fc1, D, dt, epi1, rows16(mlp, q.r0, Hd), Hd, b.fc1_b, nullptr,
+                                              nullptr, nullptr, rs, b.fc1_colsum, q.s));
+                    if (!last) {
+                        AMDS_TRY(amds_gemm_lnfold(rows16(mlp, q.r0, Hd), Hd, b.fc2_w, Hd, q.n, D, Hd, dt, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2,
+                                                  rows16(h, q.r0, D), rp, nullptr, nullptr, q.s));
+                        AMDS_TRY(amds_ln_rowstat(rp, q.n, NP, D, c->ln_eps, rs, q.s));
+                    } else {
+                        AMDS_TRY(enc_gemm(rows16(mlp, q.r0, Hd), Hd, b.fc2_w, Hd, q.n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, q.s));
+                    }
+                } else {
+                    AMDS_TRY(enc_gemm(rows16(h, q.r0, D), D, b.proj_w, D, q.n, D, D, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, q.s));
+                    AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, rows16(h, q.r0, D), D, q.n, D, c->ln_eps, dt, q.s));
+                    AMDS_TRY(enc_gemm(rows16(h, q.r0, D), D, b.fc1_w, D, q.n, n_fc1, D, epi1, rows16(mlp, q.r0, Hd), Hd, b.fc1_b, nullptr, q.s));
+                    AMDS_TRY(enc_gemm(rows16(mlp, q.r0, Hd), Hd, b.fc2_w, Hd, q.n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, q.s));
+                }
             }
         }
-    }
-    for (int l = 0; l < (fold ? 0 : c->depth); ++l) {
-        const amds_vit_block& b = w->blocks_host[l];
-        AMDS_TRY(amds_layernorm(x, D, b.ln1_w, b.ln1_b, h, D, M, D, c->ln_eps, dt, st));
-        AMDS_TRY(enc_gemm(h, D, b.qkv_w, D, M, 3 * D, D, AMDS_EPI_BIAS, qkv, 3 * D, b.qkv_b, nullptr));
-        AMDS_TRY(amds_attention_vit_hd(qkv, h, Bc, T, c->heads, D / c->heads, dt, st));
-        AMDS_TRY(enc_gemm(h, D, b.proj_w, D, M, D, D, AMDS_EPI_RESIDUAL, x, D, b.proj_b, c->layerscale ? b.ls1 : nullptr));
-        AMDS_TRY(amds_layernorm(x, D, b.ln2_w, b.ln2_b, h, D, M, D, c->ln_eps, dt, st));
-        if (c->mlp_kind == 0)
-            AMDS_TRY(enc_gemm(h, D, b.fc1_w, D, M, c->hidden, D, AMDS_EPI_BIAS_GELU, mlp, c->hidden, b.fc1_b, nullptr));
-        else
-            AMDS_TRY(enc_gemm(h, D, b.fc1_w, D, M, 2 * c->hidden, D, AMDS_EPI_SWIGLU, mlp, c->hidden, b.fc1_b, nullptr));
-        AMDS_TRY(enc_gemm(mlp, c->hidden, b.fc2_w, c->hidden, M, D, c->hidden, AMDS_EPI_RESIDUAL, x, D, b.fc2_b, c->layerscale ? b.ls2 : nullptr));
+        return AMDS_OK;
+    };
+    rc = body();
+    {   // join the side stream back on EVERY path: after an error nothing may still be running on it unordered
+        const int rj = join();
+        if (rc != AMDS_OK) return rc;
+        if (rj != AMDS_OK) return rj;
     }
     // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32
     AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));
@@ -160,16 +219,38 @@ extern "C" int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_
         return AMDS_ERR_WORKSPACE;
     }
     AMDS_REQUIRE(((uintptr_t)ws & 255) == 0, "amds_vit_forward: workspace must be 256-byte aligned");
-    const size_t tile_bytes = (size_t)cfg_host->img * cfg_host->img * 3;
+    // Ragged-tail schedule (vit_chunk): needs a side stream, which belongs to the context of the current device -- used when the host
+    // created one (amds_create).  The fork / join events are per call, so two host threads may run forwards on one device (their tail
+    // chains then share the side stream, in order).  AMDS_VIT_TAIL=0 keeps everything on `stream` (A/B).
+    VitSide sd;
+    static const bool tail_on = !(getenv("AMDS_VIT_TAIL") && atoi(getenv("AMDS_VIT_TAIL")) == 0);
+    bool any_tail = false;
     for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int m = ((B - b0 < chunk) ? B - b0 : chunk) * pl.T;
+        any_tail = any_tail || (m % 256 != 0 && m % 256 <= 128 && m >= 512);
+    }
+    if (tail_on && any_tail) {
+        if (amds_ctx* cx = ctx_of_current_device()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (ctx_side_stream(cx, &sd.side, &a, &b) != AMDS_OK) sd.side = nullptr;
+            if (sd.side) {
+                AMDS_HIP(hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming));
+                AMDS_HIP(hipEventCreateWithFlags(&sd.ev_join, hipEventDisableTiming));
+            }
+        }
+    }
+    const size_t tile_bytes = (size_t)cfg_host->img * cfg_host->img * 3;
+    rc = AMDS_OK;
+    for (int b0 = 0; b0 < B && rc == AMDS_OK; b0 += chunk) {
         const int bc = (B - b0 < chunk) ? B - b0 : chunk;
         rc = vit_chunk(cfg_host, w_host, pl, tiles + (size_t)b0 * tile_bytes,
                        reinterpret_cast<char*>(feats_f16) + (size_t)b0 * cfg_host->dim * 2,
                        tokens_f32 ? tokens_f32 + (size_t)b0 * pl.T * cfg_host->dim : nullptr, bc,
-                       reinterpret_cast<char*>(ws), (hipStream_t)stream);
-        if (rc != AMDS_OK) return rc;
+                       reinterpret_cast<char*>(ws), (hipStream_t)stream, sd);
     }
-    return AMDS_OK;
+    if (sd.ev_fork) (void)hipEventDestroy(sd.ev_fork);       // released once the recorded work has completed
+    if (sd.ev_join) (void)hipEventDestroy(sd.ev_join);
+    return rc;
 }
 
 // Two chunks in flight on two streams: the HBM-bound kernels of one chunk (LayerNorm, attention staging, epilogue

@@ -159,6 +159,7 @@ class HipViT(nn.Module):
         if self.device_.type != "cuda":
             raise RuntimeError("HipViT runs on the GPU only (no CPU fallback)")
         _lib.lib()  # fail early and loudly if the extension is missing
+        _lib.ctx(self.device_.index if self.device_.index is not None else torch.cuda.current_device())   # side stream of the ragged-tail schedule
         self._keep: list[torch.Tensor] = []
         self._ws: torch.Tensor | None = None
         # LayerNorm folded into the qkv / fc1 GEMMs (include/amdstamp.h, amds_gemm_lnfold): default on where the shapes allow it
