@@ -169,6 +169,75 @@ def cpu_baseline_mil(seconds_each: float = 4.0) -> dict:
             n += 1
         el = time.perf_counter() - t0
     out["gated_attention_pool"] = {"value": round(n / el, 1), "unit": "bags/s", "cores": threads, "sample": f"{n} bags of 1024 x 768, {el:.1f}s"}
+
+    # C2, the other heads: `vit` with ALiBi (post-softmax distance bias, running-mean scalers updated in train mode) and TransMIL
+    from oracle.transmil import transmil_forward
+    from stamp_amd.mil import TransMIL
+    torch.manual_seed(2)
+    am = VisionTransformer(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.25, use_alibi=True)
+    ap = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_mean" not in k else v.clone()) for k, v in am.state_dict().items()}
+    aopt = torch.optim.AdamW([v for v in ap.values() if v.requires_grad], lr=1e-4)
+    gx, gy = torch.meshgrid(torch.arange(32.0), torch.arange(32.0), indexing="ij")
+    acoords = (torch.stack([gx.reshape(-1), gy.reshape(-1)], -1) * 256.0).expand(Bb, Tn, 2).contiguous()       # a 256 um grid, as BASELINE.md says
+
+    def alibi_step():
+        aopt.zero_grad()
+        d = {k: v for k, v in drop_masks().items() if not k.startswith("attn")}        # ALiBi heads have no attention dropout
+        loss = torch.nn.functional.cross_entropy(mil_vit_forward(bags, acoords, None, ap, n_heads=H, use_alibi=True, drop=d), targets)
+        loss.backward()
+        aopt.step()
+
+    alibi_step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_each and n < 20:
+        alibi_step()
+        n += 1
+    el = time.perf_counter() - t0
+    out["mil_vit_train_alibi"] = {"value": round(n * Bb / el, 2), "unit": "bags/s", "cores": threads,
+                                  "sample": f"{n} steps of batch {Bb}, bags of 1024 x 1024-d with coordinates, fwd + bwd + AdamW, {el:.1f}s"}
+    tm = TransMIL(dim_output=2, dim_input=1024, dim_hidden=512)
+    tp = {k: v.clone().requires_grad_(True) for k, v in tm.state_dict().items()}
+    topt = torch.optim.AdamW(list(tp.values()), lr=1e-4)
+
+    def transmil_step():
+        topt.zero_grad()
+        d = {name: (torch.rand(Bb, Tn + 1, 512) >= 0.1).float() / 0.9 for name in ("layer1", "layer2")}
+        loss = torch.nn.functional.cross_entropy(transmil_forward(bags, tp, drop=d), targets)
+        loss.backward()
+        topt.step()
+
+    transmil_step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_each and n < 20:
+        transmil_step()
+        n += 1
+    el = time.perf_counter() - t0
+    out["transmil_train"] = {"value": round(n * Bb / el, 2), "unit": "bags/s", "cores": threads,
+                             "sample": f"{n} steps of batch {Bb}, bags of 1024 x 1024-d, fwd + bwd + AdamW, Dropout(0.1) live, {el:.1f}s"}
+
+    # C5: BASELINE.json configs[0], tests/random_data.py-shaped: 64 patients x 256 tiles x 2048-d, binary, `vit` head, 2 epochs of
+    # (51 training bags in one batch of the reference's batch size 64, then 13 full-bag validation forwards), wall seconds
+    torch.manual_seed(3)
+    c1 = VisionTransformer(dim_output=2, dim_input=2048, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.25, use_alibi=False)
+    cp = {k: v.clone().requires_grad_(True) for k, v in c1.state_dict().items()}
+    copt = torch.optim.AdamW(list(cp.values()), lr=1e-4)
+    cb = torch.rand(64, 256, 2048).half().float()
+    ct = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
+    cz = torch.zeros(64, 256, 2)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        copt.zero_grad()
+        dm = {"proj": (torch.rand(51, 256, 512) >= 0.25).float() / 0.75}
+        for l in range(2):
+            dm[f"attn{l}"] = (torch.rand(51, 8, 257, 257) >= 0.25).float() / 0.75
+            dm[f"ff1_{l}"], dm[f"ff2_{l}"] = (torch.rand(51, 257, 512) >= 0.5).float() * 2, (torch.rand(51, 257, 512) >= 0.5).float() * 2
+        torch.nn.functional.cross_entropy(mil_vit_forward(cb[:51], cz[:51], None, cp, n_heads=8, use_alibi=False, drop=dm), ct[:51]).backward()
+        copt.step()
+        with torch.no_grad():
+            for i in range(51, 64):
+                mil_vit_forward(cb[i:i + 1], cz[i:i + 1], None, cp, n_heads=8, use_alibi=False)
+    out["config1_two_epochs"] = {"value": round(time.perf_counter() - t0, 3), "unit": "s", "cores": threads,
+                                 "sample": "64 bags x 256 tiles x 2048-d, 2 epochs: one training step over 51 bags + 13 validation forwards each"}
     return out
 
 
@@ -289,6 +358,22 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     sec["transmil_train"] = {"metric": "TransMIL bags/s (fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, fp32, Dropout(0.1) live)", "value": round(64 / dt, 1),
                              "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltm))}
     del bags_f, opt
+    # BASELINE.json configs[0] (tests/random_data.py shape): 64 patients x 256 tiles x 2048-d, binary `vit` head, two epochs of one
+    # training step over the 51 training bags + 13 full-bag validation forwards through stamp_amd.mil_train.fit; wall seconds incl. the
+    # trainer's construction (weight packing), against cpu_baseline.mil.config1_two_epochs
+    from stamp_amd.mil_train import fit as mil_fit
+    torch.manual_seed(3)
+    t0c = time.perf_counter()
+    c1 = HipMil(dim_output=2, dim_input=2048, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.25, use_alibi=False)
+    cb = torch.rand(64, 256, 2048, device=ctx.device).half()
+    ct = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
+    tr1 = HipMilVitTrainer(c1, device=ctx.device, total_steps=2)
+    hist = mil_fit(tr1, lambda: [(cb[:51], None, None, ct[:51])], lambda: [(cb[i:i + 1], None, None, ct[i:i + 1]) for i in range(51, 64)], max_epochs=2, patience=16)
+    torch.cuda.synchronize()
+    sec["config1_two_epochs"] = {"metric": "wall seconds, BASELINE.json configs[0]: 64 bags x 256 tiles x 2048-d, `vit` head, 2 epochs (train step over 51 bags + 13 validation forwards each)",
+                                 "value": round(time.perf_counter() - t0c, 3), "unit": "s", "higher_is_better": False,
+                                 "validation_loss_finite": bool(all(v == v for v in hist["validation_loss"]))}
+    del cb, tr1
     if not is_swin:     # the reference's in-tree tile encoder, same tile shape
         scfg = SWIN_PRESETS["ctranspath"]
         sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)

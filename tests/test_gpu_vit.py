@@ -120,6 +120,29 @@ def test_vit_large_batch_invariance_at_bench_size(gpu):
     assert torch.equal(fd[0], fd[1])
 
 
+def test_lnfold_and_plain_paths_against_the_oracle_and_b64_tail(gpu):
+    """The two forms of a block's LayerNorms (folded into the GEMMs: the default; separate kernels: ln_fold=False) are both within the
+    stated tolerance of the fp32 oracle and of each other; and the reference's DataLoader batch of 64 tiles (64 x 257 rows = 64 row tiles
+    + 64 rows: the ragged-tail schedule on the side stream) gives the bits the same tiles get inside a 1020-tile chunk."""
+    cfg = PRESETS["vit_large_patch14_224"]
+    sd = random_vit_state_dict(cfg, seed=3, init="moderate")
+    tiles = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(21))
+    ref_f, ref_t = extract_features(tiles, sd, cfg, return_tokens=True)
+    fold, plain = HipViT(cfg, sd, device=gpu, chunk=1020), HipViT(cfg, sd, device=gpu, chunk=1020, ln_fold=False)
+    assert fold.ln_fold and not plain.ln_fold
+    ff, tf = fold(tiles.to(gpu), return_tokens=True)
+    fp, tp = plain(tiles.to(gpu), return_tokens=True)
+    e_f, e_p, d = _rel(tf.cpu(), ref_t), _rel(tp.cpu(), ref_t), _rel(tf, tp)
+    print(f"ViT-L/14 tokens vs oracle: LayerNorm folded {e_f:.3e}, separate kernels {e_p:.3e}; folded vs separate {d:.3e}")
+    assert e_f < 1e-3 and e_p < 1e-3 and d < 1e-3
+    assert _rel(ff.cpu().float(), ref_f.float()) < 1e-3 and _rel(fp.cpu().float(), ref_f.float()) < 1e-3
+    big = torch.randint(0, 256, (1020, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(22)).to(gpu)
+    for m in (fold, plain):
+        whole = m(big)
+        assert torch.equal(m(big[128:192]), whole[128:192])        # a batch of 64: remainder rows on the side stream
+        assert torch.equal(m(big[7:107]), whole[7:107])            # 100 tiles: 25 700 rows = 100 row tiles + 100 rows
+
+
 def test_cls_plus_mean_patch_embedding(gpu):
     """`VirchowConcatenated` (reference virchow_full.py:25-35): cat(class token, mean of the remaining tokens)."""
     from stamp_amd.vit import HipViTClsMean
