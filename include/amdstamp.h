@@ -436,7 +436,10 @@ int amds_linear_f32(const float* x, const float* w, const float* bias, float* ou
 
 /* Batched fp32 GEMM on the exact-fp32 MFMA: for z = (o, i), o < outer, i < inner:
  *   C[o,i] (+)= diag*I + alpha * A[o,i] * op(B[o,i]) + bias[n];  op(B) = B^T if transb (B stored [N][K]) else B ([K][N]).
- * Operand z starts at base + o*s?o + i*s?i (elements), so head slices of a packed qkv tensor are addressed in place. */
+ * Operand z starts at base + o*s?o + i*s?i (elements), so head slices of a packed qkv tensor are addressed in place.
+ * transb bit 1 (value 2): A is stored [K][M] with pitch lda and the product is A^T op(B) -- the backward's "x^T dy" products without an
+ * explicit transpose (vector loads when K, lda, ldb and the batch strides are multiples of 4 and the operands 16-byte aligned,
+ * element loads otherwise). */
 int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                    float* C, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                    float diag, const float* bias, int accumulate, void* stream);
@@ -471,8 +474,9 @@ int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const 
 int amds_softmax_rows_bwd(const float* p, float* dp, long rows, int cols, void* stream);
 int amds_landmark_mean_bwd(const float* dout, float* dx, long sxo, long sxi, int ld, int outer, int inner, int m, int l, int d,
                            float scale, int accumulate, void* stream);
+size_t amds_dwconv_seq_wgrad_workspace_bytes(int outer, int inner, int taps);
 int amds_dwconv_seq_wgrad(const float* dout, long soo, long soi, int ldo, const float* v, long svo, long svi, int ldv, float* dw,
-                          int outer, int inner, int n, int d, int taps, void* stream);
+                          int outer, int inner, int n, int d, int taps, void* ws, size_t ws_bytes, void* stream);
 size_t amds_ppeg_wgrad_workspace_bytes(int B, int C);
 int amds_ppeg_wgrad(const float* x, const float* dy, float* dcorr, int B, int H, int W, int C, void* ws, size_t ws_bytes, void* stream);
 int amds_relu_bwd(const float* h, const float* dh, float* dz, long n, void* stream);

@@ -121,7 +121,8 @@ PROTOTYPES = {
     "amds_ppeg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_softmax_rows_bwd": (_i, [_vp, _vp, _l, _i, _vp]),
     "amds_landmark_mean_bwd": (_i, [_vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "amds_dwconv_seq_wgrad": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amds_dwconv_seq_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amds_dwconv_seq_wgrad": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amds_ppeg_wgrad_workspace_bytes": (_sz, [_i, _i]),
     "amds_ppeg_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amds_relu_bwd": (_i, [_vp, _vp, _vp, _l, _vp]),

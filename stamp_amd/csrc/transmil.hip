@@ -91,12 +91,12 @@ __global__ void __launch_bounds__(256) bgemm_f32_kernel(const float* __restrict_
 // 8 values a lane needs per 16-deep k-tile (k = hi, hi + 2, ...) are two ds_read_b128; global loads are float4 and the next
 // k-tile is fetched into registers while the current one is multiplied.  Requires K, lda, ldb multiples of 4 and 16-byte
 // aligned operands; the 64 x 64 kernel above remains the fallback.
-template <int TRANSB>
+template <int TRANSB, int TRANSA = 0>
 __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restrict__ A, int lda, long sAo, long sAi,
                                                             const float* __restrict__ B, int ldb, long sBo, long sBi,
                                                             float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
                                                             int M, int N, int K, float alpha, float diag,
-                                                            const float* __restrict__ bias, int accumulate) {
+                                                            const float* __restrict__ bias, int accumulate, int vec) {
     constexpr int BT = 128, BK = 16, LDT = 20;
     __shared__ __attribute__((aligned(16))) float sA[BT * LDT];
     __shared__ __attribute__((aligned(16))) float sB[BT * LDT];
@@ -117,12 +117,34 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x4 ra[2], rb[2];
     auto gload = [&](int k0) {
+        if (!vec) {      // any shape / alignment: element loads with bounds (small or odd problems only)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4, kq = c >> 5, q4 = (c & 31) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (TRANSA) { const int gk = k0 + kq, gm = m0 + q4 + e; ra[it][e] = (gk < K && gm < M) ? A[(long)gk * lda + gm] : 0.f; }
+                    else { const int gm = m0 + row, gk = k0 + c4 + e; ra[it][e] = (gk < K && gm < M) ? A[(long)gm * lda + gk] : 0.f; }
+                    if (TRANSB) { const int gn = n0 + row, gk = k0 + c4 + e; rb[it][e] = (gk < K && gn < N) ? B[(long)gn * ldb + gk] : 0.f; }
+                    else { const int gk = k0 + kq, gn = n0 + q4 + e; rb[it][e] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : 0.f; }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4;
             const int gm = m0 + row;
             ra[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gm < M && k0 + c4 < K) ra[it] = *reinterpret_cast<const f32x4*>(A + (long)gm * lda + k0 + c4);
+            if (TRANSA) {                             // A stored [K][M] (the product is A^T B): float4 along m
+                const int k = c >> 5, m4 = (c & 31) * 4;
+                const int gk = k0 + k, gm4 = m0 + m4;
+                if (gk < K && gm4 + 3 < M) ra[it] = *reinterpret_cast<const f32x4*>(A + (long)gk * lda + gm4);
+                else if (gk < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gm4 + e < M) ra[it][e] = A[(long)gk * lda + gm4 + e];
+                }
+            } else if (gm < M && k0 + c4 < K) ra[it] = *reinterpret_cast<const f32x4*>(A + (long)gm * lda + k0 + c4);
             rb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (TRANSB) {
                 const int gn = n0 + row;
@@ -142,10 +164,16 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4;
+            if (TRANSA) {
+                const int k = c >> 5, m4 = (c & 31) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = c4 + e;
-                sA[row * LDT + (k & 1) * 8 + (k >> 1)] = ra[it][e];
+                for (int e = 0; e < 4; ++e) sA[(m4 + e) * LDT + (k & 1) * 8 + (k >> 1)] = ra[it][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c4 + e;
+                    sA[row * LDT + (k & 1) * 8 + (k >> 1)] = ra[it][e];
+                }
             }
             if (TRANSB) {
 #pragma unroll
@@ -368,17 +396,23 @@ __global__ void landmark_mean_bwd_kernel(const float* __restrict__ dout, float* 
     *q = accumulate ? *q + g : g;
 }
 
-// dw[zi][k] = sum over (zo, t, c) of dout[zo,zi][t][c] * v[zo,zi][t + k - taps/2][c]; one workgroup per (k, zi), fixed-order reduction
+// part[zo][zi][k] = sum over (t, c) of dout[zo,zi][t][c] * v[zo,zi][t + k - taps/2][c]: one workgroup per (tap k, inner zi, outer zo), lane = column
+// (coalesced rows), fixed-order tree; amds_colsum then adds the `outer` partials in index order.  (One workgroup per (k, zi) looping over all
+// bags took 10 ms per call at 64 bags x 1280 tokens: 264 workgroups with 20 k serial iterations each.)
 __global__ void __launch_bounds__(256) dwconv_seq_wgrad_kernel(const float* __restrict__ dout, long soo, long soi, int ldo, const float* __restrict__ v,
-                                                               long svo, long svi, int ldv, float* __restrict__ dw, int outer, int n, int d, int taps) {
+                                                               long svo, long svi, int ldv, float* __restrict__ part, int inner, int n, int d, int taps) {
     __shared__ float red[256];
-    const int k = blockIdx.x, zi = blockIdx.y;
+    const int k = blockIdx.x, zi = blockIdx.y, zo = blockIdx.z;
     const int pad = taps / 2;
-    const long per = (long)n * d;
+    const float* po = dout + zo * soo + zi * soi;
+    const float* pv = v + zo * svo + zi * svi;
     float s = 0.f;
-    for (int zo = 0; zo < outer; ++zo) {
-        const float* po = dout + zo * soo + zi * soi;
-        const float* pv = v + zo * svo + zi * svi;
+    if (d <= 256 && 256 % d == 0) {
+        const int c = threadIdx.x % d, tstep = 256 / d;
+        const int lo = max(0, pad - k), hi = min(n, n + pad - k);          // rows t with 0 <= t + k - pad < n
+        for (int t = lo + (int)threadIdx.x / d; t < hi; t += tstep) s += po[(long)t * ldo + c] * pv[(long)(t + k - pad) * ldv + c];
+    } else {
+        const long per = (long)n * d;
         for (long idx = threadIdx.x; idx < per; idx += 256) {
             const int t = (int)(idx / d), c = (int)(idx - (long)t * d);
             const int tt = t + k - pad;
@@ -391,7 +425,7 @@ __global__ void __launch_bounds__(256) dwconv_seq_wgrad_kernel(const float* __re
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) dw[(long)zi * taps + k] = red[0];
+    if (threadIdx.x == 0) part[((long)zo * inner + zi) * taps + k] = red[0];
 }
 
 // PPEG weight gradients: part[chunk][tap][c] = sum over this chunk's bags and the whole grid of dy[b,i,j,c] * x[b,i+r-3,j+q-3,c] for
@@ -496,13 +530,19 @@ extern "C" int amds_landmark_mean_bwd(const float* dout, float* dx, long sxo, lo
     return AMDS_OK;
 }
 
+extern "C" size_t amds_dwconv_seq_wgrad_workspace_bytes(int outer, int inner, int taps) {
+    return (size_t)outer * inner * taps * 4 + amds_colsum_workspace_bytes(outer, inner * taps);
+}
 extern "C" int amds_dwconv_seq_wgrad(const float* dout, long soo, long soi, int ldo, const float* v, long svo, long svi, int ldv, float* dw,
-                                     int outer, int inner, int n, int d, int taps, void* stream) {
-    AMDS_REQUIRE(dout && v && dw && outer > 0 && inner > 0 && n > 0 && d > 0 && taps > 0 && (taps & 1), "amds_dwconv_seq_wgrad: bad arguments");
-    hipLaunchKernelGGL(dwconv_seq_wgrad_kernel, dim3(taps, inner), dim3(256), 0, (hipStream_t)stream, dout, soo, soi, ldo, v, svo, svi, ldv, dw, outer,
-                       n, d, taps);
+                                     int outer, int inner, int n, int d, int taps, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(dout && v && dw && ws && outer > 0 && outer <= 65535 && inner > 0 && n > 0 && d > 0 && taps > 0 && (taps & 1), "amds_dwconv_seq_wgrad: bad arguments");
+    if (ws_bytes < amds_dwconv_seq_wgrad_workspace_bytes(outer, inner, taps)) { set_error("amds_dwconv_seq_wgrad: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(dwconv_seq_wgrad_kernel, dim3(taps, inner, outer), dim3(256), 0, (hipStream_t)stream, dout, soo, soi, ldo, v, svo, svi, ldv, part,
+                       inner, n, d, taps);
     AMDS_LAUNCH_CHECK("dwconv_seq_wgrad_kernel");
-    return AMDS_OK;
+    char* cws = (char*)(part + (size_t)outer * inner * taps);
+    return amds_colsum(part, (long)inner * taps, dw, outer, inner * taps, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(outer, inner * taps), stream);
 }
 
 extern "C" size_t amds_ppeg_wgrad_workspace_bytes(int B, int C) { return (size_t)cdiv(B, 4) * 50 * C * 4 + amds_colsum_workspace_bytes(cdiv(B, 4), 50 * C); }
@@ -553,10 +593,19 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
     ProfScope prof(PROF_GEMM_F32, 2.0 * outer * inner * (double)M * N * K, st);
     const bool vec_ok = K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && sAo % 4 == 0 && sAi % 4 == 0 && sBo % 4 == 0 && sBi % 4 == 0 &&
                         ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+    const bool transa = (transb & 2) != 0;            // bit 1: A is stored [K][M] (pitch lda), the product is A^T B
+    transb &= 1;
+    if (transa) {
+        const dim3 gbig(cdiv(N, 128), cdiv(M, 128), outer * inner);
+        if (transb) hipLaunchKernelGGL((bgemm_f32_big_kernel<1, 1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, vec_ok ? 1 : 0);
+        else hipLaunchKernelGGL((bgemm_f32_big_kernel<0, 1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, vec_ok ? 1 : 0);
+        AMDS_LAUNCH_CHECK("bgemm_f32_big_kernel(transa)");
+        return AMDS_OK;
+    }
     if (vec_ok && M >= 96 && N >= 96) {
         const dim3 gbig(cdiv(N, 128), cdiv(M, 128), outer * inner);
-        if (transb) hipLaunchKernelGGL((bgemm_f32_big_kernel<1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
-        else hipLaunchKernelGGL((bgemm_f32_big_kernel<0>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
+        if (transb) hipLaunchKernelGGL((bgemm_f32_big_kernel<1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, 1);
+        else hipLaunchKernelGGL((bgemm_f32_big_kernel<0>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, 1);
         AMDS_LAUNCH_CHECK("bgemm_f32_big_kernel");
         return AMDS_OK;
     }

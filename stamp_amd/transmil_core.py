@@ -29,28 +29,45 @@ from . import train_ops as T
 HEADS, ITERS, CONV_K, P_OUT = 8, 6, 33, 0.1
 
 
-def _bg(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha=1.0, diag=0.0, bias=None, accumulate=False):
+def _bg(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha=1.0, diag=0.0, bias=None, accumulate=False,
+        transa=False):
+    """transa: A is stored [K][M] with pitch lda and the product is A^T B (no explicit transpose: the kernel transposes while staging)."""
     p = lambda t: t if isinstance(t, int) else t.data_ptr()  # noqa: E731
-    _lib.check(_lib.lib().amds_bgemm_f32(p(A), lda, sAo, sAi, p(B), ldb, sBo, sBi, 1 if transb else 0, p(Cm), ldc, sCo, sCi, outer, inner,
+    _lib.check(_lib.lib().amds_bgemm_f32(p(A), lda, sAo, sAi, p(B), ldb, sBo, sBi, (1 if transb else 0) | (2 if transa else 0), p(Cm), ldc, sCo, sCi, outer, inner,
                                          M, N, K, alpha, diag, None if bias is None else p(bias), 1 if accumulate else 0, ops._stream()), "bgemm_f32")
 
 
-def _mm(A: torch.Tensor, B: torch.Tensor, transb: bool, out: torch.Tensor | None = None, alpha: float = 1.0, diag: float = 0.0, accumulate: bool = False):
-    """Batched product of contiguous [Z, M, K] with [Z, K, N] (or [Z, N, K] if transb) -> [Z, M, N]."""
-    Z, M, K = A.shape
+def _mm(A: torch.Tensor, B: torch.Tensor, transb: bool, out: torch.Tensor | None = None, alpha: float = 1.0, diag: float = 0.0, accumulate: bool = False,
+        transa: bool = False):
+    """Batched product of contiguous [Z, M, K] (or [Z, K, M] if transa) with [Z, K, N] (or [Z, N, K] if transb) -> [Z, M, N]."""
+    if transa:
+        Z, K, M = A.shape
+    else:
+        Z, M, K = A.shape
     N = B.shape[1] if transb else B.shape[2]
     if out is None:
         out = torch.empty(Z, M, N, dtype=torch.float32, device=A.device)
     zc = 32768
     for z0 in range(0, Z, zc):                        # gridDim.z limit of one launch
         z1 = min(Z, z0 + zc)
-        _bg(A[z0:z1], K, M * K, 0, B[z0:z1], B.shape[2], B.shape[1] * B.shape[2], 0, transb, out[z0:z1], N, M * N, 0, z1 - z0, 1, M, N, K,
-            alpha=alpha, diag=diag, accumulate=accumulate)
+        _bg(A[z0:z1], A.shape[2], M * K, 0, B[z0:z1], B.shape[2], B.shape[1] * B.shape[2], 0, transb, out[z0:z1], N, M * N, 0, z1 - z0, 1, M, N, K,
+            alpha=alpha, diag=diag, accumulate=accumulate, transa=transa)
     return out
 
 
 def _tr(x: torch.Tensor) -> torch.Tensor:
     return x.transpose(-1, -2).contiguous()
+
+
+def _wgrad(dy3: torch.Tensor, x3: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of a Linear over all rows of all bags, dW[M, N] = sum_b dy_b^T x_b for dy3 [b, n, M], x3 [b, n, N] (contiguous):
+    one product per bag into fp32 partials, then a fixed-order sum over the bags.  As ONE product with K = b * n (65 k - 82 k) the output's
+    few tiles left 220 of the 256 CUs idle for 3 - 11 ms per weight."""
+    b, n, M = dy3.shape
+    N = x3.shape[2]
+    part = torch.empty(b, M, N, dtype=torch.float32, device=dy3.device)
+    _bg(dy3, M, n * M, 0, x3, N, n * N, 0, False, part, N, M * N, 0, b, 1, M, N, n, transa=True)
+    return T.colsum(part.view(b, M * N)).view(M, N)
 
 
 def _f(t):
@@ -152,8 +169,7 @@ def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = Tru
     tail = merged[:, pad:, :]
     if need_params:
         tail_c = tail.reshape(b * n, Cd) if pad == 0 else tail.contiguous().view(b * n, Cd)
-        gwo = torch.empty(Cd, Cd, **f32)
-        _bg(_tr(dout), b * n, 0, 0, tail_c, Cd, 0, 0, False, gwo, Cd, 0, 0, 1, 1, Cd, Cd, b * n)       # dWo = dout^T merged_tail
+        gwo = _wgrad(dout.view(b, n, Cd), tail_c.view(b, n, Cd))                                        # dWo = dout^T merged_tail
         G["attn.to_out.0.weight"], G["attn.to_out.0.bias"] = gwo, T.colsum(dout)
     dmerged = torch.zeros(b, np_, Cd, **f32)
     _bg(dout, Cd, n * Cd, 0, P.wo, Cd, 0, 0, False, dmerged.view(-1)[pad * Cd:], Cd, np_ * Cd, 0, b, 1, n, Cd, Cd)   # dmerged_tail = dout Wo
@@ -164,34 +180,34 @@ def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = Tru
     _lib.check(lib.amds_dwconv_seq(dmerged.data_ptr(), np_ * Cd, d, Cd, wflip.data_ptr(), dvp, sb, sh, ld, b, H, np_, d, wflip.shape[1], st), "dwconv_seq(bwd)")
     if need_params:
         gconv = torch.empty(H, CONV_K, **f32)
-        _lib.check(lib.amds_dwconv_seq_wgrad(dmerged.data_ptr(), np_ * Cd, d, Cd, vp, sb, sh, ld, gconv.data_ptr(), b, H, np_, d, CONV_K, st), "dwconv_seq_wgrad")
+        nb = lib.amds_dwconv_seq_wgrad_workspace_bytes(b, H, CONV_K)
+        cws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.amds_dwconv_seq_wgrad(dmerged.data_ptr(), np_ * Cd, d, Cd, vp, sb, sh, ld, gconv.data_ptr(), b, H, np_, d, CONV_K, cws.data_ptr(), nb, st),
+                   "dwconv_seq_wgrad")
         G["attn.res_conv.weight"] = gconv.view(H, 1, CONV_K, 1)
     # out_h = a1z av  (do = head slice of dmerged, [np, d] at row pitch Cd)
     da1z = torch.empty(b, H, np_, m, **f32)
     _bg(dmerged, Cd, np_ * Cd, d, S["av"], d, H * m * d, m * d, True, da1z, m, H * np_ * m, np_ * m, b, H, np_, m, d)             # do av^T
-    a1zT = _tr(S["a1z"])                                                                                                         # [Z, m, np]
     dav = torch.empty(b, H, m, d, **f32)
-    _bg(a1zT, np_, H * m * np_, m * np_, dmerged, Cd, np_ * Cd, d, False, dav, d, H * m * d, m * d, b, H, m, d, np_)              # a1z^T do
+    _bg(S["a1z"], m, H * np_ * m, np_ * m, dmerged, Cd, np_ * Cd, d, False, dav, d, H * m * d, m * d, b, H, m, d, np_, transa=True)   # a1z^T do
     z = S["z"]
     da1 = _mm(da1z.view(Z, np_, m), z, True)                                                                                     # d(a1z) z^T
-    dz = _mm(_tr(S["a1"].view(Z, np_, m)), da1z.view(Z, np_, m), False)                                                          # a1^T d(a1z)
+    dz = _mm(S["a1"].view(Z, np_, m), da1z.view(Z, np_, m), False, transa=True)                                                  # a1^T d(a1z)
     da3 = torch.empty(b, H, m, np_, **f32)
     _bg(dav, d, H * m * d, m * d, vp, ld, sb, sh, True, da3, np_, H * m * np_, m * np_, b, H, m, np_, d)                          # d(av) v^T
-    _bg(_tr(S["a3"].view(Z, m, np_)), m, H * np_ * m, np_ * m, dav, d, H * m * d, m * d, False, dvp, ld, sb, sh, b, H, np_, d, m, accumulate=True)   # dv += a3^T d(av)
+    _bg(S["a3"], np_, H * m * np_, m * np_, dav, d, H * m * d, m * d, False, dvp, ld, sb, sh, b, H, np_, d, m, accumulate=True, transa=True)   # dv += a3^T d(av)
     # pseudo-inverse iterations, last to first
     x2 = S["a2"].view(Z, m, m)
-    x2T = _tr(x2)
     da2 = torch.zeros(Z, m, m, **f32)
     for (zk, A, T1, T2, T3) in reversed(S["its"]):
-        AT = _tr(A)
         dzk = _mm(dz, T3, True, alpha=0.25)                       # g T3^T / 4
-        dT3 = _mm(_tr(zk), dz, False, alpha=0.25)                 # z_k^T g / 4
+        dT3 = _mm(zk, dz, False, alpha=0.25, transa=True)         # z_k^T g / 4
         dA = _mm(dT3, T2, True, alpha=-1.0)                       # -dT3 T2^T
-        dT2 = _mm(AT, dT3, False, alpha=-1.0)                     # -A^T dT3
+        dT2 = _mm(A, dT3, False, alpha=-1.0, transa=True)         # -A^T dT3
         _mm(dT2, T1, True, out=dA, alpha=-1.0, accumulate=True)   # dA -= dT2 T1^T
-        _mm(AT, dT2, False, out=dA, accumulate=True)              # dA -= dT1, dT1 = -A^T dT2
+        _mm(A, dT2, False, out=dA, accumulate=True, transa=True)  # dA -= dT1, dT1 = -A^T dT2
         _mm(dA, zk, True, out=da2, accumulate=True)               # da2 += dA z_k^T
-        _mm(x2T, dA, False, out=dzk, accumulate=True)             # dz_k += a2^T dA
+        _mm(x2, dA, False, out=dzk, accumulate=True, transa=True)  # dz_k += a2^T dA
         dz = dzk
     nb = lib.amds_pinv_init_bwd_workspace_bytes(Z)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -204,19 +220,17 @@ def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = Tru
     # dq = scale dS1 kl  (+ landmark part) ; dkl = scale dS1^T q + dS2^T ql ; dql = dS2 kl + dS3 k ; dk = dS3^T ql (+ landmark part)
     _bg(dS1, m, H * np_ * m, np_ * m, kl, d, H * m * d, m * d, False, dqp, ld, sb, sh, b, H, np_, d, m, alpha=scale)
     dkl = torch.empty(b, H, m, d, **f32)
-    _bg(_tr(dS1.view(Z, np_, m)), np_, H * m * np_, m * np_, qp, ld, sb, sh, False, dkl, d, H * m * d, m * d, b, H, m, d, np_, alpha=scale)
-    _bg(_tr(dS2.view(Z, m, m)), m, H * m * m, m * m, ql, d, H * m * d, m * d, False, dkl, d, H * m * d, m * d, b, H, m, d, m, accumulate=True)
+    _bg(dS1, m, H * np_ * m, np_ * m, qp, ld, sb, sh, False, dkl, d, H * m * d, m * d, b, H, m, d, np_, alpha=scale, transa=True)      # dS1^T q
+    _bg(dS2, m, H * m * m, m * m, ql, d, H * m * d, m * d, False, dkl, d, H * m * d, m * d, b, H, m, d, m, accumulate=True, transa=True)   # + dS2^T q_l
     dql = torch.empty(b, H, m, d, **f32)
     _bg(dS2, m, H * m * m, m * m, kl, d, H * m * d, m * d, False, dql, d, H * m * d, m * d, b, H, m, d, m)
     _bg(dS3, np_, H * m * np_, m * np_, kp, ld, sb, sh, False, dql, d, H * m * d, m * d, b, H, m, d, np_, accumulate=True)
-    _bg(_tr(dS3.view(Z, m, np_)), m, H * np_ * m, np_ * m, ql, d, H * m * d, m * d, False, dkp, ld, sb, sh, b, H, np_, d, m)
+    _bg(dS3, np_, H * m * np_, m * np_, ql, d, H * m * d, m * d, False, dkp, ld, sb, sh, b, H, np_, d, m, transa=True)            # dS3^T q_l
     _lib.check(lib.amds_landmark_mean_bwd(dql.data_ptr(), dqp, sb, sh, ld, b, H, m, l, d, scale / l, 1, st), "landmark_mean_bwd")
     _lib.check(lib.amds_landmark_mean_bwd(dkl.data_ptr(), dkp, sb, sh, ld, b, H, m, l, d, 1.0 / l, 1, st), "landmark_mean_bwd")
     # to_qkv (no bias)
     if need_params:
-        gq = torch.empty(3 * Cd, Cd, **f32)
-        _bg(_tr(dqkv.view(b * np_, 3 * Cd)), b * np_, 0, 0, S["yp"].reshape(b * np_, Cd), Cd, 0, 0, False, gq, Cd, 0, 0, 1, 1, 3 * Cd, Cd, b * np_)
-        G["attn.to_qkv.weight"] = gq
+        G["attn.to_qkv.weight"] = _wgrad(dqkv, S["yp"].reshape(b, np_, Cd))
     dyp = torch.empty(b, np_, Cd, **f32)
     _bg(dqkv, 3 * Cd, 0, 0, P.wqkv, Cd, 0, 0, False, dyp, Cd, 0, 0, 1, 1, b * np_, Cd, 3 * Cd)
     return dyp[:, pad:, :].contiguous(), G
@@ -323,9 +337,7 @@ def backward(saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, ne
     dzh = torch.empty(Bb * Tn, Cd, **f32)
     _lib.check(lib.amds_relu_bwd(saved["h"].data_ptr(), dh.data_ptr(), dzh.data_ptr(), dzh.numel(), st), "relu_bwd")
     if need_params:
-        g1 = torch.empty(Cd, Fd, **f32)
-        _bg(_tr(dzh), Bb * Tn, 0, 0, saved["a"], Fd, 0, 0, False, g1, Fd, 0, 0, 1, 1, Cd, Fd, Bb * Tn)
-        G["_fc1.0.weight"], G["_fc1.0.bias"] = g1, T.colsum(dzh)
+        G["_fc1.0.weight"], G["_fc1.0.bias"] = _wgrad(dzh.view(Bb, Tn, Cd), saved["a"].view(Bb, Tn, Fd)), T.colsum(dzh)
     dbags = None
     if need_bags:
         dbags = torch.empty(Bb * Tn, Fd, **f32)

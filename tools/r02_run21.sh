@@ -1,0 +1,11 @@
+set -x
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+cd $R
+( timeout 900 python -m pytest tests/test_gpu_transmil_train.py -q -m gpu -x 2>&1 | tail -8 ) > gpurun_out/r02_run21_pytest.log 2>&1
+tail -4 gpurun_out/r02_run21_pytest.log
+timeout 300 python tools/transmil_train_only.py 64 3 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/tools/transmil_train_only.py 64 2 > /tmp/kt.log 2>&1 < /dev/null
+DB=$(find /tmp/kt -name "*.db" | head -1); echo "db=$DB"
+[ -n "$DB" ] && timeout 60 python $R/tools/rocprof_summary.py "$DB" > $R/gpurun_out/r02_transmil_train_kernel_stats.txt
+head -14 $R/gpurun_out/r02_transmil_train_kernel_stats.txt | cut -c1-100,110-200
