@@ -95,3 +95,22 @@ def test_transmil_train_mode_dropout_and_optimizer(gpu):
         opt.step()
         losses.append(l.item())
     assert sum(losses[-3:]) < sum(losses[:3])
+
+
+@pytest.mark.parametrize("Z,M,N,K", [(6, 256, 64, 1280), (3, 130, 70, 50), (1, 512, 1024, 1024)])
+@pytest.mark.parametrize("transb", [False, True])
+def test_bgemm_f32_transposed_a_and_split_k_wgrad(gpu, Z, M, N, K, transb):
+    """amds_bgemm_f32 with A stored [K][M] (transb bit 1: the backward's x^T dy products without an explicit transpose), on shapes that take
+    the vector loads and on shapes that do not; and transmil_core._wgrad (per-bag products + fixed-order sum) against one fp64 product."""
+    from stamp_amd import transmil_core as tc
+    g = torch.Generator().manual_seed(Z * 7 + M)
+    A = torch.randn(Z, K, M, generator=g).to(gpu)
+    B = (torch.randn(Z, N, K, generator=g) if transb else torch.randn(Z, K, N, generator=g)).to(gpu)
+    out = tc._mm(A, B, transb, transa=True)
+    want = A.double().transpose(1, 2) @ (B.double().transpose(1, 2) if transb else B.double())
+    assert out.shape == (Z, M, N)
+    assert ((out.double() - want).norm() / want.norm()).item() < 2e-6
+    if not transb:
+        gw = tc._wgrad(A, B)                                    # sum_z A_z^T B_z
+        assert ((gw.double() - want.sum(0)).norm() / want.sum(0).norm()).item() < 2e-6
+        assert torch.equal(gw, tc._wgrad(A, B))                  # fixed summation order: bit-reproducible
