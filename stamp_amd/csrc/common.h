@@ -1,5 +1,6 @@
 // common.h -- shared device/host helpers for libamdstamp (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -155,6 +156,49 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                      // lane ^ 16
     return v;
 }
+// Eight (sum, sum of squares) pairs per lane -> for each of the 8 rows the total over the 32 lanes sharing lane >> 5, by recursive halving:
+// a lane gives away half of its rows at each of the first three steps (lane ^ 16: v_permlane16_swap; ^ 15, ^ 7: DPP mirrors) and ends with ONE row, which the last two
+// steps (lane ^ 1, ^ 2) complete: 8 + 4 + 2 + 2 exchanges instead of 8 x 5.  Returns the pair of row  4 * bit4 + 2 * bit3 + bit2  of the
+// lane index (so lanes with (lane & 3) == 0 hold each row once).  Same coset tree as half_wave_sum: invariant under lane -> lane ^ c.
+__device__ __forceinline__ f32x2 half_wave_sum8(const f32x2 (&v)[8], int lane) {
+    auto dpp = [](float x, auto ctrl_c) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl_c)::value, 0xF, 0xF, true));
+    };
+    typedef std::integral_constant<int, 0x140> MIRROR;
+    typedef std::integral_constant<int, 0x141> HALF_MIRROR;
+    typedef std::integral_constant<int, 0xB1> XOR1;
+    typedef std::integral_constant<int, 0x4E> XOR2;
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    f32x2 a[4], b[2], c;
+    // lane ^ 16 by v_permlane16_swap (gfx950): it swaps the odd 16-lane rows of its first operand with the even rows of its second, so
+    // with (rows j, rows 4 + j) as operands every lane ends up with its own value of the row it keeps and its partner's value of the
+    // same row -- no selects, no LDS pipe.
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // inline asm: with this toolchain the __builtin_amdgcn_permlane16_swap result pair reads element 0 twice (r[0] + r[1] compiles
+            // to v + v: tools/ubench/hws8_check.hip); the nops cover the VALU-write -> permlane-read and permlane-write -> VALU-read distances
+            // the compiler's hazard recogniser cannot see inside asm
+            float lo = v[j][e], hi4 = v[4 + j][e];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi4));
+            a[j][e] = lo + hi4;
+        }
+    (void)b4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x2 keep = b3 ? a[2 + j] : a[j], send = b3 ? a[j] : a[2 + j];
+        b[j] = keep + f32x2{dpp(send[0], MIRROR{}), dpp(send[1], MIRROR{})};
+    }
+    {
+        const f32x2 keep = b2 ? b[1] : b[0], send = b2 ? b[0] : b[1];
+        c = keep + f32x2{dpp(send[0], HALF_MIRROR{}), dpp(send[1], HALF_MIRROR{})};
+    }
+    c += f32x2{dpp(c[0], XOR1{}), dpp(c[1], XOR1{})};
+    c += f32x2{dpp(c[0], XOR2{}), dpp(c[1], XOR2{})};
+    return c;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

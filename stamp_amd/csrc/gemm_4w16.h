@@ -123,6 +123,14 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 #pragma unroll
             for (int j = 0; j < FJ; ++j) b0[j] = *reinterpret_cast<const f32x4*>(ep.bias + n0 + wn * 128 + j * 16 + 4 * kb);
         }
+        // the first K tile's LDS-DMA requests go out BEHIND the bias requests and BEFORE anything waits for the bias: the accumulator
+        // initialisation then only waits for the bias (counted), and its round trip is hidden under the operand tile's instead of preceding it
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pieces(0, 0, 16);
+        if constexpr (P3 < 0) {
+            if (K / BK > 1) issue_pieces(1, 0, 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -206,11 +214,9 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
-    const int nk = K / BK;   // >= 1
-    issue_pieces(0, 0, 16);
+    const int nk = K / BK;   // >= 1   (tile 0 -- and tile 1 with SCHED -- were requested above, behind the bias)
     if constexpr (SCHED) {
         if (nk > 1) {
-            issue_pieces(1, 0, 16);
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,23 +437,19 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                         if constexpr (LNP) {
                             // 16-bit copy of the updated rows + this pass's partial row sums (the LayerNorm that follows is folded into
                             // the next GEMM, which reads the copy as its A operand)
-                            float s1[8], s2[8];
+                            f32x2 ss[8];
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 const vec4 c = Act<T>::from_f32x4(v[u]);
                                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c), rsrc_h, (offu[b8 & 1][u] + rowoff) >> 1, 0, 0);
-                                s1[u] = half_wave_sum((v[u][0] + v[u][1]) + (v[u][2] + v[u][3]));
-                                s2[u] = half_wave_sum(fmaf(v[u][0], v[u][0], v[u][1] * v[u][1]) + fmaf(v[u][2], v[u][2], v[u][3] * v[u][3]));
+                                ss[u] = f32x2{(v[u][0] + v[u][1]) + (v[u][2] + v[u][3]),
+                                              fmaf(v[u][0], v[u][0], v[u][1] * v[u][1]) + fmaf(v[u][2], v[u][2], v[u][3] * v[u][3])};
                             }
-                            float m1 = s1[0], m2 = s2[0];
-#pragma unroll
-                            for (int u = 1; u < 8; ++u) {
-                                m1 = (l31 == u) ? s1[u] : m1;
-                                m2 = (l31 == u) ? s2[u] : m2;
-                            }
-                            const int prow = m0 + wave * 64 + b8 * 16 + 2 * l31 + hi;           // lanes l31 < 8: row of (b8, u = l31, hi)
-                            if (l31 < 8 && prow < M)
-                                *reinterpret_cast<f32x2*>(ep.rowpart + ((long)prow * np_part + tn * 2 + pass) * 2) = f32x2{m1, m2};
+                            const f32x2 tot = half_wave_sum8(ss, l31);       // row u = 4 bit4 + 2 bit3 + bit2 of l31, complete in every lane
+                            const int urow = ((l31 >> 4) & 1) * 4 + ((l31 >> 3) & 1) * 2 + ((l31 >> 2) & 1);
+                            const int prow = m0 + wave * 64 + b8 * 16 + 2 * urow + hi;
+                            if ((l31 & 3) == 0 && prow < M)
+                                *reinterpret_cast<f32x2*>(ep.rowpart + ((long)prow * np_part + tn * 2 + pass) * 2) = tot;
                         }
                         if (pass == 0) load_old(1, b8);
                         __builtin_amdgcn_sched_barrier(0);
