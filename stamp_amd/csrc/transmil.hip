@@ -91,23 +91,27 @@ __global__ void __launch_bounds__(256) bgemm_f32_kernel(const float* __restrict_
 // 8 values a lane needs per 16-deep k-tile (k = hi, hi + 2, ...) are two ds_read_b128; global loads are float4 and the next
 // k-tile is fetched into registers while the current one is multiplied.  Requires K, lda, ldb multiples of 4 and 16-byte
 // aligned operands; the 64 x 64 kernel above remains the fallback.
-template <int TRANSB, int TRANSA = 0>
+// WM x WN = 4 waves: 2 x 2 -> 128 x 128 tile; 4 x 1 -> 256 x 64 (products with N <= 64: the per-head d = 64 outputs would leave half of
+// a 128-wide tile empty); 1 x 4 -> 64 x 256 (M <= 64).
+template <int TRANSB, int TRANSA = 0, int WM = 2, int WN = 2>
 __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restrict__ A, int lda, long sAo, long sAi,
                                                             const float* __restrict__ B, int ldb, long sBo, long sBi,
                                                             float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
                                                             int M, int N, int K, float alpha, float diag,
                                                             const float* __restrict__ bias, int accumulate, int vec) {
-    constexpr int BT = 128, BK = 16, LDT = 20;
-    __shared__ __attribute__((aligned(16))) float sA[BT * LDT];
-    __shared__ __attribute__((aligned(16))) float sB[BT * LDT];
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16, LDT = 20;
+    constexpr int ITA = BM * 4 / 256, ITB = BN * 4 / 256;          // float4 pieces per thread and K step
+    __shared__ __attribute__((aligned(16))) float sA[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int zo = blockIdx.z / inner, zi = blockIdx.z - zo * inner;
     A += zo * sAo + zi * sAi;
     B += zo * sBo + zi * sBi;
     Cm += zo * sCo + zi * sCi;
-    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -115,82 +119,65 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 ra[2], rb[2];
-    auto gload = [&](int k0) {
-        if (!vec) {      // any shape / alignment: element loads with bounds (small or odd problems only)
+    f32x4 ra[ITA], rb[ITB];
+    // one operand tile (R rows of the output dimension x 16 k) -> registers.  Row-major in k (TR = 0: float4 along k, 4 pieces per
+    // row) or k-major (TR = 1: the operand is stored [K][R], float4 along the row dimension, R / 4 pieces per k).
+    auto gload_op = [&](auto tr_c, auto it_c, f32x4* r, const float* P, int ld, int R, int r0, int k0, int RT) {
+        constexpr int TR = decltype(tr_c)::value, IT = decltype(it_c)::value;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4, kq = c >> 5, q4 = (c & 31) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (TRANSA) { const int gk = k0 + kq, gm = m0 + q4 + e; ra[it][e] = (gk < K && gm < M) ? A[(long)gk * lda + gm] : 0.f; }
-                    else { const int gm = m0 + row, gk = k0 + c4 + e; ra[it][e] = (gk < K && gm < M) ? A[(long)gm * lda + gk] : 0.f; }
-                    if (TRANSB) { const int gn = n0 + row, gk = k0 + c4 + e; rb[it][e] = (gk < K && gn < N) ? B[(long)gn * ldb + gk] : 0.f; }
-                    else { const int gk = k0 + kq, gn = n0 + q4 + e; rb[it][e] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : 0.f; }
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4;
-            const int gm = m0 + row;
-            ra[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (TRANSA) {                             // A stored [K][M] (the product is A^T B): float4 along m
-                const int k = c >> 5, m4 = (c & 31) * 4;
-                const int gk = k0 + k, gm4 = m0 + m4;
-                if (gk < K && gm4 + 3 < M) ra[it] = *reinterpret_cast<const f32x4*>(A + (long)gk * lda + gm4);
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * 256 + tid;
+            r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TR) {
+                const int k = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
+                const int gk = k0 + k, gr = r0 + q4;
+                if (vec && gk < K && gr + 3 < R) r[it] = *reinterpret_cast<const f32x4*>(P + (long)gk * ld + gr);
                 else if (gk < K) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (gm4 + e < M) ra[it][e] = A[(long)gk * lda + gm4 + e];
+                    for (int e = 0; e < 4; ++e) if (gr + e < R) r[it][e] = P[(long)gk * ld + gr + e];
                 }
-            } else if (gm < M && k0 + c4 < K) ra[it] = *reinterpret_cast<const f32x4*>(A + (long)gm * lda + k0 + c4);
-            rb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (TRANSB) {
-                const int gn = n0 + row;
-                if (gn < N && k0 + c4 < K) rb[it] = *reinterpret_cast<const f32x4*>(B + (long)gn * ldb + k0 + c4);
-            } else {                                  // B stored [K][N]: float4 along n
-                const int k = c >> 5, n4 = (c & 31) * 4;
-                const int gk = k0 + k, gn = n0 + n4;
-                if (gk < K && gn + 3 < N) rb[it] = *reinterpret_cast<const f32x4*>(B + (long)gk * ldb + gn);
-                else if (gk < K) {
+            } else {
+                const int row = c >> 2, c4 = (c & 3) * 4;
+                const int gr = r0 + row, gk = k0 + c4;
+                if (vec && gr < R && gk < K) r[it] = *reinterpret_cast<const f32x4*>(P + (long)gr * ld + gk);       // vec: K % 4 == 0
+                else if (gr < R) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (gn + e < N) rb[it][e] = B[(long)gk * ldb + gn + e];
+                    for (int e = 0; e < 4; ++e) if (gk + e < K) r[it][e] = P[(long)gr * ld + gk + e];
                 }
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore_op = [&](auto tr_c, auto it_c, const f32x4* r, float* S, int RT) {
+        constexpr int TR = decltype(tr_c)::value, IT = decltype(it_c)::value;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int c = it * 256 + tid, row = c >> 2, c4 = (c & 3) * 4;
-            if (TRANSA) {
-                const int k = c >> 5, m4 = (c & 31) * 4;
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * 256 + tid;
+            if (TR) {
+                const int k = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sA[(m4 + e) * LDT + (k & 1) * 8 + (k >> 1)] = ra[it][e];
+                for (int e = 0; e < 4; ++e) S[(q4 + e) * LDT + (k & 1) * 8 + (k >> 1)] = r[it][e];
             } else {
+                const int row = c >> 2, c4 = (c & 3) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = c4 + e;
-                    sA[row * LDT + (k & 1) * 8 + (k >> 1)] = ra[it][e];
+                    S[row * LDT + (k & 1) * 8 + (k >> 1)] = r[it][e];
                 }
-            }
-            if (TRANSB) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = c4 + e;
-                    sB[row * LDT + (k & 1) * 8 + (k >> 1)] = rb[it][e];
-                }
-            } else {
-                const int k = c >> 5, n4 = (c & 31) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sB[(n4 + e) * LDT + (k & 1) * 8 + (k >> 1)] = rb[it][e];
             }
         }
+    };
+    typedef std::integral_constant<int, TRANSA> TA;
+    typedef std::integral_constant<int, TRANSB ? 0 : 1> TBK;        // B stored [K][N] (no transb) is the k-major case
+    typedef std::integral_constant<int, ITA> IA;
+    typedef std::integral_constant<int, ITB> IB;
+    auto gload = [&](int k0) {
+        gload_op(TA{}, IA{}, ra, A, lda, M, m0, k0, BM);
+        gload_op(TBK{}, IB{}, rb, B, ldb, N, n0, k0, BN);
     };
     gload(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
-        lstore();
+        lstore_op(TA{}, IA{}, ra, sA, BM);
+        lstore_op(TBK{}, IB{}, rb, sB, BN);
         __syncthreads();
         if (k0 + BK < K) gload(k0 + BK);
         f32x4 fa[2][2], fb[2][2];
@@ -595,17 +582,26 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
                         ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
     const bool transa = (transb & 2) != 0;            // bit 1: A is stored [K][M] (pitch lda), the product is A^T B
     transb &= 1;
-    if (transa) {
-        const dim3 gbig(cdiv(N, 128), cdiv(M, 128), outer * inner);
-        if (transb) hipLaunchKernelGGL((bgemm_f32_big_kernel<1, 1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, vec_ok ? 1 : 0);
-        else hipLaunchKernelGGL((bgemm_f32_big_kernel<0, 1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, vec_ok ? 1 : 0);
-        AMDS_LAUNCH_CHECK("bgemm_f32_big_kernel(transa)");
-        return AMDS_OK;
-    }
-    if (vec_ok && M >= 96 && N >= 96) {
-        const dim3 gbig(cdiv(N, 128), cdiv(M, 128), outer * inner);
-        if (transb) hipLaunchKernelGGL((bgemm_f32_big_kernel<1>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, 1);
-        else hipLaunchKernelGGL((bgemm_f32_big_kernel<0>), gbig, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate, 1);
+    if (transa || (vec_ok && (M >= 96 || N >= 96))) {
+        // tile shape by the output's shape: 256 x 64 when N <= 64 (per-head d = 64 outputs), 64 x 256 when M <= 64, else 128 x 128
+        const int shape = (N <= 64 && M > 64) ? 1 : (M <= 64 && N > 64) ? 2 : 0;
+        const dim3 grid3(cdiv(N, shape == 1 ? 64 : shape == 2 ? 256 : 128), cdiv(M, shape == 1 ? 256 : shape == 2 ? 64 : 128), outer * inner);
+        const int vec = vec_ok ? 1 : 0;
+#define AMDS_BG(TB, TA, WM_, WN_)                                                                                                              \
+    hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
+                       inner, M, N, K, alpha, diag, bias, accumulate, vec)
+#define AMDS_BG_SHAPE(TB, TA)                                     \
+    do {                                                          \
+        if (shape == 1) AMDS_BG(TB, TA, 4, 1);                    \
+        else if (shape == 2) AMDS_BG(TB, TA, 1, 4);               \
+        else AMDS_BG(TB, TA, 2, 2);                               \
+    } while (0)
+        if (transb && transa) AMDS_BG_SHAPE(1, 1);
+        else if (transb) AMDS_BG_SHAPE(1, 0);
+        else if (transa) AMDS_BG_SHAPE(0, 1);
+        else AMDS_BG_SHAPE(0, 0);
+#undef AMDS_BG_SHAPE
+#undef AMDS_BG
         AMDS_LAUNCH_CHECK("bgemm_f32_big_kernel");
         return AMDS_OK;
     }
