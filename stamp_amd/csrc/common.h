@@ -168,7 +168,7 @@ __device__ __forceinline__ f32x2 half_wave_sum8(const f32x2 (&v)[8], int lane) {
     typedef std::integral_constant<int, 0x141> HALF_MIRROR;
     typedef std::integral_constant<int, 0xB1> XOR1;
     typedef std::integral_constant<int, 0x4E> XOR2;
-    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    const bool b3 = lane & 8, b2 = lane & 4;
     f32x2 a[4], b[2], c;
     // lane ^ 16 by v_permlane16_swap (gfx950): it swaps the odd 16-lane rows of its first operand with the even rows of its second, so
     // with (rows j, rows 4 + j) as operands every lane ends up with its own value of the row it keeps and its partner's value of the
@@ -184,7 +184,6 @@ __device__ __forceinline__ f32x2 half_wave_sum8(const f32x2 (&v)[8], int lane) {
             asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi4));
             a[j][e] = lo + hi4;
         }
-    (void)b4;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const f32x2 keep = b3 ? a[2 + j] : a[j], send = b3 ? a[j] : a[2 + j];

@@ -235,7 +235,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     constexpr bool RMW = (EPI == AMDS_EPI_RESIDUAL);
     const bool rmw_fast = RMW && (bias_in_acc || ep.bias == nullptr) && ep.acc_scale == 1.0f;
     const int ldo4 = (int)ep.ldo * 4;
-    __amdgpu_buffer_rsrc_t rsrc_o = rsrc_a;
+    __amdgpu_buffer_rsrc_t rsrc_o = rsrc_a;              // (re-pointed at the output rows by the residual epilogue)
     int offu[RMW ? 2 : 1][RMW ? 8 : 1];
     f32x4 old[RMW ? 4 : 1][RMW ? 8 : 1];
     auto load_old = [&](int pass, int b8) {
