@@ -101,91 +101,93 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     AMDS_TRY(amds_gemm(mlp, pl.kp, w->patch_w, pl.kp, Bc * pl.np, D, pl.kp, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
                        nullptr, w->pos_patch, pl.np, T, c->n_prefix, 1.0f / 255.0f, st));
 
-    // ---- ragged tail on a side stream.  The GEMMs work on 256-row tiles, one workgroup per CU: M = 64 x 257 rows (the reference's
-    // DataLoader batch) is 64 full row tiles + 64 rows, and that 65th row tile costs every GEMM a whole extra wave of workgroups on a
-    // mostly idle chip (proj / fc2: 260 tiles on 256 CUs = two waves for the work of one).  Everything except attention is
-    // row-local, so the last M % 256 rows run as their own chain of launches on the side stream and meet the main rows only around
-    // attention: their few workgroups fill CUs while the main chain's next kernel ramps up.  Same kernels, same arithmetic, same
-    // bits -- only the launch geometry changes.  Used when the remainder is at most half a tile.
-    const int rem = M % 256;
-    const bool split = sd.side != nullptr && rem > 0 && rem <= 128 && M - rem >= 256;
-    struct Part { int r0, n; hipStream_t s; };
-    Part parts[2] = {{0, split ? M - rem : M, st}, {M - rem, rem, sd.side}};
-    const int nparts = split ? 2 : 1;
-    bool forked = false;
-    auto fork = [&]() -> int {
-        if (!split) return AMDS_OK;
-        AMDS_HIP(hipEventRecord(sd.ev_fork, st));
-        AMDS_HIP(hipStreamWaitEvent(sd.side, sd.ev_fork, 0));
-        forked = true;
-        return AMDS_OK;
+    // ---- ragged tail on a side stream.  The GEMMs work on 256-row tiles, one workgroup per CU, and every launch is a whole number of
+    // waves of workgroups: M = 64 x 257 rows (the reference's DataLoader batch) is 64.25 row tiles, and the 65th row tile costs every GEMM
+    // a whole extra wave on a mostly idle chip (proj / fc2: 260 workgroups on 256 CUs = two waves for the work of one; 19 tile-time units
+    // per block instead of 12).  Tiles are independent through the WHOLE network (attention is per tile, everything else per row), so the
+    // last tile(s) of the batch run as their own chain of launches on the side stream, from the first LayerNorm to the last fc2, and
+    // meet the main tiles once, before the final norm: their few workgroups fill CUs the main chain leaves idle at its wave boundaries.
+    // Same kernels, same arithmetic, same bits -- only the launch geometry changes.  A tail is split off when removing 1 or 2 tiles lowers the main chain's waves per block
+    // (weights: qkv 1, proj 1, fc1 1, fc2 K/D).
+    auto block_units = [&](int tiles) {
+        const long rt = ((long)tiles * T + 255) / 256;                      // row tiles of the main chain
+        auto waves = [&](long tn) { return (rt * tn + 255) / 256; };
+        const long kf = Hd / D > 0 ? Hd / D : 1;
+        return waves(3 * D / 256) + waves(D / 256) + waves(n_fc1 / 256) + kf * waves(D / 256);
     };
-    auto join = [&]() -> int {
-        if (!split || !forked) return AMDS_OK;
-        forked = false;
-        AMDS_HIP(hipEventRecord(sd.ev_join, sd.side));
-        AMDS_HIP(hipStreamWaitEvent(st, sd.ev_join, 0));
-        return AMDS_OK;
-    };
-    auto rows16 = [&](char* base, int r0, long pitch_elems) { return base + (size_t)r0 * pitch_elems * 2; };   // 16-bit row buffers
+    int n_tail = 0;
+    if (sd.side != nullptr && D % 256 == 0 && n_fc1 % 256 == 0 && Bc >= 8) {
+        long best = block_units(Bc);
+        for (int t = 1; t <= 2; ++t) {
+            const long u = block_units(Bc - t);
+            if (u < best) { best = u; n_tail = t; }
+        }
+        // Every main launch being a whole number of full waves, a tail workgroup always displaces a main one: a few more tail tiles leave
+        // the main launches a few idle CUs per wave for the tail to land on (B = 64: 1 / 2 / 4 / 6 tail tiles -> 4 695 / 4 777 / 4 824 / 4 818 tiles/s)
+        if (n_tail > 0) n_tail = Bc / 8 < 4 ? (Bc / 8 > n_tail ? Bc / 8 : n_tail) : 4;
+    }
+    struct Part { int t0, nt; hipStream_t s; };
+    const Part parts[2] = {{0, Bc - n_tail, st}, {Bc - n_tail, n_tail, sd.side}};
+    const int nparts = n_tail > 0 ? 2 : 1;
+    auto rows16 = [&](char* base, long r0, long pitch_elems) { return base + (size_t)r0 * pitch_elems * 2; };   // 16-bit row buffers
 
-    auto body = [&]() -> int {
-        if (fold) AMDS_TRY(amds_ln_stats_cast(x, D, M, D, c->ln_eps, h, D, rowstat, dt, st));
-        AMDS_TRY(fork());
+    // the whole depth for tiles [t0, t0 + nt) on stream s
+    auto run_tiles = [&](const Part& q) -> int {
+        const long r0 = (long)q.t0 * T;
+        const int n = q.nt * T;
+        hipStream_t s = q.s;
+        float* xq = x + (size_t)r0 * D;
+        float* rp = rowpart + (size_t)r0 * NP * 2;
+        float* rs = rowstat + 2 * (size_t)r0;
+        char *hq = rows16(h, r0, D), *h2q = rows16(h2, r0, D), *qkvq = rows16(qkv, r0, 3 * D), *mlpq = rows16(mlp, r0, Hd);
+        const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU;
+        if (fold) AMDS_TRY(amds_ln_stats_cast(xq, D, n, D, c->ln_eps, hq, D, rs, dt, s));
         for (int l = 0; l < c->depth; ++l) {
             const amds_vit_block& b = w->blocks_host[l];
             const bool last = l + 1 == c->depth;
-            for (int p = 0; p < nparts; ++p) {
-                const Part& q = parts[p];
-                if (fold) {
-                    AMDS_TRY(amds_gemm_lnfold(rows16(h, q.r0, D), D, b.qkv_w, D, q.n, 3 * D, D, dt, AMDS_EPI_BIAS, rows16(qkv, q.r0, 3 * D), 3 * D,
-                                              b.qkv_b, nullptr, nullptr, nullptr, rowstat + 2 * (size_t)q.r0, b.qkv_colsum, q.s));
-                } else {
-                    AMDS_TRY(amds_layernorm(x + (size_t)q.r0 * D, D, b.ln1_w, b.ln1_b, rows16(h, q.r0, D), D, q.n, D, c->ln_eps, dt, q.s));
-                    AMDS_TRY(enc_gemm(rows16(h, q.r0, D), D, b.qkv_w, D, q.n, 3 * D, D, AMDS_EPI_BIAS, rows16(qkv, q.r0, 3 * D), 3 * D, b.qkv_b,
-                                      nullptr, q.s));
-                }
+            const float* ls1 = c->layerscale ? b.ls1 : nullptr;
+            const float* ls2 = c->layerscale ? b.ls2 : nullptr;
+            if (fold) {
+                AMDS_TRY(amds_gemm_lnfold(hq, D, b.qkv_w, D, n, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rs,
+                                          b.qkv_colsum, s));
+            } else {
+                AMDS_TRY(amds_layernorm(xq, D, b.ln1_w, b.ln1_b, hq, D, n, D, c->ln_eps, dt, s));
+                AMDS_TRY(enc_gemm(hq, D, b.qkv_w, D, n, 3 * D, D, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, s));
             }
-            AMDS_TRY(join());
-            AMDS_TRY(amds_attention_vit_hd(qkv, h, Bc, T, c->heads, D / c->heads, dt, st));
-            AMDS_TRY(fork());
-            for (int p = 0; p < nparts; ++p) {
-                const Part& q = parts[p];
-                float* xq = x + (size_t)q.r0 * D;
-                const float* ls1 = c->layerscale ? b.ls1 : nullptr;
-                const float* ls2 = c->layerscale ? b.ls2 : nullptr;
-                const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU;
-                if (fold) {
-                    float* rp = rowpart + (size_t)q.r0 * NP * 2;
-                    float* rs = rowstat + 2 * (size_t)q.r0;
-                    AMDS_TRY(amds_gemm_lnfold(rows16(h, q.r0, D), D, b.proj_w, D, q.n, D, D, dt, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1,
-                                              rows16(h2, q.r0, D), rp, nullptr, nullptr, q.s));
-                    AMDS_TRY(amds_ln_rowstat(rp, q.n, NP, D, c->ln_eps, rs, q.s));
-                    AMDS_TRY(amds_gemm_lnfold(rows16(h2, q.r0, D), D, b.fc1_w, D, q.n, n_fc1, D, dt, epi1, rows16(mlp, q.r0, Hd), Hd, b.fc1_b, nullptr,
-                                              nullptr, nullptr, rs, b.fc1_colsum, q.s));
-                    if (!last) {
-                        AMDS_TRY(amds_gemm_lnfold(rows16(mlp, q.r0, Hd), Hd, b.fc2_w, Hd, q.n, D, Hd, dt, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2,
-                                                  rows16(h, q.r0, D), rp, nullptr, nullptr, q.s));
-                        AMDS_TRY(amds_ln_rowstat(rp, q.n, NP, D, c->ln_eps, rs, q.s));
-                    } else {
-                        AMDS_TRY(enc_gemm(rows16(mlp, q.r0, Hd), Hd, b.fc2_w, Hd, q.n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, q.s));
-                    }
+            AMDS_TRY(amds_attention_vit_hd(qkvq, hq, q.nt, T, c->heads, D / c->heads, dt, s));
+            if (fold) {
+                AMDS_TRY(amds_gemm_lnfold(hq, D, b.proj_w, D, n, D, D, dt, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, h2q, rp, nullptr, nullptr, s));
+                AMDS_TRY(amds_ln_rowstat(rp, n, NP, D, c->ln_eps, rs, s));
+                AMDS_TRY(amds_gemm_lnfold(h2q, D, b.fc1_w, D, n, n_fc1, D, dt, epi1, mlpq, Hd, b.fc1_b, nullptr, nullptr, nullptr, rs, b.fc1_colsum, s));
+                if (!last) {
+                    AMDS_TRY(amds_gemm_lnfold(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, dt, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, hq, rp, nullptr, nullptr, s));
+                    AMDS_TRY(amds_ln_rowstat(rp, n, NP, D, c->ln_eps, rs, s));
                 } else {
-                    AMDS_TRY(enc_gemm(rows16(h, q.r0, D), D, b.proj_w, D, q.n, D, D, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, q.s));
-                    AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, rows16(h, q.r0, D), D, q.n, D, c->ln_eps, dt, q.s));
-                    AMDS_TRY(enc_gemm(rows16(h, q.r0, D), D, b.fc1_w, D, q.n, n_fc1, D, epi1, rows16(mlp, q.r0, Hd), Hd, b.fc1_b, nullptr, q.s));
-                    AMDS_TRY(enc_gemm(rows16(mlp, q.r0, Hd), Hd, b.fc2_w, Hd, q.n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, q.s));
+                    AMDS_TRY(enc_gemm(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, s));
                 }
+            } else {
+                AMDS_TRY(enc_gemm(hq, D, b.proj_w, D, n, D, D, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, s));
+                AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, hq, D, n, D, c->ln_eps, dt, s));
+                AMDS_TRY(enc_gemm(hq, D, b.fc1_w, D, n, n_fc1, D, epi1, mlpq, Hd, b.fc1_b, nullptr, s));
+                AMDS_TRY(enc_gemm(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, s));
             }
         }
         return AMDS_OK;
     };
-    rc = body();
-    {   // join the side stream back on EVERY path: after an error nothing may still be running on it unordered
-        const int rj = join();
-        if (rc != AMDS_OK) return rc;
-        if (rj != AMDS_OK) return rj;
+    if (nparts == 2) {     // fork: the tail chain starts once the patch embedding is done
+        AMDS_HIP(hipEventRecord(sd.ev_fork, st));
+        AMDS_HIP(hipStreamWaitEvent(sd.side, sd.ev_fork, 0));
     }
+    rc = AMDS_OK;
+    for (int p = nparts - 1; p >= 0 && rc == AMDS_OK; --p) rc = run_tiles(parts[p]);      // the tail's launches are queued first
+    if (nparts == 2) {     // join on EVERY path: after an error nothing may still be running on the side stream unordered
+        const hipError_t e1 = hipEventRecord(sd.ev_join, sd.side);
+        const hipError_t e2 = hipStreamWaitEvent(st, sd.ev_join, 0);
+        if (rc != AMDS_OK) return rc;
+        if (e1 != hipSuccess) return hip_fail(e1, "hipEventRecord(join)");
+        if (e2 != hipSuccess) return hip_fail(e2, "hipStreamWaitEvent(join)");
+    }
+    if (rc != AMDS_OK) return rc;
     // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32
     AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));
     if (tokens_f32) AMDS_TRY(amds_layernorm(x, D, w->norm_w, w->norm_b, tokens_f32, D, M, D, c->ln_eps, AMDS_F32, st));
@@ -225,10 +227,7 @@ extern "C" int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_
     VitSide sd;
     static const bool tail_on = !(getenv("AMDS_VIT_TAIL") && atoi(getenv("AMDS_VIT_TAIL")) == 0);
     bool any_tail = false;
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int m = ((B - b0 < chunk) ? B - b0 : chunk) * pl.T;
-        any_tail = any_tail || (m % 256 != 0 && m % 256 <= 128 && m >= 512);
-    }
+    for (int b0 = 0; b0 < B; b0 += chunk) any_tail = any_tail || ((B - b0 < chunk ? B - b0 : chunk) >= 8);
     if (tail_on && any_tail) {
         if (amds_ctx* cx = ctx_of_current_device()) {
             hipEvent_t a = nullptr, b = nullptr;
