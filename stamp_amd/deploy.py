@@ -1,0 +1,92 @@
+"""`stamp deploy` on the HIP heads: the prediction step and the CSV shaping around the MIL forward.
+
+Restates what the reference does AROUND `model(bags, coords=..., mask=...)`:
+  * `_predict` (src/stamp/modeling/deploy.py:390-456): eval mode, one forward per patient batch, outputs concatenated in patient order;
+    classification -> `softmax(dim=1)` (:447-448), survival -> `squeeze(-1)` (:449-450), regression raw.
+  * `_to_prediction_df` single-target (:563-590), `_to_regression_prediction_df` (:593-637), `_to_survival_prediction_df` (:640-691):
+    column names, row order and the per-patient `loss` as the reference computes it -- including that the classification loss is
+    `cross_entropy` applied to the PROBABILITIES (the softmax output is fed to a function that applies log-softmax again, :577-583).
+
+Parity: unpinned by fixtures (the reference module cannot be imported here: it needs `lightning` and `h5py`); the tests check these
+functions against the formulas above evaluated directly.  The model is any of `stamp_amd.mil`'s heads (or any module with the
+reference's forward signature); with `torch.no_grad()` + `.eval()` they take the forward-only HIP path.
+"""
+from __future__ import annotations
+
+from collections.abc import Iterable, Mapping, Sequence
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.nn.functional as F
+
+__all__ = ["predict_", "to_prediction_df", "to_regression_prediction_df", "to_survival_prediction_df"]
+
+
+@torch.no_grad()
+def predict_(model: torch.nn.Module, batches: Iterable, patient_ids: Sequence[str], *, task: str, device="cuda") -> dict[str, torch.Tensor]:
+    """batches: iterable of (bags, coords, bag_sizes, targets) as the reference's test DataLoader yields them (full bags, batch 1,
+    `modeling/data.py:255-277`); only bags / coords are used (`Lit*.predict_step`, `models/__init__.py:302-313`: `mask=None`).
+    Returns patient -> prediction on the CPU: class probabilities (classification), raw value (regression), risk score (survival)."""
+    if task not in ("classification", "regression", "survival"):
+        raise ValueError(f"unknown task {task!r}")
+    model = model.to(device).eval()
+    outs = []
+    for bags, coords, *_ in batches:
+        out = model(bags.to(device), coords=None if coords is None else coords.to(device), mask=None)
+        outs.append(out.float().cpu())
+    if not outs:
+        return {}
+    raw = torch.cat(outs, dim=0)
+    if task == "classification":
+        raw = torch.softmax(raw, dim=1)
+    elif task == "survival":
+        raw = raw.squeeze(-1)
+    if raw.shape[0] != len(patient_ids):
+        raise ValueError(f"{raw.shape[0]} predictions for {len(patient_ids)} patients")
+    return {pid: raw[i] for i, pid in enumerate(patient_ids)}
+
+
+def to_prediction_df(*, categories: Sequence, patient_to_ground_truth: Mapping, predictions: Mapping[str, torch.Tensor], patient_label: str,
+                     ground_truth_label: str) -> pd.DataFrame:
+    """patient | ground truth | pred | <ground_truth_label>_<category> ... | loss, sorted by loss (deploy.py:563-590)."""
+    cats = list(categories)
+    rows = []
+    for pid, prediction in predictions.items():
+        gt = patient_to_ground_truth.get(pid)
+        row = {patient_label: pid, ground_truth_label: gt, "pred": cats[int(prediction.argmax())]}
+        for i_cat, category in enumerate(cats):
+            row[f"{ground_truth_label}_{category}"] = float(prediction[i_cat].item())
+        row["loss"] = (F.cross_entropy(prediction.reshape(1, -1), torch.tensor(np.where(np.array(cats) == gt)[0])).item()
+                       if gt is not None else None)
+        rows.append(row)
+    return pd.DataFrame(rows).sort_values(by="loss")
+
+
+def to_regression_prediction_df(*, patient_to_ground_truth: Mapping, predictions: Mapping[str, torch.Tensor], patient_label: str,
+                                ground_truth_label: str) -> pd.DataFrame:
+    """patient | ground truth | pred | loss (per-sample L1 when the ground truth is a number), sorted by loss, missing last (:593-637)."""
+    rows = []
+    for pid, prediction in predictions.items():
+        gt = patient_to_ground_truth.get(pid)
+        has = gt is not None and str(gt).lower() != "nan" and prediction.numel() == 1
+        rows.append({patient_label: pid, ground_truth_label: gt,
+                     "pred": float(prediction.flatten().item()) if prediction.numel() == 1 else prediction.cpu().tolist(),
+                     "loss": F.l1_loss(prediction.flatten(), torch.tensor([float(gt)], dtype=prediction.dtype)).item() if has else None})
+    return pd.DataFrame(rows).sort_values(by="loss", na_position="last")
+
+
+def to_survival_prediction_df(*, patient_to_ground_truth: Mapping, predictions: Mapping[str, torch.Tensor], patient_label: str,
+                              time_label: str = "time", status_label: str = "event", cut_off: float | None = None) -> pd.DataFrame:
+    """patient | pred_score | time | event (| cut_off=<c>), in prediction order; ground truth is a (time, event) pair or unknown (:640-691)."""
+    rows = []
+    for pid, pred in predictions.items():
+        pred = pred.detach().flatten()
+        gt = patient_to_ground_truth.get(pid)
+        row = {patient_label: pid, "pred_score": float(pred.item()) if pred.numel() == 1 else pred.cpu().tolist()}
+        row[time_label], row[status_label] = gt if isinstance(gt, (tuple, list)) and len(gt) == 2 else (None, None)
+        rows.append(row)
+    df = pd.DataFrame(rows)
+    if cut_off is not None:
+        df[f"cut_off={cut_off}"] = None
+    return df

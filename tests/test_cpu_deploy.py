@@ -1,0 +1,65 @@
+"""The shaping around the MIL forward that `stamp deploy` does (stamp_amd/deploy.py; reference src/stamp/modeling/deploy.py:390-691),
+checked against the reference's formulas evaluated directly (no fixtures: the reference module needs lightning + h5py to import)."""
+import math
+
+import pandas as pd
+import torch
+
+from stamp_amd.deploy import predict_, to_prediction_df, to_regression_prediction_df, to_survival_prediction_df
+
+
+class _Head(torch.nn.Module):
+    """Stand-in with the reference heads' forward signature: mean over tiles, then a Linear."""
+
+    def __init__(self, f, c):
+        super().__init__()
+        self.lin = torch.nn.Linear(f, c)
+
+    def forward(self, bags, *, coords=None, mask=None):
+        assert mask is None
+        return self.lin(bags.float().mean(1))
+
+
+def test_predict_tasks_and_order():
+    torch.manual_seed(0)
+    head = _Head(8, 3)
+    bags = [torch.randn(1, n, 8) for n in (5, 9, 2)]
+    batches = [(b, torch.zeros(1, b.shape[1], 2), None, None) for b in bags]
+    pids = ["p2", "p0", "p1"]
+    out = predict_(head, batches, pids, task="classification", device="cpu")
+    assert list(out) == pids
+    for b, pid in zip(bags, pids):
+        want = torch.softmax(head(b), dim=1)[0]
+        assert torch.allclose(out[pid], want.detach(), atol=1e-6) and abs(out[pid].sum().item() - 1) < 1e-6
+    surv = predict_(_Head(8, 1), batches, pids, task="survival", device="cpu")
+    assert all(v.dim() == 0 for v in surv.values())
+    reg = predict_(_Head(8, 1), batches, pids, task="regression", device="cpu")
+    assert all(v.shape == (1,) for v in reg.values())
+
+
+def test_classification_table_columns_loss_and_order():
+    cats = ["mut", "wt"]
+    preds = {"a": torch.tensor([0.9, 0.1]), "b": torch.tensor([0.3, 0.7]), "c": torch.tensor([0.6, 0.4])}
+    gts = {"a": "wt", "b": "wt", "c": None}
+    df = to_prediction_df(categories=cats, patient_to_ground_truth=gts, predictions=preds, patient_label="PATIENT", ground_truth_label="KRAS")
+    assert list(df.columns) == ["PATIENT", "KRAS", "pred", "KRAS_mut", "KRAS_wt", "loss"]
+    # the reference feeds PROBABILITIES to cross_entropy: loss = -log softmax(p)[target]
+    la = -math.log(math.exp(0.1) / (math.exp(0.9) + math.exp(0.1)))
+    lb = -math.log(math.exp(0.7) / (math.exp(0.3) + math.exp(0.7)))
+    assert list(df["PATIENT"]) == ["b", "a", "c"]                   # sorted by loss, missing last
+    assert abs(df.iloc[0]["loss"] - lb) < 1e-6 and abs(df.iloc[1]["loss"] - la) < 1e-6 and pd.isna(df.iloc[2]["loss"])
+    assert list(df["pred"]) == ["wt", "mut", "mut"]
+    assert abs(df.iloc[1]["KRAS_mut"] - 0.9) < 1e-6
+
+
+def test_regression_and_survival_tables():
+    preds = {"a": torch.tensor([2.5]), "b": torch.tensor([1.0]), "c": torch.tensor([0.5])}
+    df = to_regression_prediction_df(patient_to_ground_truth={"a": 2.0, "b": None, "c": "nan"}, predictions=preds, patient_label="P",
+                                     ground_truth_label="age")
+    assert list(df.columns) == ["P", "age", "pred", "loss"]
+    assert list(df["P"])[0] == "a" and abs(df.iloc[0]["loss"] - 0.5) < 1e-6 and df["loss"].isna().sum() == 2
+    sdf = to_survival_prediction_df(patient_to_ground_truth={"a": (302.0, 1), "b": "302 dead"}, predictions={"a": torch.tensor(0.3), "b": torch.tensor([1.5])},
+                                    patient_label="P", cut_off=0.7)
+    assert list(sdf.columns) == ["P", "pred_score", "time", "event", "cut_off=0.7"]
+    assert sdf.iloc[0]["time"] == 302.0 and sdf.iloc[0]["event"] == 1 and pd.isna(sdf.iloc[1]["time"])    # pandas stores the unknown as NaN
+    assert abs(sdf.iloc[1]["pred_score"] - 1.5) < 1e-6
