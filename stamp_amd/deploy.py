@@ -20,7 +20,33 @@ import pandas as pd
 import torch
 import torch.nn.functional as F
 
-__all__ = ["predict_", "to_prediction_df", "to_regression_prediction_df", "to_survival_prediction_df"]
+__all__ = ["model_from_checkpoint", "predict_", "to_prediction_df", "to_regression_prediction_df", "to_survival_prediction_df"]
+
+
+def model_from_checkpoint(ckpt: Mapping) -> torch.nn.Module:
+    """The HIP head for a STAMP checkpoint's `{"state_dict", "hyper_parameters"}` (an already unpickled Lightning checkpoint; the reference
+    reads it in `load_model_from_ckpt`, deploy.py:49-58).  The backbone sits under `model.` in the Lightning module's state_dict
+    (`models/__init__.py:213-215`) and is built as `model_class(dim_input=, dim_output=, **params)` with `params` the hyper-parameters that
+    appear in the class's signature (`_get_model_params` / `_build_backbone`, `models/__init__.py:113-131`); `dim_output` is the number of
+    categories for classification (`:213`) and 1 for regression / survival.  `model_name` selects the class as the reference's registry
+    does (`registry.py:18-25, 43-75`)."""
+    import inspect
+
+    from . import mil
+
+    hp = dict(ckpt["hyper_parameters"])
+    name = str(getattr(hp.get("model_name"), "value", hp.get("model_name"))).lower()
+    classes = {"vit": mil.VisionTransformer, "trans_mil": mil.TransMIL, "mlp": mil.MLP, "linear": mil.Linear}
+    if name not in classes:
+        raise ValueError(f"model_name {name!r} has no HIP head (available: {sorted(classes)})")
+    cls = classes[name]
+    task = hp.get("task", "classification")
+    dim_output = len(hp["categories"]) if task == "classification" else 1
+    keys = [k for k in inspect.signature(cls.__init__).parameters if k not in ("self", "dim_input", "dim_output")]
+    model = cls(dim_input=int(hp["dim_input"]), dim_output=dim_output, **{k: hp[k] for k in keys if k in hp})
+    sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
+    model.load_state_dict(sd)          # strict: a key mismatch means a different architecture
+    return model.eval()
 
 
 @torch.no_grad()

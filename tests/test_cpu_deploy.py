@@ -63,3 +63,27 @@ def test_regression_and_survival_tables():
     assert list(sdf.columns) == ["P", "pred_score", "time", "event", "cut_off=0.7"]
     assert sdf.iloc[0]["time"] == 302.0 and sdf.iloc[0]["event"] == 1 and pd.isna(sdf.iloc[1]["time"])    # pandas stores the unknown as NaN
     assert abs(sdf.iloc[1]["pred_score"] - 1.5) < 1e-6
+
+
+def test_model_from_checkpoint_builds_the_head_and_loads_the_backbone():
+    """A Lightning-style checkpoint dict (backbone under `model.`, constructor arguments among the hyper-parameters next to unrelated metadata)
+    -> the HIP head with exactly those weights, in eval mode; unknown model names and foreign keys fail loudly."""
+    import pytest
+
+    from stamp_amd.deploy import model_from_checkpoint
+    from stamp_amd.mil import VisionTransformer
+
+    torch.manual_seed(1)
+    src = VisionTransformer(dim_output=3, dim_input=96, dim_model=64, n_layers=1, n_heads=2, dim_feedforward=64, dropout=0.1, use_alibi=True)
+    ckpt = {"state_dict": {**{f"model.{k}": v.clone() for k, v in src.state_dict().items()}, "valid_auroc.something": torch.zeros(1)},
+            "hyper_parameters": {"model_name": "vit", "task": "classification", "categories": ["a", "b", "c"], "dim_input": 96, "dim_model": 64, "n_layers": 1,
+                                 "n_heads": 2, "dim_feedforward": 64, "dropout": 0.1, "use_alibi": True, "total_steps": 10, "max_lr": 1e-4, "ground_truth_label": "x"}}
+    m = model_from_checkpoint(ckpt)
+    assert isinstance(m, VisionTransformer) and not m.training
+    for k, v in src.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    with pytest.raises(ValueError):
+        model_from_checkpoint({**ckpt, "hyper_parameters": {**ckpt["hyper_parameters"], "model_name": "barspoon"}})
+    bad = {**ckpt, "state_dict": {**ckpt["state_dict"], "model.not_a_key": torch.zeros(1)}}
+    with pytest.raises(RuntimeError):
+        model_from_checkpoint(bad)
