@@ -137,10 +137,14 @@ def test_lnfold_and_plain_paths_against_the_oracle_and_b64_tail(gpu):
     assert e_f < 1e-3 and e_p < 1e-3 and d < 1e-3
     assert _rel(ff.cpu().float(), ref_f.float()) < 1e-3 and _rel(fp.cpu().float(), ref_f.float()) < 1e-3
     big = torch.randint(0, 256, (1020, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(22)).to(gpu)
+    whole_fold = fold(big)
     for m in (fold, plain):
         whole = m(big)
-        assert torch.equal(m(big[128:192]), whole[128:192])        # a batch of 64: remainder rows on the side stream
+        assert torch.equal(m(big[128:192]), whole[128:192])        # a batch of 64: the last tiles run as their own chain on the side stream
         assert torch.equal(m(big[7:107]), whole[7:107])            # 100 tiles: 25 700 rows = 100 row tiles + 100 rows
+    # every batch size around the tail-schedule decisions (none below 8 tiles; 1-4 tail tiles above), same bits as inside the big chunk
+    for B in (1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 65, 96, 127, 128, 129, 255, 256):
+        assert torch.equal(fold(big[3:3 + B]), whole_fold[3:3 + B]), B
 
 
 def test_cls_plus_mean_patch_embedding(gpu):
