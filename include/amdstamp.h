@@ -316,7 +316,6 @@ typedef struct {
     const void*  fc1_w; const float* fc1_b;     /* [4C][C] */
     const void*  fc2_w; const float* fc2_b;     /* [C][4C] */
     const void*  mlp_pack;                      /* amds_swin_mlp192_pack image for C = 192 blocks, else NULL */
-    const void*  attn_pack;                     /* amds_swin_attn192_pack image for C = 192 blocks, else NULL */
 } amds_swin_block;
 
 typedef struct {
@@ -359,13 +358,6 @@ int amds_window_attention(const void* qkv, long ldq, void* out, long ldo, const 
 int amds_swin_attn96(float* x, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
                      const float* ln_gamma, const float* ln_beta, const float* bias_lane, const uint64_t* mask_bits, int B,
                      int grid, int shift, float ln_eps, int dtype, void* stream);
-
-/* Same branch for 192-channel blocks (6 heads): weights and bias tables streamed per head from the image built once by
- * amds_swin_attn192_pack(qkv_w [576][192], proj_w [192][192], bias_lane [6][2][2][64][16], packed [6 * 65536 bytes]). */
-int amds_swin_attn192_pack(const void* qkv_w, const void* proj_w, const float* bias_lane, void* packed, int dtype, void* stream);
-int amds_swin_attn192(float* x, const void* packed_w, const float* qkv_b, const float* proj_b, const float* ln_gamma,
-                      const float* ln_beta, const uint64_t* mask_bits, int B, int grid, int shift, float ln_eps, int dtype,
-                      void* stream);
 
 /* PatchMerging up to the Linear (ctranspath.py:717-736): x fp32 [B][grid^2][dim] -> LayerNorm(concat of the 2x2 cell
  * members (0,0),(1,0),(0,1),(1,1)) as act dtype [B][(grid/2)^2][4*dim]. */

@@ -44,7 +44,7 @@ class SwinCfg(C.Structure):
 class SwinBlock(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "qkv_w", "qkv_b", "bias_lane", "proj_w", "proj_b",
-        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "mlp_pack", "attn_pack")]
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "mlp_pack")]
 
 
 class SwinMerge(C.Structure):
@@ -99,8 +99,6 @@ PROTOTYPES = {
     "amds_swin_stem": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_window_attention": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_swin_attn96": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
-    "amds_swin_attn192_pack": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
-    "amds_swin_attn192": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "amds_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "amds_layernorm_meanpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

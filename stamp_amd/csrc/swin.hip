@@ -552,240 +552,6 @@ swin_attn96_kernel(float* x, const T* __restrict__ Wqkv, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same fused attention branch for 192-channel blocks (stage 2: 6 heads, windows of a 28x28 grid).  Wqkv (221 KB) and the bias
-// tables (96 KB) no longer fit LDS: the four waves of a workgroup (four windows) walk the six heads together and everything a head
-// needs arrives as ONE contiguous 64 KB block of a pre-packed image (amds_swin_attn192_pack): [Wq_h | Wk_h | Wv_h: 36 fragments]
-// [Wproj columns of head h as the k-permuted B operand: 12 fragments][relative-position-bias table of head h in accumulator order],
-// copied by LDS-DMA into a double buffer one head ahead -- one barrier per head.  Register dataflow as in swin_attn96_kernel.
-// ------------------------------------------------------------------------------------------------
-constexpr int SB_CHUNK = 65536;
-constexpr int SB_LDS = 2 * SB_CHUNK + (2 * 192 + 576 + 192) * 4;
-
-template <typename T>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-swin_attn192_kernel(float* x, const char* __restrict__ wpack, const float* __restrict__ bqkv, const float* __restrict__ bproj,
-                    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const unsigned long long* __restrict__ mask_bits,
-                    int G, int shift, float eps, float scale_l2, int nwin_total) {
-    typedef typename Act<T>::vec8 vec8;
-    constexpr int C = 192, KS = 12, NH = 6, NCF = 6;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;                                                      // [2][64 KB]
-    float* s_ln = reinterpret_cast<float*>(smem + 2 * SB_CHUNK);           // gamma[192] beta[192]
-    float* s_bq = s_ln + 2 * C;                                            // qkv bias [576]
-    float* s_bp = s_bq + 3 * C;                                            // proj bias [192]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    for (int i = tid; i < C; i += 256) { s_ln[i] = ln_g[i]; s_ln[C + i] = ln_b[i]; s_bp[i] = bproj[i]; }
-    for (int i = tid; i < 3 * C; i += 256) s_bq[i] = bqkv[i];
-    auto load_chunk = [&](int h, int buf) {                                // every wave copies 16 of the 64 1-KB pieces
-        const char* src = wpack + (size_t)h * SB_CHUNK;
-        char* dst = s_w + buf * SB_CHUNK;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int piece = wave * 16 + i;
-            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
-        }
-    };
-    const int nwin_side = G / SW_WS, nW = nwin_side * nwin_side;
-    const int p0 = l31, p1 = min(32 + l31, SW_N - 1);
-    const int i0 = p0 / SW_WS, j0 = p0 - i0 * SW_WS, i1 = p1 / SW_WS, j1 = p1 - i1 * SW_WS;
-    auto token_row = [&](int w, int i, int j) -> int {
-        const int b = w / nW, wi = w - b * nW;
-        const int wh = wi / nwin_side, ww = wi - wh * nwin_side;
-        int hh = wh * SW_WS + i + shift, wc = ww * SW_WS + j + shift;
-        hh = hh >= G ? hh - G : hh;
-        wc = wc >= G ? wc - G : wc;
-        return (b * G + hh) * G + wc;
-    };
-    int buf = 0;
-    load_chunk(0, 0);
-    // workgroup-level loop (the four waves share the weight stream): windows 4 wb + wave; a wave past the end works on the last window
-    const int nwb = (nwin_total + 3) / 4;
-    for (int wb = blockIdx.x; wb < nwb; wb += gridDim.x) {
-        const int win_raw = wb * 4 + wave;
-        const bool live = win_raw < nwin_total;
-        const int win = live ? win_raw : nwin_total - 1;
-        int lds_lane = lane * 16;
-        asm volatile("" : "+v"(lds_lane));
-        vec8 xf[2][KS];
-        {
-            f32x4 raw[KS][2];
-            rs_load_raw<KS>(raw, x, C, token_row(win, i0, j0), hi);
-            rs_normalise<T, KS>(xf[0], raw, s_ln + (lds_lane & 1), hi, eps);
-            rs_load_raw<KS>(raw, x, C, token_row(win, i1, j1), hi);
-            rs_normalise<T, KS>(xf[1], raw, s_ln + (lds_lane & 1), hi, eps);
-        }
-        const int wi = win % nW;
-        const int wh = wi / nwin_side, ww = wi - wh * nwin_side;
-        const int wtype = shift > 0 ? ((wh == nwin_side - 1) ? 2 : 0) + ((ww == nwin_side - 1) ? 1 : 0) : 0;
-        const unsigned long long mb = mask_bits[wtype * 64 + lane];
-        f32x16 acc_out[2][NCF];
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int cf = 0; cf < NCF; ++cf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_out[f][cf][r] = 0.f;
-#pragma unroll 1
-        for (int h = 0; h < NH; ++h) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of head h have landed ...
-            __syncthreads();                                     // ... and everybody's; every wave is done with the other buffer
-            if (h + 1 < NH) load_chunk(h + 1, buf ^ 1);
-            else if (wb + gridDim.x < nwb) load_chunk(0, buf ^ 1);
-            const char* wbase = s_w + buf * SB_CHUNK + lds_lane;
-            const char* bias_h = s_w + buf * SB_CHUNK + 48 * 1024;          // [tile 4][g 4][lane 64][4] fp32
-            vec8 kf[2][2], qf[2][2], vf[2][2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                f32x16 aq, ak, av;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 bq4 = *reinterpret_cast<const f32x4*>(s_bq + 32 * h + 8 * g4 + 4 * hi);
-                    const f32x4 bk4 = *reinterpret_cast<const f32x4*>(s_bq + C + 32 * h + 8 * g4 + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { aq[4 * g4 + e] = bq4[e]; ak[4 * g4 + e] = bk4[e]; }
-                }
-                const float bvl = s_bq[2 * C + 32 * h + l31];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) av[r] = bvl;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const vec8 wq = *reinterpret_cast<const vec8*>(wbase + ks * 1024);
-                    const vec8 wk = *reinterpret_cast<const vec8*>(wbase + (KS + ks) * 1024);
-                    const vec8 wv = *reinterpret_cast<const vec8*>(wbase + (2 * KS + ks) * 1024);
-                    aq = Act<T>::mfma32(wq, xf[f][ks], aq);
-                    ak = Act<T>::mfma32(wk, xf[f][ks], ak);
-                    av = Act<T>::mfma32(xf[f][ks], wv, av);
-                    if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    qf[f][r >> 3][r & 7] = Act<T>::from_f32(aq[r]);
-                    kf[f][r >> 3][r & 7] = Act<T>::from_f32(ak[r]);
-                    vf[f][r >> 3][r & 7] = Act<T>::from_f32(av[r]);
-                }
-            }
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                f32x16 sT[2];
-                float mx = -3.0e38f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sT[kt][r] = 0.f;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) sT[kt] = Act<T>::mfma32(kf[kt][s2], qf[qt][s2], sT[kt]);
-                    const int tile = kt * 2 + qt;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_h + ((tile * 4 + g4) * 64) * 16 + lds_lane);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sT[kt][4 * g4 + e] = fmaf(sT[kt][4 * g4 + e], scale_l2, bv[e]);
-                    }
-                    if (wtype) {
-                        const unsigned bits = (unsigned)(mb >> (tile * 16)) & 0xffffu;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sT[kt][r] += ((bits >> r) & 1u) ? -144.26950408889634f : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kt][r]);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float sum = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pexp = __builtin_amdgcn_exp2f(sT[kt][r] - mx);
-                        sT[kt][r] = pexp;
-                        sum += pexp;
-                    }
-                sum += __shfl_xor(sum, 32, 64);
-                f32x16 o;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        vec8 pf;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(sT[kt][8 * s2 + e]);
-                        o = Act<T>::mfma32(vf[kt][s2], pf, o);
-                    }
-                const float inv = 1.0f / sum;
-                vec8 of[2];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) of[r >> 3][r & 7] = Act<T>::from_f32(o[r] * inv);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int cf = 0; cf < NCF; ++cf)
-                        acc_out[qt][cf] = Act<T>::mfma32(of[s2], *reinterpret_cast<const vec8*>(wbase + (36 + cf * 2 + s2) * 1024), acc_out[qt][cf]);
-            }
-            buf ^= 1;
-        }
-        // ---- x rows += result + bias ----
-        const int b = win / nW;
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int pc = min(p, SW_N - 1);
-                const int i = pc / SW_WS, j = pc - i * SW_WS;
-                int hh = wh * SW_WS + i + shift, wc = ww * SW_WS + j + shift;
-                hh = hh >= G ? hh - G : hh;
-                wc = wc >= G ? wc - G : wc;
-                float* row = x + ((long)(b * G + hh) * G + wc) * C + l31;
-                if (f == 0 || (r & 3) + 8 * (r >> 2) < 17) {
-                    float v[NCF];
-#pragma unroll
-                    for (int cf = 0; cf < NCF; ++cf) v[cf] = row[32 * cf] + acc_out[f][cf][r] + s_bp[32 * cf + l31];
-                    if (live && p < SW_N) {
-#pragma unroll
-                        for (int cf = 0; cf < NCF; ++cf) row[32 * cf] = v[cf];
-                    }
-                }
-                if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            }
-    }
-}
-
-// weight image for swin_attn192_kernel: per head 64 pieces of 1 KB:
-//   0..35  Wq_h, Wk_h, Wv_h fragments: piece = which*12 + ks, lane (l31, hi) <- W[which*192 + 32 h + l31][16 ks + 8 hi ..+8]
-//   36..47 Wproj as the B operand of head h's two k-steps: piece = 36 + cf*2 + s, lane <- Wproj[32 cf + l31][32 h + 16 s + 4 hi + {0..3, 8..11}]
-//   48..63 the head's bias table [tile][g][lane][4] fp32 (16 KB)
-template <typename T>
-__global__ void swin_attn192_pack_kernel(const T* __restrict__ wqkv, const T* __restrict__ wproj, const float* __restrict__ bias_lane,
-                                         char* __restrict__ out) {
-    constexpr int C = 192;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // one 16-byte lane slot
-    if (idx >= 6 * 64 * 64) return;
-    const int lane = idx & 63, piece = (idx >> 6) & 63, h = idx >> 12;
-    const int l31 = lane & 31, hi = lane >> 5;
-    char* dst = out + (size_t)idx * 16;
-    if (piece < 36) {
-        const int which = piece / 12, ks = piece - which * 12;
-        const T* src = wqkv + (size_t)(which * C + 32 * h + l31) * C + 16 * ks + 8 * hi;
-        T* d = reinterpret_cast<T*>(dst);
-        for (int e = 0; e < 8; ++e) d[e] = src[e];
-    } else if (piece < 48) {
-        const int q = piece - 36, cf = q >> 1, s2 = q & 1;
-        const T* src = wproj + (size_t)(32 * cf + l31) * C + 32 * h + 16 * s2 + 4 * hi;
-        T* d = reinterpret_cast<T*>(dst);
-        for (int e = 0; e < 4; ++e) { d[e] = src[e]; d[4 + e] = src[8 + e]; }
-    } else {
-        // 16 KB = 1024 float4: flat float4 index within the table = (piece - 48) * 64 + lane = ((tile * 4 + g) * 64 + ln)
-        const int f4 = (piece - 48) * 64 + lane, ln = f4 & 63, tg = f4 >> 6, tile = tg >> 2, g4 = tg & 3;
-        const float* src = bias_lane + (((size_t)h * 4 + tile) * 64 + ln) * 16 + g4 * 4;
-        float* d = reinterpret_cast<float*>(dst);
-        for (int e = 0; e < 4; ++e) d[e] = src[e];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // PatchMerging gather + LayerNorm(4C) (ctranspath.py:717-736).  One wave per output row; the four members of a 2x2
 // cell are concatenated in the reference's order (0,0),(1,0),(0,1),(1,1) [dh = k&1, dw = k>>1].
 // ------------------------------------------------------------------------------------------------
@@ -992,50 +758,6 @@ extern "C" int amds_swin_attn96(float* x, const void* qkv_w, const float* qkv_b,
     return AMDS_OK;
 }
 
-extern "C" int amds_swin_attn192_pack(const void* qkv_w, const void* proj_w, const float* bias_lane, void* packed, int dtype, void* stream) {
-    AMDS_REQUIRE(qkv_w && proj_w && bias_lane && packed, "amds_swin_attn192_pack: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const int n = 6 * 64 * 64;
-    if (dtype == AMDS_F16) hipLaunchKernelGGL((swin_attn192_pack_kernel<f16>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const f16*)qkv_w, (const f16*)proj_w, bias_lane, (char*)packed);
-    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((swin_attn192_pack_kernel<bf16>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16*)qkv_w, (const bf16*)proj_w, bias_lane, (char*)packed);
-    else { set_error("amds_swin_attn192_pack: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
-    AMDS_LAUNCH_CHECK("swin_attn192_pack_kernel");
-    return AMDS_OK;
-}
-
-extern "C" int amds_swin_attn192(float* x, const void* packed_w, const float* qkv_b, const float* proj_b, const float* ln_gamma,
-                                 const float* ln_beta, const uint64_t* mask_bits, int B, int grid, int shift, float ln_eps, int dtype,
-                                 void* stream) {
-    AMDS_REQUIRE(x && packed_w && qkv_b && proj_b && ln_gamma && ln_beta && mask_bits, "amds_swin_attn192: null pointer");
-    AMDS_REQUIRE(grid > 0 && grid % SW_WS == 0, "amds_swin_attn192: grid=%d must be a multiple of 7", grid);
-    AMDS_REQUIRE(shift >= 0 && shift < SW_WS && (shift == 0 || grid > SW_WS), "amds_swin_attn192: bad shift=%d for grid=%d", shift, grid);
-    AMDS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "amds_swin_attn192: misaligned pointers");
-    if (B <= 0) return AMDS_OK;
-    const long nwin = (long)B * (grid / SW_WS) * (grid / SW_WS);
-    AMDS_REQUIRE(nwin < (1L << 30) && (long)B * grid * grid * 192 < (1L << 31), "amds_swin_attn192: batch too large for 32-bit token indexing");
-    hipStream_t st = (hipStream_t)stream;
-    const float scale_l2 = 0.17677669529663687f * 1.4426950408889634f;
-    int gx = (int)((nwin + 3) / 4);
-    if (gx > 256) gx = 256;
-    ProfScope prof(PROF_ATTN, nwin * (2.0 * 49 * 192 * 768 + 4.0 * 6 * 49 * 49 * 32), st);
-#define ATTN192_LAUNCH(T)                                                                                                             \
-    do {                                                                                                                              \
-        static bool attr_set = false;                                                                                                 \
-        if (!attr_set) {                                                                                                              \
-            AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_attn192_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS)); \
-            attr_set = true;                                                                                                          \
-        }                                                                                                                             \
-        hipLaunchKernelGGL((swin_attn192_kernel<T>), dim3(gx), dim3(256), SB_LDS, st, x, reinterpret_cast<const char*>(packed_w), qkv_b, proj_b, \
-                           ln_gamma, ln_beta, reinterpret_cast<const unsigned long long*>(mask_bits), grid, shift, ln_eps, scale_l2, (int)nwin); \
-    } while (0)
-    if (dtype == AMDS_F16) ATTN192_LAUNCH(f16);
-    else if (dtype == AMDS_BF16) ATTN192_LAUNCH(bf16);
-    else { set_error("amds_swin_attn192: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
-#undef ATTN192_LAUNCH
-    AMDS_LAUNCH_CHECK("swin_attn192_kernel");
-    return AMDS_OK;
-}
-
 extern "C" int amds_patch_merge_ln(const float* x, void* y, const float* gamma, const float* beta, int B, int grid, int dim,
                                    float eps, int dtype, void* stream) {
     AMDS_REQUIRE(x && y && gamma && beta, "amds_patch_merge_ln: null pointer");
@@ -1101,15 +823,9 @@ static int swin_chunk(const amds_swin_cfg* c, const amds_swin_weights* w, const 
             const amds_swin_block& b = w->blocks_host[blk];
             const int shift = (d % 2 == 1 && G > SW_WS) ? SW_WS / 2 : 0;
             static const bool fuse_attn = getenv("AMDS_SWIN_FUSE_ATTN") ? atoi(getenv("AMDS_SWIN_FUSE_ATTN")) != 0 : true;
-            // The 192-channel fused branch is correct (tests) but NOT faster than the three-kernel path: its 192 projection
-            // accumulators + 96 operand registers per wave spill (204 VGPRs) -> 52.4 vs 49.2 ms per 2048 tiles.  Kept behind a
-            // switch until the projection is split into a second phase.
-            static const bool fuse_attn192 = getenv("AMDS_SWIN_FUSE_ATTN192") ? atoi(getenv("AMDS_SWIN_FUSE_ATTN192")) != 0 : false;
             if (narrow) {
                 if (C == 96 && fuse_attn) {     // LN1 + qkv + window attention + proj + residual in one pass over x
                     AMDS_TRY(amds_swin_attn96(x, b.qkv_w, b.qkv_b, b.proj_w, b.proj_b, b.ln1_w, b.ln1_b, b.bias_lane, w->mask_bits, Bc, G, shift, c->ln_eps, dt, st));
-                } else if (C == 192 && fuse_attn192 && b.attn_pack) {  // same, weights and bias tables streamed per head (off by default, see below)
-                    AMDS_TRY(amds_swin_attn192(x, b.attn_pack, b.qkv_b, b.proj_b, b.ln1_w, b.ln1_b, w->mask_bits, Bc, G, shift, c->ln_eps, dt, st));
                 } else {
                     AMDS_TRY(amds_gemm_rowstream(x, C, b.ln1_w, b.ln1_b, c->ln_eps, b.qkv_w, C, M, 3 * C, C, dt, AMDS_EPI_BIAS, big, 3 * C, b.qkv_b, st));
                     AMDS_TRY(amds_window_attention(big, 3 * C, h, C, b.bias_lane, w->mask_bits, Bc, G, C, c->heads[s], shift, dt, st));

@@ -354,23 +354,3 @@ def swin_mlp192(x: torch.Tensor, packed_w: torch.Tensor, fc1_b, fc2_b, ln_gamma,
     _lib.check(_lib.lib().amds_swin_mlp192(_p(x), x.numel() // 192, _p(packed_w), _p(fc1_b), _p(fc2_b), _p(ln_gamma), _p(ln_beta), eps,
                                            act_code(packed_w.dtype), _stream()), "swin_mlp192")
     return x
-
-
-def swin_attn192_pack(qkv_w: torch.Tensor, proj_w: torch.Tensor, bias_lane: torch.Tensor) -> torch.Tensor:
-    """[576,192], [192,192] (act dtype) + bias_lane fp32 [6,2,2,64,16] -> the per-head 64 KB image amds_swin_attn192 streams."""
-    _dev(qkv_w, proj_w, bias_lane)
-    assert qkv_w.shape == (576, 192) and proj_w.shape == (192, 192) and bias_lane.shape == (6, 2, 2, 64, 16) and bias_lane.dtype == torch.float32
-    assert qkv_w.is_contiguous() and proj_w.is_contiguous() and bias_lane.is_contiguous() and qkv_w.dtype == proj_w.dtype
-    out = torch.empty(6 * 65536, dtype=torch.uint8, device=qkv_w.device)
-    _lib.check(_lib.lib().amds_swin_attn192_pack(_p(qkv_w), _p(proj_w), _p(bias_lane), _p(out), act_code(qkv_w.dtype), _stream()), "swin_attn192_pack")
-    return out
-
-
-def swin_attn192(x: torch.Tensor, packed_w: torch.Tensor, qkv_b, proj_b, ln_gamma, ln_beta, mask_bits, grid: int, shift: int,
-                 dtype: torch.dtype = torch.float16, eps: float = 1e-5) -> torch.Tensor:
-    """In place: x += proj(window_attention(qkv(LayerNorm(x)))) for x fp32 [B, grid^2, 192]."""
-    _dev(x, packed_w, qkv_b, proj_b, ln_gamma, ln_beta, mask_bits)
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 192 and x.shape[1] == grid * grid and packed_w.numel() == 6 * 65536
-    _lib.check(_lib.lib().amds_swin_attn192(_p(x), _p(packed_w), _p(qkv_b), _p(proj_b), _p(ln_gamma), _p(ln_beta), _p(mask_bits), x.shape[0],
-                                            grid, shift, eps, act_code(dtype), _stream()), "swin_attn192")
-    return x

@@ -239,14 +239,12 @@ class HipSwin(torch.nn.Module):
                 b.fc1_w, b.fc1_b = act(g("mlp.fc1.weight"), kp).data_ptr(), f32(g("mlp.fc1.bias")).data_ptr()
                 b.fc2_w, b.fc2_b = act(g("mlp.fc2.weight")).data_ptr(), f32(g("mlp.fc2.bias")).data_ptr()
                 b.bias_lane = f32(rel_bias_lane_table(g("attn.relative_position_bias_table"))).data_ptr()
-                if Cs == 192:        # stage 2: the fused kernels stream fragment-ordered images of the weights (+ bias tables)
+                if Cs == 192:        # stage 2: the fused MLP kernel streams a fragment-ordered image of its weights
                     pk = ops.swin_mlp192_pack(act(g("mlp.fc1.weight")), act(g("mlp.fc2.weight")))
-                    ak = ops.swin_attn192_pack(act(g("attn.qkv.weight")), act(g("attn.proj.weight")),
-                                               f32(rel_bias_lane_table(g("attn.relative_position_bias_table"))))
-                    self._keep += [pk, ak]
-                    b.mlp_pack, b.attn_pack = pk.data_ptr(), ak.data_ptr()
+                    self._keep.append(pk)
+                    b.mlp_pack = pk.data_ptr()
                 else:
-                    b.mlp_pack = b.attn_pack = None
+                    b.mlp_pack = None
         merges = (_lib.SwinMerge * 3)()
         for s in range(len(cfg.depths) - 1):
             p = f"layers.{s}.downsample."
