@@ -9,6 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stamp_amd import _lib, ops  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262140
+CFGS = tuple(int(c) for c in sys.argv[2].split(",")) if len(sys.argv) > 2 else (12, 13)
 shapes = (("qkv", 3072, 1024, _lib.EPI_BIAS), ("proj", 1024, 1024, _lib.EPI_RESIDUAL), ("fc1", 4096, 1024, _lib.EPI_BIAS_GELU),
           ("fc2", 1024, 4096, _lib.EPI_RESIDUAL))
 for rnd in range(2):
@@ -19,7 +20,7 @@ for rnd in range(2):
         sc = torch.full((N,), 0.1, device="cuda") if epi == _lib.EPI_RESIDUAL else None
         out = torch.zeros(M, N, device="cuda") if epi == _lib.EPI_RESIDUAL else None
         line = f"{name:5s} N={N} K={K}:"
-        for cfg in (12, 13):
+        for cfg in CFGS:
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             n_warm = max(4, int(0.4 / (2.0 * M * N * K / 1.0e15)))
             for _ in range(n_warm):
