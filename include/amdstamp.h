@@ -257,7 +257,11 @@ size_t amds_vit_workspace_bytes(const amds_vit_cfg* cfg_host, int batch);
  * LayerNorm, i.e. model(tiles)[:, 0].half() (reference src/stamp/preprocessing/__init__.py:324-325,
  * src/stamp/preprocessing/extractor/virchow2.py:29-30). The u8 -> (x/255-mean)/std transform
  * (reference h_optimus_0.py:22-30 etc.) is folded into patch_w/patch_b.
- * Processes the batch in chunks of `chunk` tiles (workspace sized for `chunk`). */
+ * Processes the batch in chunks of `chunk` tiles (workspace sized for `chunk`).
+ * When the host has created a context for the calling thread's current device (amds_create), a chunk whose token rows do not fill its
+ * last 256-row GEMM tile (e.g. the reference's DataLoader batch: 64 x 257 rows) runs its last few tiles as an independent chain of
+ * launches on that context's side stream -- tiles are independent through the whole network -- and `stream` waits for that chain before
+ * the final norm: same kernels, same results bit for bit, no extra wave of workgroups per GEMM.  AMDS_VIT_TAIL=0 disables it. */
 int amds_vit_forward(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host,
                      const uint8_t* tiles, void* feats_f16, int B, int chunk,
                      void* ws, size_t ws_bytes, void* stream);
