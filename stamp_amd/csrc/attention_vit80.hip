@@ -13,8 +13,8 @@ namespace amds {
 constexpr int A80_HD = 80, A80_KRS = 176, A80_VROWS = 96;
 __host__ __device__ constexpr int vt80_row_bytes(int nkt) { return (nkt & 1) ? nkt * 64 : nkt * 64 + 64; }
 
-template <typename T, int NKT>
-__global__ void __launch_bounds__(256, 1) attn_vit80_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+template <typename T, int NKT, int NTH>
+__global__ void __launch_bounds__(NTH, 1) attn_vit80_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H, int n_items) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     constexpr int KP = NKT * 32;
@@ -27,37 +27,42 @@ __global__ void __launch_bounds__(256, 1) attn_vit80_kernel(const T* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int Dm = H * A80_HD;
     const long ld = 3L * Dm;
-    const T* base = qkv + (long)b * Tn * ld + h * A80_HD;
 
     constexpr int K_ITEMS = KP * 10, V_ITEMS = (KP / 2) * 10;
-    constexpr int K_IT = (K_ITEMS + 255) / 256, V_IT = (V_ITEMS + 255) / 256;
+    constexpr int K_IT = (K_ITEMS + NTH - 1) / NTH, V_IT = (V_ITEMS + NTH - 1) / NTH, NW = NTH / 64;
+    // Persistent workgroups (one per CU: 104 KB of LDS): the K / V rows of item i+1 travel HBM -> registers while item i is computed out of
+    // LDS, and are written into LDS behind a barrier -- the one-shot form exposed the whole round trip of every item.
     u32x4 kv[K_IT];
     vec8 v0[V_IT], v1[V_IT];
+    auto stage_load = [&](int item) {
+    const int b = item / H, h = item - b * H;
+    const T* base = qkv + (long)b * Tn * ld + h * A80_HD;
 #pragma unroll
     for (int it = 0; it < K_IT; ++it) {
-        const int c = it * 256 + tid, key = c / 10, ch = c - key * 10;
+        const int c = it * NTH + tid, key = c / 10, ch = c - key * 10;
         kv[it] = u32x4{0u, 0u, 0u, 0u};
         if (c < K_ITEMS && key < Tn) kv[it] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < V_IT; ++it) {
-        const int c = it * 256 + tid, kp2 = c / 10, ch = c - kp2 * 10, k0 = kp2 * 2;
+        const int c = it * NTH + tid, kp2 = c / 10, ch = c - kp2 * 10, k0 = kp2 * 2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v0[it][e] = (T)0.f; v1[it][e] = (T)0.f; }
         if (c < V_ITEMS && k0 < Tn) v0[it] = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
         if (c < V_ITEMS && k0 + 1 < Tn) v1[it] = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
     }
+    };
+    auto stage_store = [&]() {
 #pragma unroll
     for (int it = 0; it < K_IT; ++it) {
-        const int c = it * 256 + tid, key = c / 10, ch = c - key * 10;
+        const int c = it * NTH + tid, key = c / 10, ch = c - key * 10;
         if (c < K_ITEMS) *reinterpret_cast<u32x4*>(sK + key * A80_KRS + ch * 16) = kv[it];
     }
 #pragma unroll
     for (int it = 0; it < V_IT; ++it) {
-        const int c = it * 256 + tid, kp2 = c / 10, ch = c - kp2 * 10, k0 = kp2 * 2;
+        const int c = it * NTH + tid, kp2 = c / 10, ch = c - kp2 * 10, k0 = kp2 * 2;
         if (c < V_ITEMS) {
             const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);
 #pragma unroll
@@ -69,19 +74,30 @@ __global__ void __launch_bounds__(256, 1) attn_vit80_kernel(const T* __restrict_
             }
         }
     }
-    // zero rows 80..95 of V^T (skew groups 10 and 11)
-    for (int c = tid; c < 16 * (VS / 16); c += 256) {
+    };
+    // zero rows 80..95 of V^T (skew groups 10 and 11): once, the items only ever write rows 0..79
+    for (int c = tid; c < 16 * (VS / 16); c += NTH) {
         const int r = 80 + c / (VS / 16), s16 = c % (VS / 16);
         *reinterpret_cast<u32x4*>(sVt + r * VS + (r >> 3) * 16 + s16 * 16) = u32x4{0u, 0u, 0u, 0u};
     }
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    stage_load(item);
+    stage_store();
     __syncthreads();
 
     const float sc = 0.11180339887498948f * 1.44269504088896340736f;  // 80^-0.5 * log2(e)
     const int nqb = (Tn + 31) >> 5;
+#pragma unroll 1
+    for (; item < n_items; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const T* base = qkv + (long)b * Tn * ld + h * A80_HD;
+    const bool has_next = item + (int)gridDim.x < n_items;
+    if (has_next) stage_load(item + gridDim.x);               // in flight during this item's compute
 
-    // 9 query blocks over 4 waves leaves one wave with 3: rotate which wave (= which SIMD) that is from block to block, so
-    // the two (or more) workgroups sharing a CU do not pile their heavy waves on the same SIMD
-    for (int qb = (wave + blockIdx.x) & 3; qb < nqb; qb += 4) {
+    // 9 query blocks over NW waves (8: two per SIMD, so that one wave's MFMAs run under its SIMD partner's softmax; with 4 waves the
+    // wave holding 3 blocks ran them back to back with nothing to overlap): rotate which wave gets the extra block from item to item
+    for (int qb = (wave + item) & (NW - 1); qb < nqb; qb += NW) {
         const int q = qb * 32 + l31;
         const int qc = min(q, Tn - 1);
         vec8 qf[5];
@@ -178,15 +194,38 @@ __global__ void __launch_bounds__(256, 1) attn_vit80_kernel(const T* __restrict_
                 }
         }
     }
+    __syncthreads();                                          // every wave is done with this item's K / V^T images
+    if (has_next) {
+        stage_store();
+        __syncthreads();
+    }
+    }
 }
 
 template <typename T>
 static int launch_attn80(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     const int nkt = (Tn + 31) / 32;
-    const dim3 grid(B * H), block(256);
+    static int nth = 0;
+    if (!nth) {
+        const char* e = getenv("AMDS_ATTN80_THREADS");            // 256 = the four-wave form (A/B)
+        nth = (e && atoi(e) == 256) ? 256 : 512;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        AMDS_HIP(hipGetDevice(&dev));
+        AMDS_HIP(hipGetDeviceProperties(&p, dev));
+        cus = p.multiProcessorCount;
+    }
+    const int n_items = B * H;
+    const dim3 grid(n_items < cus ? n_items : cus);
     switch (nkt) {
-#define AMDS_ATT_CASE(N) \
-    case N: hipLaunchKernelGGL((attn_vit80_kernel<T, N>), grid, block, 0, st, (const T*)qkv, (T*)out, Tn, H); break;
+#define AMDS_ATT_CASE(N)                                                                                                             \
+    case N:                                                                                                                          \
+        if (nth == 512) hipLaunchKernelGGL((attn_vit80_kernel<T, N, 512>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, Tn, H, n_items);   \
+        else hipLaunchKernelGGL((attn_vit80_kernel<T, N, 256>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, Tn, H, n_items);              \
+        break;
         AMDS_ATT_CASE(1) AMDS_ATT_CASE(2) AMDS_ATT_CASE(3) AMDS_ATT_CASE(4) AMDS_ATT_CASE(5)
         AMDS_ATT_CASE(6) AMDS_ATT_CASE(7) AMDS_ATT_CASE(8) AMDS_ATT_CASE(9)
 #undef AMDS_ATT_CASE
