@@ -21,6 +21,18 @@ constexpr int A7_BUF = A7_K_BYTES + A7_V_BYTES + A7_T_BYTES;          // 70 528 
 constexpr int A7_SCRATCH = (A7_KP + 16 + 8 * 64) * 4;
 constexpr int A7_LDS = 2 * A7_BUF + A7_SCRATCH;                       // 144 192 B
 
+// phase timeline for tools/ubench/attn257_trace.hip (compiled with -DA7_TRACE only): s_memtime of every wave of workgroup 0 at the phase
+// boundaries of its first items
+#ifdef A7_TRACE
+__device__ unsigned long long a7_trace[32 * 8 * 8];
+#define A7_MARK(k)                                                                                            \
+    do {                                                                                                      \
+        if (blockIdx.x == 0 && lane == 0 && trace_it < 32) a7_trace[(trace_it * 8 + (k)) * 8 + wave] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define A7_MARK(k) do { } while (0)
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict__ qkv, T* __restrict__ out, int H, int n_items) {
     typedef typename Act<T>::vec8 vec8;
@@ -102,6 +114,9 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
     __syncthreads();
 
     int cur = 0;
+#ifdef A7_TRACE
+    int trace_it = 0;
+#endif
 #pragma unroll 1
     for (; item < n_items; item += gridDim.x) {
         const int b = item / H, h = item - b * H;
@@ -111,7 +126,9 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
         const float* sVl = sKt + 64;
         const float* sQt = sKt + 128;
         const bool has_next = item + (int)gridDim.x < n_items;
+        A7_MARK(0);
         if (has_next) stage_load(item + gridDim.x);                   // in flight during everything below
+        A7_MARK(1);
 
         // ---- this wave's 32 queries: online softmax over 4 chunks of 2 key tiles ----
         {
@@ -173,6 +190,7 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
                         }
                     }
             }
+            A7_MARK(2);
             {   // the odd key: rank-1 update of this block's 32 queries (dot product split over the lane pair)
                 float dot = 0.f;
 #pragma unroll
@@ -209,6 +227,7 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
                 }
         }
 
+        A7_MARK(3);
         // ---- the odd query against all 257 keys: scores with lane = key (threads 0..255), output with lane = dim (8 waves x 32 keys) ----
         {
             const int key = tid;
@@ -262,14 +281,20 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
             }
         }
 
+        A7_MARK(4);
         // ---- the next item: registers -> the other LDS buffer (its loads have had this whole item to arrive) ----
         if (has_next) {
             stage_store(smem + (cur ^ 1) * A7_BUF);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
         }
+        A7_MARK(5);
         __syncthreads();
+        A7_MARK(6);
         cur ^= 1;
+#ifdef A7_TRACE
+        ++trace_it;
+#endif
     }
 }
 
