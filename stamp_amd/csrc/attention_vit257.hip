@@ -5,21 +5,24 @@
 // its HBM bytes (132 KB per item at the CU's share of the achievable bandwidth) and ~8 k of MFMA + softmax work: every item exposed one
 // HBM round trip for the K / V staging loads and one per query block for the Q fragments, ~2 us each under load, and two workgroups per
 // CU do not cover that.  Here ONE 512-thread workgroup per CU (two waves per SIMD: one wave's MFMAs beside the other's softmax VALU)
-// walks items blockIdx.x, blockIdx.x + gridDim.x, ...; while item i is computed out of LDS buffer i & 1 the K / V rows of item i + 1 and
-// this wave's Q fragments travel HBM -> registers (32 + 16 VGPRs in flight for a whole item's compute time) and are written into buffer
-// (i + 1) & 1 at the end: one barrier per item, no exposed round trip.  8 query blocks of 32 on 8 waves: one block per wave (the one-shot
-// kernel had 2 per wave on 4 waves), the odd key as a rank-1 VALU update, the odd query as a 257-key GEMV (lane = key, then lane = dim).
-// Arithmetic, LDS images and the no-shuffle MFMA operand layout are those of attention_vit.hip; results are bit-identical to it.
+// walks items blockIdx.x, blockIdx.x + gridDim.x, ...; while item i is computed out of LDS image i & 1, the K / V rows of item i + 1 travel
+// HBM -> registers -> image (i + 1) & 1 in four parts of 64 keys pipelined through the chunk loop (two 8-register sets), its Q fragments and
+// odd token HBM -> registers for the whole item: one barrier per item, no exposed round trip.  8 query blocks of 32 on 8 waves: one block per
+// wave (the one-shot kernel had 2 per wave on 4 waves); the odd key as a rank-1 VALU update; the odd query on the MFMA pipe, 32 keys per wave
+// (a one-row operand), its row merged from 9 flash-style partials by wave 0 after the item's barrier (round 2: 775 -> 742 us at 1020 tiles;
+// as a 257-key GEMV with lane = key, then lane = dim, behind three barriers it was 18 % of an item).
+// Arithmetic of the 256 even queries, LDS images and the no-shuffle MFMA operand layout are those of attention_vit.hip.
 #include "common.h"
 #include <type_traits>
 
 namespace amds {
 
 constexpr int A7_NKT = 8, A7_KP = 256, A7_VS = 576;                    // vt_row_bytes(8): 9 x 64 B
-constexpr int A7_K_BYTES = A7_KP * 128, A7_V_BYTES = 64 * A7_VS + 8 * 16, A7_T_BYTES = 3 * 64 * 4;
-constexpr int A7_BUF = A7_K_BYTES + A7_V_BYTES + A7_T_BYTES;          // 70 528 B per item image
-constexpr int A7_SCRATCH = (A7_KP + 16 + 8 * 64) * 4;
-constexpr int A7_LDS = 2 * A7_BUF + A7_SCRATCH;                       // 144 192 B
+constexpr int A7_K_BYTES = A7_KP * 128, A7_V_BYTES = 64 * A7_VS + 8 * 16, A7_T_BYTES = 3 * 64 * 4 + 128;       // + the odd query in 16 bit
+constexpr int A7_BUF = A7_K_BYTES + A7_V_BYTES + A7_T_BYTES;          // 70 656 B per item image
+constexpr int A7_PART = 68;                                           // one partial of the odd query's row: o[64] | max | sum | pad
+constexpr int A7_SCRATCH = 16 + 8 * 64 + 2 * 9 * A7_PART * 4;         // 16 zero bytes | P of the odd query, 32 keys per wave | partials x 2
+constexpr int A7_LDS = 2 * A7_BUF + A7_SCRATCH;                       // 146 736 B
 
 // phase timeline for tools/ubench/attn257_trace.hip (compiled with -DA7_TRACE only): s_memtime of every wave of workgroup 0 at the phase
 // boundaries of its first items
@@ -34,14 +37,14 @@ __device__ unsigned long long a7_trace[32 * 8 * 8];
 #endif
 
 template <typename T>
-__global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict__ qkv, T* __restrict__ out, int H, int n_items) {
+__global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ qkv, T* __restrict__ out, int H, int n_items) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     constexpr int Tn = 257, KP = A7_KP, VS = A7_VS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sP = reinterpret_cast<float*>(smem + 2 * A7_BUF);         // softmax weights of the odd query [KP] | red [16] | part [8][64]
-    float* sRed = sP + KP;
-    float* sPart = sRed + 16;
+    char* sZero = smem + 2 * A7_BUF;                                 // 16 zero bytes: what the lanes outside a 1-row MFMA operand read
+    char* sPw = sZero + 16;                                          // [8 waves][32] 16-bit softmax weights of the odd query
+    float* sPart = reinterpret_cast<float*>(sPw + 8 * 64);           // [2][9][A7_PART]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,63 +54,93 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
     const float sc = 0.125f * 1.44269504088896340736f;                // 1/sqrt(64) * log2(e)
     const int swz = (l31 >> 1) & 7;
 
-    // ---- staging registers of ONE item: 4 K chunks, 2 V key pairs, the odd token, this wave's Q fragments ----
-    u32x4 kv[4];
-    vec8 v0[2], v1[2];
+    // ---- staging of the NEXT item.  Its K / V rows come in four parts of 64 keys, part c requested at the top of chunk iteration c and
+    // written into the other LDS image two chunk iterations later (that image is idle for the whole item), through two 8-register sets
+    // (even / odd parts); its Q fragments and the odd token are requested before the chunk loop and kept until the item's end.  All 14 loads
+    // of a thread at once, from 8 waves, queued up behind the CU's 64 B / clock vector-memory path and held the slowest wave for > 4 k cycles
+    // before it started computing.  Buffer addressing: one 32-bit byte offset per stream and thread, the item in the descriptor, the part in
+    // a scalar offset. ----
+    struct Part { u32x4 k; u32x2 v0, v1; };
+    Part pa, pb;
     T tq = (T)0.f, tk = (T)0.f, tv = (T)0.f;     // raw 16-bit values: converting here would put an s_waitcnt right behind the loads
     vec8 qn[4];
-    auto stage_load = [&](int item) {                                 // issues every global load of an item, waits for nothing
-        const int b = item / H, h = item - b * H;
-        const T* base = qkv + (long)b * Tn * ld + h * 64;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = it * 512 + tid, key = c >> 3, ch = c & 7;
-            kv[it] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + ch * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int c = it * 512 + tid, k0 = (c >> 3) * 2, ch = c & 7;
-            v0[it] = *reinterpret_cast<const vec8*>(base + (long)k0 * ld + 2 * Dm + ch * 8);
-            v1[it] = *reinterpret_cast<const vec8*>(base + (long)(k0 + 1) * ld + 2 * Dm + ch * 8);
-        }
-        if (tid < 64) {
-            const T* tr = base + (long)KP * ld + tid;                 // token 256 = the odd one
-            tq = tr[0];
-            tk = tr[Dm];
-            tv = tr[2 * Dm];
-        }
-        const int q = wave * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qn[ks] = *reinterpret_cast<const vec8*>(base + (long)q * ld + (ks * 2 + hi) * 8);
+    const int ldb = (int)ld * 2;                                      // bytes per token row
+    const int vu = tid >> 1, vhalf = tid & 1;                         // V: (key pair, 16-byte chunk) = vu, 8-byte half of the chunk
+    const int voff_k = (tid >> 3) * ldb + Dm * 2 + (tid & 7) * 16;
+    const int voff_v = (vu >> 3) * 2 * ldb + Dm * 4 + (vu & 7) * 16 + vhalf * 8;
+    const int voff_q = (wave * 32 + l31) * ldb + hi * 16;
+    const int lk_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);                     // K image: row = key, chunk ^ ((key >> 1) & 7)
+    const int vk0 = (vu >> 3) * 2;                                                                    // first key of the pair inside the part
+    const int lv_off = A7_K_BYTES + ((vu & 7) * 8 + vhalf * 4) * VS + (vu & 7) * 16 + ((vk0 & ~12) | ((vk0 & 4) << 1) | ((vk0 & 8) >> 1)) * 2;
+    auto part_load = [&](Part& pt, __amdgpu_buffer_rsrc_t rs, int c) {          // waits for nothing
+        pt.k = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_k, c * 64 * ldb, 0);
+        pt.v0 = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_v, c * 64 * ldb, 0);
+        pt.v1 = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_v, c * 64 * ldb + ldb, 0);
     };
-    auto stage_store = [&](char* buf) {
-        char* sK = buf;
-        char* sVt = buf + A7_K_BYTES;
+    auto part_store = [&](const Part& pt, char* buf, int c) {
+        *reinterpret_cast<u32x4*>(buf + lk_off + c * 64 * 128) = pt.k;
+        typedef T vec4t __attribute__((ext_vector_type(4)));
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        const vec4t a = __builtin_bit_cast(vec4t, pt.v0), b2 = __builtin_bit_cast(vec4t, pt.v1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                 // V^T image: row = dim, key order inside 16-groups: bits 2 <-> 3
+            vec2 w;
+            w[0] = a[e]; w[1] = b2[e];
+            *reinterpret_cast<vec2*>(buf + lv_off + e * VS + c * 128) = w;
+        }
+    };
+    auto rest_load = [&](__amdgpu_buffer_rsrc_t rs) {                 // this wave's Q fragments and the odd token
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qn[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + ks * 32, 0, 0));
+        if (tid < 64) {                                               // token 256 = the odd one
+            tq = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, tid * 2, KP * ldb, 0));
+            tk = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, tid * 2, KP * ldb + Dm * 2, 0));
+            tv = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, tid * 2, KP * ldb + Dm * 4, 0));
+        }
+    };
+    auto rest_store = [&](char* buf) {
         float* sT = reinterpret_cast<float*>(buf + A7_K_BYTES + A7_V_BYTES);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = it * 512 + tid, key = c >> 3, ch = c & 7;
-            *reinterpret_cast<u32x4*>(sK + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[it];
+        if (tid < 64) {                                               // tail key | value | query in fp32, the query again as it came
+            sT[tid] = Act<T>::to_f32(tk); sT[64 + tid] = Act<T>::to_f32(tv); sT[128 + tid] = Act<T>::to_f32(tq);
+            reinterpret_cast<T*>(sT + 192)[tid] = tq;
         }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int c = it * 512 + tid, k0 = (c >> 3) * 2, ch = c & 7;
-            const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);       // key order inside 16-groups: bits 2 <-> 3
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                typedef T vec2 __attribute__((ext_vector_type(2)));
-                vec2 w;
-                w[0] = v0[it][e]; w[1] = v1[it][e];
-                *reinterpret_cast<vec2*>(sVt + (ch * 8 + e) * VS + ch * 16 + pos * 2) = w;
-            }
-        }
-        if (tid < 64) { sT[tid] = Act<T>::to_f32(tk); sT[64 + tid] = Act<T>::to_f32(tv); sT[128 + tid] = Act<T>::to_f32(tq); }    // tail key | value | query
+    };
+    auto item_rsrc = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(qkv + (long)b * Tn * ld + h * 64), 0, Tn * ldb, 0x00020000);
     };
 
     int item = blockIdx.x;
     if (item >= n_items) return;
-    stage_load(item);
-    stage_store(smem);
+    if (tid < 4) reinterpret_cast<float*>(sZero)[tid] = 0.f;
+    // the odd query's row, merged out of 9 partials (8 waves x 32 keys + the odd key) one barrier after they were written
+    auto merge_odd = [&](int pbuf, int it) {
+        const float* pp = sPart + pbuf * 9 * A7_PART;
+        float m = pp[64];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) m = fmaxf(m, pp[j * A7_PART + 64]);
+        float lsum = 0.f, ov = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float w = __builtin_amdgcn_exp2f(pp[j * A7_PART + 64] - m);
+            lsum = fmaf(w, pp[j * A7_PART + 65], lsum);
+            ov = fmaf(w, pp[j * A7_PART + lane], ov);
+        }
+        const int b = it / H, h = it - b * H;
+        out[((long)b * Tn + KP) * Dm + h * 64 + lane] = Act<T>::from_f32(ov / lsum);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t rs = item_rsrc(item);
+        rest_load(rs);
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            part_load(pa, rs, c);
+            part_load(pb, rs, c + 1);
+            part_store(pa, smem, c);
+            part_store(pb, smem, c + 1);
+        }
+        rest_store(smem);
+    }
     vec8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
@@ -127,7 +160,8 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
         const float* sQt = sKt + 128;
         const bool has_next = item + (int)gridDim.x < n_items;
         A7_MARK(0);
-        if (has_next) stage_load(item + gridDim.x);                   // in flight during everything below
+        if (wave == 0 && item != (int)blockIdx.x) merge_odd(cur ^ 1, item - (int)gridDim.x);
+        const __amdgpu_buffer_rsrc_t nrs = item_rsrc(has_next ? item + (int)gridDim.x : item);      // its loads go out inside the chunk loop
         A7_MARK(1);
 
         // ---- this wave's 32 queries: online softmax over 4 chunks of 2 key tiles ----
@@ -138,8 +172,7 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
             float mrun = -INFINITY, l = 0.f;
-#pragma unroll 1
-            for (int c = 0; c < A7_NKT / 2; ++c) {
+            auto chunk = [&](int c) {
                 f32x16 s[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -189,6 +222,21 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
                             o[dt] = Act<T>::mfma32(vf, pf, o[dt]);
                         }
                     }
+            };
+            char* nbuf = smem + (cur ^ 1) * A7_BUF;
+            rest_load(nrs);
+#pragma unroll 1
+            for (int j = 0; j < 2; ++j) {                             // two chunks per trip: the even / odd part's registers are loop-carried
+                __builtin_amdgcn_sched_barrier(0);
+                if (j > 0) part_store(pa, nbuf, 0);
+                part_load(pa, nrs, 2 * j);
+                __builtin_amdgcn_sched_barrier(0);
+                chunk(2 * j);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j > 0) part_store(pb, nbuf, 1);
+                part_load(pb, nrs, 2 * j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                chunk(2 * j + 1);
             }
             A7_MARK(2);
             {   // the odd key: rank-1 update of this block's 32 queries (dot product split over the lane pair)
@@ -228,63 +276,70 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
         }
 
         A7_MARK(3);
-        // ---- the odd query against all 257 keys: scores with lane = key (threads 0..255), output with lane = dim (8 waves x 32 keys) ----
+        // ---- the odd query: wave w takes keys 32 w .. 32 w + 31 on the MFMA pipe.  Scores = (a 32-row operand whose row 0 is the query, the
+        // other lanes read zeros) x K^T: row 0 of the result = one key per lane (hi = 0); its softmax weights go through 64 B of LDS into the
+        // column-0 operand of the P x V product; (max, sum, o[64]) of the 32 keys is a partial that wave 0 merges after the item's barrier ----
         {
-            const int key = tid;
-            float sv = -INFINITY;
-            if (key < KP) {
-                float dot = 0.f;
-#pragma unroll 2
-                for (int ch = 0; ch < 8; ++ch) {
-                    const vec8 kk = *reinterpret_cast<const vec8*>(sK + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4));
-                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(sQt + ch * 8), q1 = *reinterpret_cast<const f32x4*>(sQt + ch * 8 + 4);
+            const char* sQh = reinterpret_cast<const char*>(sKt + 192);
+            const char* qsrc = l31 == 0 ? sQh + hi * 16 : sZero;
+            const int qstep = l31 == 0 ? 32 : 0;
+            f32x16 s1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dot = fmaf(Act<T>::to_f32(kk[e]), q0[e], fmaf(Act<T>::to_f32(kk[4 + e]), q1[e], dot));
+            for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 qa = *reinterpret_cast<const vec8*>(qsrc + ks * qstep);
+                const vec8 kf = *reinterpret_cast<const vec8*>(sK + (wave * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+                s1 = Act<T>::mfma32(qa, kf, s1);
+            }
+            const float sv = hi == 0 ? s1[0] * sc : -INFINITY;
+            const float mw = wave_max(sv);
+            const float pk = hi == 0 ? __builtin_amdgcn_exp2f(sv - mw) : 0.f;
+            const float lw = wave_sum(pk);
+            char* pw = sPw + wave * 64;
+            if (hi == 0) reinterpret_cast<T*>(pw)[(l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)] = Act<T>::from_f32(pk);      // the V^T image's key order
+            asm volatile("" ::: "memory");                            // same wave, LDS in order: the reads below see the writes above
+            const char* psrc = l31 == 0 ? pw + hi * 16 : sZero;
+            f32x16 oq[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oq[dt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const vec8 pf = *reinterpret_cast<const vec8*>(psrc + ks * qstep);
+                const int pos = wave * 32 + ks * 16 + hi * 8;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + l31;
+                    const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                    oq[dt] = Act<T>::mfma32(vf, pf, oq[dt]);
                 }
-                sv = dot * sc;
             }
-            float st = 0.f;
-#pragma unroll 4
-            for (int d4 = 0; d4 < 16; ++d4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sQt + d4 * 4), bq = *reinterpret_cast<const f32x4*>(sKt + d4 * 4);
-                st += (a[0] * bq[0] + a[1] * bq[1]) + (a[2] * bq[2] + a[3] * bq[3]);
+            float* pp = sPart + (cur * 9 + wave) * A7_PART;
+            if (l31 == 0) {                                           // column 0 of the product: 32 dims in lane 0, 32 in lane 32
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(pp + dt * 32 + 8 * g + 4 * hi) = f32x4{oq[dt][4 * g], oq[dt][4 * g + 1], oq[dt][4 * g + 2], oq[dt][4 * g + 3]};
+                if (hi == 0) { pp[64] = mw; pp[65] = lw; }
             }
-            st *= sc;
-            const float wm = wave_max(sv);
-            if (lane == 0) sRed[wave] = wm;
-            __syncthreads();
-            const float m = fmaxf(fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3])), st);       // waves 4..7 hold -inf
-            const float pk = key < KP ? __builtin_amdgcn_exp2f(sv - m) : 0.f;
-            if (key < KP) sP[(key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1)] = pk;                 // the V^T image's key order
-            const float ws = wave_sum(pk);
-            if (lane == 0) sRed[8 + wave] = ws;
-            __syncthreads();
-            const float ptl = __builtin_amdgcn_exp2f(st - m);
-            const float ltot = ((sRed[8] + sRed[9]) + (sRed[10] + sRed[11])) + ptl;
-            const int d = lane;
-            float acc = 0.f;
-#pragma unroll
-            for (int c8 = 0; c8 < 4; ++c8) {
-                const int pos0 = wave * 32 + c8 * 8;
-                const vec8 vv = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos0 * 2);
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sP + pos0), p1 = *reinterpret_cast<const f32x4*>(sP + pos0 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = fmaf(Act<T>::to_f32(vv[e]), p0[e], fmaf(Act<T>::to_f32(vv[4 + e]), p1[e], acc));
-            }
-            sPart[wave * 64 + d] = acc;
-            __syncthreads();
-            if (wave == 0) {
-                float ov = ptl * sVl[d];
-#pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) ov += sPart[w8 * 64 + d];
-                out[((long)b * Tn + KP) * Dm + h * 64 + d] = Act<T>::from_f32(ov / ltot);
+            if (wave == 1) {                                          // the odd key's term of that row as the ninth partial
+                float* p8 = sPart + (cur * 9 + 8) * A7_PART;
+                const float st = wave_sum(sQt[lane] * sKt[lane]) * sc;
+                p8[lane] = sVl[lane];
+                if (lane == 0) { p8[64] = st; p8[65] = 1.0f; }
             }
         }
 
         A7_MARK(4);
         // ---- the next item: registers -> the other LDS buffer (its loads have had this whole item to arrive) ----
-        if (has_next) {
-            stage_store(smem + (cur ^ 1) * A7_BUF);
+        {   // (past the last item this restages the item itself into the idle image: no branch, no conditional definitions)
+            char* nbuf = smem + (cur ^ 1) * A7_BUF;
+            part_store(pa, nbuf, 2);
+            part_store(pb, nbuf, 3);
+            rest_store(nbuf);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
         }
@@ -296,6 +351,7 @@ __global__ void __launch_bounds__(512, 2) attn_vit257_kernel(const T* __restrict
         ++trace_it;
 #endif
     }
+    if (wave == 0) merge_odd(cur ^ 1, item - (int)gridDim.x);        // the last item's odd query (its barrier is the loop's last one)
 }
 
 static int g_a7_cus = 0;

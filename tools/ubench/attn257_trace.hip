@@ -16,7 +16,7 @@ int main() {
     hipDeviceSynchronize();
     static unsigned long long t[32 * 8 * 8];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(amds::a7_trace), sizeof(t));
-    const char* names[6] = {"issue next item's loads", "chunk loop (4 x QK^T, softmax, PV)", "odd key + normalise + store", "odd query (3 barriers)", "stage next item into LDS", "final barrier"};
+    const char* names[6] = {"merge of the previous odd query + descriptor", "chunk loop (4 x QK^T, softmax, PV)", "odd key + normalise + store", "odd query (MFMA partials)", "stage next item into LDS", "final barrier"};
     for (int it = 4; it < 12; ++it) {
         printf("item %2d: total %6llu cycles (wave 0)  |", it, t[((it + 1) * 8 + 0) * 8] - t[(it * 8 + 0) * 8]);
         for (int k = 0; k < 6; ++k) {
