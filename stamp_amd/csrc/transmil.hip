@@ -98,19 +98,38 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
                                                             const float* __restrict__ B, int ldb, long sBo, long sBi,
                                                             float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
                                                             int M, int N, int K, float alpha, float diag,
-                                                            const float* __restrict__ bias, int accumulate, int vec) {
+                                                            const float* __restrict__ bias, int accumulate, int vec, int xcd) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16, LDT = 20;
     constexpr int ITA = BM * 4 / 256, ITB = BN * 4 / 256;          // float4 pieces per thread and K step
-    __shared__ __attribute__((aligned(16))) float sA[BM * LDT];
-    __shared__ __attribute__((aligned(16))) float sB[BN * LDT];
+    // LDS image of an operand tile.  Row-major in k in memory: [row][k parity][k / 2] (pitch LDT), two ds_read_b128 per fragment row.
+    // k-major in memory ([K][rows]: A^T products, B of A B): [k][row] (pitch rows + 4) -- the float4 along the rows is stored as it came
+    // (ds_write_b128, conflict-free) and a fragment row is eight ds_read_b32 of 32 consecutive rows.  (Scattering that float4 into the
+    // [row][k] image put 32 lanes on 2 banks: 80 % of the LDS cycles of the kernel were bank conflicts.)
+    constexpr int TRA = TRANSA, TRB = TRANSB ? 0 : 1;
+    constexpr int LKA = BM + 4, LKB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float sA[TRA ? BK * LKA : BM * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[TRB ? BK * LKB : BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int zo = blockIdx.z / inner, zi = blockIdx.z - zo * inner;
+    // Workgroup b runs on XCD b % 8, each with its own 4 MB L2: in launch order the tiles that share an A row panel or a B column panel
+    // (neighbours in x / y) land on eight different L2s and every one of them fetches its own copy.  xcd: XCD x takes the x-th contiguous
+    // eighth of the tile list instead (n fastest, then m, then batch), so the ~96 workgroups resident on an XCD walk the same panels together.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd) {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+        const int L = bx + gx * (by + gy * bz), q = total >> 3, r = total & 7, x = L & 7;
+        const int Lp = x * q + min(x, r) + (L >> 3);
+        bx = Lp % gx;
+        const int t = Lp / gx;
+        by = t % gy;
+        bz = t / gy;
+    }
+    const int zo = bz / inner, zi = bz - zo * inner;
     A += zo * sAo + zi * sAi;
     B += zo * sBo + zi * sBi;
     Cm += zo * sCo + zi * sCi;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[2][2];
 #pragma unroll
@@ -154,15 +173,11 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
             const int c = it * 256 + tid;
             if (TR) {
                 const int k = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) S[(q4 + e) * LDT + (k & 1) * 8 + (k >> 1)] = r[it][e];
+                *reinterpret_cast<f32x4*>(S + k * (RT + 4) + q4) = r[it];
             } else {
-                const int row = c >> 2, c4 = (c & 3) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = c4 + e;
-                    S[row * LDT + (k & 1) * 8 + (k >> 1)] = r[it][e];
-                }
+                const int row = c >> 2, c4 = (c & 3) * 4;                 // k = c4 .. c4 + 3: the even pair, then the odd pair
+                *reinterpret_cast<f32x2*>(S + row * LDT + (c4 >> 1)) = f32x2{r[it][0], r[it][2]};
+                *reinterpret_cast<f32x2*>(S + row * LDT + 8 + (c4 >> 1)) = f32x2{r[it][1], r[it][3]};
             }
         }
     };
@@ -181,14 +196,19 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
         __syncthreads();
         if (k0 + BK < K) gload(k0 + BK);
         f32x4 fa[2][2], fb[2][2];
+        auto frag = [&](auto tr_c, const float* S, int row, int LK, f32x4 (&f)[2]) {      // k = hi, hi + 2, ..., hi + 14 of one row
+            if constexpr (decltype(tr_c)::value) {
+#pragma unroll
+                for (int kp = 0; kp < 8; ++kp) f[kp >> 2][kp & 3] = S[(2 * kp + hi) * LK + row];
+            } else {
+                f[0] = *reinterpret_cast<const f32x4*>(S + row * LDT + hi * 8);
+                f[1] = *reinterpret_cast<const f32x4*>(S + row * LDT + hi * 8 + 4);
+            }
+        };
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float* pa = sA + (wm * 64 + i * 32 + l31) * LDT + hi * 8;
-            fa[i][0] = *reinterpret_cast<const f32x4*>(pa);
-            fa[i][1] = *reinterpret_cast<const f32x4*>(pa + 4);
-            const float* pb = sB + (wn * 64 + i * 32 + l31) * LDT + hi * 8;
-            fb[i][0] = *reinterpret_cast<const f32x4*>(pb);
-            fb[i][1] = *reinterpret_cast<const f32x4*>(pb + 4);
+            frag(TA{}, sA, wm * 64 + i * 32 + l31, LKA, fa[i]);
+            frag(TBK{}, sB, wn * 64 + i * 32 + l31, LKB, fb[i]);
         }
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp)
@@ -587,9 +607,10 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
         const int shape = (N <= 64 && M > 64) ? 1 : (M <= 64 && N > 64) ? 2 : 0;
         const dim3 grid3(cdiv(N, shape == 1 ? 64 : shape == 2 ? 256 : 128), cdiv(M, shape == 1 ? 256 : shape == 2 ? 64 : 128), outer * inner);
         const int vec = vec_ok ? 1 : 0;
+        static const int xcd = [] { const char* e = getenv("AMDS_BGEMM_XCD"); return e ? atoi(e) : 1; }();      // 0: launch order (A/B)
 #define AMDS_BG(TB, TA, WM_, WN_)                                                                                                              \
     hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
-                       inner, M, N, K, alpha, diag, bias, accumulate, vec)
+                       inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd)
 #define AMDS_BG_SHAPE(TB, TA)                                     \
     do {                                                          \
         if (shape == 1) AMDS_BG(TB, TA, 4, 1);                    \
