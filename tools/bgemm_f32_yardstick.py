@@ -28,4 +28,11 @@ for Z, M, N, K in ((512, 256, 256, 256), (512, 1280, 256, 64), (512, 256, 64, 12
     fl = 2.0 * Z * M * N * K
     err = ((tc._mm(A, B, False).double() - A.double() @ B.double()).norm() / (A.double() @ B.double()).norm()).item()
     errv = ((torch.bmm(A, B).double() - A.double() @ B.double()).norm() / (A.double() @ B.double()).norm()).item()
+    # the other operand layouts of the same product: B stored [N][K] (transb), A stored [K][M] (transa), both
+    At, Bt = A.transpose(1, 2).contiguous(), B.transpose(1, 2).contiguous()
+    lay = []
+    for ta, tb in ((False, True), (True, False), (True, True)):
+        us = timeit(lambda: tc._mm(At if ta else A, Bt if tb else B, tb, out=out, transa=ta))
+        lay.append((ta, tb, us))
+    print("    layouts (TF/s): " + "  ".join(f"{'At' if ta else 'A'}.{'Bt' if tb else 'B'} {fl / us / 1e6:5.1f}" for ta, tb, us in lay), flush=True)
     print(f"Z={Z} M={M} N={N} K={K}: amds {us_a:8.1f} us {fl / us_a / 1e6:6.1f} TF/s (err {err:.1e}) | vendor {us_v:8.1f} us {fl / us_v / 1e6:6.1f} TF/s (err {errv:.1e})", flush=True)
