@@ -354,7 +354,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
         loss.backward()
         opt.step()
         return loss
-    dt, ltm = timeit(tm_step, 3, warm=1)
+    dt, ltm = timeit(tm_step, 4, warm=2)        # two warm steps: the second still allocates (AdamW state, workspaces of the backward)
     sec["transmil_train"] = {"metric": "TransMIL bags/s (fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, fp32, Dropout(0.1) live)", "value": round(64 / dt, 1),
                              "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltm))}
     del bags_f, opt
