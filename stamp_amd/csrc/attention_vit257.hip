@@ -92,11 +92,11 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
     auto rest_load = [&](__amdgpu_buffer_rsrc_t rs) {                 // this wave's Q fragments and the odd token
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qn[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_q + ks * 32, 0, 0));
-        if (tid < 64) {                                               // token 256 = the odd one
-            tq = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, tid * 2, KP * ldb, 0));
-            tk = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, tid * 2, KP * ldb + Dm * 2, 0));
-            tv = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, tid * 2, KP * ldb + Dm * 4, 0));
-        }
+        // token 256 = the odd one; every wave loads it (only wave 0 stores it): a branch here would cut the pipelined section into two
+        // basic blocks, and the compiler sinks a stage's vector work into the later one
+        tq = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, KP * ldb, 0));
+        tk = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, KP * ldb + Dm * 2, 0));
+        tv = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2, KP * ldb + Dm * 4, 0));
     };
     auto rest_store = [&](char* buf) {
         float* sT = reinterpret_cast<float*>(buf + A7_K_BYTES + A7_V_BYTES);
@@ -172,71 +172,118 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
             float mrun = -INFINITY, l = 0.f;
-            auto chunk = [&](int c) {
-                f32x16 s[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const vec8 kf = *reinterpret_cast<const vec8*>(sK + ((c * 2 + t) * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
-                        s[t] = Act<T>::mfma32(kf, qf[ks], s[t]);
+            // Software pipeline INSIDE the wave.  The matrix pipe takes 32 cycles per MFMA and a wave can issue ~7 independent vector
+            // instructions in each gap -- if independent work stands there in program order.  Stage c therefore carries
+            //   QK^T of chunk c + 1 (8 MFMAs, slices 0-7) and P V of chunk c - 1 (8 MFMAs, slices 8-15)   beside   the softmax of chunk c,
+            // written out as 16 slices (one MFMA, the LDS read of the MFMA two slices on, ~10 vector instructions) that the scheduler may
+            // not move across.  The accumulators are rescaled by the PREVIOUS stage's factor in slices 2-3: after P V (c - 2), which ended
+            // a stage ago, and before P V (c - 1).
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto stage = [&](auto has_pv_c, auto has_qk_c, int c, float alpha_prev, f32x16 (&sc_)[2], vec8 (&pout)[2][2], const vec8 (&pprev)[2][2],
+                             f32x16 (&sn)[2]) {
+                constexpr bool HP = decltype(has_pv_c)::value, HQ = decltype(has_qk_c)::value;
+                vec8 opnd[4];
+                auto ld = [&](int i) {                                   // operand of MFMA i: 0-7 = QK^T (K rows), 8-15 = P V (V^T rows)
+                    if (i < 0 || i >= 16) return;
+                    if (i < 8) {
+                        if (!HQ) return;
+                        const int t = i & 1, ks = i >> 1;
+                        opnd[i & 3] = *reinterpret_cast<const vec8*>(sK + (((c + 1) * 2 + t) * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+                    } else {
+                        if (!HP) return;
+                        const int q = i - 8, t = q >> 2, ks = (q >> 1) & 1, dt = q & 1;
+                        const int pos = ((c - 1) * 2 + t) * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
+                        opnd[i & 3] = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
                     }
-                }
-                float mx = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mnew = fmaxf(mrun, mx * sc);
-                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-                mrun = mnew;
-                float ls = 0.f;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -mnew));
-                        s[t][r] = p;
-                        ls += p;
+                };
+                auto mf = [&](int i) {
+                    if (i < 8) {
+                        if (!HQ) return;
+                        const int t = i & 1, ks = i >> 1;
+                        sn[t] = Act<T>::mfma32(opnd[i & 3], qf[ks], ks == 0 ? zero16 : sn[t]);
+                    } else {
+                        if (!HP) return;
+                        const int q = i - 8, t = q >> 2, ks = (q >> 1) & 1, dt = q & 1;
+                        o[dt] = Act<T>::mfma32(opnd[i & 3], pprev[t][ks], o[dt]);
                     }
-                l = l * alpha + ls;
+                };
+                float mx = -INFINITY, mnew = 0.f, alpha = 0.f, ls = 0.f;
+#ifndef A7_LD_DIST
+#define A7_LD_DIST 2
+#endif
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int i = 0; i < A7_LD_DIST; ++i) ld(i);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int sl = 0; sl < 16; ++sl) {
+                    ld(sl + A7_LD_DIST);
+                    mf(sl);
+                    if (sl < 2) {                                         // running max of the 32 scores of this lane
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                        for (int f = 16 * sl; f < 16 * sl + 16; ++f) mx = fmaxf(mx, sc_[f >> 4][f & 15]);
+                    }
+                    if (sl == 2) {
+                        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                        mnew = fmaxf(mrun, mx * sc);
+                        alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                        mrun = mnew;
+                    }
+                    if ((sl == 2 || sl == 3) && HP) {                     // (stage 0 has nothing to rescale; stage 1 multiplies zeros by 0)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        vec8 pf;
+                        for (int r = 0; r < 16; ++r) o[sl - 2][r] *= alpha_prev;
+                    }
+                    if (sl >= 3 && sl < 14) {                             // three weights per slice, rounded to the operand type at once
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[t][ks * 8 + e]);
-                        const int pos = (c * 2 + t) * 32 + ks * 16 + hi * 8;
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const int d = dt * 32 + l31;
-                            const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
-                            o[dt] = Act<T>::mfma32(vf, pf, o[dt]);
+                        for (int f = 3 * (sl - 3); f < 3 * (sl - 3) + 3 && f < 32; ++f) {
+                            const float pw = __builtin_amdgcn_exp2f(fmaf(sc_[f >> 4][f & 15], sc, -mnew));
+                            ls += pw;
+                            pout[f >> 4][(f >> 3) & 1][f & 7] = Act<T>::from_f32(pw);
                         }
                     }
+                    if (sl == 14) l = l * alpha + ls;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return alpha;
             };
+            typedef std::true_type Y;
+            typedef std::false_type N_;
             char* nbuf = smem + (cur ^ 1) * A7_BUF;
+            f32x16 sa[2], sb[2];
+            vec8 p0[2][2], p1[2][2];
+            part_load(pa, nrs, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sa[t] = zero16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const vec8 kf = *reinterpret_cast<const vec8*>(sK + (t * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+                    sa[t] = Act<T>::mfma32(kf, qf[ks], sa[t]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            part_load(pb, nrs, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float al0 = stage(N_{}, Y{}, 0, 0.f, sa, p0, p1, sb);
+            part_store(pa, nbuf, 0);
+            part_load(pa, nrs, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const float al1 = stage(Y{}, Y{}, 1, al0, sb, p1, p0, sa);
+            part_store(pb, nbuf, 1);
+            part_load(pb, nrs, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const float al2 = stage(Y{}, Y{}, 2, al1, sa, p0, p1, sb);
             rest_load(nrs);
-#pragma unroll 1
-            for (int j = 0; j < 2; ++j) {                             // two chunks per trip: the even / odd part's registers are loop-carried
-                __builtin_amdgcn_sched_barrier(0);
-                if (j > 0) part_store(pa, nbuf, 0);
-                part_load(pa, nrs, 2 * j);
-                __builtin_amdgcn_sched_barrier(0);
-                chunk(2 * j);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j > 0) part_store(pb, nbuf, 1);
-                part_load(pb, nrs, 2 * j + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                chunk(2 * j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float al3 = stage(Y{}, N_{}, 3, al2, sb, p1, p0, sa);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= al3;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                                 // P V of the last chunk
+                const int t = i >> 2, ks = (i >> 1) & 1, dt = i & 1;
+                const int pos = (6 + t) * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
+                const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                o[dt] = Act<T>::mfma32(vf, p1[t][ks], o[dt]);
             }
             A7_MARK(2);
             {   // the odd key: rank-1 update of this block's 32 queries (dot product split over the lane pair)
