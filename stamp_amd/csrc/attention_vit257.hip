@@ -9,8 +9,10 @@
 // HBM -> registers -> image (i + 1) & 1 in four parts of 64 keys pipelined through the chunk loop (two 8-register sets), its Q fragments and
 // odd token HBM -> registers for the whole item: one barrier per item, no exposed round trip.  8 query blocks of 32 on 8 waves: one block per
 // wave (the one-shot kernel had 2 per wave on 4 waves); the odd key as a rank-1 VALU update; the odd query on the MFMA pipe, 32 keys per wave
-// (a one-row operand), its row merged from 9 flash-style partials by wave 0 after the item's barrier (round 2: 775 -> 742 us at 1020 tiles;
-// as a 257-key GEMV with lane = key, then lane = dim, behind three barriers it was 18 % of an item).
+// (a one-row operand), its row merged from 9 flash-style partials by wave 0 after the item's barrier (as a 257-key GEMV with lane = key, then
+// lane = dim, behind three barriers it was 18 % of an item).  The four chunks of a wave's online softmax are software-pipelined INSIDE the wave:
+// stage c issues QK^T of chunk c + 1 and P V of chunk c - 1 (16 MFMAs) in the gaps of chunk c's softmax (16 slices the scheduler may not
+// move across).  Round 2: 775 -> 742 (odd query) -> 695 us (pipeline) per 1020-tile launch.
 // Arithmetic of the 256 even queries, LDS images and the no-shuffle MFMA operand layout are those of attention_vit.hip.
 #include "common.h"
 #include <type_traits>

@@ -1,5 +1,7 @@
 // Phase timeline of the T = 257 attention kernel (stamp_amd/csrc/attention_vit257.hip compiled with -DA7_TRACE): s_memtime of the 8 waves of
-// workgroup 0 at 7 marks per item.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DA7_TRACE -Iinclude -Istamp_amd/csrc tools/ubench/attn257_trace.hip
+// workgroup 0 at 7 marks per item.  NOTE (since the in-wave software pipeline): a mark is a conditional store, i.e. a branch; the ones around the
+// pipelined stages split its basic block and the compiler then sinks vector work across them -- this build runs ~2x slower than the product
+// kernel and its chunk-phase numbers no longer describe it.  The timelines in profiles/r02_pmc_attn257_sq.txt were taken before that change.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DA7_TRACE -Iinclude -Istamp_amd/csrc tools/ubench/attn257_trace.hip
 #include "../../stamp_amd/csrc/attention_vit257.hip"
 #include <cstdio>
 #include <vector>
