@@ -202,7 +202,8 @@ def test_gemm_patch_epilogue(gpu, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,T,H", [(2, 257, 16), (3, 261, 2), (1, 265, 24), (2, 197, 4), (2, 64, 2), (1, 33, 1), (2, 288, 2)])
+@pytest.mark.parametrize("B,T,H", [(2, 257, 16), (3, 261, 2), (1, 265, 24), (2, 197, 4), (2, 64, 2), (1, 33, 1), (2, 288, 2),
+                                   (40, 257, 16)])      # 640 (tile, head) items: the persistent T = 257 kernel walks 2-3 items per workgroup
 def test_attention_vit(gpu, dt, B, T, H):
     g = torch.Generator().manual_seed(B * 1000 + T + H)
     D = H * 64
