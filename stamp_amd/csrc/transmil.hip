@@ -320,23 +320,24 @@ __global__ void dwconv_seq_kernel(const float* __restrict__ v, long svo, long sv
 __global__ void __launch_bounds__(256) ppeg_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w7,
                                                    const float* __restrict__ b7, const float* __restrict__ w5, const float* __restrict__ b5,
                                                    const float* __restrict__ w3, const float* __restrict__ b3, int Hh, int Ww, int C) {
-    __shared__ float sw[49 * 256];
+    constexpr int SWP = 257;                                     // tap pitch: the builders below write a channel's taps with consecutive lanes (pitch 256 = one bank)
+    __shared__ float sw[49 * SWP];
     const int b = blockIdx.z, i = blockIdx.y, c0 = blockIdx.x * 256, tid = threadIdx.x, c = c0 + tid;
     const int nc = min(256, C - c0);
-    for (int idx = tid; idx < 49 * 256; idx += 256) sw[idx] = 0.f;
+    for (int idx = tid; idx < 49 * SWP; idx += 256) sw[idx] = 0.f;
     __syncthreads();
-    for (int idx = tid; idx < nc * 49; idx += 256) { const int cl = idx / 49, t = idx - cl * 49; sw[t * 256 + cl] = w7[(long)c0 * 49 + idx]; }
+    for (int idx = tid; idx < nc * 49; idx += 256) { const int cl = idx / 49, t = idx - cl * 49; sw[t * SWP + cl] = w7[(long)c0 * 49 + idx]; }
     __syncthreads();
-    for (int idx = tid; idx < nc * 25; idx += 256) { const int cl = idx / 25, t = idx - cl * 25; sw[((t / 5 + 1) * 7 + t % 5 + 1) * 256 + cl] += w5[(long)c0 * 25 + idx]; }
+    for (int idx = tid; idx < nc * 25; idx += 256) { const int cl = idx / 25, t = idx - cl * 25; sw[((t / 5 + 1) * 7 + t % 5 + 1) * SWP + cl] += w5[(long)c0 * 25 + idx]; }
     __syncthreads();
-    for (int idx = tid; idx < nc * 9; idx += 256) { const int cl = idx / 9, t = idx - cl * 9; sw[((t / 3 + 2) * 7 + t % 3 + 2) * 256 + cl] += w3[(long)c0 * 9 + idx]; }
+    for (int idx = tid; idx < nc * 9; idx += 256) { const int cl = idx / 9, t = idx - cl * 9; sw[((t / 3 + 2) * 7 + t % 3 + 2) * SWP + cl] += w3[(long)c0 * 9 + idx]; }
     __syncthreads();
     const long base = ((long)b * (1 + Hh * Ww)) * C;
     if (c >= C) return;
     if (i == 0) y[base + c] = x[base + c];                       // class token (trans_mil.py:275, 282)
     float w[49];
 #pragma unroll
-    for (int t = 0; t < 49; ++t) w[t] = sw[t * 256 + tid];
+    for (int t = 0; t < 49; ++t) w[t] = sw[t * SWP + tid];
     w[24] += 1.0f;                                               // the identity term
     const float bsum = b7[c] + b5[c] + b3[c];
     float win[7][7];                                             // win[r][q] = x[i + r - 3][j + q - 3]
