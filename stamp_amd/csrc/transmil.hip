@@ -311,6 +311,43 @@ __global__ void dwconv_seq_kernel(const float* __restrict__ v, long svo, long sv
     out[zo * soo + zi * soi + (long)t * ldo + c] += s;
 }
 
+// The same sum with a register window: a lane owns one channel and TT consecutive positions, loads its TT + TAPS - 1 inputs once (a wave
+// reads 64 consecutive channels per position: 256-byte segments) and runs the TAPS x TT multiply-adds out of registers with the taps in
+// scalar registers.  (The one-thread-per-output form above issues TAPS dependent loads per output: 1.05 ms for the 64 x 8 x 1280 x 64 values of
+// a TransMIL layer, ~0.3 TB/s.)  Four waves of a workgroup take four consecutive runs of TT positions.
+template <int TAPS, int TT>
+__global__ void __launch_bounds__(256) dwconv_seq_win_kernel(const float* __restrict__ v, long svo, long svi, int ldv, const float* __restrict__ w,
+                                                             float* __restrict__ out, long soo, long soi, int ldo, int inner, int n, int d) {
+    constexpr int PAD = TAPS / 2, NIN = TT + TAPS - 1;
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int cgroups = (d + 63) >> 6;
+    const int cg = blockIdx.x % cgroups, tb = blockIdx.x / cgroups;
+    const int c = cg * 64 + (threadIdx.x & 63);
+    const int t0 = (tb * 4 + (threadIdx.x >> 6)) * TT;
+    if (c >= d || t0 >= n) return;
+    const float* p = v + zo * svo + zi * svi + c;
+    const float* wk = w + (long)zi * TAPS;
+    float in[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int tt = t0 + i - PAD;
+        in[i] = (tt >= 0 && tt < n) ? p[(long)tt * ldv] : 0.f;
+    }
+    float wr[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) wr[k] = wk[k];
+    float* o = out + zo * soo + zi * soi + c;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        if (t0 + j < n) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) s = fmaf(wr[k], in[j + k], s);
+            o[(long)(t0 + j) * ldo] += s;
+        }
+    }
+}
+
 // x: [B][1 + H*W][C] tokens (row 0 = class token, untouched); y same shape
 // PPEG (reference trans_mil.py:265-283): y = x + dwconv7(x) + dwconv5(x) + dwconv3(x) on the HxW token grid (class token passed
 // through).  The three depthwise kernels and the identity collapse into ONE 7x7 kernel per channel; a workgroup owns 256 channels
@@ -665,6 +702,14 @@ extern "C" int amds_pinv_init(const float* x, float* z, int nmat, int n, void* s
 extern "C" int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w, float* out, long soo, long soi, int ldo,
                                int outer, int inner, int n, int d, int taps, void* stream) {
     AMDS_REQUIRE(v && w && out && outer > 0 && inner > 0 && n > 0 && d > 0 && taps > 0 && (taps & 1), "amds_dwconv_seq: bad arguments");
+    static const int win = [] { const char* e = getenv("AMDS_DWCONV_WIN"); return e ? atoi(e) : 1; }();       // 0: one thread per output (A/B)
+    if (taps == 33 && win) {           // TransMIL's residual convolution (trans_mil.py:108-110: kernel 33)
+        constexpr int TT = 32;
+        hipLaunchKernelGGL((dwconv_seq_win_kernel<33, TT>), dim3(cdiv(n, 4 * TT) * cdiv(d, 64), outer * inner), dim3(256), 0, (hipStream_t)stream, v,
+                           svo, svi, ldv, w, out, soo, soi, ldo, inner, n, d);
+        AMDS_LAUNCH_CHECK("dwconv_seq_win_kernel");
+        return AMDS_OK;
+    }
     hipLaunchKernelGGL(dwconv_seq_kernel, dim3(cdiv((long)n * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, v, svo, svi, ldv, w,
                        out, soo, soi, ldo, inner, n, d, taps);
     AMDS_LAUNCH_CHECK("dwconv_seq_kernel");
