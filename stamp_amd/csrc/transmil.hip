@@ -260,6 +260,37 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x
     for (int c = tid; c < cols; c += 256) p[c] *= inv;
 }
 
+// One WAVE per row, the row in registers (cols <= 256 NV4, cols % 4 == 0): one read, one write, no LDS, no barrier.  (A 256-thread workgroup
+// per row of 256 ... 1280 floats made three passes with two block reductions each: 1.5 TB/s on the Nystrom attention matrices.)
+template <int NV4>
+__global__ void __launch_bounds__(256) softmax_rows_wave_kernel(float* __restrict__ x, long rows, int cols) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, nv = cols >> 2;
+    f32x4* p = reinterpret_cast<f32x4*>(x + row * cols);
+    f32x4 v[NV4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int idx = i * 64 + lane;
+        v[i] = idx < nv ? p[idx] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        m = fmaxf(fmaxf(m, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = expf(v[i][e] - m); s += v[i][e]; }
+    }
+    const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) p[idx] = v[i] * inv;
+    }
+}
+
 // x: [outer][n][ld] view (head slice of width d at a column offset baked into the pointer); out [outer][inner][m][d]
 __global__ void landmark_mean_kernel(const float* __restrict__ x, long sxo, long sxi, int ld, float* __restrict__ out, int inner,
                                      int m, int l, int d, float scale) {
@@ -429,6 +460,32 @@ __global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const float* __re
     for (int c = tid; c < cols; c += 256) dr[c] = pr[c] * (dr[c] - s);
 }
 
+template <int NV4>
+__global__ void __launch_bounds__(256) softmax_rows_bwd_wave_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int cols) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, nv = cols >> 2;
+    const f32x4* pr = reinterpret_cast<const f32x4*>(p + row * cols);
+    f32x4* dr = reinterpret_cast<f32x4*>(dp + row * cols);
+    f32x4 pv[NV4], dv[NV4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int idx = i * 64 + lane;
+        const bool ok = idx < nv;
+        pv[i] = ok ? pr[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[i] = ok ? dr[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += pv[i][e] * dv[i][e];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nv) dr[idx] = pv[i] * (dv[i] - s);
+    }
+}
+
 // dx[z][j*l + t][c] (+)= scale * dout[z][j][c]   (dx addressed like the forward's x: head slice of a packed qkv-shaped tensor)
 __global__ void landmark_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, long sxo, long sxi, int ld, int inner,
                                          int m, int l, int d, float scale, int accumulate) {
@@ -561,6 +618,17 @@ using namespace amds;
 extern "C" int amds_softmax_rows_bwd(const float* p, float* dp, long rows, int cols, void* stream) {
     AMDS_REQUIRE(p && dp && rows >= 0 && cols > 0 && rows < (1L << 31), "amds_softmax_rows_bwd: bad arguments");
     if (rows == 0) return AMDS_OK;
+    if (cols % 4 == 0 && cols <= 2048 && (((uintptr_t)p | (uintptr_t)dp) & 15) == 0 && (rows + 3) / 4 <= 0x7fffffffL) {
+        const dim3 g((unsigned)((rows + 3) / 4));
+        hipStream_t st = (hipStream_t)stream;
+        if (cols <= 256) hipLaunchKernelGGL((softmax_rows_bwd_wave_kernel<1>), g, dim3(256), 0, st, p, dp, rows, cols);
+        else if (cols <= 512) hipLaunchKernelGGL((softmax_rows_bwd_wave_kernel<2>), g, dim3(256), 0, st, p, dp, rows, cols);
+        else if (cols <= 1024) hipLaunchKernelGGL((softmax_rows_bwd_wave_kernel<4>), g, dim3(256), 0, st, p, dp, rows, cols);
+        else if (cols <= 1280) hipLaunchKernelGGL((softmax_rows_bwd_wave_kernel<5>), g, dim3(256), 0, st, p, dp, rows, cols);
+        else hipLaunchKernelGGL((softmax_rows_bwd_wave_kernel<8>), g, dim3(256), 0, st, p, dp, rows, cols);
+        AMDS_LAUNCH_CHECK("softmax_rows_bwd_wave_kernel");
+        return AMDS_OK;
+    }
     hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, rows, cols);
     AMDS_LAUNCH_CHECK("softmax_rows_bwd_kernel");
     return AMDS_OK;
@@ -674,6 +742,17 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
 extern "C" int amds_softmax_rows(float* x, long rows, int cols, void* stream) {
     AMDS_REQUIRE(x && rows >= 0 && cols > 0 && rows < (1L << 31), "amds_softmax_rows: bad arguments");
     if (rows == 0) return AMDS_OK;
+    if (cols % 4 == 0 && cols <= 2048 && ((uintptr_t)x & 15) == 0 && (rows + 3) / 4 <= 0x7fffffffL) {
+        const dim3 g((unsigned)((rows + 3) / 4));
+        hipStream_t st = (hipStream_t)stream;
+        if (cols <= 256) hipLaunchKernelGGL((softmax_rows_wave_kernel<1>), g, dim3(256), 0, st, x, rows, cols);
+        else if (cols <= 512) hipLaunchKernelGGL((softmax_rows_wave_kernel<2>), g, dim3(256), 0, st, x, rows, cols);
+        else if (cols <= 1024) hipLaunchKernelGGL((softmax_rows_wave_kernel<4>), g, dim3(256), 0, st, x, rows, cols);
+        else if (cols <= 1280) hipLaunchKernelGGL((softmax_rows_wave_kernel<5>), g, dim3(256), 0, st, x, rows, cols);
+        else hipLaunchKernelGGL((softmax_rows_wave_kernel<8>), g, dim3(256), 0, st, x, rows, cols);
+        AMDS_LAUNCH_CHECK("softmax_rows_wave_kernel");
+        return AMDS_OK;
+    }
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, rows, cols);
     AMDS_LAUNCH_CHECK("softmax_rows_kernel");
     return AMDS_OK;
