@@ -530,6 +530,51 @@ __global__ void __launch_bounds__(256) dwconv_seq_wgrad_kernel(const float* __re
     if (threadIdx.x == 0) part[((long)zo * inner + zi) * taps + k] = red[0];
 }
 
+// The same sums with the 33 taps as 33 accumulators per lane: a lane owns a channel, a wave every fourth run of TT positions; per run it
+// loads TT values of dout and TT + 32 of v once and does the 33 x TT multiply-adds out of registers (the kernel above reads both tensors once
+// PER TAP: 11 GB through L2 per call, 1.15 ms).  Fixed-order reduction: lanes (butterfly), then the four waves in index order.
+template <int TAPS, int TT>
+__global__ void __launch_bounds__(256) dwconv_seq_wgrad_win_kernel(const float* __restrict__ dout, long soo, long soi, int ldo, const float* __restrict__ v,
+                                                                   long svo, long svi, int ldv, float* __restrict__ part, int inner, int n, int d) {
+    constexpr int PAD = TAPS / 2, NIN = TT + TAPS - 1;
+    __shared__ float red[4][TAPS];
+    const int zi = blockIdx.x, zo = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* po = dout + zo * soo + zi * soi;
+    const float* pv = v + zo * svo + zi * svi;
+    float s[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) s[k] = 0.f;
+    for (int c0 = 0; c0 < d; c0 += 64) {
+        const int c = c0 + lane;
+        const bool cok = c < d;
+        for (int t0 = wave * TT; t0 < n; t0 += 4 * TT) {
+            float g[TT], in[NIN];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) g[j] = (cok && t0 + j < n) ? po[(long)(t0 + j) * ldo + c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int tt = t0 + i - PAD;
+                in[i] = (cok && tt >= 0 && tt < n) ? pv[(long)tt * ldv + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k)
+#pragma unroll
+                for (int j = 0; j < TT; ++j) s[k] = fmaf(g[j], in[j + k], s[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+        const float w = wave_sum(s[k]);
+        if (lane == 0) red[wave][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < TAPS) {
+        const int k = threadIdx.x;
+        part[((long)zo * inner + zi) * TAPS + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
 // PPEG weight gradients: part[chunk][tap][c] = sum over this chunk's bags and the whole grid of dy[b,i,j,c] * x[b,i+r-3,j+q-3,c] for
 // tap = r*7+q < 49; tap 49 = sum dy (the three biases share it).  The 5x5 / 3x3 kernels' gradients are the central taps.
 __global__ void __launch_bounds__(256) ppeg_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
@@ -651,9 +696,16 @@ extern "C" int amds_dwconv_seq_wgrad(const float* dout, long soo, long soi, int 
     AMDS_REQUIRE(dout && v && dw && ws && outer > 0 && outer <= 65535 && inner > 0 && n > 0 && d > 0 && taps > 0 && (taps & 1), "amds_dwconv_seq_wgrad: bad arguments");
     if (ws_bytes < amds_dwconv_seq_wgrad_workspace_bytes(outer, inner, taps)) { set_error("amds_dwconv_seq_wgrad: workspace too small"); return AMDS_ERR_WORKSPACE; }
     float* part = (float*)ws;
-    hipLaunchKernelGGL(dwconv_seq_wgrad_kernel, dim3(taps, inner, outer), dim3(256), 0, (hipStream_t)stream, dout, soo, soi, ldo, v, svo, svi, ldv, part,
-                       inner, n, d, taps);
-    AMDS_LAUNCH_CHECK("dwconv_seq_wgrad_kernel");
+    static const int win = [] { const char* e = getenv("AMDS_DWCONV_WIN"); return e ? atoi(e) : 1; }();       // 0: one workgroup per tap (A/B)
+    if (taps == 33 && win) {
+        hipLaunchKernelGGL((dwconv_seq_wgrad_win_kernel<33, 16>), dim3(inner, outer), dim3(256), 0, (hipStream_t)stream, dout, soo, soi, ldo, v, svo, svi,
+                           ldv, part, inner, n, d);
+        AMDS_LAUNCH_CHECK("dwconv_seq_wgrad_win_kernel");
+    } else {
+        hipLaunchKernelGGL(dwconv_seq_wgrad_kernel, dim3(taps, inner, outer), dim3(256), 0, (hipStream_t)stream, dout, soo, soi, ldo, v, svo, svi, ldv, part,
+                           inner, n, d, taps);
+        AMDS_LAUNCH_CHECK("dwconv_seq_wgrad_kernel");
+    }
     char* cws = (char*)(part + (size_t)outer * inner * taps);
     return amds_colsum(part, (long)inner * taps, dw, outer, inner * taps, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(outer, inner * taps), stream);
 }
