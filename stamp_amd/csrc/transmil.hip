@@ -600,6 +600,55 @@ __global__ void __launch_bounds__(256) ppeg_wgrad_kernel(const float* __restrict
     part[((long)chunk * 50 + tap) * C + c] = s;
 }
 
+// The same 50 sums as 50 accumulators per lane: a lane owns a channel, a wave every fourth grid row of its chunk's bags; per row and run of
+// JT columns it loads the JT values of dy once and, for each of the 7 kernel rows, JT + 6 values of x, and does the 7 x 7 x JT multiply-adds
+// out of registers (the kernel above reads both tensors once PER TAP: 13 GB through L2, 1.7 ms per call).  Waves are added in index order.
+template <int JT>
+__global__ void __launch_bounds__(256) ppeg_wgrad_win_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                             int B, int Hh, int Ww, int C, int bags_per_chunk) {
+    __shared__ float red[4][50][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, chunk = blockIdx.y;
+    const bool cok = c < C;
+    const int b0 = chunk * bags_per_chunk, b1 = min(B, b0 + bags_per_chunk);
+    float s[50];
+#pragma unroll
+    for (int t = 0; t < 50; ++t) s[t] = 0.f;
+    const int rows = (b1 - b0) * Hh;
+    for (int ri = wave; ri < rows; ri += 4) {
+        const int b = b0 + ri / Hh, i = ri % Hh;
+        const long base = ((long)b * (1 + Hh * Ww)) * C + C + c;            // first grid token of the bag, this lane's channel
+        for (int j0 = 0; j0 < Ww; j0 += JT) {
+            float g[JT];
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) {
+                g[jj] = (cok && j0 + jj < Ww) ? dy[base + (long)(i * Ww + j0 + jj) * C] : 0.f;
+                s[49] += g[jj];
+            }
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const int ii = i + r - 3;
+                if (ii < 0 || ii >= Hh) continue;                       // wave-uniform
+                float xin[JT + 6];
+#pragma unroll
+                for (int m = 0; m < JT + 6; ++m) {
+                    const int jx = j0 + m - 3;
+                    xin[m] = (cok && jx >= 0 && jx < Ww) ? x[base + (long)(ii * Ww + jx) * C] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < JT; ++jj) s[r * 7 + q] = fmaf(g[jj], xin[jj + q], s[r * 7 + q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 50; ++t) red[wave][t][lane] = s[t];
+    __syncthreads();
+    for (int t = wave; t < 50; t += 4)
+        if (cok) part[((long)chunk * 50 + t) * C + c] = (red[0][t][lane] + red[1][t][lane]) + (red[2][t][lane] + red[3][t][lane]);
+}
+
 __global__ void relu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dh, float* __restrict__ dz, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -716,8 +765,14 @@ extern "C" int amds_ppeg_wgrad(const float* x, const float* dy, float* dcorr, in
     if (ws_bytes < amds_ppeg_wgrad_workspace_bytes(B, C)) { set_error("amds_ppeg_wgrad: workspace too small"); return AMDS_ERR_WORKSPACE; }
     const int nchunk = cdiv(B, 4);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(ppeg_wgrad_kernel, dim3(cdiv(C, 256), 50, nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, 4);
-    AMDS_LAUNCH_CHECK("ppeg_wgrad_kernel");
+    static const int win = [] { const char* e = getenv("AMDS_DWCONV_WIN"); return e ? atoi(e) : 1; }();       // 0: one thread per (tap, channel) (A/B)
+    if (win) {
+        hipLaunchKernelGGL((ppeg_wgrad_win_kernel<16>), dim3(cdiv(C, 64), nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, 4);
+        AMDS_LAUNCH_CHECK("ppeg_wgrad_win_kernel");
+    } else {
+        hipLaunchKernelGGL(ppeg_wgrad_kernel, dim3(cdiv(C, 256), 50, nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, 4);
+        AMDS_LAUNCH_CHECK("ppeg_wgrad_kernel");
+    }
     char* cws = (char*)(part + (size_t)nchunk * 50 * C);
     return amds_colsum(part, 50L * C, dcorr, nchunk, 50 * C, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(nchunk, 50 * C), stream);
 }
