@@ -140,7 +140,10 @@ int amds_swin_mlp192(float* x, int M, const void* packed_w, const float* fc1_b, 
  * (PATCH epilogue: 8), else 0 / 1).  0 = 128x128 tile, 1 = 128x96 tile, 8 = 256x256x64 eight-wave staggered two-group
  * pipeline, 10 = 256x256x64 four-wave kernel (128x128 wave tiles), 12 = the same on v_mfma 16x16x32 (13: its A/B schedule),
  * 3 / 7 = BK = 32 predecessors, 9 = ping-pong experiment (two 256x128 workgroups per CU).  Ids other than 12 / 13 give
- * bit-identical results; 12 / 13 sum the bias first and 32 products per MFMA: they differ from the others in the last bits. */
+ * bit-identical results; 12 / 13 sum the bias first and 32 products per MFMA: they differ from the others in the last bits.
+ * -2 = -1 plus: when M is not a multiple of 256 and dropping the last, partial row tile (<= 128 rows) saves a whole wave of workgroups on
+ * kernel 12, those rows run through kernel 0 as a second launch (the MIL training step: M = bags x 1025).  Rows of that tile then differ
+ * in the last bits from what kernel 12 would give, so paths that promise identical rows across batch compositions use -1. */
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                  int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
                  const float* pos, int np, int T, int P, float acc_scale, void* stream);

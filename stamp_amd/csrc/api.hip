@@ -219,6 +219,10 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
     EpiArgs ep;
     ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.scale = scale; ep.pos = pos;
     ep.np = np; ep.T = T; ep.P = P; ep.acc_scale = acc_scale;
+    // cfg -2 = -1 (by shape) plus permission to run a ragged last row tile as its own launch (below): the rows of that tile then come from
+    // another kernel than their neighbours, so only callers that do not promise bit-identical rows across batch compositions ask for it
+    static const bool split_on = getenv("AMDS_GEMM_SPLIT") ? atoi(getenv("AMDS_GEMM_SPLIT")) != 0 : true;       // 0: never split (A/B)
+    const bool may_split = cfg == -2 && split_on;
     if (cfg < 0) {
         cfg = default_gemm_cfg(M, N, K);
         // measured (profiles/r01_gemm_vendor_and_power.txt): at the socket power cap the four-wave kernel on 16x16x32 MFMAs (the cheaper
@@ -227,10 +231,34 @@ static int gemm_impl(int cfg, const void* A, long lda, const void* W, long ldw, 
     }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);
-    if (dtype == AMDS_F16) return gemm_dispatch<f16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);
-    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(cfg, epi, A, lda, W, ldw, M, N, K, ep, st);
-    set_error("amds_gemm: bad dtype %d", dtype);
-    return AMDS_ERR_INVALID;
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_gemm: bad dtype %d", dtype);
+    auto run = [&](int c, const void* a, int m, const EpiArgs& e) {
+        return dtype == AMDS_F16 ? gemm_dispatch<f16>(c, epi, a, lda, W, ldw, m, N, K, e, st) : gemm_dispatch<bf16>(c, epi, a, lda, W, ldw, m, N, K, e, st);
+    };
+    // Ragged M on the 256-row kernel: M = 64 bags x 1025 tokens = 256.25 row tiles puts 2 ... 8 workgroups into a wave of their own (N = 512: 514
+    // workgroups = three waves for the work of two).  When dropping the last, partial row tile saves a whole wave, its rows (<= 128) go through the
+    // 128 x 128 kernel as a second launch instead.
+    if (may_split && cfg == 12 && epi != AMDS_EPI_PATCH) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t p;
+            AMDS_HIP(hipGetDevice(&dev));
+            AMDS_HIP(hipGetDeviceProperties(&p, dev));
+            cus = p.multiProcessorCount;
+        }
+        const int full = M / 256, rem = M - full * 256;
+        const long ct = N / 256;
+        if (full > 0 && rem > 0 && rem <= 128 && cdiv((full + 1) * ct, (long)cus) > cdiv(full * ct, (long)cus)) {
+            const bool f32_out = epi == AMDS_EPI_RESIDUAL || epi == AMDS_EPI_BIAS_F32 || epi == AMDS_EPI_BIAS_GELU_F32 || epi == AMDS_EPI_BIAS_RELU_F32;
+            const int rc = run(12, A, full * 256, ep);
+            if (rc != AMDS_OK) return rc;
+            EpiArgs ep2 = ep;
+            ep2.out = (char*)out + (size_t)full * 256 * ldo * (f32_out ? 4 : 2);
+            return run(0, (const char*)A + (size_t)full * 256 * lda * 2, rem, ep2);
+        }
+    }
+    return run(cfg, A, M, ep);
 }
 
 extern "C" int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi,

@@ -28,6 +28,11 @@ import torch.nn.functional as F
 from . import _lib, ops
 from . import train_ops as T
 
+# GEMM configuration of the training step: by shape, and a ragged last row tile (M = bags x 1025 tokens is never a multiple of 256) may run as
+# its own small launch when that saves a wave of workgroups (include/amdstamp.h, amds_gemm_ex cfg -2).  The inference forward keeps -1: its
+# rows come from one kernel whatever the batch.
+_CFG_TRAIN = -2
+
 BF = torch.bfloat16
 _ENC = ("query_encoders", "key_encoders", "value_encoders")
 
@@ -327,7 +332,7 @@ def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None
         a = src
     else:
         a = ops.cast_pad(src.float(), d.Fp, BF)
-    zp = ops.gemm(a, pk.w["proj_w"], _lib.EPI_BIAS, bias=pk.m["proj_b"])                             # bf16 [Mt, Dp]
+    zp = ops.gemm(a, pk.w["proj_w"], _lib.EPI_BIAS, bias=pk.m["proj_b"], cfg=_CFG_TRAIN)                             # bf16 [Mt, Dp]
     xp = _gelu_drop_fwd(zp, torch.float32, p_proj, seed, 1000)
     x = torch.empty(Bb, S, Dp, dtype=torch.float32, device=dev)
     x[:, 0] = pk.m["cls"]
@@ -342,24 +347,24 @@ def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None
     zbuf = (lambda: torch.zeros(M, Dp, dtype=BF, device=dev)) if Dp != d.D else (lambda: None)
     for l, (Lm, Lw) in enumerate(zip(pk.m["layers"], pk.w["layers"])):
         h1, mu1, rs1 = T.layernorm_train(x, *Lm["ln1"], 1e-5, BF, rows=M, row_stride=Dp, out=zbuf(), ld_out=Dp)
-        qkv = ops.gemm(h1, Lw["in_w"], _lib.EPI_BIAS, bias=Lm["in_b"])
+        qkv = ops.gemm(h1, Lw["in_w"], _lib.EPI_BIAS, bias=Lm["in_b"], cfg=_CFG_TRAIN)
         x_mid = x.clone()
         if d.alibi:
             att, u_al, osm, lse = T.attention_alibi_fwd_train(qkv, cc, Lm["inv_rm"], Lm["bias_scale"], Bb, S, Ha)
             lse = (lse, u_al, osm)
         else:
             att, lse = T.attention_fwd_train(qkv, Bb, S, Ha, p_att, seed, 10 * l + 1)
-        ops.gemm(att, Lw["out_w"], _lib.EPI_RESIDUAL, bias=Lm["out_b"], out=x_mid)
+        ops.gemm(att, Lw["out_w"], _lib.EPI_RESIDUAL, bias=Lm["out_b"], out=x_mid, cfg=_CFG_TRAIN)
         h2, mu2, rs2 = T.layernorm_train(x_mid, *Lm["ln2"], 1e-5, BF, rows=M, row_stride=Dp, out=zbuf(), ld_out=Dp)
-        z = ops.gemm(h2, Lw["fc1_w"], _lib.EPI_BIAS, bias=Lm["fc1_b"])
+        z = ops.gemm(h2, Lw["fc1_w"], _lib.EPI_BIAS, bias=Lm["fc1_b"], cfg=_CFG_TRAIN)
         u = _gelu_drop_fwd(z, None, p_ff, seed, 10 * l + 2)
         if p_ff > 0.0:          # x_out = x_mid + Dropout(fc2(u))   (:167-168)
-            y = ops.gemm(u, Lw["fc2_w"], _lib.EPI_BIAS_F32, bias=Lm["fc2_b"])
+            y = ops.gemm(u, Lw["fc2_w"], _lib.EPI_BIAS_F32, bias=Lm["fc2_b"], cfg=_CFG_TRAIN)
             x_out = torch.empty_like(x_mid)
             _lib.check(lib.amds_dropout_add(y.data_ptr(), Dp, x_mid.data_ptr(), Dp, x_out.data_ptr(), Dp, M, Dp, p_ff, seed, 10 * l + 3, st), "dropout_add")
         else:
             x_out = x_mid.clone()
-            ops.gemm(u, Lw["fc2_w"], _lib.EPI_RESIDUAL, bias=Lm["fc2_b"], out=x_out)
+            ops.gemm(u, Lw["fc2_w"], _lib.EPI_RESIDUAL, bias=Lm["fc2_b"], out=x_out, cfg=_CFG_TRAIN)
         layers.append((x, h1, mu1, rs1, qkv, att, lse, x_mid, h2, mu2, rs2, z, u))
         x = x_out
     clsn, muf, rsf = T.layernorm_train(x, *pk.m["norm"], 1e-5, torch.float32, rows=Bb, row_stride=S * Dp)
@@ -424,12 +429,12 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
             _lib.check(lib.amds_dropout_cast_bwd(dx.data_ptr(), Dp, dyb.data_ptr(), Dp, M, Dp, _lib.BF16, p_ff, seed, 10 * l + 3, st), "dropout_cast_bwd")
         else:
             dyb = ops.cast_pad(dx, Dp, BF)
-        du = ops.gemm(dyb, Lt["fc2_w"], _lib.EPI_BIAS)                                                   # [M, FFp] = dy W2
+        du = ops.gemm(dyb, Lt["fc2_w"], _lib.EPI_BIAS, cfg=_CFG_TRAIN)                                                   # [M, FFp] = dy W2
         if need_params:
             G[p + "1.4.weight"] = wgrad(tr(dyb, "g"), tr(u, "a"), Dp, FFp, Mp)[:D, : d.FF]
             G[p + "1.4.bias"] = (T.colsum(dyb) if p_ff > 0.0 else T.colsum(dx))[:D]
         dz = _gelu_drop_bwd(z, du, p_ff, seed, 10 * l + 2)
-        dh2 = ops.gemm(dz, Lt["fc1_w"], _lib.EPI_BIAS_F32)                                               # [M, Dp] fp32
+        dh2 = ops.gemm(dz, Lt["fc1_w"], _lib.EPI_BIAS_F32, cfg=_CFG_TRAIN)                                               # [M, Dp] fp32
         if need_params:
             G[p + "1.1.weight"] = wgrad(tr(dz, "g"), tr(h2, "a"), FFp, Dp, Mp)[: d.FF, :D]
             G[p + "1.1.bias"] = T.colsum(dz)[: d.FF]
@@ -438,7 +443,7 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
         G[p + "1.0.weight"], G[p + "1.0.bias"] = g_w, g_b
         # ---- attention branch: x_mid = x_in + out_proj(attention(in_proj(LN(x_in))))
         dxb = ops.cast_pad(dx, Dp, BF)                                                                   # d(x_mid)
-        datt = ops.gemm(dxb, Lt["out_w"], _lib.EPI_BIAS)                                                 # [M, Da]
+        datt = ops.gemm(dxb, Lt["out_w"], _lib.EPI_BIAS, cfg=_CFG_TRAIN)                                                 # [M, Da]
         out_name = "0.mhsa.fc." if d.alibi else "0.mhsa.out_proj."
         if need_params:
             G[p + out_name + "weight"] = pk.unpad_out_w(wgrad(tr(dxb, "g"), tr(att, "a"), Dp, Da, Mp))
@@ -461,7 +466,7 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
                         G[p + f"0.mhsa.{e}.{h}.weight"], G[p + f"0.mhsa.{e}.{h}.bias"] = gw[i, h], gb[i, h]
             else:
                 G[p + "0.mhsa.in_proj_weight"], G[p + "0.mhsa.in_proj_bias"] = gw.reshape(3 * D, D), gb.reshape(3 * D)
-        dh1 = ops.gemm(dqkv, Lt["in_w"], _lib.EPI_BIAS_F32)
+        dh1 = ops.gemm(dqkv, Lt["in_w"], _lib.EPI_BIAS_F32, cfg=_CFG_TRAIN)
         g_w, g_b = torch.empty(D, device=dev), torch.empty(D, device=dev)
         T.layernorm_bwd(dh1, x_in, mu1, rs1, Lm["ln1"][0], dx, True, g_w, g_b, rows=M, dy_stride=Dp, x_stride=Dp, dx_stride=Dp)
         G[p + "0.norm.weight"], G[p + "0.norm.bias"] = g_w, g_b
@@ -477,7 +482,7 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
         G["project_features.0.bias"] = T.colsum(dzp)[:D]
     dbags = None
     if need_bags:
-        dbags = ops.gemm(dzp, pk.wt["proj_w"], _lib.EPI_BIAS_F32)[:, :Fd].reshape(Bb, Tn, Fd)
+        dbags = ops.gemm(dzp, pk.wt["proj_w"], _lib.EPI_BIAS_F32, cfg=_CFG_TRAIN)[:, :Fd].reshape(Bb, Tn, Fd)
     if not need_params:
         G = {}
     return G, dbags
