@@ -141,11 +141,22 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
     f32x4 ra[ITA], rb[ITB];
     // one operand tile (R rows of the output dimension x 16 k) -> registers.  Row-major in k (TR = 0: float4 along k, 4 pieces per
     // row) or k-major (TR = 1: the operand is stored [K][R], float4 along the row dimension, R / 4 pieces per k).
-    auto gload_op = [&](auto tr_c, auto it_c, f32x4* r, const float* P, int ld, int R, int r0, int k0, int RT) {
+    auto gload_op = [&](auto fast_c, auto tr_c, auto it_c, f32x4* r, const float* P, int ld, int R, int r0, int k0, int RT) {
         constexpr int TR = decltype(tr_c)::value, IT = decltype(it_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value;             // the tile is inside the operand, K % 16 == 0, float4 loads allowed: no checks
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = it * 256 + tid;
+            if constexpr (FAST) {
+                if (TR) {
+                    const int k = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
+                    r[it] = *reinterpret_cast<const f32x4*>(P + (long)(k0 + k) * ld + r0 + q4);
+                } else {
+                    const int row = c >> 2, c4 = (c & 3) * 4;
+                    r[it] = *reinterpret_cast<const f32x4*>(P + (long)(r0 + row) * ld + k0 + c4);
+                }
+                continue;
+            }
             r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (TR) {
                 const int k = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
@@ -185,9 +196,10 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
     typedef std::integral_constant<int, TRANSB ? 0 : 1> TBK;        // B stored [K][N] (no transb) is the k-major case
     typedef std::integral_constant<int, ITA> IA;
     typedef std::integral_constant<int, ITB> IB;
+    auto k_loop = [&](auto fast_c) {
     auto gload = [&](int k0) {
-        gload_op(TA{}, IA{}, ra, A, lda, M, m0, k0, BM);
-        gload_op(TBK{}, IB{}, rb, B, ldb, N, n0, k0, BN);
+        gload_op(fast_c, TA{}, IA{}, ra, A, lda, M, m0, k0, BM);
+        gload_op(fast_c, TBK{}, IB{}, rb, B, ldb, N, n0, k0, BN);
     };
     gload(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
@@ -219,6 +231,10 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kp >> 2][kp & 3], fb[j][kp >> 2][kp & 3], acc[i][j], 0, 0, 0);
         __syncthreads();
     }
+    };
+    // interior tiles (all of them for the Nystrom / pinv / projection shapes) take the loop without bounds checks: each check is a branch
+    if (vec && m0 + BM <= M && n0 + BN <= N && K % BK == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l31;
