@@ -233,25 +233,32 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
     }
     };
     // interior tiles (all of them for the Nystrom / pinv / projection shapes) take the loop without bounds checks: each check is a branch
-    if (vec && m0 + BM <= M && n0 + BN <= N && K % BK == 0) k_loop(std::true_type{});
+    const bool interior = m0 + BM <= M && n0 + BN <= N;
+    if (vec && interior && K % BK == 0) k_loop(std::true_type{});
     else k_loop(std::false_type{});
+    auto store = [&](auto inside_c) {                                // inside: no per-element bounds checks
+        constexpr bool IN = decltype(inside_c)::value;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        if (n >= N) continue;
-        const float bn = bias ? bias[n] : 0.f;
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (!IN && n >= N) continue;
+            const float bn = bias ? bias[n] : 0.f;
+            float* cn = Cm + n;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < M) {
-                    float v = alpha * acc[i][j][r] + (m == n ? diag : 0.f) + bn;
-                    if (accumulate) v += Cm[(long)m * ldc + n];
-                    Cm[(long)m * ldc + n] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (IN || m < M) {
+                        float v = alpha * acc[i][j][r] + (m == n ? diag : 0.f) + bn;
+                        if (accumulate) v += cn[(long)m * ldc];
+                        cn[(long)m * ldc] = v;
+                    }
                 }
-            }
-    }
+        }
+    };
+    if (interior) store(std::true_type{});
+    else store(std::false_type{});
 }
 
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long rows, int cols) {
