@@ -236,8 +236,8 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
     const bool interior = m0 + BM <= M && n0 + BN <= N;
     if (vec && interior && K % BK == 0) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    auto store = [&](auto inside_c) {                                // inside: no per-element bounds checks
-        constexpr bool IN = decltype(inside_c)::value;
+    auto store = [&](auto inside_c, auto diag_c) {                   // inside: no per-element bounds checks; diag: the + diag * I term is there
+        constexpr bool IN = decltype(inside_c)::value, DG = decltype(diag_c)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + l31;
@@ -250,15 +250,21 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (IN || m < M) {
-                        float v = alpha * acc[i][j][r] + (m == n ? diag : 0.f) + bn;
+                        float v = alpha * acc[i][j][r] + bn;
+                        if (DG) v += m == n ? diag : 0.f;
                         if (accumulate) v += cn[(long)m * ldc];
                         cn[(long)m * ldc] = v;
                     }
                 }
         }
     };
-    if (interior) store(std::true_type{});
-    else store(std::false_type{});
+    if (diag != 0.f) {
+        if (interior) store(std::true_type{}, std::true_type{});
+        else store(std::false_type{}, std::true_type{});
+    } else {
+        if (interior) store(std::true_type{}, std::false_type{});
+        else store(std::false_type{}, std::false_type{});
+    }
 }
 
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long rows, int cols) {
