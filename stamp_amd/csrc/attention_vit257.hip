@@ -19,7 +19,7 @@
 
 namespace amds {
 
-constexpr int A7_NKT = 8, A7_KP = 256, A7_VS = 576;                    // vt_row_bytes(8): 9 x 64 B
+constexpr int A7_KP = 256, A7_VS = 576;                                // 8 key tiles of 32; V^T rows of vt_row_bytes(8) = 9 x 64 B
 constexpr int A7_K_BYTES = A7_KP * 128, A7_V_BYTES = 64 * A7_VS + 8 * 16, A7_T_BYTES = 3 * 64 * 4 + 128;       // + the odd query in 16 bit
 constexpr int A7_BUF = A7_K_BYTES + A7_V_BYTES + A7_T_BYTES;          // 70 656 B per item image
 constexpr int A7_PART = 68;                                           // one partial of the odd query's row: o[64] | max | sum | pad
