@@ -788,18 +788,21 @@ extern "C" int amds_dwconv_seq_wgrad(const float* dout, long soo, long soi, int 
     return amds_colsum(part, (long)inner * taps, dw, outer, inner * taps, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(outer, inner * taps), stream);
 }
 
-extern "C" size_t amds_ppeg_wgrad_workspace_bytes(int B, int C) { return (size_t)cdiv(B, 4) * 50 * C * 4 + amds_colsum_workspace_bytes(cdiv(B, 4), 50 * C); }
+constexpr int PPEG_WGRAD_BAGS = 2;            // bags per partial (64 bags x 8 channel groups of the window kernel = 256 workgroups)
+extern "C" size_t amds_ppeg_wgrad_workspace_bytes(int B, int C) {
+    return (size_t)cdiv(B, PPEG_WGRAD_BAGS) * 50 * C * 4 + amds_colsum_workspace_bytes(cdiv(B, PPEG_WGRAD_BAGS), 50 * C);
+}
 extern "C" int amds_ppeg_wgrad(const float* x, const float* dy, float* dcorr, int B, int Hh, int Ww, int C, void* ws, size_t ws_bytes, void* stream) {
     AMDS_REQUIRE(x && dy && dcorr && ws && B > 0 && Hh > 0 && Ww > 0 && C > 0, "amds_ppeg_wgrad: bad arguments");
     if (ws_bytes < amds_ppeg_wgrad_workspace_bytes(B, C)) { set_error("amds_ppeg_wgrad: workspace too small"); return AMDS_ERR_WORKSPACE; }
-    const int nchunk = cdiv(B, 4);
+    const int nchunk = cdiv(B, PPEG_WGRAD_BAGS);
     float* part = (float*)ws;
     static const int win = [] { const char* e = getenv("AMDS_DWCONV_WIN"); return e ? atoi(e) : 1; }();       // 0: one thread per (tap, channel) (A/B)
     if (win) {
-        hipLaunchKernelGGL((ppeg_wgrad_win_kernel<16>), dim3(cdiv(C, 64), nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, 4);
+        hipLaunchKernelGGL((ppeg_wgrad_win_kernel<16>), dim3(cdiv(C, 64), nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, PPEG_WGRAD_BAGS);
         AMDS_LAUNCH_CHECK("ppeg_wgrad_win_kernel");
     } else {
-        hipLaunchKernelGGL(ppeg_wgrad_kernel, dim3(cdiv(C, 256), 50, nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, 4);
+        hipLaunchKernelGGL(ppeg_wgrad_kernel, dim3(cdiv(C, 256), 50, nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, part, B, Hh, Ww, C, PPEG_WGRAD_BAGS);
         AMDS_LAUNCH_CHECK("ppeg_wgrad_kernel");
     }
     char* cws = (char*)(part + (size_t)nchunk * 50 * C);
