@@ -298,6 +298,34 @@ def test_errors_are_values(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("epi_name", ["EPI_BIAS", "EPI_BIAS_F32", "EPI_RESIDUAL"])
+def test_gemm_ragged_row_tile_as_its_own_launch(gpu, epi_name):
+    """cfg -2 (the MIL training step: M = 64 bags x 1025 tokens = 256.25 row tiles, N = 512 -> 514 workgroups): the last, partial row tile runs
+    through the 128 x 128 kernel when that saves a wave.  Rows of the full tiles are the production kernel's bit for bit; the 64 rows of the
+    ragged tile match the fp64 product to the output type's rounding."""
+    epi = getattr(_lib, epi_name)
+    M, N, K = 64 * 1025, 512, 512
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(M, K, generator=g).to(gpu, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, torch.bfloat16)
+    b = torch.randn(N, generator=g).to(gpu)
+    f32 = epi != _lib.EPI_BIAS
+    base = torch.randn(M, N, generator=g).to(gpu) if epi == _lib.EPI_RESIDUAL else None
+    outs = []
+    for cfg in (12, -2):
+        out = base.clone() if base is not None else None
+        outs.append(ops.gemm(a, w, epi, bias=b, out=out, cfg=cfg))
+    full = (M // 256) * 256
+    assert torch.equal(outs[0][:full], outs[1][:full])
+    ref = a[full:].double() @ w.double().T + b.double()
+    if base is not None:
+        ref = ref + base[full:].double()
+    tol = (1e-4 if f32 else 2 * _eps(torch.bfloat16)) * max(1.0, ref.abs().max().item())
+    for o in outs:
+        assert (o[full:].double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,use_scale", [(1000, 1024, 320, True), (515, 512, 1024, False), (256, 256, 64, True)])
 def test_gemm_lnfold_producer(gpu, dt, M, N, K, use_scale):
