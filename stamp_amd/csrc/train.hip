@@ -324,10 +324,21 @@ extern "C" int amds_layernorm_train(const float* x, long x_row_stride, const flo
     if (rows == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(cdiv(rows, 4)), block(256);
-    if (out_dtype == AMDS_BF16) hipLaunchKernelGGL((ln_train_kernel<bf16, 8>), grid, block, 0, st, x, x_row_stride, gamma, beta, (bf16*)y, y_row_stride, mean, rstd, rows, cols, eps);
-    else if (out_dtype == AMDS_F16) hipLaunchKernelGGL((ln_train_kernel<f16, 8>), grid, block, 0, st, x, x_row_stride, gamma, beta, (f16*)y, y_row_stride, mean, rstd, rows, cols, eps);
-    else if (out_dtype == AMDS_F32) hipLaunchKernelGGL((ln_train_kernel<float, 8>), grid, block, 0, st, x, x_row_stride, gamma, beta, (float*)y, y_row_stride, mean, rstd, rows, cols, eps);
+    // float4 slots per lane by row width (2 = 512 columns: the MIL heads): the same arithmetic in a quarter of the registers
+#define AMDS_LN_TRAIN(TO_, MV)                                                                                                                \
+    hipLaunchKernelGGL((ln_train_kernel<TO_, MV>), grid, block, 0, st, x, x_row_stride, gamma, beta, (TO_*)y, y_row_stride, mean, rstd, rows, cols, eps)
+#define AMDS_LN_TRAIN_W(TO_)                                   \
+    do {                                                       \
+        if (cols <= 512) AMDS_LN_TRAIN(TO_, 2);                \
+        else if (cols <= 1024) AMDS_LN_TRAIN(TO_, 4);          \
+        else AMDS_LN_TRAIN(TO_, 8);                            \
+    } while (0)
+    if (out_dtype == AMDS_BF16) AMDS_LN_TRAIN_W(bf16);
+    else if (out_dtype == AMDS_F16) AMDS_LN_TRAIN_W(f16);
+    else if (out_dtype == AMDS_F32) AMDS_LN_TRAIN_W(float);
     else { set_error("amds_layernorm_train: bad dtype"); return AMDS_ERR_INVALID; }
+#undef AMDS_LN_TRAIN_W
+#undef AMDS_LN_TRAIN
     AMDS_LAUNCH_CHECK("ln_train_kernel");
     return AMDS_OK;
 }
@@ -345,8 +356,13 @@ extern "C" int amds_layernorm_bwd(const float* dy, long dy_stride, const float* 
     float* dbp = dgp + (size_t)nblk * cols;
     char* cws = (char*)(dbp + (size_t)nblk * cols);
     const size_t cws_bytes = amds_colsum_workspace_bytes(nblk, cols);
-    hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx,
-                       dx_stride, add_skip, dgp, dbp, rows, cols);
+#define AMDS_LN_BWD(MV)                                                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<MV>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, \
+                       dx_stride, add_skip, dgp, dbp, rows, cols)
+    if (cols <= 512) AMDS_LN_BWD(2);
+    else if (cols <= 1024) AMDS_LN_BWD(4);
+    else AMDS_LN_BWD(8);
+#undef AMDS_LN_BWD
     AMDS_LAUNCH_CHECK("ln_bwd_kernel");
     int rc = amds_colsum(dgp, cols, dgamma, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
     if (rc != AMDS_OK) return rc;
