@@ -21,7 +21,12 @@ import torch
 from . import h5io, ops
 
 _logger = logging.getLogger("stamp_amd")
-VERSION = "amdstamp-0.2"
+# `stamp_version` is parsed by the reference with packaging's `Version(...)` and compared with its own
+# `stamp.__version__` (modeling/data.py:793-799): it must be a PEP 440 string not newer than the STAMP release whose file
+# format this package writes (v2.5.0, pyproject.toml:3).  The build id of this package goes into `amdstamp_version`.
+STAMP_FORMAT_VERSION = "2.5.0"
+AMDSTAMP_VERSION = "0.3"
+VERSION = STAMP_FORMAT_VERSION
 _HASH_RE = re.compile(r"^[0-9a-fA-F]{6,}$")
 
 
@@ -110,7 +115,7 @@ class HipGatedAttentionEncoder:
 
     def _save_features_(self, output_path: Path, feats: np.ndarray, feat_type: str) -> None:
         h5io.write_slide_features(output_path, feats, encoder=str(self.identifier), precision=str(self.precision), code_hash=code_hash()[:8],
-                                  stamp_version=VERSION, feat_type=feat_type)
+                                  stamp_version=STAMP_FORMAT_VERSION, feat_type=feat_type, amdstamp_version=AMDSTAMP_VERSION)
 
     def encode_slides_(self, output_dir: Path, feat_dir: Path, device=None, generate_hash: bool = True, **kwargs) -> None:
         """One slide-level .h5 per tile-level .h5 under feat_dir, folder structure kept, existing outputs skipped, files whose extractor

@@ -268,21 +268,38 @@ def _np(x) -> np.ndarray:
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
-def write_tile_features(path, feats, coords_um, *, extractor: str, tile_size_um: float, tile_size_px: int, code_hash: str, stamp_version: str) -> None:
+def _pep440(stamp_version) -> str:
+    """The reference parses `stamp_version` with `packaging.version.Version` (modeling/data.py:793-795): refuse anything it would choke on."""
+    from packaging.version import InvalidVersion, Version
+    try:
+        Version(str(stamp_version))
+    except InvalidVersion as e:
+        raise ValueError(f"stamp_version must be a PEP 440 version string (STAMP parses it with packaging.Version), got {stamp_version!r}") from e
+    return str(stamp_version)
+
+
+def _build_attrs(amdstamp_version) -> dict:
+    return {} if amdstamp_version is None else {"amdstamp_version": str(amdstamp_version)}
+
+
+def write_tile_features(path, feats, coords_um, *, extractor: str, tile_size_um: float, tile_size_px: int, code_hash: str, stamp_version: str,
+                        amdstamp_version: str | None = None) -> None:
     """feats [N, D] (stored as given: the extraction loop hands fp16, preprocessing/__init__.py:325), coords [N, 2] micrometres."""
     feats, coords = _np(feats), _np(coords_um).astype(np.float32)
     if feats.ndim != 2 or coords.shape != (feats.shape[0], 2):
         raise ValueError(f"expected feats [N, D] and coords [N, 2], got {feats.shape} and {coords.shape}")
     _write(Path(path), {"coords": coords, "feats": feats},
-           {"stamp_version": str(stamp_version), "extractor": str(extractor), "unit": "um", "tile_size_um": float(tile_size_um),
-            "tile_size_px": int(tile_size_px), "code_hash": str(code_hash), "feat_type": "tile"})
+           {"stamp_version": _pep440(stamp_version), "extractor": str(extractor), "unit": "um", "tile_size_um": float(tile_size_um),
+            "tile_size_px": int(tile_size_px), "code_hash": str(code_hash), "feat_type": "tile", **_build_attrs(amdstamp_version)})
 
 
-def write_slide_features(path, feats, *, encoder: str, precision: str, code_hash: str, stamp_version: str, feat_type: str = "slide") -> None:
+def write_slide_features(path, feats, *, encoder: str, precision: str, code_hash: str, stamp_version: str, feat_type: str = "slide",
+                         amdstamp_version: str | None = None) -> None:
     if feat_type not in ("slide", "patient"):
         raise ValueError("feat_type must be 'slide' or 'patient'")
-    _write(Path(path), {"feats": _np(feats)}, {"version": str(stamp_version), "encoder": str(encoder), "precision": str(precision),
-                                               "stamp_version": str(stamp_version), "code_hash": str(code_hash), "feat_type": feat_type})
+    _write(Path(path), {"feats": _np(feats)}, {"version": _pep440(stamp_version), "encoder": str(encoder), "precision": str(precision),
+                                               "stamp_version": _pep440(stamp_version), "code_hash": str(code_hash), "feat_type": feat_type,
+                                               **_build_attrs(amdstamp_version)})
 
 
 def read_file(path) -> tuple[dict[str, np.ndarray], dict]:

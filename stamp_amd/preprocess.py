@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import h5io, tiling
-from .encoder import VERSION, code_hash
+from .encoder import AMDSTAMP_VERSION, STAMP_FORMAT_VERSION, code_hash
 from .extractor import Extractor, has_enough_texture
 
 
@@ -67,5 +67,6 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     if not feats:
         return stats
     h5io.write_tile_features(Path(output_path), torch.cat(feats), np.concatenate(coords).astype(np.float32), extractor=str(extractor.identifier),
-                             tile_size_um=tile_size_um, tile_size_px=tile_size_px, code_hash=code_hash()[:8], stamp_version=VERSION)
+                             tile_size_um=tile_size_um, tile_size_px=tile_size_px, code_hash=code_hash()[:8], stamp_version=STAMP_FORMAT_VERSION,
+                             amdstamp_version=AMDSTAMP_VERSION)
     return stats
