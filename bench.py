@@ -331,7 +331,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     for key, alibi, drop in (("train", False, None), ("train_no_dropout", False, False), ("train_alibi", True, None)):
         model = mil if not alibi else HipMil(dropout=0.25, use_alibi=True, **kw).eval()
         crd = (torch.rand(64, 1024, 2, generator=torch.Generator().manual_seed(2)) * 4e4).to(ctx.device) if alibi else None
-        trn = HipMilVitTrainer(model, device=ctx.device, total_steps=100, dropout=drop)
+        trn = HipMilVitTrainer(model, device=ctx.device, total_steps=100, sched_interval="step", dropout=drop)
         dt, (ltr, _) = timeit(lambda: trn.step(bags, tg, cw, coords=crd), 4)
         sec[key] = {"metric": f"MIL bags/s (vit head{' with ALiBi' if alibi else ''}, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands, "
                               + ("all dropout sites off)" if drop is False else "train-mode dropout as the reference: 0.25 / 0.25 / 0.5 / 0.5)"),
@@ -373,7 +373,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     c1 = HipMil(dim_output=2, dim_input=2048, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.25, use_alibi=False)
     cb = torch.rand(64, 256, 2048, device=ctx.device).half()
     ct = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
-    tr1 = HipMilVitTrainer(c1, device=ctx.device, total_steps=2)
+    tr1 = HipMilVitTrainer(c1, device=ctx.device, total_steps=2, sched_interval="step")
     hist = mil_fit(tr1, lambda: [(cb[:51], None, None, ct[:51])], lambda: [(cb[i:i + 1], None, None, ct[i:i + 1]) for i in range(51, 64)], max_epochs=2, patience=16)
     torch.cuda.synchronize()
     sec["config1_two_epochs"] = {"metric": "wall seconds, BASELINE.json configs[0]: 64 bags x 256 tiles x 2048-d, `vit` head, 2 epochs (train step over 51 bags + 13 validation forwards each)",

@@ -9,7 +9,12 @@ Mirrors what `stamp train` does for tile-level models:
   updated before use (:24-29);
 * optimiser -- :133-141: ``AdamW(lr=1e-3)`` with torch defaults wrapped in ``OneCycleLR(total_steps, max_lr, div_factor)``.  torch's
   OneCycleLR also cycles AdamW's beta1 (cycle_momentum=True: 0.95 -> 0.85 at the LR peak -> 0.95); both the LR and beta1 are read
-  off torch's own scheduler evaluated on a dummy optimiser and fed to the fused kernel;
+  off torch's own scheduler evaluated on a dummy optimiser and fed to the fused kernel.  HOW OFTEN the schedule advances is not
+  STAMP's decision: `configure_optimizers` returns a bare ``[optimizer], [scheduler]`` pair, and Lightning wraps an un-annotated
+  scheduler in its default config ``interval="epoch", frequency=1`` -- so under `stamp train` the schedule, although sized in STEPS
+  (``total_steps = len(train_dl) * max_epochs``, train.py:197-198), moves ONE position per EPOCH and the learning rate stays on the
+  first ``max_epochs`` positions of the warm-up ramp.  `sched_interval="epoch"` (the default here) reproduces that;
+  `sched_interval="step"` is the per-step OneCycle the schedule's size suggests was intended (SURVEY.md 8c);
 * epochs -- src/stamp/modeling/train.py:504-564: validation after every epoch (the caller's validation loader: full bags,
   batch size 1, :467-477), early stopping with `patience` on the validation loss (mode min), the best epoch's weights restored
   at the end (`shutil.copy(best_model_path)` + reload).
@@ -46,11 +51,39 @@ def onecycle_schedule(total_steps: int, max_lr: float, div_factor: float) -> tup
     return lrs, b1s
 
 
+class OneCycleClock:
+    """Position of a trainer on torch's OneCycle (lr, beta1) table.  interval "epoch": the position moves in `epoch_end()` only
+    (what Lightning does with the reference's bare scheduler); "step": it moves after every optimiser step.  Past the table's end
+    the last entry is held (torch's scheduler would raise; Lightning never gets there: max_epochs <= total_steps)."""
+
+    def __init__(self, total_steps: int, max_lr: float, div_factor: float, interval: str = "epoch") -> None:
+        if interval not in ("epoch", "step"):
+            raise ValueError(f"sched_interval must be 'epoch' or 'step', got {interval!r}")
+        self.interval = interval
+        self.lrs, self.b1s = onecycle_schedule(total_steps, max_lr, div_factor)
+        self.pos = 0
+
+    def current(self) -> tuple[float, float]:
+        i = min(self.pos, len(self.lrs) - 1)
+        return self.lrs[i], self.b1s[i]
+
+    def after_step(self) -> None:
+        if self.interval == "step":
+            self.pos += 1
+
+    def epoch_end(self) -> None:
+        if self.interval == "epoch":
+            self.pos += 1
+
+
 class HipMilVitTrainer:
     def __init__(self, model: VisionTransformer, *, device="cuda", max_lr: float = 1e-4, div_factor: float = 25.0,
-                 total_steps: int = 1000, weight_decay: float = 0.01, split_k: int = 32, dropout: bool | None = None) -> None:
+                 total_steps: int = 1000, weight_decay: float = 0.01, split_k: int = 32, dropout: bool | None = None,
+                 sched_interval: str = "epoch") -> None:
         """dropout: None = as the reference's train mode (live when the model's rates are > 0; the feed-forward rate is always 0.5);
-        False = all dropout sites off (deterministic steps, e.g. for parity tests against autograd)."""
+        False = all dropout sites off (deterministic steps, e.g. for parity tests against autograd).
+        sched_interval: "epoch" (default; what Lightning does with the reference's bare scheduler, see the module docstring: call
+        `epoch_end()` after every epoch -- `fit` does) or "step" (OneCycle advanced after every optimiser step)."""
         self.model = model
         self.dims = model.dims
         self.alibi = bool(model.use_alibi)
@@ -75,7 +108,8 @@ class HipMilVitTrainer:
         # ALiBi: running_mean / items_so_far are BUFFERS of the reference module (no gradient, no optimiser update)
         stat = [k for k in self.names if mil_core.is_buffer(k)]
         self._stat_idx = torch.tensor([self.offs[k][0] for k in stat], dtype=torch.long, device=self.dev)
-        self._lrs, self._b1s = onecycle_schedule(total_steps, max_lr, div_factor)
+        self.clock = OneCycleClock(total_steps, max_lr, div_factor, sched_interval)
+        self._lrs, self._b1s = self.clock.lrs, self.clock.b1s
         self.pk = PackedVit(self.dims, self.p, BF, train=True)
 
     # ---- parameter views ------------------------------------------------------------------------------------------------
@@ -93,7 +127,7 @@ class HipMilVitTrainer:
     def load_from_model(self) -> None:
         sd = self.model.state_dict()
         self.P.copy_(torch.cat([sd[k].detach().float().reshape(-1) for k in self.names]).to(self.dev))
-        self.pk.refresh(self.p)
+        self._refresh()
 
     # ---- one optimisation step ------------------------------------------------------------------------------------------------
     def step(self, bags: torch.Tensor, targets: torch.Tensor, class_weights: torch.Tensor | None = None, *, update: bool = True,
@@ -106,7 +140,20 @@ class HipMilVitTrainer:
 
         data_parallel=True: every rank of the initialised process group holds a replica and its own bags; the flat
         fp32 gradient buffer (14.7 MB for the default head) is averaged with ONE RCCL all-reduce before AdamW
-        (the reference itself is single-device, src/stamp/modeling/train.py:541-547)."""
+        (the reference itself is single-device, src/stamp/modeling/train.py:541-547).
+
+        update=False computes loss, logits and gradients and leaves EVERY piece of state as it was: no optimiser step, and the ALiBi
+        running-mean buffers (which a train-mode forward updates before use, vision_tranformer.py:24-29) are put back afterwards."""
+        if update or not self.alibi:
+            return self._step(bags, targets, class_weights, update, data_parallel, coords, loss_fn, seed)
+        stats_before = self.P[self._stat_idx].clone()
+        try:
+            return self._step(bags, targets, class_weights, update, data_parallel, coords, loss_fn, seed)
+        finally:
+            self.P[self._stat_idx] = stats_before
+            self._refresh()
+
+    def _step(self, bags, targets, class_weights, update, data_parallel, coords, loss_fn, seed):
         dev = self.dev
         dist_on = data_parallel and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         if seed is None:
@@ -118,7 +165,7 @@ class HipMilVitTrainer:
             mil_core.update_running_means(self.p, self.dims, cc)
             if dist_on:      # replicas see different bags: keep the scaler buffers identical (mean of the ranks' updates)
                 self.P[self._stat_idx] = average_buffers(self.P[self._stat_idx])
-            self.pk.refresh(self.p)
+            self._refresh()
         logits, saved = mil_core.forward_train(self.pk, bags, coords, training=self.use_dropout, seed=seed)
         # ---- loss on [Bb, C]: the reference's weighted CE with float one-hot targets (models/__init__.py:254-258) ---------------------
         with torch.enable_grad():
@@ -140,20 +187,32 @@ class HipMilVitTrainer:
             average_gradients(self.G)
         if update:
             self.step_count += 1
-            i = min(self.step_count - 1, len(self._lrs) - 1)
+            lr, b1 = self.clock.current()
             stats = self.P[self._stat_idx].clone() if self.alibi else None      # buffers: not touched by the optimiser (weight decay)
-            T.adamw(self.P, self.G, self.m, self.v, self._lrs[i], self.step_count, betas=(self._b1s[i], 0.999), weight_decay=self.wd)
+            T.adamw(self.P, self.G, self.m, self.v, lr, self.step_count, betas=(b1, 0.999), weight_decay=self.wd)
+            self.clock.after_step()
             if stats is not None:
                 self.P[self._stat_idx] = stats
-            self.pk.refresh(self.p)
+            self._refresh()
         return loss.detach(), logits
+
+    def epoch_end(self) -> None:
+        """Lightning steps an epoch-interval scheduler once after every training epoch."""
+        self.clock.epoch_end()
+
+    def _refresh(self) -> None:
+        """The packed operands follow the master parameters; any cached inference pack is stale from here on."""
+        self.pk.refresh(self.p)
+        self._eval_pk_step = -1
 
     # ---- evaluation (validation / deploy): inference kernels, fp16 operands, any bag length ---------------------------------------------
     @torch.no_grad()
     def predict(self, bags: torch.Tensor, coords: torch.Tensor | None = None) -> torch.Tensor:
-        pk = PackedVit(self.dims, self.p, torch.float16, train=False) if getattr(self, "_eval_pk_step", -1) != self.step_count else self._eval_pk
-        self._eval_pk, self._eval_pk_step = pk, self.step_count
-        return mil_core.forward_infer(pk, bags, coords, None)
+        # the fp16 inference pack is rebuilt whenever the master parameters or buffers changed since it was made (`_refresh`)
+        if getattr(self, "_eval_pk_step", -1) != self.step_count or getattr(self, "_eval_pk", None) is None:
+            self._eval_pk = PackedVit(self.dims, self.p, torch.float16, train=False)
+            self._eval_pk_step = self.step_count
+        return mil_core.forward_infer(self._eval_pk, bags, coords, None)
 
 
 def fit(trainer: HipMilVitTrainer, train_batches, valid_batches, *, max_epochs: int, patience: int = 16, class_weights=None,
@@ -176,6 +235,7 @@ def fit(trainer: HipMilVitTrainer, train_batches, valid_batches, *, max_epochs: 
             loss, _ = trainer.step(bags.to(dev), targets, class_weights, coords=None if coords is None else coords.to(dev), loss_fn=loss_fn)
             tot += float(loss) * bags.shape[0]
             cnt += bags.shape[0]
+        trainer.epoch_end()
         hist["train_loss"].append(tot / max(cnt, 1))
         vtot, vcnt = 0.0, 0
         for bags, coords, _sizes, targets in valid_batches():
@@ -200,9 +260,7 @@ def fit(trainer: HipMilVitTrainer, train_batches, valid_batches, *, max_epochs: 
                 break
     if best["P"] is not None:
         trainer.P.copy_(best["P"])
-        trainer.pk.refresh(trainer.p)
-        trainer.step_count += 0
-        trainer._eval_pk_step = -1
+        trainer._refresh()
     trainer.sync_to_model()
     hist["best_epoch"] = best["epoch"]
     return hist

@@ -69,6 +69,39 @@ def test_onecycle_schedule_is_torchs_including_beta1():
     assert abs(lrs[0] - 4e-6) < 1e-12 and abs(b1s[0] - 0.95) < 1e-12 and abs(min(b1s) - 0.85) < 1e-9 and max(lrs) == pytest.approx(1e-4)
 
 
+def test_onecycle_clock_epoch_interval_is_lightnings_default_and_step_interval_is_per_step():
+    """The reference returns a bare `[optimizer], [scheduler]` (models/__init__.py:133-141); Lightning's default for that is
+    interval="epoch": the schedule sized in steps moves once per epoch.  Both intervals against torch's own scheduler."""
+    from stamp_amd.mil_train import OneCycleClock
+
+    steps_per_epoch, epochs = 5, 4
+    total = steps_per_epoch * epochs
+    for interval in ("epoch", "step"):
+        clock = OneCycleClock(total, 1e-4, 25.0, interval)
+        opt = torch.optim.AdamW([nn.Parameter(torch.zeros(1))], lr=1e-3)
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, total_steps=total, max_lr=1e-4, div_factor=25.0)
+        n_sched = 0
+        for e in range(epochs):
+            for i in range(steps_per_epoch):
+                assert clock.current() == (opt.param_groups[0]["lr"], opt.param_groups[0]["betas"][0]), (interval, e, i)
+                opt.step()
+                clock.after_step()
+                if interval == "step" and n_sched < total - 1:
+                    sch.step()
+                    n_sched += 1
+            clock.epoch_end()
+            if interval == "epoch":
+                sch.step()
+        if interval == "epoch":      # after 4 epochs the LR is still on the warm-up ramp, 4 positions in
+            assert clock.pos == epochs and clock.pos < clock.lrs.index(max(clock.lrs))
+    with pytest.raises(ValueError):
+        OneCycleClock(10, 1e-4, 25.0, "batch")
+    held = OneCycleClock(3, 1e-4, 25.0, "step")
+    for _ in range(7):
+        held.after_step()
+    assert held.current() == (held.lrs[-1], held.b1s[-1])
+
+
 def test_padding_is_a_no_op_on_aligned_shapes_and_invertible_on_odd_ones():
     for kw, alibi in ((dict(F=1024, D=512, H=8, FF=512, C=2, L=1), False), (dict(F=456, D=132, H=4, FF=135, C=3, L=1), False),
                       (dict(F=40, D=60, H=3, FF=64, C=2, L=1), True)):
@@ -179,8 +212,14 @@ def test_fit_loop_early_stopping_and_best_weights():
             self.P = torch.zeros(1)
             self.epoch = -1
             self.step_count = 0
-            self.pk = type("pk", (), {"refresh": lambda self_, get: None})()
             self.synced = None
+            self.epochs_ended = 0
+
+        def epoch_end(self):
+            self.epochs_ended += 1
+
+        def _refresh(self):
+            pass
 
         p = None
 
@@ -206,3 +245,4 @@ def test_fit_loop_early_stopping_and_best_weights():
     assert hist["best_epoch"] == 4 and hist["stopped_epoch"] == 7 and len(hist["validation_loss"]) == 8
     assert hist["validation_loss"][:5] == pytest.approx(curve[:5])
     assert float(st.synced) == 15.0                                  # weights after epoch 4 (5 epochs x 3 steps), not the last ones
+    assert st.epochs_ended == 8                                      # the scheduler clock is told about every finished epoch

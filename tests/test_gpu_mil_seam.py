@@ -134,7 +134,7 @@ def test_module_trains_with_torch_adamw_and_onecycle_like_the_trainer(gpu):
     steps = 12
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, total_steps=steps, max_lr=2e-3, div_factor=25.0)
-    tr = HipMilVitTrainer(twin, device=gpu, max_lr=2e-3, div_factor=25.0, total_steps=steps, dropout=False)
+    tr = HipMilVitTrainer(twin, device=gpu, max_lr=2e-3, div_factor=25.0, total_steps=steps, sched_interval="step", dropout=False)
     la, lb = [], []
     for i in range(steps):
         opt.zero_grad()
@@ -248,7 +248,7 @@ def test_training_step_with_dropout_matches_oracle_given_the_same_masks(gpu, ali
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     bags, coords = torch.randn(Bb, Tn, Fd).half(), torch.rand(Bb, Tn, 2) * 3000
     targets, weights = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 1.0]]), torch.tensor([0.7, 0.3])
-    tr = HipMilVitTrainer(model, device=gpu, split_k=8, max_lr=2e-3, total_steps=45)      # dropout=None: as the reference's train mode
+    tr = HipMilVitTrainer(model, device=gpu, split_k=8, max_lr=2e-3, total_steps=45, sched_interval="step")      # dropout=None: as the reference's train mode
     seed = 777123
     loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu), seed=seed)
     loss2, logits2 = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu), seed=seed + 1)
@@ -372,6 +372,31 @@ def test_config0_shape_training_step(gpu):
     assert l1 < l0
 
 
+def test_step_without_update_leaves_all_state_and_predict_follows_the_weights(gpu):
+    """`step(update=False)` must not move the ALiBi running-mean buffers (a train-mode forward updates them before use), and `predict`
+    must never answer from a stale inference pack: after load_from_model, after a no-update ALiBi step, after an optimiser step."""
+    torch.manual_seed(12)
+    model = VisionTransformer(dim_output=2, dim_input=128, dim_model=128, n_layers=1, n_heads=2, dim_feedforward=128, dropout=0.0, use_alibi=True)
+    bags = torch.randn(4, 40, 128).half().to(gpu)
+    coords = (torch.rand(4, 40, 2) * 4e4).to(gpu)
+    targets = torch.nn.functional.one_hot(torch.tensor([0, 1, 0, 1]), 2).float()
+    tr = HipMilVitTrainer(model, device=gpu, dropout=False, split_k=4)
+    P0 = tr.P.clone()
+    p0 = tr.predict(bags, coords).clone()
+    tr.step(bags, targets, coords=coords, update=False)
+    assert torch.equal(tr.P, P0), "update=False changed parameters or buffers"
+    assert torch.equal(tr.predict(bags, coords), p0)
+    tr.step(bags, targets, coords=coords)                      # a real step moves the buffers and the weights
+    assert not torch.equal(tr.P[tr._stat_idx], P0[tr._stat_idx])
+    p1 = tr.predict(bags, coords).clone()
+    assert not torch.equal(p1, p0)
+    with torch.no_grad():
+        model.mlp_head[0].bias.add_(3.0)                       # weights changed behind the trainer's back, then loaded
+    tr.load_from_model()
+    p2 = tr.predict(bags, coords)
+    assert (p2 - p1).abs().max() > 1.0, "predict() answered from the pack of the old weights"
+
+
 def test_fit_loop_trains_validates_and_restores_the_best_epoch(gpu):
     """`train_model_` semantics end to end on a separable toy problem: per-epoch validation on FULL bags of different lengths (batch 1),
     early stopping, best weights restored into the nn.Module, which then predicts with the inference kernels."""
@@ -385,7 +410,7 @@ def test_fit_loop_trains_validates_and_restores_the_best_epoch(gpu):
 
     train = [(torch.cat([make(8, 64, 0), make(8, 64, 1)]), None, None, torch.nn.functional.one_hot(torch.tensor([0] * 8 + [1] * 8), 2).float())] * 4
     valid = [(make(1, t, lab), None, None, torch.nn.functional.one_hot(torch.tensor([lab]), 2).float()) for t, lab in ((50, 0), (300, 1), (77, 1), (129, 0))]
-    tr = HipMilVitTrainer(model, device=gpu, max_lr=2e-3, total_steps=4 * 12)
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=2e-3, total_steps=4 * 12, sched_interval="step")
     hist = fit(tr, lambda: train, lambda: valid, max_epochs=12, patience=4)
     assert len(hist["validation_loss"]) >= 2 and hist["best_epoch"] >= 0
     assert min(hist["validation_loss"]) < hist["validation_loss"][0] and hist["validation_loss"][hist["best_epoch"]] == min(hist["validation_loss"])

@@ -175,7 +175,7 @@ def test_mil_vit_training_step_matches_autograd(gpu):
         assert torch.allclose(mil_vit_forward_d(bags.double(), {k: v.double() for k, v in sd.items()}, 4).float(),
                               mil_vit_forward(bags.float(), torch.zeros(Bb, Tn, 2), None, sd, n_heads=4, use_alibi=False), atol=1e-4)
     ref_loss, ref_logits, ref_g = _oracle_loss_and_grads(sd, bags.float(), targets, weights, 4)
-    tr = HipMilVitTrainer(model, device=gpu, max_lr=1e-3, div_factor=25.0, total_steps=50, split_k=4, dropout=False)
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=1e-3, div_factor=25.0, total_steps=50, sched_interval="step", split_k=4, dropout=False)
     loss, logits = tr.step(bags.to(gpu), targets, weights, update=False)
     assert abs(loss.item() - ref_loss) < 2e-2 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
     assert (logits.cpu().double() - ref_logits).abs().max() < 3e-2 * max(1.0, ref_logits.abs().max().item())
@@ -266,7 +266,7 @@ def test_mil_vit_alibi_training_step_matches_autograd(gpu):
     loss_ref = torch.nn.functional.cross_entropy(logits_ref, targets, weight=weights)
     loss_ref.backward()
 
-    tr = HipMilVitTrainer(model, device=gpu, max_lr=1e-3, div_factor=25.0, total_steps=50, split_k=4, dropout=False)
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=1e-3, div_factor=25.0, total_steps=50, sched_interval="step", split_k=4, dropout=False)
     loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu))
     assert abs(loss.item() - loss_ref.item()) < 2e-2 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
     assert (logits.cpu() - logits_ref.detach()).abs().max() < 3e-2 * max(1.0, logits_ref.abs().max().item())
@@ -331,7 +331,7 @@ def test_trainer_regression_and_survival_losses(gpu, task):
     ref_pred = mil_vit_forward(bags.float(), torch.zeros(Bb, Tn, 2), None, params, n_heads=4, use_alibi=False)
     ref_loss = fn(ref_pred, targets)
     ref_loss.backward()
-    tr = HipMilVitTrainer(model, device=gpu, max_lr=2e-3, div_factor=25.0, total_steps=50, split_k=4, dropout=False)
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=2e-3, div_factor=25.0, total_steps=50, sched_interval="step", split_k=4, dropout=False)
     loss, pred = tr.step(bags.to(gpu), targets, update=False, loss_fn=fn)
     assert pred.shape == (Bb, 1)
     assert abs(loss.item() - fn(pred.cpu(), targets).item()) < 1e-5
