@@ -251,6 +251,13 @@ typedef struct {
     const float* pos_patch;  /* [n_patches][dim] fp32 */
     const amds_vit_block* blocks_host; /* HOST array of `depth` structs holding device pointers */
     const float* norm_w; const float* norm_b;
+    /* Compensated patch embedding (0 = off).  The tile transform is folded into the patch weight, which then multiplies the RAW 0..255
+     * values: rounding W/std to 16 bits costs (rms of u8 / rms of the normalised pixel) ~ 2x the relative error an ordinary operand
+     * rounding does, on the tensor every block builds on (measured: the largest single contribution to the feature error, DESIGN.md
+     * section 5).  With patch_lo_shift = s > 0, patch_w is [dim][2*kp] = [hi | (W/std - hi) * 2^s] (both act dtype; s = 11 for fp16, 8 for
+     * bf16 keeps the low part in the normal range) and the patch matrix carries the pixel values twice, the second copy scaled by 2^-s
+     * (exact): the fp32 accumulator sees W/std to ~22 bits.  0.2 % of the path's flops become 0.4 %. */
+    int patch_lo_shift;
 } amds_vit_weights;
 
 /* Workspace bytes for a forward over at most `batch` tiles per internal chunk. */
@@ -286,6 +293,10 @@ int amds_vit_forward_overlapped(amds_ctx* ctx, const amds_vit_cfg* cfg_host, con
  * Exposed for tests; amds_vit_forward calls it internally. */
 int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int patch, int kp,
                         int dtype, void* stream);
+/* lo_shift > 0: rows are 2*kp wide, columns kp.. repeat the values scaled by 2^-lo_shift (exact) -- the A operand for a patch weight
+ * split into [hi | (W - hi) * 2^lo_shift] (amds_vit_weights.patch_lo_shift); lo_shift = 0 is amds_tile_im2col_u8. */
+int amds_tile_im2col_u8_ex(const uint8_t* tiles, void* out, int B, int img, int patch, int kp,
+                           int dtype, int lo_shift, void* stream);
 
 /* Stand-alone tile transform: (u8/255 - mean[c]) / std[c], HWC -> CHW, fp32 out [B][3][H][W].
  * This is Extractor.transform on an already-224x224 tile (ToTensor + Normalize; reference

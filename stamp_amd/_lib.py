@@ -33,7 +33,7 @@ class VitBlock(C.Structure):
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p),
                 ("pos_patch", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)),
-                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("patch_lo_shift", C.c_int)]
 
 
 class SwinCfg(C.Structure):
@@ -103,6 +103,7 @@ PROTOTYPES = {
     "amds_layernorm_meanpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amds_tile_im2col_u8_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),
     "amds_macenko_normalize_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
     "amds_supertiles_to_tiles_workspace_bytes": (_sz, [_i, _i, _i, _i]),

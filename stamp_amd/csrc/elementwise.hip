@@ -267,9 +267,11 @@ __global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* __re
 // One block per (tile, patch-row): the p image rows (p*img*3 contiguous bytes) are staged in LDS with
 // 16-byte coalesced loads, then each thread assembles 8 consecutive k (one 16-byte store).
 // ---------------------------------------------------------------------------------------------
+// lo_scale != 0: rows are 2*kp wide and columns kp.. hold the same values times lo_scale (a power of two, exact) -- the A operand of a
+// patch-embedding GEMM whose weight is split into [hi | lo / lo_scale] (amds_tile_im2col_u8_ex).
 template <typename TO>
 __global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restrict__ tiles, TO* __restrict__ out,
-                                                        int img, int p, int kp) {
+                                                        int img, int p, int kp, float lo_scale) {
     extern __shared__ __attribute__((aligned(16))) uint8_t srow[];
     const int g = img / p;
     const int b = blockIdx.x / g, py = blockIdx.x - b * g;
@@ -279,23 +281,26 @@ __global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restric
         *reinterpret_cast<u32x4*>(srow + i) = *reinterpret_cast<const u32x4*>(src + i);
     __syncthreads();
     const int pp = p * p, k_real = 3 * pp;
-    const int chunks = kp >> 3;
-    TO* orow = out + ((long)b * g * g + (long)py * g) * kp;
+    const int ld = lo_scale != 0.f ? 2 * kp : kp;
+    const int chunks = ld >> 3, half = kp >> 3;
+    TO* orow = out + ((long)b * g * g + (long)py * g) * ld;
     typedef TO vec8 __attribute__((ext_vector_type(8)));
     for (int w = threadIdx.x; w < g * chunks; w += 256) {
         const int px = w / chunks, ch = w - px * chunks;
+        const int ch0 = ch >= half ? ch - half : ch;
+        const float sc = ch >= half ? lo_scale : 1.0f;
         vec8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = ch * 8 + e;
+            const int k = ch0 * 8 + e;
             float v = 0.f;
             if (k < k_real) {
                 const int c = k / pp, r = k - c * pp, i = r / p, j = r - i * p;
-                v = (float)srow[(i * img + px * p + j) * 3 + c];
+                v = (float)srow[(i * img + px * p + j) * 3 + c] * sc;
             }
             o[e] = (TO)v;
         }
-        *reinterpret_cast<vec8*>(orow + (long)px * kp + ch * 8) = o;
+        *reinterpret_cast<vec8*>(orow + (long)px * ld + ch * 8) = o;
     }
 }
 
@@ -393,7 +398,14 @@ extern "C" int amds_tile_normalize_u8(const uint8_t* hwc, float* chw, int B, int
 
 extern "C" int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int img, int patch, int kp, int dtype,
                                    void* stream) {
+    return amds_tile_im2col_u8_ex(tiles, out, B, img, patch, kp, dtype, 0, stream);
+}
+
+extern "C" int amds_tile_im2col_u8_ex(const uint8_t* tiles, void* out, int B, int img, int patch, int kp, int dtype, int lo_shift,
+                                      void* stream) {
     AMDS_REQUIRE(tiles && out, "amds_tile_im2col_u8: null pointer");
+    AMDS_REQUIRE(lo_shift >= 0 && lo_shift <= 14, "amds_tile_im2col_u8: lo_shift=%d out of range", lo_shift);
+    const float lo_scale = lo_shift ? ldexpf(1.0f, -lo_shift) : 0.f;
     AMDS_REQUIRE(img > 0 && patch > 0 && img % patch == 0, "amds_tile_im2col_u8: img=%d not divisible by patch=%d", img, patch);
     AMDS_REQUIRE(kp % 8 == 0 && kp >= 3 * patch * patch, "amds_tile_im2col_u8: kp=%d too small / not a multiple of 8", kp);
     AMDS_REQUIRE((patch * img * 3) % 16 == 0 && ((long)img * img * 3) % 16 == 0, "amds_tile_im2col_u8: row block not 16-byte aligned");
@@ -401,11 +413,11 @@ extern "C" int amds_tile_im2col_u8(const uint8_t* tiles, void* out, int B, int i
     const int g = img / patch;
     const size_t lds = (size_t)patch * img * 3;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(PROF_OTHER, (double)B * ((double)img * img * 3 + (double)g * g * kp * 2), st);
+    ProfScope prof(PROF_OTHER, (double)B * ((double)img * img * 3 + (double)g * g * kp * (lo_shift ? 4 : 2)), st);
     if (dtype == AMDS_F16)
-        hipLaunchKernelGGL((im2col_u8_kernel<f16>), dim3(B * g), dim3(256), lds, st, tiles, (f16*)out, img, patch, kp);
+        hipLaunchKernelGGL((im2col_u8_kernel<f16>), dim3(B * g), dim3(256), lds, st, tiles, (f16*)out, img, patch, kp, lo_scale);
     else if (dtype == AMDS_BF16)
-        hipLaunchKernelGGL((im2col_u8_kernel<bf16>), dim3(B * g), dim3(256), lds, st, tiles, (bf16*)out, img, patch, kp);
+        hipLaunchKernelGGL((im2col_u8_kernel<bf16>), dim3(B * g), dim3(256), lds, st, tiles, (bf16*)out, img, patch, kp, lo_scale);
     else { set_error("amds_tile_im2col_u8: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("im2col_u8_kernel");
     return AMDS_OK;

@@ -48,7 +48,7 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     p->off_x = o;   o += align256(rows * c->dim * 4);
     p->off_h = o;   o += align256(rows * c->dim * 2);
     p->off_qkv = o; o += align256(rows * 3 * c->dim * 2);
-    const size_t mlp_b = rows * c->hidden * 2, pm_b = (size_t)batch * p->np * p->kp * 2;
+    const size_t mlp_b = rows * c->hidden * 2, pm_b = (size_t)batch * p->np * p->kp * 2 * 2;    // patch matrix: room for the split form
     p->off_mlp = o; o += align256(mlp_b > pm_b ? mlp_b : pm_b);
     // LayerNorm-folded path: second 16-bit row buffer, partial row sums per 128-column slab, final row statistics
     p->off_h2 = o;      o += align256(rows * c->dim * 2);
@@ -96,9 +96,11 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         AMDS_REQUIRE(D % 256 == 0 && n_fc1 % 256 == 0, "vit: the LayerNorm-folded path needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", D, n_fc1);
 
     // patch embedding: im2col (raw 0..255 values) -> GEMM with folded normalisation, + pos-embed
-    AMDS_TRY(amds_tile_im2col_u8(tiles, mlp, Bc, c->img, c->patch, pl.kp, dt, st));
+    // (patch_lo_shift > 0: weight and patch matrix in the split [hi | lo] form, K doubled -- include/amdstamp.h)
+    const int kpe = w->patch_lo_shift > 0 ? 2 * pl.kp : pl.kp;
+    AMDS_TRY(amds_tile_im2col_u8_ex(tiles, mlp, Bc, c->img, c->patch, pl.kp, dt, w->patch_lo_shift, st));
     if (c->n_prefix > 0) AMDS_TRY(prefix_init(w->prefix, x, Bc, T, c->n_prefix, D, st));
-    AMDS_TRY(amds_gemm(mlp, pl.kp, w->patch_w, pl.kp, Bc * pl.np, D, pl.kp, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
+    AMDS_TRY(amds_gemm(mlp, kpe, w->patch_w, kpe, Bc * pl.np, D, kpe, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
                        nullptr, w->pos_patch, pl.np, T, c->n_prefix, 1.0f / 255.0f, st));
 
     // ---- ragged tail on a side stream.  The GEMMs work on 256-row tiles, one workgroup per CU, and every launch is a whole number of

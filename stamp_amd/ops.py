@@ -162,13 +162,14 @@ def pack_swiglu_rows(w: torch.Tensor) -> torch.Tensor:
     return dst.reshape(w.shape)
 
 
-def tile_im2col_u8(tiles: torch.Tensor, patch: int, kp: int, dtype: torch.dtype) -> torch.Tensor:
+def tile_im2col_u8(tiles: torch.Tensor, patch: int, kp: int, dtype: torch.dtype, lo_shift: int = 0) -> torch.Tensor:
+    """lo_shift > 0: rows of 2*kp, the second half = the first times 2^-lo_shift (the split patch-embedding form)."""
     _dev(tiles)
     assert tiles.dtype == torch.uint8 and tiles.is_contiguous() and tiles.shape[-1] == 3
     B, img = tiles.shape[0], tiles.shape[1]
     g = img // patch
-    out = torch.empty(B * g * g, kp, dtype=dtype, device=tiles.device)
-    _lib.check(_lib.lib().amds_tile_im2col_u8(_p(tiles), _p(out), B, img, patch, kp, act_code(dtype), _stream()), "im2col")
+    out = torch.empty(B * g * g, kp * (2 if lo_shift else 1), dtype=dtype, device=tiles.device)
+    _lib.check(_lib.lib().amds_tile_im2col_u8_ex(_p(tiles), _p(out), B, img, patch, kp, act_code(dtype), int(lo_shift), _stream()), "im2col")
     return out
 
 

@@ -147,7 +147,8 @@ class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
-                 act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None) -> None:
+                 act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None,
+                 patch_split: bool | None = None) -> None:
         super().__init__()
         if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
             raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
@@ -171,6 +172,12 @@ class HipViT(nn.Module):
         if ln_fold and not can_fold:
             raise ValueError(f"ln_fold needs dim % 256 == 0 and fc1 rows % 256 == 0 (dim={cfg.dim}, fc1 rows={n_fc1})")
         self.ln_fold = bool(ln_fold)
+        # Patch-embedding weight as a 16-bit [hi | lo] pair (include/amdstamp.h, amds_vit_weights.patch_lo_shift): default on -- the weight with
+        # the tile transform folded in multiplies RAW 0..255 values, so its rounding is the largest single error source of the whole path
+        #  and the fix costs 0.2 % of the flops.  AMDS_VIT_PATCH_SPLIT=0 / patch_split=False: the single-rounded weight (A/B).
+        if patch_split is None:
+            patch_split = os.environ.get("AMDS_VIT_PATCH_SPLIT", "1") != "0"
+        self.patch_lo_shift = (11 if act_dtype == torch.float16 else 8) if patch_split else 0
         self._pack(state_dict)
 
     # -- weight packing (one time) ----------------------------------------------------------------
@@ -210,7 +217,14 @@ class HipViT(nn.Module):
         pb = sd["patch_embed.proj.bias"].detach().double().cpu()
         pw_f = pw / std.view(1, 3, 1, 1)
         pb_f = pb - (pw * (mean / std).view(1, 3, 1, 1)).sum(dim=(1, 2, 3))
-        self.patch_w = self._act(pw_f.float().reshape(D, -1), ld=c.kp)
+        if self.patch_lo_shift:
+            flat = pw_f.reshape(D, -1)
+            hi = flat.float().to(self.act_dtype)
+            lo = ((flat - hi.double()) * 2.0 ** self.patch_lo_shift).float()
+            pad = lambda t: torch.nn.functional.pad(t.float(), (0, c.kp - t.shape[1]))  # noqa: E731
+            self.patch_w = self._act(torch.cat([pad(hi), pad(lo)], dim=1), ld=2 * c.kp)
+        else:
+            self.patch_w = self._act(pw_f.float().reshape(D, -1), ld=c.kp)
         self.patch_b = self._f32(pb_f.float())
         pos = sd["pos_embed"].detach().float().reshape(-1, D)
         toks = [sd["cls_token"].detach().float().reshape(1, D)]
@@ -277,7 +291,7 @@ class HipViT(nn.Module):
                                   1 if c.layerscale else 0, ops.act_code(self.act_dtype), c.ln_eps)
         self._w_c = _lib.VitWeights(self.patch_w.data_ptr(), self.patch_b.data_ptr(), self.prefix.data_ptr(),
                                     self.pos_patch.data_ptr(), C.cast(blocks, C.POINTER(_lib.VitBlock)),
-                                    self.norm_w.data_ptr(), self.norm_b.data_ptr())
+                                    self.norm_w.data_ptr(), self.norm_b.data_ptr(), self.patch_lo_shift)
         torch.cuda.synchronize(dev)
 
     # -- forward ----------------------------------------------------------------------------------

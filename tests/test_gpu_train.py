@@ -273,7 +273,7 @@ def test_mil_vit_alibi_training_step_matches_autograd(gpu):
     worst, report = 0.0, []
     for k in tr.names:
         if k.endswith(("running_mean", "items_so_far")):
-            assert torch.allclose(tr.p(k).cpu(), sd[k], rtol=1e-5), (k, tr.p(k).cpu(), sd[k])       # buffers: updated, exactly as the reference
+            assert torch.equal(tr.p(k).cpu(), sd0[k].float()), k       # update=False: the scaler buffers are put back (the forward itself used the updated ones)
             continue
         g, r = tr.g(k).cpu().double(), params[k].grad.double()
         if "key_encoders" in k and k.endswith(".bias"):
@@ -296,10 +296,16 @@ def test_mil_vit_alibi_training_step_matches_autograd(gpu):
     for rel, k, rn in report:
         # bias_scale is a scalar: its gradient is a signed sum over (in the last layer) only the class-token rows
         assert rel < (0.12 if k.endswith("bias_scale") else 6e-2), (k, rel, rn)
-    losses = [tr.step(bags.to(gpu), targets, weights, coords=coords.to(gpu))[0].item() for _ in range(8)]
+    losses = []
+    for i in range(8):
+        losses.append(tr.step(bags.to(gpu), targets, weights, coords=coords.to(gpu))[0].item())
+        if i == 0:      # the first real step: buffers updated exactly as the reference's train-mode forward does, and kept
+            for k in tr.names:
+                if k.endswith(("running_mean", "items_so_far")):
+                    assert torch.allclose(tr.p(k).cpu(), sd[k], rtol=1e-5), (k, tr.p(k).cpu(), sd[k])
     assert losses[-1] < losses[0] and torch.isfinite(tr.P).all()
     n_key = next(k for k in tr.names if k.endswith("items_so_far"))
-    assert tr.p(n_key).item() == 1.0 + 9                                   # nine train-mode forwards, weight decay never touched it
+    assert tr.p(n_key).item() == 1.0 + 8                                   # eight train-mode forwards that count, weight decay never touched it
     tr.sync_to_model()
     model.eval()
     with torch.no_grad():

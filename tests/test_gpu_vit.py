@@ -48,14 +48,14 @@ def test_vit_large_matches_oracle(gpu):
     assert r_f < 1e-3 and r_t < 1e-3 and mx < 2e-3
 
 
-@pytest.mark.parametrize("name,tol_cls", [("uni2_h", 1.5e-3), ("virchow2", 1.5e-3), ("h_optimus_0", 1.5e-3), ("vit_large_patch16_224", 1e-3)])
+@pytest.mark.parametrize("name,tol_cls", [("uni2_h", 1e-3), ("virchow2", 1e-3), ("h_optimus_0", 1e-3), ("vit_large_patch16_224", 1e-3)])
 def test_full_size_presets_match_oracle(gpu, name, tol_cls):
     """Full-size parity for every preset DESIGN quotes a throughput for (reference uni2.py:17-37, virchow2.py:24-54 -- ViT-H/14
     with head_dim 80 --, h_optimus_0.py:15-30, uni.py:26-31): 2 tiles, fp16 operands / fp32 accumulate / fp32 residual stream.
-    Stated tolerances: relative L2 error of ALL final tokens (fp32) <= 1e-3 for every model (BASELINE.json north_star);
-    of the fp16 CLS feature row alone <= 1e-3 for the ViT-L models and <= 1.5e-3 for the SwiGLU ViT-H / ViT-g models (measured
-    on the MI355X: UNI2-h tokens 7.0e-4, CLS 1.14e-3 -- the single CLS row, rounded to fp16 on both sides, sits at the floor
-    fp16 MFMA operands allow over 24-40 blocks; DESIGN.md section 5 lists the measured value per model)."""
+    Stated tolerance (BASELINE.json north_star): relative L2 error <= 1e-3 of ALL final tokens (fp32) AND of the fp16 CLS feature row --
+    the thing written to the .h5 -- rounded to fp16 on both sides, for every model.  Round 3: the patch-embedding weight is a 16-bit
+    [hi | lo] pair (amds_vit_weights.patch_lo_shift); its single rounding was the largest error source of the path (UNI2-h tokens
+    7.0e-4 -> 3.8e-4, CLS row 1.14e-3 -> ~8e-4; DESIGN.md section 5 lists the measured value per model)."""
     cfg = PRESETS[name]
     sd = random_vit_state_dict(cfg, seed=5, init="moderate")
     tiles = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
