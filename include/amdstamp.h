@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define AMDS_VERSION_MAJOR 0
-#define AMDS_VERSION_MINOR 1
+#define AMDS_VERSION_MINOR 2
 
 typedef enum {
     AMDS_OK = 0,
@@ -244,6 +244,18 @@ typedef struct {
     const float* fc1_colsum;                    /* [hidden] / [2*hidden] or NULL */
 } amds_vit_block;
 
+/* Exact class-token rows (optional; amds_vit_weights.exact_host).  What the reference stores per tile is ONE row of the output,
+ * model(tiles)[:, 0].half() (src/stamp/preprocessing/__init__.py:324-325): when this array is given, that row's own chain -- query row,
+ * attention output, proj / fc1 / fc2 rows of every block -- is ALSO computed in exact fp32 (fp32 MFMA, the original un-folded weights,
+ * keys / values of all tokens as the 16-bit path stored them) on a separate fp32 class stream, and written over the class rows of the
+ * main path after every sub-layer.  fp32 device pointers; LayerNorm parameters are the block's ln1_* / ln2_*. */
+typedef struct {
+    const float* q_w;    const float* q_b;     /* [dim][dim], [dim]: the q third of attn.qkv                          */
+    const float* proj_w; const float* proj_b;  /* [dim][dim], [dim]: attn.proj, rows multiplied by ls1 when LayerScale */
+    const float* fc1_w;  const float* fc1_b;   /* [fc1_out][dim] in timm's order, unpadded (SwiGLU: gate rows, then value rows) */
+    const float* fc2_w;  const float* fc2_b;   /* [dim][exact_hidden], [dim]: mlp.fc2, rows multiplied by ls2          */
+} amds_vit_exact_block;
+
 typedef struct {
     const void*  patch_w;    /* [dim][kp] act dtype; conv weight flattened (c,i,j), divided by std[c]; kp = roundup(3*p*p, 64) */
     const float* patch_b;    /* [dim] conv bias - sum_k W[k]*mean[c]/std[c] */
@@ -258,6 +270,8 @@ typedef struct {
      * bf16 keeps the low part in the normal range) and the patch matrix carries the pixel values twice, the second copy scaled by 2^-s
      * (exact): the fp32 accumulator sees W/std to ~22 bits.  0.2 % of the path's flops become 0.4 %. */
     int patch_lo_shift;
+    const amds_vit_exact_block* exact_host;   /* HOST array of `depth` structs, or NULL (off) */
+    int exact_hidden;                         /* the MLP's real (unpadded) hidden width, e.g. 3416 for Virchow2 (cfg.hidden is padded) */
 } amds_vit_weights;
 
 /* Workspace bytes for a forward over at most `batch` tiles per internal chunk. */
@@ -288,6 +302,18 @@ int amds_vit_forward_tokens(const amds_vit_cfg* cfg_host, const amds_vit_weights
  * side stream before the call's work is considered complete. */
 int amds_vit_forward_overlapped(amds_ctx* ctx, const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host, const uint8_t* tiles,
                                 void* feats_f16, int B, int chunk, void* ws, size_t ws_bytes, void* stream);
+
+/* Building blocks of the exact class-token path (exposed for tests; amds_vit_forward calls them when exact_host is set).
+ *   amds_attention_cls_f32   out[b][h*hd..] = softmax(q[b][h*hd..] . K_b,h^T / sqrt(hd)) V_b,h in fp32: ONE fp32 query row per (tile, head)
+ *                            against the keys / values of all T <= 288 tokens of that tile as stored in the packed act-dtype qkv tensor
+ *   amds_vit_cls_gather      xc[b][:] = x[b*T][:]
+ *   amds_vit_cls_scatter     x[b*T][:] = xc[b][:]; if xh / rowstat: 16-bit copy of that row and its (rstd, -mean*rstd) (amds_ln_stats_cast's form)
+ *   amds_mlp_act_f32         kind 0: u = gelu_erf(u) over `hidden` columns; kind 1 (SwiGLUPacked): u[:, j] = silu(u[:, j]) * u[:, hidden + j] */
+int amds_attention_cls_f32(const float* q, long ldq, const void* qkv, float* out, long ldo, int B, int T, int H, int head_dim,
+                           int dtype, void* stream);
+int amds_vit_cls_gather(const float* x, float* xc, int B, int T, int D, void* stream);
+int amds_vit_cls_scatter(const float* xc, float* x, void* xh, float* rowstat, int B, int T, int D, float eps, int dtype, void* stream);
+int amds_mlp_act_f32(float* u, long ld, int rows, int hidden, int kind, void* stream);
 
 /* u8 HWC tiles -> im2col patch matrix [B*np][kp] (act dtype, raw 0..255 values, zero padded).
  * Exposed for tests; amds_vit_forward calls it internally. */

@@ -30,10 +30,15 @@ class VitBlock(C.Structure):
         "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_colsum", "fc1_colsum")]
 
 
+class VitExactBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q_w", "q_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p),
                 ("pos_patch", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)),
-                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("patch_lo_shift", C.c_int)]
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("patch_lo_shift", C.c_int),
+                ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int)]
 
 
 class SwinCfg(C.Structure):
@@ -104,6 +109,10 @@ PROTOTYPES = {
     "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amds_attention_cls_f32": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
+    "amds_vit_cls_gather": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "amds_vit_cls_scatter": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "amds_mlp_act_f32": (_i, [_vp, _l, _i, _i, _i, _vp]),
     "amds_tile_normalize_u8": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp]),
     "amds_macenko_normalize_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
     "amds_supertiles_to_tiles_workspace_bytes": (_sz, [_i, _i, _i, _i]),

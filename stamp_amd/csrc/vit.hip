@@ -21,7 +21,7 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
 
 struct VitPlan {
     int np, T, kp, dim, hidden;
-    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, total;
+    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -54,6 +54,13 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     p->off_h2 = o;      o += align256(rows * c->dim * 2);
     p->off_rowpart = o; o += align256(rows * (size_t)(c->dim / 128) * 2 * 4);
     p->off_rowstat = o; o += align256(rows * 2 * 4);
+    // exact class-token path (vit_exact.hip): fp32 class stream, its LayerNorm output, query rows, attention output, MLP hidden rows
+    const size_t cls = (size_t)batch * c->dim * 4;
+    p->off_xc = o; o += align256(cls);
+    p->off_hc = o; o += align256(cls);
+    p->off_qc = o; o += align256(cls);
+    p->off_oc = o; o += align256(cls);
+    p->off_uc = o; o += align256((size_t)batch * 2 * c->hidden * 4);
     p->total = o;
     return AMDS_OK;
 }
@@ -94,6 +101,21 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     }
     if (fold)
         AMDS_REQUIRE(D % 256 == 0 && n_fc1 % 256 == 0, "vit: the LayerNorm-folded path needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", D, n_fc1);
+    // exact class-token rows (vit_exact.hip): an fp32 class stream beside the 16-bit-operand path
+    const amds_vit_exact_block* ex = w->exact_host;
+    const int xh_ = w->exact_hidden, xf1 = c->mlp_kind == 0 ? xh_ : 2 * xh_, hd = D / c->heads;
+    if (ex) {
+        AMDS_REQUIRE(xh_ > 0 && xh_ <= Hd && xh_ % 4 == 0, "vit: exact_hidden=%d must be a multiple of 4 and <= hidden=%d", xh_, Hd);
+        for (int l = 0; l < c->depth; ++l)
+            AMDS_REQUIRE(ex[l].q_w && ex[l].q_b && ex[l].proj_w && ex[l].proj_b && ex[l].fc1_w && ex[l].fc1_b && ex[l].fc2_w && ex[l].fc2_b &&
+                         w->blocks_host[l].ln1_w && w->blocks_host[l].ln1_b && w->blocks_host[l].ln2_w && w->blocks_host[l].ln2_b,
+                         "vit: exact block %d: incomplete weights", l);
+    }
+    float* xc = reinterpret_cast<float*>(ws + pl.off_xc);
+    float* hc = reinterpret_cast<float*>(ws + pl.off_hc);
+    float* qc = reinterpret_cast<float*>(ws + pl.off_qc);
+    float* oc = reinterpret_cast<float*>(ws + pl.off_oc);
+    float* uc = reinterpret_cast<float*>(ws + pl.off_uc);
 
     // patch embedding: im2col (raw 0..255 values) -> GEMM with folded normalisation, + pos-embed
     // (patch_lo_shift > 0: weight and patch matrix in the split [hi | lo] form, K doubled -- include/amdstamp.h)
@@ -143,6 +165,12 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         float* rs = rowstat + 2 * (size_t)r0;
         char *hq = rows16(h, r0, D), *h2q = rows16(h2, r0, D), *qkvq = rows16(qkv, r0, 3 * D), *mlpq = rows16(mlp, r0, Hd);
         const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU;
+        float *xcq = xc + (size_t)q.t0 * D, *hcq = hc + (size_t)q.t0 * D, *qcq = qc + (size_t)q.t0 * D, *ocq = oc + (size_t)q.t0 * D;
+        float* ucq = uc + (size_t)q.t0 * 2 * Hd;
+        auto lin32 = [&](const float* A, int lda, const float* Wt, int K, float* Cm, int ldc, int N, const float* bias, int acc) {
+            return amds_bgemm_f32(A, lda, 0, 0, Wt, K, 0, 0, 1, Cm, ldc, 0, 0, 1, 1, q.nt, N, K, 1.0f, 0.0f, bias, acc, s);
+        };
+        if (ex) AMDS_TRY(amds_vit_cls_gather(xq, xcq, q.nt, T, D, s));
         if (fold) AMDS_TRY(amds_ln_stats_cast(xq, D, n, D, c->ln_eps, hq, D, rs, dt, s));
         for (int l = 0; l < c->depth; ++l) {
             const amds_vit_block& b = w->blocks_host[l];
@@ -157,9 +185,16 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 AMDS_TRY(enc_gemm(hq, D, b.qkv_w, D, n, 3 * D, D, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, s));
             }
             AMDS_TRY(amds_attention_vit_hd(qkvq, hq, q.nt, T, c->heads, D / c->heads, dt, s));
+            if (ex) {      // class stream, attention branch: xc += proj(attention(Wq LN1(xc); K, V of all tokens as stored))
+                AMDS_TRY(amds_layernorm(xcq, D, b.ln1_w, b.ln1_b, hcq, D, q.nt, D, c->ln_eps, AMDS_F32, s));
+                AMDS_TRY(lin32(hcq, D, ex[l].q_w, D, qcq, D, D, ex[l].q_b, 0));
+                AMDS_TRY(amds_attention_cls_f32(qcq, D, qkvq, ocq, D, q.nt, T, c->heads, hd, dt, s));
+                AMDS_TRY(lin32(ocq, D, ex[l].proj_w, D, xcq, D, D, ex[l].proj_b, 1));
+            }
             if (fold) {
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.proj_w, D, n, D, D, dt, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, h2q, rp, nullptr, nullptr, s));
                 AMDS_TRY(amds_ln_rowstat(rp, n, NP, D, c->ln_eps, rs, s));
+                if (ex) AMDS_TRY(amds_vit_cls_scatter(xcq, xq, h2q, rs, q.nt, T, D, c->ln_eps, dt, s));
                 AMDS_TRY(amds_gemm_lnfold(h2q, D, b.fc1_w, D, n, n_fc1, D, dt, epi1, mlpq, Hd, b.fc1_b, nullptr, nullptr, nullptr, rs, b.fc1_colsum, s));
                 if (!last) {
                     AMDS_TRY(amds_gemm_lnfold(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, dt, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, hq, rp, nullptr, nullptr, s));
@@ -169,9 +204,18 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 }
             } else {
                 AMDS_TRY(enc_gemm(hq, D, b.proj_w, D, n, D, D, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, s));
+                if (ex) AMDS_TRY(amds_vit_cls_scatter(xcq, xq, nullptr, nullptr, q.nt, T, D, c->ln_eps, dt, s));
                 AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, hq, D, n, D, c->ln_eps, dt, s));
                 AMDS_TRY(enc_gemm(hq, D, b.fc1_w, D, n, n_fc1, D, epi1, mlpq, Hd, b.fc1_b, nullptr, s));
                 AMDS_TRY(enc_gemm(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, s));
+            }
+            if (ex) {      // class stream, MLP branch: xc += fc2(act(fc1(LN2(xc)))), then over the main path's class rows
+                AMDS_TRY(amds_layernorm(xcq, D, b.ln2_w, b.ln2_b, hcq, D, q.nt, D, c->ln_eps, AMDS_F32, s));
+                AMDS_TRY(lin32(hcq, D, ex[l].fc1_w, D, ucq, xf1, xf1, ex[l].fc1_b, 0));
+                AMDS_TRY(amds_mlp_act_f32(ucq, xf1, q.nt, xh_, c->mlp_kind, s));
+                AMDS_TRY(lin32(ucq, xf1, ex[l].fc2_w, xh_, xcq, D, D, ex[l].fc2_b, 1));
+                const bool copy16 = fold && !last;
+                AMDS_TRY(amds_vit_cls_scatter(xcq, xq, copy16 ? hq : nullptr, copy16 ? rs : nullptr, q.nt, T, D, c->ln_eps, dt, s));
             }
         }
         return AMDS_OK;

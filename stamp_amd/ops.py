@@ -152,6 +152,40 @@ def attention_alibi(qkv: torch.Tensor, coords: torch.Tensor, head_scale: torch.T
     return out
 
 
+def attention_cls_f32(q: torch.Tensor, qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64) -> torch.Tensor:
+    """ONE fp32 query row per tile (q [B, H*head_dim]) against the stored keys / values of all T tokens (packed act-dtype qkv) -> fp32 [B, H*hd]."""
+    _dev(q, qkv)
+    assert q.dtype == torch.float32 and q.is_contiguous() and qkv.is_contiguous() and q.shape == (B, H * head_dim)
+    out = torch.empty(B, H * head_dim, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().amds_attention_cls_f32(_p(q), H * head_dim, _p(qkv), _p(out), H * head_dim, B, T, H, head_dim, act_code(qkv.dtype), _stream()),
+               "attention_cls_f32")
+    return out
+
+
+def vit_cls_gather(x: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    D = x.shape[-1]
+    xc = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_vit_cls_gather(_p(x), _p(xc), B, T, D, _stream()), "vit_cls_gather")
+    return xc
+
+
+def vit_cls_scatter(xc: torch.Tensor, x: torch.Tensor, T: int, eps: float, xh: torch.Tensor | None = None, rowstat: torch.Tensor | None = None) -> None:
+    """x[b*T] = xc[b] (in place); with xh / rowstat also the 16-bit copy of those rows and their (rstd, -mean*rstd)."""
+    _dev(xc, x, xh, rowstat)
+    B, D = xc.shape
+    code = act_code(xh.dtype) if xh is not None else F16
+    _lib.check(_lib.lib().amds_vit_cls_scatter(_p(xc), _p(x), _p(xh), _p(rowstat), B, T, D, eps, code, _stream()), "vit_cls_scatter")
+
+
+def mlp_act_f32(u: torch.Tensor, hidden: int, kind: int) -> None:
+    """in place on fp32 [rows, ld]: kind 0 GELU(erf) over `hidden` columns; kind 1 SwiGLUPacked: u[:, j] = silu(u[:, j]) * u[:, hidden + j]."""
+    _dev(u)
+    assert u.dtype == torch.float32 and u.is_contiguous() and u.dim() == 2
+    _lib.check(_lib.lib().amds_mlp_act_f32(_p(u), u.shape[1], u.shape[0], hidden, kind, _stream()), "mlp_act_f32")
+
+
 def pack_swiglu_rows(w: torch.Tensor) -> torch.Tensor:
     """[2H, cols] fp32 (gate rows then value rows) -> 32-row block-interleaved layout."""
     _dev(w)

@@ -148,7 +148,11 @@ class HipViT(nn.Module):
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
                  act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None,
-                 patch_split: bool | None = None) -> None:
+                 patch_split: bool | None = None, exact: bool = False) -> None:
+        """exact=True (opt-in): the class-token row -- the only row the reference stores, `model(tiles)[:, 0].half()` -- is ALSO carried on
+        an exact-fp32 class stream (fp32 MFMA, the original un-folded fp32 weights: include/amdstamp.h `amds_vit_exact_block`,
+        csrc/vit_exact.hip) and written over the main path's class rows after every sub-layer.  Costs the fp32 weights in HBM (4 bytes per
+        parameter of q / proj / fc1 / fc2) and ~10 % of the throughput; lowers the stored feature's error ~3x."""
         super().__init__()
         if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
             raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
@@ -178,6 +182,7 @@ class HipViT(nn.Module):
         if patch_split is None:
             patch_split = os.environ.get("AMDS_VIT_PATCH_SPLIT", "1") != "0"
         self.patch_lo_shift = (11 if act_dtype == torch.float16 else 8) if patch_split else 0
+        self.exact = bool(exact)
         self._pack(state_dict)
 
     # -- weight packing (one time) ----------------------------------------------------------------
@@ -244,9 +249,21 @@ class HipViT(nn.Module):
 
         Hp = c.hidden_pad
         blocks = (_lib.VitBlock * c.depth)()
+        exact = (_lib.VitExactBlock * c.depth)() if self.exact else None
         for i in range(c.depth):
             g = lambda n: sd[f"blocks.{i}.{n}"]  # noqa: E731
             b = blocks[i]
+            if exact is not None:       # the original fp32 weights; LayerScale multiplied into the rows of proj / fc2 (fp32)
+                e = exact[i]
+                ls1 = g("ls1.gamma").detach().float().to(dev) if c.layerscale else torch.ones(D, device=dev)
+                ls2 = g("ls2.gamma").detach().float().to(dev) if c.layerscale else torch.ones(D, device=dev)
+                f32d = lambda t: t.detach().float().to(dev)  # noqa: E731
+                e.q_w, e.q_b = self._f32(f32d(g("attn.qkv.weight"))[:D]).data_ptr(), self._f32(f32d(g("attn.qkv.bias"))[:D]).data_ptr()
+                e.proj_w = self._f32(f32d(g("attn.proj.weight")) * ls1[:, None]).data_ptr()
+                e.proj_b = self._f32(f32d(g("attn.proj.bias")) * ls1).data_ptr()
+                e.fc1_w, e.fc1_b = self._f32(g("mlp.fc1.weight")).data_ptr(), self._f32(g("mlp.fc1.bias")).data_ptr()
+                e.fc2_w = self._f32(f32d(g("mlp.fc2.weight")) * ls2[:, None]).data_ptr()
+                e.fc2_b = self._f32(f32d(g("mlp.fc2.bias")) * ls2).data_ptr()
             b.ln1_w, b.ln1_b = self._f32(g("norm1.weight")).data_ptr(), self._f32(g("norm1.bias")).data_ptr()
             b.ln2_w, b.ln2_b = self._f32(g("norm2.weight")).data_ptr(), self._f32(g("norm2.bias")).data_ptr()
             if self.ln_fold:
@@ -286,12 +303,13 @@ class HipViT(nn.Module):
                 b.ls1, b.ls2 = self._f32(g("ls1.gamma")).data_ptr(), self._f32(g("ls2.gamma")).data_ptr()
             else:
                 b.ls1 = b.ls2 = None
-        self._blocks = blocks
+        self._blocks, self._exact = blocks, exact
         self._cfg_c = _lib.VitCfg(c.img, c.patch, D, c.depth, c.heads, Hp, P, 1 if c.mlp == "swiglu" else 0,
                                   1 if c.layerscale else 0, ops.act_code(self.act_dtype), c.ln_eps)
         self._w_c = _lib.VitWeights(self.patch_w.data_ptr(), self.patch_b.data_ptr(), self.prefix.data_ptr(),
                                     self.pos_patch.data_ptr(), C.cast(blocks, C.POINTER(_lib.VitBlock)),
-                                    self.norm_w.data_ptr(), self.norm_b.data_ptr(), self.patch_lo_shift)
+                                    self.norm_w.data_ptr(), self.norm_b.data_ptr(), self.patch_lo_shift,
+                                    C.cast(exact, C.POINTER(_lib.VitExactBlock)) if exact is not None else None, c.hidden)
         torch.cuda.synchronize(dev)
 
     # -- forward ----------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/amdstamp.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.amds_version() == 1
+    assert lib.amds_version() == 2          # major * 100 + minor (include/amdstamp.h)
 
 
 def test_ops_refuse_cpu_tensors():
