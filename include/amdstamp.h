@@ -462,6 +462,8 @@ int amds_vary_precision(const void* bits_in, const uint8_t* shifts, void* bits_o
 
 /* Mean over tiles: x [B][T][F] (f16/f32) -> out fp32 [B][F] (reference src/stamp/modeling/models/mlp.py:40-41). */
 int amds_mean_pool(const void* x, float* out, int B, int T, int F, int in_dtype, void* stream);
+/* its gradient: dx fp32 [B][T][F] = dy[B][F] / T (training the MLP / Linear heads on bags, mlp.py:40-41) */
+int amds_mean_pool_bwd(const float* dy, float* dx, int B, int T, int F, void* stream);
 
 /* out[M][N] = (relu?)(x[M][K] w[N][K]^T + bias) in exact fp32 (fp32-input MFMA); MLP / Linear heads, mlp.py:24-33. */
 int amds_linear_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int relu, void* stream);

@@ -83,3 +83,16 @@ def cox_neg_partial_log_likelihood(log_hz, time, event, ties_method="efron", red
         pll = torch.stack(terms)
     loss = -pll
     return (loss.sum() if reduction == "sum" else loss.nanmean()).float()
+
+
+# ---- H15: reference src/stamp/modeling/models/__init__.py:625-659 (`cox_loss`, the slide / patient-level survival objective) ----
+def cox_breslow_slide_loss(scores, times, events):
+    """Breslow negative partial log-likelihood as the reference's slide-level Lit class states it: event i's risk set is every j with
+    time_j >= time_i; mean over the events; a batch without events gives `scores.sum() * 0` (a zero that keeps the graph)."""
+    scores, times, ev = scores.flatten(), times.flatten(), events.bool().flatten()
+    if not ev.any():
+        return scores.sum() * 0.0
+    risk = times[ev][:, None] <= times[None, :]                                   # [events, N]
+    mx = scores.max()
+    lse = torch.log((risk * torch.exp(scores - mx)).sum(dim=1)) + mx
+    return -(scores[ev] - lse).mean()

@@ -41,9 +41,27 @@ __global__ void __launch_bounds__(256) mean_pool_kernel(const TI* __restrict__ x
     out[(long)b * F + f] = s / (float)T;
 }
 
+// gradient of the mean over tiles: dx[b][t][f] = dy[b][f] / T
+__global__ void mean_pool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n, int T, int F) {
+    const float inv = 1.0f / (float)T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long bt = i / F;
+        dx[i] = dy[(bt / T) * F + (i - bt * F)] * inv;
+    }
+}
+
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" int amds_mean_pool_bwd(const float* dy, float* dx, int B, int T, int F, void* stream) {
+    AMDS_REQUIRE(dy && dx && B >= 0 && T > 0 && F > 0, "amds_mean_pool_bwd: bad arguments");
+    if (B == 0) return AMDS_OK;
+    const long n = (long)B * T * F;
+    hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, T, F);
+    AMDS_LAUNCH_CHECK("mean_pool_bwd_kernel");
+    return AMDS_OK;
+}
 
 extern "C" int amds_gather_rows(const void* src, long src_ld, const long* idx, int n_idx, void* dst, long dst_ld, int n_out,
                                 int cols, int in_dtype, int out_dtype, void* stream) {

@@ -6,7 +6,8 @@ HIP logits in, takes d(loss)/d(logits) out of autograd and runs everything with 
 * classification: weighted cross-entropy on float one-hot targets (reference src/stamp/modeling/models/__init__.py:254-258)
 * regression: L1 (`LitBaseRegressor._compute_loss`, :420-422)
 * survival: Cox negative partial log-likelihood with Efron's tie handling (`neg_partial_log_likelihood`, src/stamp/modeling/
-  models/cox.py:107-270, used by `LitTileSurvival.training_step`, models/__init__.py:751-776; targets are [time, event])
+  models/cox.py:107-270, used by `LitTileSurvival.training_step`, models/__init__.py:751-776; targets are [time, event]);
+  slide / patient-level survival uses the Breslow form `cox_loss` (models/__init__.py:625-659, `LitSlideSurvival.training_step` :812-830)
 """
 from __future__ import annotations
 
@@ -60,3 +61,21 @@ def cox_survival_loss(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tenso
     """`LitTileSurvival.training_step` (models/__init__.py:759-766): targets[:, 0] = time, targets[:, 1] = event."""
     y = targets.to(preds.device, torch.float32)
     return neg_partial_log_likelihood(preds.squeeze(-1), y[:, 0], y[:, 1])
+
+
+def cox_breslow_loss(scores: torch.Tensor, times: torch.Tensor, events: torch.Tensor) -> torch.Tensor:
+    """The reference's `cox_loss` (models/__init__.py:625-659): Breslow risk sets {j: time_j >= time_i} per event i, max-shifted
+    log-sum-exp, MEAN over the events; no event in the batch -> `scores.sum() * 0.0` (zero loss that keeps the graph)."""
+    scores, times, ev = scores.flatten(), times.to(scores.device).flatten(), events.to(scores.device).bool().flatten()
+    if not bool(ev.any()):
+        return scores.sum() * 0.0
+    risk = times[ev][:, None] <= times[None, :]
+    mx = scores.max()
+    lse = torch.log((risk * torch.exp(scores - mx)).sum(dim=1)) + mx
+    return -(scores[ev] - lse).mean()
+
+
+def cox_slide_survival_loss(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """`LitSlideSurvival.training_step` (models/__init__.py:812-830): targets[:, 0] = time, targets[:, 1] = event, Breslow."""
+    y = targets.to(preds.device, torch.float32)
+    return cox_breslow_loss(preds, y[:, 0], y[:, 1])

@@ -237,8 +237,90 @@ def vary_precision(data: torch.Tensor, *, min_fraction_bits: int, generator: tor
     return ops.vary_precision(data.contiguous(), shifts)
 
 
+# ---- MLP / Linear heads (reference src/stamp/modeling/models/mlp.py) -- forward AND backward on the HIP path ----------------------------
+# These are the slide / patient-level models (`LitSlide*` / `LitPatient*`, models/__init__.py:778-937): they consume the table of slide
+# embeddings the all-gather collates (stamp_amd.distributed).  Everything is fp32 like the reference: products on the exact-fp32 MFMA
+# (amds_linear_f32 forward; amds_bgemm_f32 for dx = dz W and dW = dz^T x), bias gradients by the deterministic column sum, ReLU and
+# Dropout backward in the library (amds_relu_bwd; the counter-based mask regenerated from its seed, never stored).
+class _LinearF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu: bool):
+        x, w, b = x.detach().float().contiguous(), w.detach().float().contiguous(), b.detach().float().contiguous()
+        y = ops.linear_f32(x, w, b, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from . import train_ops as T
+        from .transmil_core import _mm
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        if ctx.relu:
+            dz = torch.empty_like(dy)
+            _lib.check(_lib.lib().amds_relu_bwd(y.data_ptr(), dy.data_ptr(), dz.data_ptr(), dz.numel(), ops._stream()), "relu_bwd")
+        else:
+            dz = dy
+        dx = _mm(dz[None], w[None], False)[0] if ctx.needs_input_grad[0] else None              # [M, N] [N, K]
+        dw = _mm(dz[None], x[None], False, transa=True)[0] if ctx.needs_input_grad[1] else None    # (dz^T) x, no explicit transpose
+        db = T.colsum(dz) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+class _DropoutF32Fn(torch.autograd.Function):
+    """nn.Dropout(p) in train mode on an fp32 [rows, cols] tensor: keep mask = the library's counter-based function of (seed, site, element);
+    the backward applies the same mask to the gradient."""
+
+    @staticmethod
+    def _apply(x, p, seed, site):
+        from . import _lib
+        y = torch.empty_like(x)
+        rows, cols = x.shape
+        _lib.check(_lib.lib().amds_dropout_cast_bwd(x.data_ptr(), cols, y.data_ptr(), cols, rows, cols, _lib.F32, float(p), int(seed), int(site),
+                                                    ops._stream()), "dropout_f32")
+        return y
+
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int, site: int):
+        ctx.args = (p, seed, site)
+        return _DropoutF32Fn._apply(x.contiguous().float(), p, seed, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _DropoutF32Fn._apply(dy.contiguous().float(), *ctx.args), None, None, None
+
+
+class _MeanPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return ops.mean_pool(x.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        B, Tn, Fd = ctx.shape
+        dx = torch.empty(B, Tn, Fd, dtype=torch.float32, device=dy.device)
+        dy = dy.contiguous().float()
+        _lib.check(_lib.lib().amds_mean_pool_bwd(dy.data_ptr(), dx.data_ptr(), B, Tn, Fd, ops._stream()), "mean_pool_bwd")
+        return dx
+
+
+def _pool_if_bag(x: torch.Tensor) -> torch.Tensor:
+    if x.ndim == 3:
+        return _MeanPoolFn.apply(x)
+    if x.ndim != 2:
+        raise ValueError(f"Expected 2D or 3D input, got {x.shape}")
+    return x
+
+
 class MLP(nn.Module):
-    """reference src/stamp/modeling/models/mlp.py:6-44 (state_dict keys `mlp.{0,3,...}`); eval forward on the HIP path."""
+    """reference src/stamp/modeling/models/mlp.py:6-44 (state_dict keys `mlp.{0,3,...}`): mean over tiles if given bags, then
+    (Linear -> ReLU -> Dropout) x (num_layers - 1) -> Linear.  Differentiable: `loss.backward()` fills `.grad` of every parameter (and of the
+    input if it requires grad) from the library's backward kernels, so any torch optimiser / Lightning trains it.  Train mode draws one
+    dropout seed per forward from torch's CPU generator (`dropout_seed` pins it)."""
 
     def __init__(self, dim_input: int, dim_hidden: int, dim_output: int, num_layers: int, dropout: float):
         super().__init__()
@@ -248,35 +330,42 @@ class MLP(nn.Module):
             d = dim_hidden
         layers.append(nn.Linear(d, dim_output))
         self.mlp = nn.Sequential(*layers)
+        self.dropout_p = float(dropout)
+        self.dropout_seed: int | None = None
 
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training through the HIP MLP head is not implemented")
-        if x.ndim == 3:
-            x = ops.mean_pool(x.contiguous())
-        elif x.ndim != 2:
-            raise ValueError(f"Expected 2D or 3D input, got {x.shape}")
-        x = x.float().contiguous()
+        if not x.is_cuda:
+            raise RuntimeError("stamp_amd.mil.MLP runs on the GPU only (no CPU fallback)")
+        x = _pool_if_bag(x).float()
         lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        drop = self.training and self.dropout_p > 0.0
+        seed = (self.dropout_seed if self.dropout_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())) if drop else 0
         for i, m in enumerate(lin):
-            x = ops.linear_f32(x, m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), relu=i < len(lin) - 1)
+            hidden = i < len(lin) - 1
+            x = _LinearF32Fn.apply(x, m.weight, m.bias, hidden)
+            if hidden and drop:
+                x = _DropoutF32Fn.apply(x, self.dropout_p, seed, i)
         return x
+
+    def dropout_masks(self, rows: int, seed: int) -> list[torch.Tensor]:
+        """The keep masks (bool [rows, dim_hidden]) the train-mode forward draws for `seed`, one per hidden layer (for parity tests)."""
+        from . import train_ops as T
+        lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        dev = lin[0].weight.device
+        return [T.dropout_mask(rows * m.out_features, self.dropout_p, seed, i, dev).view(rows, m.out_features).bool() for i, m in enumerate(lin[:-1])]
 
 
 class Linear(nn.Module):
-    """reference src/stamp/modeling/models/mlp.py:47-62."""
+    """reference src/stamp/modeling/models/mlp.py:47-62; differentiable like `MLP`."""
 
     def __init__(self, dim_input: int, dim_output: int):
         super().__init__()
         self.fc = nn.Linear(dim_input, dim_output)
 
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
-        if x.ndim == 3:
-            x = ops.mean_pool(x.contiguous())
-        elif x.ndim != 2:
-            raise ValueError(f"Expected 2D or 3D input, got {x.shape}")
-        return ops.linear_f32(x.float().contiguous(), self.fc.weight.detach().float().contiguous(),
-                              self.fc.bias.detach().float().contiguous())
+        if not x.is_cuda:
+            raise RuntimeError("stamp_amd.mil.Linear runs on the GPU only (no CPU fallback)")
+        return _LinearF32Fn.apply(_pool_if_bag(x).float(), self.fc.weight, self.fc.bias, False)
 
 
 # ---- TransMIL (reference src/stamp/modeling/models/trans_mil.py:286-326) ------------------------------------------------

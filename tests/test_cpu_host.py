@@ -140,6 +140,98 @@ def test_data_parallel_mil_gradients_equal_single_rank_gloo_world2(tmp_path):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
 
 
+_MLP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["REPO"])
+from oracle import misc
+from stamp_amd import distributed as D
+from stamp_amd.mil import MLP
+ctx = D.init_from_env(prefer_gpu=False)
+n_slides, dim = 11, 24
+counts = [900, 40, 700, 700, 65, 300, 20, 1000, 5, 410, 77]
+
+def embed(i):                                          # stands in for encode_slides_ on this rank's slides: a pure function of the slide
+    g = torch.Generator().manual_seed(1000 + i)
+    return torch.randn(dim, generator=g)
+
+mine = D.shard_slides(counts, ctx.world)[ctx.rank]
+local = torch.stack([embed(i) for i in mine]) if mine else torch.zeros(0, dim)
+table = D.gather_slide_embeddings(ctx, local, torch.tensor(mine, dtype=torch.int64), n_slides)
+single = torch.stack([embed(i) for i in range(n_slides)])          # what ONE rank owning every slide would hold
+assert torch.equal(table, single), (table - single).abs().max()
+seen = torch.zeros(n_slides, dtype=torch.int64)
+seen[torch.tensor(mine, dtype=torch.int64)] = 1
+torch.distributed.all_reduce(seen)
+assert bool((seen == 1).all()), seen                     # every slide id landed in the table exactly once
+
+# the patient-level consumer of the table (LitSlide* / LitPatient* + MLP, models/__init__.py:778-937): one AdamW step on the gathered table.
+# The head's parameter tree is the product's (stamp_amd.mil.MLP); its arithmetic on this CPU-only host is the pinned oracle's.
+torch.manual_seed(5)
+head = MLP(dim_input=dim, dim_hidden=16, dim_output=2, num_layers=3, dropout=0.0)
+opt = torch.optim.AdamW(head.parameters(), lr=1e-2)
+targets = torch.nn.functional.one_hot(torch.arange(n_slides) % 2, 2).float()
+
+def step(x):
+    opt.zero_grad()
+    sd = dict(head.state_dict(keep_vars=True))
+    loss = torch.nn.functional.cross_entropy(misc.mlp_forward(x, sd, 3), targets)
+    loss.backward()
+    opt.step()
+    return loss.detach()
+
+loss = step(table)
+flat = torch.cat([p.detach().reshape(-1) for p in head.parameters()])
+ref = [torch.zeros_like(flat) for _ in range(ctx.world)]
+torch.distributed.all_gather(ref, flat)
+assert all(torch.equal(r, flat) for r in ref)           # identical weights on every rank after the step
+
+torch.manual_seed(5)                                   # and identical to a single-rank run on the single-rank table
+head1 = MLP(dim_input=dim, dim_hidden=16, dim_output=2, num_layers=3, dropout=0.0)
+opt1 = torch.optim.AdamW(head1.parameters(), lr=1e-2)
+opt1.zero_grad()
+l1 = torch.nn.functional.cross_entropy(misc.mlp_forward(single, dict(head1.state_dict(keep_vars=True)), 3), targets)
+l1.backward()
+opt1.step()
+assert torch.equal(torch.cat([p.detach().reshape(-1) for p in head1.parameters()]), flat) and l1.item() == loss.item()
+D.barrier(ctx)
+print("rank", ctx.rank, "ok")
+"""
+
+
+def test_shard_encode_gather_then_one_mlp_step_gloo_world2(tmp_path):
+    """SURVEY.md 8e end to end on two gloo ranks: LPT shard -> per-rank slide embeddings -> ONE padded all-gather -> the table every rank
+    trains the patient-level MLP head on.  The table equals the single-rank one, every slide id lands exactly once, and one optimiser step
+    leaves identical weights on both ranks and on a single-rank run."""
+    script = tmp_path / "mlp.py"
+    script.write_text(_MLP_WORKER)
+    env = dict(os.environ, REPO=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_bench_multi_rank_branch_dry_run_gloo_world2():
+    """`bench.py --gpus 2` launched exactly as the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1 rendezvous), on
+    CPU ranks over gloo with AMDS_BENCH_DRYRUN=1: the N > 1 branch (all-gather of slide embeddings every step, barrier, max over ranks,
+    rank 0 prints ONE JSON line) runs to completion and every rank's slide lands in the gathered table."""
+    import json
+    env = dict(os.environ, AMDS_BENCH_DRYRUN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29623",
+           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["dry_run"] is True and line["value"] is None
+    assert line["scaling"] == "weak" and line["metric"].startswith("tiles/sec encoded")
+    # a wrong --gpus is refused before any work
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120, cwd=str(ROOT))
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stdout + r2.stderr)
+
+
 def test_gather_single_rank():
     from stamp_amd.distributed import DistCtx, gather_slide_embeddings
 

@@ -8,6 +8,11 @@ from stamp_amd.mil import VisionTransformer
 pytestmark = pytest.mark.gpu
 
 
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
 @pytest.mark.parametrize("Bb,T,F,C", [(2, 1024, 1024, 2), (3, 77, 768, 3), (1, 3000, 1024, 2), (2, 1, 512, 4)])
 def test_mil_vit_forward_matches_oracle(gpu, Bb, T, F, C):
     torch.manual_seed(Bb * 1000 + T)
@@ -113,6 +118,85 @@ def test_mlp_linear_heads_match_reference_golden(gpu):
             np.testing.assert_allclose(lin(x).cpu().numpy(), z[f"lin_y{key}"], rtol=1e-5, atol=1e-6)
         with pytest.raises(ValueError):
             m(torch.zeros(2, device=gpu))
+
+
+@pytest.mark.parametrize("shape", ["slide_table", "bags", "odd"])
+def test_mlp_linear_heads_train_like_torch(gpu, shape):
+    """H14 training (reference mlp.py:6-62 under LitSlide* / LitPatient* / LitTile*, models/__init__.py:778-937): `loss.backward()` through the
+    HIP heads fills the same gradients torch autograd computes for the reference module on the same fp32 inputs -- every parameter, and
+    the input (through the mean over tiles when bags are given) -- and one AdamW step leaves the same weights.  Shapes: a table of slide
+    embeddings (1000 x 768 -> 256 -> 2, configs[3]'s consumer), bags [B, T, F], and dimensions that are multiples of nothing."""
+    from stamp_amd.mil import MLP, Linear
+    torch.manual_seed(31)
+    if shape == "slide_table":
+        x0, kw = torch.randn(1000, 768), dict(dim_input=768, dim_hidden=256, dim_output=2, num_layers=3)
+    elif shape == "bags":
+        x0, kw = torch.randn(16, 77, 512).half().float(), dict(dim_input=512, dim_hidden=128, dim_output=4, num_layers=2)
+    else:
+        x0, kw = torch.randn(13, 37), dict(dim_input=37, dim_hidden=29, dim_output=3, num_layers=4)
+    C = kw["dim_output"]
+    targets = torch.nn.functional.one_hot(torch.arange(x0.shape[0]) % C, C).float().to(gpu)
+    hip = MLP(dropout=0.0, **kw).to(gpu).train()
+    ref = torch.nn.Sequential(*[type(m)(m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else type(m)() for m in hip.mlp
+                                if not isinstance(m, torch.nn.Dropout)]).to(gpu)
+    ref.load_state_dict({f"{i}.{n}": p.detach().clone() for i, k in enumerate(j for j, m in enumerate(hip.mlp) if not isinstance(m, torch.nn.Dropout))
+                         for n, p in hip.mlp[k].named_parameters()})
+    xa, xb = x0.to(gpu).requires_grad_(True), x0.to(gpu).requires_grad_(True)
+    ya = hip(xa)
+    yb = ref(xb.mean(1) if xb.dim() == 3 else xb)
+    assert _rel(ya, yb) < 1e-5
+    torch.nn.functional.cross_entropy(ya, targets).backward()
+    torch.nn.functional.cross_entropy(yb, targets).backward()
+    ga = [p.grad for p in hip.parameters()]
+    gb = [p.grad for p in ref.parameters()]
+    assert len(ga) == len(gb) and all(g is not None and g.shape == r.shape for g, r in zip(ga, gb))
+    for g, r in zip(ga, gb):
+        assert _rel(g, r) < 2e-5, (g.shape, _rel(g, r))
+    assert xa.grad.shape == x0.shape and _rel(xa.grad, xb.grad) < 2e-5
+    oa, ob = torch.optim.AdamW(hip.parameters(), lr=1e-2), torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    oa.step(); ob.step()
+    for p, r in zip(hip.parameters(), ref.parameters()):
+        assert _rel(p, r) < 1e-5
+    # Linear head
+    lin = Linear(dim_input=kw["dim_input"], dim_output=C).to(gpu).train()
+    rl = torch.nn.Linear(kw["dim_input"], C).to(gpu)
+    rl.load_state_dict(lin.fc.state_dict())
+    xa2, xb2 = x0.to(gpu).requires_grad_(True), x0.to(gpu).requires_grad_(True)
+    torch.nn.functional.cross_entropy(lin(xa2), targets).backward()
+    torch.nn.functional.cross_entropy(rl(xb2.mean(1) if xb2.dim() == 3 else xb2), targets).backward()
+    assert _rel(lin.fc.weight.grad, rl.weight.grad) < 2e-5 and _rel(lin.fc.bias.grad, rl.bias.grad) < 2e-5 and _rel(xa2.grad, xb2.grad) < 2e-5
+
+
+def test_mlp_head_dropout_is_the_references_placement(gpu):
+    """Train mode: Dropout(p) after every hidden ReLU (mlp.py:27-30), none after the last Linear.  With the keep masks the library drew
+    (exported by `dropout_masks`) applied to a torch copy, output and gradients agree; eval mode has no dropout; seeds differ -> outputs differ;
+    the realised drop rate is p."""
+    from stamp_amd.mil import MLP
+    torch.manual_seed(8)
+    hip = MLP(dim_input=96, dim_hidden=512, dim_output=2, num_layers=3, dropout=0.25).to(gpu).train()
+    x = torch.randn(200, 96, device=gpu)
+    hip.dropout_seed = 4242
+    y = hip(x)
+    masks = hip.dropout_masks(200, 4242)
+    assert len(masks) == 2 and abs(1.0 - masks[0].float().mean().item() - 0.25) < 0.01
+    lins = [m for m in hip.mlp if isinstance(m, torch.nn.Linear)]
+    params = [(m.weight.detach().clone().requires_grad_(True), m.bias.detach().clone().requires_grad_(True)) for m in lins]
+    h = x
+    for i, (w, b) in enumerate(params):
+        h = torch.nn.functional.linear(h, w, b)
+        if i < 2:
+            h = torch.relu(h) * masks[i].float() / 0.75
+    assert _rel(y, h) < 1e-5
+    y.square().mean().backward()
+    h.square().mean().backward()
+    for m, (w, b) in zip(lins, params):
+        assert _rel(m.weight.grad, w.grad) < 2e-5 and _rel(m.bias.grad, b.grad) < 2e-5
+    hip.dropout_seed = 4243
+    assert not torch.equal(hip(x), y)
+    hip.eval()
+    with torch.no_grad():
+        e1, e2 = hip(x), hip(x)
+    assert torch.equal(e1, e2) and not torch.equal(e1, y.detach())
 
 
 @pytest.mark.parametrize("Bb,T", [(2, 1024), (1, 333)])

@@ -291,9 +291,9 @@ def test_training_step_with_dropout_matches_oracle_given_the_same_masks(gpu, ali
 def test_bench_size_training_step_matches_autograd(gpu, alibi):
     """BASELINE.json configs[2] geometry: bags of 1024 tiles x 1024-d, dim_model 512, 8 heads, feed-forward 512, 2 layers, split-K 32
     (the bench's settings; batch 4 so that the fp64 oracle finishes in seconds).  Loss, logits and EVERY parameter gradient against
-    fp64 autograd through the pinned oracle.  Stated bars (bf16 MFMA operands): loss / logits 1e-2, each gradient <= 3e-2 relative
-    L2 (<= 5e-2 with ALiBi; the per-layer vector of the 8 scalar bias_scale gradients <= 0.12 -- single heads whose true gradient
-    nearly cancels can be off by more; q/k encoders measured against 5 % of the sibling value-encoder gradient)."""
+    fp64 autograd through the pinned oracle.  Stated bars (bf16 MFMA operands): loss / logits 1e-2, each gradient <= 1.5e-2 relative
+    L2 with and without ALiBi (measured <= 5.8e-3); the per-layer vector of the 8 scalar bias_scale gradients <= 2e-2 (measured 5.6e-3;
+    q/k encoders measured against 5 % of the sibling value-encoder gradient)."""
     torch.manual_seed(21)
     Bb, Tn, Fd, C, H = 4, 1024, 1024, 2, 8
     model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=512, n_layers=2, n_heads=H, dim_feedforward=512, dropout=0.0, use_alibi=alibi)
@@ -340,8 +340,76 @@ def test_bench_size_training_step_matches_autograd(gpu, alibi):
     report.sort(reverse=True)
     print(f"bench-size step, alibi={alibi}: largest gradient errors", [(round(a, 4), b) for a, b in report[:6]])
     for rel, k in report:
-        bar = 0.12 if k.endswith("bias_scale") else (5e-2 if alibi else 3e-2)
+        bar = 2e-2 if k.endswith("bias_scale") else 1.5e-2          # measured on the MI355X: <= 5.8e-3 without, <= 5.6e-3 with ALiBi
         assert rel < bar, (k, rel)
+
+
+@pytest.mark.parametrize("level", ["tile", "slide"])
+def test_survival_head_at_bag_scale_matches_autograd(gpu, level):
+    """BASELINE.json configs[4], the part whose arithmetic is in the repository: a Cox-survival MIL head at bag scale -- `vit` head with
+    dim_output = 1 on bags of 1024 tiles x 768-d (the width of the CONCH1.5 / TITAN features, titan.py:38-61), targets drawn as
+    tests/random_data.py:173-175 draws them (times U(30, 2000), events Bernoulli(0.7)).  `tile`: LitTileSurvival's Efron partial likelihood
+    (cox.py:107-270 via models/__init__.py:751-776); `slide`: the Breslow `cox_loss` of the slide / patient-level class (:625-659).  Risk
+    scores, loss and EVERY parameter gradient against fp64 autograd through the pinned oracle.  Stated bars (bf16 MFMA operands): scores /
+    loss 1e-2; weight matrices 3e-2 relative L2 (measured <= 1.2e-2); vectors (biases, LayerNorm parameters, class token) 8e-2 (measured
+    <= 6.3e-2): the Cox gradient w.r.t. the scores sums to ZERO over the batch, so every gradient that adds the same row pattern over all
+    bags -- the bias-type ones -- is a cancelling sum, and the two that shift all scores alike (head bias, final LayerNorm bias) are exactly 0."""
+    from stamp_amd import losses
+    torch.manual_seed(51)
+    Bb, Tn, Fd, H = 8, 1024, 768, 8
+    model = VisionTransformer(dim_output=1, dim_input=Fd, dim_model=512, n_layers=2, n_heads=H, dim_feedforward=512, dropout=0.0, use_alibi=False)
+    _perturb(model)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    # every bag carries its own component (as slides of different patients do).  With i.i.d. bags the class-token rows of all bags are
+    # nearly identical and -- the Cox gradient w.r.t. the scores summing to zero over the batch -- every weight gradient becomes a
+    # cancelling sum whose value is ~3 % of its terms: that measures the test data, not the kernels (bf16 terms then show 10-30 %)
+    bags = (torch.randn(Bb, Tn, Fd) + 0.7 * torch.randn(Bb, 1, Fd)).half()
+    times = torch.rand(Bb) * 1970 + 30
+    times[5] = times[2]                                               # a tie (Efron and Breslow differ there)
+    events = torch.tensor([1.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 1.0])
+    targets = torch.stack([times, events], 1)
+    fn = losses.cox_survival_loss if level == "tile" else losses.cox_slide_survival_loss
+    tr = HipMilVitTrainer(model, device=gpu, split_k=32, dropout=False)
+    loss, scores = tr.step(bags.to(gpu), targets, update=False, loss_fn=fn)
+    assert scores.shape == (Bb, 1)
+    params = {k: v.clone().double().requires_grad_(True) for k, v in sd0.items()}
+    ref = mil_vit_forward(bags.double(), torch.zeros(Bb, Tn, 2).double(), None, params, n_heads=H, use_alibi=False, dtype=torch.float64)
+    if level == "tile":
+        from oracle.misc import cox_neg_partial_log_likelihood
+        # the oracle's Efron form returns float32 of a float64 evaluation: differentiate the product's torch restatement in fp64 instead and
+        # pin ITS value to the oracle's
+        ref_loss = losses.neg_partial_log_likelihood(ref.squeeze(-1), times.double(), events)
+        assert abs(ref_loss.item() - cox_neg_partial_log_likelihood(ref.detach().squeeze(-1), times.double(), events.bool()).item()) < 1e-5
+    else:
+        from oracle.misc import cox_breslow_slide_loss
+        ref_loss = cox_breslow_slide_loss(ref, times.double(), events)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-2 * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    assert (scores.cpu().double() - ref.detach()).abs().max() < 1e-2 * max(1.0, ref.abs().max().item())
+    report = []
+    for k in tr.names:
+        g, r = tr.g(k).cpu().double(), params[k].grad.double()
+        if k.endswith("in_proj_bias"):
+            g, r = torch.cat([g[:512], g[1024:]]), torch.cat([r[:512], r[1024:]])
+        if k in ("mlp_head.0.bias", "transformer.norm.bias"):
+            # the partial likelihood is invariant to a common shift of the scores (sum_b dloss/dscore_b = 0), so the TRUE gradient of
+            # everything that shifts all scores alike is 0 (autograd: 1e-17); hold the bf16 path to "small against the sibling weight gradient"
+            sib = params[k.replace("bias", "weight")].grad.double().norm().item()
+            assert r.norm() < 1e-9 * max(sib, 1e-30) and g.norm() < 3e-2 * sib, (k, g.norm().item(), sib)
+            continue
+        report.append((_rel(g, r), k))
+    report.sort(reverse=True)
+    print(f"survival head ({level}) at 8 x 1024 x 768: largest gradient errors", [(round(a, 4), b) for a, b in report[:14]])
+    for rel, k in report:
+        assert rel < (3e-2 if sd0[k].dim() >= 2 else 8e-2), (k, rel)
+    l0 = tr.step(bags.to(gpu), targets, loss_fn=fn)[0].item()
+    for _ in range(10):
+        l1 = tr.step(bags.to(gpu), targets, loss_fn=fn)[0].item()
+    assert l1 < l0
+    # a batch without events: the reference returns a constant zero (no step is taken, nothing explodes)
+    P0 = tr.P.clone()
+    lz, _ = tr.step(bags.to(gpu), torch.stack([times, torch.zeros(Bb)], 1), loss_fn=fn)
+    assert lz.item() == 0.0 and (level == "slide" or torch.equal(tr.P, P0))
 
 
 def test_config0_shape_training_step(gpu):

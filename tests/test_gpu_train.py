@@ -295,7 +295,7 @@ def test_mil_vit_alibi_training_step_matches_autograd(gpu):
     print("largest gradient errors with ALiBi (bf16 operands):", [(round(a, 4), b, float(f"{c:.2e}")) for a, b, c in report[:8]])
     for rel, k, rn in report:
         # bias_scale is a scalar: its gradient is a signed sum over (in the last layer) only the class-token rows
-        assert rel < (0.12 if k.endswith("bias_scale") else 6e-2), (k, rel, rn)
+        assert rel < (5e-2 if k.endswith("bias_scale") else 2e-2), (k, rel, rn)      # measured: 1.8e-2 (one head's scalar) / 8.2e-3
     losses = []
     for i in range(8):
         losses.append(tr.step(bags.to(gpu), targets, weights, coords=coords.to(gpu))[0].item())

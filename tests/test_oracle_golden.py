@@ -88,6 +88,25 @@ def test_cox_known_answers_and_golden():
     assert abs(misc.cox_neg_partial_log_likelihood(lh, torch.arange(40.0), ev).item() - float(z["notie"])) < 1e-5
 
 
+def test_cox_breslow_slide_loss_golden():
+    """Slide / patient-level survival objective (`cox_loss`, models/__init__.py:625-659): the oracle's restatement AND the product's
+    torch loss (stamp_amd.losses, K14: a few hundred scalars stay torch) against the reference function's value and gradient."""
+    from stamp_amd import losses
+    z = np.load(G / "cox_slide.npz")
+    times, events = torch.from_numpy(z["times"]), torch.from_numpy(z["events"])
+    for fn in (misc.cox_breslow_slide_loss, losses.cox_breslow_loss):
+        sc = torch.from_numpy(z["scores"]).clone().requires_grad_(True)
+        loss = fn(sc, times, events)
+        assert abs(loss.item() - float(z["loss"])) < 1e-6
+        g, = torch.autograd.grad(loss, sc)
+        np.testing.assert_allclose(g.numpy(), z["grad"], rtol=1e-5, atol=1e-8)
+        s0 = torch.randn(5, requires_grad=True)
+        l0 = fn(s0, torch.arange(5.0), torch.zeros(5))
+        assert l0.item() == 0.0 and l0.requires_grad == bool(z["no_event_requires_grad"])
+    tg = torch.stack([times, events], 1)
+    assert abs(losses.cox_slide_survival_loss(torch.from_numpy(z["scores"]), tg).item() - float(z["loss"])) < 1e-6
+
+
 @pytest.mark.parametrize("name,tdt", [("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)])
 def test_vary_precision_bit_exact(name, tdt):
     z = np.load(G / "vary_precision.npz")

@@ -88,6 +88,20 @@ def exec_defs(path: Path, names: set[str], glb: dict) -> dict:
     return glb
 
 
+def exec_method(path: Path, method: str, glb: dict):
+    """exec ONE method of a class of a reference file as a plain function (decorators dropped): for static methods of classes whose
+    module cannot be imported here (lightning)."""
+    tree = ast.parse(path.read_text())
+    for cls in tree.body:
+        if isinstance(cls, ast.ClassDef):
+            for fn in cls.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == method:
+                    fn.decorator_list = []
+                    exec(compile(ast.Module(body=[fn], type_ignores=[]), str(path), "exec"), glb)
+                    return glb[method]
+    raise AssertionError(f"{method} not found in {path}")
+
+
 def sd_np(module: torch.nn.Module, prefix: str = "w:") -> dict[str, np.ndarray]:
     return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}      # copy: buffers are updated in place later
 
@@ -251,6 +265,19 @@ def golden_mlp_cox_transforms() -> None:
          breslow=np.array(cox.neg_partial_log_likelihood(lh, tt, ev, ties_method="breslow").item()),
          notie=np.array(cox.neg_partial_log_likelihood(lh, torch.arange(40.0), ev).item()),
          **{k: np.array(v) for k, v in cases.items()})
+    # the slide / patient-level survival objective: Breslow `cox_loss`, a static method of the Lit class (models/__init__.py:625-659)
+    cox_loss = exec_method(REF / "modeling" / "models" / "__init__.py", "cox_loss", {"torch": torch})
+    torch.manual_seed(6)
+    sc = torch.randn(64, 1, requires_grad=True)
+    tm_ = torch.randint(30, 2000, (64,)).float()
+    tm_[10:14] = tm_[9]                                  # a few ties
+    evn = (torch.rand(64) < 0.7).float()
+    l_ = cox_loss(sc, tm_, evn)
+    g_, = torch.autograd.grad(l_, sc)
+    sc0 = torch.randn(5, requires_grad=True)
+    l0 = cox_loss(sc0, torch.arange(5.0), torch.zeros(5))           # no events: `scores.sum() * 0.0` (keeps the graph)
+    save("cox_slide.npz", scores=sc.detach().numpy(), times=tm_.numpy(), events=evn.numpy(), loss=np.array(l_.item()), grad=g_.numpy(),
+         loss_no_event=np.array(l0.item()), no_event_requires_grad=np.array(bool(l0.requires_grad)))
     tr = load_by_path("stamp.modeling.transforms", REF / "modeling" / "transforms.py")
     out = {}
     for dt, name in ((torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")):
