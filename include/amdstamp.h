@@ -274,6 +274,49 @@ typedef struct {
     int exact_hidden;                         /* the MLP's real (unpadded) hidden width, e.g. 3416 for Virchow2 (cfg.hidden is padded) */
 } amds_vit_weights;
 
+/* ---- weight packing in the library (so that a non-Python host can use the tile encoder through this ABI alone) -------------------------
+ * A timm VisionTransformer checkpoint as HOST fp32 tensors, row-major exactly as the state_dict stores them -- what the reference's
+ * extractor factories hand to load_state_dict (src/stamp/preprocessing/extractor/uni2.py:32-43, virchow2.py:34-45, h_optimus_0.py:15-30,
+ * reddino.py:40-57): keys blocks.{l}.norm1 / attn.qkv / attn.proj / ls1.gamma / norm2 / mlp.fc1 / mlp.fc2 / ls2.gamma. */
+typedef struct {
+    const float* norm1_w; const float* norm1_b;   /* [dim] */
+    const float* qkv_w;   const float* qkv_b;     /* [3*dim][dim], [3*dim] (q | k | v thirds) */
+    const float* proj_w;  const float* proj_b;    /* [dim][dim], [dim] */
+    const float* ls1;                             /* [dim] or NULL (no LayerScale) */
+    const float* norm2_w; const float* norm2_b;
+    const float* fc1_w;   const float* fc1_b;     /* GELU: [hidden][dim]; SwiGLUPacked: [2*hidden][dim], gate rows then value rows */
+    const float* fc2_w;   const float* fc2_b;     /* [dim][hidden], [dim] */
+    const float* ls2;
+} amds_vit_host_block;
+typedef struct {
+    const float* patch_w;    /* patch_embed.proj.weight [dim][3][patch][patch] */
+    const float* patch_b;    /* [dim] */
+    const float* cls_token;  /* [dim] */
+    const float* reg_token;  /* [n_prefix-1][dim] or NULL */
+    const float* pos_embed;  /* [n_patches + (no_embed_class ? 0 : n_prefix)][dim] */
+    const amds_vit_host_block* blocks;   /* depth structs */
+    const float* norm_w; const float* norm_b;
+    int hidden;              /* the MLP's real hidden width (cfg.hidden is its 64-padded value) */
+    int no_embed_class;      /* timm's flag: 1 = position rows cover the patches only */
+    double mean[3]; double std[3];       /* the extractor's Normalize (folded into the patch embedding, in double) */
+} amds_vit_host_weights;
+#define AMDS_PACK_LNFOLD      1   /* LayerNorm folded into qkv / fc1 (amds_gemm_lnfold): W * gamma, b + W beta, row sums */
+#define AMDS_PACK_PATCH_SPLIT 2   /* patch weight as a 16-bit [hi | lo] pair (patch_lo_shift) */
+#define AMDS_PACK_EXACT       4   /* also the fp32 rows of the exact class-token path (amds_vit_exact_block) */
+/* Bytes of the packed image for these flags (0 on error: amds_last_error()). */
+size_t amds_vit_pack_bytes(const amds_vit_cfg* cfg_host, const amds_vit_host_weights* src_host, int flags);
+/* Packs into the DEVICE buffer dev_image (>= amds_vit_pack_bytes, 256-byte aligned) and fills the caller's host structs -- out_w, out_blocks
+ * [depth], out_exact [depth] (may be NULL without AMDS_PACK_EXACT) -- with pointers into it; they stay valid while dev_image lives and are what
+ * amds_vit_forward takes.  Arithmetic on the host in double (threads over blocks; AMDS_PACK_THREADS overrides the count), one upload; the
+ * call waits for the upload (a one-time call: the exception to "no synchronisation"). */
+int amds_vit_pack(const amds_vit_cfg* cfg_host, const amds_vit_host_weights* src_host, int flags, void* dev_image, size_t bytes,
+                  amds_vit_weights* out_w_host, amds_vit_block* out_blocks_host, amds_vit_exact_block* out_exact_host, void* stream);
+/* The same image into HOST memory (for hosts that manage their own uploads, and for tests without a GPU): pointers in the out structs are
+ * target_base + offset (target_base NULL: image_host itself). */
+int amds_vit_pack_host(const amds_vit_cfg* cfg_host, const amds_vit_host_weights* src_host, int flags, void* image_host, size_t bytes,
+                       const void* target_base, amds_vit_weights* out_w_host, amds_vit_block* out_blocks_host,
+                       amds_vit_exact_block* out_exact_host);
+
 /* Workspace bytes for a forward over at most `batch` tiles per internal chunk. */
 size_t amds_vit_workspace_bytes(const amds_vit_cfg* cfg_host, int batch);
 

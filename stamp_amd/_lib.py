@@ -41,6 +41,20 @@ class VitWeights(C.Structure):
                 ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int)]
 
 
+class VitHostBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "norm2_w", "norm2_b",
+                                          "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitHostWeights(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls_token", C.c_void_p), ("reg_token", C.c_void_p), ("pos_embed", C.c_void_p),
+                ("blocks", C.POINTER(VitHostBlock)), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("hidden", C.c_int), ("no_embed_class", C.c_int),
+                ("mean", C.c_double * 3), ("std", C.c_double * 3)]
+
+
+PACK_LNFOLD, PACK_PATCH_SPLIT, PACK_EXACT = 1, 2, 4
+
+
 class SwinCfg(C.Structure):
     _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
                 ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
@@ -109,6 +123,9 @@ PROTOTYPES = {
     "amds_tile_edge_fraction_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_tile_im2col_u8_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amds_vit_pack_bytes": (_sz, [_vp, _vp, _i]),
+    "amds_vit_pack": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "amds_vit_pack_host": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amds_attention_cls_f32": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "amds_vit_cls_gather": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "amds_vit_cls_scatter": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),

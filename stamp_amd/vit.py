@@ -143,6 +143,29 @@ def packed_weight_bytes(cfg: ViTConfig) -> int:
     return 2 * (D * cfg.kp + cfg.depth * (3 * D * D + D * D + fc1 * D + D * cfg.hidden_pad))
 
 
+def host_weights(cfg: ViTConfig, sd: dict[str, torch.Tensor]):
+    """(amds_vit_host_weights, keep-alive list): the checkpoint as contiguous host fp32 tensors, addressed by pointer."""
+    keep: list[torch.Tensor] = []
+
+    def ptr(key: str):
+        t = sd[key].detach().to("cpu", torch.float32).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    blocks = (_lib.VitHostBlock * cfg.depth)()
+    for i in range(cfg.depth):
+        b, pre = blocks[i], f"blocks.{i}."
+        b.norm1_w, b.norm1_b, b.norm2_w, b.norm2_b = ptr(pre + "norm1.weight"), ptr(pre + "norm1.bias"), ptr(pre + "norm2.weight"), ptr(pre + "norm2.bias")
+        b.qkv_w, b.qkv_b, b.proj_w, b.proj_b = ptr(pre + "attn.qkv.weight"), ptr(pre + "attn.qkv.bias"), ptr(pre + "attn.proj.weight"), ptr(pre + "attn.proj.bias")
+        b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b = ptr(pre + "mlp.fc1.weight"), ptr(pre + "mlp.fc1.bias"), ptr(pre + "mlp.fc2.weight"), ptr(pre + "mlp.fc2.bias")
+        b.ls1, b.ls2 = (ptr(pre + "ls1.gamma"), ptr(pre + "ls2.gamma")) if cfg.layerscale else (None, None)
+    keep.append(blocks)
+    hw = _lib.VitHostWeights(ptr("patch_embed.proj.weight"), ptr("patch_embed.proj.bias"), ptr("cls_token"), ptr("reg_token") if cfg.reg_tokens else None,
+                             ptr("pos_embed"), C.cast(blocks, C.POINTER(_lib.VitHostBlock)), ptr("norm.weight"), ptr("norm.bias"), cfg.hidden,
+                             1 if cfg.no_embed_class else 0, (C.c_double * 3)(*cfg.mean), (C.c_double * 3)(*cfg.std))
+    return hw, keep
+
+
 class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
@@ -165,7 +188,6 @@ class HipViT(nn.Module):
             raise RuntimeError("HipViT runs on the GPU only (no CPU fallback)")
         _lib.lib()  # fail early and loudly if the extension is missing
         _lib.ctx(self.device_.index if self.device_.index is not None else torch.cuda.current_device())   # side stream of the ragged-tail schedule
-        self._keep: list[torch.Tensor] = []
         self._ws: torch.Tensor | None = None
         # LayerNorm folded into the qkv / fc1 GEMMs (include/amdstamp.h, amds_gemm_lnfold): default on where the shapes allow it
         # (every preset); AMDS_VIT_LNFOLD=0 or ln_fold=False packs the plain weights and runs the stand-alone LayerNorm kernels (A/B).
@@ -185,132 +207,29 @@ class HipViT(nn.Module):
         self.exact = bool(exact)
         self._pack(state_dict)
 
-    # -- weight packing (one time) ----------------------------------------------------------------
-    def _f32(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.detach().to(self.device_, torch.float32).contiguous()
-        self._keep.append(t)
-        return t
-
-    def _act(self, w: torch.Tensor, ld: int | None = None, rows: int | None = None) -> torch.Tensor:
-        w = w.detach().to(self.device_, torch.float32)
-        w = w.reshape(w.shape[0], -1)
-        if rows is not None and rows > w.shape[0]:
-            w = torch.cat([w, w.new_zeros(rows - w.shape[0], w.shape[1])])
-        out = ops.cast_pad(w, ld or w.shape[1], self.act_dtype)
-        self._keep.append(out)
-        return out
-
-    def _folded(self, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
-        """Linear(LayerNorm(x)) with the LayerNorm's affine part moved into the Linear: (W * gamma rounded to the act dtype, b + W beta,
-        row sums of the ROUNDED W * gamma) -- the row sums must describe the weights the MFMAs actually see."""
-        gamma, beta = gamma.detach().to(self.device_, torch.float64), beta.detach().to(self.device_, torch.float64)
-        w64 = w.detach().to(self.device_, torch.float64)
-        wf = ops.cast_pad((w64 * gamma[None, :]).float().contiguous(), w.shape[1], self.act_dtype)
-        bf = (b.detach().to(self.device_, torch.float64) + w64 @ beta).float()
-        return wf, bf, wf.double().sum(1).float()
-
+    # -- weight packing (one time): in the library (amds_vit_pack, csrc/vit_pack.hip) -------------------------------
     def _pack(self, sd: dict[str, torch.Tensor]) -> None:
+        """Hands the checkpoint's tensors to `amds_vit_pack` as host fp32 pointers; every fold / rounding / padding / interleave happens in the
+        library (include/amdstamp.h), so a non-Python host packs exactly the same image."""
         c = self.cfg
         validate_state_dict(c, sd)
-        D, P, np_ = c.dim, c.n_prefix, c.n_patches
-        dev = self.device_
-        mean = torch.tensor(c.mean, dtype=torch.float64)
-        std = torch.tensor(c.std, dtype=torch.float64)
-        # patch embedding with the tile transform folded in:  conv(W, (u8/255-mean)/std) + b
-        #   = (1/255) * sum W/std * u8  +  (b - sum W*mean/std)
-        pw = sd["patch_embed.proj.weight"].detach().double().cpu()           # [D,3,p,p]
-        pb = sd["patch_embed.proj.bias"].detach().double().cpu()
-        pw_f = pw / std.view(1, 3, 1, 1)
-        pb_f = pb - (pw * (mean / std).view(1, 3, 1, 1)).sum(dim=(1, 2, 3))
-        if self.patch_lo_shift:
-            flat = pw_f.reshape(D, -1)
-            hi = flat.float().to(self.act_dtype)
-            lo = ((flat - hi.double()) * 2.0 ** self.patch_lo_shift).float()
-            pad = lambda t: torch.nn.functional.pad(t.float(), (0, c.kp - t.shape[1]))  # noqa: E731
-            self.patch_w = self._act(torch.cat([pad(hi), pad(lo)], dim=1), ld=2 * c.kp)
-        else:
-            self.patch_w = self._act(pw_f.float().reshape(D, -1), ld=c.kp)
-        self.patch_b = self._f32(pb_f.float())
-        pos = sd["pos_embed"].detach().float().reshape(-1, D)
-        toks = [sd["cls_token"].detach().float().reshape(1, D)]
-        if c.reg_tokens:
-            toks.append(sd["reg_token"].detach().float().reshape(c.reg_tokens, D))
-        prefix = torch.cat(toks)
-        if c.no_embed_class:
-            assert pos.shape[0] == np_, f"pos_embed has {pos.shape[0]} rows, expected {np_}"
-            pos_patch = pos
-        else:
-            assert pos.shape[0] == np_ + P, f"pos_embed has {pos.shape[0]} rows, expected {np_ + P}"
-            prefix = prefix + pos[:P]
-            pos_patch = pos[P:]
-        self.prefix = self._f32(prefix)
-        self.pos_patch = self._f32(pos_patch)
-        self.norm_w, self.norm_b = self._f32(sd["norm.weight"]), self._f32(sd["norm.bias"])
-
-        Hp = c.hidden_pad
-        blocks = (_lib.VitBlock * c.depth)()
-        exact = (_lib.VitExactBlock * c.depth)() if self.exact else None
-        for i in range(c.depth):
-            g = lambda n: sd[f"blocks.{i}.{n}"]  # noqa: E731
-            b = blocks[i]
-            if exact is not None:       # the original fp32 weights; LayerScale multiplied into the rows of proj / fc2 (fp32)
-                e = exact[i]
-                ls1 = g("ls1.gamma").detach().float().to(dev) if c.layerscale else torch.ones(D, device=dev)
-                ls2 = g("ls2.gamma").detach().float().to(dev) if c.layerscale else torch.ones(D, device=dev)
-                f32d = lambda t: t.detach().float().to(dev)  # noqa: E731
-                e.q_w, e.q_b = self._f32(f32d(g("attn.qkv.weight"))[:D]).data_ptr(), self._f32(f32d(g("attn.qkv.bias"))[:D]).data_ptr()
-                e.proj_w = self._f32(f32d(g("attn.proj.weight")) * ls1[:, None]).data_ptr()
-                e.proj_b = self._f32(f32d(g("attn.proj.bias")) * ls1).data_ptr()
-                e.fc1_w, e.fc1_b = self._f32(g("mlp.fc1.weight")).data_ptr(), self._f32(g("mlp.fc1.bias")).data_ptr()
-                e.fc2_w = self._f32(f32d(g("mlp.fc2.weight")) * ls2[:, None]).data_ptr()
-                e.fc2_b = self._f32(f32d(g("mlp.fc2.bias")) * ls2).data_ptr()
-            b.ln1_w, b.ln1_b = self._f32(g("norm1.weight")).data_ptr(), self._f32(g("norm1.bias")).data_ptr()
-            b.ln2_w, b.ln2_b = self._f32(g("norm2.weight")).data_ptr(), self._f32(g("norm2.bias")).data_ptr()
-            if self.ln_fold:
-                wq, bq, cq = self._folded(g("attn.qkv.weight"), g("attn.qkv.bias"), g("norm1.weight"), g("norm1.bias"))
-                self._keep.append(wq)
-                b.qkv_w, b.qkv_b, b.qkv_colsum = wq.data_ptr(), self._f32(bq).data_ptr(), self._f32(cq).data_ptr()
-            else:
-                b.qkv_w, b.qkv_b = self._act(g("attn.qkv.weight")).data_ptr(), self._f32(g("attn.qkv.bias")).data_ptr()
-                b.qkv_colsum = None
-            b.proj_w, b.proj_b = self._act(g("attn.proj.weight")).data_ptr(), self._f32(g("attn.proj.bias")).data_ptr()
-            w1, b1 = g("mlp.fc1.weight").detach().float().to(dev), g("mlp.fc1.bias").detach().float().to(dev)
-            w2, b2 = g("mlp.fc2.weight").detach().float().to(dev), g("mlp.fc2.bias").detach().float().to(dev)
-            if c.mlp == "swiglu":
-                H = c.hidden
-                assert w1.shape[0] == 2 * H
-                # zero-pad gate and value halves to Hp units each, then block-interleave in the library
-                w1p = w1.new_zeros(2 * Hp, D)
-                w1p[:H], w1p[Hp:Hp + H] = w1[:H], w1[H:]
-                b1p = b1.new_zeros(2 * Hp)
-                b1p[:H], b1p[Hp:Hp + H] = b1[:H], b1[H:]
-                w1, b1 = w1p, b1p
-            else:
-                assert w1.shape[0] == c.hidden and c.hidden % 128 == 0
-            c1 = None
-            if self.ln_fold:
-                w1, b1, c1 = self._folded(w1, b1, g("norm2.weight"), g("norm2.bias"))       # w1: act dtype from here on
-            if c.mlp == "swiglu":
-                # block-interleave gate / value rows in the library (fp32 round trip of 16-bit values is exact)
-                w1 = ops.pack_swiglu_rows(w1.float())
-                b1 = ops.pack_swiglu_rows(b1.reshape(-1, 1)).reshape(-1)
-                if c1 is not None:
-                    c1 = ops.pack_swiglu_rows(c1.reshape(-1, 1)).reshape(-1)
-            b.fc1_w, b.fc1_b = self._act(w1).data_ptr(), self._f32(b1).data_ptr()
-            b.fc1_colsum = self._f32(c1).data_ptr() if c1 is not None else None
-            b.fc2_w, b.fc2_b = self._act(w2, ld=Hp).data_ptr(), self._f32(b2).data_ptr()
-            if c.layerscale:
-                b.ls1, b.ls2 = self._f32(g("ls1.gamma")).data_ptr(), self._f32(g("ls2.gamma")).data_ptr()
-            else:
-                b.ls1 = b.ls2 = None
-        self._blocks, self._exact = blocks, exact
-        self._cfg_c = _lib.VitCfg(c.img, c.patch, D, c.depth, c.heads, Hp, P, 1 if c.mlp == "swiglu" else 0,
+        hw, keep = host_weights(c, sd)
+        flags = (_lib.PACK_LNFOLD if self.ln_fold else 0) | (_lib.PACK_PATCH_SPLIT if self.patch_lo_shift else 0) | (_lib.PACK_EXACT if self.exact else 0)
+        self._cfg_c = _lib.VitCfg(c.img, c.patch, c.dim, c.depth, c.heads, c.hidden_pad, c.n_prefix, 1 if c.mlp == "swiglu" else 0,
                                   1 if c.layerscale else 0, ops.act_code(self.act_dtype), c.ln_eps)
-        self._w_c = _lib.VitWeights(self.patch_w.data_ptr(), self.patch_b.data_ptr(), self.prefix.data_ptr(),
-                                    self.pos_patch.data_ptr(), C.cast(blocks, C.POINTER(_lib.VitBlock)),
-                                    self.norm_w.data_ptr(), self.norm_b.data_ptr(), self.patch_lo_shift,
-                                    C.cast(exact, C.POINTER(_lib.VitExactBlock)) if exact is not None else None, c.hidden)
-        torch.cuda.synchronize(dev)
+        lib = _lib.lib()
+        need = lib.amds_vit_pack_bytes(C.byref(self._cfg_c), C.byref(hw), flags)
+        if need == 0:
+            _lib.check(-1, "vit_pack_bytes")
+        self._image = torch.empty(need, dtype=torch.uint8, device=self.device_)
+        self._w_c = _lib.VitWeights()
+        self._blocks = (_lib.VitBlock * c.depth)()
+        self._exact = (_lib.VitExactBlock * c.depth)() if self.exact else None
+        with torch.cuda.device(self.device_):
+            rc = lib.amds_vit_pack(C.byref(self._cfg_c), C.byref(hw), flags, self._image.data_ptr(), need, C.byref(self._w_c), self._blocks,
+                                   self._exact, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "vit_pack")
+        del keep
 
     # -- forward ----------------------------------------------------------------------------------
     def _workspace(self, chunk: int) -> torch.Tensor:
