@@ -53,6 +53,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (for a ViT-only rocprofv3 kernel trace)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--e2e-tiles", type=int, default=100_000, help="distinct tiles of the end-to-end (M1) leg; 0 = skip")
+    ap.add_argument("--slide-tiles", type=int, default=20_736, help="tiles of the synthetic-slide leg (decode threads -> GPU resize / Canny -> encoder -> .h5); 0 = skip")
     ap.add_argument("--e2e-warmup", type=int, default=2, help="batches of the end-to-end leg run before its clock starts")
     return ap.parse_args()
 
@@ -296,6 +297,85 @@ def end_to_end_leg(model, cfg, dev, n_tiles: int, batch: int, warm_batches: int)
     return {"metric": "tiles/s end to end (M1: pinned host u8 -> H2D -> encode -> fp16 features on the host)", "value": round(n_tiles / el, 1),
             "unit": "tiles/s", "tiles": n_tiles, "distinct": True, "batch": batch, "seconds": round(el, 2), "finite": ok, "matches_plain_call": same,
             "h2d_gbytes": round(n_tiles * cfg.img * cfg.img * 3 / 1e9, 2), "d2h_mbytes": round(n_tiles * dim * 2 / 1e6, 1)}
+
+
+class SyntheticSlide:
+    """openslide's surface (`dimensions`, `read_region` -> RGBA PIL image, transparent past the edge, `get_thumbnail`) over a procedurally
+    repeated base image, so that a 70 k x 70 k pixel slide costs 48 MB: pixel (x, y) = base[y % bh, x % bw].  `read_region` does real work per
+    call (a gather of S x S pixels + the RGBA assembly), comparable to openslide serving an uncompressed region; JPEG decode is not modelled."""
+
+    def __init__(self, width: int, height: int, seed: int = 0, base: int = 4096):
+        import numpy as np
+        rng = np.random.default_rng(seed)
+        # H&E-like: two stain colours on white, blob-structured (low-frequency field, thresholded) + pixel noise, so the Canny filter sees edges
+        f = rng.standard_normal((base // 16, base // 16)).astype(np.float32)
+        f = np.kron(f, np.ones((16, 16), np.float32))
+        f = (f + np.roll(f, 7, 0) + np.roll(f, 5, 1)) / 3 + 0.35 * rng.standard_normal((base, base)).astype(np.float32)
+        a = np.clip(f, 0, 1)[..., None]
+        b = np.clip(-f, 0, 1)[..., None]
+        rgb = 255.0 - a * (255.0 - np.array([120.0, 60.0, 150.0])) - b * (255.0 - np.array([230.0, 130.0, 170.0]))
+        self._base = np.clip(rgb + rng.normal(0, 6, rgb.shape), 0, 255).astype(np.uint8)
+        self.dimensions = (int(width), int(height))
+
+    def read_region(self, location, level, size):
+        import numpy as np
+        from PIL import Image
+        assert level == 0
+        x, y = location
+        w, h = size
+        W, H = self.dimensions
+        bh, bw = self._base.shape[:2]
+        vw, vh = max(0, min(w, W - x)), max(0, min(h, H - y))
+        out = np.zeros((h, w, 4), np.uint8)
+        if vw and vh:
+            out[:vh, :vw, :3] = self._base[np.ix_((np.arange(y, y + vh) % bh), (np.arange(x, x + vw) % bw))]
+            out[:vh, :vw, 3] = 255
+        return Image.fromarray(out, "RGBA")
+
+    def get_thumbnail(self, size):
+        from PIL import Image
+        return Image.new("RGB", tuple(int(v) for v in size), (140, 90, 150))          # tissue everywhere: every supertile is foreground
+
+
+def slide_leg(model, dev, n_tiles: int) -> dict:
+    """SURVEY.md N3 / VERDICT item 6: one synthetic slide OBJECT through `stamp_amd.preprocess.extract_slide` -- reader threads -> pinned ring ->
+    GPU resize (PIL-exact) -> GPU Canny -> keep-mask compaction on the device -> encoder on accumulated chunks -> fp16 features -> .h5 -- wall
+    clock from the call to the file on disk, next to the batch-by-batch form of round 2 on a slice of the same slide."""
+    import tempfile
+
+    from stamp_amd import h5io
+    from stamp_amd.extractor import Extractor, u8_tile_transform
+    from stamp_amd.preprocess import extract_slide, extract_slide_serial
+    side = max(2, int(round((n_tiles / 4) ** 0.5)))          # mpp 0.5: 1024-pixel supertiles of 2 x 2 tiles
+    slide = SyntheticSlide(side * 1024, side * 1024, seed=5)
+    ex = Extractor(model=model, transform=u8_tile_transform, identifier="amdstamp-bench")
+    workers = min(32, os.cpu_count() or 8)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        small = SyntheticSlide(8 * 1024, 8 * 1024, seed=5)
+        extract_slide(small, ex, Path(td) / "warm.h5", slide_mpp=0.5, max_workers=workers, device=dev)          # warm: allocations, PIL, HDF5
+        t0 = time.perf_counter()
+        st = extract_slide(slide, ex, Path(td) / "slide.h5", slide_mpp=0.5, max_workers=workers, device=dev)
+        el = time.perf_counter() - t0
+        feats, ci, _ = h5io.read_tile_features(Path(td) / "slide.h5")
+        out = {"metric": "tiles/s from a slide object to the feature file (decode threads -> GPU resize / Canny / compaction -> encoder -> .h5)",
+               "value": round(st["tiles_kept"] / el, 1), "unit": "tiles/s", "tiles_seen": st["tiles_seen"], "tiles_kept": st["tiles_kept"],
+               "seconds": round(el, 2), "encoder_calls": st["encoder_calls"], "host_syncs": st["host_syncs"], "reader_threads": workers,
+               "finite": bool(np.isfinite(feats.astype(np.float32)).all()), "rows_written": int(feats.shape[0])}
+        # A/B: the batch-by-batch form on a 16 x 16-supertile corner (1 024 tiles), and the pipelined form on the same corner
+        corner = SyntheticSlide(16 * 1024, 16 * 1024, seed=5)
+        t1 = time.perf_counter()
+        s1 = extract_slide_serial(corner, ex, Path(td) / "serial.h5", slide_mpp=0.5, max_workers=workers, device=dev)
+        e1 = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        s2 = extract_slide(corner, ex, Path(td) / "pipe.h5", slide_mpp=0.5, max_workers=workers, device=dev)
+        e2 = time.perf_counter() - t2
+        fa, _, _ = h5io.read_tile_features(Path(td) / "serial.h5")
+        fb, _, _ = h5io.read_tile_features(Path(td) / "pipe.h5")
+        out["serial_1024_tiles"] = round(s1["tiles_kept"] / e1, 1)
+        out["pipelined_1024_tiles"] = round(s2["tiles_kept"] / e2, 1)
+        out["identical_to_serial"] = bool(np.array_equal(fa.view(np.uint16), fb.view(np.uint16)))
+    return out
 
 
 def drop_in_b64_leg(model, cfg, dev, n_batches: int = 48) -> dict:
@@ -610,6 +690,12 @@ def main() -> None:
             del mx, fx
         except Exception as e:
             line["exact_mode"] = {"error": repr(e)[:300]}
+    if single and not is_swin and a.slide_tiles > 0:
+        try:
+            line["slide_synthetic"] = slide_leg(model, ctx.device, a.slide_tiles)
+            line["slide_synthetic"]["vs_hbm_resident"] = round(line["slide_synthetic"]["value"] / value, 4)
+        except Exception as e:
+            line["slide_synthetic"] = {"error": repr(e)[:300]}
     if single:
         try:
             line["drop_in_b64"] = drop_in_b64_leg(model, cfg, ctx.device)

@@ -472,6 +472,13 @@ size_t amds_supertiles_to_tiles_workspace_bytes(int n, int S, int k, int t);
 int amds_supertiles_to_tiles_u8(const uint8_t* rgba, uint8_t* tiles, int n, int S, int k, int t, const int* bounds, const int* coef,
                                 int ksize, void* ws, size_t ws_bytes, void* stream);
 
+/* Keep-mask compaction on the device, between the texture filter and the tile encoder (reference tiling.py:171-193 `_tiles_with_tissue`
+ * drops the rejected tiles one by one on the host): rows i < n of src (row_bytes each, a multiple of 16) whose score[i] >= cutoff (score NULL:
+ * all) are appended in order to dst at row *count_dev, which is advanced; slot_out[i] = the row it went to, -1 if rejected (-2 if dst, of
+ * capacity_rows, was full).  The fill level never leaves the device; the host reads slot_out when it needs the coordinates. n <= 4096. */
+int amds_compact_rows_u8(const uint8_t* src, long row_bytes, const float* score, float cutoff, uint8_t* dst, int capacity_rows,
+                         int* count_dev, int* slot_out, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Gated-attention pooling (CHIEF slide encoder; reference
  * src/stamp/encoding/encoder/chief.py:74-89 CHIEFModel.forward, :255-275 Attn_Net_Gated)

@@ -11,6 +11,7 @@
 //   The hysteresis fixed point (candidates connected to an edge) does not depend on visiting order, so the stack walk of
 //   the CPU code becomes an in-LDS relaxation that repeats until no pixel changes.
 #include "common.h"
+#include <algorithm>
 
 namespace amds {
 
@@ -111,9 +112,62 @@ __global__ void __launch_bounds__(256) tile_canny_kernel(const uint8_t* __restri
     if (tid == 0) frac[b] = (float)s_count / (float)n;       // == edges.mean() / 255
 }
 
+// ---------------------------------------------------------------------------------------------
+// Keep-mask compaction on the device (no host round trip between the texture filter and the tile encoder): rows whose score passes the
+// cutoff are appended, IN ORDER, to a destination buffer whose fill level lives in device memory.
+//   slot[i] = score ? (score[i] >= cutoff ? *count + (number of kept rows before i) : -1) : *count + i;   *count += kept
+// One workgroup scans (n <= 4096 rows per call: one batch of decoded tiles), a second launch moves the rows.  Deterministic: positions
+// are a prefix sum, not atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) compact_scan_kernel(const float* __restrict__ score, float cutoff, int* __restrict__ count, int* __restrict__ slot,
+                                                           int n, int capacity) {
+    __shared__ int s_part[256];
+    const int tid = threadIdx.x;
+    const int per = (n + 255) / 256, i0 = tid * per, i1 = min(n, i0 + per);
+    int c = 0;
+    for (int i = i0; i < i1; ++i) c += (score == nullptr || score[i] >= cutoff) ? 1 : 0;
+    s_part[tid] = c;
+    __syncthreads();
+    int before = 0;
+    for (int j = 0; j < tid; ++j) before += s_part[j];          // 256 terms: not worth a tree
+    const int base = *count;
+    int pos = base + before;
+    for (int i = i0; i < i1; ++i) {
+        const bool keep = score == nullptr || score[i] >= cutoff;
+        slot[i] = keep ? (pos < capacity ? pos : -2) : -1;      // -2: would not fit (the host sizes the buffer so that it cannot happen)
+        pos += keep ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 255) *count = min(pos, capacity);
+}
+__global__ void __launch_bounds__(256) compact_move_kernel(const uint8_t* __restrict__ src, long row_bytes, const int* __restrict__ slot,
+                                                           uint8_t* __restrict__ dst) {
+    const int i = blockIdx.y, s = slot[i];
+    if (s < 0) return;
+    const u32x4* a = reinterpret_cast<const u32x4*>(src + (long)i * row_bytes);
+    u32x4* b = reinterpret_cast<u32x4*>(dst + (long)s * row_bytes);
+    const long nv = row_bytes >> 4;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) b[v] = a[v];
+}
+
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" int amds_compact_rows_u8(const uint8_t* src, long row_bytes, const float* score, float cutoff, uint8_t* dst, int capacity_rows,
+                                    int* count_dev, int* slot_out, int n, void* stream) {
+    AMDS_REQUIRE(n >= 0 && n <= 4096 && row_bytes > 0 && row_bytes % 16 == 0 && capacity_rows > 0, "amds_compact_rows_u8: bad sizes (n <= 4096, row_bytes %% 16 == 0)");
+    if (n == 0) return AMDS_OK;
+    AMDS_REQUIRE(src && dst && count_dev && slot_out, "amds_compact_rows_u8: null pointer");
+    AMDS_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "amds_compact_rows_u8: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, st, score, cutoff, count_dev, slot_out, n, capacity_rows);
+    AMDS_LAUNCH_CHECK("compact_scan_kernel");
+    const int bx = (int)std::min<long>(64, (row_bytes / 16 + 255) / 256);
+    hipLaunchKernelGGL(compact_move_kernel, dim3(bx, n), dim3(256), 0, st, src, row_bytes, slot_out, dst);
+    AMDS_LAUNCH_CHECK("compact_move_kernel");
+    return AMDS_OK;
+}
 
 extern "C" int amds_tile_edge_fraction_u8(const uint8_t* tiles, float* frac, uint8_t* edges, uint8_t* gray, int B, int S, int low, int high,
                                           void* stream) {

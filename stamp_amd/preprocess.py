@@ -31,12 +31,190 @@ def _region_array(slide, x: int, y: int, s: int) -> np.ndarray:
     return np.asarray(slide.read_region((x, y), 0, (s, s)).convert("RGBA"), dtype=np.uint8)
 
 
+def _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px):
+    h5io.write_tile_features(Path(output_path), feats, coords.astype(np.float32), extractor=str(extractor.identifier), tile_size_um=tile_size_um,
+                             tile_size_px=tile_size_px, code_hash=code_hash()[:8], stamp_version=STAMP_FORMAT_VERSION, amdstamp_version=AMDSTAMP_VERSION)
+
+
 @torch.inference_mode()
 def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float, tile_size_um: float = 256.0, tile_size_px: int = 224,
                   max_supertile_size_slide_px: int = 2 ** 10, brightness_cutoff: int | None = 240, canny_cutoff: float | None = 0.02,
-                  max_workers: int = 8, supertiles_per_batch: int = 16, device="cuda") -> dict:
+                  max_workers: int = 8, supertiles_per_batch: int = 16, encode_chunk: int | None = None, device="cuda") -> dict:
     """Writes `output_path` (nothing if the slide has no tiles, like the reference :338-340) and returns counters.
-    Defaults are the reference's (preprocessing/config.py:46-66; max_supertile_size_slide_px = 2**10 at __init__.py:307)."""
+    Defaults are the reference's (preprocessing/config.py:46-66; max_supertile_size_slide_px = 2**10 at __init__.py:307).
+
+    A three-stage pipeline (the reference's own structure -- reader threads -> one consumer, tiling.py:326-346 -- with the consumer on the GPU):
+      decode   `max_workers` reader threads fill a ring of three pinned supertile batches while the GPU works (a producer thread runs
+               `read_region` for batch i+1, i+2 under batch i's GPU work);
+      prepare  stream `prep`: H2D -> PIL-exact resize + crop -> Canny edge fraction -> keep-mask compaction ON THE DEVICE
+               (`amds_compact_rows_u8`: kept tiles are appended in order to an accumulation buffer whose fill level lives in device
+               memory; no boolean index, no host round trip per batch);
+      encode   stream `enc`: whenever `encode_chunk` (default: the model's chunk, 1020) kept tiles have accumulated, ONE encoder call on
+               them and an asynchronous fp16 D2H of its features; the accumulation buffer is double-buffered against it.
+    The host blocks only when a chunk may be complete (to read which tiles were kept) and at the end.  Tiles come out in supertile order,
+    so the file equals `extract_slide_serial`'s bit for bit (a tile's feature does not depend on its batch)."""
+    import queue
+    import threading
+
+    from . import _lib, ops
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("extract_slide runs on the GPU only (no CPU fallback)")
+    geo = tiling.supertile_geometry(slide_mpp, tile_size_um, tile_size_px, max_supertile_size_slide_px)
+    S, k = geo.supertile_size_slide_px, geo.tiles_per_side
+    dims = tuple(int(v) for v in slide.dimensions)
+    gw, gh = tiling.thumbnail_size(dims, S)
+    origins = tiling.foreground_coords(dims, slide.get_thumbnail((2 * gw, 2 * gh)), S, brightness_cutoff)
+    stats = {"supertiles": len(origins), "tiles_seen": 0, "tiles_kept": 0, "encoder_calls": 0, "host_syncs": 0}
+    if not origins:
+        return stats
+    model = extractor.model
+    spb, kk, t = int(supertiles_per_batch), k * k, int(tile_size_px)
+    chunk = int(encode_chunk or getattr(model, "chunk", 1020))
+    row_bytes = t * t * 3
+    n_buf = 3
+    host = [torch.empty(spb, S, S, 4, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
+    host_np = [h.numpy() for h in host]               # the reader threads write through numpy views (no torch state in worker threads)
+    buf_free: "queue.Queue[int]" = queue.Queue()
+    for i in range(n_buf):
+        buf_free.put(i)
+    buf_ev: list = [None] * n_buf                      # H2D of the buffer's previous content has completed
+    ready: "queue.Queue" = queue.Queue(maxsize=n_buf)
+    stop = threading.Event()
+
+    def producer():
+        try:
+            with futures.ThreadPoolExecutor(max_workers) as pool:
+                for i in range(0, len(origins), spb):
+                    if stop.is_set():
+                        return
+                    b = buf_free.get()
+                    if buf_ev[b] is not None:
+                        buf_ev[b].synchronize()
+                    batch = origins[i:i + spb]
+
+                    def fill(jo, b=b):
+                        host_np[b][jo[0]][...] = _region_array(slide, jo[1][0], jo[1][1], S)
+                    list(pool.map(fill, enumerate(batch)))
+                    ready.put((b, batch))
+            ready.put(None)
+        except BaseException as e:      # surfaces in the consumer: the reference logs and skips the slide (__init__.py:328-336)
+            ready.put(e)
+
+    with torch.cuda.device(dev):
+        prep, enc = torch.cuda.Stream(), torch.cuda.Stream()
+        cap = chunk + spb * kk
+        acc = [torch.empty(cap, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        acc_ev: list = [None, None]                    # the encoder call that read this buffer has been queued up to this event
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream().synchronize()
+        cur, n_have, ub = 0, 0, 0
+        pending: list = []                             # batches whose keep decisions the host has not read yet
+        cur_coords: list = []
+        feats_parts: list = []
+        coords_parts: list = []
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+
+        def flush(final: bool) -> None:
+            nonlocal cur, n_have, ub
+            if pending:
+                pending[-1][1].synchronize()
+                stats["host_syncs"] += 1
+                for slots_h, _ev, cu in pending:
+                    keep = slots_h.numpy() >= 0
+                    if (slots_h.numpy() == -2).any():
+                        raise RuntimeError("extract_slide: accumulation buffer overflow")
+                    cur_coords.append(cu[keep])
+                    n_have += int(keep.sum())
+                pending.clear()
+            while n_have >= chunk or (final and n_have > 0):
+                m = min(n_have, chunk)
+                allc = np.concatenate(cur_coords) if cur_coords else np.zeros((0, 2))
+                ev_prep = torch.cuda.Event()
+                ev_prep.record(prep)
+                with torch.cuda.stream(enc):
+                    enc.wait_event(ev_prep)
+                    f = model(acc[cur][:m]).detach().half()
+                    fh = torch.empty(f.shape, dtype=torch.float16).pin_memory()
+                    fh.copy_(f, non_blocking=True)
+                    ev_enc = torch.cuda.Event()
+                    ev_enc.record(enc)
+                stats["encoder_calls"] += 1
+                feats_parts.append((fh, ev_enc, f))
+                coords_parts.append(allc[:m])
+                rem = n_have - m
+                other = 1 - cur
+                with torch.cuda.stream(prep):
+                    if acc_ev[other] is not None:
+                        prep.wait_event(acc_ev[other])
+                    if rem:
+                        acc[other][:rem].copy_(acc[cur][m:n_have])
+                    count.fill_(rem)
+                acc_ev[cur] = ev_enc
+                cur_coords[:] = [allc[m:]] if rem else []
+                cur, n_have = other, rem
+            ub = n_have
+
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                b, batch = item
+                nb = len(batch)
+                with torch.cuda.stream(prep):
+                    rgba = host[b][:nb].to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(prep)
+                    buf_ev[b] = ev
+                    buf_free.put(b)
+                    tiles = tiling.supertiles_to_tiles(rgba, k, t)
+                    frac = ops.tile_edge_fraction(tiles, 40, 100) if canny_cutoff is not None else None
+                    slots = torch.empty(tiles.shape[0], dtype=torch.int32, device=dev)
+                    _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(),
+                                                               float(canny_cutoff or 0.0), acc[cur].data_ptr(), cap, count.data_ptr(), slots.data_ptr(),
+                                                               tiles.shape[0], prep.cuda_stream), "compact_rows")
+                    slots_h = torch.empty(tiles.shape[0], dtype=torch.int32).pin_memory()
+                    slots_h.copy_(slots, non_blocking=True)
+                    ev2 = torch.cuda.Event()
+                    ev2.record(prep)
+                cu = np.concatenate([tiling.tile_coords_um(o, slide_mpp, k, tile_size_um) for o in batch])
+                pending.append((slots_h, ev2, cu))
+                stats["tiles_seen"] += nb * kk
+                ub += nb * kk
+                if ub >= chunk:
+                    flush(False)
+            flush(True)
+        finally:
+            stop.set()
+            while th.is_alive():                        # unblock a producer waiting for a free buffer
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    pass
+                buf_free.put(0)
+                th.join(timeout=0.05)
+        for _fh, ev_enc, _f in feats_parts:
+            ev_enc.synchronize()
+        prep.synchronize()
+    if not feats_parts:
+        return stats
+    feats = torch.cat([p[0] for p in feats_parts])
+    coords = np.concatenate(coords_parts)
+    stats["tiles_kept"] = int(feats.shape[0])
+    _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px)
+    return stats
+
+
+@torch.inference_mode()
+def extract_slide_serial(slide, extractor: Extractor, output_path, *, slide_mpp: float, tile_size_um: float = 256.0, tile_size_px: int = 224,
+                  max_supertile_size_slide_px: int = 2 ** 10, brightness_cutoff: int | None = 240, canny_cutoff: float | None = 0.02,
+                  max_workers: int = 8, supertiles_per_batch: int = 16, device="cuda") -> dict:
+    """The un-pipelined form (round 2): decode a batch -> wait -> H2D -> resize -> Canny -> boolean index (host sync) -> encoder -> `.cpu()`,
+    batch by batch.  Kept as the A/B partner of `extract_slide`: same files bit for bit (tests/test_gpu_tiling.py), a fraction of the rate."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("extract_slide runs on the GPU only (no CPU fallback)")

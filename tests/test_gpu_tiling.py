@@ -116,3 +116,57 @@ def test_extract_slide_end_to_end_writes_stamp_h5(gpu, tmp_path):
     s2 = extract_slide(Slide(), ex, out2, slide_mpp=0.5, brightness_cutoff=224, canny_cutoff=0.02, device=gpu)
     _, ci2, _ = h5io.read_tile_features(out2)
     assert 0 < s2["tiles_kept"] <= s2["tiles_seen"] and {tuple(c) for c in ci2.coords_um.tolist()} <= {tuple(c) for c in z["coords_um"].astype(np.float32).tolist()}
+    # the pipelined path (reader threads under the GPU work, keep-mask compacted on the device, encoder calls on accumulated chunks) writes what
+    # the batch-by-batch path writes, bit for bit -- whatever the chunk / batch geometry: chunks smaller than a batch (several encoder calls per
+    # flush + a remainder carried over), equal, larger than the slide
+    from stamp_amd.preprocess import extract_slide_serial
+    for canny in (None, 0.02):
+        ref_path = tmp_path / "feats" / f"serial_{canny}.h5"
+        extract_slide_serial(Slide(), ex, ref_path, slide_mpp=0.5, brightness_cutoff=224, canny_cutoff=canny, supertiles_per_batch=3, device=gpu)
+        fr, cr, _ = h5io.read_tile_features(ref_path)
+        for chunk, spb in ((5, 3), (12, 3), (7, 16), (10_000, 2)):
+            pth = tmp_path / "feats" / f"pipe_{canny}_{chunk}_{spb}.h5"
+            st = extract_slide(Slide(), ex, pth, slide_mpp=0.5, brightness_cutoff=224, canny_cutoff=canny, supertiles_per_batch=spb, encode_chunk=chunk,
+                               max_workers=3, device=gpu)
+            fp, cp, _ = h5io.read_tile_features(pth)
+            assert np.array_equal(fp.view(np.uint16), fr.view(np.uint16)) and np.array_equal(cp.coords_um, cr.coords_um), (canny, chunk, spb)
+            assert st["tiles_kept"] == fr.shape[0] and st["encoder_calls"] == -(-fr.shape[0] // chunk)
+
+    class Broken(Slide):                               # a reader failure surfaces as an exception (the reference logs and skips the slide)
+        def read_region(self, loc, level, size):
+            raise OSError("cannot read region")
+    with pytest.raises(OSError):
+        extract_slide(Broken(), ex, tmp_path / "feats" / "broken.h5", slide_mpp=0.5, brightness_cutoff=224, device=gpu)
+    assert not (tmp_path / "feats" / "broken.h5").exists()
+
+
+def test_compact_rows_on_device(gpu):
+    """amds_compact_rows_u8: kept rows appended in order behind a device-resident fill level; slots tell the host where each row went."""
+    import ctypes as C  # noqa: F401
+
+    from stamp_amd import _lib, ops
+    torch.manual_seed(0)
+    rb = 150528
+    dst = torch.zeros(40, rb, dtype=torch.uint8, device=gpu)
+    count = torch.zeros(1, dtype=torch.int32, device=gpu)
+    expect = []
+    for n, cutoff in ((13, 0.5), (1, 0.5), (17, 0.2), (9, None)):
+        src = torch.randint(0, 256, (n, rb), dtype=torch.uint8, device=gpu)
+        score = torch.rand(n, device=gpu)
+        slots = torch.empty(n, dtype=torch.int32, device=gpu)
+        _lib.check(_lib.lib().amds_compact_rows_u8(src.data_ptr(), rb, None if cutoff is None else score.data_ptr(), float(cutoff or 0), dst.data_ptr(), 40,
+                                                   count.data_ptr(), slots.data_ptr(), n, ops._stream()), "compact")
+        keep = torch.ones(n, dtype=torch.bool, device=gpu) if cutoff is None else score >= cutoff
+        base = len(expect)
+        want = torch.full((n,), -1, dtype=torch.int32)
+        fit = 0
+        for i in torch.nonzero(keep).flatten().tolist():
+            if base + fit < 40:
+                want[i] = base + fit
+                expect.append(src[i].clone())
+                fit += 1
+            else:
+                want[i] = -2
+        assert torch.equal(slots.cpu(), want), (slots, want)
+        assert count.item() == len(expect)
+    assert torch.equal(dst[:len(expect)], torch.stack(expect))
