@@ -28,7 +28,10 @@ from .extractor import Extractor, has_enough_texture
 
 
 def _region_array(slide, x: int, y: int, s: int) -> np.ndarray:
-    return np.asarray(slide.read_region((x, y), 0, (s, s)).convert("RGBA"), dtype=np.uint8)
+    im = slide.read_region((x, y), 0, (s, s))
+    if im.mode != "RGBA":              # openslide hands out RGBA already: no second 4 MB copy under the GIL
+        im = im.convert("RGBA")
+    return np.asarray(im, dtype=np.uint8)
 
 
 def _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px):
@@ -44,7 +47,7 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     Defaults are the reference's (preprocessing/config.py:46-66; max_supertile_size_slide_px = 2**10 at __init__.py:307).
 
     A three-stage pipeline (the reference's own structure -- reader threads -> one consumer, tiling.py:326-346 -- with the consumer on the GPU):
-      decode   `max_workers` reader threads fill a ring of three pinned supertile batches while the GPU works (a producer thread runs
+      decode   `max_workers` reader threads fill a ring of six pinned supertile batches while the GPU works (a producer thread runs
                `read_region` for batch i+1, i+2 under batch i's GPU work);
       prepare  stream `prep`: H2D -> PIL-exact resize + crop -> Canny edge fraction -> keep-mask compaction ON THE DEVICE
                (`amds_compact_rows_u8`: kept tiles are appended in order to an accumulation buffer whose fill level lives in device
@@ -65,14 +68,15 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     dims = tuple(int(v) for v in slide.dimensions)
     gw, gh = tiling.thumbnail_size(dims, S)
     origins = tiling.foreground_coords(dims, slide.get_thumbnail((2 * gw, 2 * gh)), S, brightness_cutoff)
-    stats = {"supertiles": len(origins), "tiles_seen": 0, "tiles_kept": 0, "encoder_calls": 0, "host_syncs": 0}
+    import time as _time
+    stats = {"supertiles": len(origins), "tiles_seen": 0, "tiles_kept": 0, "encoder_calls": 0, "host_syncs": 0, "wait_reader_s": 0.0, "wait_gpu_s": 0.0}
     if not origins:
         return stats
     model = extractor.model
     spb, kk, t = int(supertiles_per_batch), k * k, int(tile_size_px)
     chunk = int(encode_chunk or getattr(model, "chunk", 1020))
     row_bytes = t * t * 3
-    n_buf = 3
+    n_buf = 6
     host = [torch.empty(spb, S, S, 4, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
     host_np = [h.numpy() for h in host]               # the reader threads write through numpy views (no torch state in worker threads)
     buf_free: "queue.Queue[int]" = queue.Queue()
@@ -83,26 +87,39 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     stop = threading.Event()
 
     def producer():
+        # up to n_buf batches are being decoded at any time: the reads of batch i+1, i+2 are submitted to the pool as soon as a pinned
+        # buffer is free, batches are handed over in order as they complete
         try:
+            inflight: list = []
             with futures.ThreadPoolExecutor(max_workers) as pool:
+                def hand_over():
+                    b0, batch0, futs0 = inflight.pop(0)
+                    for fu in futs0:
+                        fu.result()
+                    ready.put((b0, batch0))
                 for i in range(0, len(origins), spb):
                     if stop.is_set():
                         return
+                    while len(inflight) >= n_buf:
+                        hand_over()
                     b = buf_free.get()
                     if buf_ev[b] is not None:
                         buf_ev[b].synchronize()
                     batch = origins[i:i + spb]
 
-                    def fill(jo, b=b):
-                        host_np[b][jo[0]][...] = _region_array(slide, jo[1][0], jo[1][1], S)
-                    list(pool.map(fill, enumerate(batch)))
-                    ready.put((b, batch))
+                    def fill(j, o, b=b):
+                        host_np[b][j][...] = _region_array(slide, o[0], o[1], S)
+                    inflight.append((b, batch, [pool.submit(fill, j, o) for j, o in enumerate(batch)]))
+                while inflight:
+                    hand_over()
             ready.put(None)
         except BaseException as e:      # surfaces in the consumer: the reference logs and skips the slide (__init__.py:328-336)
             ready.put(e)
 
     with torch.cuda.device(dev):
-        prep, enc = torch.cuda.Stream(), torch.cuda.Stream()
+        # `prep` at high priority: its small kernels (resize, Canny, compaction) are dispatched ahead of the encoder's queued workgroups, so the
+        # host's wait for a batch's keep decisions does not sit behind a whole encoder chunk
+        prep, enc, h2d = torch.cuda.Stream(priority=-1), torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
         cap = chunk + spb * kk
         acc = [torch.empty(cap, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
         acc_ev: list = [None, None]                    # the encoder call that read this buffer has been queued up to this event
@@ -113,13 +130,26 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
         cur_coords: list = []
         feats_parts: list = []
         coords_parts: list = []
+        # host-side staging allocated ONCE (pinning memory is a driver call): per-batch keep slots, and the feature rows of the whole slide
+        n_batches = (len(origins) + spb - 1) // spb
+        slots_ring = torch.empty(n_batches, spb * kk, dtype=torch.int32).pin_memory()
+        feat_dim = int(getattr(getattr(model, "cfg", None), "out_dim", 0) or getattr(getattr(model, "cfg", None), "dim", 0) or 0)
+        feats_host = torch.empty(len(origins) * kk, feat_dim, dtype=torch.float16).pin_memory() if feat_dim else None
+        n_out = 0
+        # micrometre coordinates of every tile of every foreground supertile, in yield order (tiling.py:237-246), vectorised
+        og = np.asarray(origins, dtype=np.float64) * slide_mpp                                  # [n, 2] (x, y)
+        off = np.array([(x * tile_size_um, y * tile_size_um) for y in range(k) for x in range(k)], dtype=np.float64)
+        all_coords = (og[:, None, :] + off[None, :, :]).reshape(-1, 2)
+        batch_idx = 0
         th = threading.Thread(target=producer, daemon=True)
         th.start()
 
         def flush(final: bool) -> None:
-            nonlocal cur, n_have, ub
+            nonlocal cur, n_have, ub, n_out
             if pending:
+                t_ = _time.perf_counter()
                 pending[-1][1].synchronize()
+                stats["wait_gpu_s"] += _time.perf_counter() - t_
                 stats["host_syncs"] += 1
                 for slots_h, _ev, cu in pending:
                     keep = slots_h.numpy() >= 0
@@ -136,11 +166,12 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
                 with torch.cuda.stream(enc):
                     enc.wait_event(ev_prep)
                     f = model(acc[cur][:m]).detach().half()
-                    fh = torch.empty(f.shape, dtype=torch.float16).pin_memory()
+                    fh = feats_host[n_out:n_out + m] if feats_host is not None and f.shape[1] == feats_host.shape[1] else torch.empty(f.shape, dtype=torch.float16).pin_memory()
                     fh.copy_(f, non_blocking=True)
                     ev_enc = torch.cuda.Event()
                     ev_enc.record(enc)
                 stats["encoder_calls"] += 1
+                n_out += m
                 feats_parts.append((fh, ev_enc, f))
                 coords_parts.append(allc[:m])
                 rem = n_have - m
@@ -158,30 +189,36 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
 
         try:
             while True:
+                t_ = _time.perf_counter()
                 item = ready.get()
+                stats["wait_reader_s"] += _time.perf_counter() - t_
                 if item is None:
                     break
                 if isinstance(item, BaseException):
                     raise item
                 b, batch = item
                 nb = len(batch)
-                with torch.cuda.stream(prep):
+                with torch.cuda.stream(h2d):        # its own stream: a pinned buffer is free again as soon as ITS copy is done, not behind prep's kernels
                     rgba = host[b][:nb].to(dev, non_blocking=True)
                     ev = torch.cuda.Event()
-                    ev.record(prep)
+                    ev.record(h2d)
                     buf_ev[b] = ev
                     buf_free.put(b)
+                with torch.cuda.stream(prep):
+                    prep.wait_event(ev)
+                    rgba.record_stream(prep)
                     tiles = tiling.supertiles_to_tiles(rgba, k, t)
                     frac = ops.tile_edge_fraction(tiles, 40, 100) if canny_cutoff is not None else None
                     slots = torch.empty(tiles.shape[0], dtype=torch.int32, device=dev)
                     _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(),
                                                                float(canny_cutoff or 0.0), acc[cur].data_ptr(), cap, count.data_ptr(), slots.data_ptr(),
                                                                tiles.shape[0], prep.cuda_stream), "compact_rows")
-                    slots_h = torch.empty(tiles.shape[0], dtype=torch.int32).pin_memory()
+                    slots_h = slots_ring[batch_idx, :tiles.shape[0]]
                     slots_h.copy_(slots, non_blocking=True)
                     ev2 = torch.cuda.Event()
                     ev2.record(prep)
-                cu = np.concatenate([tiling.tile_coords_um(o, slide_mpp, k, tile_size_um) for o in batch])
+                cu = all_coords[batch_idx * spb * kk: batch_idx * spb * kk + nb * kk]
+                batch_idx += 1
                 pending.append((slots_h, ev2, cu))
                 stats["tiles_seen"] += nb * kk
                 ub += nb * kk
@@ -197,9 +234,11 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
                     pass
                 buf_free.put(0)
                 th.join(timeout=0.05)
+        t_ = _time.perf_counter()
         for _fh, ev_enc, _f in feats_parts:
             ev_enc.synchronize()
         prep.synchronize()
+        stats["wait_gpu_s"] += _time.perf_counter() - t_
     if not feats_parts:
         return stats
     feats = torch.cat([p[0] for p in feats_parts])

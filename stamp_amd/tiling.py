@@ -99,6 +99,15 @@ def resize_coefficients(in_size: int, out_size: int) -> tuple[np.ndarray, np.nda
     return bounds, taps
 
 
+@lru_cache(maxsize=16)
+def _resize_tables_on_device(in_size: int, out_size: int, device_index: int):
+    """The tap tables of `resize_coefficients` as device tensors, uploaded once per (S, S', device): per call they would be two synchronous
+    pageable H2D copies in front of every batch of supertiles."""
+    bounds, taps = resize_coefficients(in_size, out_size)
+    dev = torch.device("cuda", device_index)
+    return torch.from_numpy(bounds).to(dev), torch.from_numpy(taps).to(dev), int(taps.shape[1])
+
+
 def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: int = 224) -> torch.Tensor:
     """u8 [n, S, S, 4] (what `read_region` returns, on the GPU) -> u8 [n * k * k, tile_px, tile_px, 3]: resize to k * tile_px, drop alpha,
     crop -- tiles of supertile i are rows i*k*k .. (i+1)*k*k - 1 in (y outer, x inner) order."""
@@ -109,13 +118,12 @@ def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: i
     rgba = rgba.contiguous()
     n, S = rgba.shape[0], rgba.shape[1]
     k, t = int(tiles_per_side), int(tile_size_px)
-    bounds, taps = resize_coefficients(S, k * t)
     dev = rgba.device
-    b_d, t_d = torch.from_numpy(bounds).to(dev), torch.from_numpy(taps).to(dev)
+    b_d, t_d, ksize = _resize_tables_on_device(S, k * t, dev.index if dev.index is not None else torch.cuda.current_device())
     out = torch.empty(n * k * k, t, t, 3, dtype=torch.uint8, device=dev)
     lib = _lib.lib()
     nb = lib.amds_supertiles_to_tiles_workspace_bytes(n, S, k, t)
     ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
-    _lib.check(lib.amds_supertiles_to_tiles_u8(rgba.data_ptr(), out.data_ptr(), n, S, k, t, b_d.data_ptr(), t_d.data_ptr(), taps.shape[1], ws.data_ptr(), nb,
+    _lib.check(lib.amds_supertiles_to_tiles_u8(rgba.data_ptr(), out.data_ptr(), n, S, k, t, b_d.data_ptr(), t_d.data_ptr(), ksize, ws.data_ptr(), nb,
                                                ops._stream()), "supertiles_to_tiles")
     return out
