@@ -166,6 +166,13 @@ int amds_gemm_lnfold(const void* A, long lda, const void* W, long ldw, int M, in
                      const float* colsum, void* stream);
 /* rowpart [M][NP][2] (NP = N/128 of the producer) -> rowstat [M][2] = (rstd, -mean * rstd) with biased variance over D columns */
 int amds_ln_rowstat(const float* rowpart, int M, int NP, int D, float eps, float* rowstat, void* stream);
+/* Same, also counting into diag (device int[2], caller-zeroed, may be NULL): [0] rows whose sum of squares reaches the act dtype's
+ * max^2 (fp16: 65504^2) -- since |x| <= sqrt(sum x^2), rows below that limit provably hold no element the 16-bit copy cannot represent, rows
+ * at or above it may (real ViT-H / ViT-g checkpoints have massive-activation channels; a saturated copy shows up as non-finite features);
+ * [1] rows with |mean| > 8 sigma, where rounding x instead of x - mean costs the folded form precision (amds_gemm_lnfold's stated
+ * precondition is |mean| << std).  amds_vit_forward counts over every folded LayerNorm of the call into its workspace
+ * (amds_vit_workspace_diag_offset). */
+int amds_ln_rowstat_diag(const float* rowpart, int M, int NP, int D, float eps, float* rowstat, int* diag, int dtype, void* stream);
 /* the first LayerNorm of a stack: x fp32 [M][D] (pitch ldx) -> xh act dtype [M][D] (pitch ldxh) + rowstat [M][2] */
 int amds_ln_stats_cast(const float* x, long ldx, int M, int D, float eps, void* xh, long ldxh, float* rowstat, int dtype, void* stream);
 
@@ -319,6 +326,11 @@ int amds_vit_pack_host(const amds_vit_cfg* cfg_host, const amds_vit_host_weights
 
 /* Workspace bytes for a forward over at most `batch` tiles per internal chunk. */
 size_t amds_vit_workspace_bytes(const amds_vit_cfg* cfg_host, int batch);
+
+/* Byte offset, inside a workspace sized by amds_vit_workspace_bytes(cfg, batch), of int32[2] range diagnostics of the LayerNorm-folded path
+ * (see amds_ln_rowstat_diag): the forward ADDS to them; zero them when you want a fresh count, read them whenever the stream has drained.
+ * (0 on error.) */
+size_t amds_vit_workspace_diag_offset(const amds_vit_cfg* cfg_host, int batch);
 
 /* tiles: u8 [B][img][img][3] (HWC, as decoded) -> feats: fp16 [B][dim] = CLS token of the final
  * LayerNorm, i.e. model(tiles)[:, 0].half() (reference src/stamp/preprocessing/__init__.py:324-325,

@@ -157,8 +157,11 @@ static int launch_ln(const float* x, long xs, const float* g, const float* b, vo
 // LayerNorm folded into the GEMMs (amds_gemm_lnfold): the two small kernels around them
 // ---------------------------------------------------------------------------------------------
 // partial (sum, sum of squares) per 128-column slab [M][NP][2] -> (rstd, -mean * rstd) per row, slabs added in index order
+// diag (optional, int[2]): [0] += rows whose sum of squares reaches sq_limit (the 16-bit copy of such a row MAY hold an element beyond the act
+// dtype's range: |x| <= sqrt(sum x^2), so rows below the limit provably cannot), [1] += rows with |mean| > 8 sigma (the folded form rounds
+// x, not x - mean: its error grows with |mean| / sigma).  Rare events: the atomics never run on healthy rows.
 __global__ void __launch_bounds__(256) ln_rowstat_kernel(const float* __restrict__ rowpart, int M, int NP, float inv_d, float eps,
-                                                         float* __restrict__ rowstat) {
+                                                         float* __restrict__ rowstat, int* __restrict__ diag, float sq_limit) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= M) return;
     const f32x2* p = reinterpret_cast<const f32x2*>(rowpart) + (long)r * NP;
@@ -170,6 +173,10 @@ __global__ void __launch_bounds__(256) ln_rowstat_kernel(const float* __restrict
     }
     const float mean = s1 * inv_d, var = fmaxf(s2 * inv_d - mean * mean, 0.f), rstd = rsqrtf(var + eps);
     reinterpret_cast<f32x2*>(rowstat)[r] = f32x2{rstd, -mean * rstd};
+    if (diag) {
+        if (!(s2 < sq_limit)) atomicAdd(diag, 1);              // also catches NaN / inf sums
+        if (mean * mean > 64.f * var) atomicAdd(diag + 1, 1);
+    }
 }
 
 // the first LayerNorm of a stack (its input does not come out of a RESIDUAL GEMM): x fp32 -> 16-bit copy + (rstd, -mean * rstd)
@@ -427,7 +434,18 @@ extern "C" int amds_ln_rowstat(const float* rowpart, int M, int NP, int D, float
     AMDS_REQUIRE(rowpart && rowstat && M >= 0 && NP > 0 && D > 0, "amds_ln_rowstat: bad arguments");
     if (M == 0) return AMDS_OK;
     ProfScope prof(PROF_LN, (double)M * (NP * 8.0 + 8.0), (hipStream_t)stream);
-    hipLaunchKernelGGL(ln_rowstat_kernel, dim3(cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, rowpart, M, NP, 1.0f / (float)D, eps, rowstat);
+    hipLaunchKernelGGL(ln_rowstat_kernel, dim3(cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, rowpart, M, NP, 1.0f / (float)D, eps, rowstat,
+                       (int*)nullptr, 0.f);
+    AMDS_LAUNCH_CHECK("ln_rowstat_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_ln_rowstat_diag(const float* rowpart, int M, int NP, int D, float eps, float* rowstat, int* diag, int dtype, void* stream) {
+    AMDS_REQUIRE(rowpart && rowstat && M >= 0 && NP > 0 && D > 0, "amds_ln_rowstat_diag: bad arguments");
+    if (M == 0) return AMDS_OK;
+    ProfScope prof(PROF_LN, (double)M * (NP * 8.0 + 8.0), (hipStream_t)stream);
+    const float lim = dtype == AMDS_F16 ? 65504.f * 65504.f : 3.0e38f;
+    hipLaunchKernelGGL(ln_rowstat_kernel, dim3(cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, rowpart, M, NP, 1.0f / (float)D, eps, rowstat, diag, lim);
     AMDS_LAUNCH_CHECK("ln_rowstat_kernel");
     return AMDS_OK;
 }

@@ -21,7 +21,7 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
 
 struct VitPlan {
     int np, T, kp, dim, hidden;
-    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, total;
+    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -61,6 +61,7 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     p->off_qc = o; o += align256(cls);
     p->off_oc = o; o += align256(cls);
     p->off_uc = o; o += align256((size_t)batch * 2 * c->hidden * 4);
+    p->off_diag = o; o += 256;          // int32[2] range diagnostics of the folded LayerNorms (amds_ln_rowstat_diag)
     p->total = o;
     return AMDS_OK;
 }
@@ -80,6 +81,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     char* h2 = ws + pl.off_h2;
     float* rowpart = reinterpret_cast<float*>(ws + pl.off_rowpart);
     float* rowstat = reinterpret_cast<float*>(ws + pl.off_rowstat);
+    int* diag = reinterpret_cast<int*>(ws + pl.off_diag);
     const int D = c->dim, T = pl.T, M = Bc * T, dt = c->dtype, Hd = c->hidden, NP = D / 128;
     const int n_fc1 = c->mlp_kind == 0 ? Hd : 2 * Hd;
     int rc;
@@ -193,12 +195,12 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
             }
             if (fold) {
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.proj_w, D, n, D, D, dt, AMDS_EPI_RESIDUAL, xq, D, b.proj_b, ls1, h2q, rp, nullptr, nullptr, s));
-                AMDS_TRY(amds_ln_rowstat(rp, n, NP, D, c->ln_eps, rs, s));
+                AMDS_TRY(amds_ln_rowstat_diag(rp, n, NP, D, c->ln_eps, rs, diag, dt, s));
                 if (ex) AMDS_TRY(amds_vit_cls_scatter(xcq, xq, h2q, rs, q.nt, T, D, c->ln_eps, dt, s));
                 AMDS_TRY(amds_gemm_lnfold(h2q, D, b.fc1_w, D, n, n_fc1, D, dt, epi1, mlpq, Hd, b.fc1_b, nullptr, nullptr, nullptr, rs, b.fc1_colsum, s));
                 if (!last) {
                     AMDS_TRY(amds_gemm_lnfold(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, dt, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, hq, rp, nullptr, nullptr, s));
-                    AMDS_TRY(amds_ln_rowstat(rp, n, NP, D, c->ln_eps, rs, s));
+                    AMDS_TRY(amds_ln_rowstat_diag(rp, n, NP, D, c->ln_eps, rs, diag, dt, s));
                 } else {
                     AMDS_TRY(enc_gemm(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, s));
                 }
@@ -244,6 +246,12 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" size_t amds_vit_workspace_diag_offset(const amds_vit_cfg* cfg_host, int batch) {
+    VitPlan p;
+    if (make_plan(cfg_host, batch, &p) != AMDS_OK) return 0;
+    return p.off_diag;
+}
 
 extern "C" size_t amds_vit_workspace_bytes(const amds_vit_cfg* cfg_host, int batch) {
     VitPlan p;

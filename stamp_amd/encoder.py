@@ -151,3 +151,101 @@ class HipGatedAttentionEncoder:
                 _logger.warning(f"No features found for patient {patient_id}, skipping.")
                 continue
             self._save_features_(output_path, self._generate_patient_embedding(feats_list, device, **kwargs), "patient")
+
+
+class HipTitanShapedEncoder(HipGatedAttentionEncoder):
+    """A STAND-IN with TITAN's interface and tensor shapes -- NOT TITAN's arithmetic.  **Parity unpinned by construction.**
+
+    The reference's `Titan` encoder (src/stamp/encoding/encoder/titan.py:28-61) calls `model.encode_slide_from_patch_features(feats,
+    coords_px, patch_size_lvl0)` of `AutoModel.from_pretrained("MahmoodLab/TITAN", trust_remote_code=True)`: the model's code and weights
+    live on the Hugging Face hub, not in the repository, and cannot be fetched here -- there is nothing to restate and nothing to compare
+    against.  What IS in the repository is the seam: 768-d CONCH1.5 tile features + integer level-0 pixel coordinates in, one 768-d slide
+    vector out (float32, `required_extractors = [conch1_5]`), the per-patient "virtual slide" built by concatenating a patient's slides
+    along x with a running offset (:87-179).  This class implements that seam on the HIP path with a transformer of TITAN's published
+    geometry (6 layers, 12 heads of 64, width 768, feed-forward 3072, attention biased by 2-D tile distance) assembled from this package's
+    own MIL `vit` blocks with their post-softmax ALiBi -- so that BASELINE.json configs[4]'s slide-encoding stage has a same-shape
+    workload to measure, and so that a maintainer with hub access has the slot real TITAN weights + its own attention rule would fill.
+    Features it writes carry `encoder = "titan-standin"`, never "titan"."""
+
+    GEOMETRY = dict(dim_input=768, dim_model=768, n_layers=6, n_heads=12, dim_feedforward=3072, dim_output=768)
+
+    def __init__(self, state_dict: dict[str, torch.Tensor] | None = None, *, seed: int = 0, identifier: str = "titan-standin",
+                 required_extractors: tuple[str, ...] = ("conch1_5",), device="cuda") -> None:
+        from .mil import VisionTransformer
+        self.identifier = identifier
+        self.precision = torch.float32              # titan.py:33
+        self.required_extractors = list(required_extractors)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipTitanShapedEncoder runs on the GPU only (no CPU fallback)")
+        g = torch.Generator().manual_seed(seed)
+        rng_state = torch.get_rng_state()
+        torch.manual_seed(int(torch.randint(0, 2 ** 31, (1,), generator=g)))
+        self.net = VisionTransformer(dropout=0.0, use_alibi=True, **self.GEOMETRY).eval()
+        torch.set_rng_state(rng_state)
+        if state_dict is not None:
+            self.net.load_state_dict(state_dict)
+        self.net = self.net.to(self.device)
+        self.model = self
+
+    def attention_raw(self, feats):
+        raise NotImplementedError("the TITAN-shaped stand-in has no gated-attention scores")
+
+    @torch.no_grad()
+    def _generate_slide_embedding(self, feats: torch.Tensor, device=None, coords=None, **kwargs) -> np.ndarray:
+        if coords is None:
+            raise ValueError("Coords must be provided.")                                  # titan.py:46-47
+        if feats.dim() == 3 and feats.shape[0] == 1:                                      # the patient path hands [1, N, F] (titan.py:73)
+            feats = feats[0]
+        if feats.dim() != 2 or feats.shape[0] == 0 or feats.shape[1] != self.GEOMETRY["dim_input"]:
+            raise ValueError(f"expected a non-empty [N, 768] feature matrix, got {tuple(feats.shape)}")
+        # titan.py:49-53: micrometres -> level-0 pixels, truncated to int64; here additionally expressed in tiles (the distance unit of the bias)
+        coords_px = (torch.tensor(np.asarray(coords.coords_um), dtype=self.precision) / coords.mpp).to(torch.int64)
+        grid = coords_px.to(torch.float32) / float(int(coords.tile_size_px))
+        out = self.net(feats.to(self.device, torch.float32)[None].contiguous(), coords=grid.to(self.device)[None].contiguous(), mask=None)
+        return out.detach().squeeze().cpu().numpy()
+
+    @torch.no_grad()
+    def _generate_patient_embedding(self, feats_list: list, device=None, coords_list=None, **kwargs) -> np.ndarray:
+        if coords_list is None:
+            raise ValueError("coords_list must be provided.")                             # titan.py:70-71
+        cat = torch.cat([f.to(self.device) for f in feats_list], dim=0).unsqueeze(0)
+        coords = h5io.CoordsInfo(np.concatenate([c.coords_um for c in coords_list], axis=0), coords_list[0].tile_size_um, coords_list[0].tile_size_px)
+        return self._generate_slide_embedding(cat, device, coords)
+
+    def encode_patients_(self, output_dir: Path, feat_dir: Path, patient_to_files: dict[str, list[str]], device=None, generate_hash: bool = True,
+                         **kwargs) -> None:
+        """titan.py:87-179: one virtual slide per patient, the patient's slides laid side by side along x (offset = rightmost tile's x + tile
+        width of everything placed so far); all slides of a patient must share one mpp."""
+        import math
+        encode_dir = Path(output_dir) / (f"{self.identifier}-pat-{code_hash()[:8]}" if generate_hash else f"{self.identifier}-pat")
+        os.makedirs(encode_dir, exist_ok=True)
+        for patient_id, files in patient_to_files.items():
+            output_path = (encode_dir / str(patient_id)).with_suffix(".h5")
+            if output_path.exists():
+                _logger.info(f"skipping {patient_id} because {output_path} already exists")
+                continue
+            feats_list, coords_list, x_off, mpp = [], [], 0.0, -1.0
+            for name in files:
+                if not str(name).endswith(".h5"):
+                    _logger.warning(f"Skipping {name} (not an .h5 file)")
+                    continue
+                try:
+                    feats, coords = self._validate_and_read_features(os.path.join(feat_dir, name))
+                except (FileNotFoundError, ValueError, OSError) as e:
+                    _logger.warning(f"Skipping {name}: {e}")
+                    continue
+                if mpp < 0:
+                    mpp = coords.mpp
+                elif not math.isclose(mpp, coords.mpp, rel_tol=1e-5):
+                    raise ValueError("All patient slides must have the same mpp value. Try reprocessing the slides using the same tile_size_um and "
+                                     "tile_size_px values for all of them.")
+                cu = np.array(coords.coords_um, dtype=np.float64, copy=True)
+                cu[:, 0] += x_off
+                x_off = float(cu[:, 0].max()) + float(coords.tile_size_um)
+                feats_list.append(feats)
+                coords_list.append(h5io.CoordsInfo(cu, coords.tile_size_um, coords.tile_size_px))
+            if not feats_list:
+                _logger.warning(f"No features found for patient {patient_id}, skipping.")
+                continue
+            self._save_features_(output_path, self._generate_patient_embedding(feats_list, device, coords_list), "patient")

@@ -238,7 +238,29 @@ class HipViT(nn.Module):
             _lib.check(-1, "vit_workspace_bytes")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
+            self._ws_chunk = None
+        if getattr(self, "_ws_chunk", None) != chunk:      # the counters live at a chunk-dependent offset: a new geometry starts a new count
+            self._ws_chunk = chunk
+            self._diag_view(chunk).zero_()
         return self._ws
+
+    def _diag_view(self, chunk: int) -> torch.Tensor:
+        off = _lib.lib().amds_vit_workspace_diag_offset(C.byref(self._cfg_c), chunk)
+        return self._ws[off:off + 8].view(torch.int32)
+
+    def range_diagnostics(self, reset: bool = False) -> dict:
+        """Counts, accumulated over the forwards since the workspace was made (or the last reset), of residual rows entering a FOLDED LayerNorm
+        (a) whose sum of squares reached fp16's max^2 -- only such rows can hold an element their 16-bit copy cannot represent (massive-
+        activation channels of real ViT-H / ViT-g checkpoints; the features of an affected tile come out non-finite) -- and (b) with
+        |mean| > 8 sigma, where the folded form loses precision.  Both 0 on every preset with the synthetic weights; non-zero on a real
+        checkpoint means: construct with ln_fold=False (stand-alone LayerNorm kernels, no 16-bit copy of un-normalised rows).  Synchronises."""
+        if self._ws is None or not self.ln_fold or getattr(self, "_ws_chunk", None) is None:
+            return {"rows_beyond_fp16_range_possible": 0, "rows_mean_over_8_sigma": 0}
+        d = self._diag_view(self._ws_chunk)
+        out = d.cpu().tolist()
+        if reset:
+            d.zero_()
+        return {"rows_beyond_fp16_range_possible": int(out[0]), "rows_mean_over_8_sigma": int(out[1])}
 
     def _as_u8_hwc(self, tiles: torch.Tensor) -> torch.Tensor:
         c = self.cfg
@@ -274,6 +296,7 @@ class HipViT(nn.Module):
             need = 2 * _lib.lib().amds_vit_workspace_bytes(C.byref(self._cfg_c), chunk)
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
+            self._ws_chunk = None           # (the two-stream schedule keeps two plans in the buffer; the range counters are not read back from it)
             rc = _lib.lib().amds_vit_forward_overlapped(_lib.ctx(tiles.device.index or 0), C.byref(self._cfg_c), C.byref(self._w_c), tiles.data_ptr(), feats.data_ptr(),
                                                         B, chunk, self._ws.data_ptr(), self._ws.numel(),
                                                         torch.cuda.current_stream().cuda_stream)

@@ -178,3 +178,55 @@ def test_encoder_file_loop_on_h5_files(gpu, tmp_path):
     assert a["feat_type"] == "patient" and np.abs(d["feats"] - refp.numpy()).max() < 1e-4 * max(1.0, float(refp.abs().max()))
     with pytest.raises(ValueError):
         enc.encode_patients_(out_dir, feat_dir, {"P2": ["s3.h5"]}, gpu, generate_hash=False)
+
+
+def test_titan_shaped_stand_in_seam(gpu, tmp_path):
+    """H19.  TITAN's arithmetic is remote code (titan.py:30) -- this encoder is a labelled STAND-IN of TITAN's interface and geometry (parity
+    unpinned by construction; see its docstring).  What can be pinned is pinned: the seam (768-d CONCH1.5 features + coordinates in, one 768-d
+    float32 vector out, coords required, the extractor check), that the stand-in's own arithmetic is this package's MIL `vit` + ALiBi
+    (compared against the pinned oracle of THAT network on the stand-in's weights), and the reference's patient-level "virtual slide"
+    construction (titan.py:87-179: slides side by side along x with a running offset)."""
+    from oracle.mil_vit import mil_vit_forward
+    from stamp_amd import h5io
+    from stamp_amd.encoder import HipTitanShapedEncoder
+
+    enc = HipTitanShapedEncoder(seed=3, device=gpu)
+    assert enc.identifier == "titan-standin" and enc.required_extractors == ["conch1_5"] and enc.precision == torch.float32
+    g = torch.Generator().manual_seed(1)
+    N = 900
+    feats = torch.randn(N, 768, generator=g).half().float()
+    grid = torch.stack([torch.randint(0, 60, (N,), generator=g), torch.randint(0, 40, (N,), generator=g)], 1).double()
+    coords = h5io.CoordsInfo((grid * 256.0).numpy(), 256.0, 512)                     # CONCH1.5 tiles: 512 px at 0.5 um / px
+    emb = enc._generate_slide_embedding(feats, gpu, coords=coords)
+    assert emb.shape == (768,) and emb.dtype == np.float32 and np.isfinite(emb).all()
+    assert np.array_equal(emb, enc._generate_slide_embedding(feats, gpu, coords=coords))                 # deterministic
+    with pytest.raises(ValueError, match="Coords must be provided"):
+        enc._generate_slide_embedding(feats, gpu)
+    # the stand-in's arithmetic == the pinned oracle of the MIL vit + ALiBi network on the same weights and the same tile-unit coordinates
+    sd = {k: v.detach().cpu() for k, v in enc.net.state_dict().items()}
+    cpx = (torch.tensor(coords.coords_um, dtype=torch.float32) / coords.mpp).to(torch.int64).float() / 512.0
+    ref = mil_vit_forward(feats[None], cpx[None], None, sd, n_heads=12, use_alibi=True)[0].numpy()
+    assert np.linalg.norm(emb - ref) / np.linalg.norm(ref) < 5e-3
+    # patient level: two slides laid side by side == one slide with the second shifted by (max x + tile width) of the first
+    a, b = slice(0, 500), slice(500, N)
+    ca, cb = h5io.CoordsInfo(coords.coords_um[a].copy(), 256.0, 512), h5io.CoordsInfo(coords.coords_um[b].copy(), 256.0, 512)
+    for nm, sl, ci in (("s1.h5", a, ca), ("s2.h5", b, cb)):
+        h5io.write_tile_features(tmp_path / nm, feats[sl].half(), ci.coords_um.astype(np.float32), extractor="conch1_5-0a1b2c3d", tile_size_um=256.0,
+                                 tile_size_px=512, code_hash="0a1b2c3d", stamp_version="2.5.0")
+    enc.encode_patients_(tmp_path / "out", tmp_path, {"P1": ["s1.h5", "s2.h5", "notes.txt"]}, device=gpu, generate_hash=False)
+    d, at = h5io.read_file(tmp_path / "out" / "titan-standin-pat" / "P1.h5")
+    shifted = coords.coords_um[b].copy()
+    shifted[:, 0] += coords.coords_um[a][:, 0].max() + 256.0
+    virt = h5io.CoordsInfo(np.concatenate([coords.coords_um[a], shifted]), 256.0, 512)
+    want = enc._generate_slide_embedding(torch.cat([feats[a], feats[b]]), gpu, coords=virt)
+    assert at["encoder"] == "titan-standin" and at["feat_type"] == "patient" and np.allclose(d["feats"], want, rtol=1e-5, atol=1e-6)
+    # slides extracted with another extractor are refused (encoder/__init__.py:173-180)
+    h5io.write_tile_features(tmp_path / "other.h5", feats[:10].half(), coords.coords_um[:10].astype(np.float32), extractor="uni2", tile_size_um=256.0,
+                             tile_size_px=512, code_hash="0a1b2c3d", stamp_version="2.5.0")
+    with pytest.raises(ValueError, match="must be extracted with one of"):
+        enc._validate_and_read_features(str(tmp_path / "other.h5"))
+    # different mpp within one patient is an error, as in the reference
+    h5io.write_tile_features(tmp_path / "s3.h5", feats[:10].half(), coords.coords_um[:10].astype(np.float32), extractor="conch1_5", tile_size_um=256.0,
+                             tile_size_px=224, code_hash="0a1b2c3d", stamp_version="2.5.0")
+    with pytest.raises(ValueError, match="same mpp"):
+        enc.encode_patients_(tmp_path / "out2", tmp_path, {"P2": ["s1.h5", "s3.h5"]}, device=gpu, generate_hash=False)

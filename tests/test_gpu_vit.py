@@ -154,6 +154,35 @@ def test_full_size_presets_exact_class_rows(gpu, name):
     assert r_f < 6e-4 and r_c < 4e-4 and r_t < 1e-3, (r_f, r_c, r_t)
 
 
+def test_folded_layernorm_range_diagnostics(gpu):
+    """the folded path feeds the UN-normalised residual rows through a 16-bit copy.  The forward counts, for free (in the 9 us
+    row-statistics kernel), the rows that could hold an element beyond fp16's range (sum of squares >= 65504^2: rows below provably cannot)
+    and the rows with |mean| > 8 sigma.  Healthy weights: both 0.  A checkpoint with a massive-activation channel: counted, and
+    `ln_fold=False` encodes the same tiles with finite features."""
+    cfg = PRESETS["vit_large_patch14_224"]
+    from dataclasses import replace
+    cfg = replace(cfg, depth=2)
+    sd = random_vit_state_dict(cfg, seed=2, init="moderate")
+    tiles = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(gpu)
+    m = HipViT(cfg, sd, device=gpu, chunk=3)
+    f = m(tiles)
+    assert m.range_diagnostics() == {"rows_beyond_fp16_range_possible": 0, "rows_mean_over_8_sigma": 0} and torch.isfinite(f.float()).all()
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["blocks.0.attn.proj.bias"][7] = 3.0e5 / 0.3          # one massive channel after the first attention branch (LayerScale ~0.3)
+    mb = HipViT(cfg, bad, device=gpu, chunk=3)
+    fb = mb(tiles)
+    d = mb.range_diagnostics(reset=True)
+    assert d["rows_beyond_fp16_range_possible"] >= 3 * cfg.tokens and not torch.isfinite(fb.float()).all()      # loud twice: counter AND non-finite features
+    assert mb.range_diagnostics()["rows_beyond_fp16_range_possible"] == 0                                        # reset
+    fu = HipViT(cfg, bad, device=gpu, chunk=3, ln_fold=False)(tiles)                                             # the stand-alone LayerNorm path is not affected
+    assert torch.isfinite(fu.float()).all()
+    shifted = {k: v.clone() for k, v in sd.items()}
+    shifted["blocks.0.attn.proj.bias"] += 60.0 / shifted["blocks.0.ls1.gamma"]       # every channel shifted by +60 after LayerScale: |mean| >> sigma
+    ms = HipViT(cfg, shifted, device=gpu, chunk=3)
+    ms(tiles)
+    assert ms.range_diagnostics()["rows_mean_over_8_sigma"] >= cfg.tokens
+
+
 def test_vit_large_bf16_matches_oracle(gpu):
     """BASELINE.json configs[1] says "bf16".  bf16 operands carry 8 mantissa bits (eps 3.9e-3): the 1e-3 feature bar of
     north_star is NOT reachable with them, which is why the product default is fp16 operands (same MFMA rate).
