@@ -490,6 +490,9 @@ int amds_supertiles_to_tiles_u8(const uint8_t* rgba, uint8_t* tiles, int n, int 
  * capacity_rows, was full).  The fill level never leaves the device; the host reads slot_out when it needs the coordinates. n <= 4096. */
 int amds_compact_rows_u8(const uint8_t* src, long row_bytes, const float* score, float cutoff, uint8_t* dst, int capacity_rows,
                          int* count_dev, int* slot_out, int n, void* stream);
+/* After the first m rows of an accumulation buffer went to the encoder: rows [m, *count_dev) of src move to the front of dst (at most
+ * max_rows of them: the launch geometry) and *count_dev -= m, all in stream order and without the host knowing the fill level. */
+int amds_compact_shift_u8(const uint8_t* src, uint8_t* dst, long row_bytes, int m, int max_rows, int* count_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gated-attention pooling (CHIEF slide encoder; reference

@@ -128,6 +128,7 @@ PROTOTYPES = {
     "amds_vit_pack_bytes": (_sz, [_vp, _vp, _i]),
     "amds_vit_pack": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amds_vit_pack_host": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "amds_compact_shift_u8": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
     "amds_compact_rows_u8": (_i, [_vp, _l, _vp, _f, _vp, _i, _vp, _vp, _i, _vp]),
     "amds_attention_cls_f32": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "amds_vit_cls_gather": (_i, [_vp, _vp, _i, _i, _i, _vp]),

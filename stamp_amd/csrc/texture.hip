@@ -150,9 +150,36 @@ __global__ void __launch_bounds__(256) compact_move_kernel(const uint8_t* __rest
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) b[v] = a[v];
 }
 
+// rows [m, *count) of src -> rows [0, *count - m) of dst, then *count -= m: what is left of an accumulation buffer after its first m rows
+// went to the encoder moves to the front of the other buffer, the fill level staying on the device
+__global__ void __launch_bounds__(256) compact_shift_move_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, long row_bytes, int m,
+                                                                 const int* __restrict__ count) {
+    const int r = m + blockIdx.y;
+    if (r >= *count) return;
+    const u32x4* a = reinterpret_cast<const u32x4*>(src + (long)r * row_bytes);
+    u32x4* b = reinterpret_cast<u32x4*>(dst + (long)(r - m) * row_bytes);
+    const long nv = row_bytes >> 4;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) b[v] = a[v];
+}
+__global__ void compact_shift_count_kernel(int* __restrict__ count, int m) { *count = max(*count - m, 0); }
+
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" int amds_compact_shift_u8(const uint8_t* src, uint8_t* dst, long row_bytes, int m, int max_rows, int* count_dev, void* stream) {
+    AMDS_REQUIRE(src && dst && count_dev && row_bytes > 0 && row_bytes % 16 == 0 && m >= 0 && max_rows >= 0 && max_rows <= 65535,
+                 "amds_compact_shift_u8: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (max_rows > 0) {
+        const int bx = (int)std::min<long>(64, (row_bytes / 16 + 255) / 256);
+        hipLaunchKernelGGL(compact_shift_move_kernel, dim3(bx, max_rows), dim3(256), 0, st, src, dst, row_bytes, m, count_dev);
+        AMDS_LAUNCH_CHECK("compact_shift_move_kernel");
+    }
+    hipLaunchKernelGGL(compact_shift_count_kernel, dim3(1), dim3(1), 0, st, count_dev, m);
+    AMDS_LAUNCH_CHECK("compact_shift_count_kernel");
+    return AMDS_OK;
+}
 
 extern "C" int amds_compact_rows_u8(const uint8_t* src, long row_bytes, const float* score, float cutoff, uint8_t* dst, int capacity_rows,
                                     int* count_dev, int* slot_out, int n, void* stream) {

@@ -27,6 +27,9 @@ from .encoder import AMDSTAMP_VERSION, STAMP_FORMAT_VERSION, code_hash
 from .extractor import Extractor, has_enough_texture
 
 
+_TIMELINE: list | None = None          # debugging aid (tools/slide_only.py timeline): host times of batch arrivals / encoder calls + GPU events
+
+
 def _region_array(slide, x: int, y: int, s: int) -> np.ndarray:
     im = slide.read_region((x, y), 0, (s, s))
     if im.mode != "RGBA":              # openslide hands out RGBA already: no second 4 MB copy under the GIL
@@ -42,20 +45,21 @@ def _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px):
 @torch.inference_mode()
 def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float, tile_size_um: float = 256.0, tile_size_px: int = 224,
                   max_supertile_size_slide_px: int = 2 ** 10, brightness_cutoff: int | None = 240, canny_cutoff: float | None = 0.02,
-                  max_workers: int = 8, supertiles_per_batch: int = 16, encode_chunk: int | None = None, device="cuda") -> dict:
+                  max_workers: int = 8, supertiles_per_batch: int = 64, encode_chunk: int | None = None, device="cuda") -> dict:
     """Writes `output_path` (nothing if the slide has no tiles, like the reference :338-340) and returns counters.
     Defaults are the reference's (preprocessing/config.py:46-66; max_supertile_size_slide_px = 2**10 at __init__.py:307).
 
     A three-stage pipeline (the reference's own structure -- reader threads -> one consumer, tiling.py:326-346 -- with the consumer on the GPU):
       decode   `max_workers` reader threads fill a ring of six pinned supertile batches while the GPU works (a producer thread runs
                `read_region` for batch i+1, i+2 under batch i's GPU work);
-      prepare  stream `prep`: H2D -> PIL-exact resize + crop -> Canny edge fraction -> keep-mask compaction ON THE DEVICE
-               (`amds_compact_rows_u8`: kept tiles are appended in order to an accumulation buffer whose fill level lives in device
-               memory; no boolean index, no host round trip per batch);
-      encode   stream `enc`: whenever `encode_chunk` (default: the model's chunk, 1020) kept tiles have accumulated, ONE encoder call on
-               them and an asynchronous fp16 D2H of its features; the accumulation buffer is double-buffered against it.
-    The host blocks only when a chunk may be complete (to read which tiles were kept) and at the end.  Tiles come out in supertile order,
-    so the file equals `extract_slide_serial`'s bit for bit (a tile's feature does not depend on its batch)."""
+      prepare  H2D on its own stream (DMA engines), then on the compute stream: PIL-exact resize + crop -> Canny edge fraction -> keep-mask
+               compaction ON THE DEVICE (`amds_compact_rows_u8`: kept tiles are appended in order to an accumulation buffer whose fill level
+               lives in device memory; no boolean index, no host round trip per batch -- the host reads the keep decisions asynchronously,
+               whenever they arrive, only to know the coordinates and when a chunk is full);
+      encode   whenever `encode_chunk` (default: the model's chunk, 1020) kept tiles are known to have accumulated, ONE encoder call on
+               them, an asynchronous fp16 D2H of its features, and `amds_compact_shift_u8` moves the rest to the other buffer.
+    The host never waits for the GPU before the end of the slide (unless the accumulation buffer -- two chunks -- would overflow).  Tiles come
+    out in supertile order, so the file equals `extract_slide_serial`'s bit for bit (a tile's feature does not depend on its batch)."""
     import queue
     import threading
 
@@ -69,6 +73,7 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     gw, gh = tiling.thumbnail_size(dims, S)
     origins = tiling.foreground_coords(dims, slide.get_thumbnail((2 * gw, 2 * gh)), S, brightness_cutoff)
     import time as _time
+    t_begin = _time.perf_counter()
     stats = {"supertiles": len(origins), "tiles_seen": 0, "tiles_kept": 0, "encoder_calls": 0, "host_syncs": 0, "wait_reader_s": 0.0, "wait_gpu_s": 0.0}
     if not origins:
         return stats
@@ -76,7 +81,11 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     spb, kk, t = int(supertiles_per_batch), k * k, int(tile_size_px)
     chunk = int(encode_chunk or getattr(model, "chunk", 1020))
     row_bytes = t * t * 3
-    n_buf = 6
+    # the ring must hold well over one encoder chunk of tiles (two here): a slot is recycled when the compute stream has cut its tiles, and
+    # that stream is busy with the encoder for a whole chunk at a time -- every batch handed over during an encoder call stays locked until
+    # the call ends, while the readers must keep producing the next chunk
+    n_buf = max(3, -(-2 * chunk // (spb * kk)) + 1)
+    n_buf = max(2, min(n_buf, (4 << 30) // (spb * S * S * 4), -(-len(origins) // spb) + 1))       # <= 4 GB of pinned memory, not more slots than batches
     host = [torch.empty(spb, S, S, 4, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
     host_np = [h.numpy() for h in host]               # the reader threads write through numpy views (no torch state in worker threads)
     buf_free: "queue.Queue[int]" = queue.Queue()
@@ -94,17 +103,23 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
             with futures.ThreadPoolExecutor(max_workers) as pool:
                 def hand_over():
                     b0, batch0, futs0 = inflight.pop(0)
+                    t_ = _time.perf_counter()
                     for fu in futs0:
                         fu.result()
+                    stats["reader_wait_decode_s"] = stats.get("reader_wait_decode_s", 0.0) + _time.perf_counter() - t_
                     ready.put((b0, batch0))
                 for i in range(0, len(origins), spb):
                     if stop.is_set():
                         return
                     while len(inflight) >= n_buf:
                         hand_over()
+                    t_ = _time.perf_counter()
                     b = buf_free.get()
+                    stats["reader_wait_free_buffer_s"] = stats.get("reader_wait_free_buffer_s", 0.0) + _time.perf_counter() - t_
+                    t_ = _time.perf_counter()
                     if buf_ev[b] is not None:
                         buf_ev[b].synchronize()
+                    stats["reader_wait_h2d_s"] = stats.get("reader_wait_h2d_s", 0.0) + _time.perf_counter() - t_
                     batch = origins[i:i + spb]
 
                     def fill(j, o, b=b):
@@ -117,114 +132,133 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
             ready.put(e)
 
     with torch.cuda.device(dev):
-        # `prep` at high priority: its small kernels (resize, Canny, compaction) are dispatched ahead of the encoder's queued workgroups, so the
-        # host's wait for a batch's keep decisions does not sit behind a whole encoder chunk
-        prep, enc, h2d = torch.cuda.Stream(priority=-1), torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
-        cap = chunk + spb * kk
+        # ONE compute stream (the caller's) for resize / Canny / compaction AND the encoder: side-stream kernels that need a CU's LDS
+        # (Canny: 100 KB) were starved for milliseconds each behind the encoder's GEMM workgroups (128 KB LDS, thousands queued), so the
+        # small kernels of the NEXT chunk simply run between two encoder calls (~10 ms per 1020 tiles).  What overlaps with the encoder is
+        # everything that is not a kernel: the reader threads, the H2D copies (their own stream: DMA engines), the host's bookkeeping.
+        cs = torch.cuda.current_stream()
+        h2d = torch.cuda.Stream()
+        cap = 2 * chunk + spb * kk                     # the host learns keep decisions late (it never waits for them): room for two chunks
         acc = [torch.empty(cap, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
-        acc_ev: list = [None, None]                    # the encoder call that read this buffer has been queued up to this event
         count = torch.zeros(1, dtype=torch.int32, device=dev)
-        torch.cuda.current_stream().synchronize()
-        cur, n_have, ub = 0, 0, 0
-        pending: list = []                             # batches whose keep decisions the host has not read yet
-        cur_coords: list = []
-        feats_parts: list = []
-        coords_parts: list = []
+        # device-side ring, allocated once: per pinned buffer its device copy, the tiles cut from it and their slots
+        d_rgba = [torch.empty(spb, S, S, 4, dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+        d_tiles = [torch.empty(spb * kk, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+        d_slots = [torch.empty(spb * kk, dtype=torch.int32, device=dev) for _ in range(n_buf)]
+        d_ws = torch.empty(max(_lib.lib().amds_supertiles_to_tiles_workspace_bytes(spb, S, k, t), 4), dtype=torch.uint8, device=dev)
+        d_done: list = [None] * n_buf                  # the compute stream has finished with this slot's device buffers
         # host-side staging allocated ONCE (pinning memory is a driver call): per-batch keep slots, and the feature rows of the whole slide
         n_batches = (len(origins) + spb - 1) // spb
         slots_ring = torch.empty(n_batches, spb * kk, dtype=torch.int32).pin_memory()
         feat_dim = int(getattr(getattr(model, "cfg", None), "out_dim", 0) or getattr(getattr(model, "cfg", None), "dim", 0) or 0)
         feats_host = torch.empty(len(origins) * kk, feat_dim, dtype=torch.float16).pin_memory() if feat_dim else None
-        n_out = 0
         # micrometre coordinates of every tile of every foreground supertile, in yield order (tiling.py:237-246), vectorised
         og = np.asarray(origins, dtype=np.float64) * slide_mpp                                  # [n, 2] (x, y)
         off = np.array([(x * tile_size_um, y * tile_size_um) for y in range(k) for x in range(k)], dtype=np.float64)
         all_coords = (og[:, None, :] + off[None, :, :]).reshape(-1, 2)
+        cs.synchronize()
+        cur = 0
+        pending: list = []                             # batches whose keep decisions have not reached the host yet, in order
+        kept_coords: list = []                         # coordinates of the kept tiles, in order (== the order of the feature rows)
+        kept_known = 0                                 # kept tiles among the batches the host has heard from
+        encoded = 0                                    # tiles handed to the encoder so far
+        unknown = 0                                    # tiles of the batches in `pending` (each of them may or may not have been kept)
+        feats_parts: list = []
         batch_idx = 0
+        stats["setup_s"] = round(_time.perf_counter() - t_begin, 3)
         th = threading.Thread(target=producer, daemon=True)
         th.start()
 
-        def flush(final: bool) -> None:
-            nonlocal cur, n_have, ub, n_out
-            if pending:
-                t_ = _time.perf_counter()
-                pending[-1][1].synchronize()
-                stats["wait_gpu_s"] += _time.perf_counter() - t_
-                stats["host_syncs"] += 1
-                for slots_h, _ev, cu in pending:
-                    keep = slots_h.numpy() >= 0
-                    if (slots_h.numpy() == -2).any():
-                        raise RuntimeError("extract_slide: accumulation buffer overflow")
-                    cur_coords.append(cu[keep])
-                    n_have += int(keep.sum())
-                pending.clear()
-            while n_have >= chunk or (final and n_have > 0):
-                m = min(n_have, chunk)
-                allc = np.concatenate(cur_coords) if cur_coords else np.zeros((0, 2))
-                ev_prep = torch.cuda.Event()
-                ev_prep.record(prep)
-                with torch.cuda.stream(enc):
-                    enc.wait_event(ev_prep)
-                    f = model(acc[cur][:m]).detach().half()
-                    fh = feats_host[n_out:n_out + m] if feats_host is not None and f.shape[1] == feats_host.shape[1] else torch.empty(f.shape, dtype=torch.float16).pin_memory()
-                    fh.copy_(f, non_blocking=True)
-                    ev_enc = torch.cuda.Event()
-                    ev_enc.record(enc)
-                stats["encoder_calls"] += 1
-                n_out += m
-                feats_parts.append((fh, ev_enc, f))
-                coords_parts.append(allc[:m])
-                rem = n_have - m
-                other = 1 - cur
-                with torch.cuda.stream(prep):
-                    if acc_ev[other] is not None:
-                        prep.wait_event(acc_ev[other])
-                    if rem:
-                        acc[other][:rem].copy_(acc[cur][m:n_have])
-                    count.fill_(rem)
-                acc_ev[cur] = ev_enc
-                cur_coords[:] = [allc[m:]] if rem else []
-                cur, n_have = other, rem
-            ub = n_have
+        def absorb(block: bool) -> None:
+            nonlocal kept_known, unknown
+            while pending and (block or pending[0][1].query()):
+                slots_h, ev, cu = pending.pop(0)
+                unknown -= slots_h.shape[0]
+                if block:
+                    t_ = _time.perf_counter()
+                    ev.synchronize()
+                    stats["wait_gpu_s"] += _time.perf_counter() - t_
+                    stats["host_syncs"] += 1
+                sl = slots_h.numpy()
+                if (sl == -2).any():
+                    raise RuntimeError("extract_slide: accumulation buffer overflow")
+                keep = sl >= 0
+                kept_coords.append(cu[keep])
+                kept_known += int(keep.sum())
+
+        def encode(m: int) -> None:
+            """The first m accumulated tiles -> encoder -> pinned feature rows; the rest of the buffer moves to the front of the other one."""
+            nonlocal cur, encoded
+            if _TIMELINE is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(cs)
+                _TIMELINE.append(("enc_enqueue", _time.perf_counter() - t_begin, e0))
+            f = model(acc[cur][:m]).detach().half()
+            fh = feats_host[encoded:encoded + m] if feats_host is not None and f.shape[1] == feats_host.shape[1] else torch.empty(f.shape, dtype=torch.float16).pin_memory()
+            fh.copy_(f, non_blocking=True)
+            ev_f = torch.cuda.Event()
+            ev_f.record(cs)
+            feats_parts.append((fh, ev_f, f))
+            stats["encoder_calls"] += 1
+            other = 1 - cur
+            _lib.check(_lib.lib().amds_compact_shift_u8(acc[cur].data_ptr(), acc[other].data_ptr(), row_bytes, m, cap - m, count.data_ptr(), cs.cuda_stream),
+                       "compact_shift")
+            cur = other
+            encoded += m
 
         try:
-            while True:
+            reader_done = False
+            while not reader_done:
+                absorb(False)
+                while kept_known - encoded >= chunk:
+                    encode(chunk)
+                if kept_known - encoded + unknown + spb * kk > cap:      # the device buffer could overflow: wait for the oldest decisions
+                    absorb(True)                                           # (kept_known - encoded < chunk here, so pending is not empty)
+                    continue
                 t_ = _time.perf_counter()
-                item = ready.get()
+                try:
+                    item = ready.get(timeout=0.002)
+                except queue.Empty:
+                    stats["wait_reader_s"] += _time.perf_counter() - t_
+                    continue
                 stats["wait_reader_s"] += _time.perf_counter() - t_
                 if item is None:
+                    reader_done = True
                     break
                 if isinstance(item, BaseException):
                     raise item
                 b, batch = item
                 nb = len(batch)
-                with torch.cuda.stream(h2d):        # its own stream: a pinned buffer is free again as soon as ITS copy is done, not behind prep's kernels
-                    rgba = host[b][:nb].to(dev, non_blocking=True)
+                if _TIMELINE is not None:
+                    _TIMELINE.append(("batch_ready", _time.perf_counter() - t_begin, None))
+                with torch.cuda.stream(h2d):        # its own stream: a pinned buffer is free again as soon as ITS copy is done
+                    if d_done[b] is not None:
+                        h2d.wait_event(d_done[b])
+                    rgba = d_rgba[b][:nb]
+                    rgba.copy_(host[b][:nb], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(h2d)
                     buf_ev[b] = ev
                     buf_free.put(b)
-                with torch.cuda.stream(prep):
-                    prep.wait_event(ev)
-                    rgba.record_stream(prep)
-                    tiles = tiling.supertiles_to_tiles(rgba, k, t)
-                    frac = ops.tile_edge_fraction(tiles, 40, 100) if canny_cutoff is not None else None
-                    slots = torch.empty(tiles.shape[0], dtype=torch.int32, device=dev)
-                    _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(),
-                                                               float(canny_cutoff or 0.0), acc[cur].data_ptr(), cap, count.data_ptr(), slots.data_ptr(),
-                                                               tiles.shape[0], prep.cuda_stream), "compact_rows")
-                    slots_h = slots_ring[batch_idx, :tiles.shape[0]]
-                    slots_h.copy_(slots, non_blocking=True)
-                    ev2 = torch.cuda.Event()
-                    ev2.record(prep)
-                cu = all_coords[batch_idx * spb * kk: batch_idx * spb * kk + nb * kk]
+                cs.wait_event(ev)
+                tiles = tiling.supertiles_to_tiles(rgba, k, t, out=d_tiles[b], workspace=d_ws)
+                frac = ops.tile_edge_fraction(tiles, 40, 100) if canny_cutoff is not None else None
+                slots = d_slots[b][:tiles.shape[0]]
+                _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(),
+                                                           float(canny_cutoff or 0.0), acc[cur].data_ptr(), cap, count.data_ptr(), slots.data_ptr(),
+                                                           tiles.shape[0], cs.cuda_stream), "compact_rows")
+                slots_h = slots_ring[batch_idx, :tiles.shape[0]]
+                slots_h.copy_(slots, non_blocking=True)
+                ev2 = torch.cuda.Event()
+                ev2.record(cs)
+                d_done[b] = ev2
+                pending.append((slots_h, ev2, all_coords[batch_idx * spb * kk: batch_idx * spb * kk + nb * kk]))
                 batch_idx += 1
-                pending.append((slots_h, ev2, cu))
                 stats["tiles_seen"] += nb * kk
-                ub += nb * kk
-                if ub >= chunk:
-                    flush(False)
-            flush(True)
+                unknown += nb * kk
+            absorb(True)
+            while kept_known - encoded > 0:
+                encode(min(chunk, kept_known - encoded))
         finally:
             stop.set()
             while th.is_alive():                        # unblock a producer waiting for a free buffer
@@ -235,16 +269,19 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
                 buf_free.put(0)
                 th.join(timeout=0.05)
         t_ = _time.perf_counter()
-        for _fh, ev_enc, _f in feats_parts:
-            ev_enc.synchronize()
-        prep.synchronize()
+        for _fh, ev_f, _f in feats_parts:
+            ev_f.synchronize()
         stats["wait_gpu_s"] += _time.perf_counter() - t_
+        coords_parts = kept_coords
+        stats["pipeline_s"] = round(_time.perf_counter() - t_begin - stats["setup_s"], 3)
     if not feats_parts:
         return stats
     feats = torch.cat([p[0] for p in feats_parts])
     coords = np.concatenate(coords_parts)
     stats["tiles_kept"] = int(feats.shape[0])
+    t_ = _time.perf_counter()
     _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px)
+    stats["write_s"] = round(_time.perf_counter() - t_, 3)
     return stats
 
 

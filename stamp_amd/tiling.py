@@ -108,7 +108,8 @@ def _resize_tables_on_device(in_size: int, out_size: int, device_index: int):
     return torch.from_numpy(bounds).to(dev), torch.from_numpy(taps).to(dev), int(taps.shape[1])
 
 
-def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: int = 224) -> torch.Tensor:
+def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: int = 224, *, out: torch.Tensor | None = None,
+                        workspace: torch.Tensor | None = None) -> torch.Tensor:
     """u8 [n, S, S, 4] (what `read_region` returns, on the GPU) -> u8 [n * k * k, tile_px, tile_px, 3]: resize to k * tile_px, drop alpha,
     crop -- tiles of supertile i are rows i*k*k .. (i+1)*k*k - 1 in (y outer, x inner) order."""
     if not rgba.is_cuda:
@@ -120,10 +121,15 @@ def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: i
     k, t = int(tiles_per_side), int(tile_size_px)
     dev = rgba.device
     b_d, t_d, ksize = _resize_tables_on_device(S, k * t, dev.index if dev.index is not None else torch.cuda.current_device())
-    out = torch.empty(n * k * k, t, t, 3, dtype=torch.uint8, device=dev)
     lib = _lib.lib()
     nb = lib.amds_supertiles_to_tiles_workspace_bytes(n, S, k, t)
-    ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty(n * k * k, t, t, 3, dtype=torch.uint8, device=dev)
+    else:           # caller-owned destination (a pipeline's ring buffer): the first n*k*k tiles of it
+        if out.dtype != torch.uint8 or not out.is_contiguous() or out.shape[0] < n * k * k or tuple(out.shape[1:]) != (t, t, 3):
+            raise ValueError(f"out must be contiguous u8 [>= {n * k * k}, {t}, {t}, 3], got {tuple(out.shape)}")
+        out = out[: n * k * k]
+    ws = workspace if workspace is not None and workspace.numel() >= nb else torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
     _lib.check(lib.amds_supertiles_to_tiles_u8(rgba.data_ptr(), out.data_ptr(), n, S, k, t, b_d.data_ptr(), t_d.data_ptr(), ksize, ws.data_ptr(), nb,
                                                ops._stream()), "supertiles_to_tiles")
     return out

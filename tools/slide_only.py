@@ -27,4 +27,15 @@ with tempfile.TemporaryDirectory() as td:
     t0 = time.perf_counter()
     st = extract_slide(SyntheticSlide(side * 1024, side * 1024, seed=5), ex, Path(td) / "s.h5", slide_mpp=0.5, max_workers=workers, canny_cutoff=canny, supertiles_per_batch=spb)
     el = time.perf_counter() - t0
+import stamp_amd.preprocess as PP
+if len(sys.argv) > 6:
+    PP._TIMELINE = []
+    with tempfile.TemporaryDirectory() as td:
+        extract_slide(SyntheticSlide(side * 1024, side * 1024, seed=5), ex, Path(td) / "t.h5", slide_mpp=0.5, max_workers=workers, canny_cutoff=canny, supertiles_per_batch=spb)
+    torch.cuda.synchronize()
+    encs = [e for e in PP._TIMELINE if e[0] == "enc_enqueue"]
+    base = encs[0][2]
+    print("host time of encoder enqueue (s) / GPU start of that encoder call relative to the first (ms):")
+    print([(round(t, 3), round(base.elapsed_time(ev), 1)) for _, t, ev in encs])
+    print("batch arrivals (s):", [round(t, 3) for n, t, _ in PP._TIMELINE if n == "batch_ready"])
 print({"workers": workers, "spb": spb, **st, "seconds": round(el, 2), "tiles_per_s": round(st["tiles_kept"] / el, 1)})
