@@ -47,7 +47,7 @@ class SwinConfig:
 
 
 SWIN_PRESETS = {
-    "ctranspath": SwinConfig(),                                             # ctranspath.py:999-1010
+    "ctranspath": SwinConfig(),                                             # ctranspath.py:999-1009
     "test_swin_tiny": SwinConfig(img=112, depths=(2, 2), heads=(3, 6)),     # 28x28 -> 14x14 grid, 192-d
 }
 
