@@ -58,15 +58,19 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const T* __restrict_
 // DROP: dropout on the attention probabilities (amds_attention_fwd_train): with M = keep-mask * 1/(1-p) regenerated from the same
 // counters, dV = (M o P)^T dO, dP = M o (dO V^T), dS = P o (dP - Dq) where Dq = rowsum(dO o O) still holds for O = (M o P) V.
 template <typename T, bool ALIBI = false, bool DROP = false>
-__global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ dq_sum,
                                                                T* __restrict__ dqkv, int Tn, int H, const float* __restrict__ coords = nullptr,
                                                                const float* __restrict__ dist_scale = nullptr, uint64_t seed = 0,
                                                                uint32_t drop_stream = 0, uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
+    // ONE LDS stage (42 KB) and <= 256 registers: two workgroups per CU.  With two stages (84 KB, 288-304 registers) a CU held a single
+    // workgroup -- one wave per SIMD, every MFMA -> exp2 -> MFMA chain exposed -- and the kernel ran at 385 TFLOP/s against 620-630 for the
+    // forward and the dQ kernel, which always had two.  The next tile still travels global -> registers under the current tile's compute; it
+    // is written to the stage between two barriers, and the partner workgroup's MFMAs fill those.
     constexpr int STAGE = 2 * BT_ROW_BYTES + 2 * BT_TR_BYTES + 2 * BT_TILE * 4 + ((ALIBI || DROP) ? 2 * BT_TILE * 4 : 0);
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
     stage_store(0);
     __syncthreads();
     for (int j = 0; j < ntile; ++j) {
-        const int buf = j & 1;
+        const int buf = 0;
         if (j + 1 < ntile) stage_load(j + 1);
         const char* sQ = smem + buf * STAGE;
         const char* sG = sQ + BT_ROW_BYTES;
@@ -214,7 +218,8 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkdv_kernel(const T* __restri
                 }
             }
         }
-        if (j + 1 < ntile) stage_store(buf ^ 1);
+        __syncthreads();                                  // every wave is done reading the stage
+        if (j + 1 < ntile) stage_store(0);
         __syncthreads();
     }
     if (key < Tn) {

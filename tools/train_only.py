@@ -11,7 +11,7 @@ from stamp_amd.mil_train import HipMilVitTrainer  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 torch.manual_seed(1)
-mil = HipMil(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.0, use_alibi=False).eval()
+mil = HipMil(dim_output=2, dim_input=1024, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=float(sys.argv[2]) if len(sys.argv) > 2 else 0.25, use_alibi=False).eval()
 bags = torch.randn(64, 1024, 1024, generator=torch.Generator().manual_seed(1)).half().cuda()
 trn = HipMilVitTrainer(mil, device="cuda", total_steps=100, sched_interval="step")
 tg = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
