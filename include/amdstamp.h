@@ -77,7 +77,7 @@ int amds_ctx_device(const amds_ctx* ctx);
 /* Live per-kernel timing for bench.py's roofline line: while enabled on the context of the calling thread's current device, every
  * launch made through this library is bracketed by a pair of HIP events recorded on the launch stream.  kind: 0 = MFMA GEMM
  * (work = 2*M*N*K flops), 1 = ViT attention (flops), 2 = LayerNorm (bytes), 3 = im2col (bytes),
- * 4 = fp32-MFMA GEMM (flops).  amds_profile_read waits for the recorded events and returns the summed
+ * 4 = fp32-MFMA GEMM (flops), 5 = fp8-MFMA GEMM (flops).  amds_profile_read waits for the recorded events and returns the summed
  * duration, launch count and summed work of one kind since the last reset (at most 32768 launches). */
 int amds_profile_enable(amds_ctx* ctx, int on);
 int amds_profile_reset(amds_ctx* ctx);
@@ -147,6 +147,20 @@ int amds_swin_mlp192(float* x, int M, const void* packed_w, const float* fc1_b, 
 int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                  int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
                  const float* pos, int np, int T, int P, float acc_scale, void* stream);
+
+/* OPT-IN fp8 (OCP e4m3) GEMM on v_mfma_f32_16x16x128_f8f6f4 (gfx950: 5 PFLOP/s dense peak, twice the fp16 rate), fp32 accumulate -- the "fp8 MFMA
+ * weights" of BASELINE.json configs[4].  The reference computes in fp32 (src/stamp/preprocessing/__init__.py:324-325): e4m3 has 3 mantissa bits,
+ * so this is never the default and its accuracy delta is measured and stated (tests/test_gpu_fp8.py).
+ *   out[m][n] = act( (sum_k A8[m][k] * W8[n][k]) * rowscale[m] * colscale[n] + bias[n] )
+ * A8 [M][lda], W8 [N][ldw]: e4m3 bytes, K contiguous, K % 128 == 0, N % 256 == 0, pitches multiples of 16.  rowscale [M] (per-row activation
+ * scale, amds_quantize_rows_e4m3), colscale [N] (per-output-channel weight scale; for RESIDUAL the caller multiplies LayerScale into it and
+ * into bias), bias [N]: fp32, each may be NULL.  epi: AMDS_EPI_BIAS / AMDS_EPI_BIAS_GELU (out f16 [M][ldo]) or AMDS_EPI_RESIDUAL (out fp32
+ * [M][ldo], out += ...).  Replaces the same nn.Linear calls as amds_gemm when the host opts in. */
+int amds_gemm_fp8(const void* A8, long lda, const void* W8, long ldw, int M, int N, int K, int epi, void* out, long ldo, const float* bias,
+                  const float* colscale, const float* rowscale, void* stream);
+/* q[r][c] = e4m3(x[r][c] / scale[r]), scale[r] = max_c |x[r][c]| / 448 (1 for an all-zero row): per-row dynamic quantisation of an activation
+ * (f16 or fp32 rows, cols % 4 == 0, <= 8192) or, applied to a weight matrix [N][K], its per-output-channel scales. */
+int amds_quantize_rows_e4m3(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int cols, int in_dtype, void* stream);
 
 /* LayerNorm folded into the GEMMs around it (tile encoder, round 2).  timm's Block computes x += proj(attn(norm1(x))); x += fc2(act(fc1(
  * norm2(x)))) (reference extractors virchow2.py:29-30, uni2.py:32-43 -> timm VisionTransformer.forward).  With

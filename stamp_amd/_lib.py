@@ -97,6 +97,8 @@ PROTOTYPES = {
     "amds_layernorm": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp]),
     "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_ex": (_i, [_i, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "amds_gemm_fp8": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
+    "amds_quantize_rows_e4m3": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _vp]),
     "amds_gemm_lnfold": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amds_ln_rowstat": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "amds_ln_rowstat_diag": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),

@@ -252,7 +252,7 @@ __device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wa
 }  // namespace amds
 struct amds_ctx;
 namespace amds {
-enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_GEMM_F32 = 4, PROF_NKINDS = 5 };
+enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_GEMM_F32 = 4, PROF_GEMM_FP8 = 5, PROF_NKINDS = 6 };
 struct ProfRec { hipEvent_t a, b; int kind; double work; bool closed; };
 extern std::atomic<int> g_prof_any;            // number of contexts whose profiler is on (fast path: one relaxed load per launch)
 int prof_begin(int kind, double work, hipStream_t st, amds_ctx** ctx_out);

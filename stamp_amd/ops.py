@@ -152,6 +152,33 @@ def attention_alibi(qkv: torch.Tensor, coords: torch.Tensor, head_scale: torch.T
     return out
 
 
+def quantize_rows_e4m3(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """f16 / fp32 [rows, cols] -> (e4m3 bytes [rows, cols] as uint8, fp32 scale [rows]): q = e4m3(x / scale), scale = rowmax|x| / 448."""
+    _dev(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float16, torch.float32)
+    rows, cols = x.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_quantize_rows_e4m3(_p(x), x.stride(0), _p(q), cols, _p(sc), rows, cols, _DT[x.dtype], _stream()), "quantize_rows_e4m3")
+    return q, sc
+
+
+def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, epi: int, *, rowscale=None, colscale=None, bias=None, out=None) -> torch.Tensor:
+    """OPT-IN fp8 GEMM: act((a8 @ w8^T) * rowscale[:, None] * colscale[None, :] + bias); a8 [M, K], w8 [N, K] e4m3 bytes (uint8).
+    epi EPI_BIAS / EPI_BIAS_GELU -> f16 [M, N]; EPI_RESIDUAL -> `out` fp32 [M, N] += ..."""
+    _dev(a8, w8, rowscale, colscale, bias, out)
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.stride(1) == 1
+    M, K = a8.shape
+    N = w8.shape[0]
+    if epi == _lib.EPI_RESIDUAL:
+        assert out is not None and out.dtype == torch.float32 and out.shape == (M, N)
+    elif out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=a8.device)
+    _lib.check(_lib.lib().amds_gemm_fp8(_p(a8), a8.stride(0), _p(w8), w8.stride(0), M, N, K, epi, _p(out), out.stride(0), _p(bias), _p(colscale), _p(rowscale),
+                                        _stream()), "gemm_fp8")
+    return out
+
+
 def attention_cls_f32(q: torch.Tensor, qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64) -> torch.Tensor:
     """ONE fp32 query row per tile (q [B, H*head_dim]) against the stored keys / values of all T tokens (packed act-dtype qkv) -> fp32 [B, H*hd]."""
     _dev(q, qkv)
