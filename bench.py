@@ -49,6 +49,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--swin-chunk", type=int, default=1024, help="tiles per internal chunk of the CTransPath forward (5.2 MB of workspace per tile)")
     ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--overlap", type=int, default=0, help="1 = two chunks in flight on two streams")
+    ap.add_argument("--fp8", action="store_true", help="headline run with HipViT(fp8=True): the blocks' Linears on the fp8 MFMA (opt-in, ~6 %% feature error)")
     ap.add_argument("--exact", action="store_true", help="headline run with HipViT(exact=True): the class-token rows also on an exact-fp32 stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (for a ViT-only rocprofv3 kernel trace)")
@@ -595,7 +596,7 @@ def main() -> None:
     else:
         cfg = PRESETS[a.model]
         sd = random_vit_state_dict(cfg, seed=0, init="moderate")
-        model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk, exact=a.exact)
+        model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk, exact=a.exact, fp8=a.fp8)
         model.overlap = bool(a.overlap)
     g = torch.Generator().manual_seed(1234 + ctx.rank)
     tiles = torch.randint(0, 256, (a.tiles, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g).to(ctx.device)
@@ -665,7 +666,7 @@ def main() -> None:
                                 "synthetic 224x224x3 u8 tiles resident in HBM, seeded weights, fp16 768-d features out") if is_swin else
                                ("BASELINE.json configs[1]: ViT-L/14 (dim 1024, depth 24, 16 heads, 257 tokens, GELU MLP, "
                                 "LayerScale) tile extraction on synthetic 224x224x3 u8 tiles resident in HBM, "
-                                "random-init weights, fp16 CLS features out" + (", exact class-token rows" if a.exact else "")),
+                                "random-init weights, fp16 CLS features out" + (", exact class-token rows" if a.exact else "") + (", OPT-IN fp8 (e4m3) GEMM operands" if a.fp8 else "")),
                    "model": a.model, "tiles_per_step_per_gpu": a.tiles, "chunk": a.swin_chunk if is_swin else a.chunk,
                    "operands": a.act, "accumulate": "f32", "residual_stream": "f32",
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
@@ -717,6 +718,33 @@ def main() -> None:
             line["slide_synthetic"]["vs_min_of_reader_and_encoder"] = round(line["slide_synthetic"]["value"] / min(value, line["slide_synthetic"]["reader_only"]), 4)
         except Exception as e:
             line["slide_synthetic"] = {"error": repr(e)[:300]}
+    if single and not is_swin and not a.exact and not a.fp8 and cfg.mlp == "gelu":
+        # the opt-in fp8 variant (BASELINE.json configs[4]: "fp8 MFMA weights") on the same workload: HipViT(fp8=True), csrc/gemm_fp8.hip; its own
+        # roofline fraction is against the 5 PFLOP/s dense fp8 peak; what it costs in accuracy is in tests/test_gpu_fp8.py / DESIGN.md section 5
+        try:
+            m8 = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk, fp8=True)
+            m8(tiles)
+            lib.amds_profile_reset(actx)
+            lib.amds_profile_enable(actx, 1)
+            torch.cuda.synchronize()
+            t08 = time.perf_counter()
+            for _ in range(3):
+                f8 = m8(tiles)
+            torch.cuda.synchronize()
+            el8 = time.perf_counter() - t08
+            lib.amds_profile_enable(actx, 0)
+            _lib.check(lib.amds_profile_read(actx, 5, C.byref(ms), C.byref(n), C.byref(work)), "profile_read")
+            tf8 = work.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+            rel8 = ((f8.float() - out.float()).norm() / out.float().norm()).item()
+            line["fp8_mode"] = {"metric": "tiles/s with the blocks' four Linears on the fp8 MFMA (e4m3 operands, per-row / per-channel scales; OPT-IN, never the default)",
+                                "value": round(3 * a.tiles / el8, 1), "unit": "tiles/s", "vs_default": round(3 * a.tiles / el8 / value, 4),
+                                "rel_l2_vs_default_features": float(f"{rel8:.3e}"),
+                                "roofline": {"kernel": "gemm_fp8_kernel (v_mfma_f32_16x16x128_f8f6f4)", "bound": "mfma", "achieved": round(tf8, 1), "peak": 5000.0,
+                                             "unit": "TFLOP/s", "frac": round(tf8 / 5000.0, 4), "launches": n.value},
+                                "finite": bool(torch.isfinite(f8.float()).all())}
+            del m8, f8
+        except Exception as e:
+            line["fp8_mode"] = {"error": repr(e)[:300]}
     if single:
         try:
             line["drop_in_b64"] = drop_in_b64_leg(model, cfg, ctx.device)

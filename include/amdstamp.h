@@ -277,6 +277,17 @@ typedef struct {
     const float* fc2_w;  const float* fc2_b;   /* [dim][exact_hidden], [dim]: mlp.fc2, rows multiplied by ls2          */
 } amds_vit_exact_block;
 
+/* OPT-IN fp8 GEMMs of the blocks (amds_gemm_fp8; GELU-MLP models; never the default -- see its comment).  When amds_vit_weights.fp8_host
+ * is set, the blocks' weights must be the PLAIN packing (no LayerNorm fold: ln1_* / ln2_* and the biases are read), and every Linear of a
+ * block runs as  LayerNorm / attention / GELU output (f16) -> amds_quantize_rows_e4m3 (per-row scale) -> amds_gemm_fp8  with these e4m3 weights
+ * and fp32 per-output-channel vectors (cs = weight scale, for proj / fc2 times LayerScale; *_b = bias times LayerScale). */
+typedef struct {
+    const void* qkv_w8;  const float* qkv_cs;                        /* [3*dim][dim] e4m3, [3*dim] */
+    const void* proj_w8; const float* proj_cs; const float* proj_b;  /* [dim][dim], [dim], [dim] */
+    const void* fc1_w8;  const float* fc1_cs;                        /* [hidden][dim], [hidden] */
+    const void* fc2_w8;  const float* fc2_cs;  const float* fc2_b;   /* [dim][hidden], [dim], [dim] */
+} amds_vit_fp8_block;
+
 typedef struct {
     const void*  patch_w;    /* [dim][kp] act dtype; conv weight flattened (c,i,j), divided by std[c]; kp = roundup(3*p*p, 64) */
     const float* patch_b;    /* [dim] conv bias - sum_k W[k]*mean[c]/std[c] */
@@ -293,6 +304,7 @@ typedef struct {
     int patch_lo_shift;
     const amds_vit_exact_block* exact_host;   /* HOST array of `depth` structs, or NULL (off) */
     int exact_hidden;                         /* the MLP's real (unpadded) hidden width, e.g. 3416 for Virchow2 (cfg.hidden is padded) */
+    const amds_vit_fp8_block* fp8_host;       /* HOST array of `depth` structs, or NULL (off) */
 } amds_vit_weights;
 
 /* ---- weight packing in the library (so that a non-Python host can use the tile encoder through this ABI alone) -------------------------

@@ -34,11 +34,15 @@ class VitExactBlock(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q_w", "q_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
+class VitFp8Block(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w8", "qkv_cs", "proj_w8", "proj_cs", "proj_b", "fc1_w8", "fc1_cs", "fc2_w8", "fc2_cs", "fc2_b")]
+
+
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p),
                 ("pos_patch", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("patch_lo_shift", C.c_int),
-                ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int)]
+                ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int), ("fp8_host", C.POINTER(VitFp8Block))]
 
 
 class VitHostBlock(C.Structure):

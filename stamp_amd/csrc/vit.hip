@@ -21,7 +21,7 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
 
 struct VitPlan {
     int np, T, kp, dim, hidden;
-    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, total;
+    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, off_q8, off_q8s, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -62,6 +62,9 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     p->off_oc = o; o += align256(cls);
     p->off_uc = o; o += align256((size_t)batch * 2 * c->hidden * 4);
     p->off_diag = o; o += 256;          // int32[2] range diagnostics of the folded LayerNorms (amds_ln_rowstat_diag)
+    // opt-in fp8 GEMMs: the quantised A operand (e4m3 bytes, widest = the MLP hidden) and its per-row scales
+    p->off_q8 = o;  o += align256(rows * (size_t)(c->hidden > c->dim ? c->hidden : c->dim));
+    p->off_q8s = o; o += align256(rows * 4);
     p->total = o;
     return AMDS_OK;
 }
@@ -113,6 +116,17 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                          w->blocks_host[l].ln1_w && w->blocks_host[l].ln1_b && w->blocks_host[l].ln2_w && w->blocks_host[l].ln2_b,
                          "vit: exact block %d: incomplete weights", l);
     }
+    // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
+    const amds_vit_fp8_block* f8 = w->fp8_host;
+    if (f8) {
+        AMDS_REQUIRE(!fold && !ex && c->mlp_kind == 0 && dt == AMDS_F16, "vit: the fp8 path needs the plain packing (no LayerNorm fold, no exact rows), a GELU MLP and fp16 activations");
+        AMDS_REQUIRE(D % 256 == 0 && Hd % 256 == 0, "vit: the fp8 path needs dim %% 256 == 0 and hidden %% 256 == 0");
+        for (int l = 0; l < c->depth; ++l)
+            AMDS_REQUIRE(f8[l].qkv_w8 && f8[l].qkv_cs && f8[l].proj_w8 && f8[l].proj_cs && f8[l].proj_b && f8[l].fc1_w8 && f8[l].fc1_cs && f8[l].fc2_w8 && f8[l].fc2_cs && f8[l].fc2_b,
+                         "vit: fp8 block %d: incomplete weights", l);
+    }
+    char* q8 = ws + pl.off_q8;
+    float* q8s = reinterpret_cast<float*>(ws + pl.off_q8s);
     float* xc = reinterpret_cast<float*>(ws + pl.off_xc);
     float* hc = reinterpret_cast<float*>(ws + pl.off_hc);
     float* qc = reinterpret_cast<float*>(ws + pl.off_qc);
@@ -179,6 +193,22 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
             const bool last = l + 1 == c->depth;
             const float* ls1 = c->layerscale ? b.ls1 : nullptr;
             const float* ls2 = c->layerscale ? b.ls2 : nullptr;
+            if (f8) {      // every Linear: f16 rows -> per-row e4m3 -> fp8 MFMA GEMM with (row scale x channel scale) in the epilogue
+                char* a8 = q8 + (size_t)r0 * (Hd > D ? Hd : D);
+                float* as = q8s + r0;
+                AMDS_TRY(amds_layernorm(xq, D, b.ln1_w, b.ln1_b, hq, D, n, D, c->ln_eps, dt, s));
+                AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
+                AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].qkv_w8, D, n, 3 * D, D, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, f8[l].qkv_cs, as, s));
+                AMDS_TRY(amds_attention_vit_hd(qkvq, hq, q.nt, T, c->heads, D / c->heads, dt, s));
+                AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
+                AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].proj_w8, D, n, D, D, AMDS_EPI_RESIDUAL, xq, D, f8[l].proj_b, f8[l].proj_cs, as, s));
+                AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, hq, D, n, D, c->ln_eps, dt, s));
+                AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
+                AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].fc1_w8, D, n, Hd, D, AMDS_EPI_BIAS_GELU, mlpq, Hd, b.fc1_b, f8[l].fc1_cs, as, s));
+                AMDS_TRY(amds_quantize_rows_e4m3(mlpq, Hd, a8, Hd, as, n, Hd, AMDS_F16, s));
+                AMDS_TRY(amds_gemm_fp8(a8, Hd, f8[l].fc2_w8, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, f8[l].fc2_b, f8[l].fc2_cs, as, s));
+                continue;
+            }
             if (fold) {
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.qkv_w, D, n, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rs,
                                           b.qkv_colsum, s));

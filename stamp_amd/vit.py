@@ -171,7 +171,7 @@ class HipViT(nn.Module):
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
                  act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None,
-                 patch_split: bool | None = None, exact: bool = False) -> None:
+                 patch_split: bool | None = None, exact: bool = False, fp8: bool = False) -> None:
         """exact=True (opt-in): the class-token row -- the only row the reference stores, `model(tiles)[:, 0].half()` -- is ALSO carried on
         an exact-fp32 class stream (fp32 MFMA, the original un-folded fp32 weights: include/amdstamp.h `amds_vit_exact_block`,
         csrc/vit_exact.hip) and written over the main path's class rows after every sub-layer.  Costs the fp32 weights in HBM (4 bytes per
@@ -205,7 +205,14 @@ class HipViT(nn.Module):
             patch_split = os.environ.get("AMDS_VIT_PATCH_SPLIT", "1") != "0"
         self.patch_lo_shift = (11 if act_dtype == torch.float16 else 8) if patch_split else 0
         self.exact = bool(exact)
+        self.fp8 = bool(fp8)
+        if self.fp8:
+            if cfg.mlp != "gelu" or act_dtype != torch.float16 or exact:
+                raise ValueError("fp8=True needs a GELU-MLP preset, fp16 activations and exact=False")
+            self.ln_fold = False             # the fp8 chain normalises, THEN quantises: plain packing
         self._pack(state_dict)
+        if self.fp8:
+            self._pack_fp8(state_dict)
 
     # -- weight packing (one time): in the library (amds_vit_pack, csrc/vit_pack.hip) -------------------------------
     def _pack(self, sd: dict[str, torch.Tensor]) -> None:
@@ -230,6 +237,32 @@ class HipViT(nn.Module):
                                    self._exact, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "vit_pack")
         del keep
+
+    def _pack_fp8(self, sd: dict[str, torch.Tensor]) -> None:
+        """e4m3 weights with per-output-channel scales (the library's own row quantiser applied to the weight rows), LayerScale multiplied into
+        the channel vectors of proj / fc2."""
+        c, dev = self.cfg, self.device_
+        self._fp8_keep: list[torch.Tensor] = []
+        self._fp8 = (_lib.VitFp8Block * c.depth)()
+
+        def keep(t):
+            self._fp8_keep.append(t)
+            return t.data_ptr()
+        for i in range(c.depth):
+            g = lambda n: sd[f"blocks.{i}.{n}"].detach().to(dev, torch.float32).contiguous()  # noqa: E731
+            ls1 = g("ls1.gamma") if c.layerscale else torch.ones(c.dim, device=dev)
+            ls2 = g("ls2.gamma") if c.layerscale else torch.ones(c.dim, device=dev)
+            f = self._fp8[i]
+            w8, sw = ops.quantize_rows_e4m3(g("attn.qkv.weight"))
+            f.qkv_w8, f.qkv_cs = keep(w8), keep(sw)
+            w8, sw = ops.quantize_rows_e4m3(g("attn.proj.weight"))
+            f.proj_w8, f.proj_cs, f.proj_b = keep(w8), keep((sw * ls1).contiguous()), keep((g("attn.proj.bias") * ls1).contiguous())
+            w8, sw = ops.quantize_rows_e4m3(g("mlp.fc1.weight"))
+            f.fc1_w8, f.fc1_cs = keep(w8), keep(sw)
+            w8, sw = ops.quantize_rows_e4m3(g("mlp.fc2.weight"))
+            f.fc2_w8, f.fc2_cs, f.fc2_b = keep(w8), keep((sw * ls2).contiguous()), keep((g("mlp.fc2.bias") * ls2).contiguous())
+        self._w_c.fp8_host = C.cast(self._fp8, C.POINTER(_lib.VitFp8Block))
+        torch.cuda.synchronize(dev)
 
     # -- forward ----------------------------------------------------------------------------------
     def _workspace(self, chunk: int) -> torch.Tensor:

@@ -22,8 +22,24 @@ from stamp_amd.vit import PRESETS, random_vit_state_dict  # noqa: E402
 SITES = ("w_patch", "a_qkv", "w_qkv", "qkv", "p", "o", "w_proj", "a_fc1", "w_fc1", "u", "w_fc2")
 
 
-def forward(tiles, sd, cfg, on: set, dt=torch.float16, cls_exact: bool = False, dev="cpu"):
-    r = lambda t, s: t.to(dt).float() if s in on else t  # noqa: E731
+def _q8(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """e4m3 with one scale per slice along `dim` (rows of an activation, output channels of a weight): amds_quantize_rows_e4m3's arithmetic"""
+    amax = t.abs().amax(dim=dim, keepdim=True)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (t / s).to(torch.float8_e4m3fn).float() * s
+
+
+def forward(tiles, sd, cfg, on: set, dt=torch.float16, cls_exact: bool = False, dev="cpu", fp8: bool = False):
+    """fp8=True: the four GEMMs of every block take e4m3 operands (activations scaled per row, weights per output channel -- what
+    amds_gemm_fp8 multiplies), everything else as the fp16 path."""
+    def r(t, s):
+        if s not in on:
+            return t
+        if fp8 and s in ("a_qkv", "a_fc1", "o", "u"):
+            return _q8(t, -1)
+        if fp8 and s in ("w_qkv", "w_fc1", "w_proj", "w_fc2"):
+            return _q8(t, 1)
+        return t.to(dt).float()
     D, p, H = cfg.dim, cfg.patch, cfg.heads
     hd = D // H
     B = tiles.shape[0]
@@ -48,6 +64,12 @@ def forward(tiles, sd, cfg, on: set, dt=torch.float16, cls_exact: bool = False, 
         """Linear(LayerNorm(x)) the way the folded kernels do it: A = round(x), W' = round(W gamma), statistics in fp32."""
         mean = x.mean(-1, keepdim=True)
         rstd = (x.var(-1, unbiased=False, keepdim=True) + cfg.ln_eps).rsqrt()
+        if fp8:      # no fold: the NORMALISED rows are quantised (LayerNorm -> quantise -> GEMM)
+            h = (x - mean) * rstd * gamma + beta
+            y = F.linear(r(h, sa), r(w, sw), b)
+            if cls_exact:
+                y[:, 0] = F.linear(h[:, 0], w, b)
+            return y
         wf = r(w * gamma[None, :], sw)
         y = (F.linear(r(x, sa), wf) - mean * wf.sum(1)) * rstd + (b + w @ beta)
         if cls_exact:
@@ -107,9 +129,11 @@ def main():
             print(f"{label:28s} tokens {rel(t, ref):.3e}   cls row (fp32) {rel(t[:, 0], ref[:, 0]):.3e}   cls row (fp16 both) {cls16:.3e}", flush=True)
 
         print(f"{name}: {n} tiles, seed {seed}, device {dev}")
-        report("all sites (the HIP path)", set(SITES))
-        report("all, class-token rows exact", set(SITES), cls_exact=True)
+        report("all sites (round 2's path)", set(SITES))
+        report("all but w_patch (the default path)", set(SITES) - {"w_patch"})
+        report("same, class-token rows exact", set(SITES) - {"w_patch"}, cls_exact=True)
         if quick:
+            report("fp8 GEMM operands (e4m3)", set(SITES) - {"w_patch"}, fp8=True)
             return
         for s in SITES:
             report("only " + s, {s})
@@ -118,6 +142,7 @@ def main():
         report("all but o, u", set(SITES) - {"o", "u"})
         report("all but a_*, o, u", set(SITES) - {"a_qkv", "a_fc1", "o", "u"})
         report("all but qkv, p", set(SITES) - {"qkv", "p"})
+        report("fp8 GEMM operands (e4m3)", set(SITES) - {"w_patch"}, fp8=True)
 
 
 if __name__ == "__main__":
