@@ -161,6 +161,19 @@ int amds_gemm_fp8(const void* A8, long lda, const void* W8, long ldw, int M, int
 /* q[r][c] = e4m3(x[r][c] / scale[r]), scale[r] = max_c |x[r][c]| / 448 (1 for an all-zero row): per-row dynamic quantisation of an activation
  * (f16 or fp32 rows, cols % 4 == 0, <= 8192) or, applied to a weight matrix [N][K], its per-output-channel scales. */
 int amds_quantize_rows_e4m3(const void* x, long ldx, void* q, long ldq, float* scale, int rows, int cols, int in_dtype, void* stream);
+/* Producers of the fp8 path that spare a 16-bit round trip (all opt-in, like amds_gemm_fp8):
+ *   amds_layernorm_quant_e4m3  nn.LayerNorm of fp32 rows fused with the row quantisation: q / scale as amds_quantize_rows_e4m3 of the normalised row,
+ *                              rownorm[r] (optional) = its L2 norm
+ *   amds_row_bound_scale       us[r] = (rownorm[r] * c0 + c1) / 448 -- with c0 = max_n ||w_n||, c1 = max_n |b_n| a scale that provably covers
+ *                              |Linear(h_r)| (Cauchy-Schwarz) and |gelu(Linear(h_r))|: the OUTPUT row scale of ...
+ *   amds_gemm_fp8_out8         ... amds_gemm_fp8 (BIAS / BIAS_GELU) writing e4m3 directly: out8[m][n] = e4m3(value / out_rowscale[m]); a bounding
+ *                              scale instead of the row maximum costs fp8 nothing in relative precision (it is a floating-point format: only the
+ *                              subnormal floor moves up), and no kernel has to re-read a 16-bit copy to find the maximum */
+int amds_layernorm_quant_e4m3(const float* x, long ldx, const float* gamma, const float* beta, float eps, void* q, long ldq, float* scale,
+                              float* rownorm, int rows, int cols, void* stream);
+int amds_row_bound_scale(const float* rownorm, float c0, float c1, float* us, int rows, void* stream);
+int amds_gemm_fp8_out8(const void* A8, long lda, const void* W8, long ldw, int M, int N, int K, int epi, void* out8, long ldo8,
+                       const float* out_rowscale, const float* bias, const float* colscale, const float* rowscale, void* stream);
 
 /* LayerNorm folded into the GEMMs around it (tile encoder, round 2).  timm's Block computes x += proj(attn(norm1(x))); x += fc2(act(fc1(
  * norm2(x)))) (reference extractors virchow2.py:29-30, uni2.py:32-43 -> timm VisionTransformer.forward).  With
@@ -285,6 +298,7 @@ typedef struct {
     const void* qkv_w8;  const float* qkv_cs;                        /* [3*dim][dim] e4m3, [3*dim] */
     const void* proj_w8; const float* proj_cs; const float* proj_b;  /* [dim][dim], [dim], [dim] */
     const void* fc1_w8;  const float* fc1_cs;                        /* [hidden][dim], [hidden] */
+    float fc1_wnorm_max; float fc1_babs_max;                         /* max_n ||fc1.weight[n]||_2 and max_n |fc1.bias[n]|: the bound behind amds_row_bound_scale */
     const void* fc2_w8;  const float* fc2_cs;  const float* fc2_b;   /* [dim][hidden], [dim], [dim] */
 } amds_vit_fp8_block;
 

@@ -35,7 +35,8 @@ class VitExactBlock(C.Structure):
 
 
 class VitFp8Block(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("qkv_w8", "qkv_cs", "proj_w8", "proj_cs", "proj_b", "fc1_w8", "fc1_cs", "fc2_w8", "fc2_cs", "fc2_b")]
+    _fields_ = ([(n, C.c_void_p) for n in ("qkv_w8", "qkv_cs", "proj_w8", "proj_cs", "proj_b", "fc1_w8", "fc1_cs")] + [("fc1_wnorm_max", C.c_float), ("fc1_babs_max", C.c_float)]
+                + [(n, C.c_void_p) for n in ("fc2_w8", "fc2_cs", "fc2_b")])
 
 
 class VitWeights(C.Structure):
@@ -102,6 +103,9 @@ PROTOTYPES = {
     "amds_gemm": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_ex": (_i, [_i, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "amds_gemm_fp8": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
+    "amds_layernorm_quant_e4m3": (_i, [_vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp, _i, _i, _vp]),
+    "amds_row_bound_scale": (_i, [_vp, _f, _f, _vp, _i, _vp]),
+    "amds_gemm_fp8_out8": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "amds_quantize_rows_e4m3": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _vp]),
     "amds_gemm_lnfold": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amds_ln_rowstat": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),

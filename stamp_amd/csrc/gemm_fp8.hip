@@ -38,6 +38,10 @@ struct Fp8Epi {
     const float* bias;         // [N] or null
     const float* colscale;     // [N] or null (weight scale per output channel; for RESIDUAL the caller multiplies LayerScale in)
     const float* rowscale;     // [M] or null (activation scale per row)
+    // BIAS / BIAS_GELU only: e4m3 output instead of f16 -- out8[m][n] = e4m3(value / out_rowscale[m]) (the A operand of the next fp8 GEMM)
+    uint8_t* out8 = nullptr;
+    long ldo8 = 0;
+    const float* out_rowscale = nullptr;
 };
 
 template <int EPI>
@@ -224,11 +228,29 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const uint8_t* __restri
                     v[u] = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
                     if ((u >> 2) & 1) v[u] = u32x4{v[u][2], v[u][3], v[u][0], v[u][1]};
                 }
+                if (ep.out8) {      // 8 f16 values of one row -> 8 e4m3 bytes, scaled by the row's output scale
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
-                    const int chunk = l31 ^ (row & 31);
-                    if (m0 + row < M) *reinterpret_cast<u32x4*>(reinterpret_cast<f16*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + chunk * 8) = v[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                        const int chunk = l31 ^ (row & 31);
+                        if (m0 + row < M) {
+                            const float inv = 1.0f / ep.out_rowscale[m0 + row];
+                            const f16x8 h = __builtin_bit_cast(f16x8, v[u]);
+                            int w0 = 0, w1 = 0;
+                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[0] * inv, (float)h[1] * inv, w0, false);
+                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[2] * inv, (float)h[3] * inv, w0, true);
+                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[4] * inv, (float)h[5] * inv, w1, false);
+                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[6] * inv, (float)h[7] * inv, w1, true);
+                            *reinterpret_cast<u32x2*>(ep.out8 + (long)(m0 + row) * ep.ldo8 + n0 + chunk * 8) = u32x2{(unsigned)w0, (unsigned)w1};
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
+                        const int chunk = l31 ^ (row & 31);
+                        if (m0 + row < M) *reinterpret_cast<u32x4*>(reinterpret_cast<f16*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 + chunk * 8) = v[u];
+                    }
                 }
             } else {
                 f32x4 v[8], o[8];
@@ -311,9 +333,116 @@ __global__ void __launch_bounds__(256) quant_rows_e4m3_kernel(const TI* __restri
     if (lane == 0) scale[row] = s;
 }
 
+// LayerNorm (nn.LayerNorm semantics, two-pass statistics in fp32 as layernorm_kernel) fused with the row quantisation: x fp32 row -> e4m3 row +
+// scale (+ the normalised row's L2 norm, from which the caller bounds the next Linear's outputs).  One wave per row, row in registers.
+template <int MAXV>
+__global__ void __launch_bounds__(256) layernorm_quant_e4m3_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps, uint8_t* __restrict__ q, long ldq,
+                                                                   float* __restrict__ scale, float* __restrict__ rownorm, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ldx;
+    const int nv = cols >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                qq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(qq) / (float)cols + eps);
+    float mx = 0.f, n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4), b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                mx = fmaxf(mx, fabsf(v[i][e]));
+                n2 = fmaf(v[i][e], v[i][e], n2);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    n2 = wave_sum(n2);
+    const float sc = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) *reinterpret_cast<uint32_t*>(q + (long)row * ldq + c * 4) = pack4_e4m3(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
+    }
+    if (lane == 0) {
+        scale[row] = sc;
+        if (rownorm) rownorm[row] = sqrtf(n2);
+    }
+}
+
+// us[m] = (rownorm[m] * c0 + c1) / 448: a per-row scale that provably covers |Linear(h_m)| <= ||h_m|| max_n ||w_n|| + max |b| (Cauchy-Schwarz) and
+// therefore |gelu(.)| too -- the output scale of a GEMM whose epilogue writes e4m3 directly (no second pass over a 16-bit copy to find the row maximum)
+__global__ void row_bound_scale_kernel(const float* __restrict__ rownorm, float c0, float c1, float* __restrict__ us, int rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) us[r] = fmaxf(rownorm[r] * c0 + c1, 1e-30f) * (1.0f / 448.0f);
+}
+
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" int amds_layernorm_quant_e4m3(const float* x, long ldx, const float* gamma, const float* beta, float eps, void* q, long ldq, float* scale,
+                                         float* rownorm, int rows, int cols, void* stream) {
+    AMDS_REQUIRE(x && gamma && beta && q && scale && rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048 && ldx >= cols && ldq >= cols && ldx % 4 == 0 && ldq % 4 == 0,
+                 "amds_layernorm_quant_e4m3: bad arguments (cols %% 4 == 0, cols <= 2048)");
+    if (rows == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_LN, (double)rows * cols * 5.0, st);
+    if (cols <= 1024) hipLaunchKernelGGL((layernorm_quant_e4m3_kernel<4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, (uint8_t*)q, ldq, scale, rownorm, rows, cols);
+    else hipLaunchKernelGGL((layernorm_quant_e4m3_kernel<8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, (uint8_t*)q, ldq, scale, rownorm, rows, cols);
+    AMDS_LAUNCH_CHECK("layernorm_quant_e4m3_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_row_bound_scale(const float* rownorm, float c0, float c1, float* us, int rows, void* stream) {
+    AMDS_REQUIRE(rownorm && us && rows >= 0, "amds_row_bound_scale: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    hipLaunchKernelGGL(row_bound_scale_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, rownorm, c0, c1, us, rows);
+    AMDS_LAUNCH_CHECK("row_bound_scale_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_gemm_fp8_out8(const void* A8, long lda, const void* W8, long ldw, int M, int N, int K, int epi, void* out8, long ldo8,
+                                  const float* out_rowscale, const float* bias, const float* colscale, const float* rowscale, void* stream) {
+    AMDS_REQUIRE(A8 && W8 && out8 && out_rowscale, "amds_gemm_fp8_out8: null pointer");
+    AMDS_REQUIRE(epi == AMDS_EPI_BIAS || epi == AMDS_EPI_BIAS_GELU, "amds_gemm_fp8_out8: epilogue %d (BIAS or BIAS_GELU)", epi);
+    AMDS_REQUIRE(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 128 == 0, "amds_gemm_fp8_out8: N %% 256 == 0 and K %% 128 == 0 required (M=%d N=%d K=%d)", M, N, K);
+    AMDS_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldo8 >= N && ldo8 % 8 == 0, "amds_gemm_fp8_out8: pitches");
+    AMDS_REQUIRE((((uintptr_t)A8 | (uintptr_t)W8) & 15) == 0 && ((uintptr_t)out8 & 7) == 0, "amds_gemm_fp8_out8: alignment");
+    Fp8Epi ep{nullptr, 0, bias, colscale, rowscale};
+    ep.out8 = reinterpret_cast<uint8_t*>(out8);
+    ep.ldo8 = ldo8;
+    ep.out_rowscale = out_rowscale;
+    hipStream_t st = (hipStream_t)stream;
+    if (epi == AMDS_EPI_BIAS) return launch_fp8<AMDS_EPI_BIAS>(A8, lda, W8, ldw, M, N, K, ep, st);
+    return launch_fp8<AMDS_EPI_BIAS_GELU>(A8, lda, W8, ldw, M, N, K, ep, st);
+}
 
 extern "C" int amds_gemm_fp8(const void* A8, long lda, const void* W8, long ldw, int M, int N, int K, int epi, void* out, long ldo, const float* bias,
                              const float* colscale, const float* rowscale, void* stream) {

@@ -21,7 +21,7 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
 
 struct VitPlan {
     int np, T, kp, dim, hidden;
-    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, off_q8, off_q8s, total;
+    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, off_q8, off_q8s, off_q8n, off_q8u, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -65,6 +65,8 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     // opt-in fp8 GEMMs: the quantised A operand (e4m3 bytes, widest = the MLP hidden) and its per-row scales
     p->off_q8 = o;  o += align256(rows * (size_t)(c->hidden > c->dim ? c->hidden : c->dim));
     p->off_q8s = o; o += align256(rows * 4);
+    p->off_q8n = o; o += align256(rows * 4);          // L2 norms of the normalised rows entering fc1
+    p->off_q8u = o; o += align256(rows * 4);          // the bounding row scales of fc1's e4m3 output
     p->total = o;
     return AMDS_OK;
 }
@@ -127,6 +129,8 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     }
     char* q8 = ws + pl.off_q8;
     float* q8s = reinterpret_cast<float*>(ws + pl.off_q8s);
+    float* q8n = reinterpret_cast<float*>(ws + pl.off_q8n);
+    float* q8u = reinterpret_cast<float*>(ws + pl.off_q8u);
     float* xc = reinterpret_cast<float*>(ws + pl.off_xc);
     float* hc = reinterpret_cast<float*>(ws + pl.off_hc);
     float* qc = reinterpret_cast<float*>(ws + pl.off_qc);
@@ -196,17 +200,17 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
             if (f8) {      // every Linear: f16 rows -> per-row e4m3 -> fp8 MFMA GEMM with (row scale x channel scale) in the epilogue
                 char* a8 = q8 + (size_t)r0 * (Hd > D ? Hd : D);
                 float* as = q8s + r0;
-                AMDS_TRY(amds_layernorm(xq, D, b.ln1_w, b.ln1_b, hq, D, n, D, c->ln_eps, dt, s));
-                AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
+                float *an = q8n + r0, *au = q8u + r0;
+                char* u8 = mlp + (size_t)r0 * Hd;          // the MLP buffer holds the e4m3 hidden rows (1 byte per element: the first half of it)
+                AMDS_TRY(amds_layernorm_quant_e4m3(xq, D, b.ln1_w, b.ln1_b, c->ln_eps, a8, D, as, nullptr, n, D, s));
                 AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].qkv_w8, D, n, 3 * D, D, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, f8[l].qkv_cs, as, s));
                 AMDS_TRY(amds_attention_vit_hd(qkvq, hq, q.nt, T, c->heads, D / c->heads, dt, s));
                 AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
                 AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].proj_w8, D, n, D, D, AMDS_EPI_RESIDUAL, xq, D, f8[l].proj_b, f8[l].proj_cs, as, s));
-                AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, hq, D, n, D, c->ln_eps, dt, s));
-                AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
-                AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].fc1_w8, D, n, Hd, D, AMDS_EPI_BIAS_GELU, mlpq, Hd, b.fc1_b, f8[l].fc1_cs, as, s));
-                AMDS_TRY(amds_quantize_rows_e4m3(mlpq, Hd, a8, Hd, as, n, Hd, AMDS_F16, s));
-                AMDS_TRY(amds_gemm_fp8(a8, Hd, f8[l].fc2_w8, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, f8[l].fc2_b, f8[l].fc2_cs, as, s));
+                AMDS_TRY(amds_layernorm_quant_e4m3(xq, D, b.ln2_w, b.ln2_b, c->ln_eps, a8, D, as, an, n, D, s));
+                AMDS_TRY(amds_row_bound_scale(an, f8[l].fc1_wnorm_max, f8[l].fc1_babs_max, au, n, s));
+                AMDS_TRY(amds_gemm_fp8_out8(a8, D, f8[l].fc1_w8, D, n, Hd, D, AMDS_EPI_BIAS_GELU, u8, Hd, au, b.fc1_b, f8[l].fc1_cs, as, s));
+                AMDS_TRY(amds_gemm_fp8(u8, Hd, f8[l].fc2_w8, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, f8[l].fc2_b, f8[l].fc2_cs, au, s));
                 continue;
             }
             if (fold) {

@@ -163,6 +163,36 @@ def quantize_rows_e4m3(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     return q, sc
 
 
+def layernorm_quant_e4m3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_norm: bool = False):
+    """nn.LayerNorm of fp32 rows fused with the per-row e4m3 quantisation -> (q uint8 [rows, cols], scale [rows][, L2 norm of the normalised rows])."""
+    _dev(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    nrm = torch.empty(rows, dtype=torch.float32, device=x.device) if want_norm else None
+    _lib.check(_lib.lib().amds_layernorm_quant_e4m3(_p(x), x.stride(0), _p(gamma), _p(beta), eps, _p(q), cols, _p(sc), _p(nrm), rows, cols, _stream()), "layernorm_quant_e4m3")
+    return (q, sc, nrm) if want_norm else (q, sc)
+
+
+def row_bound_scale(rownorm: torch.Tensor, c0: float, c1: float) -> torch.Tensor:
+    _dev(rownorm)
+    us = torch.empty_like(rownorm)
+    _lib.check(_lib.lib().amds_row_bound_scale(_p(rownorm), float(c0), float(c1), _p(us), rownorm.numel(), _stream()), "row_bound_scale")
+    return us
+
+
+def gemm_fp8_out8(a8: torch.Tensor, w8: torch.Tensor, epi: int, out_rowscale: torch.Tensor, *, rowscale=None, colscale=None, bias=None) -> torch.Tensor:
+    """amds_gemm_fp8 with an e4m3 OUTPUT: out8[m][n] = e4m3(act(...) / out_rowscale[m]) -> uint8 [M, N]."""
+    _dev(a8, w8, out_rowscale, rowscale, colscale, bias)
+    M, K = a8.shape
+    N = w8.shape[0]
+    out8 = torch.empty(M, N, dtype=torch.uint8, device=a8.device)
+    _lib.check(_lib.lib().amds_gemm_fp8_out8(_p(a8), a8.stride(0), _p(w8), w8.stride(0), M, N, K, epi, _p(out8), N, _p(out_rowscale), _p(bias), _p(colscale), _p(rowscale),
+                                             _stream()), "gemm_fp8_out8")
+    return out8
+
+
 def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, epi: int, *, rowscale=None, colscale=None, bias=None, out=None) -> torch.Tensor:
     """OPT-IN fp8 GEMM: act((a8 @ w8^T) * rowscale[:, None] * colscale[None, :] + bias); a8 [M, K], w8 [N, K] e4m3 bytes (uint8).
     epi EPI_BIAS / EPI_BIAS_GELU -> f16 [M, N]; EPI_RESIDUAL -> `out` fp32 [M, N] += ..."""

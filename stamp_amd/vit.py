@@ -257,8 +257,12 @@ class HipViT(nn.Module):
             f.qkv_w8, f.qkv_cs = keep(w8), keep(sw)
             w8, sw = ops.quantize_rows_e4m3(g("attn.proj.weight"))
             f.proj_w8, f.proj_cs, f.proj_b = keep(w8), keep((sw * ls1).contiguous()), keep((g("attn.proj.bias") * ls1).contiguous())
-            w8, sw = ops.quantize_rows_e4m3(g("mlp.fc1.weight"))
+            w1 = g("mlp.fc1.weight")
+            w8, sw = ops.quantize_rows_e4m3(w1)
             f.fc1_w8, f.fc1_cs = keep(w8), keep(sw)
+            # the bound that lets fc1's epilogue write e4m3 directly (amds_row_bound_scale); margin 1.15 >= (1 + 2^-4)^2: both operands of the product
+            # are e4m3-rounded, each element by at most 2^-4 of itself
+            f.fc1_wnorm_max, f.fc1_babs_max = 1.15 * float(w1.double().norm(dim=1).max()), float(g("mlp.fc1.bias").abs().max())
             w8, sw = ops.quantize_rows_e4m3(g("mlp.fc2.weight"))
             f.fc2_w8, f.fc2_cs, f.fc2_b = keep(w8), keep((sw * ls2).contiguous()), keep((g("mlp.fc2.bias") * ls2).contiguous())
         self._w_c.fp8_host = C.cast(self._fp8, C.POINTER(_lib.VitFp8Block))

@@ -84,6 +84,35 @@ def test_gemm_fp8_accuracy_delta_is_what_e4m3_costs(gpu):
     assert 1e-2 < e8 < 6e-2 and e16 < 1e-3
 
 
+def test_fp8_producers_layernorm_quant_and_direct_e4m3_output(gpu):
+    """The two fusions that spare the fp8 path a 16-bit round trip: LayerNorm + row quantisation in one kernel, and fc1 writing e4m3 directly under a
+    per-row scale that BOUNDS its outputs (Cauchy-Schwarz: ||h|| max ||w_n|| + max |b|), so no pass has to find the row maximum afterwards."""
+    g = torch.Generator().manual_seed(3)
+    M, D, Hd = 700, 1024, 4096
+    x = (torch.randn(M, D, generator=g) * 3 + 0.5).to(gpu)
+    gamma, beta = (1 + 0.2 * torch.randn(D, generator=g)).to(gpu), (0.1 * torch.randn(D, generator=g)).to(gpu)
+    q, sc, nrm = ops.layernorm_quant_e4m3(x, gamma, beta, 1e-6, want_norm=True)
+    h = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6)
+    assert torch.allclose(sc.double(), h.abs().amax(1) / 448.0, rtol=1e-5) and torch.allclose(nrm.double(), h.norm(dim=1), rtol=1e-5)
+    back = _deq(q) * sc.double()[:, None]
+    assert ((back - h).abs() / h.abs().amax(1, keepdim=True)).max() < 2 ** -4 + 1e-5 and _rel(back, h) < 4e-2
+    # a second, independent path to the same bytes: LayerNorm in fp32 (torch) then the plain row quantiser
+    q2, sc2 = ops.quantize_rows_e4m3(h.float())
+    assert (q != q2).float().mean() < 2e-3                      # identical up to fp32-vs-fp64 LayerNorm rounding at e4m3 decision boundaries
+    # fc1 -> GELU -> e4m3 under the bounding scale, against the same GEMM with f16 output quantised afterwards by its true row maximum
+    w = (torch.randn(Hd, D, generator=g) / D ** 0.5).to(gpu)
+    b = (0.1 * torch.randn(Hd, generator=g)).to(gpu)
+    w8, sw = ops.quantize_rows_e4m3(w)
+    us = ops.row_bound_scale(nrm, 1.15 * float(w.double().norm(dim=1).max()), float(b.abs().max()))
+    u8 = ops.gemm_fp8_out8(q, w8, _lib.EPI_BIAS_GELU, us, rowscale=sc, colscale=sw, bias=b)
+    u16 = ops.gemm_fp8(q, w8, _lib.EPI_BIAS_GELU, rowscale=sc, colscale=sw, bias=b).double()
+    assert (u16.abs().amax(1) <= us.double() * 448.0).all()     # the bound holds: nothing saturates
+    headroom = (us.double() * 448.0 / u16.abs().amax(1)).median().item()
+    got = _deq(u8) * us.double()[:, None]
+    print(f"bounding scale: median headroom over the true row maximum {headroom:.1f}x; e4m3 output vs the f16 one {_rel(got, u16):.3e}")
+    assert _rel(got, u16) < 4e-2 and 2.0 < headroom < 64.0
+
+
 def test_gemm_fp8_rejects_bad_shapes(gpu):
     a8 = torch.zeros(10, 100, dtype=torch.uint8, device=gpu)
     w8 = torch.zeros(256, 100, dtype=torch.uint8, device=gpu)
