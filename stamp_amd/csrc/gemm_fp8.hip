@@ -228,21 +228,23 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const uint8_t* __restri
                     v[u] = *reinterpret_cast<const u32x4*>(smem + row * 512 + l31 * 16);
                     if ((u >> 2) & 1) v[u] = u32x4{v[u][2], v[u][3], v[u][0], v[u][1]};
                 }
-                if (ep.out8) {      // 8 f16 values of one row -> 8 e4m3 bytes, scaled by the row's output scale
+                if (ep.out8) {      // 8 f16 values of one row -> 8 e4m3 bytes, scaled by the row's output scale (the 8 scales requested together)
+                    float inv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) inv[u] = ep.out_rowscale[min(m0 + wave * 64 + (b8 * 8 + u) * 2 + hi, M - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) inv[u] = __builtin_amdgcn_rcpf(inv[u]);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int row = wave * 64 + (b8 * 8 + u) * 2 + hi;
                         const int chunk = l31 ^ (row & 31);
-                        if (m0 + row < M) {
-                            const float inv = 1.0f / ep.out_rowscale[m0 + row];
-                            const f16x8 h = __builtin_bit_cast(f16x8, v[u]);
-                            int w0 = 0, w1 = 0;
-                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[0] * inv, (float)h[1] * inv, w0, false);
-                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[2] * inv, (float)h[3] * inv, w0, true);
-                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[4] * inv, (float)h[5] * inv, w1, false);
-                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[6] * inv, (float)h[7] * inv, w1, true);
-                            *reinterpret_cast<u32x2*>(ep.out8 + (long)(m0 + row) * ep.ldo8 + n0 + chunk * 8) = u32x2{(unsigned)w0, (unsigned)w1};
-                        }
+                        const f16x8 h = __builtin_bit_cast(f16x8, v[u]);
+                        int w0 = 0, w1 = 0;
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[0] * inv[u], (float)h[1] * inv[u], w0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[2] * inv[u], (float)h[3] * inv[u], w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[4] * inv[u], (float)h[5] * inv[u], w1, false);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)h[6] * inv[u], (float)h[7] * inv[u], w1, true);
+                        if (m0 + row < M) *reinterpret_cast<u32x2*>(ep.out8 + (long)(m0 + row) * ep.ldo8 + n0 + chunk * 8) = u32x2{(unsigned)w0, (unsigned)w1};
                     }
                 } else {
 #pragma unroll
