@@ -81,10 +81,8 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     spb, kk, t = int(supertiles_per_batch), k * k, int(tile_size_px)
     chunk = int(encode_chunk or getattr(model, "chunk", 1020))
     row_bytes = t * t * 3
-    # the ring must hold well over one encoder chunk of tiles (two here): a slot is recycled when the compute stream has cut its tiles, and
-    # that stream is busy with the encoder for a whole chunk at a time -- every batch handed over during an encoder call stays locked until
-    # the call ends, while the readers must keep producing the next chunk
-    n_buf = max(3, -(-2 * chunk // (spb * kk)) + 1)
+    # pinned ring: four batches (one being consumed, up to three being decoded)
+    n_buf = 4
     n_buf = max(2, min(n_buf, (4 << 30) // (spb * S * S * 4), -(-len(origins) // spb) + 1))       # <= 4 GB of pinned memory, not more slots than batches
     host = [torch.empty(spb, S, S, 4, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
     host_np = [h.numpy() for h in host]               # the reader threads write through numpy views (no torch state in worker threads)
@@ -141,12 +139,14 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
         cap = 2 * chunk + spb * kk                     # the host learns keep decisions late (it never waits for them): room for two chunks
         acc = [torch.empty(cap, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
         count = torch.zeros(1, dtype=torch.int32, device=dev)
-        # device-side ring, allocated once: per pinned buffer its device copy, the tiles cut from it and their slots
-        d_rgba = [torch.empty(spb, S, S, 4, dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-        d_tiles = [torch.empty(spb * kk, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-        d_slots = [torch.empty(spb * kk, dtype=torch.int32, device=dev) for _ in range(n_buf)]
+        # device-side ring (supertiles and the tiles cut from them), allocated once and LONGER than the pinned ring (three chunks of tiles; HBM is not the scarce resource): a device slot
+        # is recycled only when the compute stream has cut its tiles, and that stream is busy with the encoder for a chunk at a time, while a
+        # pinned slot is free again as soon as its H2D copy is done -- so the readers keep going through an encoder call
+        n_dev = max(n_buf, min(-(-3 * chunk // (spb * kk)) + 2, (8 << 30) // (spb * S * S * 4), -(-len(origins) // spb) + 1))
+        d_rgba = [torch.empty(spb, S, S, 4, dtype=torch.uint8, device=dev) for _ in range(n_dev)]
+        d_tiles = [torch.empty(spb * kk, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(n_dev)]
         d_ws = torch.empty(max(_lib.lib().amds_supertiles_to_tiles_workspace_bytes(spb, S, k, t), 4), dtype=torch.uint8, device=dev)
-        d_done: list = [None] * n_buf                  # the compute stream has finished with this slot's device buffers
+        d_done: list = [None] * n_dev                  # the compute stream has finished with this slot's device buffers
         # host-side staging allocated ONCE (pinning memory is a driver call): per-batch keep slots, and the feature rows of the whole slide
         n_batches = (len(origins) + spb - 1) // spb
         slots_ring = torch.empty(n_batches, spb * kk, dtype=torch.int32).pin_memory()
@@ -195,10 +195,7 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
                 _TIMELINE.append(("enc_enqueue", _time.perf_counter() - t_begin, e0))
             f = model(acc[cur][:m]).detach().half()
             fh = feats_host[encoded:encoded + m] if feats_host is not None and f.shape[1] == feats_host.shape[1] else torch.empty(f.shape, dtype=torch.float16).pin_memory()
-            fh.copy_(f, non_blocking=True)
-            ev_f = torch.cuda.Event()
-            ev_f.record(cs)
-            feats_parts.append((fh, ev_f, f))
+            feats_parts.append((fh, None, f))          # the D2H of the features is issued after the last encoder call (2 KB per tile stay on the device till then)
             stats["encoder_calls"] += 1
             other = 1 - cur
             _lib.check(_lib.lib().amds_compact_shift_u8(acc[cur].data_ptr(), acc[other].data_ptr(), row_bytes, m, cap - m, count.data_ptr(), cs.cuda_stream),
@@ -231,27 +228,33 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
                 nb = len(batch)
                 if _TIMELINE is not None:
                     _TIMELINE.append(("batch_ready", _time.perf_counter() - t_begin, None))
+                ds = batch_idx % n_dev
                 with torch.cuda.stream(h2d):        # its own stream: a pinned buffer is free again as soon as ITS copy is done
-                    if d_done[b] is not None:
-                        h2d.wait_event(d_done[b])
-                    rgba = d_rgba[b][:nb]
+                    if d_done[ds] is not None:
+                        h2d.wait_event(d_done[ds])
+                    rgba = d_rgba[ds][:nb]
+                    if _TIMELINE is not None:
+                        e_s = torch.cuda.Event(enable_timing=True)
+                        e_s.record(h2d)
                     rgba.copy_(host[b][:nb], non_blocking=True)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=_TIMELINE is not None)
                     ev.record(h2d)
+                    if _TIMELINE is not None:
+                        _TIMELINE.append(("h2d", _time.perf_counter() - t_begin, (e_s, ev)))
                     buf_ev[b] = ev
                     buf_free.put(b)
                 cs.wait_event(ev)
-                tiles = tiling.supertiles_to_tiles(rgba, k, t, out=d_tiles[b], workspace=d_ws)
+                tiles = tiling.supertiles_to_tiles(rgba, k, t, out=d_tiles[ds], workspace=d_ws)
                 frac = ops.tile_edge_fraction(tiles, 40, 100) if canny_cutoff is not None else None
-                slots = d_slots[b][:tiles.shape[0]]
-                _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(),
-                                                           float(canny_cutoff or 0.0), acc[cur].data_ptr(), cap, count.data_ptr(), slots.data_ptr(),
-                                                           tiles.shape[0], cs.cuda_stream), "compact_rows")
+                # the keep decisions go STRAIGHT into pinned host memory (device-accessible: the kernel stores over PCIe).  As D2H copy commands they
+                # sat in the copy queue behind the encoder and held up the H2D copies submitted after them until the encoder call had finished
                 slots_h = slots_ring[batch_idx, :tiles.shape[0]]
-                slots_h.copy_(slots, non_blocking=True)
+                _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(),
+                                                           float(canny_cutoff or 0.0), acc[cur].data_ptr(), cap, count.data_ptr(), slots_h.data_ptr(),
+                                                           tiles.shape[0], cs.cuda_stream), "compact_rows")
                 ev2 = torch.cuda.Event()
                 ev2.record(cs)
-                d_done[b] = ev2
+                d_done[ds] = ev2
                 pending.append((slots_h, ev2, all_coords[batch_idx * spb * kk: batch_idx * spb * kk + nb * kk]))
                 batch_idx += 1
                 stats["tiles_seen"] += nb * kk
@@ -269,8 +272,9 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
                 buf_free.put(0)
                 th.join(timeout=0.05)
         t_ = _time.perf_counter()
-        for _fh, ev_f, _f in feats_parts:
-            ev_f.synchronize()
+        for fh, _e, f in feats_parts:
+            fh.copy_(f, non_blocking=True)
+        cs.synchronize()
         stats["wait_gpu_s"] += _time.perf_counter() - t_
         coords_parts = kept_coords
         stats["pipeline_s"] = round(_time.perf_counter() - t_begin - stats["setup_s"], 3)
