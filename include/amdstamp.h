@@ -574,6 +574,51 @@ int amds_mean_pool_bwd(const float* dy, float* dx, int B, int T, int F, void* st
 int amds_linear_f32(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MIL `vit` head, deploy / validation forward as one call (reference
+ * src/stamp/modeling/models/vision_tranformer.py:332-384 VisionTransformer.forward in eval mode; called from
+ * src/stamp/modeling/models/__init__.py:288-313 validation_step / predict_step of the tile-level Lightning wrappers)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_feats;    /* dim_input  */
+    int dim;        /* dim_model (head_dim = dim / heads <= 64, dim % 4 == 0) */
+    int heads;
+    int ff;         /* dim_feedforward */
+    int classes;    /* dim_output */
+    int layers;
+    int alibi;      /* use_alibi */
+    int dtype;      /* MFMA operand type of the 16-bit weights below: AMDS_F16 (inference packs) or AMDS_BF16 */
+} amds_mil_vit_cfg;
+
+/* Device pointers.  Padded sizes: Fp / Dp / FFp = n_feats / dim / ff rounded up to 256, Ha = heads rounded up to 4, Da = 64 Ha; padding
+ * rows, columns and heads are zero (amds_cast_pad).  16-bit matrices are [N][K] row-major in cfg.dtype unless noted. */
+typedef struct {
+    const float* ln1_w; const float* ln1_b;     /* [dim]                       layers.l.0.norm                            :183, 215 */
+    const void* in_w;   const float* in_b;      /* [3 Da][Dp], [3 Da]          in_proj (q | k | v, head h at rows 64h..64h+63; head_dim < 64:
+                                                 *                             q rows scaled by sqrt(64 / head_dim))      :191 / :100-120 */
+    const void* out_w;  const float* out_b;     /* [Dp][Da], [Dp]              out_proj / mhsa.fc; BF16 when cfg.alibi     :191 / :121, 154 */
+    const float* head_scale;                    /* [Ha] bias_scale_h / running_mean_h (ALiBi only, else NULL)              :31, 60 */
+    const float* ln2_w; const float* ln2_b;     /* [dim]                       layers.l.1.0                               :163 */
+    const void* fc1_w;  const float* fc1_b;     /* [FFp][Dp], [FFp]            layers.l.1.1                               :164 */
+    const void* fc2_w;  const float* fc2_b;     /* [Dp][FFp], [Dp]             layers.l.1.4                               :167 */
+} amds_mil_vit_layer;
+
+typedef struct {
+    const float* class_token;                   /* [Dp]                                                                    :312, 347 */
+    const void* proj_w; const float* proj_b;    /* [Dp][Fp], [Dp]              project_features.0                          :314, 342 */
+    const amds_mil_vit_layer* layers_host;      /* HOST array of cfg.layers entries */
+    const float* norm_w; const float* norm_b;   /* [dim]                       transformer.norm                           :278, 294 */
+    const float* head_w; const float* head_b;   /* [classes][dim] fp32, [classes]   mlp_head.0                            :329, 384 */
+} amds_mil_vit_weights;
+
+size_t amds_mil_vit_workspace_bytes(const amds_mil_vit_cfg* cfg_host, int n_bags, int n_tiles);
+/* bags: [n_bags][n_tiles][n_feats] contiguous, bags_dtype AMDS_F32 / AMDS_F16 / AMDS_BF16 (staged to cfg.dtype rows of pitch Fp unless it
+ * already has that form).  coords: fp32 [n_bags][n_tiles][2], required when cfg.alibi.  mask: u8 [n_bags][n_tiles], 1 = padded tile, or NULL
+ * (the reference's `mask` argument, :359-381).  logits: fp32 [n_bags][classes].  Launches only, on `stream`; ws 256-byte aligned. */
+int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds_mil_vit_weights* w_host, const void* bags, int bags_dtype,
+                         const float* coords, const uint8_t* mask, float* logits, int n_bags, int n_tiles, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * TransMIL building blocks (reference src/stamp/modeling/models/trans_mil.py), fp32 throughout
  * ---------------------------------------------------------------------------------------------- */
 

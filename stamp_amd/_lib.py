@@ -60,6 +60,20 @@ class VitHostWeights(C.Structure):
 PACK_LNFOLD, PACK_PATCH_SPLIT, PACK_EXACT = 1, 2, 4
 
 
+class MilVitCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_feats", "dim", "heads", "ff", "classes", "layers", "alibi", "dtype")]
+
+
+class MilVitLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "head_scale", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
+                                          "fc2_w", "fc2_b")]
+
+
+class MilVitWeights(C.Structure):
+    _fields_ = [("class_token", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("layers_host", C.POINTER(MilVitLayer)),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+
+
 class SwinCfg(C.Structure):
     _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
                 ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
@@ -152,6 +166,8 @@ PROTOTYPES = {
     "amds_vary_precision": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "amds_mean_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_linear_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_mil_vit_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "amds_mil_vit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_bgemm_f32": (_i, [_vp, _i, _l, _l, _vp, _i, _l, _l, _i, _vp, _i, _l, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp]),
     "amds_softmax_rows": (_i, [_vp, _l, _i, _vp]),
     "amds_landmark_mean": (_i, [_vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),

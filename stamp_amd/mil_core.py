@@ -19,6 +19,7 @@ float4).  When nothing needs padding (the defaults: 512 / 8 heads / 512) the pac
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from dataclasses import dataclass
 
@@ -214,6 +215,29 @@ class PackedVit:
             self.w["layers"].append(Lw)
             if self.train:
                 self.wt["layers"].append({k: T.transpose16(v) for k, v in Lw.items()})
+        self._c = None
+
+    def c_structs(self):
+        """(amds_mil_vit_cfg, amds_mil_vit_weights) over this pack's device tensors (include/amdstamp.h, "MIL `vit` head"); the ctypes
+        objects and the per-layer ALiBi scales they point to live as long as the pack is not refreshed."""
+        if self._c is None:
+            d, m, w = self.dims, self.m, self.w
+            cfg = _lib.MilVitCfg(d.F, d.D, d.H, d.FF, d.C, d.L, int(d.alibi), ops.act_code(self.act))
+            layers = (_lib.MilVitLayer * max(d.L, 1))()
+            keep = []
+            for l, (Lm, Lw) in enumerate(zip(m["layers"], w["layers"])):
+                hs = None
+                if d.alibi:
+                    hs = (Lm["bias_scale"] * Lm["inv_rm"]).contiguous()
+                    keep.append(hs)
+                layers[l] = _lib.MilVitLayer(Lm["ln1"][0].data_ptr(), Lm["ln1"][1].data_ptr(), Lw["in_w"].data_ptr(), Lm["in_b"].data_ptr(),
+                                             Lw["out_w"].data_ptr(), Lm["out_b"].data_ptr(), hs.data_ptr() if hs is not None else None,
+                                             Lm["ln2"][0].data_ptr(), Lm["ln2"][1].data_ptr(), Lw["fc1_w"].data_ptr(), Lm["fc1_b"].data_ptr(),
+                                             Lw["fc2_w"].data_ptr(), Lm["fc2_b"].data_ptr())
+            wc = _lib.MilVitWeights(m["cls"].data_ptr(), w["proj_w"].data_ptr(), m["proj_b"].data_ptr(), layers, m["norm"][0].data_ptr(),
+                                    m["norm"][1].data_ptr(), m["head_w"].data_ptr(), m["head_b"].data_ptr())
+            self._c = (cfg, wc, layers, keep)
+        return self._c[0], self._c[1]
 
 
 def _coords_with_cls(coords: torch.Tensor, Bb: int, dev) -> torch.Tensor:
@@ -230,7 +254,50 @@ def _ln(x, rows, cols, ld_in, gamma, beta, out_dtype, ld_out, buf=None):
 
 
 # ---- inference forward (fp16 operands; deploy / validation / the reference's `mask` path) -----------------------------------------
+_INFER_WS: dict = {}
+
+
 def forward_infer(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, mask: torch.Tensor | None) -> torch.Tensor:
+    """bags [batch, tile, feature] -> logits [batch, dim_output]: ONE library call (amds_mil_vit_forward, csrc/mil_vit.hip) -- the host
+    checks shapes, hands over pointers and keeps one workspace per device."""
+    d = pk.dims
+    if bags.dim() != 3 or bags.shape[-1] != d.F:
+        raise ValueError(f"bags must be [batch, tile, {d.F}], got {tuple(bags.shape)}")
+    ops._dev(bags)          # no CPU fallback
+    Bb, Tn, _ = bags.shape
+    dev = bags.device
+    if d.alibi and coords is None:
+        raise ValueError("use_alibi=True needs coords")
+    if bags.dtype not in ops._DT:
+        bags = bags.float()
+    bags = bags.contiguous()
+    c = m8 = None
+    if d.alibi:
+        if coords.shape != (Bb, Tn, 2):
+            raise ValueError(f"coords must be [batch, tile, 2] = {(Bb, Tn, 2)}, got {tuple(coords.shape)}")
+        c = coords.to(dev, torch.float32).contiguous()
+    if mask is not None:
+        if mask.shape != (Bb, Tn):
+            raise ValueError(f"mask must be [batch, tile] = {(Bb, Tn)}, got {tuple(mask.shape)}")
+        m8 = mask.to(dev, torch.uint8).contiguous()
+    cfg, wc = pk.c_structs()
+    lib = _lib.lib()
+    need = lib.amds_mil_vit_workspace_bytes(C.byref(cfg), Bb, Tn)
+    if need == 0:
+        _lib.check(-1, "mil_vit_workspace_bytes")
+    ws = _INFER_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        _INFER_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    logits = torch.empty(Bb, d.C, dtype=torch.float32, device=dev)
+    _lib.check(lib.amds_mil_vit_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), ops._DT[bags.dtype], c.data_ptr() if c is not None else None,
+                                        m8.data_ptr() if m8 is not None else None, logits.data_ptr(), Bb, Tn, ws.data_ptr(), ws.numel(),
+                                        ops._stream()), "mil_vit_forward")
+    return logits
+
+
+def forward_infer_stepwise(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, mask: torch.Tensor | None) -> torch.Tensor:
+    """The same forward, one library call per kernel from the host (what `forward_infer` did before amds_mil_vit_forward existed): kept
+    as the cross-check of the C entry point in tests/ -- results are bit-identical."""
     d = pk.dims
     Bb, Tn, Fd = bags.shape
     dev = bags.device

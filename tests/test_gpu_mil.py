@@ -257,3 +257,58 @@ def test_transmil_bag_1024_vs_oracle(gpu):
         out = model.to(gpu)(bags.to(gpu))
     err = (out.cpu() - ref).abs().max().item()
     assert err < 2e-3 * max(1.0, ref.abs().max().item()), (err, ref, out)
+
+
+@pytest.mark.parametrize("alibi,masked,dims,bdt", [(False, False, (512, 512, 8, 512), torch.float16), (True, False, (512, 512, 8, 512), torch.float16),
+                                                   (False, True, (456, 132, 4, 135), torch.float32), (True, True, (456, 132, 4, 135), torch.float32),
+                                                   (False, False, (300, 96, 3, 200), torch.float16), (True, False, (768, 256, 4, 512), torch.bfloat16)])
+def test_mil_vit_forward_one_call_equals_the_kernel_by_kernel_chain(gpu, alibi, masked, dims, bdt):
+    """amds_mil_vit_forward (one C call: staging, class token, L layers, final norm, head) against the same kernels launched one by one from
+    the host -- bit-identical logits, with the reference's odd test shapes (tests/test_model.py:9-32), padding masks, ALiBi, any bag dtype."""
+    from stamp_amd import mil_core
+    F, D, H, FF = dims
+    torch.manual_seed(F + D + int(alibi))
+    model = VisionTransformer(dim_output=3, dim_input=F, dim_model=D, n_layers=2, n_heads=H, dim_feedforward=FF, dropout=0.0, use_alibi=alibi).eval()
+    Bb, T = 3, 211
+    bags = torch.randn(Bb, T, F).to(bdt).to(gpu)
+    coords = (torch.rand(Bb, T, 2) * 2000).to(gpu)
+    mask = None
+    if masked:
+        mask = torch.zeros(Bb, T, dtype=torch.bool)
+        mask[0, 150:] = True
+        mask[2, 7:] = True
+        mask = mask.to(gpu)
+    pk = model._infer_pack(bags.device)
+    with torch.no_grad():
+        one = mil_core.forward_infer(pk, bags, coords, mask)
+        chain = mil_core.forward_infer_stepwise(pk, bags, coords, mask)
+        again = model(bags, coords=coords, mask=mask)
+    assert one.shape == (Bb, 3) and torch.isfinite(one).all()
+    assert torch.equal(one, chain) and torch.equal(one, again)
+    with pytest.raises(ValueError, match="bags must be"):
+        mil_core.forward_infer(pk, bags[..., :-1], coords, mask)
+    if alibi:
+        with pytest.raises(ValueError, match="needs coords"):
+            mil_core.forward_infer(pk, bags, None, mask)
+
+
+def test_mil_vit_forward_c_abi_guards(gpu):
+    import ctypes as C
+
+    from stamp_amd import _lib
+    lib = _lib.lib()
+    cfg = _lib.MilVitCfg(512, 512, 8, 512, 2, 2, 0, _lib.F16)
+    need = lib.amds_mil_vit_workspace_bytes(C.byref(cfg), 4, 512)
+    assert need > 4 * 513 * 512 * 4
+    assert lib.amds_mil_vit_workspace_bytes(C.byref(_lib.MilVitCfg(512, 520, 8, 512, 2, 2, 0, _lib.F16)), 4, 512) == 0      # head_dim 65
+    assert b"head_dim" in lib.amds_last_error()
+    model = VisionTransformer(dim_output=2, dim_input=512, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.0, use_alibi=False).eval()
+    pk = model._infer_pack(torch.device(gpu))
+    cfg, wc = pk.c_structs()
+    bags = torch.randn(4, 512, 512, device=gpu).half()
+    out = torch.zeros(4, 2, device=gpu)
+    small = torch.empty(1024, dtype=torch.uint8, device=gpu)
+    rc = lib.amds_mil_vit_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), _lib.F16, None, None, out.data_ptr(), 4, 512, small.data_ptr(), small.numel(), None)
+    assert rc == -2 and b"workspace" in lib.amds_last_error()      # AMDS_ERR_WORKSPACE
+    rc = lib.amds_mil_vit_forward(C.byref(cfg), C.byref(wc), None, _lib.F16, None, None, out.data_ptr(), 4, 512, small.data_ptr(), small.numel(), None)
+    assert rc == -1 and b"null" in lib.amds_last_error()              # AMDS_ERR_INVALID
