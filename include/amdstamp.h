@@ -600,6 +600,10 @@ typedef struct {
     const float* ln2_w; const float* ln2_b;     /* [dim]                       layers.l.1.0                               :163 */
     const void* fc1_w;  const float* fc1_b;     /* [FFp][Dp], [FFp]            layers.l.1.1                               :164 */
     const void* fc2_w;  const float* fc2_b;     /* [Dp][FFp], [Dp]             layers.l.1.4                               :167 */
+    /* training only (amds_mil_vit_train_*), NULL otherwise: the 16-bit matrices transposed, [K][N] (amds_transpose16), for the
+     * input-gradient GEMMs, and the two factors of head_scale (ALiBi) */
+    const void* in_wt;  const void* out_wt; const void* fc1_wt; const void* fc2_wt;
+    const float* bias_scale; const float* inv_running_mean;      /* [Ha] each */
 } amds_mil_vit_layer;
 
 typedef struct {
@@ -608,6 +612,7 @@ typedef struct {
     const amds_mil_vit_layer* layers_host;      /* HOST array of cfg.layers entries */
     const float* norm_w; const float* norm_b;   /* [dim]                       transformer.norm                           :278, 294 */
     const float* head_w; const float* head_b;   /* [classes][dim] fp32, [classes]   mlp_head.0                            :329, 384 */
+    const void* proj_wt;                        /* [Fp][Dp] transposed proj_w: only for the gradient w.r.t. the bags (heat-maps), else NULL */
 } amds_mil_vit_weights;
 
 size_t amds_mil_vit_workspace_bytes(const amds_mil_vit_cfg* cfg_host, int n_bags, int n_tiles);
@@ -617,6 +622,52 @@ size_t amds_mil_vit_workspace_bytes(const amds_mil_vit_cfg* cfg_host, int n_bags
 int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds_mil_vit_weights* w_host, const void* bags, int bags_dtype,
                          const float* coords, const uint8_t* mask, float* logits, int n_bags, int n_tiles, void* ws, size_t ws_bytes,
                          void* stream);
+
+/* The TRAINING step of the same head, forward and backward as one call each (reference: the train-mode forward of
+ * vision_tranformer.py:332-384 with its Dropout sites :157-169, :191, :314-318 live, and loss.backward() through it,
+ * src/stamp/modeling/models/__init__.py:239-279).  cfg.dtype must be AMDS_BF16 (bf16 MFMA operands, fp32 accumulation, residual stream
+ * and gradients).  Dropout masks are counter-based functions of (seed, site, element): the backward regenerates them from the same
+ * amds_mil_vit_dropout.  The ALiBi running means (:24-29) are updated by the caller BEFORE the forward (amds_cdist_rowsum). */
+typedef struct {
+    float p_proj;       /* project_features' Dropout = the constructor's `dropout`                    :314-318 */
+    float p_att;        /* nn.MultiheadAttention's dropout = the constructor's `dropout` (ignored when cfg.alibi)  :191 */
+    float p_ff;         /* feed_forward's two Dropouts (0.5: the reference never forwards `dropout` to them)       :157-169, :268-271 */
+    uint64_t seed;
+} amds_mil_vit_dropout;  /* all zero = eval-mode arithmetic with saved activations (parity tests against autograd) */
+
+/* fp32 device buffers in the PADDED layout of the weights they belong to (amds_mil_vit_layer / _weights); the caller slices the
+ * reference shapes out of them (padding rows / columns / heads receive zeros or don't-care values). */
+typedef struct {
+    float* ln1_w; float* ln1_b;     /* [dim] */
+    float* in_w;  float* in_b;      /* [3 Da][Dp], [3 Da] */
+    float* out_w; float* out_b;     /* [Dp][Da], [Dp] */
+    float* bias_scale;              /* [Ha]  (ALiBi only) */
+    float* ln2_w; float* ln2_b;     /* [dim] */
+    float* fc1_w; float* fc1_b;     /* [FFp][Dp], [FFp] */
+    float* fc2_w; float* fc2_b;     /* [Dp][FFp], [Dp] */
+} amds_mil_vit_layer_grads;
+typedef struct {
+    float* class_token;             /* [Dp] */
+    float* proj_w; float* proj_b;   /* [Dp][Fp], [Dp] */
+    const amds_mil_vit_layer_grads* layers_host;     /* HOST array of cfg.layers entries */
+    float* norm_w; float* norm_b;   /* [dim] */
+    float* head_w; float* head_b;   /* [classes][dim], [classes] */
+} amds_mil_vit_grads;
+
+/* `saved`: the activations the backward reads (one arena, written by the forward, read-only afterwards: several backwards may follow one
+ * forward, e.g. one per class for a Jacobian).  `ws`: scratch of the backward.  0 on a bad configuration (amds_last_error). */
+size_t amds_mil_vit_train_saved_bytes(const amds_mil_vit_cfg* cfg_host, int n_bags, int n_tiles);
+size_t amds_mil_vit_train_workspace_bytes(const amds_mil_vit_cfg* cfg_host, int n_bags, int n_tiles, int split_k);
+/* bags / coords / logits as amds_mil_vit_forward (no mask: the reference trains with mask=None, models/__init__.py:252). */
+int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, const amds_mil_vit_weights* w_host, const void* bags, int bags_dtype,
+                               const float* coords, const amds_mil_vit_dropout* drop_host, float* logits, int n_bags, int n_tiles,
+                               void* saved, size_t saved_bytes, void* stream);
+/* dlogits: fp32 [n_bags][classes].  grads_host NULL = no parameter gradients (input gradient only); dbags: fp32 [n_bags*n_tiles][Fp] or
+ * NULL.  Weight gradients dW = dy^T x contract over the token dimension in `split_k` fp32 partials (32 is the tuned value) that are summed
+ * in a fixed order: the step is deterministic. */
+int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, const amds_mil_vit_weights* w_host, const float* dlogits,
+                                const amds_mil_vit_dropout* drop_host, int n_bags, int n_tiles, const void* saved, size_t saved_bytes,
+                                const amds_mil_vit_grads* grads_host, float* dbags, int split_k, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TransMIL building blocks (reference src/stamp/modeling/models/trans_mil.py), fp32 throughout

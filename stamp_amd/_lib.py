@@ -66,11 +66,25 @@ class MilVitCfg(C.Structure):
 
 class MilVitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "head_scale", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
-                                          "fc2_w", "fc2_b")]
+                                          "fc2_w", "fc2_b", "in_wt", "out_wt", "fc1_wt", "fc2_wt", "bias_scale", "inv_running_mean")]
 
 
 class MilVitWeights(C.Structure):
     _fields_ = [("class_token", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("layers_host", C.POINTER(MilVitLayer)),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("proj_wt", C.c_void_p)]
+
+
+class MilVitDropout(C.Structure):
+    _fields_ = [("p_proj", C.c_float), ("p_att", C.c_float), ("p_ff", C.c_float), ("seed", C.c_uint64)]
+
+
+class MilVitLayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "bias_scale", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
+                                          "fc2_w", "fc2_b")]
+
+
+class MilVitGrads(C.Structure):
+    _fields_ = [("class_token", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("layers_host", C.POINTER(MilVitLayerGrads)),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
 
 
@@ -168,6 +182,10 @@ PROTOTYPES = {
     "amds_linear_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_mil_vit_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_mil_vit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_mil_vit_train_saved_bytes": (_sz, [_vp, _i, _i]),
+    "amds_mil_vit_train_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "amds_mil_vit_train_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_mil_vit_train_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _sz, _vp]),
     "amds_bgemm_f32": (_i, [_vp, _i, _l, _l, _vp, _i, _l, _l, _i, _vp, _i, _l, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp]),
     "amds_softmax_rows": (_i, [_vp, _l, _i, _vp]),
     "amds_landmark_mean": (_i, [_vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -234,8 +234,15 @@ class PackedVit:
                                              Lw["out_w"].data_ptr(), Lm["out_b"].data_ptr(), hs.data_ptr() if hs is not None else None,
                                              Lm["ln2"][0].data_ptr(), Lm["ln2"][1].data_ptr(), Lw["fc1_w"].data_ptr(), Lm["fc1_b"].data_ptr(),
                                              Lw["fc2_w"].data_ptr(), Lm["fc2_b"].data_ptr())
+                if self.train:
+                    Lt = self.wt["layers"][l]
+                    layers[l].in_wt, layers[l].out_wt = Lt["in_w"].data_ptr(), Lt["out_w"].data_ptr()
+                    layers[l].fc1_wt, layers[l].fc2_wt = Lt["fc1_w"].data_ptr(), Lt["fc2_w"].data_ptr()
+                if d.alibi:
+                    layers[l].bias_scale, layers[l].inv_running_mean = Lm["bias_scale"].data_ptr(), Lm["inv_rm"].data_ptr()
             wc = _lib.MilVitWeights(m["cls"].data_ptr(), w["proj_w"].data_ptr(), m["proj_b"].data_ptr(), layers, m["norm"][0].data_ptr(),
-                                    m["norm"][1].data_ptr(), m["head_w"].data_ptr(), m["head_b"].data_ptr())
+                                    m["norm"][1].data_ptr(), m["head_w"].data_ptr(), m["head_b"].data_ptr(),
+                                    self.wt["proj_w"].data_ptr() if self.train else None)
             self._c = (cfg, wc, layers, keep)
         return self._c[0], self._c[1]
 
@@ -379,8 +386,135 @@ def update_running_means(get, d: VitDims, cc: torch.Tensor) -> None:
         torch._foreach_add_(ns, 1.0)
 
 
+_TRAIN_WS: dict = {}
+
+
+def _drop_struct(d: VitDims, training: bool, seed: int) -> "_lib.MilVitDropout":
+    return _lib.MilVitDropout(d.p_drop if training else 0.0, d.p_drop if (training and not d.alibi) else 0.0, d.p_ff if training else 0.0,
+                              int(seed) & (2 ** 64 - 1))
+
+
 def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, *, training: bool, seed: int = 0):
-    """-> (logits fp32 [Bb, C], saved).  `training` switches the dropout sites on (the running means are the caller's job)."""
+    """-> (logits fp32 [Bb, C], saved).  `training` switches the dropout sites on (the running means are the caller's job).
+    ONE library call (amds_mil_vit_train_forward, csrc/mil_vit_train.hip); `saved` holds the activation arena the backward reads."""
+    d = pk.dims
+    if not pk.train or pk.act != BF:
+        raise RuntimeError("forward_train needs a training pack (PackedVit(..., torch.bfloat16, train=True))")
+    if bags.dim() != 3 or bags.shape[-1] != d.F:
+        raise ValueError(f"bags must be [batch, tile, {d.F}], got {tuple(bags.shape)}")
+    ops._dev(bags)
+    Bb, Tn, Fd = bags.shape
+    dev = bags.device
+    if d.alibi and coords is None:
+        raise ValueError("use_alibi=True needs coords")
+    if bags.dtype not in ops._DT:
+        bags = bags.float()
+    bags = bags.contiguous()
+    c = None
+    if d.alibi:
+        if coords.shape != (Bb, Tn, 2):
+            raise ValueError(f"coords must be [batch, tile, 2] = {(Bb, Tn, 2)}, got {tuple(coords.shape)}")
+        c = coords.to(dev, torch.float32).contiguous()
+    cfg, wc = pk.c_structs()
+    lib = _lib.lib()
+    need = lib.amds_mil_vit_train_saved_bytes(C.byref(cfg), Bb, Tn)
+    if need == 0:
+        _lib.check(-1, "mil_vit_train_saved_bytes")
+    arena = torch.empty(need, dtype=torch.uint8, device=dev)
+    logits = torch.empty(Bb, d.C, dtype=torch.float32, device=dev)
+    drop = _drop_struct(d, training, seed)
+    _lib.check(lib.amds_mil_vit_train_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), ops._DT[bags.dtype], c.data_ptr() if c is not None else None,
+                                              C.byref(drop), logits.data_ptr(), Bb, Tn, arena.data_ptr(), arena.numel(), ops._stream()),
+               "mil_vit_train_forward")
+    return logits, dict(arena=arena, shape=(Bb, Tn, Fd), drop=drop)
+
+
+def _grad_buffers(d: VitDims, dev):
+    """One flat fp32 buffer holding every gradient in the padded layout + the amds_mil_vit_grads over it + named views."""
+    sizes = [("class_token", (d.Dp,)), ("proj_w", (d.Dp, d.Fp)), ("proj_b", (d.Dp,)), ("norm_w", (d.D,)), ("norm_b", (d.D,)), ("head_w", (d.C, d.D)),
+             ("head_b", (d.C,))]
+    per = [("ln1_w", (d.D,)), ("ln1_b", (d.D,)), ("in_w", (3 * d.Da, d.Dp)), ("in_b", (3 * d.Da,)), ("out_w", (d.Dp, d.Da)), ("out_b", (d.Dp,)),
+           ("bias_scale", (d.Ha,)), ("ln2_w", (d.D,)), ("ln2_b", (d.D,)), ("fc1_w", (d.FFp, d.Dp)), ("fc1_b", (d.FFp,)), ("fc2_w", (d.Dp, d.FFp)),
+           ("fc2_b", (d.Dp,))]
+    al = lambda n: (n + 63) // 64 * 64  # noqa: E731   (256-byte aligned sub-buffers)
+    total = sum(al(math.prod(sh)) for _, sh in sizes) + d.L * sum(al(math.prod(sh)) for _, sh in per)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    off = 0
+
+    def view(sh):
+        nonlocal off
+        n = math.prod(sh)
+        v = flat[off:off + n].view(sh)
+        off += al(n)
+        return v
+
+    top = {k: view(sh) for k, sh in sizes}
+    layers = [{k: view(sh) for k, sh in per} for _ in range(d.L)]
+    lg = (_lib.MilVitLayerGrads * max(d.L, 1))()
+    for l, Lg in enumerate(layers):
+        lg[l] = _lib.MilVitLayerGrads(*[Lg[k].data_ptr() for k, _ in per])
+    gc = _lib.MilVitGrads(top["class_token"].data_ptr(), top["proj_w"].data_ptr(), top["proj_b"].data_ptr(), lg, top["norm_w"].data_ptr(),
+                          top["norm_b"].data_ptr(), top["head_w"].data_ptr(), top["head_b"].data_ptr())
+    return flat, gc, lg, top, layers
+
+
+def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False, split_k: int = 32):
+    """-> (grads: reference-named, reference-shaped fp32 tensors (empty dict if not need_params), dbags fp32 [Bb,T,F] or None).
+    ONE library call (amds_mil_vit_train_backward); the host slices the reference shapes out of the padded gradient buffers."""
+    d = pk.dims
+    dev = dlogits.device
+    Bb, Tn, Fd = saved["shape"]
+    cfg, wc = pk.c_structs()
+    lib = _lib.lib()
+    dlogits = dlogits.contiguous().float()
+    if dlogits.shape != (Bb, d.C):
+        raise ValueError(f"dlogits must be {(Bb, d.C)}, got {tuple(dlogits.shape)}")
+    need = lib.amds_mil_vit_train_workspace_bytes(C.byref(cfg), Bb, Tn, split_k)
+    if need == 0:
+        _lib.check(-1, "mil_vit_train_workspace_bytes")
+    ws = _TRAIN_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        _TRAIN_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    gc = top = layers = None
+    if need_params:
+        _flat, gc, _lg, top, layers = _grad_buffers(d, dev)
+    dbp = torch.empty(Bb * Tn, d.Fp, dtype=torch.float32, device=dev) if need_bags else None
+    arena = saved["arena"]
+    _lib.check(lib.amds_mil_vit_train_backward(C.byref(cfg), C.byref(wc), dlogits.data_ptr(), C.byref(saved["drop"]), Bb, Tn, arena.data_ptr(), arena.numel(),
+                                               C.byref(gc) if gc is not None else None, dbp.data_ptr() if dbp is not None else None, split_k,
+                                               ws.data_ptr(), ws.numel(), ops._stream()), "mil_vit_train_backward")
+    dbags = dbp[:, :Fd].reshape(Bb, Tn, Fd) if need_bags else None
+    G: dict[str, torch.Tensor] = {}
+    if not need_params:
+        return G, dbags
+    D = d.D
+    G["mlp_head.0.weight"], G["mlp_head.0.bias"] = top["head_w"], top["head_b"]
+    G["transformer.norm.weight"], G["transformer.norm.bias"] = top["norm_w"], top["norm_b"]
+    G["class_token"] = top["class_token"][:D]
+    G["project_features.0.weight"], G["project_features.0.bias"] = top["proj_w"][:D, :Fd], top["proj_b"][:D]
+    for l, Lg in enumerate(layers):
+        p = layer_prefix(l)
+        G[p + "1.4.weight"], G[p + "1.4.bias"] = Lg["fc2_w"][:D, : d.FF], Lg["fc2_b"][:D]
+        G[p + "1.1.weight"], G[p + "1.1.bias"] = Lg["fc1_w"][: d.FF, :D], Lg["fc1_b"][: d.FF]
+        G[p + "1.0.weight"], G[p + "1.0.bias"] = Lg["ln2_w"], Lg["ln2_b"]
+        G[p + "0.norm.weight"], G[p + "0.norm.bias"] = Lg["ln1_w"], Lg["ln1_b"]
+        out_name = "0.mhsa.fc." if d.alibi else "0.mhsa.out_proj."
+        G[p + out_name + "weight"], G[p + out_name + "bias"] = pk.unpad_out_w(Lg["out_w"]), Lg["out_b"][:D]
+        gw, gb = pk.unpad_in_w(Lg["in_w"]), pk.unpad_in_b(Lg["in_b"])
+        if d.alibi:
+            for h in range(d.H):
+                G[p + f"0.mhsa.attentions.{h}.bias_scale"] = Lg["bias_scale"][h:h + 1]
+            for i, e in enumerate(_ENC):
+                for h in range(d.H):
+                    G[p + f"0.mhsa.{e}.{h}.weight"], G[p + f"0.mhsa.{e}.{h}.bias"] = gw[i, h], gb[i, h]
+        else:
+            G[p + "0.mhsa.in_proj_weight"], G[p + "0.mhsa.in_proj_bias"] = gw.reshape(3 * D, D), gb.reshape(3 * D)
+    return G, dbags
+
+
+def forward_train_stepwise(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, *, training: bool, seed: int = 0):
+    """The training forward, one library call per kernel from the host (what `forward_train` did before amds_mil_vit_train_forward
+    existed): kept as the cross-check of the C entry points in tests/ -- logits and gradients are bit-identical."""
     d = pk.dims
     dev = bags.device
     Bb, Tn, Fd = bags.shape
@@ -445,8 +579,8 @@ def _bgemm(A, lda, B, ldb, transb, Cm, ldc, M, N, K):
                                          M, N, K, 1.0, 0.0, None, 0, ops._stream()), "bgemm_f32")
 
 
-def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False, split_k: int = 32):
-    """-> (grads: reference-named, reference-shaped fp32 tensors (empty dict if not need_params), dbags fp32 [Bb,T,F] or None)."""
+def backward_stepwise(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False, split_k: int = 32):
+    """Backward of `forward_train_stepwise` (its `saved`), kernel by kernel from the host; same results as `backward`."""
     d = pk.dims
     dev = dlogits.device
     Bb, Tn, Fd = saved["shape"]

@@ -350,3 +350,66 @@ def test_trainer_regression_and_survival_losses(gpu, task):
         assert ((g - r).norm() / (r.norm() + 1e-12)).item() < 6e-2, k
     ls = [tr.step(bags.to(gpu), targets, loss_fn=fn)[0].item() for _ in range(10)]
     assert ls[-1] < ls[0]
+
+
+@pytest.mark.parametrize("alibi,dims,p_drop,bdt", [(False, (512, 512, 8, 512), 0.0, torch.float16), (False, (512, 512, 8, 512), 0.25, torch.float16),
+                                                   (True, (512, 512, 8, 512), 0.0, torch.float16), (False, (456, 132, 4, 135), 0.1, torch.float32),
+                                                   (True, (456, 132, 4, 135), 0.0, torch.float32), (False, (768, 256, 4, 512), 0.0, torch.bfloat16)])
+def test_mil_vit_train_one_call_equals_the_kernel_by_kernel_chain(gpu, alibi, dims, p_drop, bdt):
+    """amds_mil_vit_train_forward / _backward (one C call each) against the same kernels launched one by one from the host: logits, every
+    parameter gradient and the gradient w.r.t. the bags are bit-identical -- default and odd (padded) shapes, dropout live (same counter-based
+    masks from the same seed), ALiBi, every bag dtype; a second backward from the same saved activations (Jacobian rows) reproduces the first."""
+    from stamp_amd import mil_core
+    from stamp_amd.mil import VisionTransformer
+    F, D, H, FF = dims
+    torch.manual_seed(F + D + int(alibi))
+    model = VisionTransformer(dim_output=3, dim_input=F, dim_model=D, n_layers=2, n_heads=H, dim_feedforward=FF, dropout=p_drop, use_alibi=alibi)
+    sd = {k: v.detach().to(gpu, torch.float32) for k, v in model.state_dict().items()}
+    pk = mil_core.PackedVit(model.dims, lambda n: sd[n], torch.bfloat16, train=True)
+    Bb, Tn = 3, 157
+    bags = torch.randn(Bb, Tn, F).to(bdt).to(gpu)
+    coords = (torch.rand(Bb, Tn, 2) * 2000).to(gpu)
+    dlogits = torch.randn(Bb, 3, device=gpu)
+    training = p_drop > 0
+    lg1, sv1 = mil_core.forward_train(pk, bags, coords, training=training, seed=1234)
+    lg0, sv0 = mil_core.forward_train_stepwise(pk, bags, coords, training=training, seed=1234)
+    assert torch.isfinite(lg1).all() and torch.equal(lg1, lg0)
+    G1, db1 = mil_core.backward(pk, sv1, dlogits, need_params=True, need_bags=True)
+    G0, db0 = mil_core.backward_stepwise(pk, sv0, dlogits, need_params=True, need_bags=True)
+    assert set(G1) == set(G0) and set(G1) == {k for k in sd if not mil_core.is_buffer(k)}
+    for k in G0:
+        assert G1[k].shape == G0[k].shape == sd[k].shape, k
+        assert torch.equal(G1[k], G0[k]), (k, (G1[k] - G0[k]).abs().max().item())
+    assert db1.shape == (Bb, Tn, F) and torch.equal(db1, db0)
+    G2, db2 = mil_core.backward(pk, sv1, 2.0 * dlogits, need_params=False, need_bags=True)      # input gradient only, saved activations untouched
+    assert G2 == {} and torch.allclose(db2, 2.0 * db1, rtol=2e-2, atol=2e-2 * db1.abs().max().item())
+    G3, _ = mil_core.backward(pk, sv1, dlogits, need_params=True, need_bags=False)
+    assert all(torch.equal(G3[k], G1[k]) for k in G1)
+    if training:        # another seed, other masks
+        lg5, _ = mil_core.forward_train(pk, bags, coords, training=True, seed=99)
+        assert not torch.equal(lg5, lg1)
+
+
+def test_mil_vit_train_c_abi_guards(gpu):
+    import ctypes as C
+    lib = _lib.lib()
+    cfg16 = _lib.MilVitCfg(512, 512, 8, 512, 2, 2, 0, _lib.F16)
+    assert lib.amds_mil_vit_train_saved_bytes(C.byref(cfg16), 2, 64) == 0 and b"bf16" in lib.amds_last_error()
+    cfg = _lib.MilVitCfg(512, 512, 8, 512, 2, 2, 0, _lib.BF16)
+    n_saved, n_ws = lib.amds_mil_vit_train_saved_bytes(C.byref(cfg), 2, 64), lib.amds_mil_vit_train_workspace_bytes(C.byref(cfg), 2, 64, 32)
+    assert n_saved > 0 and n_ws > 0
+    assert lib.amds_mil_vit_train_workspace_bytes(C.byref(cfg), 2, 64, 0) == 0
+    from stamp_amd import mil_core
+    from stamp_amd.mil import VisionTransformer
+    model = VisionTransformer(dim_output=2, dim_input=512, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.0, use_alibi=False)
+    sd = {k: v.detach().to(gpu, torch.float32) for k, v in model.state_dict().items()}
+    pk = mil_core.PackedVit(model.dims, lambda n: sd[n], torch.bfloat16, train=True)
+    cfg, wc = pk.c_structs()
+    bags = torch.randn(2, 64, 512, device=gpu).half()
+    out = torch.zeros(2, 2, device=gpu)
+    small = torch.empty(4096, dtype=torch.uint8, device=gpu)
+    drop = _lib.MilVitDropout(0.0, 0.0, 0.0, 0)
+    rc = lib.amds_mil_vit_train_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), _lib.F16, None, C.byref(drop), out.data_ptr(), 2, 64, small.data_ptr(), small.numel(), None)
+    assert rc == -2 and b"arena" in lib.amds_last_error()
+    with pytest.raises(RuntimeError, match="training pack"):
+        mil_core.forward_train(model._infer_pack(torch.device(gpu)), bags, None, training=False)
