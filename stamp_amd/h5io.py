@@ -15,7 +15,8 @@ coordinate conventions -- STAMP v2 (``tile_size`` + ``unit == "um"``), the curre
 
 Backend: `h5py` when it can be imported (the reference's dependency); otherwise the same C library h5py wraps, ``libhdf5``,
 through ctypes -- strings are written as variable-length UTF-8, Python floats / ints as 64-bit scalars, exactly what h5py does,
-so the files interchange with the reference's.  If neither is available the functions raise; nothing is silently skipped.
+so the files interchange with the reference's.  If neither is on the machine (e.g. a bare GPU box), `stamp_amd.h5min` -- a pure-Python
+implementation of the subset of the format these files use -- takes over (`backend()`); files of one backend are read by the others.
 """
 from __future__ import annotations
 
@@ -27,6 +28,8 @@ from dataclasses import dataclass
 from pathlib import Path
 
 import numpy as np
+
+from . import h5min
 
 try:                                    # the reference's own dependency, when present
     import h5py as _h5py
@@ -50,6 +53,23 @@ def _find_libhdf5():
         except OSError:
             continue
     return None
+
+
+def backend() -> str:
+    """Which implementation reads / writes the files: "h5py" when it imports (the reference's dependency), else "c" = libhdf5 through
+    ctypes when the shared library is on the machine, else "min" = the pure-Python subset in `stamp_amd.h5min` (enough for STAMP's feature
+    files).  AMDSTAMP_H5_BACKEND=h5py|c|min forces one (tests)."""
+    forced = os.environ.get("AMDSTAMP_H5_BACKEND", "")
+    if forced:
+        if forced not in ("h5py", "c", "min") or (forced == "h5py" and _h5py is None):
+            raise RuntimeError(f"AMDSTAMP_H5_BACKEND={forced!r} is not available")
+        return forced
+    if _h5py is not None:
+        return "h5py"
+    global _LIB
+    if _LIB is None and _find_libhdf5() is None:
+        return "min"
+    return "c"
 
 
 def _lib():
@@ -243,12 +263,15 @@ def _write(path: Path, datasets: dict[str, np.ndarray], attrs: dict) -> None:
     fd, tmp = tempfile.mkstemp(dir=path.parent)          # intermediate name: no half-written files (preprocessing/__init__.py:344-366)
     os.close(fd)
     try:
-        if _h5py is not None:
+        be = backend()
+        if be == "h5py":
             with _h5py.File(tmp, "w") as f:
                 for k, v in datasets.items():
                     f[k] = v
                 for k, v in attrs.items():
                     f.attrs[k] = v
+        elif be == "min":
+            h5min.write(tmp, {k: np.asarray(v) for k, v in datasets.items()}, attrs)
         else:
             w = _CWriter(tmp)
             try:
@@ -304,11 +327,14 @@ def write_slide_features(path, feats, *, encoder: str, precision: str, code_hash
 
 def read_file(path) -> tuple[dict[str, np.ndarray], dict]:
     """(datasets among feats / coords / patch_embeddings, root attributes)."""
-    if _h5py is not None:
+    be = backend()
+    if be == "h5py":
         with _h5py.File(path, "r") as f:
             d = {k: f[k][()] for k in ("feats", "coords", "patch_embeddings") if k in f}
             a = {k: (v.decode() if isinstance(v, bytes) else (v.item() if hasattr(v, "item") else v)) for k, v in f.attrs.items()}
         return d, a
+    if be == "min":
+        return h5min.read(path, want=("feats", "coords", "patch_embeddings"))
     return _c_read(str(path))
 
 

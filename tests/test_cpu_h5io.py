@@ -1,22 +1,11 @@
-"""STAMP's HDF5 feature-file schema through stamp_amd.h5io (libhdf5 via ctypes when h5py is absent): round trips, the three
+"""STAMP's HDF5 feature-file schema through stamp_amd.h5io (h5py, else libhdf5 via ctypes, else the pure-Python subset): round trips, the three
 coordinate conventions of the reference's `get_coords`, `detect_feature_type`'s rule, atomic replace."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
-h5io = pytest.importorskip("stamp_amd.h5io")
-
-
-def _have_backend():
-    if h5io._h5py is not None:
-        return True
-    try:
-        h5io._lib()
-        return True
-    except RuntimeError:
-        return False
-
-
-pytestmark = pytest.mark.skipif(not _have_backend(), reason="neither h5py nor libhdf5 on this machine")
+h5io = pytest.importorskip("stamp_amd.h5io")      # (every machine has a backend: h5py, libhdf5 via ctypes, or stamp_amd/h5min.py)
 
 
 def test_tile_feature_file_round_trip(tmp_path):
@@ -124,3 +113,128 @@ def test_attribute_types_on_disk_are_h5pys(tmp_path):
     d = {c.split('"', 1)[0]: c for c in full.split('DATASET "')[1:]}
     assert "H5T_IEEE_F16LE" in d["feats"] or "16-bit little-endian floating-point" in d["feats"], d["feats"]     # h5dump 1.10 has no name for f16
     assert "( 3, 8 )" in d["feats"] and "H5T_IEEE_F32LE" in d["coords"] and "( 3, 2 )" in d["coords"]
+
+
+# ---- the pure-Python backend (stamp_amd/h5min.py): machines with neither h5py nor libhdf5 ------------------------------------------------
+def _have_c():
+    try:
+        h5io._lib()
+        return True
+    except RuntimeError:
+        return False
+
+
+_ATTRS = {"stamp_version": "2.5.0", "extractor": "virchow2-é", "unit": "um", "tile_size_um": 256.0, "tile_size_px": 224, "code_hash": "0a1b2c3d",
+          "feat_type": "tile"}
+
+
+def test_h5min_round_trip_and_edge_shapes(tmp_path):
+    from stamp_amd import h5min
+    rng = np.random.default_rng(0)
+    for n in (37, 1, 0):
+        feats = rng.standard_normal((n, 1024)).astype(np.float16)
+        coords = (rng.random((n, 2)) * 1e4).astype(np.float32)
+        p = tmp_path / f"t{n}.h5"
+        h5min.write(p, {"feats": feats, "coords": coords}, _ATTRS)
+        d, a = h5min.read(p)
+        assert a == _ATTRS and list(a) == list(_ATTRS)
+        assert d["feats"].dtype == np.float16 and d["feats"].shape == (n, 1024) and np.array_equal(d["feats"], feats)
+        assert d["coords"].dtype == np.float32 and np.array_equal(d["coords"], coords)
+    h5min.write(tmp_path / "s.h5", {"feats": np.arange(768, dtype=np.float32)}, {"encoder": "chief", "flag": True, "n": np.int64(-3), "x": np.float32(0.5)})
+    d, a = h5min.read(tmp_path / "s.h5", want=("feats", "coords"))
+    assert set(d) == {"feats"} and d["feats"].shape == (768,) and a == {"encoder": "chief", "flag": 1, "n": -3, "x": 0.5}
+    with pytest.raises(ValueError, match="not an HDF5 file"):
+        (tmp_path / "junk.h5").write_bytes(b"x" * 200)
+        h5min.read(tmp_path / "junk.h5")
+    raw = bytearray((tmp_path / "s.h5").read_bytes())
+    raw[8] = 2                                              # superblock version 2: the "latest" format family
+    (tmp_path / "v2.h5").write_bytes(bytes(raw))
+    with pytest.raises(h5min.Unsupported, match="superblock version 2"):
+        h5min.read(tmp_path / "v2.h5")
+    with pytest.raises(TypeError):
+        h5min.write(tmp_path / "bad.h5", {}, {"a": [1, 2]})
+
+
+def test_h5min_files_interchange_with_libhdf5(tmp_path, monkeypatch):
+    """Both directions against the real library (what h5py wraps), where it exists: a file written by the pure-Python backend reads back
+    identically through libhdf5 and h5dump prints the same types and values for it as for the library's own file; a file written by
+    libhdf5 reads back identically through the pure-Python reader."""
+    from stamp_amd import h5min
+    if not _have_c():
+        pytest.skip("no libhdf5 on this machine to compare with")
+    rng = np.random.default_rng(1)
+    feats = rng.standard_normal((211, 1536)).astype(np.float16)
+    coords = (rng.random((211, 2)) * 1e5).astype(np.float32)
+    pm, pc = tmp_path / "m.h5", tmp_path / "c.h5"
+    h5min.write(pm, {"feats": feats, "coords": coords}, _ATTRS)
+    d, a = h5io._c_read(str(pm))
+    assert np.array_equal(d["feats"], feats) and d["feats"].dtype == np.float16 and np.array_equal(d["coords"], coords) and a == _ATTRS
+    monkeypatch.setenv("AMDSTAMP_H5_BACKEND", "c")
+    assert h5io.backend() == "c"
+    h5io._write(pc, {"feats": feats, "coords": coords}, _ATTRS)
+    d, a = h5min.read(pc)
+    assert np.array_equal(d["feats"], feats) and np.array_equal(d["coords"], coords) and a == _ATTRS
+    import shutil
+    import subprocess
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if Path("/opt/conda/bin/h5dump").exists() else None)
+    if h5dump:
+        outs = [subprocess.run([h5dump, str(p)], capture_output=True, text=True, check=True).stdout.split("\n", 1)[1] for p in (pm, pc)]
+        assert outs[0] == outs[1] and "H5T_VARIABLE" in outs[0] and "H5T_CSET_UTF8" in outs[0]
+
+
+def test_h5min_reads_chunked_compressed_datasets(tmp_path):
+    """Legacy feature files may be chunked and gzip-compressed (h5py `compression="gzip", shuffle=True`): v1 chunk B-tree + deflate /
+    shuffle / fletcher32 filters, made here with the real library."""
+    import ctypes as C
+    from stamp_amd import h5min
+    if not _have_c():
+        pytest.skip("no libhdf5 on this machine to make the file with")
+    lib = h5io._lib()
+    hid, u64 = C.c_int64, C.c_uint64
+    for name, res, args in (("H5Pcreate", hid, [hid]), ("H5Pset_chunk", C.c_int, [hid, C.c_int, C.POINTER(u64)]), ("H5Pset_deflate", C.c_int, [hid, C.c_uint]),
+                            ("H5Pset_shuffle", C.c_int, [hid]), ("H5Pset_fletcher32", C.c_int, [hid]), ("H5Pclose", C.c_int, [hid]),
+                            ("H5Zfilter_avail", C.c_int, [C.c_int])):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.H5Zfilter_avail(1) <= 0:
+        pytest.skip("this libhdf5 has no deflate filter")
+    rng = np.random.default_rng(2)
+    feats = np.round(rng.standard_normal((1000, 96)) * 4).astype(np.float16)            # compressible
+    coords = (rng.integers(0, 400, (1000, 2)) * 256).astype(np.float32)
+    p = tmp_path / "z.h5"
+    f = lib.H5Fcreate(str(p).encode(), 2, 0, 0)
+    assert f >= 0
+    for nm, arr, chunk in (("feats", feats, (128, 96)), ("coords", coords, (300, 2))):
+        dcpl = lib.H5Pcreate(h5io._g("H5P_CLS_DATASET_CREATE_ID_g"))
+        assert dcpl >= 0 and lib.H5Pset_chunk(dcpl, 2, (u64 * 2)(*chunk)) >= 0
+        assert lib.H5Pset_shuffle(dcpl) >= 0 and lib.H5Pset_deflate(dcpl, 4) >= 0
+        if nm == "coords":
+            assert lib.H5Pset_fletcher32(dcpl) >= 0
+        sp = lib.H5Screate_simple(2, (u64 * 2)(*arr.shape), None)
+        t, own = h5io._np_type(lib, arr)
+        d = lib.H5Dcreate2(f, nm.encode(), t, sp, 0, dcpl, 0)
+        assert d >= 0 and lib.H5Dwrite(d, t, 0, 0, 0, arr.ctypes.data_as(C.c_void_p)) >= 0
+        lib.H5Dclose(d), lib.H5Sclose(sp), lib.H5Pclose(dcpl)
+    lib.H5Fclose(f)
+    assert p.stat().st_size < feats.nbytes                                                # it did compress
+    d, _ = h5min.read(p)
+    assert np.array_equal(d["feats"], feats) and np.array_equal(d["coords"], coords)
+
+
+def test_public_api_on_the_pure_python_backend(tmp_path, monkeypatch):
+    monkeypatch.setenv("AMDSTAMP_H5_BACKEND", "min")
+    assert h5io.backend() == "min"
+    rng = np.random.default_rng(3)
+    feats = rng.standard_normal((50, 768)).astype(np.float16)
+    coords = (rng.integers(0, 40, (50, 2)) * 256.0).astype(np.float32)
+    p = tmp_path / "a" / "slide.h5"
+    h5io.write_tile_features(p, feats, coords, extractor="ctranspath", tile_size_um=256.0, tile_size_px=224, code_hash="deadbeef", stamp_version="2.5.0")
+    d, a = h5io.read_file(p)
+    assert np.array_equal(d["feats"], feats) and np.array_equal(d["coords"], coords)
+    assert a["extractor"] == "ctranspath" and a["feat_type"] == "tile" and a["tile_size_px"] == 224 and a["tile_size_um"] == 256.0 and a["unit"] == "um"
+    assert h5io.feature_type(a) == "tile"
+    info = h5io.get_coords(d, a)
+    assert info.tile_size_um == 256.0 and info.tile_size_px == 224
+    monkeypatch.setenv("AMDSTAMP_H5_BACKEND", "nope")
+    with pytest.raises(RuntimeError, match="not available"):
+        h5io.backend()

@@ -144,11 +144,6 @@ def test_encoder_file_loop_on_h5_files(gpu, tmp_path):
     from stamp_amd import h5io
     from stamp_amd.encoder import HipGatedAttentionEncoder, resolve_extractor_name
 
-    if h5io._h5py is None:
-        try:
-            h5io._lib()
-        except RuntimeError:
-            pytest.skip("no HDF5 backend on this machine")
     assert resolve_extractor_name("chief-ctranspath-0a1b2c3d") == "chief-ctranspath" and resolve_extractor_name("chief-ctranspath") == "chief-ctranspath"
     g = torch.Generator().manual_seed(0)
     F_, L, Dd = 768, 512, 256
