@@ -307,11 +307,12 @@ def extract_slide_serial(slide, extractor: Extractor, output_path, *, slide_mpp:
     n_tiles = 0
     model = extractor.model
     host = torch.empty(supertiles_per_batch, S, S, 4, dtype=torch.uint8).pin_memory()
+    host_np = host.numpy()                         # (the regions may come as read-only arrays: copied through the numpy view)
     with futures.ThreadPoolExecutor(max_workers) as pool:
         for i in range(0, len(origins), supertiles_per_batch):
             batch = origins[i:i + supertiles_per_batch]
             for j, arr in enumerate(pool.map(lambda o: _region_array(slide, o[0], o[1], S), batch)):
-                host[j].copy_(torch.from_numpy(arr))
+                host_np[j] = arr
             tiles = tiling.supertiles_to_tiles(host[:len(batch)].to(dev, non_blocking=True), k, tile_size_px)
             cu = np.concatenate([tiling.tile_coords_um(o, slide_mpp, k, tile_size_um) for o in batch])
             n_tiles += tiles.shape[0]
