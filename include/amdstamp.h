@@ -551,6 +551,12 @@ size_t amds_gated_attn_pool_workspace_bytes(int N, int F, int L, int D);
 int amds_gated_attn_pool(const float* x, const amds_gap_weights* w_host, float* out, float* attn_raw,
                          int N, int F, int L, int D, void* ws, size_t ws_bytes, void* stream);
 
+/* EAGLE's tile selection (reference src/stamp/encoding/encoder/eagle.py:106-118: `torch.topk(attention_raw, min(25, N))`, then the mean of
+ * the matching rows of the aggregation features): idx_out[r], r < k, = index of the r-th largest score (ties: the lower index first),
+ * mean_out[c] = mean_r rows[idx_out[r]][c].  1 <= k <= min(32, n); rows f32 / f16 [n][ld]; score = attn_raw of amds_gated_attn_pool. */
+int amds_topk_rows_mean(const float* score, int n, int k, const void* rows, long ld, int cols, int rows_dtype, int* idx_out, float* mean_out,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small rows of the MIL path
  * ---------------------------------------------------------------------------------------------- */

@@ -200,6 +200,7 @@ PROTOTYPES = {
     "amds_ppeg_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amds_relu_bwd": (_i, [_vp, _vp, _vp, _l, _vp]),
     "amds_mean_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "amds_topk_rows_mean": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp]),
     "amds_pinv_init_bwd_workspace_bytes": (_sz, [_i]),
     "amds_pinv_init_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_gemm_batched": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp]),

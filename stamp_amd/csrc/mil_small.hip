@@ -50,6 +50,52 @@ __global__ void mean_pool_bwd_kernel(const float* __restrict__ dy, float* __rest
     }
 }
 
+
+// EAGLE's tile selection (reference src/stamp/encoding/encoder/eagle.py:106-118): the k largest attention scores of a slide (k <= 32,
+// ties -> the lower index), in descending order, and the mean of the matching rows of a second feature matrix.  One workgroup: k rounds
+// of an argmax over the n scores (n ~ 10^4..10^5, k = 25: a few 10 us), then the column means.
+template <typename T>
+__global__ void __launch_bounds__(1024) topk_rows_mean_kernel(const float* __restrict__ score, int n, int k, const T* __restrict__ rows, long ld, int cols,
+                                                               int* __restrict__ idx_out, float* __restrict__ mean_out) {
+    __shared__ int sel[32];
+    __shared__ float wv[16];
+    __shared__ int wi[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            bool taken = false;
+            for (int q = 0; q < r; ++q) taken |= (sel[q] == i);
+            if (taken) continue;
+            const float v = score[i];
+            if (bi == 0x7fffffff || v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = wv[0];
+            int ix = wi[0];
+            for (int w2 = 1; w2 < 16; ++w2)
+                if (wi[w2] != 0x7fffffff && (ix == 0x7fffffff || wv[w2] > v || (wv[w2] == v && wi[w2] < ix))) { v = wv[w2]; ix = wi[w2]; }
+            sel[r] = ix;
+            idx_out[r] = ix;
+        }
+        __syncthreads();
+    }
+    const float inv = 1.0f / (float)k;
+    for (int c = tid; c < cols; c += 1024) {
+        float acc = 0.f;
+        for (int r = 0; r < k; ++r) acc += (float)rows[(long)sel[r] * ld + c];
+        mean_out[c] = acc * inv;
+    }
+}
+
 }  // namespace amds
 
 using namespace amds;
@@ -111,4 +157,18 @@ extern "C" int amds_linear_f32(const float* x, const float* w, const float* bias
     AMDS_REQUIRE(M >= 0 && N > 0 && K > 0, "amds_linear_f32: bad shape");
     if (M == 0) return AMDS_OK;
     return gemm_f32(x, K, w, K, bias, out, N, M, N, K, relu, (hipStream_t)stream);
+}
+
+extern "C" int amds_topk_rows_mean(const float* score, int n, int k, const void* rows, long ld, int cols, int rows_dtype, int* idx_out, float* mean_out,
+                                   void* stream) {
+    AMDS_REQUIRE(score && rows && idx_out && mean_out, "amds_topk_rows_mean: null pointer");
+    AMDS_REQUIRE(n > 0 && k > 0 && k <= 32 && k <= n && cols > 0 && ld >= cols, "amds_topk_rows_mean: bad sizes n=%d k=%d cols=%d (1 <= k <= min(32, n))", n, k, cols);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows_dtype == AMDS_F32)
+        hipLaunchKernelGGL((topk_rows_mean_kernel<float>), dim3(1), dim3(1024), 0, st, score, n, k, (const float*)rows, ld, cols, idx_out, mean_out);
+    else if (rows_dtype == AMDS_F16)
+        hipLaunchKernelGGL((topk_rows_mean_kernel<f16>), dim3(1), dim3(1024), 0, st, score, n, k, (const f16*)rows, ld, cols, idx_out, mean_out);
+    else { set_error("amds_topk_rows_mean: bad dtype %d", rows_dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("topk_rows_mean_kernel");
+    return AMDS_OK;
 }

@@ -153,6 +153,137 @@ class HipGatedAttentionEncoder:
             self._save_features_(output_path, self._generate_patient_embedding(feats_list, device, **kwargs), "patient")
 
 
+def align_by_coords(ref_coords_um: np.ndarray, other_coords_um: np.ndarray, decimals: int = 5) -> np.ndarray:
+    """The reference's `_align_vir2_to_ctp_by_coords` (eagle.py:265-300) as a permutation: other[perm[i]] lies at ref[i]'s coordinate (rounded
+    to `decimals`); duplicates are matched in file order; a coordinate missing from `other`, or left over in it, raises ValueError."""
+    from collections import defaultdict, deque
+    ref = np.round(np.asarray(ref_coords_um, dtype=np.float64), decimals)
+    oth = np.round(np.asarray(other_coords_um, dtype=np.float64), decimals)
+    buckets: dict = defaultdict(deque)
+    for j, key in enumerate(map(tuple, oth)):
+        buckets[key].append(j)
+    perm = np.empty(ref.shape[0], dtype=np.int64)
+    for i, key in enumerate(map(tuple, ref)):
+        if not buckets[key]:
+            raise ValueError(f"Missing coord in other set: {key}")
+        perm[i] = buckets[key].popleft()
+    unused = sum(len(q) for q in buckets.values())
+    if unused != 0:
+        raise ValueError(f"virchow2 features contain {unused} extra coords not in ref.")
+    return perm
+
+
+class HipEagleEncoder(HipGatedAttentionEncoder):
+    """The reference's EAGLE slide / patient encoder (src/stamp/encoding/encoder/eagle.py:28-263) on the HIP path: CHIEF's gated-attention scores
+    of a slide's CTransPath tile features (`amds_gated_attn_pool`'s attention_raw) pick the 25 highest-scoring tiles, the embedding is the mean
+    of THOSE tiles' Virchow2 features (`amds_topk_rows_mean`: selection and mean in one launch).  Same seam as the reference class:
+    `_generate_slide_embedding(feats, device, agg_feats=)`, `_generate_patient_embedding(feats_list, device, agg_feats_list=)`,
+    `encode_slides_(..., agg_feat_dir=)`, `encode_patients_(..., agg_feat_dir=)`; the two feature files of a slide must describe the same
+    tiles -- a permuted second file is re-ordered by coordinates (:66-81), anything else is an error for that slide."""
+    TOP_K = 25                                                                                   # eagle.py:107
+
+    def __init__(self, state_dict: dict[str, torch.Tensor], *, identifier: str = "eagle", required_extractors: tuple[str, ...] = ("ctranspath", "chief-ctranspath"),
+                 required_agg_extractor: str = "virchow2", device="cuda") -> None:
+        super().__init__(state_dict, identifier=identifier, required_extractors=required_extractors, device=device)
+        self.required_agg_extractor = required_agg_extractor                                      # eagle.py:30
+
+    def top_tiles(self, feats: torch.Tensor) -> torch.Tensor:
+        """Indices (descending score) of the tiles EAGLE keeps."""
+        araw = self.attention_raw(feats)
+        k = min(self.TOP_K, araw.shape[0])
+        return ops.topk_rows_mean(araw, feats.to(self.device, torch.float32).contiguous(), k)[0].long()
+
+    @torch.no_grad()
+    def _generate_slide_embedding(self, feats: torch.Tensor, device=None, agg_feats: torch.Tensor | None = None, **kwargs) -> np.ndarray:
+        if agg_feats is None:
+            raise ValueError("agg_feats is required for slide embedding")                        # eagle.py:98-99
+        if feats.dim() != 2 or feats.shape[0] == 0:
+            raise ValueError(f"expected a non-empty [N, F] feature matrix, got {tuple(feats.shape)}")
+        if agg_feats.dim() != 2 or agg_feats.shape[0] != feats.shape[0]:
+            raise ValueError(f"agg_feats must have one row per tile: {tuple(agg_feats.shape)} vs {tuple(feats.shape)}")
+        araw = self.attention_raw(feats)
+        agg = agg_feats.to(self.device)
+        if agg.dtype not in (torch.float32, torch.float16):
+            agg = agg.float()
+        k = min(self.TOP_K, araw.shape[0])
+        _, mean = ops.topk_rows_mean(araw, agg.contiguous(), k)
+        return mean.detach().cpu().numpy()
+
+    @torch.no_grad()
+    def _generate_patient_embedding(self, feats_list: list, device=None, agg_feats_list: list | None = None, **kwargs) -> np.ndarray:
+        if agg_feats_list is None:
+            raise ValueError("agg_feats_list is required for patient embedding")                 # eagle.py:129-130
+        return self._generate_slide_embedding(torch.cat([f.to(self.device) for f in feats_list], dim=0),
+                                              agg_feats=torch.cat([f.to(self.device) for f in agg_feats_list], dim=0))
+
+    def _validate_and_read_features_with_agg(self, h5_ctp: str, h5_vir2: str, slide_name: str):
+        """(:41-94) both files read and validated; the second re-ordered to the first's tile order when it is a permutation of it."""
+        feats, coords, extractor = self._read_h5(h5_ctp)
+        if extractor not in self.required_extractors:
+            raise ValueError(f"Features must be extracted with one of {self.required_extractors}. Features located in {h5_ctp} are extracted with {extractor}")
+        agg_feats, agg_coords, extractor = self._read_h5(h5_vir2)
+        if extractor != self.required_agg_extractor:
+            raise ValueError(f"Aggregated features must be extracted with {self.required_agg_extractor} Features located in {h5_vir2} are extracted with {extractor}")
+        c0, c1 = np.asarray(coords.coords_um), np.asarray(agg_coords.coords_um)
+        if c0.shape != c1.shape or not np.allclose(c0, c1, atol=1e-5, rtol=0):
+            try:
+                perm = align_by_coords(c0, c1, decimals=5)
+            except ValueError as e:
+                raise ValueError(f"Coordinates mismatch between ctranspath and virchow2 features for slide {slide_name}. Alignment attempt failed: {e}")
+            agg_feats, c1 = agg_feats[torch.from_numpy(perm)], c1[perm]
+            if not np.allclose(c0, c1, atol=1e-5, rtol=0):
+                raise ValueError(f"Coordinates mismatch between ctranspath and virchow2 features for slide {slide_name}. Ensure that both are aligned.")
+        return feats, agg_feats
+
+    def encode_slides_(self, output_dir: Path, feat_dir: Path, device=None, generate_hash: bool = True, **kwargs) -> None:
+        """(:136-185) one slide-level file per tile-feature file of `feat_dir` whose twin exists in `agg_feat_dir`; existing outputs skipped,
+        slides whose two files do not fit together reported and skipped."""
+        agg_feat_dir = kwargs.get("agg_feat_dir")
+        if not agg_feat_dir:
+            raise ValueError("agg_feat_dir that contains virchow2 features is required for Eagle's encode_slides")
+        encode_dir = Path(output_dir) / (f"{self.identifier}-slide-{code_hash()[:8]}" if generate_hash else f"{self.identifier}-slide")
+        os.makedirs(encode_dir, exist_ok=True)
+        for name in sorted(os.listdir(feat_dir)):
+            output_path = (encode_dir / Path(name).name).with_suffix(".h5")
+            if output_path.exists():
+                _logger.info(f"skipping {name} because {output_path} already exists")
+                continue
+            try:
+                feats, agg = self._validate_and_read_features_with_agg(os.path.join(feat_dir, name), os.path.join(agg_feat_dir, name), Path(name).name)
+            except ValueError as e:
+                _logger.warning(str(e))
+                continue
+            self._save_features_(output_path, self._generate_slide_embedding(feats, device, agg_feats=agg), "slide")
+
+    def encode_patients_(self, output_dir: Path, feat_dir: Path, patient_to_files: dict[str, list[str]], device=None, generate_hash: bool = True,
+                         **kwargs) -> None:
+        """(:188-262) one patient-level file from all of the patient's slides; a slide whose file is missing is skipped, a patient with no slide
+        left is reported and skipped.  `patient_to_files`: the grouping of the reference's slide table."""
+        agg_feat_dir = kwargs.get("agg_feat_dir")
+        if not agg_feat_dir:
+            raise ValueError("agg_feat_dir that contains virchow2 features is required for Eagle's encode_patients")
+        encode_dir = Path(output_dir) / (f"{self.identifier}-pat-{code_hash()[:8]}" if generate_hash else f"{self.identifier}-pat")
+        os.makedirs(encode_dir, exist_ok=True)
+        for patient_id, files in patient_to_files.items():
+            output_path = (encode_dir / str(patient_id)).with_suffix(".h5")
+            if output_path.exists():
+                _logger.info(f"skipping {patient_id} because {output_path} already exists")
+                continue
+            feats_list, agg_list = [], []
+            for f in files:
+                try:
+                    feats, agg = self._validate_and_read_features_with_agg(os.path.join(feat_dir, f), os.path.join(agg_feat_dir, f), Path(f).stem)
+                except FileNotFoundError as e:
+                    _logger.warning(f"[{patient_id}] skip slide (FileNotFoundError): {Path(f).stem} -> {e}")
+                    continue
+                feats_list.append(feats)
+                agg_list.append(agg)
+            if not feats_list:
+                _logger.warning(f"No ctranspath features for patient {patient_id}")
+                continue
+            self._save_features_(output_path, self._generate_patient_embedding(feats_list, device, agg_feats_list=agg_list), "patient")
+
+
 class HipTitanShapedEncoder(HipGatedAttentionEncoder):
     """A STAND-IN with TITAN's interface and tensor shapes -- NOT TITAN's arithmetic.  **Parity unpinned by construction.**
 

@@ -293,6 +293,18 @@ def gated_attn_pool(x: torch.Tensor, weights: dict[str, torch.Tensor], return_at
     return (out, araw) if return_attn else out
 
 
+def topk_rows_mean(score: torch.Tensor, rows: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """(indices int32 [k] of the k largest scores, descending; mean fp32 [cols] of rows[indices]) -- EAGLE's selection (eagle.py:106-118)."""
+    _dev(score, rows)
+    assert score.dtype == torch.float32 and score.is_contiguous() and score.dim() == 1
+    assert rows.dim() == 2 and rows.stride(1) == 1 and rows.shape[0] == score.numel() and rows.dtype in (torch.float32, torch.float16)
+    idx = torch.empty(k, dtype=torch.int32, device=score.device)
+    mean = torch.empty(rows.shape[1], dtype=torch.float32, device=score.device)
+    _lib.check(_lib.lib().amds_topk_rows_mean(_p(score), score.numel(), k, _p(rows), rows.stride(0), rows.shape[1], _DT[rows.dtype], _p(idx), _p(mean),
+                                              _stream()), "topk_rows_mean")
+    return idx, mean
+
+
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, n_out: int, out_dtype: torch.dtype) -> torch.Tensor:
     """dst[i] = src[idx[i]] (cast to out_dtype) for i < len(idx), zero rows up to n_out."""
     _dev(src, idx)

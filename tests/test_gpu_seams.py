@@ -225,3 +225,65 @@ def test_titan_shaped_stand_in_seam(gpu, tmp_path):
                              tile_size_px=224, code_hash="0a1b2c3d", stamp_version="2.5.0")
     with pytest.raises(ValueError, match="same mpp"):
         enc.encode_patients_(tmp_path / "out2", tmp_path, {"P2": ["s1.h5", "s3.h5"]}, device=gpu, generate_hash=False)
+
+
+def test_eagle_encoder_matches_reference_fixture_and_file_loop(gpu, tmp_path):
+    """The reference's EAGLE encoder (encoding/encoder/eagle.py): HIP selection + mean against the fixture made by the reference's own
+    `_generate_slide_embedding`, then its file loops on real .h5 pairs -- a permuted Virchow2 file is re-ordered by coordinates, a file from the
+    wrong extractor or with foreign coordinates is reported and skipped, a patient = its slides concatenated."""
+    from oracle import eagle
+    from stamp_amd import h5io, ops
+    from stamp_amd.encoder import HipEagleEncoder
+
+    z = np.load(Path(__file__).parent / "golden" / "eagle.npz")
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    enc = HipEagleEncoder(sd, device=gpu)
+    assert enc.identifier == "eagle" and enc.required_extractors == ["ctranspath", "chief-ctranspath"] and enc.required_agg_extractor == "virchow2"
+    for tag in ("a", "b"):
+        x, agg = torch.from_numpy(z[f"{tag}_x"]), torch.from_numpy(z[f"{tag}_agg"])
+        emb = enc._generate_slide_embedding(x, gpu, agg_feats=agg)
+        assert emb.dtype == np.float32 and emb.shape == (agg.shape[1],)
+        np.testing.assert_allclose(emb, z[f"{tag}_emb"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(enc.top_tiles(x).cpu().numpy(), z[f"{tag}_top"])                      # the same 25 (or N) tiles, in the same order
+        emb16 = enc._generate_slide_embedding(x, gpu, agg_feats=agg.half())                         # fp16 aggregation features as stored on disk
+        np.testing.assert_allclose(emb16, z[f"{tag}_emb"], rtol=1e-5, atol=1e-6)                    # (the fixture's values are fp16-exact)
+    with pytest.raises(ValueError, match="agg_feats is required"):
+        enc._generate_slide_embedding(torch.from_numpy(z["a_x"]), gpu)
+    # ties: the lower index wins, k <= 32 enforced
+    sc = torch.tensor([1.0, 3.0, 3.0, 2.0, 3.0], device=gpu)
+    rows = torch.arange(5, dtype=torch.float32, device=gpu).unsqueeze(1).repeat(1, 4).contiguous()
+    idx, mean = ops.topk_rows_mean(sc, rows, 3)
+    assert idx.tolist() == [1, 2, 4] and torch.allclose(mean, torch.full((4,), 7.0 / 3.0, device=gpu))
+    with pytest.raises(RuntimeError, match="1 <= k"):
+        ops.topk_rows_mean(sc, rows, 6)
+    # ---- file loops
+    g = torch.Generator().manual_seed(5)
+    ctp_dir, vir_dir, out_dir = tmp_path / "ctp", tmp_path / "vir", tmp_path / "out"
+    Fd = z["a_x"].shape[1]
+    slides = {}
+    for name, n in (("s1", 120), ("s2", 40), ("s3", 30), ("s4", 20)):
+        f = (torch.randn(n, Fd, generator=g) * 0.7).half()
+        a = torch.randn(n, 96, generator=g).half()
+        c = (torch.stack([torch.arange(n) % 13, torch.arange(n) // 13], 1) * 256.0).float()
+        slides[name] = (f, a, c)
+        h5io.write_tile_features(ctp_dir / f"{name}.h5", f, c, extractor="chief-ctranspath-0a1b2c3d" if name != "s3" else "uni2", tile_size_um=256.0, tile_size_px=224,
+                                 code_hash="x", stamp_version="2.5.0")
+        perm = torch.randperm(n, generator=g) if name == "s2" else torch.arange(n)                   # s2: the Virchow2 file lists the tiles in another order
+        ca = c[perm] if name != "s4" else c[perm] + 1000.0                                             # s4: coordinates of some other slide
+        h5io.write_tile_features(vir_dir / f"{name}.h5", a[perm], ca, extractor="virchow2", tile_size_um=256.0, tile_size_px=224, code_hash="x", stamp_version="2.5.0")
+    with pytest.raises(ValueError, match="agg_feat_dir"):
+        enc.encode_slides_(out_dir, ctp_dir, gpu, generate_hash=False)
+    enc.encode_slides_(out_dir, ctp_dir, gpu, generate_hash=False, agg_feat_dir=vir_dir)
+    assert sorted(p.name for p in (out_dir / "eagle-slide").glob("*.h5")) == ["s1.h5", "s2.h5"]     # s3: wrong extractor; s4: coordinates do not match
+    for name in ("s1", "s2"):
+        f, a, _ = slides[name]
+        d, at = h5io.read_file(out_dir / "eagle-slide" / f"{name}.h5")
+        ref, _ = eagle.eagle_slide_embedding(f.float(), a.float(), sd)
+        assert at["feat_type"] == "slide" and at["encoder"] == "eagle" and d["feats"].shape == (96,)
+        np.testing.assert_allclose(d["feats"], ref, rtol=1e-5, atol=1e-6)
+    enc.encode_patients_(out_dir, ctp_dir, {"P1": ["s1.h5", "s2.h5", "missing.h5"], "P2": ["missing.h5"]}, gpu, generate_hash=False, agg_feat_dir=vir_dir)
+    assert sorted(p.name for p in (out_dir / "eagle-pat").glob("*.h5")) == ["P1.h5"]
+    d, at = h5io.read_file(out_dir / "eagle-pat" / "P1.h5")
+    refp = eagle.eagle_patient_embedding([slides["s1"][0].float(), slides["s2"][0].float()], [slides["s1"][1].float(), slides["s2"][1].float()], sd)
+    assert at["feat_type"] == "patient"
+    np.testing.assert_allclose(d["feats"], refp, rtol=1e-5, atol=1e-6)

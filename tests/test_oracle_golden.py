@@ -216,3 +216,34 @@ def test_mil_vit_train_mode_matches_reference(tag, alibi):
     loss.backward()
     for k, g in grads.items():
         np.testing.assert_allclose(params[k].grad.numpy(), g.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_eagle_slide_embedding_golden(tag):
+    """oracle/eagle.py against the outputs of the reference's own `Eagle._generate_slide_embedding` (tools/make_golden.py::golden_eagle)."""
+    from oracle import eagle
+    z, sd = _load("eagle.npz")
+    x, agg = torch.from_numpy(z[f"{tag}_x"]), torch.from_numpy(z[f"{tag}_agg"])
+    emb, top = eagle.eagle_slide_embedding(x, agg, sd)
+    assert np.array_equal(top, z[f"{tag}_top"]) and len(top) == min(25, x.shape[0])
+    np.testing.assert_allclose(emb, z[f"{tag}_emb"], rtol=1e-6, atol=1e-7)
+    assert emb.dtype == np.float32 and emb.shape == (agg.shape[1],)
+    pe = eagle.eagle_patient_embedding([x[:5], x[5:]], [agg[:5], agg[5:]], sd)                 # a patient = its slides concatenated
+    np.testing.assert_allclose(pe, z[f"{tag}_emb"], rtol=1e-6, atol=1e-7)
+
+
+def test_eagle_coordinate_alignment_golden():
+    from oracle import eagle
+    from stamp_amd.encoder import align_by_coords
+    z = np.load(G / "eagle.npz")
+    # the fixture's `other` file holds the reference tiles in shuffled order (+ sub-rounding jitter, one duplicated coordinate); its feature rows
+    # carry their own position in the ORIGINAL order, so the reference's aligned features read 0..59 except where duplicates may swap
+    for fn in (eagle.align_by_coords, align_by_coords):            # the oracle and the product's host-side twin
+        perm = fn(z["al_ref"], z["al_other"], 5)
+        assert np.array_equal(z["al_other"][perm], z["al_coords"])
+        assert sorted(perm.tolist()) == list(range(60)) and np.array_equal(z["al_ids"][perm], z["al_rows"])      # the same rows as the reference picked
+        with pytest.raises(ValueError, match="Missing coord"):
+            fn(z["al_ref"], z["al_other"][:-1], 5)
+        with pytest.raises(ValueError, match="extra coords"):
+            fn(z["al_ref"][:-1], z["al_other"], 5)
+    assert np.array_equal(np.sort(z["al_rows"]), np.arange(60))

@@ -137,6 +137,53 @@ def golden_chief() -> None:
              **{k: v for k, v in sd_np(model).items() if k.startswith("w:attention_net.")})  # only the used path
 
 
+def golden_eagle() -> None:
+    """EAGLE slide encoder: the reference's own `_generate_slide_embedding` (run as a plain function on a stand-in `self` holding the reference's
+    CHIEFModel) and its coordinate alignment helper, on seeded inputs."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    glb = {"nn": nn, "torch": torch, "F": F, "np": np}
+    exec_defs(REF / "encoding" / "encoder" / "chief.py", {"CHIEFModel", "Attn_Net_Gated", "Attn_Net", "Att_Head", "initialize_weights"}, glb)
+    from collections import defaultdict, deque
+    eg = {"torch": torch, "np": np, "Tensor": torch.Tensor, "DeviceLikeType": object, "defaultdict": defaultdict, "deque": deque}
+    gen = exec_method(REF / "encoding" / "encoder" / "eagle.py", "_generate_slide_embedding", eg)
+    exec_defs(REF / "encoding" / "encoder" / "eagle.py", {"_align_vir2_to_ctp_by_coords"}, eg)
+    align = eg["_align_vir2_to_ctp_by_coords"]
+    out = {}
+    torch.manual_seed(500)
+    model = glb["CHIEFModel"](size_arg="xs", dropout=True, n_classes=2).eval()
+    Fdim = model.size_dict["xs"][0]
+    with torch.no_grad():           # values exactly representable in 16 bits: the fixture compresses to a fraction of its size
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            p.copy_(p.bfloat16().float())
+    out.update({k: v for k, v in sd_np(model).items() if k.startswith("w:attention_net.")})
+    for tag, N in (("a", 200), ("b", 9)):                       # b: fewer tiles than the 25 EAGLE keeps
+        x = (torch.randn(N, Fdim) * 0.7).half().float()
+        agg = torch.randn(N, 64).half().float()
+        me = types.SimpleNamespace(model=model)
+        emb = gen(me, x, "cpu", agg)
+        with torch.no_grad():
+            araw = model(x)["attention_raw"].squeeze(0)
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_agg": agg.numpy(), f"{tag}_emb": emb, f"{tag}_top": torch.topk(araw, min(25, N))[1].numpy(),
+                    f"{tag}_araw": araw.numpy()})
+    # alignment: a shuffled copy of a coordinate set that contains one duplicate pair
+    rng = np.random.default_rng(7)
+    ref = (rng.integers(0, 40, (60, 2)) * 256.0).astype(np.float32)
+    ref[17] = ref[3]
+    perm0 = rng.permutation(60)
+    other = ref[perm0] + rng.uniform(-2e-6, 2e-6, (60, 2)).astype(np.float32)
+    feats = torch.arange(60, dtype=torch.float32).unsqueeze(1).repeat(1, 3)[perm0]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        al_feats, al_coords = align(ref, other, feats, 5)
+    out.update(al_ref=ref, al_other=other, al_ids=feats[:, 0].numpy().astype(np.int64), al_rows=al_feats[:, 0].numpy().astype(np.int64), al_coords=al_coords)
+    save("eagle.npz", **out)
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -527,6 +574,7 @@ def golden_texture_gray() -> None:
 def main() -> None:
     install_shims()
     golden_chief()
+    golden_eagle()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
