@@ -703,6 +703,32 @@ int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w,
 int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
               const float* b3, int B, int H, int W, int C, void* stream);
 
+/* The whole deploy / validation forward of the TransMIL head as one call (reference src/stamp/modeling/models/trans_mil.py:299-326 in eval
+ * mode; called from the same Lightning steps as the `vit` head, models/__init__.py:288-313): fp32 throughout.  heads = 8, landmarks =
+ * dim / 2, 6 pseudo-inverse iterations, 33-tap residual convolution (:252-254, :52). */
+typedef struct { int n_feats; int dim; int classes; } amds_transmil_cfg;      /* dim_input, dim_hidden (multiple of 8), dim_output */
+typedef struct {
+    const float* norm_w; const float* norm_b;      /* [dim]            layerN.norm                       :248 */
+    const float* qkv_w;                            /* [3 dim][dim]     layerN.attn.to_qkv (no bias)      :64 */
+    const float* out_w; const float* out_b;        /* [dim][dim],[dim] layerN.attn.to_out.0              :66 */
+    const float* conv_w;                           /* [8][33]          layerN.attn.res_conv.weight       :71-78 */
+} amds_transmil_layer;
+typedef struct {
+    const float* fc1_w; const float* fc1_b;        /* [dim][n_feats], [dim]     _fc1.0                   :290 */
+    const float* cls_token;                        /* [dim]                                              :291 */
+    amds_transmil_layer layer[2];                  /* layer1, layer2                                     :293-294 */
+    const float* ppeg_w7; const float* ppeg_b7;    /* [dim][49], [dim]          pos_layer.proj           :269 */
+    const float* ppeg_w5; const float* ppeg_b5;    /* [dim][25]                 pos_layer.proj1          :270 */
+    const float* ppeg_w3; const float* ppeg_b3;    /* [dim][9]                  pos_layer.proj2          :271 */
+    const float* norm_w; const float* norm_b;      /* [dim]                     norm                     :295 */
+    const float* fc2_w; const float* fc2_b;        /* [classes][dim], [classes] _fc2                     :296 */
+} amds_transmil_weights;                           /* device pointers, fp32 */
+size_t amds_transmil_workspace_bytes(const amds_transmil_cfg* cfg_host, int n_bags, int n_tiles);
+/* bags: [n_bags][n_tiles][n_feats] contiguous, AMDS_F32 / AMDS_F16 / AMDS_BF16 (cast to fp32 like the reference); logits fp32
+ * [n_bags][classes].  Launches only, on `stream`; ws 256-byte aligned. */
+int amds_transmil_forward(const amds_transmil_cfg* cfg_host, const amds_transmil_weights* w_host, const void* bags, int bags_dtype, float* logits,
+                          int n_bags, int n_tiles, void* ws, size_t ws_bytes, void* stream);
+
 /* Backward pieces of the TransMIL head (training: the reference differentiates trans_mil.py with autograd inside
  * LitTileClassifier._step, src/stamp/modeling/models/__init__.py:239-279); fp32 like the forward.  The matrix products of the
  * backward are amds_bgemm_f32 calls.

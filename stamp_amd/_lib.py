@@ -88,6 +88,19 @@ class MilVitGrads(C.Structure):
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
 
 
+class TransMilCfg(C.Structure):
+    _fields_ = [("n_feats", C.c_int), ("dim", C.c_int), ("classes", C.c_int)]
+
+
+class TransMilLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "qkv_w", "out_w", "out_b", "conv_w")]
+
+
+class TransMilWeights(C.Structure):
+    _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("cls_token", C.c_void_p), ("layer", TransMilLayer * 2)] + \
+               [(n, C.c_void_p) for n in ("ppeg_w7", "ppeg_b7", "ppeg_w5", "ppeg_b5", "ppeg_w3", "ppeg_b3", "norm_w", "norm_b", "fc2_w", "fc2_b")]
+
+
 class SwinCfg(C.Structure):
     _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
                 ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
@@ -182,6 +195,8 @@ PROTOTYPES = {
     "amds_linear_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_mil_vit_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_mil_vit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "amds_transmil_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_mil_vit_train_saved_bytes": (_sz, [_vp, _i, _i]),
     "amds_mil_vit_train_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "amds_mil_vit_train_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),

@@ -401,6 +401,9 @@ def _bgemm(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer,
                                          torch.cuda.current_stream().cuda_stream), "bgemm_f32")
 
 
+_TRANSMIL_WS: dict = {}
+
+
 class TransMIL(nn.Module):
     """Same constructor and state_dict keys as the reference TransMIL (trans_mil.py:286-326); fp32 on the HIP path.  Inference forward
     below; training (forward with saved intermediates + hand-derived backward) in stamp_amd/transmil_core.py, reached through one
@@ -512,6 +515,65 @@ class TransMIL(nn.Module):
                 return _TransMilFunction.apply(h, holder, self, self.training, seed, *params)
             with torch.no_grad():
                 return _TransMilFunction.forward(h, holder, self, self.training, seed, *params)
+        return self._forward_c(h)
+
+    # ---- deploy / validation forward: ONE library call (amds_transmil_forward, csrc/transmil_fwd.hip) -----------------------------------
+    def _c_weights(self, dev):
+        """amds_transmil_weights over fp32 device copies of the parameters, rebuilt when a parameter changed (version counters)."""
+        tensors = dict(self.named_parameters())
+        key = (str(dev), tuple((t.data_ptr(), t._version) for t in tensors.values()))
+        if getattr(self, "_cw_key", None) != key:
+            g = lambda n: tensors[n].detach().to(dev, torch.float32).contiguous()  # noqa: E731
+            keep = {}
+
+            def ptr(name, shape=None):
+                t = g(name)
+                if shape is not None:
+                    t = t.reshape(shape).contiguous()
+                keep[name] = t
+                return t.data_ptr()
+
+            Cd = self.dim_hidden
+            w = _lib.TransMilWeights()
+            w.fc1_w, w.fc1_b, w.cls_token = ptr("_fc1.0.weight"), ptr("_fc1.0.bias"), ptr("cls_token", (Cd,))
+            for i, nm in enumerate(("layer1", "layer2")):
+                w.layer[i] = _lib.TransMilLayer(ptr(f"{nm}.norm.weight"), ptr(f"{nm}.norm.bias"), ptr(f"{nm}.attn.to_qkv.weight"), ptr(f"{nm}.attn.to_out.0.weight"),
+                                                ptr(f"{nm}.attn.to_out.0.bias"), ptr(f"{nm}.attn.res_conv.weight", (8, -1)))
+            w.ppeg_w7, w.ppeg_b7 = ptr("pos_layer.proj.weight", (Cd, -1)), ptr("pos_layer.proj.bias")
+            w.ppeg_w5, w.ppeg_b5 = ptr("pos_layer.proj1.weight", (Cd, -1)), ptr("pos_layer.proj1.bias")
+            w.ppeg_w3, w.ppeg_b3 = ptr("pos_layer.proj2.weight", (Cd, -1)), ptr("pos_layer.proj2.bias")
+            w.norm_w, w.norm_b, w.fc2_w, w.fc2_b = ptr("norm.weight"), ptr("norm.bias"), ptr("_fc2.weight"), ptr("_fc2.bias")
+            self._cw, self._cw_keep, self._cw_key = w, keep, key
+        return self._cw
+
+    def _forward_c(self, h: torch.Tensor) -> torch.Tensor:
+        import ctypes as C
+        Bb, T, F = h.shape
+        dev = h.device
+        if h.dtype not in ops._DT:
+            h = h.float()
+        h = h.contiguous()
+        cfg = _lib.TransMilCfg(F, self.dim_hidden, self.n_classes)
+        if self._fc1[0].in_features != F:
+            raise ValueError(f"bags must be [batch, tile, {self._fc1[0].in_features}], got {tuple(h.shape)}")
+        w = self._c_weights(dev)
+        lib = _lib.lib()
+        need = lib.amds_transmil_workspace_bytes(C.byref(cfg), Bb, T)
+        if need == 0:
+            _lib.check(-1, "transmil_workspace_bytes")
+        ws = _TRANSMIL_WS.get(dev)
+        if ws is None or ws.numel() < need:
+            _TRANSMIL_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        logits = torch.empty(Bb, self.n_classes, dtype=torch.float32, device=dev)
+        _lib.check(lib.amds_transmil_forward(C.byref(cfg), C.byref(w), h.data_ptr(), ops._DT[h.dtype], logits.data_ptr(), Bb, T, ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream), "transmil_forward")
+        return logits
+
+    def _forward_stepwise(self, h: torch.Tensor) -> torch.Tensor:
+        """The same forward, one library call per kernel from the host (what `forward` did before amds_transmil_forward existed): kept as the
+        cross-check of the C entry point in tests/ -- bit-identical logits."""
+        import math
+        Bb, T, F = h.shape
         Cd = self.dim_hidden
         x = ops.linear_f32(h.reshape(Bb * T, F).float().contiguous(), self._f(self._fc1[0].weight), self._f(self._fc1[0].bias), relu=True)
         x = x.view(Bb, T, Cd)

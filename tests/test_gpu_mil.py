@@ -312,3 +312,24 @@ def test_mil_vit_forward_c_abi_guards(gpu):
     assert rc == -2 and b"workspace" in lib.amds_last_error()      # AMDS_ERR_WORKSPACE
     rc = lib.amds_mil_vit_forward(C.byref(cfg), C.byref(wc), None, _lib.F16, None, None, out.data_ptr(), 4, 512, small.data_ptr(), small.numel(), None)
     assert rc == -1 and b"null" in lib.amds_last_error()              # AMDS_ERR_INVALID
+
+
+@pytest.mark.parametrize("Bb,T,F,Cd,bdt", [(2, 1024, 1024, 512, torch.float16), (3, 50, 768, 256, torch.float32), (1, 300, 512, 512, torch.float16), (2, 1, 128, 64, torch.float32),
+                                           (1, 4100, 256, 128, torch.bfloat16)])
+def test_transmil_forward_one_call_equals_the_kernel_by_kernel_chain(gpu, Bb, T, F, Cd, bdt):
+    """amds_transmil_forward (one C call) against the same kernels launched one by one from the host: bit-identical logits -- with and
+    without the front padding of the Nystrom attention, a single tile, square and non-square tile counts, every bag dtype."""
+    from stamp_amd.mil import TransMIL
+    torch.manual_seed(T + Cd)
+    model = TransMIL(dim_output=3, dim_input=F, dim_hidden=Cd).eval().to(gpu)
+    bags = torch.randn(Bb, T, F).to(bdt).to(gpu)
+    with torch.no_grad():
+        one = model(bags)
+        chain = model._forward_stepwise(bags)
+    assert one.shape == (Bb, 3) and torch.isfinite(one).all() and torch.equal(one, chain)
+    with torch.no_grad():
+        model._fc2.bias.add_(1.0)                          # the cached device weights follow the parameters
+        assert torch.allclose(model(bags), one + 1.0, atol=1e-5)
+    with pytest.raises(ValueError, match="bags must be"):
+        with torch.no_grad():
+            model(bags[..., :-1])
