@@ -729,6 +729,26 @@ size_t amds_transmil_workspace_bytes(const amds_transmil_cfg* cfg_host, int n_ba
 int amds_transmil_forward(const amds_transmil_cfg* cfg_host, const amds_transmil_weights* w_host, const void* bags, int bags_dtype, float* logits,
                           int n_bags, int n_tiles, void* ws, size_t ws_bytes, void* stream);
 
+/* One TransMIL layer's attention in TRAINING, forward and backward as one call each (reference trans_mil.py:81-163 with mask = None, the
+ * residual of :263, `to_out`'s Dropout(0.1) of :66 live when p_drop > 0; loss.backward() through it, models/__init__.py:239-279):
+ *   fwd:  x_res[b][n][dim] += Dropout(to_out(NystromAttention(y[b][n][dim])))     -- every intermediate the backward reads goes to `saved`
+ *   bwd:  dy[b][n][dim] = gradient w.r.t. y given dx = the gradient of the residual stream after the block; parameter gradients into
+ *         grads_host (reference shapes, or NULL).  `saved` is read-only in the backward (several backwards may follow one forward).
+ * The dropout mask is the counter-based function of (seed, stream_id, element) of amds_dropout_add: pass the same triple to both. */
+typedef struct {
+    float* qkv_w;       /* [3 dim][dim]   attn.to_qkv.weight   */
+    float* out_w;       /* [dim][dim]     attn.to_out.0.weight */
+    float* out_b;       /* [dim]          attn.to_out.0.bias   */
+    float* conv_w;      /* [8][33]        attn.res_conv.weight */
+} amds_nystrom_grads;
+size_t amds_nystrom_attn_saved_bytes(int dim, int n_bags, int n_tokens);
+size_t amds_nystrom_attn_workspace_bytes(int dim, int n_bags, int n_tokens);
+int amds_nystrom_attn_fwd(const amds_transmil_layer* w_host, int dim, const float* y, float* x_res, int n_bags, int n_tokens, float p_drop,
+                          uint64_t seed, uint32_t stream_id, void* saved, size_t saved_bytes, void* stream);
+int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim, const float* dx, float* dy, const amds_nystrom_grads* grads_host, int n_bags,
+                          int n_tokens, float p_drop, uint64_t seed, uint32_t stream_id, const void* saved, size_t saved_bytes, void* ws,
+                          size_t ws_bytes, void* stream);
+
 /* Backward pieces of the TransMIL head (training: the reference differentiates trans_mil.py with autograd inside
  * LitTileClassifier._step, src/stamp/modeling/models/__init__.py:239-279); fp32 like the forward.  The matrix products of the
  * backward are amds_bgemm_f32 calls.

@@ -101,6 +101,10 @@ class TransMilWeights(C.Structure):
                [(n, C.c_void_p) for n in ("ppeg_w7", "ppeg_b7", "ppeg_w5", "ppeg_b5", "ppeg_w3", "ppeg_b3", "norm_w", "norm_b", "fc2_w", "fc2_b")]
 
 
+class NystromGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "out_w", "out_b", "conv_w")]
+
+
 class SwinCfg(C.Structure):
     _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
                 ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
@@ -196,6 +200,10 @@ PROTOTYPES = {
     "amds_mil_vit_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_mil_vit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
+    "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amds_nystrom_attn_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _vp, _sz, _vp]),
+    "amds_nystrom_attn_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _vp, _sz, _vp, _sz, _vp]),
     "amds_transmil_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_mil_vit_train_saved_bytes": (_sz, [_vp, _i, _i]),
     "amds_mil_vit_train_workspace_bytes": (_sz, [_vp, _i, _i, _i]),

@@ -84,8 +84,68 @@ class _Nys:
         self.wconv = get(f"{name}.attn.res_conv.weight").reshape(HEADS, -1).contiguous()
 
 
+_NY_WS: dict = {}
+STEPWISE = False        # tests flip this to run the kernel-by-kernel chains below instead of the two library calls
+
+
+def _layer_struct(P: _Nys) -> "_lib.TransMilLayer":
+    return _lib.TransMilLayer(P.norm_w.data_ptr(), P.norm_b.data_ptr(), P.wqkv.data_ptr(), P.wo.data_ptr(), P.bo.data_ptr(), P.wconv.data_ptr())
+
+
 def nystrom_forward(y: torch.Tensor, P: _Nys, x_res: torch.Tensor, p_drop: float, seed: int, sid: int):
-    """x_res += Dropout(to_out(NystromAttention(y)))[:, -n:]; returns what the backward needs."""
+    """x_res += Dropout(to_out(NystromAttention(y)))[:, -n:]; returns what the backward needs.  ONE library call (amds_nystrom_attn_fwd,
+    csrc/nystrom_train.hip): the intermediates live in one arena the backward reads."""
+    if STEPWISE:
+        return nystrom_forward_stepwise(y, P, x_res, p_drop, seed, sid)
+    import ctypes as C
+    b, n, Cd = y.shape
+    assert y.is_contiguous() and x_res.is_contiguous() and y.dtype == torch.float32 and x_res.dtype == torch.float32
+    lib = _lib.lib()
+    need = lib.amds_nystrom_attn_saved_bytes(Cd, b, n)
+    if need == 0:
+        _lib.check(-1, "nystrom_attn_saved_bytes")
+    arena = torch.empty(need, dtype=torch.uint8, device=y.device)
+    L = _layer_struct(P)
+    _lib.check(lib.amds_nystrom_attn_fwd(C.byref(L), Cd, y.data_ptr(), x_res.data_ptr(), b, n, float(p_drop), int(seed) & (2 ** 64 - 1), int(sid),
+                                         arena.data_ptr(), arena.numel(), ops._stream()), "nystrom_attn_fwd")
+    return dict(arena=arena, n=n, p_drop=p_drop, seed=seed, sid=sid)
+
+
+def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = True):
+    """dx: gradient of the residual stream after the block [b, n, C] -> (dy [b, n, C] gradient w.r.t. the LayerNorm output, grads).
+    ONE library call (amds_nystrom_attn_bwd)."""
+    if "arena" not in S:
+        return nystrom_backward_stepwise(S, P, dx, need_params)
+    import ctypes as C
+    b, n, Cd = dx.shape
+    dev = dx.device
+    dx = dx.contiguous()
+    lib = _lib.lib()
+    need = lib.amds_nystrom_attn_workspace_bytes(Cd, b, n)
+    if need == 0:
+        _lib.check(-1, "nystrom_attn_workspace_bytes")
+    ws = _NY_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        _NY_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    dy = torch.empty(b, n, Cd, dtype=torch.float32, device=dev)
+    G, gc = {}, None
+    if need_params:
+        f32 = dict(dtype=torch.float32, device=dev)
+        G = {"attn.to_qkv.weight": torch.empty(3 * Cd, Cd, **f32), "attn.to_out.0.weight": torch.empty(Cd, Cd, **f32), "attn.to_out.0.bias": torch.empty(Cd, **f32),
+             "attn.res_conv.weight": torch.empty(HEADS, 1, CONV_K, 1, **f32)}
+        gc = _lib.NystromGrads(G["attn.to_qkv.weight"].data_ptr(), G["attn.to_out.0.weight"].data_ptr(), G["attn.to_out.0.bias"].data_ptr(),
+                               G["attn.res_conv.weight"].data_ptr())
+    L = _layer_struct(P)
+    arena = S["arena"]
+    _lib.check(lib.amds_nystrom_attn_bwd(C.byref(L), Cd, dx.data_ptr(), dy.data_ptr(), C.byref(gc) if gc is not None else None, b, n, float(S["p_drop"]),
+                                         int(S["seed"]) & (2 ** 64 - 1), int(S["sid"]), arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel(), ops._stream()),
+               "nystrom_attn_bwd")
+    return dy, G
+
+
+def nystrom_forward_stepwise(y: torch.Tensor, P: _Nys, x_res: torch.Tensor, p_drop: float, seed: int, sid: int):
+    """The same forward, one library call per kernel from the host (what `nystrom_forward` did before amds_nystrom_attn_fwd existed): kept as
+    the cross-check of the C entry points in tests/ -- results are bit-identical."""
     b, n, Cd = y.shape
     H, m = HEADS, Cd // 2
     d = Cd // H
@@ -143,8 +203,8 @@ def nystrom_forward(y: torch.Tensor, P: _Nys, x_res: torch.Tensor, p_drop: float
                 seed=seed, sid=sid)
 
 
-def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = True):
-    """dx: gradient of the residual stream after the block [b, n, C] -> (dy [b, n, C] gradient w.r.t. the LayerNorm output, grads)."""
+def nystrom_backward_stepwise(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = True):
+    """Backward of `nystrom_forward_stepwise` (its saved dict), kernel by kernel from the host; same results as `nystrom_backward`."""
     b, n, Cd = dx.shape
     H, m = HEADS, Cd // 2
     d = Cd // H

@@ -114,3 +114,45 @@ def test_bgemm_f32_transposed_a_and_split_k_wgrad(gpu, Z, M, N, K, transb):
         gw = tc._wgrad(A, B)                                    # sum_z A_z^T B_z
         assert ((gw.double() - want.sum(0)).norm() / want.sum(0).norm()).item() < 2e-6
         assert torch.equal(gw, tc._wgrad(A, B))                  # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("Bb,Tn,Fd,Cd,train", [(2, 50, 96, 64, False), (3, 300, 128, 128, True), (2, 1024, 256, 512, True), (1, 255, 64, 256, False)])
+def test_nystrom_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, Cd, train):
+    """amds_nystrom_attn_fwd / _bwd (one C call per layer and direction) against the same kernels launched one by one from the host: logits,
+    every parameter gradient and d/d(bags) bit-identical -- with and without front padding (n = 65 < one landmark block; n = 1025 -> 1280;
+    n = 257 on 128 landmarks -> 384), dropout live (same counter-based masks from the same seed) and off."""
+    from stamp_amd import transmil_core as tc
+    model, bags, targets = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn + 1)
+    model = model.to(gpu)
+    get = model._get(torch.device(gpu))
+    dlogits = torch.randn(Bb, 2, device=gpu)
+    res = []
+    for stepwise in (False, True):
+        tc.STEPWISE = stepwise
+        try:
+            logits, saved = tc.forward_train(get, bags.to(gpu), (Fd, Cd, 2), training=train, seed=4321)
+            G, db = tc.backward(saved, dlogits, need_params=True, need_bags=True)
+            G2, db2 = tc.backward(saved, dlogits, need_params=False, need_bags=True)        # input gradient only, saved activations untouched
+        finally:
+            tc.STEPWISE = False
+        assert G2 == {} and torch.equal(db2, db)
+        res.append((logits, G, db))
+    (l1, G1, d1), (l0, G0, d0) = res
+    assert torch.isfinite(l1).all() and torch.equal(l1, l0) and torch.equal(d1, d0)
+    assert set(G1) == set(G0) == {n for n, _ in model.named_parameters()}
+    for k in G0:
+        assert G1[k].shape == G0[k].shape == dict(model.named_parameters())[k].shape, k
+        assert torch.equal(G1[k], G0[k]), (k, (G1[k] - G0[k]).abs().max().item())
+
+
+def test_nystrom_c_abi_guards(gpu):
+    import ctypes as C
+    lib = _lib.lib()
+    assert lib.amds_nystrom_attn_saved_bytes(100, 2, 65) == 0 and b"multiple of 8" in lib.amds_last_error()
+    assert lib.amds_nystrom_attn_saved_bytes(64, 2, 65) > 0 and lib.amds_nystrom_attn_workspace_bytes(64, 2, 65) > 0
+    w = [torch.zeros(n, device=gpu) for n in (64, 64, 3 * 64 * 64, 64 * 64, 64, 8 * 33)]
+    L = _lib.TransMilLayer(*[t.data_ptr() for t in w])
+    y = torch.zeros(2, 65, 64, device=gpu)
+    small = torch.empty(1024, dtype=torch.uint8, device=gpu)
+    rc = lib.amds_nystrom_attn_fwd(C.byref(L), 64, y.data_ptr(), y.data_ptr(), 2, 65, 0.0, 0, 0, small.data_ptr(), small.numel(), None)
+    assert rc == -2 and b"arena" in lib.amds_last_error()
