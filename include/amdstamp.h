@@ -676,6 +676,52 @@ int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, const amds_mil
                                 const amds_mil_vit_grads* grads_host, float* dbags, int split_k, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * barspoon head, deploy / validation forward as one call (reference src/stamp/modeling/models/barspoon.py:27-205
+ * `EncDecTransformer` in eval mode: projector, sinusoidal position encoding, pre-norm transformer encoder over the tiles, one class
+ * token per target decoded against the tiles by a pre-norm transformer decoder, one Linear head per target)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_feats;                /* d_features */
+    int dim;                    /* d_model (head_dim = dim / heads <= 64 for both stacks, dim % 4 == 0) */
+    int enc_heads, dec_heads;   /* num_encoder_heads, num_decoder_heads */
+    int ff;                     /* dim_feedforward */
+    int enc_layers, dec_layers;
+    int n_targets;
+    int positional_encoding;
+    int dtype;                  /* MFMA operand type of the 16-bit weights: AMDS_F16 or AMDS_BF16 */
+} amds_barspoon_cfg;
+/* decoder layer: fp32 device pointers in the reference's shapes, except the cross-attention's K / V projection, which runs over the tiles:
+ * ca_kv_w 16-bit [2 Db][Dp] (Db = 64 dec_heads: K heads then V heads, each padded to 64 channels; Dp = dim rounded up to 256), ca_kv_b fp32 [2 Db] */
+typedef struct {
+    const float* ln1_w; const float* ln1_b;             /* norm1                                                   */
+    const float* sa_in_w; const float* sa_in_b;         /* self_attn.in_proj_{weight,bias}      [3 dim][dim], [3 dim] */
+    const float* sa_out_w; const float* sa_out_b;       /* self_attn.out_proj                   [dim][dim], [dim]   */
+    const float* ln2_w; const float* ln2_b;             /* norm2                                                   */
+    const float* ca_q_w; const float* ca_q_b;           /* multihead_attn.in_proj rows 0..dim   [dim][dim], [dim]   */
+    const void* ca_kv_w; const float* ca_kv_b;          /* multihead_attn.in_proj rows dim..3dim, padded (above)    */
+    const float* ca_out_w; const float* ca_out_b;       /* multihead_attn.out_proj              [dim][dim], [dim]   */
+    const float* ln3_w; const float* ln3_b;             /* norm3                                                   */
+    const float* fc1_w; const float* fc1_b;             /* linear1                              [ff][dim], [ff]     */
+    const float* fc2_w; const float* fc2_b;             /* linear2                              [dim][ff], [dim]    */
+} amds_barspoon_dec_layer;
+typedef struct {
+    const void* proj_w; const float* proj_b;            /* projector.0: 16-bit [Dp][Fp], fp32 [Dp] (padded like amds_mil_vit_weights.proj_w) */
+    const amds_mil_vit_layer* enc_layers_host;          /* HOST array: transformer_encoder.layers.l in the MIL `vit` head's padded layer form
+                                                         * (norm1 -> ln1, self_attn -> in / out, norm2 -> ln2, linear1 -> fc1, linear2 -> fc2) */
+    const float* class_tokens;                          /* [n_targets][dim], in target order                        :135-140 */
+    const amds_barspoon_dec_layer* dec_layers_host;     /* HOST array */
+    const float* const* head_w_host;                    /* HOST arrays of n_targets device pointers: heads.<t>.weight [n_out_t][dim], .bias [n_out_t] */
+    const float* const* head_b_host;
+    const int* n_out_host;                              /* HOST array: n_out_t */
+    const float* pe_div;                                /* [dim / 4] fp32: 100000^(i / dim), as torch computes it   :176-178 */
+} amds_barspoon_weights;
+size_t amds_barspoon_workspace_bytes(const amds_barspoon_cfg* cfg_host, int n_bags, int n_tiles);
+/* bags [n_bags][n_tiles][n_feats] (AMDS_F32 / F16 / BF16), positions fp32 [n_bags][n_tiles][2] (required when positional_encoding);
+ * logits fp32 [n_bags][sum_t n_out_t], target t at column offset sum_{s<t} n_out_s.  Launches only, on `stream`; ws 256-byte aligned. */
+int amds_barspoon_forward(const amds_barspoon_cfg* cfg_host, const amds_barspoon_weights* w_host, const void* bags, int bags_dtype,
+                          const float* positions, float* logits, int n_bags, int n_tiles, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * TransMIL building blocks (reference src/stamp/modeling/models/trans_mil.py), fp32 throughout
  * ---------------------------------------------------------------------------------------------- */
 

@@ -105,6 +105,21 @@ class NystromGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "out_w", "out_b", "conv_w")]
 
 
+class BarspoonCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_feats", "dim", "enc_heads", "dec_heads", "ff", "enc_layers", "dec_layers", "n_targets", "positional_encoding", "dtype")]
+
+
+class BarspoonDecLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_w", "ln2_b", "ca_q_w", "ca_q_b", "ca_kv_w", "ca_kv_b",
+                                          "ca_out_w", "ca_out_b", "ln3_w", "ln3_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class BarspoonWeights(C.Structure):
+    _fields_ = [("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("enc_layers_host", C.POINTER(MilVitLayer)), ("class_tokens", C.c_void_p),
+                ("dec_layers_host", C.POINTER(BarspoonDecLayer)), ("head_w_host", C.POINTER(C.c_void_p)), ("head_b_host", C.POINTER(C.c_void_p)),
+                ("n_out_host", C.POINTER(C.c_int)), ("pe_div", C.c_void_p)]
+
+
 class SwinCfg(C.Structure):
     _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
                 ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
@@ -199,6 +214,8 @@ PROTOTYPES = {
     "amds_linear_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_mil_vit_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_mil_vit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_barspoon_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "amds_barspoon_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -247,3 +247,19 @@ def test_eagle_coordinate_alignment_golden():
         with pytest.raises(ValueError, match="extra coords"):
             fn(z["al_ref"][:-1], z["al_other"], 5)
     assert np.array_equal(np.sort(z["al_rows"]), np.arange(60))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_barspoon_golden(tag):
+    """oracle/barspoon.py against logits of the reference's own `EncDecTransformer` (tools/make_golden.py::golden_barspoon)."""
+    from oracle import barspoon
+    z = np.load(G / "barspoon.npz")
+    sd = {k[len(tag) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}_w:")}
+    hp = z[f"{tag}_hparams"]
+    targets = [str(t) for t in z[f"{tag}_targets"]]
+    out = barspoon.barspoon_forward(torch.from_numpy(z[f"{tag}_x"]), torch.from_numpy(z[f"{tag}_pos"]), sd, targets, num_encoder_heads=int(hp[1]),
+                                    num_decoder_heads=int(hp[2]), positional_encoding=bool(hp[6]))
+    assert list(out) == targets
+    for j, t in enumerate(targets):
+        assert out[t].shape == (z[f"{tag}_x"].shape[0], int(z[f"{tag}_nout"][j]))
+        np.testing.assert_allclose(out[t].numpy(), z[f"{tag}_logits_{j}"], rtol=1e-5, atol=2e-6)

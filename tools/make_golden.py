@@ -184,6 +184,41 @@ def golden_eagle() -> None:
     save("eagle.npz", **out)
 
 
+def golden_barspoon() -> None:
+    """barspoon head: the reference's own `EncDecTransformer` (its module imports lightning / torchmetrics: only the class and `sanitize` are
+    executed), eval mode, two geometries: the defaults' shape in small (2 + 2 layers) and a single-target single-layer one without positional
+    encoding."""
+    import re
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    glb = {"nn": nn, "torch": torch, "F": F, "re": re}
+    exec_defs(REF / "modeling" / "models" / "barspoon.py", {"EncDecTransformer", "sanitize"}, glb)
+    out = {}
+    for tag, kw, targets, Fd, B, T in (("a", dict(d_model=128, num_encoder_heads=2, num_decoder_heads=2, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=256),
+                                        {"KRAS": 2, "MSI status": 3, "grade-x": 4}, 96, 2, 150),
+                                       ("b", dict(d_model=64, num_encoder_heads=1, num_decoder_heads=1, num_encoder_layers=1, num_decoder_layers=1, dim_feedforward=128,
+                                                  positional_encoding=False), {"t": 2}, 40, 1, 33)):
+        torch.manual_seed(900 + T)
+        model = glb["EncDecTransformer"](Fd, targets, **kw).eval()
+        with torch.no_grad():           # values exactly representable in 16 bits: the fixture compresses
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.add_(0.05 * torch.randn_like(p))
+                p.copy_(p.bfloat16().float())
+        x = torch.randn(B, T, Fd).half().float()
+        pos = (torch.rand(B, T, 2) * 30000.0).half().float()
+        with torch.no_grad():
+            logits = model(x, pos)
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_pos": pos.numpy(), f"{tag}_targets": np.array(list(targets)), f"{tag}_nout": np.array(list(targets.values()))})
+        out.update({f"{tag}_logits_{j}": logits[t].numpy() for j, t in enumerate(targets)})
+        out.update({f"{tag}_{k}": v for k, v in sd_np(model).items()})
+        out[f"{tag}_hparams"] = np.array([kw["d_model"], kw["num_encoder_heads"], kw["num_decoder_heads"], kw["num_encoder_layers"], kw["num_decoder_layers"],
+                                          kw["dim_feedforward"], int(kw.get("positional_encoding", True))])
+    save("barspoon.npz", **out)
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -575,6 +610,7 @@ def main() -> None:
     install_shims()
     golden_chief()
     golden_eagle()
+    golden_barspoon()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
