@@ -5,7 +5,7 @@ Same constructor, same module tree and therefore the same state_dict keys as the
 / `nn.TransformerDecoder` are instantiated as parameter holders and never called): a checkpoint's `model.*` entries load with
 `load_state_dict(strict=True)`.  `forward(tile_tokens, tile_positions)` -> `{target_label: logits [batch, n_out]}` is ONE library call
 (`amds_barspoon_forward`, csrc/barspoon.hip): the tile side on the 16-bit MFMA path (weights zero-padded like the MIL `vit` head's), the class
-tokens in exact fp32.  Eval + no-grad only: training this head (the reference's `LitMilClassificationMixin.step`, :247-306) is NOT built --
+tokens in exact fp32.  Eval + no-grad only: training this head (the reference's `LitMilClassificationMixin.step`, :263-321) is NOT built --
 a forward that needs gradients raises.
 """
 from __future__ import annotations
