@@ -154,8 +154,9 @@ int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int 
  *   out[m][n] = act( (sum_k A8[m][k] * W8[n][k]) * rowscale[m] * colscale[n] + bias[n] )
  * A8 [M][lda], W8 [N][ldw]: e4m3 bytes, K contiguous, K % 128 == 0, N % 256 == 0, pitches multiples of 16.  rowscale [M] (per-row activation
  * scale, amds_quantize_rows_e4m3), colscale [N] (per-output-channel weight scale; for RESIDUAL the caller multiplies LayerScale into it and
- * into bias), bias [N]: fp32, each may be NULL.  epi: AMDS_EPI_BIAS / AMDS_EPI_BIAS_GELU (out f16 [M][ldo]) or AMDS_EPI_RESIDUAL (out fp32
- * [M][ldo], out += ...).  Replaces the same nn.Linear calls as amds_gemm when the host opts in. */
+ * into bias), bias [N]: fp32, each may be NULL.  epi: AMDS_EPI_BIAS / AMDS_EPI_BIAS_GELU (out f16 [M][ldo]), AMDS_EPI_SWIGLU (packed fc1 with
+ * the 32-row gate / value interleave of amds_pack_swiglu_rows: out f16 [M][N / 2] = silu(gate) * value) or AMDS_EPI_RESIDUAL (out fp32 [M][ldo],
+ * out += ...).  Replaces the same nn.Linear calls as amds_gemm when the host opts in. */
 int amds_gemm_fp8(const void* A8, long lda, const void* W8, long ldw, int M, int N, int K, int epi, void* out, long ldo, const float* bias,
                   const float* colscale, const float* rowscale, void* stream);
 /* q[r][c] = e4m3(x[r][c] / scale[r]), scale[r] = max_c |x[r][c]| / 448 (1 for an all-zero row): per-row dynamic quantisation of an activation

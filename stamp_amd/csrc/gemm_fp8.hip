@@ -179,6 +179,40 @@ gemm_fp8_kernel(const uint8_t* __restrict__ A, long lda, const uint8_t* __restri
     float rsc[FI];
 #pragma unroll
     for (int i = 0; i < FI; ++i) rsc[i] = ep.rowscale ? ep.rowscale[min(m0 + wm * 128 + i * 16 + l15, M - 1)] : 1.0f;
+    if constexpr (EPI == AMDS_EPI_SWIGLU) {
+        // packed fc1 (timm SwiGLUPacked, rows interleaved in blocks of 32: [gate 32 | value 32]): column blocks j = 0, 1, 4, 5 hold gates, j + 2 the
+        // values of the same outputs -- in the same lane.  out[m][c] = silu(g) * v, f16, N / 2 columns: 256 rows x 128 columns per workgroup,
+        // staged through LDS in 256-byte rows (16-byte chunk index XOR row & 15) and stored row-wise, 16 bytes per lane.
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int row = wm * 128 + i * 16 + l15;
+#pragma unroll
+            for (int jg = 0; jg < 4; ++jg) {
+                const int j = (jg >> 1) * 4 + (jg & 1);
+                const int col = n0 + wn * 128 + j * 16 + 4 * kb;
+                const f32x4 csg = ep.colscale ? *reinterpret_cast<const f32x4*>(ep.colscale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 csv = ep.colscale ? *reinterpret_cast<const f32x4*>(ep.colscale + col + 32) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 cbg = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 cbv = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + col + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 g = agpr_read8(acc[i][j]) * rsc[i] * csg + cbg;
+                const f32x4 v = agpr_read8(acc[i][j + 2]) * rsc[i] * csv + cbv;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = g[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[e])) * v[e];
+                const int c = wn * 64 + jg * 16 + 4 * kb;                       // output column inside the workgroup's 128
+                *reinterpret_cast<h4*>(smem + row * 256 + (((c >> 3) ^ (row & 15)) << 4) + (c & 4) * 2) = Act<f16>::from_f32x4(o);
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = wave * 64 + it * 4 + kb;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * 256 + l15 * 16);
+            const int chunk = l15 ^ (row & 15);
+            if (m0 + row < M) *reinterpret_cast<u32x4*>(reinterpret_cast<f16*>(ep.out) + (long)(m0 + row) * ep.ldo + n0 / 2 + chunk * 8) = v;
+        }
+        return;
+    }
     constexpr int NPASS = F16OUT ? 1 : 2, JP = FJ / NPASS;
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -450,7 +484,8 @@ extern "C" int amds_gemm_fp8(const void* A8, long lda, const void* W8, long ldw,
                              const float* colscale, const float* rowscale, void* stream) {
     AMDS_REQUIRE(A8 && W8 && out, "amds_gemm_fp8: null pointer");
     AMDS_REQUIRE(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 128 == 0, "amds_gemm_fp8: N %% 256 == 0 and K %% 128 == 0 required (M=%d N=%d K=%d)", M, N, K);
-    AMDS_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldo >= N && ldo % 8 == 0, "amds_gemm_fp8: pitches must be multiples of 16 bytes");
+    AMDS_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldo >= (epi == AMDS_EPI_SWIGLU ? N / 2 : N) && ldo % 8 == 0,
+                 "amds_gemm_fp8: pitches must be multiples of 16 bytes");
     AMDS_REQUIRE((((uintptr_t)A8 | (uintptr_t)W8 | (uintptr_t)out) & 15) == 0, "amds_gemm_fp8: operands must be 16-byte aligned");
     const Fp8Epi ep{out, ldo, bias, colscale, rowscale};
     hipStream_t st = (hipStream_t)stream;
@@ -458,7 +493,8 @@ extern "C" int amds_gemm_fp8(const void* A8, long lda, const void* W8, long ldw,
         case AMDS_EPI_BIAS: return launch_fp8<AMDS_EPI_BIAS>(A8, lda, W8, ldw, M, N, K, ep, st);
         case AMDS_EPI_BIAS_GELU: return launch_fp8<AMDS_EPI_BIAS_GELU>(A8, lda, W8, ldw, M, N, K, ep, st);
         case AMDS_EPI_RESIDUAL: return launch_fp8<AMDS_EPI_RESIDUAL>(A8, lda, W8, ldw, M, N, K, ep, st);
-        default: set_error("amds_gemm_fp8: epilogue %d not supported (BIAS, BIAS_GELU, RESIDUAL)", epi); return AMDS_ERR_INVALID;
+        case AMDS_EPI_SWIGLU: return launch_fp8<AMDS_EPI_SWIGLU>(A8, lda, W8, ldw, M, N, K, ep, st);
+        default: set_error("amds_gemm_fp8: epilogue %d not supported (BIAS, BIAS_GELU, SWIGLU, RESIDUAL)", epi); return AMDS_ERR_INVALID;
     }
 }
 

@@ -121,7 +121,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
     const amds_vit_fp8_block* f8 = w->fp8_host;
     if (f8) {
-        AMDS_REQUIRE(!fold && !ex && c->mlp_kind == 0 && dt == AMDS_F16, "vit: the fp8 path needs the plain packing (no LayerNorm fold, no exact rows), a GELU MLP and fp16 activations");
+        AMDS_REQUIRE(!fold && !ex && dt == AMDS_F16, "vit: the fp8 path needs the plain packing (no LayerNorm fold, no exact rows) and fp16 activations");
         AMDS_REQUIRE(D % 256 == 0 && Hd % 256 == 0, "vit: the fp8 path needs dim %% 256 == 0 and hidden %% 256 == 0");
         for (int l = 0; l < c->depth; ++l)
             AMDS_REQUIRE(f8[l].qkv_w8 && f8[l].qkv_cs && f8[l].proj_w8 && f8[l].proj_cs && f8[l].proj_b && f8[l].fc1_w8 && f8[l].fc1_cs && f8[l].fc2_w8 && f8[l].fc2_cs && f8[l].fc2_b,
@@ -207,9 +207,16 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 AMDS_TRY(amds_attention_vit_hd(qkvq, hq, q.nt, T, c->heads, D / c->heads, dt, s));
                 AMDS_TRY(amds_quantize_rows_e4m3(hq, D, a8, D, as, n, D, AMDS_F16, s));
                 AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].proj_w8, D, n, D, D, AMDS_EPI_RESIDUAL, xq, D, f8[l].proj_b, f8[l].proj_cs, as, s));
-                AMDS_TRY(amds_layernorm_quant_e4m3(xq, D, b.ln2_w, b.ln2_b, c->ln_eps, a8, D, as, an, n, D, s));
-                AMDS_TRY(amds_row_bound_scale(an, f8[l].fc1_wnorm_max, f8[l].fc1_babs_max, au, n, s));
-                AMDS_TRY(amds_gemm_fp8_out8(a8, D, f8[l].fc1_w8, D, n, Hd, D, AMDS_EPI_BIAS_GELU, u8, Hd, au, b.fc1_b, f8[l].fc1_cs, as, s));
+                if (c->mlp_kind == 0) {
+                    AMDS_TRY(amds_layernorm_quant_e4m3(xq, D, b.ln2_w, b.ln2_b, c->ln_eps, a8, D, as, an, n, D, s));
+                    AMDS_TRY(amds_row_bound_scale(an, f8[l].fc1_wnorm_max, f8[l].fc1_babs_max, au, n, s));
+                    AMDS_TRY(amds_gemm_fp8_out8(a8, D, f8[l].fc1_w8, D, n, Hd, D, AMDS_EPI_BIAS_GELU, u8, Hd, au, b.fc1_b, f8[l].fc1_cs, as, s));
+                } else {      // SwiGLUPacked: silu(g) * v has no useful a-priori bound -> f16 out, then the row quantiser (u8 = the front of the q8 buffer)
+                    AMDS_TRY(amds_layernorm_quant_e4m3(xq, D, b.ln2_w, b.ln2_b, c->ln_eps, a8, D, as, nullptr, n, D, s));
+                    AMDS_TRY(amds_gemm_fp8(a8, D, f8[l].fc1_w8, D, n, 2 * Hd, D, AMDS_EPI_SWIGLU, mlpq, Hd, b.fc1_b, f8[l].fc1_cs, as, s));
+                    u8 = a8;
+                    AMDS_TRY(amds_quantize_rows_e4m3(mlpq, Hd, u8, Hd, au, n, Hd, AMDS_F16, s));
+                }
                 AMDS_TRY(amds_gemm_fp8(u8, Hd, f8[l].fc2_w8, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, f8[l].fc2_b, f8[l].fc2_cs, au, s));
                 continue;
             }

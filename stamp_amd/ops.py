@@ -195,7 +195,7 @@ def gemm_fp8_out8(a8: torch.Tensor, w8: torch.Tensor, epi: int, out_rowscale: to
 
 def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, epi: int, *, rowscale=None, colscale=None, bias=None, out=None) -> torch.Tensor:
     """OPT-IN fp8 GEMM: act((a8 @ w8^T) * rowscale[:, None] * colscale[None, :] + bias); a8 [M, K], w8 [N, K] e4m3 bytes (uint8).
-    epi EPI_BIAS / EPI_BIAS_GELU -> f16 [M, N]; EPI_RESIDUAL -> `out` fp32 [M, N] += ..."""
+    epi EPI_BIAS / EPI_BIAS_GELU -> f16 [M, N]; EPI_SWIGLU (w8 = the 32-row interleaved packed fc1) -> f16 [M, N / 2]; EPI_RESIDUAL -> `out` fp32 [M, N] += ..."""
     _dev(a8, w8, rowscale, colscale, bias, out)
     assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.stride(1) == 1
     M, K = a8.shape
@@ -203,7 +203,7 @@ def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, epi: int, *, rowscale=None, col
     if epi == _lib.EPI_RESIDUAL:
         assert out is not None and out.dtype == torch.float32 and out.shape == (M, N)
     elif out is None:
-        out = torch.empty(M, N, dtype=torch.float16, device=a8.device)
+        out = torch.empty(M, N // 2 if epi == _lib.EPI_SWIGLU else N, dtype=torch.float16, device=a8.device)
     _lib.check(_lib.lib().amds_gemm_fp8(_p(a8), a8.stride(0), _p(w8), w8.stride(0), M, N, K, epi, _p(out), out.stride(0), _p(bias), _p(colscale), _p(rowscale),
                                         _stream()), "gemm_fp8")
     return out

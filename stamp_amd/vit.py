@@ -207,8 +207,8 @@ class HipViT(nn.Module):
         self.exact = bool(exact)
         self.fp8 = bool(fp8)
         if self.fp8:
-            if cfg.mlp != "gelu" or act_dtype != torch.float16 or exact:
-                raise ValueError("fp8=True needs a GELU-MLP preset, fp16 activations and exact=False")
+            if act_dtype != torch.float16 or exact or cfg.dim % 256 or cfg.hidden % 256:
+                raise ValueError("fp8=True needs fp16 activations, exact=False, and dim / hidden multiples of 256 (ViT-L, UNI2-h, H-optimus; not Virchow's 3416)")
             self.ln_fold = False             # the fp8 chain normalises, THEN quantises: plain packing
         self._pack(state_dict)
         if self.fp8:
@@ -258,6 +258,8 @@ class HipViT(nn.Module):
             w8, sw = ops.quantize_rows_e4m3(g("attn.proj.weight"))
             f.proj_w8, f.proj_cs, f.proj_b = keep(w8), keep((sw * ls1).contiguous()), keep((g("attn.proj.bias") * ls1).contiguous())
             w1 = g("mlp.fc1.weight")
+            if c.mlp == "swiglu":               # the 32-row gate / value interleave of the packed fc1 (the bias of the plain pack already has it)
+                w1 = ops.pack_swiglu_rows(w1)
             w8, sw = ops.quantize_rows_e4m3(w1)
             f.fc1_w8, f.fc1_cs = keep(w8), keep(sw)
             # the bound that lets fc1's epilogue write e4m3 directly (amds_row_bound_scale); margin 1.15 >= (1 + 2^-4)^2: both operands of the product

@@ -142,8 +142,8 @@ def test_vit_fp8_mode_small_and_full_size(gpu):
     assert e16 < 1e-3 and 2e-3 < e8 < 5e-2 and torch.isfinite(f8).all()
     m = HipViT(small, sd, device=gpu, chunk=5, fp8=True)
     assert torch.equal(m(tiles.to(gpu)), m(tiles.to(gpu)))                                   # deterministic
-    with pytest.raises(ValueError, match="GELU"):
-        HipViT(PRESETS["test_tiny_swiglu"], random_vit_state_dict(PRESETS["test_tiny_swiglu"], 0), device=gpu, fp8=True)
+    with pytest.raises(ValueError, match="multiples of 256"):
+        HipViT(PRESETS["test_tiny_swiglu"], random_vit_state_dict(PRESETS["test_tiny_swiglu"], 0), device=gpu, fp8=True)     # dim 128, hidden 192
     cfg = PRESETS["vit_large_patch14_224"]
     sdl = random_vit_state_dict(cfg, seed=0, init="moderate")
     tl = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
@@ -152,3 +152,41 @@ def test_vit_fp8_mode_small_and_full_size(gpu):
     el = _rel(fl, refl)
     print(f"ViT-L/14, fp8 GEMMs: stored CLS feature vs the fp32 oracle {el:.3e} (emulation: 5.8e-2; fp16 path 5.3e-4)")
     assert 3e-2 < el < 9e-2
+
+
+@pytest.mark.parametrize("M,H,K", [(300, 128, 128), (1000, 512, 1024), (65, 384, 256)])
+def test_gemm_fp8_swiglu_epilogue(gpu, M, H, K):
+    """Packed fc1 of timm's SwiGLUPacked on the fp8 MFMA: rows interleaved in 32-row gate / value blocks (amds_pack_swiglu_rows), out = silu(gate) * value."""
+    g = torch.Generator().manual_seed(M + H + K)
+    a = torch.randn(M, K, generator=g).to(gpu)
+    w = (torch.randn(2 * H, K, generator=g) / K ** 0.5).to(gpu)               # [gate rows | value rows], the checkpoint's order
+    bias = (0.3 * torch.randn(2 * H, generator=g)).to(gpu)
+    wp, bp = ops.pack_swiglu_rows(w), ops.pack_swiglu_rows(bias.reshape(-1, 1)).reshape(-1)
+    a8, sa = ops.quantize_rows_e4m3(a)
+    w8, sw = ops.quantize_rows_e4m3(wp)
+    out = ops.gemm_fp8(a8, w8, _lib.EPI_SWIGLU, rowscale=sa, colscale=sw, bias=bp)
+    assert out.shape == (M, H) and out.dtype == torch.float16
+    # the same quantised operands in fp64, un-interleaved: row r of the packed matrix is gate / value row perm[r] of the checkpoint's
+    perm = ops.pack_swiglu_rows(torch.arange(2 * H, dtype=torch.float32, device=gpu).reshape(-1, 1)).reshape(-1).long()
+    pre = torch.empty(M, 2 * H, dtype=torch.float64, device=gpu)
+    pre[:, perm] = (_deq(a8) @ _deq(w8).T) * sa.double()[:, None] * sw.double()[None, :] + bp.double()
+    want = torch.nn.functional.silu(pre[:, :H]) * pre[:, H:]
+    assert _rel(out, want) < 8e-4, _rel(out, want)
+
+
+def test_vit_fp8_mode_swiglu_preset(gpu):
+    """fp8=True on a SwiGLUPacked trunk with register tokens (UNI2-h's structure at test size: dim 256, hidden 512): fc1 through the SWIGLU epilogue,
+    its f16 output re-quantised per row for fc2.  Same statement as for the GELU trunk: e4m3's error, no more."""
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd.vit import HipViT, ViTConfig, random_vit_state_dict
+    cfg = ViTConfig(dim=256, depth=2, heads=4, hidden=512, mlp="swiglu", reg_tokens=4, no_embed_class=True)
+    sd = random_vit_state_dict(cfg, seed=3)
+    tiles = torch.randint(0, 256, (5, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(4))
+    ref = extract_features(tiles, sd, cfg).float()
+    m = HipViT(cfg, sd, device=gpu, chunk=3, fp8=True)
+    f8 = m(tiles.to(gpu)).float().cpu()
+    f16 = HipViT(cfg, sd, device=gpu, chunk=3)(tiles.to(gpu)).float().cpu()
+    e8, e16 = _rel(f8, ref), _rel(f16, ref)
+    print(f"2-block 256-wide SwiGLU ViT: fp8 GEMMs {e8:.3e}, fp16 path {e16:.3e}")
+    assert e16 < 1e-3 and 2e-3 < e8 < 5e-2 and torch.isfinite(f8).all()
+    assert torch.equal(m(tiles.to(gpu)), m(tiles.to(gpu)))
