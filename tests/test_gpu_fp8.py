@@ -119,7 +119,8 @@ def test_gemm_fp8_rejects_bad_shapes(gpu):
     with pytest.raises(RuntimeError, match="K % 128"):
         ops.gemm_fp8(a8, w8, _lib.EPI_BIAS)
     with pytest.raises(RuntimeError, match="not supported"):
-        ops.gemm_fp8(torch.zeros(10, 128, dtype=torch.uint8, device=gpu), torch.zeros(256, 128, dtype=torch.uint8, device=gpu), _lib.EPI_SWIGLU)
+        ops.gemm_fp8(torch.zeros(10, 128, dtype=torch.uint8, device=gpu), torch.zeros(256, 128, dtype=torch.uint8, device=gpu), _lib.EPI_PATCH,
+                     out=torch.zeros(10, 256, dtype=torch.float16, device=gpu))
 
 
 def test_vit_fp8_mode_small_and_full_size(gpu):
