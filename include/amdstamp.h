@@ -404,7 +404,8 @@ int amds_vit_forward_overlapped(amds_ctx* ctx, const amds_vit_cfg* cfg_host, con
  *                            against the keys / values of all T <= 288 tokens of that tile as stored in the packed act-dtype qkv tensor
  *   amds_vit_cls_gather      xc[b][:] = x[b*T][:]
  *   amds_vit_cls_scatter     x[b*T][:] = xc[b][:]; if xh / rowstat: 16-bit copy of that row and its (rstd, -mean*rstd) (amds_ln_stats_cast's form)
- *   amds_mlp_act_f32         kind 0: u = gelu_erf(u) over `hidden` columns; kind 1 (SwiGLUPacked): u[:, j] = silu(u[:, j]) * u[:, hidden + j] */
+ *   amds_mlp_act_f32         kind 0: u = gelu_erf(u) over `hidden` columns; kind 1 (SwiGLUPacked): u[:, j] = silu(u[:, j]) * u[:, hidden + j];
+ *                            kind 2: u = silu(u) */
 int amds_attention_cls_f32(const float* q, long ldq, const void* qkv, float* out, long ldo, int B, int T, int H, int head_dim,
                            int dtype, void* stream);
 int amds_vit_cls_gather(const float* x, float* xc, int B, int T, int D, void* stream);
@@ -534,6 +535,35 @@ int amds_compact_rows_u8(const uint8_t* src, long row_bytes, const float* score,
 /* After the first m rows of an accumulation buffer went to the encoder: rows [m, *count_dev) of src move to the front of dst (at most
  * max_rows of them: the launch geometry) and *count_dev -= m, all in stream order and without the host knowing the fill level. */
 int amds_compact_shift_u8(const uint8_t* src, uint8_t* dst, long row_bytes, int m, int max_rows, int* count_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * TICON tile contextualiser in the form the reference's extractor uses it (src/stamp/preprocessing/extractor/ticon.py:691-718
+ * `HOptimusTICON.forward`: every tile's embedding ALONE through `EncoderDecoder.forward` :543-562, one token, zero coordinates):
+ * input projection (Linear, SiLU, Linear, LayerNorm :80-99), `depth` blocks (x += g1 * proj(v_proj(LN(x))): with one key the attention
+ * :183-215 is the identity on its value; x += g2 * fc2(silu(x1) * x2), (x1 | x2) = fc1(LN(x)) :54-77), final LayerNorm :506.
+ * Exact fp32 (fp32 MFMA): the stage is 0.05 % of the tile encoder's flops.  All pointers fp32 device; proj_w / proj_b and fc2_w / fc2_b carry the
+ * block's LayerScale (gamma1 / gamma2 multiplied into rows and bias by the host at pack time).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* ln1_w; const float* ln1_b;        /* residual1.norm                                  */
+    const float* v_w; const float* v_b;            /* residual1.fn.v_proj            [dim][dim]       */
+    const float* proj_w; const float* proj_b;      /* gamma1 * residual1.fn.proj     [dim][dim]       */
+    const float* ln2_w; const float* ln2_b;        /* residual2.norm                                  */
+    const float* fc1_w; const float* fc1_b;        /* residual2.fn.fc1               [hidden][dim]    */
+    const float* fc2_w; const float* fc2_b;        /* gamma2 * residual2.fn.fc2      [dim][hidden/2]  */
+} amds_ticon_block;
+typedef struct {
+    int in_dim, dim, hidden, depth;                /* hidden = int(dim * 16 / 3) (:58-66), even */
+    const float* in_fc1_w; const float* in_fc1_b;  /* input_proj_<key>.fc1           [dim][in_dim]    */
+    const float* in_fc2_w; const float* in_fc2_b;  /* input_proj_<key>.fc2           [dim][dim]       */
+    const float* in_norm_w; const float* in_norm_b;
+    const amds_ticon_block* blocks_host;           /* HOST array of `depth` entries (encoder.blocks)  */
+    const float* norm_w; const float* norm_b;      /* enc_norm                                        */
+} amds_ticon_weights;
+size_t amds_ticon_tile_workspace_bytes(const amds_ticon_weights* w_host, int n_tiles);
+/* emb: [n_tiles][in_dim] AMDS_F32 / AMDS_F16 (the tile encoder's feature rows); out: [n_tiles][dim] in out_dtype (AMDS_F32 or AMDS_F16). */
+int amds_ticon_tile_forward(const amds_ticon_weights* w_host, const void* emb, int emb_dtype, void* out, int out_dtype, int n_tiles, void* ws,
+                            size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gated-attention pooling (CHIEF slide encoder; reference

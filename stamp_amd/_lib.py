@@ -120,6 +120,16 @@ class BarspoonWeights(C.Structure):
                 ("n_out_host", C.POINTER(C.c_int)), ("pe_div", C.c_void_p)]
 
 
+class TiconBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "v_w", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class TiconWeights(C.Structure):
+    _fields_ = [("in_dim", C.c_int), ("dim", C.c_int), ("hidden", C.c_int), ("depth", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("in_fc1_w", "in_fc1_b", "in_fc2_w", "in_fc2_b", "in_norm_w", "in_norm_b")] + \
+               [("blocks_host", C.POINTER(TiconBlock)), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+
+
 class SwinCfg(C.Structure):
     _fields_ = [("img", C.c_int), ("embed", C.c_int), ("n_stages", C.c_int), ("depths", C.c_int * 4),
                 ("heads", C.c_int * 4), ("dtype", C.c_int), ("ln_eps", C.c_float)]
@@ -216,6 +226,8 @@ PROTOTYPES = {
     "amds_mil_vit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_barspoon_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_barspoon_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_ticon_tile_workspace_bytes": (_sz, [_vp, _i]),
+    "amds_ticon_tile_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),

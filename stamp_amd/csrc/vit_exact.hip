@@ -165,7 +165,7 @@ __global__ void cls_gather_kernel(const float* __restrict__ x, float* __restrict
 }
 
 // MLP activation in fp32 on [rows][ld]: kind 0: u = gelu_erf(u) in place over `hidden` columns (nn.GELU, exact erf);
-// kind 1: u[:, j] = silu(u[:, j]) * u[:, hidden + j] for j < hidden (timm SwiGLUPacked: fc1 -> chunk(2) -> silu(x1) * x2).
+// kind 1: u[:, j] = silu(u[:, j]) * u[:, hidden + j] for j < hidden (timm SwiGLUPacked: fc1 -> chunk(2) -> silu(x1) * x2); kind 2: u = silu(u).
 __global__ void mlp_act_f32_kernel(float* __restrict__ u, long ld, int rows, int hidden, int kind) {
     const long total = (long)rows * hidden;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -174,6 +174,9 @@ __global__ void mlp_act_f32_kernel(float* __restrict__ u, long ld, int rows, int
         float* p = u + r * ld + c;
         if (kind == 0) {
             *p = gelu_erf(*p);
+        } else if (kind == 2) {
+            const float g = *p;
+            *p = g / (1.0f + expf(-g));
         } else {
             const float g = *p, v = p[hidden];
             *p = (g / (1.0f + expf(-g))) * v;
@@ -228,7 +231,7 @@ extern "C" int amds_vit_cls_gather(const float* x, float* xc, int B, int T, int 
 }
 
 extern "C" int amds_mlp_act_f32(float* u, long ld, int rows, int hidden, int kind, void* stream) {
-    AMDS_REQUIRE(u && rows >= 0 && hidden > 0 && (kind == 0 || kind == 1) && ld >= (long)hidden * (kind == 1 ? 2 : 1), "amds_mlp_act_f32: bad arguments");
+    AMDS_REQUIRE(u && rows >= 0 && hidden > 0 && kind >= 0 && kind <= 2 && ld >= (long)hidden * (kind == 1 ? 2 : 1), "amds_mlp_act_f32: bad arguments");
     if (rows == 0) return AMDS_OK;
     const long total = (long)rows * hidden;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);

@@ -46,6 +46,14 @@ def hip_vit_extractor(name: str, state_dict: dict[str, torch.Tensor], *, identif
     return Extractor(model=model, transform=u8_tile_transform, identifier=identifier or f"amdstamp-{name}")
 
 
+def hip_ticon_extractor(vit_state_dict: dict[str, torch.Tensor], ticon_state_dict: dict[str, torch.Tensor], *, identifier: str = "ticon", device="cuda",
+                        chunk: int = 512) -> Extractor:
+    """The reference's `ticon()` factory (src/stamp/preprocessing/extractor/ticon.py:721-741) with the HIP model: H-optimus-1 trunk + TICON on every
+    tile alone (`stamp_amd.ticon.HipHOptimusTicon`); the normalisation constants of the reference's transform (:729-732) are the trunk preset's."""
+    from .ticon import HipHOptimusTicon
+    return Extractor(model=HipHOptimusTicon(vit_state_dict, ticon_state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
+
+
 def hip_ctranspath_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "ctranspath", cfg: SwinConfig | None = None,
                              device="cuda", act_dtype=torch.float16, chunk: int = 1024) -> Extractor:
     """The reference's `ctranspath()` / `chief_ctranspath()` factories (src/stamp/preprocessing/extractor/ctranspath.py:34-70,

@@ -287,3 +287,41 @@ def test_eagle_encoder_matches_reference_fixture_and_file_loop(gpu, tmp_path):
     refp = eagle.eagle_patient_embedding([slides["s1"][0].float(), slides["s2"][0].float()], [slides["s1"][1].float(), slides["s2"][1].float()], sd)
     assert at["feat_type"] == "patient"
     np.testing.assert_allclose(d["feats"], refp, rtol=1e-5, atol=1e-6)
+
+
+def test_ticon_tile_stage_and_extractor(gpu):
+    """TICON as the reference's extractor runs it (ticon.py:691-718: every tile alone): the HIP stage (one C call, exact fp32) against the fixture made
+    by the reference's own `EncoderDecoder`, both input projections; then the two-stage extractor (H-optimus trunk + TICON) at test size against
+    the oracles of both stages."""
+    from oracle import ticon as ot
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd.extractor import Extractor
+    from stamp_amd.ticon import HipHOptimusTicon, HipTiconTile
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+
+    z = np.load(Path(__file__).parent / "golden" / "ticon.npz")
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    for key in ("hoptimus1", "conchv15"):
+        m = HipTiconTile(sd, key=key, device=gpu)
+        emb = torch.from_numpy(z[f"emb_{key}"]).to(gpu)
+        y = m(emb)
+        assert y.dtype == torch.float32 and y.shape == z[f"out_{key}"].shape
+        np.testing.assert_allclose(y.cpu().numpy(), z[f"out_{key}"], rtol=2e-5, atol=2e-5)
+        assert torch.equal(y, m(emb.half()))                                 # fp16 embeddings (the fixture's are fp16-exact)
+        assert m(emb[:0]).shape == (0, y.shape[1])
+    with pytest.raises(KeyError, match="lacks"):
+        HipTiconTile(sd, key="uni2h", device=gpu)                            # the fixture has no such input projection
+    with pytest.raises(ValueError, match="tile embeddings"):
+        m(torch.zeros(3, 7, device=gpu))
+    # two stages: a test-size SwiGLU trunk with register tokens (H-optimus's structure) whose width is the fixture's hoptimus1 input width (128)
+    cfg = PRESETS["test_tiny_swiglu"]
+    vsd = random_vit_state_dict(cfg, seed=5)
+    model = HipHOptimusTicon(vsd, sd, device=gpu, chunk=4, vit_cfg=cfg)
+    tiles = torch.randint(0, 256, (6, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(6))
+    out = model(tiles.to(gpu))
+    assert out.dtype == torch.float16 and out.shape == (6, 96)                 # TICON's own width
+    ref = ot.ticon_tile_forward(extract_features(tiles, vsd, cfg).float(), sd, "hoptimus1")          # fp16 trunk features, as the HIP trunk hands them over
+    rel = ((out.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 2e-3, rel
+    ex = Extractor(model=model, transform=lambda im: im, identifier="ticon")
+    assert ex.identifier == "ticon" and ex.model is model

@@ -263,3 +263,12 @@ def test_barspoon_golden(tag):
     for j, t in enumerate(targets):
         assert out[t].shape == (z[f"{tag}_x"].shape[0], int(z[f"{tag}_nout"][j]))
         np.testing.assert_allclose(out[t].numpy(), z[f"{tag}_logits_{j}"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("key", ["hoptimus1", "conchv15"])
+def test_ticon_tile_golden(key):
+    """oracle/ticon.py against outputs of the reference's own TICON `EncoderDecoder` called as its extractor calls it (one token per tile)."""
+    from oracle import ticon
+    z, sd = _load("ticon.npz")
+    y = ticon.ticon_tile_forward(torch.from_numpy(z[f"emb_{key}"]), sd, key)
+    np.testing.assert_allclose(y.numpy(), z[f"out_{key}"], rtol=1e-6, atol=1e-6)

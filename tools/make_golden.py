@@ -219,6 +219,40 @@ def golden_barspoon() -> None:
     save("barspoon.npz", **out)
 
 
+def golden_ticon() -> None:
+    """TICON tile contextualiser: the reference's own `EncoderDecoder` (ticon.py; the module top imports timm / huggingface_hub: only the model
+    classes are executed) at a small width, called exactly as `HOptimusTICON.forward` calls it -- one token per tile, zero coordinates."""
+    import math
+    from collections.abc import Callable, Mapping
+    from functools import partial
+    from typing import Any
+
+    import torch.nn as nn
+
+    glb = {"nn": nn, "torch": torch, "math": math, "Tensor": torch.Tensor, "Float": sys.modules["jaxtyping"].Float, "Callable": Callable, "Mapping": Mapping,
+           "Any": Any, "partial": partial}
+    exec_defs(REF / "preprocessing" / "extractor" / "ticon.py",
+              {"LayerScale", "Mlp", "ProjectionMlp", "get_slopes", "scaled_dot_product_attention_custom", "Attention", "NaiveResidual", "EfficientResidual", "Block",
+               "Transformer", "EncoderDecoder", "_init_weights"}, glb)
+    torch.manual_seed(77)
+    cfg = dict(transformers_kwargs={"embed_dim": 96, "drop_path_rate": 0.0, "block_kwargs": {"attn_kwargs": {"num_heads": 6}}}, encoder_kwargs={"depth": 3},
+               decoder_kwargs={"depth": 1}, in_dims=[48, 128], tile_encoder_keys=["conchv15", "hoptimus1"], num_decoders=1, decoder_out_dims=[48, 128])
+    model = glb["EncoderDecoder"](**cfg).init_weights().eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():                       # the reference initialises biases to 0 and LayerScale to 1: make every parameter matter
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            p.copy_(p.bfloat16().float())
+    out = {}
+    for key, d_in in (("hoptimus1", 128), ("conchv15", 48)):
+        emb = torch.randn(9, d_in).half().float()
+        with torch.no_grad():
+            y = model(x=emb.unsqueeze(1), relative_coords=torch.zeros(9, 1, 2), tile_encoder_key=key).squeeze(1)
+        out[f"emb_{key}"], out[f"out_{key}"] = emb.numpy(), y.numpy()
+    out.update({k: v for k, v in sd_np(model).items() if ".decoder_" not in k and "output_proj" not in k and "mask_dict" not in k})
+    save("ticon.npz", **out)
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -611,6 +645,7 @@ def main() -> None:
     golden_chief()
     golden_eagle()
     golden_barspoon()
+    golden_ticon()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
