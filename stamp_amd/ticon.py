@@ -22,7 +22,7 @@ _WS: dict = {}
 
 class HipTiconTile(nn.Module):
     """TICON on single tiles: `forward(emb [B, in_dim] f16 / f32 on the GPU) -> [B, dim]` (f32, or f16 with `out_dtype=torch.float16`).
-    `state_dict`: the `EncoderDecoder`'s own (the reference strips the checkpoint's "backbone." prefix, ticon.py:608-613); `key`: which input
+    `state_dict`: the `EncoderDecoder`'s own (the reference strips the checkpoint's "backbone." prefix, ticon.py:614-619); `key`: which input
     projection to use ("hoptimus1" in the reference's extractor)."""
 
     def __init__(self, state_dict: dict[str, torch.Tensor], *, key: str = "hoptimus1", device="cuda", out_dtype: torch.dtype = torch.float32) -> None:
