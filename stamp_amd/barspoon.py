@@ -20,7 +20,6 @@ from torch import nn
 from . import _lib, ops
 from .mil_core import PackedVit, VitDims, layer_prefix
 
-_WS: dict = {}
 
 
 def sanitize(x: str) -> str:
@@ -129,9 +128,7 @@ class EncDecTransformer(nn.Module):
         need = lib.amds_barspoon_workspace_bytes(C.byref(cfg), Bb, T)
         if need == 0:
             _lib.check(-1, "barspoon_workspace_bytes")
-        ws = _WS.get(dev)
-        if ws is None or ws.numel() < need:
-            _WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = ops.scratch("barspoon", dev, need)
         logits = torch.empty(Bb, total, dtype=torch.float32, device=dev)
         _lib.check(lib.amds_barspoon_forward(C.byref(cfg), C.byref(wc), x.data_ptr(), ops._DT[x.dtype], pos.data_ptr() if pos is not None else None,
                                              logits.data_ptr(), Bb, T, ws.data_ptr(), ws.numel(), ops._stream()), "barspoon_forward")

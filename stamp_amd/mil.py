@@ -401,7 +401,6 @@ def _bgemm(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer,
                                          torch.cuda.current_stream().cuda_stream), "bgemm_f32")
 
 
-_TRANSMIL_WS: dict = {}
 
 
 class TransMIL(nn.Module):
@@ -561,9 +560,7 @@ class TransMIL(nn.Module):
         need = lib.amds_transmil_workspace_bytes(C.byref(cfg), Bb, T)
         if need == 0:
             _lib.check(-1, "transmil_workspace_bytes")
-        ws = _TRANSMIL_WS.get(dev)
-        if ws is None or ws.numel() < need:
-            _TRANSMIL_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = ops.scratch("transmil", dev, need)
         logits = torch.empty(Bb, self.n_classes, dtype=torch.float32, device=dev)
         _lib.check(lib.amds_transmil_forward(C.byref(cfg), C.byref(w), h.data_ptr(), ops._DT[h.dtype], logits.data_ptr(), Bb, T, ws.data_ptr(), ws.numel(),
                                              torch.cuda.current_stream().cuda_stream), "transmil_forward")

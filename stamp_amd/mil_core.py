@@ -261,7 +261,6 @@ def _ln(x, rows, cols, ld_in, gamma, beta, out_dtype, ld_out, buf=None):
 
 
 # ---- inference forward (fp16 operands; deploy / validation / the reference's `mask` path) -----------------------------------------
-_INFER_WS: dict = {}
 
 
 def forward_infer(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, mask: torch.Tensor | None) -> torch.Tensor:
@@ -292,9 +291,7 @@ def forward_infer(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None
     need = lib.amds_mil_vit_workspace_bytes(C.byref(cfg), Bb, Tn)
     if need == 0:
         _lib.check(-1, "mil_vit_workspace_bytes")
-    ws = _INFER_WS.get(dev)
-    if ws is None or ws.numel() < need:
-        _INFER_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = ops.scratch("mil_vit_infer", dev, need)
     logits = torch.empty(Bb, d.C, dtype=torch.float32, device=dev)
     _lib.check(lib.amds_mil_vit_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), ops._DT[bags.dtype], c.data_ptr() if c is not None else None,
                                         m8.data_ptr() if m8 is not None else None, logits.data_ptr(), Bb, Tn, ws.data_ptr(), ws.numel(),
@@ -386,7 +383,6 @@ def update_running_means(get, d: VitDims, cc: torch.Tensor) -> None:
         torch._foreach_add_(ns, 1.0)
 
 
-_TRAIN_WS: dict = {}
 
 
 def _drop_struct(d: VitDims, training: bool, seed: int) -> "_lib.MilVitDropout":
@@ -472,9 +468,7 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
     need = lib.amds_mil_vit_train_workspace_bytes(C.byref(cfg), Bb, Tn, split_k)
     if need == 0:
         _lib.check(-1, "mil_vit_train_workspace_bytes")
-    ws = _TRAIN_WS.get(dev)
-    if ws is None or ws.numel() < need:
-        _TRAIN_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = ops.scratch("mil_vit_train", dev, need)
     gc = top = layers = None
     if need_params:
         _flat, gc, _lg, top, layers = _grad_buffers(d, dev)

@@ -25,6 +25,20 @@ def _dev(*ts: torch.Tensor) -> None:
             raise RuntimeError("stamp_amd ops need tensors on the GPU (no CPU fallback)")
 
 
+_SCRATCH: dict = {}
+
+
+def scratch(tag: str, dev: torch.device, nbytes: int) -> torch.Tensor:
+    """A grow-only uint8 workspace for the whole-model library calls, one per (purpose, device, stream, host thread): two forwards that may be in
+    flight at once (different streams, or two host threads interleaving launches on one stream) never share scratch memory."""
+    import threading
+    key = (tag, str(dev), _stream(), threading.get_ident())
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _SCRATCH[key] = ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _p(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 

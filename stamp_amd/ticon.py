@@ -17,7 +17,6 @@ from torch import nn
 from . import _lib, ops
 from .vit import PRESETS, HipViT
 
-_WS: dict = {}
 
 
 class HipTiconTile(nn.Module):
@@ -76,9 +75,7 @@ class HipTiconTile(nn.Module):
         need = lib.amds_ticon_tile_workspace_bytes(C.byref(self._w), B)
         if need == 0 and B > 0:
             _lib.check(-1, "ticon_tile_workspace_bytes")
-        ws = _WS.get(dev)
-        if ws is None or ws.numel() < max(need, 256):
-            _WS[dev] = ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        ws = ops.scratch("ticon", dev, need)
         out = torch.empty(B, self.dim, dtype=self.out_dtype, device=dev)
         _lib.check(lib.amds_ticon_tile_forward(C.byref(self._w), emb.data_ptr(), ops._DT[emb.dtype], out.data_ptr(), ops._DT[self.out_dtype], B, ws.data_ptr(), ws.numel(),
                                                ops._stream()), "ticon_tile_forward")

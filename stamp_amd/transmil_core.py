@@ -84,7 +84,6 @@ class _Nys:
         self.wconv = get(f"{name}.attn.res_conv.weight").reshape(HEADS, -1).contiguous()
 
 
-_NY_WS: dict = {}
 STEPWISE = False        # tests flip this to run the kernel-by-kernel chains below instead of the two library calls
 
 
@@ -124,9 +123,7 @@ def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = Tru
     need = lib.amds_nystrom_attn_workspace_bytes(Cd, b, n)
     if need == 0:
         _lib.check(-1, "nystrom_attn_workspace_bytes")
-    ws = _NY_WS.get(dev)
-    if ws is None or ws.numel() < need:
-        _NY_WS[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = ops.scratch("nystrom", dev, need)
     dy = torch.empty(b, n, Cd, dtype=torch.float32, device=dev)
     G, gc = {}, None
     if need_params:
