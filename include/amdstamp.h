@@ -526,6 +526,15 @@ size_t amds_supertiles_to_tiles_workspace_bytes(int n, int S, int k, int t);
 int amds_supertiles_to_tiles_u8(const uint8_t* rgba, uint8_t* tiles, int n, int S, int k, int t, const int* bounds, const int* coef,
                                 int ksize, void* ws, size_t ws_bytes, void* stream);
 
+/* Resize(O, bicubic) + CenterCrop(t) on RGB u8 tiles -- the transform some of the reference's extractors put in front of their model
+ * (src/stamp/preprocessing/extractor/gigapath.py:21-28: Resize(256, BICUBIC), CenterCrop(224)).  torchvision's Resize on a PIL
+ * image is Pillow's own two-pass 8-bit resample (bit for bit as above, without the alpha handling); the crop offset is torchvision's
+ * int(round((O - t) / 2.0)).  tiles [n][S][S][3] -> out [n][t][t][3]; bounds / coef: the tap tables of an S -> O resize (as for
+ * amds_supertiles_to_tiles_u8).  ws: amds_tile_resize_crop_workspace_bytes(n, S, t). */
+size_t amds_tile_resize_crop_workspace_bytes(int n, int S, int t);
+int amds_tile_resize_crop_u8(const uint8_t* tiles, uint8_t* out, int n, int S, int O, int t, const int* bounds, const int* coef, int ksize, void* ws,
+                             size_t ws_bytes, void* stream);
+
 /* Keep-mask compaction on the device, between the texture filter and the tile encoder (reference tiling.py:171-193 `_tiles_with_tissue`
  * drops the rejected tiles one by one on the host): rows i < n of src (row_bytes each, a multiple of 16) whose score[i] >= cutoff (score NULL:
  * all) are appended in order to dst at row *count_dev, which is advanced; slot_out[i] = the row it went to, -1 if rejected (-2 if dst, of

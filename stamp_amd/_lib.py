@@ -228,6 +228,8 @@ PROTOTYPES = {
     "amds_barspoon_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_ticon_tile_workspace_bytes": (_sz, [_vp, _i]),
     "amds_ticon_tile_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_tile_resize_crop_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amds_tile_resize_crop_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -64,9 +64,67 @@ __global__ void __launch_bounds__(256) resize_v_kernel(const uchar4* __restrict_
     o[0] = (unsigned char)r; o[1] = (unsigned char)g; o[2] = (unsigned char)bl;
 }
 
+// ---- RGB tile: Resize(O, bicubic) then CenterCrop(t), the transform some of the reference's extractors put in front of their model
+// (gigapath.py:21-28 Resize(256, BICUBIC) + CenterCrop(224)).  torchvision's Resize on a PIL image is PIL's own resize:
+// the same two-pass 8-bit resample as above without the alpha handling; the crop picks columns / rows [c0, c0 + t) of the O x O image, so only
+// those are computed.  tiles [B][S][S][3] -> mid [B][S][t][3] -> out [B][t][t][3].
+__global__ void __launch_bounds__(256) tile_resize_h_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ mid, int S, int t, int c0,
+                                                            const int2* __restrict__ bounds, const int* __restrict__ coef, int ksize) {
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (xo >= t) return;
+    const unsigned char* row = src + ((long)blockIdx.z * S + y) * S * 3;
+    const int2 b = bounds[c0 + xo];
+    const int* k = coef + (long)(c0 + xo) * ksize;
+    int a0 = 1 << (RS_PREC - 1), a1 = a0, a2 = a0;
+    for (int x = 0; x < b.y; ++x) {
+        const unsigned char* p = row + (b.x + x) * 3;
+        const int w = k[x];
+        a0 += p[0] * w; a1 += p[1] * w; a2 += p[2] * w;
+    }
+    unsigned char* o = mid + (((long)blockIdx.z * S + y) * t + xo) * 3;
+    o[0] = (unsigned char)clip8(a0 >> RS_PREC); o[1] = (unsigned char)clip8(a1 >> RS_PREC); o[2] = (unsigned char)clip8(a2 >> RS_PREC);
+}
+
+__global__ void __launch_bounds__(256) tile_resize_v_kernel(const unsigned char* __restrict__ mid, unsigned char* __restrict__ out, int S, int t, int c0,
+                                                            const int2* __restrict__ bounds, const int* __restrict__ coef, int ksize) {
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yo = blockIdx.y;
+    if (xo >= t) return;
+    const unsigned char* img = mid + (long)blockIdx.z * S * t * 3;
+    const int2 b = bounds[c0 + yo];
+    const int* k = coef + (long)(c0 + yo) * ksize;
+    int a0 = 1 << (RS_PREC - 1), a1 = a0, a2 = a0;
+    for (int y = 0; y < b.y; ++y) {
+        const unsigned char* p = img + ((long)(b.x + y) * t + xo) * 3;
+        const int w = k[y];
+        a0 += p[0] * w; a1 += p[1] * w; a2 += p[2] * w;
+    }
+    unsigned char* o = out + (((long)blockIdx.z * t + yo) * t + xo) * 3;
+    o[0] = (unsigned char)clip8(a0 >> RS_PREC); o[1] = (unsigned char)clip8(a1 >> RS_PREC); o[2] = (unsigned char)clip8(a2 >> RS_PREC);
+}
+
 }  // namespace amds
 
 using namespace amds;
+
+extern "C" size_t amds_tile_resize_crop_workspace_bytes(int n, int S, int t) { return (size_t)n * S * t * 3; }
+
+extern "C" int amds_tile_resize_crop_u8(const uint8_t* tiles, uint8_t* out, int n, int S, int O, int t, const int* bounds, const int* coef, int ksize, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if (n == 0) return AMDS_OK;
+    AMDS_REQUIRE(tiles && out && bounds && coef && ws, "amds_tile_resize_crop_u8: null pointer");
+    AMDS_REQUIRE(n > 0 && n <= 65535 && S > 0 && S <= 65535 && O >= t && t > 0 && t <= 65535 && ksize > 0, "amds_tile_resize_crop_u8: bad shape (crop %d of %d)", t, O);
+    if (ws_bytes < amds_tile_resize_crop_workspace_bytes(n, S, t)) { set_error("amds_tile_resize_crop_u8: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int q = (O - t) / 2;                                      // torchvision center_crop: int(round((size - crop) / 2.0)); Python rounds half to even
+    const int c0e = ((O - t) % 2 == 0 || q % 2 == 0) ? q : q + 1;
+    hipLaunchKernelGGL(tile_resize_h_kernel, dim3(cdiv(t, 256), S, n), dim3(256), 0, st, tiles, (unsigned char*)ws, S, t, c0e, (const int2*)bounds, coef, ksize);
+    AMDS_LAUNCH_CHECK("tile_resize_h_kernel");
+    hipLaunchKernelGGL(tile_resize_v_kernel, dim3(cdiv(t, 256), t, n), dim3(256), 0, st, (const unsigned char*)ws, out, S, t, c0e, (const int2*)bounds, coef, ksize);
+    AMDS_LAUNCH_CHECK("tile_resize_v_kernel");
+    return AMDS_OK;
+}
 
 extern "C" size_t amds_supertiles_to_tiles_workspace_bytes(int n, int S, int k, int t) { return (size_t)n * S * k * t * 4; }
 

@@ -46,6 +46,28 @@ def hip_vit_extractor(name: str, state_dict: dict[str, torch.Tensor], *, identif
     return Extractor(model=model, transform=u8_tile_transform, identifier=identifier or f"amdstamp-{name}")
 
 
+class ResizeCropThenModel(torch.nn.Module):
+    """`model(resize_center_crop(tiles))`: a tile transform that is not the identity on the tile size, done on the GPU in front of the HIP model
+    (Pillow's bicubic resample bit for bit + torchvision's crop offset: `stamp_amd.tiling.resize_center_crop`)."""
+
+    def __init__(self, model: torch.nn.Module, resized: int, crop: int) -> None:
+        super().__init__()
+        self.model, self.resized, self.crop = model, int(resized), int(crop)
+
+    @torch.no_grad()
+    def forward(self, tiles: torch.Tensor) -> torch.Tensor:
+        from .tiling import resize_center_crop
+        return self.model(resize_center_crop(tiles, self.resized, self.crop))
+
+
+def hip_gigapath_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "gigapath", device="cuda", chunk: int = 512) -> Extractor:
+    """The reference's `gigapath()` factory (src/stamp/preprocessing/extractor/gigapath.py:14-34) with the HIP trunk: Resize(256, BICUBIC) +
+    CenterCrop(224) on the GPU (bit-identical with what torchvision does to the PIL tile), then the ViT-g/16 preset; ToTensor + Normalize are
+    folded into the patch embedding as for every other preset."""
+    trunk = HipViT(PRESETS["gigapath"], state_dict, device=device, chunk=chunk)
+    return Extractor(model=ResizeCropThenModel(trunk, 256, 224), transform=u8_tile_transform, identifier=identifier)
+
+
 def hip_ticon_extractor(vit_state_dict: dict[str, torch.Tensor], ticon_state_dict: dict[str, torch.Tensor], *, identifier: str = "ticon", device="cuda",
                         chunk: int = 512) -> Extractor:
     """The reference's `ticon()` factory (src/stamp/preprocessing/extractor/ticon.py:721-741) with the HIP model: H-optimus-1 trunk + TICON on every

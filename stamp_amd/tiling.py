@@ -108,6 +108,30 @@ def _resize_tables_on_device(in_size: int, out_size: int, device_index: int):
     return torch.from_numpy(bounds).to(dev), torch.from_numpy(taps).to(dev), int(taps.shape[1])
 
 
+def resize_center_crop(tiles: torch.Tensor, resized: int, crop: int) -> torch.Tensor:
+    """torchvision's `Resize(resized, BICUBIC)` + `CenterCrop(crop)` on square RGB u8 tiles [n, S, S, 3] on the GPU -> u8 [n, crop, crop, 3], bit for bit
+    what the reference's transform produces from the PIL tile (gigapath.py:21-28): Pillow's bicubic resample + torchvision's crop offset."""
+    if not tiles.is_cuda:
+        raise RuntimeError("resize_center_crop needs the tiles on the GPU (no CPU fallback)")
+    if tiles.dtype != torch.uint8 or tiles.dim() != 4 or tiles.shape[-1] != 3 or tiles.shape[1] != tiles.shape[2]:
+        raise ValueError(f"expected u8 [n, S, S, 3], got {tiles.dtype} {tuple(tiles.shape)}")
+    if crop > resized:
+        raise ValueError(f"crop {crop} larger than the resized image {resized}")
+    tiles = tiles.contiguous()
+    n, S = tiles.shape[0], tiles.shape[1]
+    dev = tiles.device
+    b_d, t_d, ksize = _resize_tables_on_device(S, int(resized), dev.index if dev.index is not None else torch.cuda.current_device())
+    lib = _lib.lib()
+    out = torch.empty(n, crop, crop, 3, dtype=torch.uint8, device=dev)
+    for i0 in range(0, n, 32768):                          # gridDim.z of one launch
+        m = min(32768, n - i0)
+        nb = lib.amds_tile_resize_crop_workspace_bytes(m, S, crop)
+        ws = ops.scratch("resize_crop", dev, nb)
+        _lib.check(lib.amds_tile_resize_crop_u8(tiles[i0:i0 + m].data_ptr(), out[i0:i0 + m].data_ptr(), m, S, int(resized), int(crop), b_d.data_ptr(), t_d.data_ptr(), ksize,
+                                                ws.data_ptr(), ws.numel(), ops._stream()), "tile_resize_crop")
+    return out
+
+
 def supertiles_to_tiles(rgba: torch.Tensor, tiles_per_side: int, tile_size_px: int = 224, *, out: torch.Tensor | None = None,
                         workspace: torch.Tensor | None = None) -> torch.Tensor:
     """u8 [n, S, S, 4] (what `read_region` returns, on the GPU) -> u8 [n * k * k, tile_px, tile_px, 3]: resize to k * tile_px, drop alpha,

@@ -88,6 +88,11 @@ PRESETS: dict[str, ViTConfig] = {
     # pack time).  Mean / std are in-tree (h_optimus_0.py:26-28).
     "h_optimus_0": ViTConfig(dim=1536, depth=40, heads=24, hidden=4096, mlp="swiglu", reg_tokens=4, no_embed_class=True,
                              mean=(0.707223, 0.578729, 0.703617), std=(0.211883, 0.230117, 0.177517)),
+    # Prov-GigaPath's tile encoder = timm vit_giant_patch14_dinov2 with 16-pixel patches (reference gigapath.py:18: the factory passes the hub name
+    # only; width 1536, depth 40, 24 heads, SwiGLUPacked 8192 -> 4096, no register tokens are the model card's hyper-parameters, checked against
+    # the state_dict shapes at pack time).  Its transform is NOT the identity on 224-pixel tiles: Resize(256, bicubic) + CenterCrop(224)
+    # (gigapath.py:21-28) -- `stamp_amd.extractor.hip_gigapath_extractor` puts `tiling.resize_center_crop` in front of the trunk.
+    "gigapath": ViTConfig(patch=16, dim=1536, depth=40, heads=24, hidden=4096, mlp="swiglu", reg_tokens=0, no_embed_class=False),
     # ViT-L/16 (reference UNI, uni.py:26-31)
     "vit_large_patch16_224": ViTConfig(patch=16),
     # small shapes for tests

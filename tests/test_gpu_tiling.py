@@ -165,3 +165,42 @@ def test_compact_rows_on_device(gpu):
         assert torch.equal(slots.cpu(), want), (slots, want)
         assert count.item() == len(expect)
     assert torch.equal(dst[:len(expect)], torch.stack(expect))
+
+
+@pytest.mark.parametrize("S,resized,crop", [(224, 256, 224), (224, 384, 384), (100, 257, 224), (256, 224, 200)])
+def test_resize_center_crop_is_pillows_resize_plus_torchvisions_crop(gpu, S, resized, crop):
+    """`Resize(resized, BICUBIC)` + `CenterCrop(crop)` as the reference's gigapath transform applies them to the PIL tile (gigapath.py:21-28): Pillow's
+    bicubic `Image.resize` (what torchvision calls for PIL inputs) and torchvision's crop offset int(round((resized - crop) / 2.0)) -- bit for bit,
+    up- and down-scaling, odd differences (Python's round half to even)."""
+    from PIL import Image
+    from stamp_amd.tiling import resize_center_crop
+    rng = np.random.default_rng(S + resized)
+    tiles = rng.integers(0, 256, (5, S, S, 3), dtype=np.uint8)
+    tiles[1] = (np.indices((S, S)).sum(0) % 256)[..., None].astype(np.uint8)            # smooth ramp with wrap-arounds
+    tiles[2, : S // 2] = 255
+    out = resize_center_crop(torch.from_numpy(tiles).to(gpu), resized, crop).cpu().numpy()
+    c0 = int(round((resized - crop) / 2.0))
+    for i in range(5):
+        ref = np.asarray(Image.fromarray(tiles[i], "RGB").resize((resized, resized), Image.BICUBIC))[c0:c0 + crop, c0:c0 + crop]
+        assert out[i].shape == ref.shape and np.array_equal(out[i], ref), (i, np.abs(out[i].astype(int) - ref.astype(int)).max())
+    assert resize_center_crop(torch.from_numpy(tiles[:0]).to(gpu), resized, crop).shape == (0, crop, crop, 3)
+    with pytest.raises(ValueError, match="larger"):
+        resize_center_crop(torch.from_numpy(tiles).to(gpu), 100, 224)
+
+
+def test_gigapath_extractor_runs_the_transform_in_front_of_the_trunk(gpu):
+    from dataclasses import replace
+
+    from PIL import Image
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd.extractor import ResizeCropThenModel
+    from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
+    cfg = replace(PRESETS["gigapath"], dim=128, depth=2, heads=2, hidden=192)            # GigaPath's structure (16-pixel patches, SwiGLU, no register tokens) at test size
+    sd = random_vit_state_dict(cfg, seed=8)
+    tiles = torch.randint(0, 256, (4, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
+    model = ResizeCropThenModel(HipViT(cfg, sd, device=gpu, chunk=4), 256, 224)
+    out = model(tiles.to(gpu)).float().cpu()
+    pil = np.stack([np.asarray(Image.fromarray(t.numpy(), "RGB").resize((256, 256), Image.BICUBIC))[16:240, 16:240] for t in tiles])
+    ref = extract_features(torch.from_numpy(pil), sd, cfg).float()
+    rel = ((out - ref).norm() / ref.norm()).item()
+    assert out.shape == (4, 128) and rel < 1e-3, rel
