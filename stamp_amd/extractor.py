@@ -46,6 +46,12 @@ def hip_vit_extractor(name: str, state_dict: dict[str, torch.Tensor], *, identif
     return Extractor(model=model, transform=u8_tile_transform, identifier=identifier or f"amdstamp-{name}")
 
 
+def hip_dinobloom_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "dino-bloom", device="cuda", chunk: int = 1020) -> Extractor:
+    """The reference's `dino_bloom()` factory (src/stamp/preprocessing/extractor/dinobloom.py:56-84) with the HIP trunk.  `state_dict`: the checkpoint's
+    `"teacher"` entries without the `dino_head` / `ibot_head` keys and with the `"backbone."` prefix removed, as the reference prepares them (:39-46)."""
+    return Extractor(model=HipViT(PRESETS["dinobloom_s"], state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
+
+
 class ResizeCropThenModel(torch.nn.Module):
     """`model(resize_center_crop(tiles))`: a tile transform that is not the identity on the tile size, done on the GPU in front of the HIP model
     (Pillow's bicubic resample bit for bit + torchvision's crop offset: `stamp_amd.tiling.resize_center_crop`)."""

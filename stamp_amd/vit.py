@@ -93,6 +93,10 @@ PRESETS: dict[str, ViTConfig] = {
     # the state_dict shapes at pack time).  Its transform is NOT the identity on 224-pixel tiles: Resize(256, bicubic) + CenterCrop(224)
     # (gigapath.py:21-28) -- `stamp_amd.extractor.hip_gigapath_extractor` puts `tiling.resize_center_crop` in front of the trunk.
     "gigapath": ViTConfig(patch=16, dim=1536, depth=40, heads=24, hidden=4096, mlp="swiglu", reg_tokens=0, no_embed_class=False),
+    # DinoBloom-S = DINOv2 ViT-S/14 fine-tuned (reference dinobloom.py:25-53: `torch.hub.load("facebookresearch/dinov2", "dinov2_vits14")`, embed size 384
+    # from `_embed_sizes`, pos_embed re-made for 257 tokens; depth 12, 6 heads, GELU MLP 1536, LayerScale are DINOv2-S's published hyper-parameters,
+    # checked against the state_dict at pack time; the hub model's state_dict uses the same names as timm's, plus `mask_token`, ignored here).
+    "dinobloom_s": ViTConfig(dim=384, depth=12, heads=6, hidden=1536),
     # ViT-L/16 (reference UNI, uni.py:26-31)
     "vit_large_patch16_224": ViTConfig(patch=16),
     # small shapes for tests

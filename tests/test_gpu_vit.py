@@ -48,7 +48,7 @@ def test_vit_large_matches_oracle(gpu):
     assert r_f < 1e-3 and r_t < 1e-3 and mx < 2e-3
 
 
-@pytest.mark.parametrize("name,tol_cls", [("uni2_h", 1e-3), ("virchow2", 1e-3), ("h_optimus_0", 1e-3), ("vit_large_patch16_224", 1e-3)])
+@pytest.mark.parametrize("name,tol_cls", [("uni2_h", 1e-3), ("virchow2", 1e-3), ("h_optimus_0", 1e-3), ("vit_large_patch16_224", 1e-3), ("dinobloom_s", 1e-3), ("gigapath", 1e-3)])
 def test_full_size_presets_match_oracle(gpu, name, tol_cls):
     """Full-size parity for every preset DESIGN quotes a throughput for (reference uni2.py:17-37, virchow2.py:24-54 -- ViT-H/14
     with head_dim 80 --, h_optimus_0.py:15-30, uni.py:26-31): 2 tiles, fp16 operands / fp32 accumulate / fp32 residual stream.
