@@ -597,6 +597,13 @@ int amds_gated_attn_pool(const float* x, const amds_gap_weights* w_host, float* 
 int amds_topk_rows_mean(const float* score, int n, int k, const void* rows, long ld, int cols, int rows_dtype, int* idx_out, float* mean_out,
                         void* stream);
 
+/* KEEP's image head (reference src/stamp/preprocessing/extractor/keep.py:38-47, `KEEPImageModel.encode_image`): out = normalize(W2 gelu(W1 feats + b1) + b2),
+ * F.normalize's x / max(||x||_2, 1e-12), exact fp32.  feats: the ViT-L/16 trunk's class features [rows][in_dim] (AMDS_F32 / AMDS_F16); w1 [proj][in_dim],
+ * w2 [proj][proj] fp32; out fp32 [rows][proj]. */
+size_t amds_proj_head_l2norm_workspace_bytes(int rows, int in_dim, int proj_dim);
+int amds_proj_head_l2norm(const void* feats, int feats_dtype, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int rows,
+                          int in_dim, int proj_dim, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small rows of the MIL path
  * ---------------------------------------------------------------------------------------------- */

@@ -96,3 +96,11 @@ def cox_breslow_slide_loss(scores, times, events):
     mx = scores.max()
     lse = torch.log((risk * torch.exp(scores - mx)).sum(dim=1)) + mx
     return -(scores[ev] - lse).mean()
+
+
+def keep_image_head(feats: torch.Tensor, sd: dict) -> torch.Tensor:
+    """KEEP's `encode_image` after the trunk (reference src/stamp/preprocessing/extractor/keep.py:38-47): normalize(Linear(GELU(Linear(feats)))), F.normalize's
+    x / max(||x||, 1e-12).  Pinned by tests/golden/keep_head.npz (the reference's own class with an identity trunk)."""
+    import torch.nn.functional as F
+    h = F.gelu(F.linear(feats, sd["visual_head.0.weight"], sd["visual_head.0.bias"]))
+    return F.normalize(F.linear(h, sd["visual_head.2.weight"], sd["visual_head.2.bias"]), dim=-1)

@@ -230,6 +230,8 @@ PROTOTYPES = {
     "amds_ticon_tile_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_tile_resize_crop_workspace_bytes": (_sz, [_i, _i, _i]),
     "amds_tile_resize_crop_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "amds_proj_head_l2norm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amds_proj_head_l2norm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -96,6 +96,25 @@ __global__ void __launch_bounds__(1024) topk_rows_mean_kernel(const float* __res
     }
 }
 
+
+// torch.nn.functional.normalize(x, dim=-1): x / max(||x||_2, eps), one wave per row (KEEP's encode_image, reference keep.py:45-47)
+__global__ void __launch_bounds__(256) l2_normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cols, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long)row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s = fmaf(xr[c], xr[c], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+    for (int c = lane; c < cols; c += 64) out[(long)row * cols + c] = xr[c] * inv;
+}
+
+__global__ void __launch_bounds__(256) f16_rows_to_f32_kernel(const f16* __restrict__ src, float* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (float)src[i];
+}
+
 }  // namespace amds
 
 using namespace amds;
@@ -170,5 +189,37 @@ extern "C" int amds_topk_rows_mean(const float* score, int n, int k, const void*
         hipLaunchKernelGGL((topk_rows_mean_kernel<f16>), dim3(1), dim3(1024), 0, st, score, n, k, (const f16*)rows, ld, cols, idx_out, mean_out);
     else { set_error("amds_topk_rows_mean: bad dtype %d", rows_dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("topk_rows_mean_kernel");
+    return AMDS_OK;
+}
+
+extern "C" size_t amds_proj_head_l2norm_workspace_bytes(int rows, int in_dim, int proj_dim) {
+    return (((size_t)rows * in_dim * 4 + 255) & ~(size_t)255) + 2 * (((size_t)rows * proj_dim * 4 + 255) & ~(size_t)255);
+}
+
+// KEEP's image head (reference src/stamp/preprocessing/extractor/keep.py:38-47): normalize(Linear(GELU(Linear(feats)))), exact fp32
+extern "C" int amds_proj_head_l2norm(const void* feats, int feats_dtype, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int rows,
+                                     int in_dim, int proj_dim, void* ws, size_t ws_bytes, void* stream) {
+    if (rows == 0) return AMDS_OK;
+    AMDS_REQUIRE(feats && w1 && b1 && w2 && b2 && out && ws, "amds_proj_head_l2norm: null pointer");
+    AMDS_REQUIRE(rows > 0 && in_dim > 0 && proj_dim > 0 && (feats_dtype == AMDS_F32 || feats_dtype == AMDS_F16), "amds_proj_head_l2norm: bad arguments");
+    if (ws_bytes < amds_proj_head_l2norm_workspace_bytes(rows, in_dim, proj_dim)) { set_error("amds_proj_head_l2norm: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    AMDS_REQUIRE(((uintptr_t)ws & 255) == 0, "amds_proj_head_l2norm: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = reinterpret_cast<char*>(ws);
+    const size_t o1 = ((size_t)rows * in_dim * 4 + 255) & ~(size_t)255, o2 = o1 + (((size_t)rows * proj_dim * 4 + 255) & ~(size_t)255);
+    const float* x = reinterpret_cast<const float*>(feats);
+    if (feats_dtype == AMDS_F16) {
+        const long n = (long)rows * in_dim;
+        hipLaunchKernelGGL(f16_rows_to_f32_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, (const f16*)feats, (float*)base, n);
+        AMDS_LAUNCH_CHECK("f16_rows_to_f32_kernel");
+        x = reinterpret_cast<const float*>(base);
+    }
+    float *h = reinterpret_cast<float*>(base + o1), *y = reinterpret_cast<float*>(base + o2);
+    int rc = gemm_f32(x, in_dim, w1, in_dim, b1, h, proj_dim, rows, proj_dim, in_dim, 0, st);
+    if (rc != AMDS_OK) return rc;
+    if ((rc = amds_mlp_act_f32(h, proj_dim, rows, proj_dim, 0, stream)) != AMDS_OK) return rc;                   // nn.GELU (exact erf)
+    if ((rc = gemm_f32(h, proj_dim, w2, proj_dim, b2, y, proj_dim, rows, proj_dim, proj_dim, 0, st)) != AMDS_OK) return rc;
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, y, out, rows, proj_dim, 1e-12f);
+    AMDS_LAUNCH_CHECK("l2_normalize_rows_kernel");
     return AMDS_OK;
 }

@@ -52,6 +52,51 @@ def hip_dinobloom_extractor(state_dict: dict[str, torch.Tensor], *, identifier: 
     return Extractor(model=HipViT(PRESETS["dinobloom_s"], state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
 
 
+class HipKeep(torch.nn.Module):
+    """`KEEPImageModel` of the reference (src/stamp/preprocessing/extractor/keep.py:25-50): timm ViT-L/16 trunk, then `visual_head` (Linear, GELU,
+    Linear) and an L2 normalisation -- trunk = the ViT-L/16 preset, head = ONE library call in exact fp32 (`amds_proj_head_l2norm`) on the trunk's
+    stored fp16 class features.  `state_dict`: the checkpoint's `visual.*` / `visual_head.*` entries (:83-88); LayerScale keys named `.ls1.weight`
+    are accepted like the reference's `_remap_layerscale_keys` does (:53-59).  Output fp32 [B, projection_dim] (the reference's loop casts to half)."""
+
+    def __init__(self, state_dict: dict[str, torch.Tensor], *, device="cuda", chunk: int = 1020, vit_cfg: ViTConfig | None = None) -> None:
+        super().__init__()
+        sd = {}
+        for k, v in state_dict.items():
+            if ".ls1.weight" in k or ".ls2.weight" in k:
+                k = k.replace(".weight", ".gamma")
+            sd[k] = v
+        trunk = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+        head = {k[len("visual_head."):]: v for k, v in sd.items() if k.startswith("visual_head.")}
+        missing = [k for k in ("0.weight", "0.bias", "2.weight", "2.bias") if k not in head]
+        if missing:
+            raise KeyError(f"KEEP state_dict lacks visual_head.{missing}")
+        self.vit = HipViT(vit_cfg or PRESETS["vit_large_patch16_224"], trunk, device=device, chunk=chunk)
+        dev = self.vit.device_
+        self._h = [head[k].detach().to(dev, torch.float32).contiguous() for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
+        self.proj_dim, self.in_dim = self._h[0].shape
+        if self.in_dim != self.vit.cfg.dim or tuple(self._h[2].shape) != (self.proj_dim, self.proj_dim):
+            raise ValueError(f"visual_head shapes {tuple(self._h[0].shape)}, {tuple(self._h[2].shape)} do not fit a {self.vit.cfg.dim}-d trunk")
+
+    @torch.no_grad()
+    def forward(self, tiles: torch.Tensor) -> torch.Tensor:
+        from . import _lib, ops
+        feats = self.vit(tiles)                                      # fp16 [B, dim]
+        B, dev = feats.shape[0], feats.device
+        out = torch.empty(B, self.proj_dim, dtype=torch.float32, device=dev)
+        lib = _lib.lib()
+        nb = lib.amds_proj_head_l2norm_workspace_bytes(B, self.in_dim, self.proj_dim)
+        ws = ops.scratch("keep_head", dev, nb)
+        w1, b1, w2, b2 = self._h
+        _lib.check(lib.amds_proj_head_l2norm(feats.data_ptr(), ops._DT[feats.dtype], w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), B,
+                                             self.in_dim, self.proj_dim, ws.data_ptr(), ws.numel(), ops._stream()), "proj_head_l2norm")
+        return out
+
+
+def hip_keep_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "keep", device="cuda", chunk: int = 1020) -> Extractor:
+    """The reference's `keep()` factory (keep.py:95-116); its transform (Resize(224, bicubic) + CenterCrop(224), :99-106) is the identity on 224-pixel tiles."""
+    return Extractor(model=HipKeep(state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
+
+
 class ResizeCropThenModel(torch.nn.Module):
     """`model(resize_center_crop(tiles))`: a tile transform that is not the identity on the tile size, done on the GPU in front of the HIP model
     (Pillow's bicubic resample bit for bit + torchvision's crop offset: `stamp_amd.tiling.resize_center_crop`)."""

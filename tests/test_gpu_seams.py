@@ -325,3 +325,41 @@ def test_ticon_tile_stage_and_extractor(gpu):
     assert rel < 2e-3, rel
     ex = Extractor(model=model, transform=lambda im: im, identifier="ticon")
     assert ex.identifier == "ticon" and ex.model is model
+
+
+def test_keep_extractor_head_and_trunk(gpu):
+    """KEEP (keep.py:25-50): ViT-L/16 trunk + `visual_head` + L2 normalisation.  The head (one exact-fp32 library call) against the fixture made by the
+    reference's own class; the two stages together at test size against the oracles of both; the `.ls1.weight` key spelling of the checkpoint."""
+    from dataclasses import replace
+
+    from oracle import misc
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd import _lib, ops
+    from stamp_amd.extractor import HipKeep
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+    import ctypes as C
+    z = np.load(Path(__file__).parent / "golden" / "keep_head.npz")
+    hsd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    feats = torch.from_numpy(z["feats"]).to(gpu)
+    lib = _lib.lib()
+    w = [hsd[f"visual_head.{k}"].to(gpu).contiguous() for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
+    for x in (feats, feats.half()):
+        out = torch.empty(11, 96, device=gpu)
+        nb = lib.amds_proj_head_l2norm_workspace_bytes(11, 128, 96)
+        ws = torch.empty(nb, dtype=torch.uint8, device=gpu)
+        _lib.check(lib.amds_proj_head_l2norm(x.data_ptr(), ops._DT[x.dtype], *[t.data_ptr() for t in w], out.data_ptr(), 11, 128, 96, ws.data_ptr(), nb, None), "head")
+        np.testing.assert_allclose(out.cpu().numpy(), z["out"], rtol=2e-5, atol=2e-6)
+    cfg = replace(PRESETS["vit_large_patch16_224"], dim=128, depth=2, heads=2, hidden=256)
+    vsd = random_vit_state_dict(cfg, seed=12)
+    sd = {f"visual.{k.replace('.gamma', '.weight') if '.ls' in k else k}": v for k, v in vsd.items()}          # the checkpoint's LayerScale spelling (keep.py:53-59)
+    sd.update(hsd)
+    sd["logit_scale"] = torch.zeros(())                                                                       # entries outside visual.* are ignored (:83-88)
+    model = HipKeep(sd, device=gpu, chunk=3, vit_cfg=cfg)
+    tiles = torch.randint(0, 256, (5, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(13))
+    out = model(tiles.to(gpu))
+    assert out.dtype == torch.float32 and out.shape == (5, 96)
+    ref = misc.keep_image_head(extract_features(tiles, vsd, cfg).float(), hsd)
+    assert ((out.cpu() - ref).norm() / ref.norm()).item() < 1e-3
+    np.testing.assert_allclose(out.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+    with pytest.raises(KeyError, match="visual_head"):
+        HipKeep({k: v for k, v in sd.items() if not k.startswith("visual_head.2")}, device=gpu, vit_cfg=cfg)

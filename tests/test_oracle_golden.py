@@ -272,3 +272,10 @@ def test_ticon_tile_golden(key):
     z, sd = _load("ticon.npz")
     y = ticon.ticon_tile_forward(torch.from_numpy(z[f"emb_{key}"]), sd, key)
     np.testing.assert_allclose(y.numpy(), z[f"out_{key}"], rtol=1e-6, atol=1e-6)
+
+
+def test_keep_image_head_golden():
+    z, sd = _load("keep_head.npz")
+    out = misc.keep_image_head(torch.from_numpy(z["feats"]), sd)
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.linalg.norm(out.numpy(), axis=1), 1.0, rtol=1e-5)

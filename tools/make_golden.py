@@ -253,6 +253,32 @@ def golden_ticon() -> None:
     save("ticon.npz", **out)
 
 
+def golden_keep_head() -> None:
+    """KEEP's image head: the reference's own `KEEPImageModel.encode_image` (keep.py:25-50) with the timm trunk replaced by the identity (timm is not
+    in this image; the trunk is pinned elsewhere) -- pins visual_head + the L2 normalisation."""
+    import torch.nn as nn
+
+    class _Trunk(nn.Module):
+        num_features = 128
+
+        def forward(self, x):
+            return x
+
+    timm_stub = types.SimpleNamespace(create_model=lambda *a, **k: _Trunk())
+    glb = {"nn": nn, "torch": torch, "timm": timm_stub}
+    exec_defs(REF / "preprocessing" / "extractor" / "keep.py", {"KEEPImageModel"}, glb)
+    torch.manual_seed(31)
+    model = glb["KEEPImageModel"](vision_config={"img_size": 224, "patch_size": 16, "init_values": 1e-5, "num_classes": 0}, projection_dim=96).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.bfloat16().float())
+    feats = torch.randn(11, 128).half().float()
+    feats[3] = 0.0                                                  # an all-zero feature row: normalize's eps branch after the biases
+    with torch.no_grad():
+        out = model(feats)
+    save("keep_head.npz", feats=feats.numpy(), out=out.numpy(), **{k: v for k, v in sd_np(model).items() if k.startswith("w:visual_head.")})
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -646,6 +672,7 @@ def main() -> None:
     golden_eagle()
     golden_barspoon()
     golden_ticon()
+    golden_keep_head()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
