@@ -112,6 +112,10 @@ int amds_gemm(const void* A, long lda, const void* W, long ldw, int M, int N, in
               int dtype, int epi, void* out, long ldo, const float* bias, const float* scale,
               const float* pos, int np, int T, int P, float acc_scale, void* stream);
 
+/* CLIP's activation in place on 16-bit rows: u = u * sigmoid(1.702 u) (HF transformers `quick_gelu`, the MLP of the PLIP extractor's vision tower,
+ * reference src/stamp/preprocessing/extractor/plip.py:16-22 -> CLIPModel.get_image_features).  cols, ld multiples of 8. */
+int amds_quick_gelu_inplace(void* u, long ld, long rows, int cols, int dtype, void* stream);
+
 /* Weights-stationary GEMM for narrow layers (K = 96, 192 or 384; N % 32 == 0): out = epi([LayerNorm](A) W^T + bias).
  * The W slice of a workgroup lives in LDS for the whole launch and row groups stream through it from global memory
  * straight into MFMA operand registers.  If ln_gamma/ln_beta are given, A is the fp32 residual stream [M][lda] and
@@ -257,7 +261,7 @@ typedef struct {
     int heads;        /* dim / 64 or dim / 80 */
     int hidden;       /* MLP hidden width (input width of fc2) */
     int n_prefix;     /* cls + register tokens */
-    int mlp_kind;     /* 0 = Linear-GELU-Linear, 1 = SwiGLUPacked (fc1 out = 2*hidden) */
+    int mlp_kind;     /* 0 = Linear-GELU-Linear, 1 = SwiGLUPacked (fc1 out = 2*hidden), 2 = Linear-quick_gelu-Linear (HF CLIP: x sigmoid(1.702 x); plain packing only) */
     int layerscale;   /* 0/1 */
     int dtype;        /* AMDS_F16 / AMDS_BF16 */
     float ln_eps;     /* 1e-6 for timm ViTs */
@@ -320,6 +324,8 @@ typedef struct {
     const amds_vit_exact_block* exact_host;   /* HOST array of `depth` structs, or NULL (off) */
     int exact_hidden;                         /* the MLP's real (unpadded) hidden width, e.g. 3416 for Virchow2 (cfg.hidden is padded) */
     const amds_vit_fp8_block* fp8_host;       /* HOST array of `depth` structs, or NULL (off) */
+    const float* pre_norm_w;                  /* [dim] LayerNorm applied to the embedded tokens before the first block (HF CLIP `pre_layrnorm`, timm */
+    const float* pre_norm_b;                  /* `norm_pre`), or NULL: none (every timm preset).  Not filled by amds_vit_pack: the host sets them. */
 } amds_vit_weights;
 
 /* ---- weight packing in the library (so that a non-Python host can use the tile encoder through this ABI alone) -------------------------

@@ -43,7 +43,8 @@ class VitWeights(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p),
                 ("pos_patch", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("patch_lo_shift", C.c_int),
-                ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int), ("fp8_host", C.POINTER(VitFp8Block))]
+                ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int), ("fp8_host", C.POINTER(VitFp8Block)),
+                ("pre_norm_w", C.c_void_p), ("pre_norm_b", C.c_void_p)]
 
 
 class VitHostBlock(C.Structure):
@@ -232,6 +233,7 @@ PROTOTYPES = {
     "amds_tile_resize_crop_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "amds_proj_head_l2norm_workspace_bytes": (_sz, [_i, _i, _i]),
     "amds_proj_head_l2norm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_quick_gelu_inplace": (_i, [_vp, _l, _l, _i, _i, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
     "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -335,6 +335,29 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
     return AMDS_OK;
 }
 
+// CLIP's activation (HF `quick_gelu`: x * sigmoid(1.702 x)), in place on 16-bit rows [rows][ld], `cols` columns (the PLIP extractor's MLP:
+// fc1 writes the pre-activation with the plain bias epilogue, this turns it into fc2's A operand)
+template <typename T>
+__global__ void __launch_bounds__(256) quick_gelu_inplace_kernel(T* __restrict__ u, long ld, long rows, int cols) {
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    const int c8 = cols >> 3;
+    const long total = rows * c8;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8);
+        vec8* p = reinterpret_cast<vec8*>(u + r * ld) + c;
+        vec8 v = *p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)v[e];
+            v[e] = (T)(x / (1.0f + __expf(-1.702f * x)));
+        }
+        *p = v;
+    }
+}
+
 }  // namespace amds
 
 using namespace amds;
@@ -467,5 +490,17 @@ extern "C" int amds_ln_stats_cast(const float* x, long ldx, int M, int D, float 
         else hipLaunchKernelGGL((ln_stats_cast_kernel<bf16, 8>), dim3(grid), dim3(256), 0, st, x, ldx, (bf16*)xh, ldxh, M, D, eps, rowstat);
     }
     AMDS_LAUNCH_CHECK("ln_stats_cast_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_quick_gelu_inplace(void* u, long ld, long rows, int cols, int dtype, void* stream) {
+    AMDS_REQUIRE(u && rows >= 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 8 == 0, "amds_quick_gelu_inplace: bad arguments (cols, ld multiples of 8)");
+    if (rows == 0) return AMDS_OK;
+    const long total = rows * (cols >> 3);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (dtype == AMDS_F16) hipLaunchKernelGGL((quick_gelu_inplace_kernel<f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (f16*)u, ld, rows, cols);
+    else if (dtype == AMDS_BF16) hipLaunchKernelGGL((quick_gelu_inplace_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16*)u, ld, rows, cols);
+    else { set_error("amds_quick_gelu_inplace: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    AMDS_LAUNCH_CHECK("quick_gelu_inplace_kernel");
     return AMDS_OK;
 }

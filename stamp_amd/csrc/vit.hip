@@ -32,7 +32,7 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     AMDS_REQUIRE(c->dim % 128 == 0 && c->heads > 0 && (c->heads * 64 == c->dim || c->heads * 80 == c->dim),
                  "vit: dim=%d must be a multiple of 128 and heads*64 or heads*80", c->dim);
     AMDS_REQUIRE(c->hidden % 64 == 0 && c->hidden > 0, "vit: hidden=%d must be a multiple of 64 (zero-pad)", c->hidden);
-    AMDS_REQUIRE(c->mlp_kind == 0 || c->mlp_kind == 1, "vit: bad mlp_kind");
+    AMDS_REQUIRE(c->mlp_kind >= 0 && c->mlp_kind <= 2, "vit: bad mlp_kind");
     AMDS_REQUIRE(c->mlp_kind == 1 || c->hidden % 128 == 0, "vit: GELU hidden=%d must be a multiple of 128", c->hidden);
     AMDS_REQUIRE(c->dtype == AMDS_F16 || c->dtype == AMDS_BF16, "vit: bad act dtype");
     AMDS_REQUIRE(c->depth > 0 && c->n_prefix >= 0 && batch > 0, "vit: bad depth/prefix/batch");
@@ -88,7 +88,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     float* rowstat = reinterpret_cast<float*>(ws + pl.off_rowstat);
     int* diag = reinterpret_cast<int*>(ws + pl.off_diag);
     const int D = c->dim, T = pl.T, M = Bc * T, dt = c->dtype, Hd = c->hidden, NP = D / 128;
-    const int n_fc1 = c->mlp_kind == 0 ? Hd : 2 * Hd;
+    const int n_fc1 = c->mlp_kind == 1 ? 2 * Hd : Hd;
     int rc;
 #define AMDS_TRY(call) do { rc = (call); if (rc != AMDS_OK) return rc; } while (0)
     // One kernel family per GEMM whatever the batch: a tile's features must not depend on which chunk it travels in (bit-exact,
@@ -108,9 +108,10 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     }
     if (fold)
         AMDS_REQUIRE(D % 256 == 0 && n_fc1 % 256 == 0, "vit: the LayerNorm-folded path needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", D, n_fc1);
+    AMDS_REQUIRE(c->mlp_kind != 2 || (!fold && !w->exact_host && !w->fp8_host), "vit: the quick-GELU MLP (CLIP) runs on the plain packing only (no LayerNorm fold, exact rows or fp8)");
     // exact class-token rows (vit_exact.hip): an fp32 class stream beside the 16-bit-operand path
     const amds_vit_exact_block* ex = w->exact_host;
-    const int xh_ = w->exact_hidden, xf1 = c->mlp_kind == 0 ? xh_ : 2 * xh_, hd = D / c->heads;
+    const int xh_ = w->exact_hidden, xf1 = c->mlp_kind == 1 ? 2 * xh_ : xh_, hd = D / c->heads;
     if (ex) {
         AMDS_REQUIRE(xh_ > 0 && xh_ <= Hd && xh_ % 4 == 0, "vit: exact_hidden=%d must be a multiple of 4 and <= hidden=%d", xh_, Hd);
         for (int l = 0; l < c->depth; ++l)
@@ -144,6 +145,11 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     if (c->n_prefix > 0) AMDS_TRY(prefix_init(w->prefix, x, Bc, T, c->n_prefix, D, st));
     AMDS_TRY(amds_gemm(mlp, kpe, w->patch_w, kpe, Bc * pl.np, D, kpe, dt, AMDS_EPI_PATCH, x, D, w->patch_b,
                        nullptr, w->pos_patch, pl.np, T, c->n_prefix, 1.0f / 255.0f, st));
+    // CLIP-style trunks normalise the embeddings before the first block (HF `pre_layrnorm`, timm `norm_pre`): in place, each wave holds its row
+    if (w->pre_norm_w) {
+        AMDS_REQUIRE(w->pre_norm_b, "vit: pre_norm_b missing");
+        AMDS_TRY(amds_layernorm(x, D, w->pre_norm_w, w->pre_norm_b, x, D, Bc * T, D, c->ln_eps, AMDS_F32, st));
+    }
 
     // ---- ragged tail on a side stream.  The GEMMs work on 256-row tiles, one workgroup per CU, and every launch is a whole number of
     // waves of workgroups: M = 64 x 257 rows (the reference's DataLoader batch) is 64.25 row tiles, and the 65th row tile costs every GEMM
@@ -184,7 +190,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         float* rp = rowpart + (size_t)r0 * NP * 2;
         float* rs = rowstat + 2 * (size_t)r0;
         char *hq = rows16(h, r0, D), *h2q = rows16(h2, r0, D), *qkvq = rows16(qkv, r0, 3 * D), *mlpq = rows16(mlp, r0, Hd);
-        const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : AMDS_EPI_SWIGLU;
+        const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : (c->mlp_kind == 1 ? AMDS_EPI_SWIGLU : AMDS_EPI_BIAS);      // kind 2: + quick-GELU pass below
         float *xcq = xc + (size_t)q.t0 * D, *hcq = hc + (size_t)q.t0 * D, *qcq = qc + (size_t)q.t0 * D, *ocq = oc + (size_t)q.t0 * D;
         float* ucq = uc + (size_t)q.t0 * 2 * Hd;
         auto lin32 = [&](const float* A, int lda, const float* Wt, int K, float* Cm, int ldc, int N, const float* bias, int acc) {
@@ -250,6 +256,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 if (ex) AMDS_TRY(amds_vit_cls_scatter(xcq, xq, nullptr, nullptr, q.nt, T, D, c->ln_eps, dt, s));
                 AMDS_TRY(amds_layernorm(xq, D, b.ln2_w, b.ln2_b, hq, D, n, D, c->ln_eps, dt, s));
                 AMDS_TRY(enc_gemm(hq, D, b.fc1_w, D, n, n_fc1, D, epi1, mlpq, Hd, b.fc1_b, nullptr, s));
+                if (c->mlp_kind == 2) AMDS_TRY(amds_quick_gelu_inplace(mlpq, Hd, n, Hd, dt, s));        // CLIP: x * sigmoid(1.702 x)
                 AMDS_TRY(enc_gemm(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, b.fc2_b, ls2, s));
             }
             if (ex) {      // class stream, MLP branch: xc += fc2(act(fc1(LN2(xc)))), then over the main path's class rows

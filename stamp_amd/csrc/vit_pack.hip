@@ -202,7 +202,7 @@ int walk(const amds_vit_cfg* c, const amds_vit_host_weights* s, const Dims& d, A
     float* nw = A.take<float>(D, ow ? &ow->norm_w : nullptr);
     float* nb = A.take<float>(D, ow ? &ow->norm_b : nullptr);
     if (fill) { copy_f32(nw, s->norm_w, D); copy_f32(nb, s->norm_b, D); }
-    if (ow) { ow->blocks_host = ob; ow->patch_lo_shift = d.lo_shift; ow->exact_host = d.exact ? oe : nullptr; ow->exact_hidden = d.Hr; ow->fp8_host = nullptr; }
+    if (ow) { ow->blocks_host = ob; ow->patch_lo_shift = d.lo_shift; ow->exact_host = d.exact ? oe : nullptr; ow->exact_hidden = d.Hr; ow->fp8_host = nullptr; ow->pre_norm_w = nullptr; ow->pre_norm_b = nullptr; }
 
     // ---- row maps
     std::vector<int> id3(3 * D), idD(D), fc1_map(d.fc1_rows_pad);

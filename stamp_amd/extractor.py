@@ -97,6 +97,52 @@ def hip_keep_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str =
     return Extractor(model=HipKeep(state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
 
 
+def clip_vision_to_timm_names(sd: dict[str, torch.Tensor]) -> tuple[dict[str, torch.Tensor], torch.Tensor]:
+    """HF `CLIPModel` state_dict -> (the vision tower under timm's VisionTransformer names, visual_projection.weight).  Data movement only: q / k / v
+    projections concatenated into `attn.qkv`, the bias-free patch convolution given a zero bias, embeddings reshaped."""
+    p = "vision_model."
+    D = sd[p + "embeddings.class_embedding"].numel()
+    out = {"patch_embed.proj.weight": sd[p + "embeddings.patch_embedding.weight"], "patch_embed.proj.bias": torch.zeros(D),
+           "cls_token": sd[p + "embeddings.class_embedding"].reshape(1, 1, D), "pos_embed": sd[p + "embeddings.position_embedding.weight"].unsqueeze(0),
+           "norm_pre.weight": sd[p + "pre_layrnorm.weight"], "norm_pre.bias": sd[p + "pre_layrnorm.bias"],
+           "norm.weight": sd[p + "post_layernorm.weight"], "norm.bias": sd[p + "post_layernorm.bias"]}
+    l = 0
+    while f"{p}encoder.layers.{l}.layer_norm1.weight" in sd:
+        q, b = f"{p}encoder.layers.{l}.", f"blocks.{l}."
+        for a, t in (("layer_norm1", "norm1"), ("layer_norm2", "norm2"), ("self_attn.out_proj", "attn.proj"), ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+            out[b + t + ".weight"], out[b + t + ".bias"] = sd[q + a + ".weight"], sd[q + a + ".bias"]
+        out[b + "attn.qkv.weight"] = torch.cat([sd[q + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0)
+        out[b + "attn.qkv.bias"] = torch.cat([sd[q + f"self_attn.{n}_proj.bias"] for n in ("q", "k", "v")], dim=0)
+        l += 1
+    return out, sd["visual_projection.weight"]
+
+
+class HipPlip(torch.nn.Module):
+    """`PLIP` of the reference (src/stamp/preprocessing/extractor/plip.py:16-22: `CLIPModel.get_image_features`): CLIP's vision tower on the HIP tile
+    encoder (quick_gelu MLP, pre-LayerNorm: `ViTConfig(mlp="quick_gelu", pre_norm=True)`), then `visual_projection` in exact fp32 on the fp32 class
+    row.  `state_dict`: the HF `CLIPModel`'s (text tower entries are ignored).  Output fp32 [B, projection_dim]."""
+
+    def __init__(self, state_dict: dict[str, torch.Tensor], *, device="cuda", chunk: int = 1020, vit_cfg: ViTConfig | None = None) -> None:
+        super().__init__()
+        vsd, proj = clip_vision_to_timm_names({k: v for k, v in state_dict.items() if k.startswith("vision_model.") or k.startswith("visual_projection.")})
+        self.vit = HipViT(vit_cfg or PRESETS["plip"], vsd, device=device, chunk=chunk)
+        self.proj = proj.detach().to(self.vit.device_, torch.float32).contiguous()
+        if self.proj.shape[1] != self.vit.cfg.dim:
+            raise ValueError(f"visual_projection takes {self.proj.shape[1]}-d features, the tower gives {self.vit.cfg.dim}")
+
+    @torch.no_grad()
+    def forward(self, tiles: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        _, toks = self.vit(tiles, return_tokens=True)                 # fp32 [B, T, D], post_layernorm applied
+        return ops.linear_f32(toks[:, 0].contiguous(), self.proj, None)
+
+
+def hip_plip_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "plip", device="cuda", chunk: int = 1020) -> Extractor:
+    """The reference's `plip()` factory (plip.py:25-40); Resize(224) is the identity on 224-pixel tiles, ToTensor + Normalize are folded into the patch
+    embedding like every preset's."""
+    return Extractor(model=HipPlip(state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
+
+
 class ResizeCropThenModel(torch.nn.Module):
     """`model(resize_center_crop(tiles))`: a tile transform that is not the identity on the tile size, done on the GPU in front of the HIP model
     (Pillow's bicubic resample bit for bit + torchvision's crop offset: `stamp_amd.tiling.resize_center_crop`)."""

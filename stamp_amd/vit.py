@@ -33,7 +33,8 @@ class ViTConfig:
     depth: int = 24
     heads: int = 16
     hidden: int = 4096           # fc2 input width (for SwiGLUPacked: half of fc1's output width)
-    mlp: str = "gelu"            # "gelu" (timm Mlp) | "swiglu" (timm SwiGLUPacked + SiLU)
+    mlp: str = "gelu"            # "gelu" (timm Mlp) | "swiglu" (timm SwiGLUPacked + SiLU) | "quick_gelu" (HF CLIP: x * sigmoid(1.702 x))
+    pre_norm: bool = False       # LayerNorm on the embedded tokens before the first block (HF CLIP `pre_layrnorm` / timm `norm_pre`)
     reg_tokens: int = 0
     no_embed_class: bool = False
     layerscale: bool = True      # timm init_values is not None
@@ -97,6 +98,11 @@ PRESETS: dict[str, ViTConfig] = {
     # from `_embed_sizes`, pos_embed re-made for 257 tokens; depth 12, 6 heads, GELU MLP 1536, LayerScale are DINOv2-S's published hyper-parameters,
     # checked against the state_dict at pack time; the hub model's state_dict uses the same names as timm's, plus `mask_token`, ignored here).
     "dinobloom_s": ViTConfig(dim=384, depth=12, heads=6, hidden=1536),
+    # PLIP = HF CLIP ViT-B/32's vision tower (reference plip.py:26: `CLIPModel.from_pretrained("vinid/plip")`; width 768, 12 layers, 12 heads, MLP 3072
+    # with quick_gelu, 32-pixel patches, pre-LayerNorm, no LayerScale, eps 1e-5 are the CLIP ViT-B/32 configuration, checked against the state_dict
+    # at pack time; CLIP's normalisation constants are in-tree, plip.py:31-32).  `stamp_amd.extractor.HipPlip` adds the visual projection.
+    "plip": ViTConfig(patch=32, dim=768, depth=12, heads=12, hidden=3072, mlp="quick_gelu", pre_norm=True, layerscale=False, ln_eps=1e-5,
+                      mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)),
     # ViT-L/16 (reference UNI, uni.py:26-31)
     "vit_large_patch16_224": ViTConfig(patch=16),
     # small shapes for tests
@@ -114,6 +120,8 @@ def expected_state_dict_shapes(cfg: ViTConfig) -> dict[str, tuple]:
                             "pos_embed": (1, cfg.n_patches + (0 if cfg.no_embed_class else cfg.n_prefix), D), "norm.weight": (D,), "norm.bias": (D,)}
     if cfg.reg_tokens:
         sh["reg_token"] = (1, cfg.reg_tokens, D)
+    if cfg.pre_norm:
+        sh.update({"norm_pre.weight": (D,), "norm_pre.bias": (D,)})
     for i in range(cfg.depth):
         b = f"blocks.{i}."
         sh.update({b + "norm1.weight": (D,), b + "norm1.bias": (D,), b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
@@ -203,7 +211,7 @@ class HipViT(nn.Module):
         n_fc1 = cfg.hidden_pad * (2 if cfg.mlp == "swiglu" else 1)
         can_fold = cfg.dim % 256 == 0 and n_fc1 % 256 == 0
         if ln_fold is None:
-            ln_fold = can_fold and os.environ.get("AMDS_VIT_LNFOLD", "1") != "0"
+            ln_fold = can_fold and cfg.mlp != "quick_gelu" and os.environ.get("AMDS_VIT_LNFOLD", "1") != "0"
         if ln_fold and not can_fold:
             raise ValueError(f"ln_fold needs dim % 256 == 0 and fc1 rows % 256 == 0 (dim={cfg.dim}, fc1 rows={n_fc1})")
         self.ln_fold = bool(ln_fold)
@@ -215,8 +223,12 @@ class HipViT(nn.Module):
         self.patch_lo_shift = (11 if act_dtype == torch.float16 else 8) if patch_split else 0
         self.exact = bool(exact)
         self.fp8 = bool(fp8)
+        if cfg.mlp == "quick_gelu":          # CLIP's MLP: fc1 (plain bias epilogue) -> activation pass -> fc2; plain packing only
+            if exact or fp8 or ln_fold:
+                raise ValueError("a quick_gelu (CLIP) trunk runs on the plain packing only: no ln_fold, exact or fp8")
+            self.ln_fold = False
         if self.fp8:
-            if act_dtype != torch.float16 or exact or cfg.dim % 256 or cfg.hidden % 256:
+            if act_dtype != torch.float16 or exact or cfg.dim % 256 or cfg.hidden % 256 or cfg.mlp == "quick_gelu":
                 raise ValueError("fp8=True needs fp16 activations, exact=False, and dim / hidden multiples of 256 (ViT-L, UNI2-h, H-optimus; not Virchow's 3416)")
             self.ln_fold = False             # the fp8 chain normalises, THEN quantises: plain packing
         self._pack(state_dict)
@@ -231,7 +243,7 @@ class HipViT(nn.Module):
         validate_state_dict(c, sd)
         hw, keep = host_weights(c, sd)
         flags = (_lib.PACK_LNFOLD if self.ln_fold else 0) | (_lib.PACK_PATCH_SPLIT if self.patch_lo_shift else 0) | (_lib.PACK_EXACT if self.exact else 0)
-        self._cfg_c = _lib.VitCfg(c.img, c.patch, c.dim, c.depth, c.heads, c.hidden_pad, c.n_prefix, 1 if c.mlp == "swiglu" else 0,
+        self._cfg_c = _lib.VitCfg(c.img, c.patch, c.dim, c.depth, c.heads, c.hidden_pad, c.n_prefix, {"gelu": 0, "swiglu": 1, "quick_gelu": 2}[c.mlp],
                                   1 if c.layerscale else 0, ops.act_code(self.act_dtype), c.ln_eps)
         lib = _lib.lib()
         need = lib.amds_vit_pack_bytes(C.byref(self._cfg_c), C.byref(hw), flags)
@@ -246,6 +258,9 @@ class HipViT(nn.Module):
                                    self._exact, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "vit_pack")
         del keep
+        if c.pre_norm:          # not part of the packed image: two fp32 vectors the host hands over (include/amdstamp.h, amds_vit_weights.pre_norm_*)
+            self._pre_norm = [sd[k].detach().to(self.device_, torch.float32).contiguous() for k in ("norm_pre.weight", "norm_pre.bias")]
+            self._w_c.pre_norm_w, self._w_c.pre_norm_b = self._pre_norm[0].data_ptr(), self._pre_norm[1].data_ptr()
 
     def _pack_fp8(self, sd: dict[str, torch.Tensor]) -> None:
         """e4m3 weights with per-output-channel scales (the library's own row quantiser applied to the weight rows), LayerScale multiplied into
@@ -418,6 +433,8 @@ def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate")
     sd["cls_token"] = rn(1, 1, D, s=0.5 if stress else 1e-6)
     if cfg.reg_tokens:
         sd["reg_token"] = rn(1, cfg.reg_tokens, D, s=0.5 if stress else 1e-6)
+    if cfg.pre_norm:
+        sd["norm_pre.weight"], sd["norm_pre.bias"] = 1.0 + rn(D, s=0.1), rn(D, s=0.1)
     n_pos = cfg.n_patches + (0 if cfg.no_embed_class else cfg.n_prefix)
     sd["pos_embed"] = rn(1, n_pos, D, s=0.5 if stress else 0.02)
     for i in range(cfg.depth):

@@ -363,3 +363,51 @@ def test_keep_extractor_head_and_trunk(gpu):
     np.testing.assert_allclose(out.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
     with pytest.raises(KeyError, match="visual_head"):
         HipKeep({k: v for k, v in sd.items() if not k.startswith("visual_head.2")}, device=gpu, vit_cfg=cfg)
+
+
+def test_plip_extractor_matches_transformers_fixture(gpu):
+    """PLIP (plip.py:16-36): CLIP's vision tower (32-pixel patches, pre-LayerNorm, quick_gelu MLP, no LayerScale) on the HIP tile encoder + the visual
+    projection, against image features produced by the installed `transformers` CLIPModel itself (tests/golden/plip.npz).  Bar: the fp16-operand
+    path's 1e-3 relative L2; then the full-size preset (ViT-B/32) against the oracle pinned to that fixture."""
+    from dataclasses import replace
+
+    from oracle import clip_vision as cv
+    from stamp_amd.extractor import HipPlip, clip_vision_to_timm_names
+    from stamp_amd.vit import PRESETS, HipViT
+    z = np.load(Path(__file__).parent / "golden" / "plip.npz")
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    cfg = replace(PRESETS["plip"], dim=128, depth=2, heads=2, hidden=256)
+    model = HipPlip(sd, device=gpu, chunk=2, vit_cfg=cfg)
+    tiles = torch.from_numpy(z["tiles"])
+    out = model(tiles.to(gpu))
+    ref = torch.from_numpy(z["image_features"])
+    rel = ((out.cpu() - ref).norm() / ref.norm()).item()
+    assert out.dtype == torch.float32 and out.shape == ref.shape and rel < 1e-3, rel
+    assert torch.equal(out, model(tiles.to(gpu)))
+    with pytest.raises(ValueError, match="plain packing"):
+        HipViT(cfg, clip_vision_to_timm_names(sd)[0], device=gpu, exact=True)
+    # full size: CLIP ViT-B/32 (768 wide, 12 layers), random weights, 3 tiles
+    g = torch.Generator().manual_seed(3)
+    big = {}
+    D, Hd, P = 768, 3072, 512
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc  # noqa: E731
+    big["vision_model.embeddings.class_embedding"] = rn(D, sc=0.5)
+    big["vision_model.embeddings.patch_embedding.weight"] = rn(D, 3, 32, 32, sc=(3 * 32 * 32) ** -0.5)
+    big["vision_model.embeddings.position_embedding.weight"] = rn(50, D, sc=0.5)
+    for n in ("pre_layrnorm", "post_layernorm"):
+        big[f"vision_model.{n}.weight"], big[f"vision_model.{n}.bias"] = 1.0 + rn(D, sc=0.1), rn(D, sc=0.1)
+    for l in range(12):
+        q = f"vision_model.encoder.layers.{l}."
+        for n in ("layer_norm1", "layer_norm2"):
+            big[q + n + ".weight"], big[q + n + ".bias"] = 1.0 + rn(D, sc=0.1), rn(D, sc=0.1)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            big[q + f"self_attn.{n}.weight"], big[q + f"self_attn.{n}.bias"] = rn(D, D, sc=D ** -0.5 * (0.4 if n == "out_proj" else 1.0)), rn(D, sc=0.1)
+        big[q + "mlp.fc1.weight"], big[q + "mlp.fc1.bias"] = rn(Hd, D, sc=D ** -0.5), rn(Hd, sc=0.1)
+        big[q + "mlp.fc2.weight"], big[q + "mlp.fc2.bias"] = rn(D, Hd, sc=Hd ** -0.5 * 0.4), rn(D, sc=0.1)
+    big["visual_projection.weight"] = rn(P, D, sc=D ** -0.5)
+    t3 = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=g)
+    refb = cv.clip_image_features(cv.tiles_to_pixels(t3), big, heads=12)
+    outb = HipPlip(big, device=gpu, chunk=3)(t3.to(gpu)).cpu()
+    relb = ((outb - refb).norm() / refb.norm()).item()
+    print(f"PLIP (CLIP ViT-B/32) full size: image features vs the fp32 oracle {relb:.3e}")
+    assert outb.shape == (3, 512) and relb < 1e-3, relb

@@ -279,3 +279,11 @@ def test_keep_image_head_golden():
     out = misc.keep_image_head(torch.from_numpy(z["feats"]), sd)
     np.testing.assert_allclose(out.numpy(), z["out"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(np.linalg.norm(out.numpy(), axis=1), 1.0, rtol=1e-5)
+
+
+def test_plip_clip_vision_golden():
+    """oracle/clip_vision.py against the installed `transformers` CLIPModel.get_image_features (the call of the reference's plip.py:16-22)."""
+    from oracle import clip_vision as cv
+    z, sd = _load("plip.npz")
+    y = cv.clip_image_features(cv.tiles_to_pixels(torch.from_numpy(z["tiles"])), sd, heads=int(z["heads"]))
+    np.testing.assert_allclose(y.numpy(), z["image_features"], rtol=1e-5, atol=2e-6)

@@ -279,6 +279,36 @@ def golden_keep_head() -> None:
     save("keep_head.npz", feats=feats.numpy(), out=out.numpy(), **{k: v for k, v in sd_np(model).items() if k.startswith("w:visual_head.")})
 
 
+def golden_plip() -> None:
+    """PLIP's vision tower: the installed `transformers` CLIPModel itself (the package the reference's plip.py calls), randomly initialised at a small
+    width, `get_image_features` on transformed tiles."""
+    import logging
+
+    from transformers import CLIPConfig, CLIPModel, CLIPTextConfig, CLIPVisionConfig
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from oracle.clip_vision import tiles_to_pixels
+    logging.getLogger("transformers").setLevel(logging.ERROR)
+    vc = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=224, patch_size=32, projection_dim=64)
+    tc = CLIPTextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=100, max_position_embeddings=16, projection_dim=64,
+                        bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    torch.manual_seed(41)
+    model = CLIPModel(CLIPConfig(text_config=tc.to_dict(), vision_config=vc.to_dict(), projection_dim=64)).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("vision_model") or n.startswith("visual_projection"):
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+                p.copy_(p.bfloat16().float())
+    tiles = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(42))
+    with torch.no_grad():
+        y = model.get_image_features(tiles_to_pixels(tiles))
+    y = y if isinstance(y, torch.Tensor) else y.pooler_output           # transformers 5: a BaseModelOutputWithPooling whose pooler_output is the projected embedding
+    import transformers
+    save("plip.npz", tiles=tiles.numpy(), image_features=y.numpy(), heads=np.array(2), transformers_version=np.array(transformers.__version__),
+         **{k: v for k, v in sd_np(model).items() if k.startswith("w:vision_model") or k.startswith("w:visual_projection")})
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -673,6 +703,7 @@ def main() -> None:
     golden_barspoon()
     golden_ticon()
     golden_keep_head()
+    golden_plip()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
