@@ -405,6 +405,37 @@ class HipViTClsMean(nn.Module):
         return self
 
 
+def hf_dinov2_to_timm_names(sd: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+    """HF `transformers` `Dinov2Model` / `Dinov2WithRegistersModel` state_dict -> timm VisionTransformer names (what `HipViT` and the reference's
+    factories use).  Data movement only: query / key / value concatenated into `attn.qkv`, `layer_scale*.lambda1` -> `ls*.gamma`, SwiGLU
+    `weights_in` / `weights_out` -> `mlp.fc1` / `mlp.fc2`; with register tokens the position table gets zero rows for them (HF adds positions to
+    the class token and the patches only), which is timm's `no_embed_class=False` layout."""
+    p = "embeddings."
+    out = {"patch_embed.proj.weight": sd[p + "patch_embeddings.projection.weight"], "patch_embed.proj.bias": sd[p + "patch_embeddings.projection.bias"],
+           "cls_token": sd[p + "cls_token"], "norm.weight": sd["layernorm.weight"], "norm.bias": sd["layernorm.bias"]}
+    pos = sd[p + "position_embeddings"]
+    if p + "register_tokens" in sd:
+        reg = sd[p + "register_tokens"]
+        out["reg_token"] = reg
+        pos = torch.cat([pos[:, :1], torch.zeros(1, reg.shape[1], pos.shape[2], dtype=pos.dtype), pos[:, 1:]], dim=1)
+    out["pos_embed"] = pos
+    l = 0
+    while f"encoder.layer.{l}.norm1.weight" in sd:
+        q, b = f"encoder.layer.{l}.", f"blocks.{l}."
+        for n in ("norm1", "norm2"):
+            out[b + n + ".weight"], out[b + n + ".bias"] = sd[q + n + ".weight"], sd[q + n + ".bias"]
+        a = q + "attention.attention."
+        out[b + "attn.qkv.weight"] = torch.cat([sd[a + f"{n}.weight"] for n in ("query", "key", "value")], dim=0)
+        out[b + "attn.qkv.bias"] = torch.cat([sd[a + f"{n}.bias"] for n in ("query", "key", "value")], dim=0)
+        out[b + "attn.proj.weight"], out[b + "attn.proj.bias"] = sd[q + "attention.output.dense.weight"], sd[q + "attention.output.dense.bias"]
+        out[b + "ls1.gamma"], out[b + "ls2.gamma"] = sd[q + "layer_scale1.lambda1"], sd[q + "layer_scale2.lambda1"]
+        f1, f2 = ("mlp.weights_in", "mlp.weights_out") if (q + "mlp.weights_in.weight") in sd else ("mlp.fc1", "mlp.fc2")
+        out[b + "mlp.fc1.weight"], out[b + "mlp.fc1.bias"] = sd[q + f1 + ".weight"], sd[q + f1 + ".bias"]
+        out[b + "mlp.fc2.weight"], out[b + "mlp.fc2.bias"] = sd[q + f2 + ".weight"], sd[q + f2 + ".bias"]
+        l += 1
+    return out
+
+
 def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate") -> dict[str, torch.Tensor]:
     """Random timm-named weights (no checkpoints are reachable offline).
 

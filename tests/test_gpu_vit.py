@@ -276,3 +276,26 @@ def test_cls_plus_mean_patch_embedding(gpu):
     assert out.dtype == torch.float16 and out.shape == (5, 2 * cfg.dim)
     assert _rel(out.cpu().float(), ref) < 2e-3
     assert model(tiles[:0].to(gpu)).shape == (0, 2 * cfg.dim)
+
+
+@pytest.mark.parametrize("tag,kw", [("gelu", dict(hidden=256)), ("swiglu", dict(hidden=344, mlp="swiglu")), ("reg4", dict(hidden=344, mlp="swiglu", reg_tokens=4))])
+def test_hip_vit_matches_transformers_dinov2_fixture(gpu, tag, kw):
+    """The HIP tile encoder against outputs of an INDEPENDENT third-party implementation (`transformers`' Dinov2Model / Dinov2WithRegistersModel,
+    tests/golden/dinov2_hf.npz; timm itself is not installed): GELU + LayerScale, SwiGLU (hidden 344 -> zero-padded), SwiGLU + 4 register tokens.
+    Bar: the fp16-operand path's 1e-3 relative L2 on the compared tokens and on the stored class feature."""
+    from pathlib import Path
+
+    import numpy as np
+
+    from stamp_amd.vit import ViTConfig, hf_dinov2_to_timm_names
+    z = np.load(Path(__file__).parent / "golden" / "dinov2_hf.npz")
+    sd = hf_dinov2_to_timm_names({k[len(tag) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}_w:")})
+    cfg = ViTConfig(dim=128, depth=2, heads=2, **kw)
+    model = HipViT(cfg, sd, device=gpu, chunk=2)
+    f, t = model(torch.from_numpy(z["tiles"]).to(gpu), return_tokens=True)
+    sel = list(range(10)) + [-2, -1]
+    ref = torch.from_numpy(z[f"{tag}_tokens"])
+    r_t, r_f = _rel(t[:, sel].cpu(), ref), _rel(f.float().cpu(), ref[:, 0])
+    print(f"dinov2 ({tag}) vs transformers: tokens {r_t:.3e}, CLS feature {r_f:.3e}")
+    assert r_t < 1e-3 and r_f < 1e-3
+    np.testing.assert_allclose(t.norm(dim=-1).cpu().numpy(), z[f"{tag}_token_norms"], rtol=3e-3)

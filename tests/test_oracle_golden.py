@@ -287,3 +287,25 @@ def test_plip_clip_vision_golden():
     z, sd = _load("plip.npz")
     y = cv.clip_image_features(cv.tiles_to_pixels(torch.from_numpy(z["tiles"])), sd, heads=int(z["heads"]))
     np.testing.assert_allclose(y.numpy(), z["image_features"], rtol=1e-5, atol=2e-6)
+
+
+_DINO_VARIANTS = {"gelu": dict(hidden=256), "swiglu": dict(hidden=344, mlp="swiglu"), "reg4": dict(hidden=344, mlp="swiglu", reg_tokens=4)}
+
+
+@pytest.mark.parametrize("tag", list(_DINO_VARIANTS))
+def test_vit_oracle_equals_transformers_dinov2(tag):
+    """The tile-encoder oracle (a restatement of timm's VisionTransformer, which is NOT installed here) against an independent third-party
+    implementation of the same architecture that IS: `transformers`' Dinov2Model / Dinov2WithRegistersModel -- GELU MLP + LayerScale (the reference's
+    RedDino / DinoBloom / ViT-L/14 structure), SwiGLU, SwiGLU + 4 register tokens (its ViT-g family's).  Fixture: tools/make_golden.py::golden_dinov2_hf --
+    the committed outputs the GPU test holds the HIP path to (tests/test_gpu_vit.py); the LIVE comparison on every branch and at full ViT-L/14 size is
+    tests/test_oracle_vit.py."""
+    from oracle.vit_tile_encoder import extract_features
+    from stamp_amd.vit import ViTConfig, hf_dinov2_to_timm_names
+    z = np.load(G / "dinov2_hf.npz")
+    sd = hf_dinov2_to_timm_names({k[len(tag) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}_w:")})
+    cfg = ViTConfig(dim=128, depth=2, heads=2, **_DINO_VARIANTS[tag])
+    feats, toks = extract_features(torch.from_numpy(z["tiles"]), sd, cfg, return_tokens=True)
+    sel = list(range(10)) + [-2, -1]
+    np.testing.assert_allclose(toks[:, sel].numpy(), z[f"{tag}_tokens"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(toks.norm(dim=-1).numpy(), z[f"{tag}_token_norms"], rtol=1e-5)
+    np.testing.assert_allclose(feats.float().numpy(), z[f"{tag}_tokens"][:, 0], rtol=2e-3, atol=2e-3)       # the stored feature = fp16 of the class row

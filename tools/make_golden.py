@@ -309,6 +309,40 @@ def golden_plip() -> None:
          **{k: v for k, v in sd_np(model).items() if k.startswith("w:vision_model") or k.startswith("w:visual_projection")})
 
 
+def golden_dinov2_hf() -> None:
+    """The ViT trunk against an INDEPENDENT third-party implementation that IS in this image: `transformers`' Dinov2Model / Dinov2WithRegistersModel
+    (timm, which the reference calls, is not installed; DINOv2 is the architecture of the reference's RedDino / DinoBloom extractors and -- with
+    SwiGLU and register tokens -- of its ViT-g family).  Random weights at a small width, three structural variants."""
+    import logging
+
+    from transformers import Dinov2Config, Dinov2Model, Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+
+    logging.getLogger("transformers").setLevel(logging.ERROR)
+    out = {}
+    tiles = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(52))
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    px = (tiles.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    out["tiles"] = tiles.numpy()
+    for tag, cls, kw in (("gelu", Dinov2Model, dict(mlp_ratio=2, use_swiglu_ffn=False)), ("swiglu", Dinov2Model, dict(mlp_ratio=4, use_swiglu_ffn=True)),
+                         ("reg4", Dinov2WithRegistersModel, dict(mlp_ratio=4, use_swiglu_ffn=True, num_register_tokens=4))):
+        ccls = Dinov2WithRegistersConfig if cls is Dinov2WithRegistersModel else Dinov2Config
+        cfg = ccls(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, patch_size=14, image_size=224, layerscale_value=0.3, layer_norm_eps=1e-6, **kw)
+        torch.manual_seed(60 + len(tag))
+        model = cls(cfg).eval()
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() == 1 or "token" in n or "position" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+                p.copy_(p.bfloat16().float())
+            toks = model(px).last_hidden_state
+        out[f"{tag}_tokens"] = toks[:, list(range(10)) + [-2, -1]].numpy()          # class token, registers, first and last patches (the fixture stays small)
+        out[f"{tag}_token_norms"] = toks.norm(dim=-1).numpy()                            # ... and every token's norm
+        out.update({f"{tag}_{k}": v for k, v in sd_np(model).items() if "mask_token" not in k})
+    import transformers
+    out["transformers_version"] = np.array(transformers.__version__)
+    save("dinov2_hf.npz", **out)
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -704,6 +738,7 @@ def main() -> None:
     golden_ticon()
     golden_keep_head()
     golden_plip()
+    golden_dinov2_hf()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
