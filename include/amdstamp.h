@@ -848,6 +848,26 @@ int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim, const floa
                           int n_tokens, float p_drop, uint64_t seed, uint32_t stream_id, const void* saved, size_t saved_bytes, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* The whole TransMIL TRAINING step's forward and backward, one call each: the loop around amds_nystrom_attn_fwd / _bwd (reference
+ * trans_mil.py:299-325 in train mode -- Dropout(0.1) on both `to_out`s, dropout sites 1 and 2 of `seed` -- and loss.backward() through it).
+ * Gradients in the reference's shapes; PPEG's three kernels share one tap-correlation table ppeg_corr [50][dim] (amds_ppeg_wgrad: the 7x7 kernel's
+ * gradient is taps 0..48, the 5x5 / 3x3 ones its central 25 / 9 taps, every bias tap 49 -- the host slices). */
+typedef struct {
+    float* fc1_w; float* fc1_b;          /* [dim][n_feats], [dim] */
+    float* cls_token;                    /* [dim] */
+    struct { float* norm_w; float* norm_b; float* qkv_w; float* out_w; float* out_b; float* conv_w; } layer[2];
+    float* ppeg_corr;                    /* [50][dim] */
+    float* norm_w; float* norm_b;        /* [dim] */
+    float* fc2_w; float* fc2_b;          /* [classes][dim], [classes] */
+} amds_transmil_grads;
+size_t amds_transmil_train_saved_bytes(const amds_transmil_cfg* cfg_host, int n_bags, int n_tiles);
+size_t amds_transmil_train_workspace_bytes(const amds_transmil_cfg* cfg_host, int n_bags, int n_tiles);
+int amds_transmil_train_forward(const amds_transmil_cfg* cfg_host, const amds_transmil_weights* w_host, const void* bags, int bags_dtype, float p_drop,
+                                uint64_t seed, float* logits, int n_bags, int n_tiles, void* saved, size_t saved_bytes, void* stream);
+int amds_transmil_train_backward(const amds_transmil_cfg* cfg_host, const amds_transmil_weights* w_host, const float* dlogits, float p_drop, uint64_t seed,
+                                 int n_bags, int n_tiles, const void* saved, size_t saved_bytes, const amds_transmil_grads* grads_host, float* dbags, void* ws,
+                                 size_t ws_bytes, void* stream);
+
 /* Backward pieces of the TransMIL head (training: the reference differentiates trans_mil.py with autograd inside
  * LitTileClassifier._step, src/stamp/modeling/models/__init__.py:239-279); fp32 like the forward.  The matrix products of the
  * backward are amds_bgemm_f32 calls.

@@ -102,6 +102,15 @@ class TransMilWeights(C.Structure):
                [(n, C.c_void_p) for n in ("ppeg_w7", "ppeg_b7", "ppeg_w5", "ppeg_b5", "ppeg_w3", "ppeg_b3", "norm_w", "norm_b", "fc2_w", "fc2_b")]
 
 
+class TransMilLayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "qkv_w", "out_w", "out_b", "conv_w")]
+
+
+class TransMilGrads(C.Structure):
+    _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("cls_token", C.c_void_p), ("layer", TransMilLayerGrads * 2), ("ppeg_corr", C.c_void_p),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
+
+
 class NystromGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "out_w", "out_b", "conv_w")]
 
@@ -235,6 +244,10 @@ PROTOTYPES = {
     "amds_proj_head_l2norm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "amds_quick_gelu_inplace": (_i, [_vp, _l, _l, _i, _i, _vp]),
     "amds_transmil_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "amds_transmil_train_saved_bytes": (_sz, [_vp, _i, _i]),
+    "amds_transmil_train_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "amds_transmil_train_forward": (_i, [_vp, _vp, _vp, _i, _f, C.c_uint64, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_transmil_train_backward": (_i, [_vp, _vp, _vp, _f, C.c_uint64, _i, _i, _vp, _sz, _vp, _vp, _vp, _sz, _vp]),
     "amds_nystrom_attn_saved_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_workspace_bytes": (_sz, [_i, _i, _i]),
     "amds_nystrom_attn_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, C.c_uint64, C.c_uint32, _vp, _sz, _vp]),

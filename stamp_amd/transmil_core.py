@@ -84,7 +84,7 @@ class _Nys:
         self.wconv = get(f"{name}.attn.res_conv.weight").reshape(HEADS, -1).contiguous()
 
 
-STEPWISE = False        # tests flip this to run the kernel-by-kernel chains below instead of the two library calls
+STEPWISE = 0            # tests: 0 = the whole-step library calls, 1 = host loop around amds_nystrom_attn_fwd / _bwd, 2 = everything kernel by kernel from the host
 
 
 def _layer_struct(P: _Nys) -> "_lib.TransMilLayer":
@@ -94,7 +94,7 @@ def _layer_struct(P: _Nys) -> "_lib.TransMilLayer":
 def nystrom_forward(y: torch.Tensor, P: _Nys, x_res: torch.Tensor, p_drop: float, seed: int, sid: int):
     """x_res += Dropout(to_out(NystromAttention(y)))[:, -n:]; returns what the backward needs.  ONE library call (amds_nystrom_attn_fwd,
     csrc/nystrom_train.hip): the intermediates live in one arena the backward reads."""
-    if STEPWISE:
+    if STEPWISE >= 2:
         return nystrom_forward_stepwise(y, P, x_res, p_drop, seed, sid)
     import ctypes as C
     b, n, Cd = y.shape
@@ -293,8 +293,103 @@ def nystrom_backward_stepwise(S: dict, P: _Nys, dx: torch.Tensor, need_params: b
     return dyp[:, pad:, :].contiguous(), G
 
 
+def _c_weights(get, Cd: int):
+    """amds_transmil_weights over the parameters `get` returns (fp32 device tensors), + the tensors it points to."""
+    keep = {}
+
+    def ptr(name, shape=None):
+        t = get(name)
+        if shape is not None:
+            t = t.reshape(shape).contiguous()
+        keep[name] = t
+        return t.data_ptr()
+
+    w = _lib.TransMilWeights()
+    w.fc1_w, w.fc1_b, w.cls_token = ptr("_fc1.0.weight"), ptr("_fc1.0.bias"), ptr("cls_token", (Cd,))
+    for i, nm in enumerate(("layer1", "layer2")):
+        w.layer[i] = _lib.TransMilLayer(ptr(f"{nm}.norm.weight"), ptr(f"{nm}.norm.bias"), ptr(f"{nm}.attn.to_qkv.weight"), ptr(f"{nm}.attn.to_out.0.weight"),
+                                        ptr(f"{nm}.attn.to_out.0.bias"), ptr(f"{nm}.attn.res_conv.weight", (HEADS, -1)))
+    w.ppeg_w7, w.ppeg_b7 = ptr("pos_layer.proj.weight", (Cd, -1)), ptr("pos_layer.proj.bias")
+    w.ppeg_w5, w.ppeg_b5 = ptr("pos_layer.proj1.weight", (Cd, -1)), ptr("pos_layer.proj1.bias")
+    w.ppeg_w3, w.ppeg_b3 = ptr("pos_layer.proj2.weight", (Cd, -1)), ptr("pos_layer.proj2.bias")
+    w.norm_w, w.norm_b, w.fc2_w, w.fc2_b = ptr("norm.weight"), ptr("norm.bias"), ptr("_fc2.weight"), ptr("_fc2.bias")
+    return w, keep
+
+
 def forward_train(get, bags: torch.Tensor, dims: tuple[int, int, int], *, training: bool, seed: int = 0):
-    """-> (logits [Bb, C], saved).  dims = (dim_input, dim_hidden, dim_output)."""
+    """-> (logits [Bb, C], saved).  dims = (dim_input, dim_hidden, dim_output).  ONE library call (amds_transmil_train_forward,
+    csrc/transmil_train.hip); `saved` holds the activation arena the backward reads."""
+    if STEPWISE >= 1:
+        return forward_train_stepwise(get, bags, dims, training=training, seed=seed)
+    import ctypes as C
+    Fd, Cd, Cc = dims
+    Bb, Tn, _ = bags.shape
+    dev = bags.device
+    if bags.dtype not in ops._DT:
+        bags = bags.float()
+    bags = bags.contiguous()
+    cfg = _lib.TransMilCfg(Fd, Cd, Cc)
+    w, keep = _c_weights(get, Cd)
+    lib = _lib.lib()
+    need = lib.amds_transmil_train_saved_bytes(C.byref(cfg), Bb, Tn)
+    if need == 0:
+        _lib.check(-1, "transmil_train_saved_bytes")
+    arena = torch.empty(need, dtype=torch.uint8, device=dev)
+    logits = torch.empty(Bb, Cc, dtype=torch.float32, device=dev)
+    p_out = P_OUT if training else 0.0
+    _lib.check(lib.amds_transmil_train_forward(C.byref(cfg), C.byref(w), bags.data_ptr(), ops._DT[bags.dtype], p_out, int(seed) & (2 ** 64 - 1), logits.data_ptr(), Bb, Tn,
+                                               arena.data_ptr(), arena.numel(), ops._stream()), "transmil_train_forward")
+    return logits, dict(arena=arena, cfg=cfg, w=w, keep=keep, shape=(Bb, Tn, Fd), dims=dims, p_out=p_out, seed=seed)
+
+
+def backward(saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False):
+    """-> (grads keyed by the reference's state_dict names, dbags or None).  ONE library call (amds_transmil_train_backward)."""
+    if "arena" not in saved:
+        return backward_stepwise(saved, dlogits, need_params=need_params, need_bags=need_bags)
+    import ctypes as C
+    Fd, Cd, Cc = saved["dims"]
+    Bb, Tn, _ = saved["shape"]
+    dev = dlogits.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    dlogits = dlogits.contiguous().float()
+    lib = _lib.lib()
+    need = lib.amds_transmil_train_workspace_bytes(C.byref(saved["cfg"]), Bb, Tn)
+    if need == 0:
+        _lib.check(-1, "transmil_train_workspace_bytes")
+    ws = ops.scratch("transmil_train", dev, need)
+    G: dict[str, torch.Tensor] = {}
+    gc = corr = None
+    if need_params:
+        G = {"_fc1.0.weight": torch.empty(Cd, Fd, **f32), "_fc1.0.bias": torch.empty(Cd, **f32), "cls_token": torch.empty(1, 1, Cd, **f32),
+             "norm.weight": torch.empty(Cd, **f32), "norm.bias": torch.empty(Cd, **f32), "_fc2.weight": torch.empty(Cc, Cd, **f32), "_fc2.bias": torch.empty(Cc, **f32)}
+        corr = torch.empty(50, Cd, **f32)
+        gc = _lib.TransMilGrads()
+        gc.fc1_w, gc.fc1_b, gc.cls_token, gc.ppeg_corr = G["_fc1.0.weight"].data_ptr(), G["_fc1.0.bias"].data_ptr(), G["cls_token"].data_ptr(), corr.data_ptr()
+        gc.norm_w, gc.norm_b, gc.fc2_w, gc.fc2_b = G["norm.weight"].data_ptr(), G["norm.bias"].data_ptr(), G["_fc2.weight"].data_ptr(), G["_fc2.bias"].data_ptr()
+        for i, nm in enumerate(("layer1", "layer2")):
+            L = {f"{nm}.norm.weight": torch.empty(Cd, **f32), f"{nm}.norm.bias": torch.empty(Cd, **f32), f"{nm}.attn.to_qkv.weight": torch.empty(3 * Cd, Cd, **f32),
+                 f"{nm}.attn.to_out.0.weight": torch.empty(Cd, Cd, **f32), f"{nm}.attn.to_out.0.bias": torch.empty(Cd, **f32),
+                 f"{nm}.attn.res_conv.weight": torch.empty(HEADS, 1, CONV_K, 1, **f32)}
+            G.update(L)
+            gc.layer[i] = _lib.TransMilLayerGrads(*[t.data_ptr() for t in L.values()])
+    dbags = torch.empty(Bb * Tn, Fd, **f32) if need_bags else None
+    arena = saved["arena"]
+    _lib.check(lib.amds_transmil_train_backward(C.byref(saved["cfg"]), C.byref(saved["w"]), dlogits.data_ptr(), saved["p_out"], int(saved["seed"]) & (2 ** 64 - 1), Bb, Tn,
+                                                arena.data_ptr(), arena.numel(), C.byref(gc) if gc is not None else None, dbags.data_ptr() if dbags is not None else None,
+                                                ws.data_ptr(), ws.numel(), ops._stream()), "transmil_train_backward")
+    if need_params:      # PPEG: the three kernels' gradients are windows of one tap-correlation table (include/amdstamp.h, amds_ppeg_wgrad)
+        c7 = corr[:49].t().reshape(Cd, 7, 7)
+        G["pos_layer.proj.weight"] = c7.reshape(Cd, 1, 7, 7).contiguous()
+        G["pos_layer.proj1.weight"] = c7[:, 1:6, 1:6].reshape(Cd, 1, 5, 5).contiguous()
+        G["pos_layer.proj2.weight"] = c7[:, 2:5, 2:5].reshape(Cd, 1, 3, 3).contiguous()
+        for c in ("proj", "proj1", "proj2"):
+            G[f"pos_layer.{c}.bias"] = corr[49].clone()
+    return G, (dbags.view(Bb, Tn, Fd) if need_bags else None)
+
+
+def forward_train_stepwise(get, bags: torch.Tensor, dims: tuple[int, int, int], *, training: bool, seed: int = 0):
+    """The training forward as a host-side loop around the per-layer attention calls (what `forward_train` did before amds_transmil_train_forward
+    existed): the cross-check of the C entry points in tests/ -- bit-identical results."""
     Fd, Cd, C = dims
     Bb, Tn, _ = bags.shape
     dev = bags.device
@@ -335,8 +430,8 @@ def forward_train(get, bags: torch.Tensor, dims: tuple[int, int, int], *, traini
     return logits, saved
 
 
-def backward(saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False):
-    """-> (grads keyed by the reference's state_dict names, dbags or None)."""
+def backward_stepwise(saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False):
+    """Backward of `forward_train_stepwise` (its saved dict): host-side loop, same results as `backward`."""
     Fd, Cd, C = saved["dims"]
     Bb, Tn, _ = saved["shape"]
     n, side, add = saved["n"], saved["side"], saved["add"]

@@ -348,7 +348,7 @@ def test_docs_cite_existing_symbols_and_lines():
     types = {"amds_ctx", "amds_vit_cfg", "amds_vit_weights", "amds_vit_block", "amds_vit_host_weights", "amds_vit_host_block", "amds_vit_exact_block",
              "amds_swin_cfg", "amds_swin_weights", "amds_gap_weights", "amds_status", "amds_dtype", "amds_epilogue", "amds_mil_vit_cfg",
              "amds_mil_vit_weights", "amds_mil_vit_layer", "amds_mil_vit_grads", "amds_mil_vit_layer_grads", "amds_mil_vit_dropout",
-             "amds_transmil_cfg", "amds_transmil_weights", "amds_transmil_layer", "amds_nystrom_grads", "amds_barspoon_cfg", "amds_barspoon_weights", "amds_barspoon_dec_layer", "amds_ticon_weights", "amds_ticon_block"}
+             "amds_transmil_cfg", "amds_transmil_weights", "amds_transmil_layer", "amds_nystrom_grads", "amds_barspoon_cfg", "amds_barspoon_weights", "amds_barspoon_dec_layer", "amds_ticon_weights", "amds_ticon_block", "amds_transmil_grads"}
     assert all(re.search(r"\}\s*" + t + r"\s*;|typedef struct " + t + r"\b|\b" + t + r"\s*\*", (ROOT / "include" / "amdstamp.h").read_text()) for t in types), \
         [t for t in types if not re.search(r"\}\s*" + t + r"\s*;|typedef struct " + t + r"\b|\b" + t + r"\s*\*", (ROOT / "include" / "amdstamp.h").read_text())]
     doc = set(re.findall(r"\b(amds_[a-z0-9_]+)", (ROOT / "INTEGRATION.md").read_text()))

@@ -117,32 +117,39 @@ def test_bgemm_f32_transposed_a_and_split_k_wgrad(gpu, Z, M, N, K, transb):
 
 
 @pytest.mark.parametrize("Bb,Tn,Fd,Cd,train", [(2, 50, 96, 64, False), (3, 300, 128, 128, True), (2, 1024, 256, 512, True), (1, 255, 64, 256, False)])
-def test_nystrom_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, Cd, train):
-    """amds_nystrom_attn_fwd / _bwd (one C call per layer and direction) against the same kernels launched one by one from the host: logits,
-    every parameter gradient and d/d(bags) bit-identical -- with and without front padding (n = 65 < one landmark block; n = 1025 -> 1280;
-    n = 257 on 128 landmarks -> 384), dropout live (same counter-based masks from the same seed) and off."""
+def test_transmil_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, Cd, train):
+    """amds_transmil_train_forward / _backward (the whole step, one C call each) and amds_nystrom_attn_fwd / _bwd (one call per layer and direction under a
+    host loop) against the same kernels launched one by one from the host: logits, every parameter gradient and d/d(bags) bit-identical -- with and
+    without front padding (n = 65 < one landmark block; n = 1025 -> 1280; n = 257 on 128 landmarks -> 384), wrap padding, dropout live (same
+    counter-based masks from the same seed) and off; a second, input-gradient-only backward from the same saved activations."""
     from stamp_amd import transmil_core as tc
     model, bags, targets = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn + 1)
     model = model.to(gpu)
     get = model._get(torch.device(gpu))
     dlogits = torch.randn(Bb, 2, device=gpu)
     res = []
-    for stepwise in (False, True):
-        tc.STEPWISE = stepwise
+    for level in (0, 1, 2):
+        tc.STEPWISE = level
         try:
             logits, saved = tc.forward_train(get, bags.to(gpu), (Fd, Cd, 2), training=train, seed=4321)
             G, db = tc.backward(saved, dlogits, need_params=True, need_bags=True)
             G2, db2 = tc.backward(saved, dlogits, need_params=False, need_bags=True)        # input gradient only, saved activations untouched
         finally:
-            tc.STEPWISE = False
+            tc.STEPWISE = 0
         assert G2 == {} and torch.equal(db2, db)
         res.append((logits, G, db))
-    (l1, G1, d1), (l0, G0, d0) = res
-    assert torch.isfinite(l1).all() and torch.equal(l1, l0) and torch.equal(d1, d0)
-    assert set(G1) == set(G0) == {n for n, _ in model.named_parameters()}
-    for k in G0:
-        assert G1[k].shape == G0[k].shape == dict(model.named_parameters())[k].shape, k
-        assert torch.equal(G1[k], G0[k]), (k, (G1[k] - G0[k]).abs().max().item())
+    l0, G0, d0 = res[2]
+    names = {n: p.shape for n, p in model.named_parameters()}
+    for l1, G1, d1 in res[:2]:
+        assert torch.isfinite(l1).all() and torch.equal(l1, l0) and torch.equal(d1, d0)
+        assert set(G1) == set(G0) == set(names)
+        for k in G0:
+            assert G1[k].shape == G0[k].shape == names[k], k
+            assert torch.equal(G1[k], G0[k]), (k, (G1[k] - G0[k]).abs().max().item())
+    model.train()                                   # the nn.Module under autograd runs on the same calls
+    x = bags.to(gpu).requires_grad_(True)
+    torch.nn.functional.cross_entropy(model(x), targets.to(gpu)).backward()
+    assert x.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
 def test_nystrom_c_abi_guards(gpu):
