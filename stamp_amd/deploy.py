@@ -36,9 +36,17 @@ def model_from_checkpoint(ckpt: Mapping) -> torch.nn.Module:
 
     hp = dict(ckpt["hyper_parameters"])
     name = str(getattr(hp.get("model_name"), "value", hp.get("model_name"))).lower()
+    if name == "barspoon" or ("category_weights" in hp and "d_model" in hp):
+        # LitEncDecTransformer (models/__init__.py:857-899): one head per target, sized by its `category_weights` entry; deploy forward only here
+        from .barspoon import EncDecTransformer
+        kw = {k: hp[k] for k in ("d_model", "num_encoder_heads", "num_decoder_heads", "num_encoder_layers", "num_decoder_layers", "dim_feedforward", "positional_encoding")
+              if k in hp}
+        model = EncDecTransformer(int(hp["dim_input"]), {t: len(w) for t, w in hp["category_weights"].items()}, **kw)
+        model.load_state_dict({k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")})
+        return model.eval()
     classes = {"vit": mil.VisionTransformer, "trans_mil": mil.TransMIL, "mlp": mil.MLP, "linear": mil.Linear}
     if name not in classes:
-        raise ValueError(f"model_name {name!r} has no HIP head (available: {sorted(classes)})")
+        raise ValueError(f"model_name {name!r} has no HIP head (available: {sorted(classes) + ['barspoon']})")
     cls = classes[name]
     task = hp.get("task", "classification")
     dim_output = len(hp["categories"]) if task == "classification" else 1

@@ -82,8 +82,20 @@ def test_model_from_checkpoint_builds_the_head_and_loads_the_backbone():
     assert isinstance(m, VisionTransformer) and not m.training
     for k, v in src.state_dict().items():
         assert torch.equal(m.state_dict()[k], v), k
-    with pytest.raises(ValueError):
-        model_from_checkpoint({**ckpt, "hyper_parameters": {**ckpt["hyper_parameters"], "model_name": "barspoon"}})
+    with pytest.raises(ValueError, match="no HIP head"):
+        model_from_checkpoint({**ckpt, "hyper_parameters": {**ckpt["hyper_parameters"], "model_name": "nonesuch"}})
+    # barspoon checkpoints (LitEncDecTransformer, models/__init__.py:857-899): heads sized by `category_weights`
+    from stamp_amd.barspoon import EncDecTransformer
+    bsrc = EncDecTransformer(40, {"KRAS": 2, "MSI status": 3}, d_model=64, num_encoder_heads=1, num_decoder_heads=1, num_encoder_layers=1, num_decoder_layers=1,
+                             dim_feedforward=128, positional_encoding=False)
+    bck = {"state_dict": {f"model.{k}": v.clone() for k, v in bsrc.state_dict().items()},
+           "hyper_parameters": {"task": "classification", "dim_input": 40, "category_weights": {"KRAS": torch.ones(2), "MSI status": torch.ones(3)}, "d_model": 64,
+                                "num_encoder_heads": 1, "num_decoder_heads": 1, "num_encoder_layers": 1, "num_decoder_layers": 1, "dim_feedforward": 128,
+                                "positional_encoding": False, "learning_rate": 1e-4, "categories": {"KRAS": ["wt", "mut"], "MSI status": ["a", "b", "c"]}}}
+    bm = model_from_checkpoint(bck)
+    assert isinstance(bm, EncDecTransformer) and not bm.training and list(bm.target_labels) == ["KRAS", "MSI status"] and not bm.positional_encoding
+    for k, v in bsrc.state_dict().items():
+        assert torch.equal(bm.state_dict()[k], v), k
     bad = {**ckpt, "state_dict": {**ckpt["state_dict"], "model.not_a_key": torch.zeros(1)}}
     with pytest.raises(RuntimeError):
         model_from_checkpoint(bad)
