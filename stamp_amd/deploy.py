@@ -65,6 +65,21 @@ def predict_(model: torch.nn.Module, batches: Iterable, patient_ids: Sequence[st
     if task not in ("classification", "regression", "survival"):
         raise ValueError(f"unknown task {task!r}")
     model = model.to(device).eval()
+    if hasattr(model, "target_labels") and hasattr(model, "class_tokens"):
+        # multi-target head (barspoon): `LitMilClassificationMixin.predict_step` returns softmax(logits) per target (barspoon.py:333-344) and the
+        # reference's `_predict` applies softmax to what it gets AGAIN when the task is classification (deploy.py:416-438) -- reproduced, not repaired
+        per: dict[str, list[torch.Tensor]] = {}
+        for bags, coords, *_ in batches:
+            out = model(bags.to(device), coords.to(device))
+            for t, v in out.items():
+                per.setdefault(t, []).append(torch.softmax(v.float(), 1).cpu())
+        if not per:
+            return {}
+        cat = {t: torch.cat(v, dim=0) for t, v in per.items()}
+        if task == "classification":
+            cat = {t: torch.softmax(v, dim=1) for t, v in cat.items()}
+        n = next(iter(cat.values())).shape[0]
+        return {pid: {t: cat[t][i] for t in cat} for i, pid in enumerate(list(patient_ids)[:n])}
     outs = []
     for bags, coords, *_ in batches:
         out = model(bags.to(device), coords=None if coords is None else coords.to(device), mask=None)
@@ -83,7 +98,55 @@ def predict_(model: torch.nn.Module, batches: Iterable, patient_ids: Sequence[st
 
 def to_prediction_df(*, categories: Sequence, patient_to_ground_truth: Mapping, predictions: Mapping[str, torch.Tensor], patient_label: str,
                      ground_truth_label: str) -> pd.DataFrame:
-    """patient | ground truth | pred | <ground_truth_label>_<category> ... | loss, sorted by loss (deploy.py:563-590)."""
+    """patient | ground truth | pred | <ground_truth_label>_<category> ... | loss, sorted by loss (deploy.py:563-590).  Multi-target predictions
+    (patient -> {target: probabilities}, barspoon): patient | <target> ... | pred_<t> | <t>_<category> ... | loss = sum over the targets with a
+    known ground truth, in prediction order, unsorted (:479-558); `categories`: {target: [category, ...]}; a missing list is inferred from the
+    ground truths (sorted)."""
+    first = next(iter(predictions.values())) if len(predictions) else None
+    if isinstance(first, dict):
+        targets = list(first.keys())
+        cats_map = dict(categories) if isinstance(categories, dict) else {}
+        if not isinstance(categories, dict) and isinstance(categories, Sequence):
+            try:
+                cats_map = {t: list(categories[i]) for i, t in enumerate(targets)}
+            except Exception:  # noqa: BLE001
+                cats_map = {}
+        if any(t not in cats_map for t in targets):
+            inferred = {t: set() for t in targets}
+            for gt in patient_to_ground_truth.values():
+                if isinstance(gt, dict):
+                    for t in targets:
+                        if gt.get(t) is not None:
+                            inferred[t].add(gt.get(t))
+            for t in targets:
+                cats_map.setdefault(t, sorted(inferred[t]))
+        rows = []
+        for pid, pd_ in predictions.items():
+            gt_entry = patient_to_ground_truth.get(pid)
+            row: dict = {patient_label: pid}
+            for t in targets:
+                row[t] = gt_entry.get(t) if isinstance(gt_entry, dict) else gt_entry
+            total, has = 0.0, False
+            for t in targets:
+                probs = pd_[t].detach().cpu()
+                cats_t = cats_map.get(t, [])
+                if probs.numel() == 1:
+                    row[f"pred_{t}"] = float(probs.item())
+                else:
+                    idx = int(probs.argmax().item())
+                    row[f"pred_{t}"] = cats_t[idx] if idx < len(cats_t) else idx
+                for i_cat, c in enumerate(cats_t):
+                    row[f"{t}_{c}"] = float(probs[i_cat].item()) if i_cat < probs.shape[0] else None
+                if isinstance(gt_entry, dict) and gt_entry.get(t) is not None:
+                    try:
+                        ti = int(np.where(np.array(cats_t) == gt_entry.get(t))[0][0])
+                        total += F.cross_entropy(probs.reshape(1, -1), torch.tensor([ti])).item()
+                        has = True
+                    except Exception:  # noqa: BLE001
+                        pass
+            row["loss"] = total if has else None
+            rows.append(row)
+        return pd.DataFrame(rows)
     cats = list(categories)
     rows = []
     for pid, prediction in predictions.items():

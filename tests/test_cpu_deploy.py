@@ -99,3 +99,51 @@ def test_model_from_checkpoint_builds_the_head_and_loads_the_backbone():
     bad = {**ckpt, "state_dict": {**ckpt["state_dict"], "model.not_a_key": torch.zeros(1)}}
     with pytest.raises(RuntimeError):
         model_from_checkpoint(bad)
+
+
+def test_tables_equal_the_references_own_functions():
+    """The three prediction tables against CSV text produced by the reference's own `_to_prediction_df` (single- and multi-target, with given and with
+    inferred category lists), `_to_regression_prediction_df` and `_to_survival_prediction_df` on the same inputs (tests/golden/deploy_tables.json,
+    tools/make_golden.py::golden_deploy_tables): same columns, same row order, same values."""
+    import io
+    import json
+    from pathlib import Path
+
+    z = json.loads((Path(__file__).parent / "golden" / "deploy_tables.json").read_text())
+
+    def same(df, csv):
+        ref = pd.read_csv(io.StringIO(csv))
+        got = pd.read_csv(io.StringIO(df.to_csv(index=False)))
+        assert list(got.columns) == list(ref.columns), (list(got.columns), list(ref.columns))
+        pd.testing.assert_frame_equal(got, ref, check_exact=False, rtol=1e-6, atol=1e-7)
+
+    s = z["single"]
+    same(to_prediction_df(categories=s["categories"], patient_to_ground_truth=s["gts"], predictions={k: torch.tensor(v) for k, v in s["preds"].items()},
+                          patient_label="PATIENT", ground_truth_label="KRAS"), s["csv"])
+    m = z["multi"]
+    mp = {k: {t: torch.tensor(v) for t, v in d.items()} for k, d in m["preds"].items()}
+    same(to_prediction_df(categories=m["categories"], patient_to_ground_truth=m["gts"], predictions=mp, patient_label="PATIENT", ground_truth_label=["KRAS", "MSI status"]),
+         m["csv"])
+    same(to_prediction_df(categories=[], patient_to_ground_truth=m["gts"], predictions=mp, patient_label="PATIENT", ground_truth_label=None), z["multi_inferred_csv"])
+    r = z["regression"]
+    same(to_regression_prediction_df(patient_to_ground_truth=r["gts"], predictions={k: torch.tensor(v) for k, v in r["preds"].items()}, patient_label="P",
+                                     ground_truth_label="age"), r["csv"])
+    sv = z["survival"]
+    same(to_survival_prediction_df(patient_to_ground_truth={k: (tuple(v) if isinstance(v, list) else v) for k, v in sv["gts"].items()},
+                                   predictions={k: torch.tensor(v) for k, v in sv["preds"].items()}, patient_label="P", cut_off=0.7), sv["csv"])
+
+
+def test_predict_multi_target_head_reproduces_the_references_double_softmax():
+    class _Multi(torch.nn.Module):                       # the barspoon head's surface: forward(tokens, positions) -> {target: logits}
+        target_labels = ["A", "B"]
+        class_tokens = None
+
+        def forward(self, x, pos):
+            m = x.float().mean(1)
+            return {"A": m[:, :2], "B": m[:, 2:5]}
+
+    bags = [torch.randn(1, n, 8) for n in (4, 7)]
+    out = predict_(_Multi(), [(b, torch.zeros(1, b.shape[1], 2), None, None) for b in bags], ["x", "y"], task="classification", device="cpu")
+    assert list(out) == ["x", "y"] and set(out["x"]) == {"A", "B"}
+    want = torch.softmax(torch.softmax(bags[1].mean(1)[:, 2:5], 1), 1)[0]          # predict_step's softmax, then _predict's (deploy.py:416-438)
+    assert torch.allclose(out["y"]["B"], want, atol=1e-6)

@@ -343,6 +343,48 @@ def golden_dinov2_hf() -> None:
     save("dinov2_hf.npz", **out)
 
 
+def golden_deploy_tables() -> None:
+    """The three prediction tables of `stamp deploy`: the reference's own `_to_prediction_df` (single- and multi-target), `_to_regression_prediction_df`,
+    `_to_survival_prediction_df` (src/stamp/modeling/deploy.py:459-691; the module imports lightning: only these functions are executed) on fixed
+    inputs; stored as the inputs + the CSV text of each resulting table."""
+    import json
+    from collections.abc import Mapping, Sequence
+    from typing import Any, cast
+
+    import pandas as pd
+    import torch.nn.functional as F
+
+    glb = {"pd": pd, "np": np, "torch": torch, "F": F, "cast": cast, "Mapping": Mapping, "Sequence": Sequence, "PatientId": str, "GroundTruth": Any, "PandasLabel": str,
+           "Category": Any, "SurvivalGroundTruth": Any}
+    exec_defs(REF / "modeling" / "deploy.py", {"_to_prediction_df", "_to_regression_prediction_df", "_to_survival_prediction_df"}, glb)
+    g = torch.Generator().manual_seed(5)
+    out: dict = {}
+    cats = ["mut", "wt", "other"]
+    preds = {f"p{i}": torch.softmax(torch.randn(3, generator=g), 0) for i in range(6)}
+    gts = {"p0": "wt", "p1": "mut", "p2": None, "p3": "other", "p4": "wt", "p5": "mut"}
+    df = glb["_to_prediction_df"](categories=cats, patient_to_ground_truth=gts, predictions=preds, patient_label="PATIENT", ground_truth_label="KRAS")
+    out["single"] = {"categories": cats, "gts": gts, "preds": {k: v.tolist() for k, v in preds.items()}, "csv": df.to_csv(index=False)}
+    mcats = {"KRAS": ["mut", "wt"], "MSI status": ["MSI", "MSS", "unknown"]}
+    mpreds = {f"q{i}": {"KRAS": torch.softmax(torch.randn(2, generator=g), 0), "MSI status": torch.softmax(torch.randn(3, generator=g), 0)} for i in range(5)}
+    mgts = {"q0": {"KRAS": "wt", "MSI status": "MSS"}, "q1": {"KRAS": None, "MSI status": "MSI"}, "q2": {"KRAS": None, "MSI status": None}, "q3": {"KRAS": "mut", "MSI status": "unknown"}}
+    dfm = glb["_to_prediction_df"](categories=mcats, patient_to_ground_truth=mgts, predictions=mpreds, patient_label="PATIENT", ground_truth_label=["KRAS", "MSI status"])
+    out["multi"] = {"categories": mcats, "gts": mgts, "preds": {k: {t: v.tolist() for t, v in d.items()} for k, d in mpreds.items()}, "csv": dfm.to_csv(index=False)}
+    dfi = glb["_to_prediction_df"](categories=[], patient_to_ground_truth=mgts, predictions=mpreds, patient_label="PATIENT", ground_truth_label=None)     # categories inferred
+    out["multi_inferred_csv"] = dfi.to_csv(index=False)
+    rpreds = {"a": torch.tensor([2.5]), "b": torch.tensor([1.0]), "c": torch.tensor([0.5]), "d": torch.tensor([-1.25])}
+    rgts = {"a": 2.0, "b": None, "c": "nan", "d": 0.75}
+    out["regression"] = {"gts": rgts, "preds": {k: v.tolist() for k, v in rpreds.items()},
+                         "csv": glb["_to_regression_prediction_df"](patient_to_ground_truth=rgts, predictions=rpreds, patient_label="P", ground_truth_label="age").to_csv(index=False)}
+    spreds = {"a": torch.tensor(0.3), "b": torch.tensor([1.5]), "c": torch.tensor([-0.2])}
+    sgts = {"a": [302.0, 1], "b": "302 dead", "c": [55.5, 0]}
+    out["survival"] = {"gts": sgts, "preds": {k: v.flatten().tolist() for k, v in spreds.items()},
+                       "csv": glb["_to_survival_prediction_df"](patient_to_ground_truth={k: (tuple(v) if isinstance(v, list) else v) for k, v in sgts.items()}, predictions=spreds,
+                                                                patient_label="P", cut_off=0.7).to_csv(index=False)}
+    OUT.mkdir(parents=True, exist_ok=True)
+    (OUT / "deploy_tables.json").write_text(json.dumps(out, indent=1))
+    print("wrote deploy_tables.json")
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -739,6 +781,7 @@ def main() -> None:
     golden_keep_head()
     golden_plip()
     golden_dinov2_hf()
+    golden_deploy_tables()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
