@@ -36,6 +36,7 @@ try:                                    # the reference's own dependency, when p
 except Exception:                       # noqa: BLE001
     _h5py = None
 
+STAMP_FORMAT = "2.5.0"          # the STAMP release whose file format this package reads and writes (pyproject.toml:3); = encoder.STAMP_FORMAT_VERSION
 _HID = C.c_int64
 _LIB = None
 
@@ -358,7 +359,7 @@ class CoordsInfo:
 
 
 def _stride(coords: np.ndarray) -> float:
-    """reference `get_stride` (data.py:865-874): the smallest non-zero step between sorted unique coordinates along any axis."""
+    """reference `get_stride` (data.py:1150-1161): the smallest step between sorted unique coordinates along either axis."""
     best = np.inf
     for ax in range(coords.shape[1]):
         u = np.unique(coords[:, ax].astype(np.float32))
@@ -368,7 +369,7 @@ def _stride(coords: np.ndarray) -> float:
 
 
 def get_coords(datasets: dict[str, np.ndarray], attrs: dict) -> CoordsInfo:
-    """The reference's `get_coords` (data.py:741-808) on an opened file's contents."""
+    """The reference's `get_coords` (data.py:741-808) on an opened file's contents; pinned by tests/golden/get_coords.json (the reference's own function)."""
     if "coords" not in datasets:                               # multiplex bypass (:743-757)
         n = datasets["patch_embeddings"].shape[0]
         return CoordsInfo(np.stack([np.arange(n), np.zeros(n)], axis=1).astype(np.float32), 0.0, 0)
@@ -380,6 +381,10 @@ def get_coords(datasets: dict[str, np.ndarray], attrs: dict) -> CoordsInfo:
         tile_um, coords_um = float(attrs["tile_size_um"]), coords
     elif round(attrs.get("tile_size", _stride(coords))) == 224:   # historic format: coordinates in units of 256 um / 224 px
         tile_um, tile_px, coords_um = 256.0, 224, coords / 224 * 256
+    if attrs.get("stamp_version"):                             # a file from a newer STAMP than the format this package speaks is refused (:793-799)
+        from packaging.version import Version
+        if Version(str(attrs["stamp_version"])) > Version(STAMP_FORMAT):
+            raise RuntimeError(f"features were extracted with a newer version of stamp, please update your stamp to at least version {Version(str(attrs['stamp_version']))}.")
     if not tile_px and "tile_size_px" in attrs:
         tile_px = int(attrs["tile_size_px"])
     if not tile_um or coords_um is None:

@@ -238,3 +238,23 @@ def test_public_api_on_the_pure_python_backend(tmp_path, monkeypatch):
     monkeypatch.setenv("AMDSTAMP_H5_BACKEND", "nope")
     with pytest.raises(RuntimeError, match="not available"):
         h5io.backend()
+
+
+def test_get_coords_equals_the_references_own_function():
+    """`h5io.get_coords` against results of the reference's own `get_coords` (modeling/data.py:741-808, executed by name over stand-in file objects;
+    tests/golden/get_coords.json): STAMP v2, the current format, the historic 224-stride format by attribute and by stride, the coords-less bypass,
+    a file from a newer STAMP (refused) and an un-inferable one (refused)."""
+    import json
+
+    z = json.loads((Path(__file__).parent / "golden" / "get_coords.json").read_text())
+    assert set(z) == {"v2", "current", "historic_attr", "historic_stride", "no_coords", "newer", "unknown"}
+    for name, rec in z.items():
+        ds = {k: np.asarray(v, dtype=np.float32) for k, v in rec["datasets"].items()}
+        if "error" in rec:
+            with pytest.raises(RuntimeError) as ei:
+                h5io.get_coords(ds, rec["attrs"])
+            assert str(ei.value) == rec["message"], name
+            continue
+        ci = h5io.get_coords(ds, rec["attrs"])
+        assert np.array_equal(np.asarray(ci.coords_um, dtype=np.float32), np.asarray(rec["coords_um"], dtype=np.float32)), name
+        assert float(ci.tile_size_um) == rec["tile_size_um"] and ci.tile_size_px == rec["tile_size_px"], name

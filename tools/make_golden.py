@@ -385,6 +385,63 @@ def golden_deploy_tables() -> None:
     print("wrote deploy_tables.json")
 
 
+def golden_get_coords() -> None:
+    """The reference's own feature-file coordinate loader `get_coords` / `get_stride` / `CoordsInfo` (src/stamp/modeling/data.py:726-808, 1150-1161; the module
+    imports h5py: a stand-in with just `Dataset` / `File`-like objects is handed to the functions), on the formats it distinguishes: STAMP v2, the current
+    one, the historic 224-stride one (by attribute and by stride), the coords-less bypass, a file from a newer STAMP, an un-inferable file."""
+    import json
+    import logging
+    from dataclasses import dataclass
+    from typing import cast
+
+    from packaging.version import Version
+
+    class Dataset:                                                   # h5py.Dataset stand-in
+        def __init__(self, arr):
+            self.arr = np.asarray(arr)
+            self.shape = self.arr.shape
+
+        def __getitem__(self, k):
+            return self.arr[k]
+
+    class FileStub(dict):
+        filename = "stub.h5"
+
+        def __init__(self, datasets, attrs):
+            super().__init__({k: Dataset(v) for k, v in datasets.items()})
+            self.attrs = dict(attrs)
+
+    h5 = types.SimpleNamespace(Dataset=Dataset, File=FileStub)
+    glb = {"np": np, "torch": torch, "h5py": h5, "dataclass": dataclass, "Version": Version, "stamp": types.SimpleNamespace(__version__="2.5.0"), "cast": cast,
+           "Tensor": torch.Tensor, "Microns": float, "TilePixels": int, "SlideMPP": float, "_logger": logging.getLogger("golden")}
+    tree = ast.parse((REF / "modeling" / "data.py").read_text())
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in {"CoordsInfo", "get_coords", "get_stride"}]
+    assert len(body) == 3
+    for n in body:                                                   # keep @dataclass on CoordsInfo, nothing else is decorated
+        exec(compile(ast.Module(body=[n], type_ignores=[]), "data.py", "exec"), glb)
+    rng = np.random.default_rng(3)
+    grid = np.stack([rng.integers(0, 30, 40), rng.integers(0, 20, 40)], 1).astype(np.float32)
+    cases = {"v2": ({"coords": grid * 256.0}, {"tile_size": 256.0, "unit": "um"}),
+             "current": ({"coords": grid * 112.5}, {"tile_size_um": 112.5, "tile_size_px": 224, "unit": "um", "stamp_version": "2.4.0"}),
+             "historic_attr": ({"coords": grid * 224.0 + 7.0}, {"tile_size": 224}),
+             "historic_stride": ({"coords": grid * 224.0}, {}),
+             "no_coords": ({"patch_embeddings": np.zeros((13, 8), np.float32)}, {}),
+             "newer": ({"coords": grid * 256.0}, {"tile_size_um": 256.0, "stamp_version": "9.1.0"}),
+             "unknown": ({"coords": grid * 300.0}, {})}
+    out = {}
+    for name, (ds, attrs) in cases.items():
+        rec = {"datasets": {k: v.tolist() for k, v in ds.items()}, "attrs": attrs}
+        try:
+            ci = glb["get_coords"](FileStub(ds, attrs))
+            rec.update(coords_um=np.asarray(ci.coords_um).tolist(), tile_size_um=float(ci.tile_size_um), tile_size_px=None if ci.tile_size_px is None else int(ci.tile_size_px))
+        except Exception as e:  # noqa: BLE001
+            rec.update(error=type(e).__name__, message=str(e))
+        out[name] = rec
+    OUT.mkdir(parents=True, exist_ok=True)
+    (OUT / "get_coords.json").write_text(json.dumps(out))
+    print("wrote get_coords.json", {k: v.get("error", "ok") for k, v in out.items()})
+
+
 def golden_mil_vit() -> None:
     vt = load_by_path("stamp.modeling.models.vision_tranformer", REF / "modeling" / "models" / "vision_tranformer.py")
     for tag, use_alibi, kw in (
@@ -782,6 +839,7 @@ def main() -> None:
     golden_plip()
     golden_dinov2_hf()
     golden_deploy_tables()
+    golden_get_coords()
     golden_mil_vit()
     golden_mil_vit_train()
     golden_transmil()
