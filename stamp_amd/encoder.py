@@ -47,7 +47,7 @@ def code_hash(directory: Path | None = None) -> str:
     d = Path(directory) if directory else Path(__file__).resolve().parent
     h = hashlib.sha256()
     for f in sorted(d.glob("*.py")):
-        h.update(hashlib.sha256(f.read_bytes()).hexdigest().encode())
+        h.update(hashlib.sha256(f.read_bytes()).digest())             # the raw 32-byte digests, like the reference (:51-54)
     return h.hexdigest()
 
 _KEYS = {"fc_w": "attention_net.0.weight", "fc_b": "attention_net.0.bias",

@@ -373,3 +373,46 @@ def test_docs_cite_existing_symbols_and_lines():
             if max(nums) > n:
                 bad.append((d.name, m.group(0), n))
     assert not bad, bad
+
+
+def test_code_hash_and_extractor_name_rules_equal_the_references_functions(tmp_path):
+    """`encoder.code_hash` = the reference's `get_processing_code_hash` (utils/cache.py:42-55) and `encoder.resolve_extractor_name` = its
+    `_resolve_extractor_name` (encoding/encoder/__init__.py:232-250): where the reference tree is present (the build container) its own functions are
+    executed by name on the same inputs; elsewhere the recorded answers are used."""
+    import ast
+    import hashlib
+    import re
+    from functools import cache
+
+    from stamp_amd.encoder import code_hash, resolve_extractor_name
+    names = ["chief-ctranspath-0a1b2c3d", "chief-ctranspath", "virchow2", "virchow2-deadbeef", "uni2-12345", "h-optimus-0", "h-optimus-0-abcdef12", " ctranspath-ABCDEF ",
+             "mstar-xyz123", "conch1_5-00000000", "a-b-c-123456"]
+    recorded = ["chief-ctranspath", "chief-ctranspath", "virchow2", "virchow2", "uni2-12345", "h-optimus-0", "h-optimus-0", "ctranspath", "mstar-xyz123", "conch1_5", "a-b-c"]
+    assert [resolve_extractor_name(n) for n in names] == recorded
+    with pytest.raises(ValueError):
+        resolve_extractor_name("")
+    for i, body in enumerate((b"print(1)\n", b"x = 2\n" * 1000, b"")):
+        (tmp_path / f"m{i}.py").write_bytes(body)
+    (tmp_path / "notes.txt").write_text("ignored")
+    h = hashlib.sha256()
+    for i, body in enumerate((b"print(1)\n", b"x = 2\n" * 1000, b"")):
+        h.update(hashlib.sha256(body).digest())
+    assert code_hash(tmp_path) == h.hexdigest()
+    ref = Path("/root/reference/src/stamp")
+    if not ref.is_dir():
+        return
+    if not hasattr(hashlib, "file_digest"):                     # Python 3.10: the 3.11 helper the reference uses
+        def file_digest(f, algo):
+            hh = hashlib.new(algo)
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                hh.update(chunk)
+            return hh
+        hashlib.file_digest = file_digest
+    glb = {"hashlib": hashlib, "Path": Path, "cache": cache, "re": re}
+    for path, wanted in ((ref / "utils" / "cache.py", {"get_processing_code_hash"}), (ref / "encoding" / "encoder" / "__init__.py", {"_resolve_extractor_name"})):
+        tree = ast.parse(path.read_text())
+        body = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in wanted) or
+                (isinstance(n, ast.Assign) and any(getattr(t, "id", "") == "_HASH_RE" for t in n.targets))]
+        exec(compile(ast.Module(body=body, type_ignores=[]), str(path), "exec"), glb)
+    assert glb["get_processing_code_hash"](tmp_path / "m0.py") == code_hash(tmp_path)
+    assert [glb["_resolve_extractor_name"](n) for n in names] == recorded
