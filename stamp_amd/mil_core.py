@@ -454,9 +454,32 @@ def _grad_buffers(d: VitDims, dev):
     return flat, gc, lg, top, layers
 
 
-def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False, split_k: int = 32):
+def _direct_grad_structs(d: VitDims, grad_views):
+    """When nothing is padded (widths multiples of 256, 64-channel heads in multiples of 4, no ALiBi) the padded gradient layout IS the reference's:
+    amds_mil_vit_grads can point straight at the caller's own gradient tensors (`grad_views(name)`, e.g. views of a trainer's flat buffer) and
+    the per-step copies disappear.  -> (MilVitGrads, keep-alive, {name: tensor}) or None when the shapes (or a pointer's alignment) do not allow it."""
+    if d.alibi or d.D != d.Dp or d.F != d.Fp or d.FF != d.FFp or d.hd != 64 or d.Ha != d.H:
+        return None
+    names = param_names(d)
+    G = {n: grad_views(n) for n in names}
+    if any((not t.is_contiguous()) or t.dtype != torch.float32 or t.data_ptr() % 16 for t in G.values()):
+        return None
+    lg = (_lib.MilVitLayerGrads * max(d.L, 1))()
+    for l in range(d.L):
+        p = layer_prefix(l)
+        lg[l] = _lib.MilVitLayerGrads(G[p + "0.norm.weight"].data_ptr(), G[p + "0.norm.bias"].data_ptr(), G[p + "0.mhsa.in_proj_weight"].data_ptr(),
+                                      G[p + "0.mhsa.in_proj_bias"].data_ptr(), G[p + "0.mhsa.out_proj.weight"].data_ptr(), G[p + "0.mhsa.out_proj.bias"].data_ptr(), None,
+                                      G[p + "1.0.weight"].data_ptr(), G[p + "1.0.bias"].data_ptr(), G[p + "1.1.weight"].data_ptr(), G[p + "1.1.bias"].data_ptr(),
+                                      G[p + "1.4.weight"].data_ptr(), G[p + "1.4.bias"].data_ptr())
+    gc = _lib.MilVitGrads(G["class_token"].data_ptr(), G["project_features.0.weight"].data_ptr(), G["project_features.0.bias"].data_ptr(), lg,
+                          G["transformer.norm.weight"].data_ptr(), G["transformer.norm.bias"].data_ptr(), G["mlp_head.0.weight"].data_ptr(), G["mlp_head.0.bias"].data_ptr())
+    return gc, lg, G
+
+
+def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, need_bags: bool = False, split_k: int = 32, grad_views=None):
     """-> (grads: reference-named, reference-shaped fp32 tensors (empty dict if not need_params), dbags fp32 [Bb,T,F] or None).
-    ONE library call (amds_mil_vit_train_backward); the host slices the reference shapes out of the padded gradient buffers."""
+    ONE library call (amds_mil_vit_train_backward); the host slices the reference shapes out of the padded gradient buffers -- or, with
+    `grad_views` (name -> the caller's own gradient tensor) and an unpadded geometry, the library writes into those tensors directly."""
     d = pk.dims
     dev = dlogits.device
     Bb, Tn, Fd = saved["shape"]
@@ -469,8 +492,12 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
     if need == 0:
         _lib.check(-1, "mil_vit_train_workspace_bytes")
     ws = ops.scratch("mil_vit_train", dev, need)
-    gc = top = layers = None
-    if need_params:
+    gc = top = layers = direct = None
+    if need_params and grad_views is not None:
+        direct = _direct_grad_structs(d, grad_views)
+    if direct is not None:
+        gc = direct[0]
+    elif need_params:
         _flat, gc, _lg, top, layers = _grad_buffers(d, dev)
     dbp = torch.empty(Bb * Tn, d.Fp, dtype=torch.float32, device=dev) if need_bags else None
     arena = saved["arena"]
@@ -481,6 +508,8 @@ def backward(pk: PackedVit, saved: dict, dlogits: torch.Tensor, *, need_params: 
     G: dict[str, torch.Tensor] = {}
     if not need_params:
         return G, dbags
+    if direct is not None:
+        return direct[2], dbags
     D = d.D
     G["mlp_head.0.weight"], G["mlp_head.0.bias"] = top["head_w"], top["head_b"]
     G["transformer.norm.weight"], G["transformer.norm.bias"] = top["norm_w"], top["norm_b"]

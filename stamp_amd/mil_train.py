@@ -179,9 +179,10 @@ class HipMilVitTrainer:
             dlogits = torch.autograd.grad(loss, lg, allow_unused=True)[0] if loss.requires_grad else None
         if dlogits is None:      # e.g. a Cox batch without events (cox.py:219-224 returns a constant 0): nothing to learn from, no step
             return loss.detach(), logits
-        G, _ = mil_core.backward(self.pk, saved, dlogits, need_params=True, need_bags=False, split_k=self.split_k)
-        for k, gk in G.items():
-            self.g(k).copy_(gk)
+        G, _ = mil_core.backward(self.pk, saved, dlogits, need_params=True, need_bags=False, split_k=self.split_k, grad_views=self.g)
+        for k, gk in G.items():          # (unpadded geometries: the library wrote into the flat buffer's views themselves -- nothing to copy)
+            if gk.data_ptr() != self.g(k).data_ptr():
+                self.g(k).copy_(gk)
         # ---- AdamW + OneCycleLR ---------------------------------------------------------------------------------------------------
         if dist_on:
             average_gradients(self.G)
