@@ -7,9 +7,10 @@ Restates what the reference does AROUND `model(bags, coords=..., mask=...)`:
     column names, row order and the per-patient `loss` as the reference computes it -- including that the classification loss is
     `cross_entropy` applied to the PROBABILITIES (the softmax output is fed to a function that applies log-softmax again, :577-583).
 
-Parity: unpinned by fixtures (the reference module cannot be imported here: it needs `lightning` and `h5py`); the tests check these
-functions against the formulas above evaluated directly.  The model is any of `stamp_amd.mil`'s heads (or any module with the
-reference's forward signature); with `torch.no_grad()` + `.eval()` they take the forward-only HIP path.
+Parity: pinned.  The reference module cannot be imported here (it needs `lightning` and `h5py`), so `tools/make_golden.py::golden_deploy_tables`
+executes its three table functions by name out of the file and commits their output for fixed inputs (`tests/golden/deploy_tables.json`;
+`tests/test_cpu_deploy.py` compares cell by cell).  The model is any of `stamp_amd.mil`'s heads (or any module with the reference's forward
+signature); with `torch.no_grad()` + `.eval()` they take the forward-only HIP path.
 """
 from __future__ import annotations
 
