@@ -647,6 +647,8 @@ def main() -> None:
                 break
             except Exception:
                 traffic = None
+    tail_on = (not is_swin) and getattr(model, "cls_tail", False) and os.environ.get("AMDS_VIT_CLS_TAIL", "1") != "0"
+    flops_exec = cfg.matmul_flops_per_tile() - (cfg.matmul_flops_skipped_by_cls_tail() if tail_on else 0.0)
     alg_bytes = None
     if not is_swin:
         # algorithmic HBM bytes per GEMM launch, averaged over the four launches of a block (operands once, fp32 residual rows read +
@@ -671,7 +673,11 @@ def main() -> None:
                    "operands": a.act, "accumulate": "f32", "residual_stream": "f32",
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
-                   "whole_path_mfma_frac": round(value / ctx.world * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                   # the last block's class-row tail (include/amdstamp.h amds_vit_weights.cls_tail): rows of the last block that nothing reads are not
+                   # computed, so the whole-path fraction is priced on the products actually EXECUTED, not on the network's nominal count
+                   "cls_tail": bool(tail_on),
+                   "gflop_per_tile_executed": round(flops_exec / 1e9, 3),
+                   "whole_path_mfma_frac": round(value / ctx.world * flops_exec / 1e12 / MFMA_PEAK_TFLOPS, 4)},
         "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles where N is not a multiple of 256, gemm_4w16_kernel in stage 4 and the stage-3 MLP)" if is_swin else
                                ("gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues"
                                 + ("; LayerNorm folded in: proj / fc2 also emit a 16-bit row copy + row sums, qkv / fc1 apply the row statistics" if getattr(model, "ln_fold", False) else "") + ")"), "bound": "mfma",
@@ -711,6 +717,25 @@ def main() -> None:
             del mx, fx
         except Exception as e:
             line["exact_mode"] = {"error": repr(e)[:300]}
+    if single and tail_on:
+        # the same workload with the WHOLE last block computed (cls_tail=False): what the class-row tail removes, and that the features agree
+        try:
+            mf = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk, exact=a.exact, fp8=a.fp8, cls_tail=False)
+            mf(tiles)
+            torch.cuda.synchronize()
+            t0f = time.perf_counter()
+            for _ in range(3):
+                ff = mf(tiles)
+            torch.cuda.synchronize()
+            elf = time.perf_counter() - t0f
+            rel = ((ff.float() - out.float()).norm() / ff.float().norm()).item()
+            line["full_last_block"] = {"metric": "tiles/s with every row of the last block computed (cls_tail=False)", "value": round(3 * a.tiles / elf, 1), "unit": "tiles/s",
+                                       "gflop_per_tile_executed": round(cfg.matmul_flops_per_tile() / 1e9, 3),
+                                       "whole_path_mfma_frac": round(3 * a.tiles / elf * cfg.matmul_flops_per_tile() / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                       "default_vs_this": round(value / (3 * a.tiles / elf), 4), "rel_l2_default_vs_this_features": float(f"{rel:.3e}")}
+            del mf, ff
+        except Exception as e:
+            line["full_last_block"] = {"error": repr(e)[:300]}
     if single and not is_swin and a.slide_tiles > 0:
         try:
             line["slide_synthetic"] = slide_leg(model, ctx.device, a.slide_tiles)

@@ -326,6 +326,15 @@ typedef struct {
     const amds_vit_fp8_block* fp8_host;       /* HOST array of `depth` structs, or NULL (off) */
     const float* pre_norm_w;                  /* [dim] LayerNorm applied to the embedded tokens before the first block (HF CLIP `pre_layrnorm`, timm */
     const float* pre_norm_b;                  /* `norm_pre`), or NULL: none (every timm preset).  Not filled by amds_vit_pack: the host sets them. */
+    /* Class-row tail of the LAST block (NULL = off; AMDS_PACK_CLS_TAIL fills it).  What the reference keeps of the trunk's output is the class
+     * row, `model(tiles)[:, 0]` (src/stamp/preprocessing/__init__.py:324-325, extractor/virchow2.py:29-30), and in the last block only the keys /
+     * values of the other tokens reach that row.  When this struct is given and no token tensor is requested (amds_vit_forward, tokens_f32 ==
+     * NULL of amds_vit_forward_tokens), the last block computes the k | v columns of qkv for all tokens and then ONLY the class row's chain
+     * -- query, attention, proj, MLP -- in fp32 with these un-folded weights (the kernels of the exact class-token path), and the final
+     * LayerNorm reads that row: 3.5 % of ViT-L/14's products (5.64 of 162.02 GFLOP per tile) are never computed because nothing reads them.
+     * The stored features are those of the full last block up to the 16-bit path's rounding (this row is carried in fp32 instead).
+     * Requires mlp_kind 0 / 1; ignored when a token tensor is requested. */
+    const amds_vit_exact_block* cls_tail;     /* HOST pointer to ONE struct (device pointers inside): the last block's fp32 rows */
 } amds_vit_weights;
 
 /* ---- weight packing in the library (so that a non-Python host can use the tile encoder through this ABI alone) -------------------------
@@ -357,6 +366,7 @@ typedef struct {
 #define AMDS_PACK_LNFOLD      1   /* LayerNorm folded into qkv / fc1 (amds_gemm_lnfold): W * gamma, b + W beta, row sums */
 #define AMDS_PACK_PATCH_SPLIT 2   /* patch weight as a 16-bit [hi | lo] pair (patch_lo_shift) */
 #define AMDS_PACK_EXACT       4   /* also the fp32 rows of the exact class-token path (amds_vit_exact_block) */
+#define AMDS_PACK_CLS_TAIL    8   /* also the fp32 rows of the LAST block (amds_vit_weights.cls_tail = &out_exact[depth - 1]; out_exact [depth] required) */
 /* Bytes of the packed image for these flags (0 on error: amds_last_error()). */
 size_t amds_vit_pack_bytes(const amds_vit_cfg* cfg_host, const amds_vit_host_weights* src_host, int flags);
 /* Packs into the DEVICE buffer dev_image (>= amds_vit_pack_bytes, 256-byte aligned) and fills the caller's host structs -- out_w, out_blocks

@@ -44,7 +44,7 @@ class VitWeights(C.Structure):
                 ("pos_patch", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("patch_lo_shift", C.c_int),
                 ("exact_host", C.POINTER(VitExactBlock)), ("exact_hidden", C.c_int), ("fp8_host", C.POINTER(VitFp8Block)),
-                ("pre_norm_w", C.c_void_p), ("pre_norm_b", C.c_void_p)]
+                ("pre_norm_w", C.c_void_p), ("pre_norm_b", C.c_void_p), ("cls_tail", C.POINTER(VitExactBlock))]
 
 
 class VitHostBlock(C.Structure):
@@ -58,7 +58,7 @@ class VitHostWeights(C.Structure):
                 ("mean", C.c_double * 3), ("std", C.c_double * 3)]
 
 
-PACK_LNFOLD, PACK_PATCH_SPLIT, PACK_EXACT = 1, 2, 4
+PACK_LNFOLD, PACK_PATCH_SPLIT, PACK_EXACT, PACK_CLS_TAIL = 1, 2, 4, 8
 
 
 class MilVitCfg(C.Structure):

@@ -119,6 +119,16 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                          w->blocks_host[l].ln1_w && w->blocks_host[l].ln1_b && w->blocks_host[l].ln2_w && w->blocks_host[l].ln2_b,
                          "vit: exact block %d: incomplete weights", l);
     }
+    // Class-row tail (amds_vit_weights.cls_tail): with only the class features requested, the last block computes keys / values for all
+    // tokens and then the class row's own chain in fp32 -- nothing else of that block is ever read.  AMDS_VIT_CLS_TAIL=0 runs the full block (A/B).
+    static const bool tail_env = !(getenv("AMDS_VIT_CLS_TAIL") && atoi(getenv("AMDS_VIT_CLS_TAIL")) == 0);
+    const amds_vit_exact_block* tl = (tail_env && tokens_f32 == nullptr && c->mlp_kind != 2) ? (ex ? &ex[c->depth - 1] : w->cls_tail) : nullptr;
+    if (tl) {
+        AMDS_REQUIRE(xh_ > 0 && xh_ <= Hd && xh_ % 4 == 0, "vit: exact_hidden=%d must be a multiple of 4 and <= hidden=%d", xh_, Hd);
+        const amds_vit_block& lb = w->blocks_host[c->depth - 1];
+        AMDS_REQUIRE(tl->q_w && tl->q_b && tl->proj_w && tl->proj_b && tl->fc1_w && tl->fc1_b && tl->fc2_w && tl->fc2_b && lb.ln1_w && lb.ln1_b && lb.ln2_w && lb.ln2_b,
+                     "vit: cls_tail: incomplete weights");
+    }
     // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
     const amds_vit_fp8_block* f8 = w->fp8_host;
     if (f8) {
@@ -203,6 +213,37 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
             const bool last = l + 1 == c->depth;
             const float* ls1 = c->layerscale ? b.ls1 : nullptr;
             const float* ls2 = c->layerscale ? b.ls2 : nullptr;
+            if (last && tl) {
+                // keys | values of all tokens: the k | v rows of the qkv weight (rows D .. 3D; bias, row sums and channel scales alike), written
+                // into the k | v thirds of the packed tensor; the q third keeps the previous block's values and is not read
+                const size_t wkv = (size_t)D * D;
+                if (f8) {
+                    char* a8 = q8 + (size_t)r0 * (Hd > D ? Hd : D);
+                    float* as = q8s + r0;
+                    AMDS_TRY(amds_layernorm_quant_e4m3(xq, D, b.ln1_w, b.ln1_b, c->ln_eps, a8, D, as, nullptr, n, D, s));
+                    AMDS_TRY(amds_gemm_fp8(a8, D, (const char*)f8[l].qkv_w8 + wkv, D, n, 2 * D, D, AMDS_EPI_BIAS, qkvq + (size_t)D * 2, 3 * D, b.qkv_b + D,
+                                           f8[l].qkv_cs + D, as, s));
+                } else if (fold) {
+                    AMDS_TRY(amds_gemm_lnfold(hq, D, (const char*)b.qkv_w + wkv * 2, D, n, 2 * D, D, dt, AMDS_EPI_BIAS, qkvq + (size_t)D * 2, 3 * D, b.qkv_b + D,
+                                              nullptr, nullptr, nullptr, rs, b.qkv_colsum + D, s));
+                } else {
+                    AMDS_TRY(amds_layernorm(xq, D, b.ln1_w, b.ln1_b, hq, D, n, D, c->ln_eps, dt, s));
+                    // the kernel family the full qkv product (N = 3 D) takes, so that k | v carry the same bits as in a full block
+                    AMDS_TRY(amds_gemm_ex((3 * D) % 256 == 0 ? kcfg : -1, hq, D, (const char*)b.qkv_w + wkv * 2, D, n, 2 * D, D, dt, AMDS_EPI_BIAS, qkvq + (size_t)D * 2, 3 * D,
+                                          b.qkv_b + D, nullptr, nullptr, 0, 0, 0, 1.0f, s));
+                }
+                // the class row: xc += proj(attention(Wq LN1(xc); K, V)); xc += fc2(act(fc1(LN2(xc)))) -- fp32, LayerScale inside the rows
+                if (!ex) AMDS_TRY(amds_vit_cls_gather(xq, xcq, q.nt, T, D, s));
+                AMDS_TRY(amds_layernorm(xcq, D, b.ln1_w, b.ln1_b, hcq, D, q.nt, D, c->ln_eps, AMDS_F32, s));
+                AMDS_TRY(lin32(hcq, D, tl->q_w, D, qcq, D, D, tl->q_b, 0));
+                AMDS_TRY(amds_attention_cls_f32(qcq, D, qkvq, ocq, D, q.nt, T, c->heads, hd, dt, s));
+                AMDS_TRY(lin32(ocq, D, tl->proj_w, D, xcq, D, D, tl->proj_b, 1));
+                AMDS_TRY(amds_layernorm(xcq, D, b.ln2_w, b.ln2_b, hcq, D, q.nt, D, c->ln_eps, AMDS_F32, s));
+                AMDS_TRY(lin32(hcq, D, tl->fc1_w, D, ucq, xf1, xf1, tl->fc1_b, 0));
+                AMDS_TRY(amds_mlp_act_f32(ucq, xf1, q.nt, xh_, c->mlp_kind, s));
+                AMDS_TRY(lin32(ucq, xf1, tl->fc2_w, xh_, xcq, D, D, tl->fc2_b, 1));
+                continue;
+            }
             if (f8) {      // every Linear: f16 rows -> per-row e4m3 -> fp8 MFMA GEMM with (row scale x channel scale) in the epilogue
                 char* a8 = q8 + (size_t)r0 * (Hd > D ? Hd : D);
                 float* as = q8s + r0;
@@ -285,7 +326,8 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     }
     if (rc != AMDS_OK) return rc;
     // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32
-    AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));
+    if (tl) AMDS_TRY(amds_layernorm(xc, D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));      // the class stream holds the last block's output
+    else AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));
     if (tokens_f32) AMDS_TRY(amds_layernorm(x, D, w->norm_w, w->norm_b, tokens_f32, D, M, D, c->ln_eps, AMDS_F32, st));
 #undef AMDS_TRY
     return AMDS_OK;

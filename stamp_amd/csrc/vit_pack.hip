@@ -93,7 +93,7 @@ struct Arena {
     }
 };
 
-struct Dims { int D, P, np, kp, Hp, Hr, fc1_rows_real, fc1_rows_pad, n_pos; bool swiglu, fold, split, exact; int lo_shift; };
+struct Dims { int D, P, np, kp, Hp, Hr, fc1_rows_real, fc1_rows_pad, n_pos; bool swiglu, fold, split, exact, tail; int lo_shift; };
 
 int make_dims(const amds_vit_cfg* c, const amds_vit_host_weights* s, int flags, Dims* d) {
     AMDS_REQUIRE(c && s, "amds_vit_pack: null cfg / weights");
@@ -115,6 +115,7 @@ int make_dims(const amds_vit_cfg* c, const amds_vit_host_weights* s, int flags, 
     d->fold = (flags & AMDS_PACK_LNFOLD) != 0;
     d->split = (flags & AMDS_PACK_PATCH_SPLIT) != 0;
     d->exact = (flags & AMDS_PACK_EXACT) != 0;
+    d->tail = (flags & AMDS_PACK_CLS_TAIL) != 0 && c->mlp_kind != 2;      // the class-row tail has no quick-GELU form
     d->lo_shift = d->split ? (c->dtype == AMDS_F16 ? 11 : 8) : 0;
     if (d->fold) AMDS_REQUIRE(d->D % 256 == 0 && d->fc1_rows_pad % 256 == 0, "amds_vit_pack: LayerNorm fold needs dim %% 256 == 0 and fc1 rows %% 256 == 0 (dim=%d, fc1 rows=%d)", d->D, d->fc1_rows_pad);
     AMDS_REQUIRE(!d->swiglu || d->Hp % 32 == 0, "amds_vit_pack: SwiGLU hidden_pad %% 32");
@@ -202,7 +203,8 @@ int walk(const amds_vit_cfg* c, const amds_vit_host_weights* s, const Dims& d, A
     float* nw = A.take<float>(D, ow ? &ow->norm_w : nullptr);
     float* nb = A.take<float>(D, ow ? &ow->norm_b : nullptr);
     if (fill) { copy_f32(nw, s->norm_w, D); copy_f32(nb, s->norm_b, D); }
-    if (ow) { ow->blocks_host = ob; ow->patch_lo_shift = d.lo_shift; ow->exact_host = d.exact ? oe : nullptr; ow->exact_hidden = d.Hr; ow->fp8_host = nullptr; ow->pre_norm_w = nullptr; ow->pre_norm_b = nullptr; }
+    if (ow) { ow->blocks_host = ob; ow->patch_lo_shift = d.lo_shift; ow->exact_host = d.exact ? oe : nullptr; ow->exact_hidden = d.Hr; ow->fp8_host = nullptr; ow->pre_norm_w = nullptr; ow->pre_norm_b = nullptr;
+              ow->cls_tail = d.tail ? &oe[c->depth - 1] : nullptr; }
 
     // ---- row maps
     std::vector<int> id3(3 * D), idD(D), fc1_map(d.fc1_rows_pad);
@@ -239,7 +241,8 @@ int walk(const amds_vit_cfg* c, const amds_vit_host_weights* s, const Dims& d, A
         else { t.qkv_c = t.fc1_c = nullptr; if (b) b->qkv_colsum = b->fc1_colsum = nullptr; }
 #undef TAKE16
 #undef TAKE32
-        if (d.exact) {
+        t.xq_w = nullptr;
+        if (d.exact || (d.tail && l + 1 == c->depth)) {
             amds_vit_exact_block* e = oe ? &oe[l] : nullptr;
             t.xq_w = A.take<float>((size_t)D * D, e ? &e->q_w : nullptr);        t.xq_b = A.take<float>(D, e ? &e->q_b : nullptr);
             t.xp_w = A.take<float>((size_t)D * D, e ? &e->proj_w : nullptr);     t.xp_b = A.take<float>(D, e ? &e->proj_b : nullptr);
@@ -263,7 +266,7 @@ int walk(const amds_vit_cfg* c, const amds_vit_host_weights* s, const Dims& d, A
         pack_linear(a, hb.proj_w, hb.proj_b, D, idD, nullptr, nullptr, t.proj, D, t.proj_b, nullptr);
         pack_linear(a, hb.fc2_w, hb.fc2_b, d.Hr, idD, nullptr, nullptr, t.fc2, d.Hp, t.fc2_b, nullptr);
         if (t.ls1) { copy_f32(t.ls1, hb.ls1, D); copy_f32(t.ls2, hb.ls2, D); }
-        if (d.exact) {
+        if (t.xq_w) {
             copy_f32(t.xq_w, hb.qkv_w, (size_t)D * D); copy_f32(t.xq_b, hb.qkv_b, D);
             copy_f32(t.x1_w, hb.fc1_w, (size_t)d.fc1_rows_real * D); copy_f32(t.x1_b, hb.fc1_b, d.fc1_rows_real);
             for (int n = 0; n < D; ++n) {
@@ -305,7 +308,7 @@ extern "C" int amds_vit_pack_host(const amds_vit_cfg* cfg_host, const amds_vit_h
     int rc = make_dims(cfg_host, src_host, flags, &d);
     if (rc != AMDS_OK) return rc;
     AMDS_REQUIRE(image_host && out_w_host && out_blocks_host, "amds_vit_pack_host: null output");
-    AMDS_REQUIRE(!d.exact || out_exact_host, "amds_vit_pack_host: AMDS_PACK_EXACT needs out_exact");
+    AMDS_REQUIRE(!(d.exact || d.tail) || out_exact_host, "amds_vit_pack_host: AMDS_PACK_EXACT / AMDS_PACK_CLS_TAIL need out_exact [depth]");
     AMDS_REQUIRE(((uintptr_t)image_host & 15) == 0 && ((uintptr_t)target_base & 255) == 0, "amds_vit_pack_host: image must be 16-byte, target 256-byte aligned");
     const size_t need = amds_vit_pack_bytes(cfg_host, src_host, flags);
     if (bytes < need) { set_error("amds_vit_pack: buffer %zu < required %zu bytes", bytes, need); return AMDS_ERR_WORKSPACE; }

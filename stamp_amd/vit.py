@@ -70,6 +70,13 @@ class ViTConfig:
         att = 2 * 2 * T * T * D
         return 2 * np_ * 3 * self.patch ** 2 * D + self.depth * (lin + att)
 
+    def matmul_flops_skipped_by_cls_tail(self) -> float:
+        """Products of the LAST block that the class-row tail (HipViT(cls_tail=True), include/amdstamp.h `amds_vit_weights.cls_tail`) never
+        computes: the q / proj / fc1 / fc2 rows and the attention of the T - 1 tokens nothing reads."""
+        T, D = self.tokens, self.dim
+        fc1_out = self.hidden * (2 if self.mlp == "swiglu" else 1)
+        return 2 * (T - 1) * (D * D + D * D + D * fc1_out + self.hidden * D) + 2 * 2 * T * (T - 1) * D
+
 
 PRESETS: dict[str, ViTConfig] = {
     # DINOv2-style ViT-L/14 (reference: RedDino-large, reddino.py:40-45); the BASELINE.json headline shape
@@ -188,11 +195,16 @@ class HipViT(nn.Module):
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
                  act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None,
-                 patch_split: bool | None = None, exact: bool = False, fp8: bool = False) -> None:
+                 patch_split: bool | None = None, exact: bool = False, fp8: bool = False, cls_tail: bool | None = None) -> None:
         """exact=True (opt-in): the class-token row -- the only row the reference stores, `model(tiles)[:, 0].half()` -- is ALSO carried on
         an exact-fp32 class stream (fp32 MFMA, the original un-folded fp32 weights: include/amdstamp.h `amds_vit_exact_block`,
         csrc/vit_exact.hip) and written over the main path's class rows after every sub-layer.  Costs the fp32 weights in HBM (4 bytes per
-        parameter of q / proj / fc1 / fc2) and ~10 % of the throughput; lowers the stored feature's error ~3x."""
+        parameter of q / proj / fc1 / fc2) and ~10 % of the throughput; lowers the stored feature's error ~3x.
+
+        cls_tail (default on; AMDS_VIT_CLS_TAIL=0 / cls_tail=False off): when only the class features are asked for -- what `extract_` stores,
+        `model(tiles)[:, 0]`, src/stamp/preprocessing/__init__.py:324-325 -- the last block computes keys / values for all tokens and then the
+        class row's own chain only (fp32, the kernels of the exact path; include/amdstamp.h `amds_vit_weights.cls_tail`): the other rows of
+        that block are read by nothing.  Costs the last block's fp32 rows in HBM (ViT-L/14: 50 MB); `return_tokens=True` runs the full block."""
         super().__init__()
         if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
             raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
@@ -223,6 +235,9 @@ class HipViT(nn.Module):
         self.patch_lo_shift = (11 if act_dtype == torch.float16 else 8) if patch_split else 0
         self.exact = bool(exact)
         self.fp8 = bool(fp8)
+        if cls_tail is None:
+            cls_tail = os.environ.get("AMDS_VIT_CLS_TAIL", "1") != "0"
+        self.cls_tail = bool(cls_tail) and cfg.mlp != "quick_gelu"
         if cfg.mlp == "quick_gelu":          # CLIP's MLP: fc1 (plain bias epilogue) -> activation pass -> fc2; plain packing only
             if exact or fp8 or ln_fold:
                 raise ValueError("a quick_gelu (CLIP) trunk runs on the plain packing only: no ln_fold, exact or fp8")
@@ -242,7 +257,8 @@ class HipViT(nn.Module):
         c = self.cfg
         validate_state_dict(c, sd)
         hw, keep = host_weights(c, sd)
-        flags = (_lib.PACK_LNFOLD if self.ln_fold else 0) | (_lib.PACK_PATCH_SPLIT if self.patch_lo_shift else 0) | (_lib.PACK_EXACT if self.exact else 0)
+        flags = (_lib.PACK_LNFOLD if self.ln_fold else 0) | (_lib.PACK_PATCH_SPLIT if self.patch_lo_shift else 0) | (_lib.PACK_EXACT if self.exact else 0) \
+            | (_lib.PACK_CLS_TAIL if self.cls_tail else 0)
         self._cfg_c = _lib.VitCfg(c.img, c.patch, c.dim, c.depth, c.heads, c.hidden_pad, c.n_prefix, {"gelu": 0, "swiglu": 1, "quick_gelu": 2}[c.mlp],
                                   1 if c.layerscale else 0, ops.act_code(self.act_dtype), c.ln_eps)
         lib = _lib.lib()
@@ -252,7 +268,7 @@ class HipViT(nn.Module):
         self._image = torch.empty(need, dtype=torch.uint8, device=self.device_)
         self._w_c = _lib.VitWeights()
         self._blocks = (_lib.VitBlock * c.depth)()
-        self._exact = (_lib.VitExactBlock * c.depth)() if self.exact else None
+        self._exact = (_lib.VitExactBlock * c.depth)() if (self.exact or self.cls_tail) else None
         with torch.cuda.device(self.device_):
             rc = lib.amds_vit_pack(C.byref(self._cfg_c), C.byref(hw), flags, self._image.data_ptr(), need, C.byref(self._w_c), self._blocks,
                                    self._exact, torch.cuda.current_stream().cuda_stream)

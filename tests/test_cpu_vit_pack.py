@@ -47,7 +47,7 @@ def _pack(cfg, sd, flags, dt=torch.float16):
 CFG_FOLD = ViTConfig(dim=256, depth=2, heads=4, hidden=488, mlp="swiglu", reg_tokens=4, no_embed_class=True)       # Hp = 512, fc1 rows 1024
 
 
-@pytest.mark.parametrize("name,flags", [("test_tiny", 0), ("test_tiny", 2), ("test_tiny_swiglu", 2), ("test_tiny_hd80", 2 | 4), ("fold", 1 | 2), ("fold", 1 | 2 | 4),
+@pytest.mark.parametrize("name,flags", [("test_tiny", 0), ("test_tiny", 2), ("test_tiny_swiglu", 2), ("test_tiny_hd80", 2 | 4), ("fold", 1 | 2), ("fold", 1 | 2 | 4), ("fold", 1 | 2 | 8), ("test_tiny_swiglu", 2 | 4 | 8),
                                         ("fold_bf16", 1 | 2)])
 def test_packed_image_matches_the_torch_restatement(name, flags):
     dt = torch.bfloat16 if name.endswith("bf16") else torch.float16
@@ -56,7 +56,7 @@ def test_packed_image_matches_the_torch_restatement(name, flags):
     w, blocks, exact, keep, _ = _pack(cfg, sd, flags, dt)
     rd = _f16 if dt == torch.float16 else _bf16
     D, P, np_, kp, Hp, H = cfg.dim, cfg.n_prefix, cfg.n_patches, cfg.kp, cfg.hidden_pad, cfg.hidden
-    fold, split, ex = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+    fold, split, ex, tail = bool(flags & 1), bool(flags & 2), bool(flags & 4), bool(flags & 8)
     # ---- patch embedding
     mean, std = torch.tensor(cfg.mean, dtype=torch.float64), torch.tensor(cfg.std, dtype=torch.float64)
     pw = sd["patch_embed.proj.weight"].double()
@@ -123,7 +123,7 @@ def test_packed_image_matches_the_torch_restatement(name, flags):
         assert torch.equal(w2[:, :H], g("mlp.fc2.weight").float().to(dt)) and not w2[:, H:].any() and torch.equal(_f32(b.fc2_b, D), g("mlp.fc2.bias").float())
         if cfg.layerscale:
             assert torch.equal(_f32(b.ls1, D), g("ls1.gamma").float()) and torch.equal(_f32(b.ls2, D), g("ls2.gamma").float())
-        if ex:
+        if ex or (tail and i == cfg.depth - 1):      # AMDS_PACK_CLS_TAIL: the last block's fp32 rows only
             e = exact[i]
             f1 = 2 * H if cfg.mlp == "swiglu" else H
             ls1, ls2 = g("ls1.gamma").float(), g("ls2.gamma").float()
@@ -131,6 +131,11 @@ def test_packed_image_matches_the_torch_restatement(name, flags):
             assert torch.equal(_f32(e.proj_w, D * D).view(D, D), g("attn.proj.weight").float() * ls1[:, None]) and torch.equal(_f32(e.proj_b, D), g("attn.proj.bias").float() * ls1)
             assert torch.equal(_f32(e.fc1_w, f1 * D).view(f1, D), w1) and torch.equal(_f32(e.fc1_b, f1), b1)
             assert torch.equal(_f32(e.fc2_w, D * H).view(D, H), g("mlp.fc2.weight").float() * ls2[:, None]) and torch.equal(_f32(e.fc2_b, D), g("mlp.fc2.bias").float() * ls2)
+    # amds_vit_weights.cls_tail points at the last block's struct (HOST pointer) exactly when the flag is set
+    last = C.addressof(exact[cfg.depth - 1])
+    assert (C.cast(w.cls_tail, C.c_void_p).value == last) if tail else not w.cls_tail
+    if tail and not ex:
+        assert all(not exact[i].q_w for i in range(cfg.depth - 1))
     del keep
 
 
@@ -147,6 +152,7 @@ def test_pack_refuses_what_it_cannot_pack():
     w, blocks = _lib.VitWeights(), (_lib.VitBlock * cfg.depth)()
     assert lib.amds_vit_pack_host(C.byref(cc), C.byref(hw), 0, base, need - 256, None, C.byref(w), blocks, None) == -2     # AMDS_ERR_WORKSPACE
     assert lib.amds_vit_pack_host(C.byref(cc), C.byref(hw), 4, base, need, None, C.byref(w), blocks, None) == -1           # exact without out_exact
+    assert lib.amds_vit_pack_host(C.byref(cc), C.byref(hw), 8, base, need, None, C.byref(w), blocks, None) == -1           # class-row tail without out_exact
     hw.hidden = cfg.hidden + 64
     assert lib.amds_vit_pack_bytes(C.byref(cc), C.byref(hw), 0) == 0
     del keep

@@ -141,6 +141,9 @@ def test_vit_fp8_mode_small_and_full_size(gpu):
     e8, e16 = _rel(f8, ref), _rel(f16, ref)
     print(f"2-block 256-wide ViT: fp8 GEMMs {e8:.3e}, fp16 path {e16:.3e}")
     assert e16 < 1e-3 and 2e-3 < e8 < 5e-2 and torch.isfinite(f8).all()
+    f8_full = HipViT(small, sd, device=gpu, chunk=2, fp8=True, cls_tail=False)(tiles.to(gpu)).float().cpu()      # the whole last block on the fp8 MFMA
+    print(f"  fp8, full last block {_rel(f8_full, ref):.3e}; class-row tail vs full {_rel(f8, f8_full):.3e}")
+    assert _rel(f8, f8_full) < 5e-2 and _rel(f8, ref) < 1.1 * _rel(f8_full, ref)
     m = HipViT(small, sd, device=gpu, chunk=5, fp8=True)
     assert torch.equal(m(tiles.to(gpu)), m(tiles.to(gpu)))                                   # deterministic
     with pytest.raises(ValueError, match="multiples of 256"):

@@ -24,13 +24,15 @@ def test_tiny_vit_matches_oracle(gpu, name, dt):
     tol = 2e-3 if dt == torch.float16 else 2e-2
     assert _rel(t.cpu(), ref_t) < tol, _rel(t.cpu(), ref_t)
     assert f.dtype == torch.float16 and _rel(f.cpu().float(), ref_f.float()) < tol
-    # determinism: same input twice -> bit-identical
+    # the product's default call (class features only: the last block's class-row tail, amds_vit_weights.cls_tail) against the same oracle
     f2 = model(tiles.to(gpu))
-    assert torch.equal(f, f2)
+    assert f2.dtype == torch.float16 and _rel(f2.cpu().float(), ref_f.float()) < tol
+    # determinism: same input twice -> bit-identical
+    assert torch.equal(f2, model(tiles.to(gpu)))
     # float (already-normalised CHW) input takes the same path
     from oracle.vit_tile_encoder import tile_transform
     f3 = model(tile_transform(tiles, cfg.mean, cfg.std).to(gpu))
-    assert torch.equal(f, f3)
+    assert torch.equal(f2, f3)
 
 
 def test_vit_large_matches_oracle(gpu):
@@ -44,8 +46,9 @@ def test_vit_large_matches_oracle(gpu):
     f, t = model(tiles.to(gpu), return_tokens=True)
     r_t, r_f = _rel(t.cpu(), ref_t), _rel(f.cpu().float(), ref_f.float())
     mx = ((f.cpu().float() - ref_f.float()).abs().max() / ref_f.float().abs().max()).item()
-    print(f"ViT-L/14 fp16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e}, max-abs/max {mx:.3e}")
-    assert r_f < 1e-3 and r_t < 1e-3 and mx < 2e-3
+    r_d = _rel(model(tiles.to(gpu)).cpu().float(), ref_f.float())        # the default call: class features only (class-row tail in the last block)
+    print(f"ViT-L/14 fp16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e} (default call, class-row tail: {r_d:.3e}), max-abs/max {mx:.3e}")
+    assert r_f < 1e-3 and r_t < 1e-3 and mx < 2e-3 and r_d < 1e-3
 
 
 @pytest.mark.parametrize("name,tol_cls", [("uni2_h", 1e-3), ("virchow2", 1e-3), ("h_optimus_0", 1e-3), ("vit_large_patch16_224", 1e-3), ("dinobloom_s", 1e-3), ("gigapath", 1e-3)])
@@ -63,8 +66,9 @@ def test_full_size_presets_match_oracle(gpu, name, tol_cls):
     model = HipViT(cfg, sd, device=gpu, act_dtype=torch.float16, chunk=2)
     f, t = model(tiles.to(gpu), return_tokens=True)
     r_t, r_f = _rel(t.cpu(), ref_t), _rel(f.cpu().float(), ref_f.float())
-    print(f"{name} fp16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e}")
-    assert bool(torch.isfinite(f.float()).all()) and r_t < 1e-3 and r_f < tol_cls, (r_f, r_t)
+    r_d = _rel(model(tiles.to(gpu)).cpu().float(), ref_f.float())        # the default call: class features only (class-row tail in the last block)
+    print(f"{name} fp16 operands: rel-L2 tokens {r_t:.3e}, CLS features {r_f:.3e} (default call, class-row tail: {r_d:.3e})")
+    assert bool(torch.isfinite(f.float()).all()) and r_t < 1e-3 and r_f < tol_cls and r_d < tol_cls, (r_f, r_t, r_d)
 
 
 @pytest.mark.parametrize("T,H,hd", [(257, 16, 64), (265, 24, 64), (261, 16, 80), (50, 2, 64), (288, 3, 80)])
@@ -296,6 +300,37 @@ def test_hip_vit_matches_transformers_dinov2_fixture(gpu, tag, kw):
     sel = list(range(10)) + [-2, -1]
     ref = torch.from_numpy(z[f"{tag}_tokens"])
     r_t, r_f = _rel(t[:, sel].cpu(), ref), _rel(f.float().cpu(), ref[:, 0])
-    print(f"dinov2 ({tag}) vs transformers: tokens {r_t:.3e}, CLS feature {r_f:.3e}")
-    assert r_t < 1e-3 and r_f < 1e-3
+    r_d = _rel(model(torch.from_numpy(z["tiles"]).to(gpu)).float().cpu(), ref[:, 0])       # the default call (class-row tail)
+    print(f"dinov2 ({tag}) vs transformers: tokens {r_t:.3e}, CLS feature {r_f:.3e} (default call {r_d:.3e})")
+    assert r_t < 1e-3 and r_f < 1e-3 and r_d < 1e-3
     np.testing.assert_allclose(t.norm(dim=-1).cpu().numpy(), z[f"{tag}_token_norms"], rtol=3e-3)
+
+
+@pytest.mark.parametrize("name", ["test_tiny", "test_tiny_swiglu", "test_tiny_hd80"])
+@pytest.mark.parametrize("fold", [True, False])
+def test_class_row_tail_of_the_last_block(gpu, name, fold):
+    """cls_tail (the default): with only the class features requested -- what the reference stores, `model(tiles)[:, 0]`,
+    src/stamp/preprocessing/__init__.py:324-325 -- the last block computes keys / values and the class row's own chain only
+    (include/amdstamp.h, amds_vit_weights.cls_tail).  Same features as the full block up to the 16-bit path's rounding and no further from the
+    oracle; asking for the token tensor runs the full block (the cls_tail=False bits); chunk / batch invariant and deterministic."""
+    cfg = PRESETS[name]
+    if fold and (cfg.dim % 256 or (cfg.hidden_pad * (2 if cfg.mlp == "swiglu" else 1)) % 256):
+        pytest.skip("shape cannot fold")
+    sd = random_vit_state_dict(cfg, seed=1, init="moderate")
+    tiles = torch.randint(0, 256, (9, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    ref_f = extract_features(tiles, sd, cfg)
+    full = HipViT(cfg, sd, device=gpu, chunk=4, ln_fold=fold, cls_tail=False)
+    tail = HipViT(cfg, sd, device=gpu, chunk=4, ln_fold=fold)
+    assert tail.cls_tail and not full.cls_tail
+    f_full, f_tail = full(tiles.to(gpu)), tail(tiles.to(gpu))
+    e_full, e_tail = _rel(f_full.cpu().float(), ref_f.float()), _rel(f_tail.cpu().float(), ref_f.float())
+    print(f"{name} fold={fold}: CLS rel-L2 vs oracle: full last block {e_full:.3e}, class-row tail {e_tail:.3e}; tail vs full {_rel(f_tail.float(), f_full.float()):.3e}")
+    assert e_tail < 1e-3 and e_tail < 1.1 * e_full + 1e-5
+    assert _rel(f_tail.float(), f_full.float()) < 1e-3
+    f_tok, t_tok = tail(tiles.to(gpu), return_tokens=True)
+    assert torch.equal(f_tok, f_full) and torch.equal(f_tok, t_tok[:, 0].half())        # a token tensor needs the whole block
+    assert torch.equal(f_tail, tail(tiles.to(gpu)))
+    assert torch.equal(f_tail[:3], HipViT(cfg, sd, device=gpu, chunk=9, ln_fold=fold)(tiles[:3].to(gpu)))
+    # with the exact class stream the tail IS that stream's last block: same bits with and without it
+    ex_full = HipViT(cfg, sd, device=gpu, chunk=4, ln_fold=fold, exact=True, cls_tail=False)(tiles.to(gpu))
+    assert torch.equal(HipViT(cfg, sd, device=gpu, chunk=4, ln_fold=fold, exact=True)(tiles.to(gpu)), ex_full)
