@@ -736,6 +736,26 @@ def main() -> None:
             del mf, ff
         except Exception as e:
             line["full_last_block"] = {"error": repr(e)[:300]}
+    if single and not is_swin and getattr(model, "ln_fold", False) and not a.exact and act == torch.float16 and os.environ.get("AMDS_VIT_PLANES", "1") != "0":
+        # the same model with the residual stream as fp32 rows + a 16-bit copy (AMDS_VIT_PLANES=0, read per call) instead of the two fp16 planes
+        try:
+            os.environ["AMDS_VIT_PLANES"] = "0"
+            model(tiles)
+            torch.cuda.synchronize()
+            t0r = time.perf_counter()
+            for _ in range(3):
+                fr = model(tiles)
+            torch.cuda.synchronize()
+            elr = time.perf_counter() - t0r
+            rel = ((fr.float() - out.float()).norm() / fr.float().norm()).item()
+            line["residual_fp32_rows"] = {"metric": "tiles/s with the residual stream as fp32 rows + a 16-bit copy (AMDS_VIT_PLANES=0) instead of two fp16 planes",
+                                          "value": round(3 * a.tiles / elr, 1), "unit": "tiles/s", "default_vs_this": round(value / (3 * a.tiles / elr), 4),
+                                          "rel_l2_default_vs_this_features": float(f"{rel:.3e}")}
+            del fr
+        except Exception as e:
+            line["residual_fp32_rows"] = {"error": repr(e)[:300]}
+        finally:
+            os.environ.pop("AMDS_VIT_PLANES", None)
     if single and not is_swin and a.slide_tiles > 0:
         try:
             line["slide_synthetic"] = slide_leg(model, ctx.device, a.slide_tiles)

@@ -196,6 +196,21 @@ int amds_gemm_fp8_out8(const void* A8, long lda, const void* W8, long ldw, int M
 int amds_gemm_lnfold(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi, void* out,
                      long ldo, const float* bias, const float* scale, void* xh, float* rowpart, const float* rowstat,
                      const float* colsum, void* stream);
+
+/* The RESIDUAL producer of amds_gemm_lnfold with the residual stream held as TWO fp16 planes instead of fp32 rows + a 16-bit copy:
+ *   x = hi + lo;   x += scale[n] * (A W^T + bias[n]);   hi = fp16(x);   lo = fp16(x - hi);   rowpart = partial (sum, sum of squares) of the fp32 x
+ * in place on hi / lo [M][ld] (fp16; ld elements).  hi is exactly the 16-bit copy the consumer GEMMs read as their A operand, so a block's
+ * proj / fc2 launches move 4 + 4 bytes per element instead of 4 + 4 + 2; x keeps ~22 mantissa bits (elements below 2^-13 |x|_row keep the
+ * absolute resolution of fp16 subnormals, 6e-8).  fp16 operands only (a bf16 pair would hold 16 bits).  Tile encoder: the default on the
+ * folded path (vit.hip); replaces the fp32 rows `x += ...` of `Block.forward` in timm's VisionTransformer behind
+ * src/stamp/preprocessing/extractor/uni2.py:32-43, virchow2.py:29-30. */
+int amds_gemm_lnfold_planes(const void* A, long lda, const void* W, long ldw, int M, int N, int K, void* hi, void* lo, long ld,
+                            const float* bias, const float* scale, float* rowpart, void* stream);
+/* x fp32 [M][ldx] -> hi = fp16(x), lo = fp16(x - hi) [M][ld] + (rstd, -mean * rstd) per row: amds_ln_stats_cast for the plane form. */
+int amds_ln_stats_split(const float* x, long ldx, int M, int D, float eps, void* hi, void* lo, long ld, float* rowstat, void* stream);
+/* out[i][:] = hi[i * row_stride][:] + lo[i * row_stride][:] in fp32, i < rows (row_stride 1: every row; T: the class rows of [B*T] tokens). */
+int amds_planes_to_f32(const void* hi, const void* lo, long ld, long row_stride, float* out, long ldo, long rows, int D, void* stream);
+
 /* rowpart [M][NP][2] (NP = N/128 of the producer) -> rowstat [M][2] = (rstd, -mean * rstd) with biased variance over D columns */
 int amds_ln_rowstat(const float* rowpart, int M, int NP, int D, float eps, float* rowstat, void* stream);
 /* Same, also counting into diag (device int[2], caller-zeroed, may be NULL): [0] rows whose sum of squares reaches the act dtype's

@@ -322,6 +322,25 @@ extern "C" int amds_gemm_lnfold(const void* A, long lda, const void* W, long ldw
     return AMDS_ERR_INVALID;
 }
 
+// The RESIDUAL producer with the residual stream held as two fp16 planes (include/amdstamp.h): x = hi + lo;  x += scale * (A W^T + bias);
+// hi = fp16(x), lo = fp16(x - hi), rowpart = partial (sum, sum of squares) of the fp32 x.  In place; no fp32 rows exist.
+extern "C" int amds_gemm_lnfold_planes(const void* A, long lda, const void* W, long ldw, int M, int N, int K, void* hi, void* lo, long ld,
+                                       const float* bias, const float* scale, float* rowpart, void* stream) {
+    AMDS_REQUIRE(A && W && hi && lo && rowpart, "amds_gemm_lnfold_planes: null pointer");
+    AMDS_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 256 == 0, "amds_gemm_lnfold_planes: needs K %% 64 == 0 and N %% 256 == 0 (M=%d N=%d K=%d)", M, N, K);
+    AMDS_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ld % 4 == 0 && ld >= N, "amds_gemm_lnfold_planes: bad pitches");
+    AMDS_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0,
+                 "amds_gemm_lnfold_planes: pointers must be 16-byte aligned");
+    AMDS_REQUIRE(hi != lo && A != hi && A != lo, "amds_gemm_lnfold_planes: the planes are updated in place and must not alias each other or A");
+    if (M == 0) return AMDS_OK;
+    EpiArgs ep;
+    ep.out = hi; ep.ldo = ld; ep.bias = bias; ep.scale = scale; ep.pos = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.0f;
+    ep.xh = hi; ep.xl = lo; ep.rowpart = rowpart;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, 2.0 * M * (double)N * K, st);
+    return gemm_dispatch<f16>(12, AMDS_EPI_RESIDUAL, A, lda, W, ldw, M, N, K, ep, st);
+}
+
 // tuning hook: explicit kernel id (see gemm_kernel.h)
 extern "C" int amds_gemm_ex(int cfg, const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype,
                             int epi, void* out, long ldo, const float* bias, const float* scale, const float* pos,

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) ln_rowstat_kernel(const float* __restrict
 // the first LayerNorm of a stack (its input does not come out of a RESIDUAL GEMM): x fp32 -> 16-bit copy + (rstd, -mean * rstd)
 template <typename TO, int MAXV>
 __global__ void __launch_bounds__(256) ln_stats_cast_kernel(const float* __restrict__ x, long xs, TO* __restrict__ y, long ys, int rows,
-                                                            int cols, float eps, float* __restrict__ rowstat) {
+                                                            int cols, float eps, float* __restrict__ rowstat, TO* __restrict__ ylo = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -202,12 +202,32 @@ __global__ void __launch_bounds__(256) ln_stats_cast_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = (TO)v[e];
             *reinterpret_cast<vec4*>(yr + c * 4) = w;
+            if (ylo != nullptr) {           // second plane of the (hi | lo) residual stream: what the 16-bit rounding of x left over
+                vec4 wl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wl[e] = (TO)(v[e] - (float)w[e]);
+                *reinterpret_cast<vec4*>(ylo + (long)row * ys + c * 4) = wl;
+            }
         }
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     const float mean = s1 / (float)cols, var = fmaxf(s2 / (float)cols - mean * mean, 0.f), rstd = rsqrtf(var + eps);
     if (lane == 0) reinterpret_cast<f32x2*>(rowstat)[row] = f32x2{rstd, -mean * rstd};
+}
+
+// (hi | lo) planes -> fp32 rows: out[i][:] = hi[i * rstride][:] + lo[i * rstride][:]   (rstride = 1: every row; = T: the class rows)
+__global__ void planes_to_f32_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo, long ld, long rstride, float* __restrict__ out, long ldo,
+                                     long rows, int cols) {
+    const int nv = cols >> 2;
+    const long total = rows * nv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / nv;
+        const int c = (int)(i - r * nv) * 4;
+        const long src = r * rstride * ld + c;
+        const f16x4 h = *reinterpret_cast<const f16x4*>(hi + src), l = *reinterpret_cast<const f16x4*>(lo + src);
+        *reinterpret_cast<f32x4*>(out + r * ldo + c) = __builtin_convertvector(h, f32x4) + __builtin_convertvector(l, f32x4);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -490,6 +510,29 @@ extern "C" int amds_ln_stats_cast(const float* x, long ldx, int M, int D, float 
         else hipLaunchKernelGGL((ln_stats_cast_kernel<bf16, 8>), dim3(grid), dim3(256), 0, st, x, ldx, (bf16*)xh, ldxh, M, D, eps, rowstat);
     }
     AMDS_LAUNCH_CHECK("ln_stats_cast_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_ln_stats_split(const float* x, long ldx, int M, int D, float eps, void* hi, void* lo, long ld, float* rowstat, void* stream) {
+    AMDS_REQUIRE(x && hi && lo && rowstat && M >= 0, "amds_ln_stats_split: bad arguments");
+    AMDS_REQUIRE(D > 0 && D % 4 == 0 && D <= 64 * 4 * 8 && ldx % 4 == 0 && ld % 4 == 0, "amds_ln_stats_split: D=%d must be a multiple of 4, at most 2048", D);
+    if (M == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_LN, (double)M * D * 8.0, st);
+    const int grid = cdiv(M, 4);
+    if (D <= 1024) hipLaunchKernelGGL((ln_stats_cast_kernel<f16, 4>), dim3(grid), dim3(256), 0, st, x, ldx, (f16*)hi, ld, M, D, eps, rowstat, (f16*)lo);
+    else hipLaunchKernelGGL((ln_stats_cast_kernel<f16, 8>), dim3(grid), dim3(256), 0, st, x, ldx, (f16*)hi, ld, M, D, eps, rowstat, (f16*)lo);
+    AMDS_LAUNCH_CHECK("ln_stats_cast_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_planes_to_f32(const void* hi, const void* lo, long ld, long row_stride, float* out, long ldo, long rows, int D, void* stream) {
+    AMDS_REQUIRE(hi && lo && out && rows >= 0 && D > 0 && D % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && row_stride > 0, "amds_planes_to_f32: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const long total = rows * (D >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)hi, (const f16*)lo, ld, row_stride, out, ldo, rows, D);
+    AMDS_LAUNCH_CHECK("planes_to_f32_kernel");
     return AMDS_OK;
 }
 

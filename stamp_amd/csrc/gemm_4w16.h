@@ -386,9 +386,29 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
             const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(
                 ep.xh ? reinterpret_cast<T*>(ep.xh) + (long)m0 * ep.ldo + n0 : reinterpret_cast<T*>(ep.out), 0,
                 ep.xh ? (int)((((long)rows_o - 1) * ep.ldo + BN) * 2) : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrc_l = __builtin_amdgcn_make_buffer_rsrc(
+                ep.xl ? reinterpret_cast<T*>(ep.xl) + (long)m0 * ep.ldo + n0 : reinterpret_cast<T*>(ep.out), 0,
+                ep.xl ? (int)((((long)rows_o - 1) * ep.ldo + BN) * 2) : 0, 0x00020000);
             const int np_part = N / 128;
-            auto run = [&](auto has_scale_c, auto lnp_c) {
-                constexpr bool HS = decltype(has_scale_c)::value, LNP = decltype(lnp_c)::value;
+            auto run = [&](auto has_scale_c, auto lnp_c, auto pl_c) {
+                constexpr bool HS = decltype(has_scale_c)::value, LNP = decltype(lnp_c)::value, PL = decltype(pl_c)::value;
+                // PL: the residual rows live in two 16-bit planes (hi = the next GEMM's A operand, lo = x - hi): the old value of a lane's 4
+                // columns is 8 + 8 bytes instead of 16, and nothing but the planes is written back (10 -> 8 bytes per element moved)
+                auto load_prev = [&](int pass, int b8) {
+                    if constexpr (PL) {
+                        int rowoff = b8 * 16 * ldo4 + pass * 256;
+                        asm volatile("" : "+s"(rowoff));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int o = (offu[b8 & 1][u] + rowoff) >> 1;
+                            const u32x2 ph = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_h, o, 0, 0));
+                            const u32x2 pl = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_l, o, 0, 0));
+                            old[b8][u] = __builtin_bit_cast(f32x4, u32x4{ph[0], ph[1], pl[0], pl[1]});
+                        }
+                    } else {
+                        load_old(pass, b8);
+                    }
+                };
                 f32x4 sc[4];
                 auto load_scale = [&](int pass) {
                     if constexpr (HS) {
@@ -399,7 +419,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                 };
                 load_scale(0);
 #pragma unroll
-                for (int b8 = 0; b8 < 4; ++b8) load_old(0, b8);
+                for (int b8 = 0; b8 < 4; ++b8) load_prev(0, b8);
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -431,8 +451,15 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                         asm volatile("" : "+s"(rowoff));
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            v[u] += old[b8][u];
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rsrc_o, offu[b8 & 1][u] + rowoff, 0, 0);
+                            if constexpr (PL) {
+                                const u32x4 o = __builtin_bit_cast(u32x4, old[b8][u]);
+                                const f32x4 ph = __builtin_convertvector(__builtin_bit_cast(vec4, u32x2{o[0], o[1]}), f32x4);
+                                const f32x4 pl = __builtin_convertvector(__builtin_bit_cast(vec4, u32x2{o[2], o[3]}), f32x4);
+                                v[u] += ph + pl;
+                            } else {
+                                v[u] += old[b8][u];
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rsrc_o, offu[b8 & 1][u] + rowoff, 0, 0);
+                            }
                         }
                         if constexpr (LNP) {
                             // 16-bit copy of the updated rows + this pass's partial row sums (the LayerNorm that follows is folded into
@@ -442,6 +469,10 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                             for (int u = 0; u < 8; ++u) {
                                 const vec4 c = Act<T>::from_f32x4(v[u]);
                                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c), rsrc_h, (offu[b8 & 1][u] + rowoff) >> 1, 0, 0);
+                                if constexpr (PL) {
+                                    const vec4 cl = Act<T>::from_f32x4(v[u] - __builtin_convertvector(c, f32x4));
+                                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cl), rsrc_l, (offu[b8 & 1][u] + rowoff) >> 1, 0, 0);
+                                }
                                 ss[u] = f32x2{(v[u][0] + v[u][1]) + (v[u][2] + v[u][3]),
                                               fmaf(v[u][0], v[u][0], v[u][1] * v[u][1]) + fmaf(v[u][2], v[u][2], v[u][3] * v[u][3])};
                             }
@@ -451,7 +482,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                             if ((l31 & 3) == 0 && prow < M)
                                 *reinterpret_cast<f32x2*>(ep.rowpart + ((long)prow * np_part + tn * 2 + pass) * 2) = tot;
                         }
-                        if (pass == 0) load_old(1, b8);
+                        if (pass == 0) load_prev(1, b8);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (pass == 0) {
@@ -462,10 +493,12 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                     }
                 }
             };
-            if (ep.xh) {
-                if (ep.scale) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{});
+            if (ep.xl) {
+                if (ep.scale) run(std::true_type{}, std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}, std::true_type{});
+            } else if (ep.xh) {
+                if (ep.scale) run(std::true_type{}, std::true_type{}, std::false_type{}); else run(std::false_type{}, std::true_type{}, std::false_type{});
             } else {
-                if (ep.scale) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{});
+                if (ep.scale) run(std::true_type{}, std::false_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}, std::false_type{});
             }
             return;
         }

@@ -41,6 +41,9 @@ struct EpiArgs {
     //   consumer (BIAS / BIAS_GELU / SWIGLU): rowstat = [M][2] (rstd, -mean*rstd), colsum = [N] sum_k W'[n][k]:
     //       out = act( acc * rstd[m] + (colsum[n] * (-mean*rstd)[m] + bias[n]) )
     void* xh = nullptr;
+    // residual stream as a 16-bit (hi | lo) pair of planes (amds_gemm_lnfold_planes): x = xh + xl is read, updated and written back as
+    // xh = round16(x), xl = round16(x - xh); no fp32 rows are touched (out is not read or written)
+    void* xl = nullptr;
     float* rowpart = nullptr;
     const float* rowstat = nullptr;
     const float* colsum = nullptr;

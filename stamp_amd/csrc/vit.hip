@@ -21,7 +21,7 @@ int prefix_init(const float* prefix, float* x, int B, int T, int P, int dim, hip
 
 struct VitPlan {
     int np, T, kp, dim, hidden;
-    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, off_q8, off_q8s, off_q8n, off_q8u, total;
+    size_t off_x, off_h, off_qkv, off_mlp, off_h2, off_lo, off_rowpart, off_rowstat, off_xc, off_hc, off_qc, off_oc, off_uc, off_diag, off_q8, off_q8s, off_q8n, off_q8u, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -52,6 +52,7 @@ static int make_plan(const amds_vit_cfg* c, int batch, VitPlan* p) {
     p->off_mlp = o; o += align256(mlp_b > pm_b ? mlp_b : pm_b);
     // LayerNorm-folded path: second 16-bit row buffer, partial row sums per 128-column slab, final row statistics
     p->off_h2 = o;      o += align256(rows * c->dim * 2);
+    p->off_lo = o;      o += align256(rows * c->dim * 2);          // lo plane of the (hi | lo) residual stream (hi = off_h)
     p->off_rowpart = o; o += align256(rows * (size_t)(c->dim / 128) * 2 * 4);
     p->off_rowstat = o; o += align256(rows * 2 * 4);
     // exact class-token path (vit_exact.hip): fp32 class stream, its LayerNorm output, query rows, attention output, MLP hidden rows
@@ -84,6 +85,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     char* qkv = ws + pl.off_qkv;
     char* mlp = ws + pl.off_mlp;
     char* h2 = ws + pl.off_h2;
+    char* lo = ws + pl.off_lo;
     float* rowpart = reinterpret_cast<float*>(ws + pl.off_rowpart);
     float* rowstat = reinterpret_cast<float*>(ws + pl.off_rowstat);
     int* diag = reinterpret_cast<int*>(ws + pl.off_diag);
@@ -121,7 +123,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     }
     // Class-row tail (amds_vit_weights.cls_tail): with only the class features requested, the last block computes keys / values for all
     // tokens and then the class row's own chain in fp32 -- nothing else of that block is ever read.  AMDS_VIT_CLS_TAIL=0 runs the full block (A/B).
-    static const bool tail_env = !(getenv("AMDS_VIT_CLS_TAIL") && atoi(getenv("AMDS_VIT_CLS_TAIL")) == 0);
+    const bool tail_env = !(getenv("AMDS_VIT_CLS_TAIL") && atoi(getenv("AMDS_VIT_CLS_TAIL")) == 0);
     const amds_vit_exact_block* tl = (tail_env && tokens_f32 == nullptr && c->mlp_kind != 2) ? (ex ? &ex[c->depth - 1] : w->cls_tail) : nullptr;
     if (tl) {
         AMDS_REQUIRE(xh_ > 0 && xh_ <= Hd && xh_ % 4 == 0, "vit: exact_hidden=%d must be a multiple of 4 and <= hidden=%d", xh_, Hd);
@@ -129,6 +131,12 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         AMDS_REQUIRE(tl->q_w && tl->q_b && tl->proj_w && tl->proj_b && tl->fc1_w && tl->fc1_b && tl->fc2_w && tl->fc2_b && lb.ln1_w && lb.ln1_b && lb.ln2_w && lb.ln2_b,
                      "vit: cls_tail: incomplete weights");
     }
+    // Residual stream as two fp16 planes (folded path, fp16 operands, no exact class stream): x = hi + lo with hi = fp16(x) -- the very rows the
+    // qkv / fc1 GEMMs read as their A operand -- and lo = fp16(x - hi).  The proj / fc2 epilogues read 4 + write 4 bytes per element instead of
+    // reading 4 and writing 4 + 2 (fp32 row + its 16-bit copy): 0.54 GB less per launch at M = 262 140, D = 1024.  x keeps ~22 mantissa bits
+    // (fp32: 24; the GEMM operands: 11).  AMDS_VIT_PLANES=0: fp32 rows + copy (A/B; read at every call).
+    const bool planes_env = !(getenv("AMDS_VIT_PLANES") && atoi(getenv("AMDS_VIT_PLANES")) == 0);
+    const bool planes = planes_env && fold && !ex && dt == AMDS_F16;
     // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
     const amds_vit_fp8_block* f8 = w->fp8_host;
     if (f8) {
@@ -199,7 +207,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         float* xq = x + (size_t)r0 * D;
         float* rp = rowpart + (size_t)r0 * NP * 2;
         float* rs = rowstat + 2 * (size_t)r0;
-        char *hq = rows16(h, r0, D), *h2q = rows16(h2, r0, D), *qkvq = rows16(qkv, r0, 3 * D), *mlpq = rows16(mlp, r0, Hd);
+        char *hq = rows16(h, r0, D), *h2q = rows16(h2, r0, D), *loq = rows16(lo, r0, D), *qkvq = rows16(qkv, r0, 3 * D), *mlpq = rows16(mlp, r0, Hd);
         const int epi1 = c->mlp_kind == 0 ? AMDS_EPI_BIAS_GELU : (c->mlp_kind == 1 ? AMDS_EPI_SWIGLU : AMDS_EPI_BIAS);      // kind 2: + quick-GELU pass below
         float *xcq = xc + (size_t)q.t0 * D, *hcq = hc + (size_t)q.t0 * D, *qcq = qc + (size_t)q.t0 * D, *ocq = oc + (size_t)q.t0 * D;
         float* ucq = uc + (size_t)q.t0 * 2 * Hd;
@@ -207,7 +215,8 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
             return amds_bgemm_f32(A, lda, 0, 0, Wt, K, 0, 0, 1, Cm, ldc, 0, 0, 1, 1, q.nt, N, K, 1.0f, 0.0f, bias, acc, s);
         };
         if (ex) AMDS_TRY(amds_vit_cls_gather(xq, xcq, q.nt, T, D, s));
-        if (fold) AMDS_TRY(amds_ln_stats_cast(xq, D, n, D, c->ln_eps, hq, D, rs, dt, s));
+        if (planes) AMDS_TRY(amds_ln_stats_split(xq, D, n, D, c->ln_eps, hq, loq, D, rs, s));
+        else if (fold) AMDS_TRY(amds_ln_stats_cast(xq, D, n, D, c->ln_eps, hq, D, rs, dt, s));
         for (int l = 0; l < c->depth; ++l) {
             const amds_vit_block& b = w->blocks_host[l];
             const bool last = l + 1 == c->depth;
@@ -233,7 +242,8 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                                           b.qkv_b + D, nullptr, nullptr, 0, 0, 0, 1.0f, s));
                 }
                 // the class row: xc += proj(attention(Wq LN1(xc); K, V)); xc += fc2(act(fc1(LN2(xc)))) -- fp32, LayerScale inside the rows
-                if (!ex) AMDS_TRY(amds_vit_cls_gather(xq, xcq, q.nt, T, D, s));
+                if (planes) AMDS_TRY(amds_planes_to_f32(hq, loq, D, T, xcq, D, q.nt, D, s));
+                else if (!ex) AMDS_TRY(amds_vit_cls_gather(xq, xcq, q.nt, T, D, s));
                 AMDS_TRY(amds_layernorm(xcq, D, b.ln1_w, b.ln1_b, hcq, D, q.nt, D, c->ln_eps, AMDS_F32, s));
                 AMDS_TRY(lin32(hcq, D, tl->q_w, D, qcq, D, D, tl->q_b, 0));
                 AMDS_TRY(amds_attention_cls_f32(qcq, D, qkvq, ocq, D, q.nt, T, c->heads, hd, dt, s));
@@ -265,6 +275,17 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                     AMDS_TRY(amds_quantize_rows_e4m3(mlpq, Hd, u8, Hd, au, n, Hd, AMDS_F16, s));
                 }
                 AMDS_TRY(amds_gemm_fp8(u8, Hd, f8[l].fc2_w8, Hd, n, D, Hd, AMDS_EPI_RESIDUAL, xq, D, f8[l].fc2_b, f8[l].fc2_cs, au, s));
+                continue;
+            }
+            if (planes) {      // hi plane (hq) = the A operand of qkv / fc1; attention writes h2q; proj / fc2 update (hq, loq) in place
+                AMDS_TRY(amds_gemm_lnfold(hq, D, b.qkv_w, D, n, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rs,
+                                          b.qkv_colsum, s));
+                AMDS_TRY(amds_attention_vit_hd(qkvq, h2q, q.nt, T, c->heads, D / c->heads, dt, s));
+                AMDS_TRY(amds_gemm_lnfold_planes(h2q, D, b.proj_w, D, n, D, D, hq, loq, D, b.proj_b, ls1, rp, s));
+                AMDS_TRY(amds_ln_rowstat_diag(rp, n, NP, D, c->ln_eps, rs, diag, dt, s));
+                AMDS_TRY(amds_gemm_lnfold(hq, D, b.fc1_w, D, n, n_fc1, D, dt, epi1, mlpq, Hd, b.fc1_b, nullptr, nullptr, nullptr, rs, b.fc1_colsum, s));
+                AMDS_TRY(amds_gemm_lnfold_planes(mlpq, Hd, b.fc2_w, Hd, n, D, Hd, hq, loq, D, b.fc2_b, ls2, rp, s));
+                if (!last) AMDS_TRY(amds_ln_rowstat_diag(rp, n, NP, D, c->ln_eps, rs, diag, dt, s));
                 continue;
             }
             if (fold) {
@@ -326,7 +347,11 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     }
     if (rc != AMDS_OK) return rc;
     // final LayerNorm: CLS rows -> fp16 features (".half()" of the reference); optionally all tokens in fp32
-    if (tl) AMDS_TRY(amds_layernorm(xc, D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));      // the class stream holds the last block's output
+    if (planes && !tl) {      // the planes hold the stream: class rows (and, for the token tensor, every row) back to fp32
+        AMDS_TRY(amds_planes_to_f32(h, lo, D, T, xc, D, Bc, D, st));
+        if (tokens_f32) AMDS_TRY(amds_planes_to_f32(h, lo, D, 1, x, D, M, D, st));
+    }
+    if (tl || planes) AMDS_TRY(amds_layernorm(xc, D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));      // the class stream holds the last block's output
     else AMDS_TRY(amds_layernorm(x, (long)T * D, w->norm_w, w->norm_b, feats_f16, D, Bc, D, c->ln_eps, AMDS_F16, st));
     if (tokens_f32) AMDS_TRY(amds_layernorm(x, D, w->norm_w, w->norm_b, tokens_f32, D, M, D, c->ln_eps, AMDS_F32, st));
 #undef AMDS_TRY

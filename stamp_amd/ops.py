@@ -137,6 +137,40 @@ def ln_stats_cast(x: torch.Tensor, eps: float, dtype: torch.dtype) -> tuple[torc
     return xh, rs
 
 
+def ln_stats_split(x: torch.Tensor, eps: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """fp32 rows -> (hi = fp16(x), lo = fp16(x - hi), [M, 2] (rstd, -mean * rstd)): the residual stream's two-plane form (amds_ln_stats_split)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, D = x.shape
+    hi, lo = torch.empty(M, D, dtype=torch.float16, device=x.device), torch.empty(M, D, dtype=torch.float16, device=x.device)
+    rs = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().amds_ln_stats_split(_p(x), x.stride(0), M, D, eps, _p(hi), _p(lo), D, _p(rs), _stream()), "ln_stats_split")
+    return hi, lo, rs
+
+
+def planes_to_f32(hi: torch.Tensor, lo: torch.Tensor, row_stride: int = 1) -> torch.Tensor:
+    """out[i] = hi[i * row_stride] + lo[i * row_stride] in fp32 (amds_planes_to_f32)."""
+    _dev(hi, lo)
+    assert hi.dtype == lo.dtype == torch.float16 and hi.shape == lo.shape and hi.is_contiguous() and lo.is_contiguous()
+    rows = (hi.shape[0] + row_stride - 1) // row_stride
+    out = torch.empty(rows, hi.shape[1], dtype=torch.float32, device=hi.device)
+    _lib.check(_lib.lib().amds_planes_to_f32(_p(hi), _p(lo), hi.stride(0), row_stride, _p(out), out.stride(0), rows, hi.shape[1], _stream()), "planes_to_f32")
+    return out
+
+
+def gemm_lnfold_planes(a: torch.Tensor, w: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, *, bias=None, scale=None) -> torch.Tensor:
+    """(hi, lo) += scale * (a w^T + bias) on the two-plane residual stream, in place; returns the partial row sums [M, N / 128, 2]
+    (include/amdstamp.h, amds_gemm_lnfold_planes)."""
+    _dev(a, w, hi, lo, bias, scale)
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.dtype == w.dtype == hi.dtype == lo.dtype == torch.float16 and hi.shape == lo.shape == (M, N) and hi.stride(0) == lo.stride(0)
+    rowpart = torch.empty(M, N // 128, 2, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().amds_gemm_lnfold_planes(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, _p(hi), _p(lo), hi.stride(0), _p(bias), _p(scale),
+                                                  _p(rowpart), _stream()), "gemm_lnfold_planes")
+    return rowpart
+
+
 def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64) -> torch.Tensor:
     _dev(qkv)
     assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * head_dim)

@@ -358,6 +358,51 @@ def test_gemm_lnfold_producer(gpu, dt, M, N, K, use_scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,use_scale", [(1000, 1024, 320, True), (515, 512, 1024, False), (256, 256, 64, True)])
+def test_gemm_lnfold_planes(gpu, M, N, K, use_scale):
+    """amds_gemm_lnfold_planes: the residual rows as two fp16 planes.  The fp32 value the epilogue forms is bit for bit what the fp32-row
+    RESIDUAL epilogue writes for the same old value hi + lo; the planes hold its fp16 rounding and the fp16 rounding of what that left over;
+    the partial row sums are those of the fp32 value.  Then 48 updates in a row (a 24-block trunk): the pair drifts from an fp64 running sum
+    by ~1e-7 of the row's magnitude -- the fp32 rows it replaces drift by about as much."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(gpu, torch.float16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu, torch.float16)
+    bias = torch.randn(N, generator=g).to(gpu)
+    scale = (0.5 + torch.rand(N, generator=g)).to(gpu) if use_scale else None
+    x0 = (torch.randn(M, N, generator=g) * torch.logspace(-3, 1, N)).to(gpu)               # columns from 1e-3 to 10: lo reaches fp16's subnormals
+    hi, lo, rs0 = ops.ln_stats_split(x0, 1e-6)
+    assert torch.equal(hi, x0.half()) and torch.equal(lo, (x0 - hi.float()).half())
+    xh_ref, rs_ref = ops.ln_stats_cast(x0, 1e-6, torch.float16)
+    assert torch.equal(hi, xh_ref) and torch.equal(rs0, rs_ref)
+    xin = ops.planes_to_f32(hi, lo)
+    assert torch.equal(xin, hi.float() + lo.float())
+    assert ((xin - x0).abs() <= 2.0 ** -21 * x0.abs() + 2.0 ** -25).all()                  # ~22 bits, or fp16's subnormal spacing / 2
+    assert torch.equal(ops.planes_to_f32(hi, lo, 7), xin[::7])
+    ref = xin.clone()
+    ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=bias, scale=scale, out=ref, cfg=12)
+    rowpart = ops.gemm_lnfold_planes(a, w, hi, lo, bias=bias, scale=scale)
+    assert torch.equal(hi, ref.half()) and torch.equal(lo, (ref - hi.float()).half())
+    cols = ref.view(M, N // 256, 2, 2, 64)
+    slab = cols.permute(0, 1, 3, 2, 4).reshape(M, N // 128, 128).double()
+    want = torch.stack([slab.sum(-1), (slab * slab).sum(-1)], -1)
+    assert torch.allclose(rowpart.double(), want, rtol=2e-5, atol=1e-3)
+    # drift over a trunk's worth of updates, against fp64 (the increments themselves taken from an fp32-row run of the same GEMM)
+    x32 = ops.planes_to_f32(hi, lo)
+    inc = ops.gemm(a, w, _lib.EPI_BIAS_F32, bias=bias, cfg=12).double() * (scale.double() if use_scale else 1.0)      # the same increment every time
+    x64 = x32.double() + 48 * inc
+    for _ in range(48):
+        ops.gemm(a, w, _lib.EPI_RESIDUAL, bias=bias, scale=scale, out=x32, cfg=12)
+        ops.gemm_lnfold_planes(a, w, hi, lo, bias=bias, scale=scale)
+    xp = ops.planes_to_f32(hi, lo).double()
+    d_pl = ((xp - x64).norm() / x64.norm()).item()
+    d_32 = ((x32.double() - x64).norm() / x64.norm()).item()
+    print(f"48 residual updates, M={M} N={N}: (hi | lo) planes drift {d_pl:.2e}, fp32 rows {d_32:.2e} (relative L2 vs an fp64 running sum)")
+    assert d_pl < 2e-6
+    with pytest.raises(RuntimeError, match="alias"):
+        _lib.check(_lib.lib().amds_gemm_lnfold_planes(a.data_ptr(), K, w.data_ptr(), K, M, N, K, hi.data_ptr(), hi.data_ptr(), N, None, None, rowpart.data_ptr(), None), "planes")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "swiglu"])
 def test_gemm_lnfold_consumer(gpu, dt, epi):

@@ -334,3 +334,33 @@ def test_class_row_tail_of_the_last_block(gpu, name, fold):
     # with the exact class stream the tail IS that stream's last block: same bits with and without it
     ex_full = HipViT(cfg, sd, device=gpu, chunk=4, ln_fold=fold, exact=True, cls_tail=False)(tiles.to(gpu))
     assert torch.equal(HipViT(cfg, sd, device=gpu, chunk=4, ln_fold=fold, exact=True)(tiles.to(gpu)), ex_full)
+
+
+def test_residual_planes_against_fp32_rows(gpu, monkeypatch):
+    """The folded path keeps the residual stream as two fp16 planes (hi = the GEMMs' A operand, lo = x - hi; include/amdstamp.h,
+    amds_gemm_lnfold_planes) instead of fp32 rows + a 16-bit copy.  Against the fp32-row form (AMDS_VIT_PLANES=0) on the full ViT-L/14:
+    neither is further from the oracle than the other (measured: tokens 3.054e-4 / 3.053e-4, stored feature 5.18e-4 / 5.17e-4).  The two
+    forms differ from EACH OTHER by ~2e-4 on the tokens: an fp32-eps change of a residual element flips the fp16 rounding of the next GEMM
+    operand for ~2e-4 of the elements, and 48 such sites make the two runs two samples of the same 16-bit rounding noise -- which is why the
+    bar is the oracle, not the other form.  Batch / chunk invariance holds in the plane form too."""
+    cfg = PRESETS["vit_large_patch14_224"]
+    sd = random_vit_state_dict(cfg, seed=0, init="moderate")
+    tiles = torch.randint(0, 256, (6, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    ref_f, ref_t = extract_features(tiles[:4], sd, cfg, return_tokens=True)
+    model = HipViT(cfg, sd, device=gpu, chunk=4)
+    assert model.ln_fold
+    f_pl, t_pl = model(tiles.to(gpu), return_tokens=True)
+    d_pl = model(tiles.to(gpu))
+    monkeypatch.setenv("AMDS_VIT_PLANES", "0")
+    f_32, t_32 = model(tiles.to(gpu), return_tokens=True)
+    d_32 = model(tiles.to(gpu))
+    monkeypatch.delenv("AMDS_VIT_PLANES")
+    assert torch.equal(d_pl, model(tiles.to(gpu)))
+    r_ft, r_dd, r_tt = _rel(f_pl.float(), f_32.float()), _rel(d_pl.float(), d_32.float()), _rel(t_pl, t_32)
+    e_pl, e_32 = _rel(t_pl[:4].cpu(), ref_t), _rel(t_32[:4].cpu(), ref_t)
+    c_pl, c_32 = _rel(d_pl[:4].cpu().float(), ref_f.float()), _rel(d_32[:4].cpu().float(), ref_f.float())
+    print(f"ViT-L/14 planes vs fp32 rows: features {r_ft:.2e} (default call {r_dd:.2e}), tokens {r_tt:.2e}; vs oracle: tokens {e_pl:.3e} / {e_32:.3e}, "
+          f"stored feature {c_pl:.3e} / {c_32:.3e}")
+    assert r_tt < 6e-4 and r_ft < 1e-3 and r_dd < 1e-3              # two samples of the same rounding noise (each ~3e-4 / 5e-4 from the oracle)
+    assert e_pl < 1e-3 and c_pl < 1e-3 and e_pl < 1.05 * e_32 and c_pl < 1.1 * c_32
+    assert torch.equal(d_pl[:3], HipViT(cfg, sd, device=gpu, chunk=6)(tiles[:3].to(gpu)))
