@@ -650,12 +650,15 @@ def main() -> None:
     tail_on = (not is_swin) and getattr(model, "cls_tail", False) and os.environ.get("AMDS_VIT_CLS_TAIL", "1") != "0"
     flops_exec = cfg.matmul_flops_per_tile() - (cfg.matmul_flops_skipped_by_cls_tail() if tail_on else 0.0)
     alg_bytes = None
+    planes_on = False
     if not is_swin:
         # algorithmic HBM bytes per GEMM launch, averaged over the four launches of a block (operands once, fp32 residual rows read +
         # written, outputs once; with the LayerNorm folded in, proj / fc2 also write the 16-bit copy of the rows)
         Mrows, Dm, Hd = min(a.chunk, a.tiles) * cfg.tokens, cfg.dim, cfg.hidden_pad
         n1 = Hd * (2 if cfg.mlp == "swiglu" else 1)
-        fold = 2 * Mrows * Dm if getattr(model, "ln_fold", False) else 0
+        planes_on = getattr(model, "ln_fold", False) and not a.exact and act == torch.float16 and os.environ.get("AMDS_VIT_PLANES", "1") != "0"
+        # residual update: fp32 rows read + written (8 B per element) plus, folded, the 16-bit copy (2 B); as two fp16 planes: 4 B read + 4 B written
+        fold = 2 * Mrows * Dm if (getattr(model, "ln_fold", False) and not planes_on) else 0
         per = [2 * Mrows * Dm + 2 * 3 * Dm * Dm + 2 * Mrows * 3 * Dm, 2 * Mrows * Dm + 2 * Dm * Dm + 8 * Mrows * Dm + fold,
                2 * Mrows * Dm + 2 * n1 * Dm + 2 * Mrows * Hd, 2 * Mrows * Hd + 2 * Dm * Hd + 8 * Mrows * Dm + fold]
         alg_bytes = sum(per) / 4
@@ -670,17 +673,19 @@ def main() -> None:
                                 "LayerScale) tile extraction on synthetic 224x224x3 u8 tiles resident in HBM, "
                                 "random-init weights, fp16 CLS features out" + (", exact class-token rows" if a.exact else "") + (", OPT-IN fp8 (e4m3) GEMM operands" if a.fp8 else "")),
                    "model": a.model, "tiles_per_step_per_gpu": a.tiles, "chunk": a.swin_chunk if is_swin else a.chunk,
-                   "operands": a.act, "accumulate": "f32", "residual_stream": "f32",
+                   "operands": a.act, "accumulate": "f32",
                    "parallelism": f"slide-sharded x{ctx.world}, all-gather of slide embeddings" if ctx.world > 1 else "single GPU",
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    # the last block's class-row tail (include/amdstamp.h amds_vit_weights.cls_tail): rows of the last block that nothing reads are not
                    # computed, so the whole-path fraction is priced on the products actually EXECUTED, not on the network's nominal count
-                   "cls_tail": bool(tail_on),
+                   "cls_tail": bool(tail_on), "residual_stream": "f16 hi|lo planes" if (not is_swin and planes_on) else "f32",
                    "gflop_per_tile_executed": round(flops_exec / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * flops_exec / 1e12 / MFMA_PEAK_TFLOPS, 4)},
         "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles where N is not a multiple of 256, gemm_4w16_kernel in stage 4 and the stage-3 MLP)" if is_swin else
                                ("gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues"
-                                + ("; LayerNorm folded in: proj / fc2 also emit a 16-bit row copy + row sums, qkv / fc1 apply the row statistics" if getattr(model, "ln_fold", False) else "") + ")"), "bound": "mfma",
+                                + ("; LayerNorm folded in: proj / fc2 also emit row sums, qkv / fc1 apply the row statistics" if getattr(model, "ln_fold", False) else "")
+                                + ("; residual stream as two fp16 planes (hi = the next GEMM's A operand, lo = x - hi) updated in place by proj / fc2" if planes_on else
+                                   ("; proj / fc2 update fp32 rows and write their 16-bit copy" if getattr(model, "ln_fold", False) else "")) + ")"), "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": (f"HBM-side bytes per GEMM launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/{pmc_name}); "
