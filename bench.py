@@ -492,10 +492,11 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
         loss = torch.nn.functional.cross_entropy(tm(bags_f), tgd)
         loss.backward()
         opt.step()
-        return loss
-    # Three blocks of 4 steps after two warm steps (the second still allocates: AdamW state, workspaces of the backward).  Two full runs of round 2
-    # showed ONE slow block here (345 / 446 bags/s against 750-1100 in every other run: ~600 launches per step through Python leave little host
-    # margin), so every block is reported and `value` is their MEDIAN.
+        return loss.detach()       # NOT the attached loss: see below
+    # Three blocks of 4 steps after two warm steps; every block is reported and `value` is their MEDIAN.  The slow blocks of earlier runs (345 / 446 / 472
+    # bags/s against 1.1 k) were this function's doing, not the library's: it returned the ATTACHED loss, whose graph pins the step's 15 GB
+    # saved-activation arena; the caller's reference from the previous block then forced a third arena, i.e. one 15 GB hipMalloc (260-450 ms,
+    # tools/transmil_step_times.py) inside a timed 230 ms block.  A training loop that keeps only detached values needs one arena.
     blocks = []
     for i in range(3):
         dt, ltm = timeit(tm_step, 4, warm=2 if i == 0 else 0)
