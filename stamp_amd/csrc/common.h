@@ -106,16 +106,20 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return fmaf(copysignf(erf_abs, x), h, h);             // 0.5 x (1 + erf(x/sqrt2))
 }
 // erf-GELU without transcendentals, for 16-bit outputs on VALU-bound epilogues: erf(z) ~ zc * P(zc^2) with zc = z clamped
-// to [-3.25, 3.25] and P a degree-11 minimax (Chebyshev-fitted) polynomial evaluated by Horner in u = 2 zc^2/3.25^2 - 1
-// (|error| <= 9e-7 inside the range, 4.3e-6 = 1 - erf(3.25) beyond it -> |gelu error| <= 2.2e-6 |x|, far below half an
-// ulp of fp16/bf16).  Written on 2-vectors so that it compiles to v_pk_fma_f32 / v_pk_mul_f32: 9.5 instructions per
-// element against ~22 issue slots for the rcp/exp form above (quarter-rate transcendentals counted as four).
+// to [-3, 3] and P a degree-8 near-minimax polynomial (Lawson-weighted least squares, tools/gelu_poly_fit.py) evaluated by Horner in
+// u = 2 zc^2/3^2 - 1, CONSTRAINED to 3 P(1) = 1: beyond the clamp the result is exactly 0 or x (an unconstrained fit leaves
+// 0.5 |x| (1 - erf(zmax)) there, which grows with |x| -- massive activations).  |erf error| <= 2.2e-5 (= 1 - erf(3), at the clamp)
+// -> |gelu error| <= 1.1e-5 |x| <= 4.7e-5: 5 % of half an fp16 ulp of the result where it is largest.  Round 3 (end): degree 11 on
+// [-3.25, 3.25] (2.2e-6 |x|) was 100x finer than a 16-bit output can hold; three Horner steps fewer are 16 % of this epilogue's
+// VALU work, which is un-overlapped (one wave per SIMD): fc1's launch 2 353 -> 2 3xx us.  Written on 2-vectors so that it compiles to
+// v_pk_fma_f32 / v_pk_mul_f32.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The scaling by 1/sqrt2 is folded into the clamp bound, the argument map and the coefficients (three packed operations fewer
-// per 2 outputs than clamping z = x/sqrt2):  xc = clamp(x, +-3.25 sqrt2),  u = xc^2 / 3.25^2 - 1,  gelu = h + h (xc Q(u)),  h = x/2.
-constexpr float GELU_XMAX = 4.59619407771256f, GELU_USCALE = 0.09467455621301775f;
-constexpr float GELU_Q[12] = {3.073371250e-01f, -1.516402814e-01f, 1.083792275e-01f, -8.086256723e-02f, 5.821552511e-02f, -3.940696708e-02f,
-                              2.493799295e-02f, -1.386272869e-02f, 6.385995681e-03f, -3.540644640e-03f, 2.470353036e-03f, -8.427158838e-04f};
+// per 2 outputs than clamping z = x/sqrt2):  xc = clamp(x, +-3 sqrt2),  u = xc^2 / 3^2 - 1,  gelu = h + h (xc Q(u)),  h = x/2.
+constexpr int GELU_DEG = 8;
+constexpr float GELU_XMAX = 4.242640495300293f, GELU_USCALE = 0.1111111119389534f;
+constexpr float GELU_Q[GELU_DEG + 1] = {3.324316144e-01f, -1.617360711e-01f, 1.114244238e-01f, -7.858549058e-02f, 5.109526962e-02f, -2.810213529e-02f,
+                                        1.688414440e-02f, -1.262922771e-02f, 4.919740371e-03f};
 // the same polynomial on NC independent 2-vectors, Horner steps interleaved across them: one wave per SIMD (4-wave GEMM) has
 // nobody to hide the dependent v_pk_fma latency behind, so a single chain runs at a fraction of the VALU rate
 template <int NC>
@@ -125,10 +129,10 @@ __device__ __forceinline__ void gelu_erf_poly2_n(f32x2 (&x)[NC]) {
     for (int k = 0; k < NC; ++k) {
         xc[k] = __builtin_elementwise_min(__builtin_elementwise_max(x[k], f32x2{-GELU_XMAX, -GELU_XMAX}), f32x2{GELU_XMAX, GELU_XMAX});
         u[k] = xc[k] * xc[k] * GELU_USCALE - 1.0f;
-        p[k] = f32x2{GELU_Q[11], GELU_Q[11]};
+        p[k] = f32x2{GELU_Q[GELU_DEG], GELU_Q[GELU_DEG]};
     }
 #pragma unroll
-    for (int i = 10; i >= 0; --i)
+    for (int i = GELU_DEG - 1; i >= 0; --i)
 #pragma unroll
         for (int k = 0; k < NC; ++k) p[k] = p[k] * u[k] + GELU_Q[i];
 #pragma unroll

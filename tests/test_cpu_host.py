@@ -50,6 +50,12 @@ def test_flops_per_tile_matches_survey():
     assert abs(PRESETS["vit_large_patch14_224"].matmul_flops_per_tile() / 1e9 - 162.02) < 0.01
     assert abs(PRESETS["uni2_h"].matmul_flops_per_tile() / 1e9 - 370.94) < 0.01
     assert abs(PRESETS["virchow2"].matmul_flops_per_tile() / 1e9 - 340.13) < 0.01
+    # what the class-row tail of the last block never computes: q / proj / fc1 / fc2 rows and the attention of T - 1 tokens
+    c = PRESETS["vit_large_patch14_224"]
+    T, D, H = c.tokens, c.dim, c.hidden
+    assert c.matmul_flops_skipped_by_cls_tail() == 2 * (T - 1) * (2 * D * D + 2 * D * H) + 4 * T * (T - 1) * D
+    assert abs(c.matmul_flops_skipped_by_cls_tail() / 1e9 - 5.638) < 0.001
+    assert abs((PRESETS["uni2_h"].matmul_flops_per_tile() - PRESETS["uni2_h"].matmul_flops_skipped_by_cls_tail()) / 1e9 - 358.054) < 0.01
 
 
 def test_shard_slides_lpt():
