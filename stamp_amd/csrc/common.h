@@ -115,11 +115,12 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // v_pk_fma_f32 / v_pk_mul_f32.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The scaling by 1/sqrt2 is folded into the clamp bound, the argument map and the coefficients (three packed operations fewer
-// per 2 outputs than clamping z = x/sqrt2):  xc = clamp(x, +-3 sqrt2),  u = xc^2 / 3^2 - 1,  gelu = h + h (xc Q(u)),  h = x/2.
+// per 2 outputs than clamping z = x/sqrt2):  xc = clamp(x, +-3 sqrt2),  u = xc^2 / 3^2 - 1,  gelu = x (1/2 + xc Q(u) / 2).
 constexpr int GELU_DEG = 8;
 constexpr float GELU_XMAX = 4.242640495300293f, GELU_USCALE = 0.1111111119389534f;
-constexpr float GELU_Q[GELU_DEG + 1] = {3.324316144e-01f, -1.617360711e-01f, 1.114244238e-01f, -7.858549058e-02f, 5.109526962e-02f, -2.810213529e-02f,
-                                        1.688414440e-02f, -1.262922771e-02f, 4.919740371e-03f};
+// half the coefficients tools/gelu_poly_fit.py prints (exact in fp32): the kernel evaluates gelu = x (1/2 + xc Q(u))
+constexpr float GELU_Q[GELU_DEG + 1] = {0.5f * 3.324316144e-01f, 0.5f * -1.617360711e-01f, 0.5f * 1.114244238e-01f, 0.5f * -7.858549058e-02f, 0.5f * 5.109526962e-02f,
+                                        0.5f * -2.810213529e-02f, 0.5f * 1.688414440e-02f, 0.5f * -1.262922771e-02f, 0.5f * 4.919740371e-03f};
 // the same polynomial on NC independent 2-vectors, Horner steps interleaved across them: one wave per SIMD (4-wave GEMM) has
 // nobody to hide the dependent v_pk_fma latency behind, so a single chain runs at a fraction of the VALU rate
 template <int NC>
@@ -127,7 +128,8 @@ __device__ __forceinline__ void gelu_erf_poly2_n(f32x2 (&x)[NC]) {
     f32x2 xc[NC], u[NC], p[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        xc[k] = __builtin_elementwise_min(__builtin_elementwise_max(x[k], f32x2{-GELU_XMAX, -GELU_XMAX}), f32x2{GELU_XMAX, GELU_XMAX});
+        // v_med3_f32 per element; elementwise min(max()) also canonicalises its input (one v_max_f32 x, x more per element)
+        xc[k] = f32x2{__builtin_amdgcn_fmed3f(x[k][0], -GELU_XMAX, GELU_XMAX), __builtin_amdgcn_fmed3f(x[k][1], -GELU_XMAX, GELU_XMAX)};
         u[k] = xc[k] * xc[k] * GELU_USCALE - 1.0f;
         p[k] = f32x2{GELU_Q[GELU_DEG], GELU_Q[GELU_DEG]};
     }
@@ -136,10 +138,7 @@ __device__ __forceinline__ void gelu_erf_poly2_n(f32x2 (&x)[NC]) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) p[k] = p[k] * u[k] + GELU_Q[i];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const f32x2 h = x[k] * 0.5f;
-        x[k] = h * (xc[k] * p[k]) + h;
-    }
+    for (int k = 0; k < NC; ++k) x[k] = x[k] * (xc[k] * p[k] + 0.5f);      // x (1/2 + erf/2): GELU_Q carries the 1/2
 }
 __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
     f32x2 q[1] = {x};
