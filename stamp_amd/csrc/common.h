@@ -105,40 +105,37 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float h = 0.5f * x;
     return fmaf(copysignf(erf_abs, x), h, h);             // 0.5 x (1 + erf(x/sqrt2))
 }
-// erf-GELU without transcendentals, for 16-bit outputs on VALU-bound epilogues: erf(z) ~ zc * P(zc^2) with zc = z clamped
-// to [-3, 3] and P a degree-8 near-minimax polynomial (Lawson-weighted least squares, tools/gelu_poly_fit.py) evaluated by Horner in
-// u = 2 zc^2/3^2 - 1, CONSTRAINED to 3 P(1) = 1: beyond the clamp the result is exactly 0 or x (an unconstrained fit leaves
-// 0.5 |x| (1 - erf(zmax)) there, which grows with |x| -- massive activations).  |erf error| <= 2.2e-5 (= 1 - erf(3), at the clamp)
-// -> |gelu error| <= 1.1e-5 |x| <= 4.7e-5: 5 % of half an fp16 ulp of the result where it is largest.  Round 3 (end): degree 11 on
-// [-3.25, 3.25] (2.2e-6 |x|) was 100x finer than a 16-bit output can hold; three Horner steps fewer are 16 % of this epilogue's
-// VALU work, which is un-overlapped (one wave per SIMD): fc1's launch 2 353 -> 2 3xx us.  Written on 2-vectors so that it compiles to
-// v_pk_fma_f32 / v_pk_mul_f32.
+// erf-GELU without transcendentals, for 16-bit outputs on VALU-bound epilogues:  gelu(x) = x (1/2 + xc R(xc^2)),  xc = clamp(x, +-3 sqrt2),
+// R of degree 8.  Derivation (tools/gelu_poly_fit.py): erf(z) ~ zc P(u) on |z| <= 3 with u = 2 zc^2 / 9 - 1, P near-minimax (Lawson-weighted
+// least squares) under the CONSTRAINT 3 P(1) = 1 -- the approximation saturates at +-1, so beyond the clamp gelu is 0 or x to 2e-8 |x| (an
+// unconstrained fit leaves 0.5 |x| (1 - erf(zmax)) there, which grows with |x|: massive activations); then re-expanded in t = xc^2 with the 1/sqrt2
+// of z = x / sqrt2 and the 1/2 folded in, and R[0], R[1] moved by -6 / +1 ulp so that the fp32 FMA chain lands on xc R(18) = -+1/2 at the clamp.
+// |gelu error| <= 1.4e-5 |x| <= 5.6e-5: 6 % of half an fp16 ulp of the result where it is largest.  Round 3 (end): degree 11 in u on |z| <= 3.25
+// (2.2e-6 |x|) was 100x finer than a 16-bit output can hold, and this epilogue's VALU work is un-overlapped (one wave per SIMD): per pair of
+// outputs 2 v_med3 + 1 v_pk_mul (t) + 8 v_pk_fma (Horner) + 1 v_pk_fma + 1 v_pk_mul, against 2 + 2 + 2 + 11 + 3 before; fc1's launch 2 353 -> 2 2xx us.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The scaling by 1/sqrt2 is folded into the clamp bound, the argument map and the coefficients (three packed operations fewer
-// per 2 outputs than clamping z = x/sqrt2):  xc = clamp(x, +-3 sqrt2),  u = xc^2 / 3^2 - 1,  gelu = x (1/2 + xc Q(u) / 2).
 constexpr int GELU_DEG = 8;
-constexpr float GELU_XMAX = 4.242640495300293f, GELU_USCALE = 0.1111111119389534f;
-// half the coefficients tools/gelu_poly_fit.py prints (exact in fp32): the kernel evaluates gelu = x (1/2 + xc Q(u))
-constexpr float GELU_Q[GELU_DEG + 1] = {0.5f * 3.324316144e-01f, 0.5f * -1.617360711e-01f, 0.5f * 1.114244238e-01f, 0.5f * -7.858549058e-02f, 0.5f * 5.109526962e-02f,
-                                        0.5f * -2.810213529e-02f, 0.5f * 1.688414440e-02f, 0.5f * -1.262922771e-02f, 0.5f * 4.919740371e-03f};
+constexpr float GELU_XMAX = 4.242640495300293f;
+constexpr float GELU_R[GELU_DEG + 1] = {3.989038765e-01f, -6.635002047e-02f, 9.821003303e-03f, -1.110561891e-03f, 9.383271390e-05f,
+                                        -5.674323347e-06f, 2.286626994e-07f, -5.434610983e-09f, 5.714419563e-11f};
 // the same polynomial on NC independent 2-vectors, Horner steps interleaved across them: one wave per SIMD (4-wave GEMM) has
 // nobody to hide the dependent v_pk_fma latency behind, so a single chain runs at a fraction of the VALU rate
 template <int NC>
 __device__ __forceinline__ void gelu_erf_poly2_n(f32x2 (&x)[NC]) {
-    f32x2 xc[NC], u[NC], p[NC];
+    f32x2 xc[NC], t[NC], p[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         // v_med3_f32 per element; elementwise min(max()) also canonicalises its input (one v_max_f32 x, x more per element)
         xc[k] = f32x2{__builtin_amdgcn_fmed3f(x[k][0], -GELU_XMAX, GELU_XMAX), __builtin_amdgcn_fmed3f(x[k][1], -GELU_XMAX, GELU_XMAX)};
-        u[k] = xc[k] * xc[k] * GELU_USCALE - 1.0f;
-        p[k] = f32x2{GELU_Q[GELU_DEG], GELU_Q[GELU_DEG]};
+        t[k] = xc[k] * xc[k];
+        p[k] = f32x2{GELU_R[GELU_DEG], GELU_R[GELU_DEG]};
     }
 #pragma unroll
     for (int i = GELU_DEG - 1; i >= 0; --i)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) p[k] = p[k] * u[k] + GELU_Q[i];
+        for (int k = 0; k < NC; ++k) p[k] = p[k] * t[k] + GELU_R[i];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) x[k] = x[k] * (xc[k] * p[k] + 0.5f);      // x (1/2 + erf/2): GELU_Q carries the 1/2
+    for (int k = 0; k < NC; ++k) x[k] = x[k] * (xc[k] * p[k] + 0.5f);
 }
 __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
     f32x2 q[1] = {x};

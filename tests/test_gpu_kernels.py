@@ -358,6 +358,36 @@ def test_gemm_lnfold_producer(gpu, dt, M, N, K, use_scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [12, -1])
+def test_gelu_epilogue_polynomial_over_its_whole_range(gpu, cfg):
+    """The BIAS_GELU epilogue evaluates erf by a degree-8 polynomial in x^2 (common.h, tools/gelu_poly_fit.py).  A GEMM with an identity
+    weight and the test values as bias puts exact pre-activations into the accumulators: a dense sweep of [-8, 8], the clamp points +-3 sqrt2,
+    and massive values.  Bars: |error| <= 1.5e-5 |x| + half an fp16 ulp of the result inside; beyond the clamp 0 (negative side, to 5e-8 |x|) or x."""
+    import math
+    N = K = 256
+    xs = torch.cat([torch.linspace(-8, 8, 256 * 1021), torch.tensor([-3 * math.sqrt(2), 3 * math.sqrt(2), -4.2426, 4.2427, -6.0, 6.0, -30.0, 30.0, -1e3, 1e3, -6e4, 6e4, 0.0, -0.0])])
+    pad = (-xs.numel()) % N
+    xs = torch.cat([xs, torch.zeros(pad)]).reshape(-1, N).to(gpu)
+    M = xs.shape[0]
+    a = torch.zeros(M, K, dtype=torch.float16, device=gpu)
+    w = torch.eye(N, K, dtype=torch.float16, device=gpu)
+    # the value enters through an fp32 "residual-free" route: acc = 0 * w + bias is per column, so feed rows through A instead: A = hi + lo of x
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    a2 = torch.cat([hi, lo], 1)                         # [M, 2K]: x = hi + lo reproduces the fp32 value to 2^-22
+    w2 = torch.cat([w, w], 1)
+    out = ops.gemm(a2, w2, _lib.EPI_BIAS_GELU, bias=torch.zeros(N, device=gpu), cfg=cfg).double()
+    x = hi.double() + lo.double()
+    ref = torch.nn.functional.gelu(x)
+    half_ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, device=gpu, dtype=torch.float64)) * 2.0 ** -11
+    err = (out - ref).abs()
+    assert bool((err <= 1.5e-5 * x.abs() + 1.01 * half_ulp).all()), float((err - 1.5e-5 * x.abs() - half_ulp).max())
+    neg_tail, pos_tail = x < -4.3, x > 4.3
+    assert bool((out[neg_tail].abs() <= 5e-8 * x[neg_tail].abs() + 6e-8).all()) and torch.equal(out[pos_tail], x[pos_tail].half().double())
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,use_scale", [(1000, 1024, 320, True), (515, 512, 1024, False), (256, 256, 64, True)])
 def test_gemm_lnfold_planes(gpu, M, N, K, use_scale):
     """amds_gemm_lnfold_planes: the residual rows as two fp16 planes.  The fp32 value the epilogue forms is bit for bit what the fp32-row
