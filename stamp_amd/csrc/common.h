@@ -112,7 +112,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // of z = x / sqrt2 and the 1/2 folded in, and R[0], R[1] moved by -6 / +1 ulp so that the fp32 FMA chain lands on xc R(18) = -+1/2 at the clamp.
 // |gelu error| <= 1.4e-5 |x| <= 5.6e-5: 6 % of half an fp16 ulp of the result where it is largest.  Round 3 (end): degree 11 in u on |z| <= 3.25
 // (2.2e-6 |x|) was 100x finer than a 16-bit output can hold, and this epilogue's VALU work is un-overlapped (one wave per SIMD): per pair of
-// outputs 2 v_med3 + 1 v_pk_mul (t) + 8 v_pk_fma (Horner) + 1 v_pk_fma + 1 v_pk_mul, against 2 + 2 + 2 + 11 + 3 before; fc1's launch 2 353 -> 2 2xx us.
+// outputs 2 v_med3 + 1 v_pk_mul (t) + 8 v_pk_fma (Horner) + 1 v_pk_fma + 1 v_pk_mul, against 2 + 2 + 2 + 11 + 3 before; fc1's launch 2 353 -> 2 230 us.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int GELU_DEG = 8;
 constexpr float GELU_XMAX = 4.242640495300293f;
