@@ -142,7 +142,9 @@ __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
     gelu_erf_poly2_n<1>(q);
     return q[0];
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) for 16-bit outputs: v_rcp_f32 (1 ulp) instead of the IEEE division `x / (1 + e)` expands to (v_div_scale x 2, v_rcp, 5 fma,
+// v_div_fmas, v_div_fixup: 11 of the 17 VALU instructions per output of the SWIGLU epilogue, which is un-overlapped like the GELU one)
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // Sum over the 32 lanes that share lane >> 5; every lane gets the total.  Every step is an XOR butterfly (lane ^ 1, ^ 2, ^ 7, ^ 15, ^ 16:
 // quad_perm, row_half_mirror, row_mirror, ds_swizzle -- five independent masks), so the association tree is a fixed partition of the
