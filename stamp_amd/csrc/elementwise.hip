@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) quick_gelu_inplace_kernel(T* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = (float)v[e];
-            v[e] = (T)(x / (1.0f + __expf(-1.702f * x)));
+            v[e] = (T)(x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)));      // v_rcp_f32 (1 ulp): the result is rounded to 16 bits
         }
         *p = v;
     }
