@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* __re
 // ---------------------------------------------------------------------------------------------
 // lo_scale != 0: rows are 2*kp wide and columns kp.. hold the same values times lo_scale (a power of two, exact) -- the A operand of a
 // patch-embedding GEMM whose weight is split into [hi | lo / lo_scale] (amds_tile_im2col_u8_ex).
+constexpr int IM2COL_KMAX = 1024;          // kp = roundup(3 p^2, 64): 640 (p = 14), 768 (p = 16), 1024 at most (p <= 18)
 template <typename TO>
 __global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restrict__ tiles, TO* __restrict__ out,
                                                         int img, int p, int kp, float lo_scale) {
@@ -306,8 +307,15 @@ __global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restric
     const uint8_t* src = tiles + ((long)b * img + (long)py * p) * img * 3;
     for (int i = threadIdx.x * 16; i < nbytes; i += 256 * 16)
         *reinterpret_cast<u32x4*>(srow + i) = *reinterpret_cast<const u32x4*>(src + i);
-    __syncthreads();
+    // column k = (c, i, j) of the patch matrix -> byte offset of that pixel inside the staged rows, relative to the patch's first pixel: computed
+    // once per block (two runtime integer divisions per entry) instead of once per output element (they were most of this kernel's 412 us)
+    __shared__ int koff[IM2COL_KMAX];
     const int pp = p * p, k_real = 3 * pp;
+    for (int k = threadIdx.x; k < kp; k += 256) {
+        const int c = k / pp, r = k - c * pp, i = r / p, j = r - i * p;
+        koff[k] = k < k_real ? (i * img + j) * 3 + c : -1;
+    }
+    __syncthreads();
     const int ld = lo_scale != 0.f ? 2 * kp : kp;
     const int chunks = ld >> 3, half = kp >> 3;
     TO* orow = out + ((long)b * g * g + (long)py * g) * ld;
@@ -316,16 +324,12 @@ __global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restric
         const int px = w / chunks, ch = w - px * chunks;
         const int ch0 = ch >= half ? ch - half : ch;
         const float sc = ch >= half ? lo_scale : 1.0f;
+        const uint8_t* pbase = srow + px * p * 3;
         vec8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = ch0 * 8 + e;
-            float v = 0.f;
-            if (k < k_real) {
-                const int c = k / pp, r = k - c * pp, i = r / p, j = r - i * p;
-                v = (float)srow[(i * img + px * p + j) * 3 + c] * sc;
-            }
-            o[e] = (TO)v;
+            const int off = koff[ch0 * 8 + e];
+            o[e] = (TO)(off >= 0 ? (float)pbase[off] * sc : 0.f);
         }
         *reinterpret_cast<vec8*>(orow + (long)px * ld + ch * 8) = o;
     }
@@ -457,7 +461,7 @@ extern "C" int amds_tile_im2col_u8_ex(const uint8_t* tiles, void* out, int B, in
     AMDS_REQUIRE(lo_shift >= 0 && lo_shift <= 14, "amds_tile_im2col_u8: lo_shift=%d out of range", lo_shift);
     const float lo_scale = lo_shift ? ldexpf(1.0f, -lo_shift) : 0.f;
     AMDS_REQUIRE(img > 0 && patch > 0 && img % patch == 0, "amds_tile_im2col_u8: img=%d not divisible by patch=%d", img, patch);
-    AMDS_REQUIRE(kp % 8 == 0 && kp >= 3 * patch * patch, "amds_tile_im2col_u8: kp=%d too small / not a multiple of 8", kp);
+    AMDS_REQUIRE(kp % 8 == 0 && kp >= 3 * patch * patch && kp <= IM2COL_KMAX, "amds_tile_im2col_u8: kp=%d too small / not a multiple of 8 / above 1024", kp);
     AMDS_REQUIRE((patch * img * 3) % 16 == 0 && ((long)img * img * 3) % 16 == 0, "amds_tile_im2col_u8: row block not 16-byte aligned");
     if (B == 0) return AMDS_OK;
     const int g = img / patch;
