@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* __re
 // ---------------------------------------------------------------------------------------------
 // lo_scale != 0: rows are 2*kp wide and columns kp.. hold the same values times lo_scale (a power of two, exact) -- the A operand of a
 // patch-embedding GEMM whose weight is split into [hi | lo / lo_scale] (amds_tile_im2col_u8_ex).
-constexpr int IM2COL_KMAX = 1024;          // kp = roundup(3 p^2, 64): 640 (p = 14), 768 (p = 16), 1024 at most (p <= 18)
+constexpr int IM2COL_KMAX = 4096;          // kp = roundup(3 p^2, 64): 640 (p = 14), 768 (p = 16), 3072 (p = 32: CLIP ViT-B/32); 16 KB of LDS
 template <typename TO>
 __global__ void __launch_bounds__(256) im2col_u8_kernel(const uint8_t* __restrict__ tiles, TO* __restrict__ out,
                                                         int img, int p, int kp, float lo_scale) {
@@ -461,7 +461,7 @@ extern "C" int amds_tile_im2col_u8_ex(const uint8_t* tiles, void* out, int B, in
     AMDS_REQUIRE(lo_shift >= 0 && lo_shift <= 14, "amds_tile_im2col_u8: lo_shift=%d out of range", lo_shift);
     const float lo_scale = lo_shift ? ldexpf(1.0f, -lo_shift) : 0.f;
     AMDS_REQUIRE(img > 0 && patch > 0 && img % patch == 0, "amds_tile_im2col_u8: img=%d not divisible by patch=%d", img, patch);
-    AMDS_REQUIRE(kp % 8 == 0 && kp >= 3 * patch * patch && kp <= IM2COL_KMAX, "amds_tile_im2col_u8: kp=%d too small / not a multiple of 8 / above 1024", kp);
+    AMDS_REQUIRE(kp % 8 == 0 && kp >= 3 * patch * patch && kp <= IM2COL_KMAX, "amds_tile_im2col_u8: kp=%d too small / not a multiple of 8 / above 4096", kp);
     AMDS_REQUIRE((patch * img * 3) % 16 == 0 && ((long)img * img * 3) % 16 == 0, "amds_tile_im2col_u8: row block not 16-byte aligned");
     if (B == 0) return AMDS_OK;
     const int g = img / patch;
