@@ -422,3 +422,21 @@ def test_code_hash_and_extractor_name_rules_equal_the_references_functions(tmp_p
         exec(compile(ast.Module(body=body, type_ignores=[]), str(path), "exec"), glb)
     assert glb["get_processing_code_hash"](tmp_path / "m0.py") == code_hash(tmp_path)
     assert [glb["_resolve_extractor_name"](n) for n in names] == recorded
+
+
+def test_gelu_polynomial_in_the_kernel_header_is_what_the_fit_script_derives():
+    """stamp_amd/csrc/common.h carries the erf polynomial of the GELU epilogue as literals; tools/gelu_poly_fit.py derives them (constrained
+    near-minimax fit, re-expansion in x^2, the ulp search that makes the fp32 FMA chain saturate at the clamp).  Same numbers, and the fp32
+    emulation of the kernel's arithmetic meets the bounds the header states: |error| <= 1.4e-5 |x|, <= 2.5e-8 |x| beyond the clamp."""
+    import re
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "gelu_poly_fit.py")], capture_output=True, text=True, check=True).stdout
+    want = [float(v.rstrip("f")) for v in re.search(r"GELU_R = \{([^}]*)\}", out).group(1).split(",")]
+    hdr = (root / "stamp_amd" / "csrc" / "common.h").read_text()
+    got = [float(v.strip().rstrip("f")) for v in re.search(r"GELU_R\[GELU_DEG \+ 1\] = \{([^}]*)\}", hdr, re.S).group(1).split(",")]
+    assert got == want and len(got) == 9
+    assert float(re.search(r"GELU_XMAX = ([0-9.]+)f", hdr).group(1)) == float(re.search(r"GELU_XMAX = ([0-9.]+)", out).group(1))
+    m = re.search(r"x\^2 form.*residue at the clamp ([0-9.e+-]+);.*max error / \|x\| = ([0-9.e+-]+);", out)
+    assert float(m.group(1)) < 2.5e-8 and float(m.group(2)) < 1.4e-5
