@@ -34,7 +34,11 @@ __device__ __forceinline__ f32x4 agpr_read(const f32x4& a) {
     return v;
 }
 
-template <typename T, int EPI, int P3 = 6, int P0 = 6, bool SPREAD = true>
+// PRL / PRS (AMDS_GEMM_PROBE builds only, kernel ids 21-23): the overlap probe of round 4.  Every K tile additionally issues PRL 16-byte
+// loads and PRS 16-byte stores per lane against a scratch region (ep.pos), spread behind the MFMAs of the third unit, and the K loop waits for
+// its operands with a COUNTED vmcnt so that this traffic stays in flight -- i.e. an epilogue's worth of HBM traffic perfectly overlapped with
+// the matrix pipe, on top of the unchanged real epilogue.  T(probe) - T(id 12) = what overlapped epilogue bytes would still cost.
+template <typename T, int EPI, int P3 = 6, int P0 = 6, bool SPREAD = true, int PRL = 0, int PRS = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
                  EpiArgs ep, int tiles_m, int tiles_n) {
@@ -248,9 +252,54 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         }
     };
 
+    // ---- overlap probe (PRL + PRS > 0): scratch traffic issued inside the K loop
+    constexpr int PRN = PRL + PRS, PRM = PRL > PRS ? PRL : PRS;
+    static_assert(PRN <= 8 && (PRN == 0 || SCHED == 0), "probe: at most 8 requests per K tile, SCHED 0 only");
+    i32x4 pdesc = i32x4{0, 0, 0, 0};
+    u32x4 pd[PRL > 0 ? PRL : 1];
+    if constexpr (PRN > 0) {
+        const long tile_bytes = (long)(K / BK) * 4096 * PRM;
+        const unsigned long base = reinterpret_cast<unsigned long>(ep.pos) + (unsigned long)blockIdx.x * tile_bytes;
+        pdesc = i32x4{(int)(unsigned)(base & 0xffffffffu), (int)(unsigned)((base >> 32) & 0xffffu), (int)tile_bytes, 0x00020000};
+        pdesc[0] = __builtin_amdgcn_readfirstlane(pdesc[0]);
+        pdesc[1] = __builtin_amdgcn_readfirstlane(pdesc[1]);
+        pdesc[2] = __builtin_amdgcn_readfirstlane(pdesc[2]);
+#pragma unroll
+        for (int q = 0; q < (PRL > 0 ? PRL : 1); ++q) pd[q] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const int pvoff = tid * 16;
+    auto unit_probe = [&](int s, int ih, int kt) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            Act<T>::mfma16_agpr(wf[s][m & 7], af[s][ih * 4 + (m >> 3)], acc[ih * 4 + (m >> 3)][m & 7]);
+            if constexpr (PRN > 0) {
+                if ((m & 3) == 0 && (m >> 2) < PRN) {
+                    const int q = m >> 2;
+                    int soff = (kt * PRM + (q < PRL ? q : q - PRL)) * 4096;
+                    if (q < PRL) {
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(pd[q < PRL ? q : 0]) : "v"(pvoff), "s"(pdesc), "s"(soff) : "memory");
+                    } else {
+                        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(wf[s][q & 7]), "v"(pvoff), "s"(pdesc), "s"(soff) : "memory");
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     auto k_tile = [&](int kt, auto next_c, auto next2_c) {
         constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
-        if constexpr (SCHED == 0) {
+        if constexpr (SCHED == 0 && PRN > 0) {
+            if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, Q3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
+            if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, Q3 + Q0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
+            unit_probe(1, 0, kt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRN) : "memory");   // the probe's requests of THIS tile may stay in flight
+            AMDS_BARRIER();
+            if constexpr (NEXT2) unit(1, 1, I16{}, kt + 1, 0, 0, 0, IP3{}, kt + 2, 0);
+            else if constexpr (NEXT) unit(1, 1, I16{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
+            else unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+        } else if constexpr (SCHED == 0) {
             if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, Q3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
             if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, Q3 + Q0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
             unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
@@ -302,6 +351,11 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         }
     }
     k_tile(kt, std::false_type{}, std::false_type{});
+    if constexpr (PRN > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < (PRL > 0 ? PRL : 1); ++q) asm volatile("" ::"v"(pd[q]));
+    }
     AMDS_BARRIER();                 // every wave is done with the LDS stages
 #undef AMDS_BARRIER
     // MFMA result -> accumulator read hazard: the compiler does not know the inline asm is an MFMA, so it neither pads the read of
@@ -604,14 +658,26 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     }
 }
 
-template <typename T, int EPI, bool SPREAD = true, int P3 = 6, int P0 = 6>
+template <typename T, int EPI, bool SPREAD = true, int P3 = 6, int P0 = 6, int PRL = 0, int PRS = 0>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st) {
     if constexpr (!epi_is_staged<EPI>() && EPI != AMDS_EPI_SWIGLU) {
         return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     } else {
         constexpr int LDS = 2 * (256 + 256) * 128;
-        auto kern = gemm_4w16_kernel<T, EPI, P3, P0, SPREAD>;
+        auto kern = gemm_4w16_kernel<T, EPI, P3, P0, SPREAD, PRL, PRS>;
+        EpiArgs epp = ep;
+        if constexpr (PRL + PRS > 0) {      // probe scratch: one region per workgroup, never read by anything real
+            static char* scratch = nullptr;
+            static size_t scratch_bytes = 0;
+            const size_t need = (size_t)cdiv(M, 256) * (N / 256) * (K / 64) * 4096 * (PRL > PRS ? PRL : PRS);
+            if (need > scratch_bytes) {
+                if (scratch) AMDS_HIP(hipFree(scratch));
+                AMDS_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), need));
+                scratch_bytes = need;
+            }
+            epp.pos = reinterpret_cast<const float*>(scratch);
+        }
         static bool attr_set = false;
         if (!attr_set) {
             AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -619,7 +685,7 @@ static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, in
         }
         const int tiles_m = cdiv(M, 256), tiles_n = N / 256;
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, ep.nbatch), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
-                           reinterpret_cast<const T*>(W), ldw, M, N, K, ep, tiles_m, tiles_n);
+                           reinterpret_cast<const T*>(W), ldw, M, N, K, epp, tiles_m, tiles_n);
         AMDS_LAUNCH_CHECK("gemm_4w16_kernel");
         return AMDS_OK;
     }

@@ -416,7 +416,7 @@ static int launch_gemm_8p64(const void* A, long lda, const void* W, long ldw, in
 template <typename T, int EPI>
 static int launch_gemm_4w64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w64.h
-template <typename T, int EPI, bool SPREAD, int P3, int P0>
+template <typename T, int EPI, bool SPREAD, int P3, int P0, int PRL, int PRS>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w16.h
 
@@ -433,8 +433,15 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
                        const EpiArgs& ep, hipStream_t st) {
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
-    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6>(A, lda, W, ldw, M, N, K, ep, st);
-    if (cfg == 13 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, -2, 0>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 0>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 13 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, -2, 0, 0, 0>(A, lda, W, ldw, M, N, K, ep, st);
+#ifdef AMDS_GEMM_PROBE      // overlap probe of round 4 (gemm_4w16.h PRL / PRS; make PROBE=1): K-loop traffic of (0, 2) / (1, 1) / (4, 4) loads, stores per lane and K tile
+    if constexpr (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_RESIDUAL) {
+        if (cfg == 21 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 2>(A, lda, W, ldw, M, N, K, ep, st);
+        if (cfg == 22 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 1, 1>(A, lda, W, ldw, M, N, K, ep, st);
+        if (cfg == 23 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 4, 4>(A, lda, W, ldw, M, N, K, ep, st);
+    }
+#endif
     if (cfg == 12 || cfg == 13) cfg = 8;
 
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
