@@ -33,7 +33,8 @@ typedef enum {
     AMDS_ERR_INVALID = -1,   /* bad argument / unsupported shape */
     AMDS_ERR_WORKSPACE = -2, /* workspace too small */
     AMDS_ERR_HIP = -3,       /* a HIP runtime call failed */
-    AMDS_ERR_NODEVICE = -4   /* no gfx950 device visible */
+    AMDS_ERR_NODEVICE = -4,  /* no gfx950 device visible */
+    AMDS_ERR_RANGE = -5      /* amds_check_finite: a result holds non-finite values (an intermediate left the 16-bit range) */
 } amds_status;
 
 typedef enum { AMDS_F16 = 0, AMDS_BF16 = 1, AMDS_F32 = 2 } amds_dtype;
@@ -416,6 +417,16 @@ size_t amds_vit_workspace_diag_offset(const amds_vit_cfg* cfg_host, int batch);
 int amds_vit_forward(const amds_vit_cfg* cfg_host, const amds_vit_weights* w_host,
                      const uint8_t* tiles, void* feats_f16, int B, int chunk,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* The guard a host runs over features BEFORE it persists them (the reference writes `model(tiles)[:, 0].half()` straight into the .h5,
+ * src/stamp/preprocessing/__init__.py:324-345; its per-slide try/except :328-336 is the only place an error can surface).  Counts the
+ * non-finite values among x[0..n) (dtype 0 = f16, 1 = bf16, 2 = f32) into *count_dev (device int, zeroed by this call), copies the count to
+ * *count_host and SYNCHRONISES `stream` (the one call of the tile-encoder API that does).  AMDS_OK if it is 0, AMDS_ERR_RANGE otherwise:
+ * the 16-bit activation formats of the fast path hold |x| <= 65504 (f16); a checkpoint with larger intermediates (massive-activation
+ * channels) turns the affected tiles' features into NaN -- every overflow propagates to the class row through the attention -- so a zero
+ * count is also the proof that no intermediate of the call overflowed.  On AMDS_ERR_RANGE re-run the tiles with a packing that keeps
+ * fp32 residual rows (amds_vit_pack without AMDS_PACK_LNFOLD) or bf16 activations; `stamp_amd.vit.HipViT` does so by itself. */
+int amds_check_finite(const void* x, long n, int dtype, int* count_dev, int* count_host, void* stream);
 
 /* Same, but also returns the final-LayerNorm'd tokens (fp32 [B][T][dim]) for parity checks and for
  * CLS (+) mean-patch extractors (reference src/stamp/preprocessing/extractor/virchow_full.py:30-35).

@@ -14,6 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libamdstamp.so"
 
 F16, BF16, F32 = 0, 1, 2
+ERR_RANGE = -5          # amds_check_finite: non-finite values in a result
 (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_RESIDUAL, EPI_BIAS_F32, EPI_SWIGLU, EPI_PATCH,
  EPI_BIAS_GELU_F32, EPI_BIAS_RELU_F32) = range(9)
 
@@ -191,6 +192,7 @@ PROTOTYPES = {
     "amds_ln_rowstat": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "amds_ln_rowstat_diag": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "amds_vit_workspace_diag_offset": (_sz, [_vp, _i]),
+    "amds_check_finite": (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     "amds_ln_stats_cast": (_i, [_vp, _l, _i, _i, _f, _vp, _l, _vp, _i, _vp]),
     "amds_gemm_lnfold_planes": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp]),
     "amds_ln_stats_split": (_i, [_vp, _l, _i, _i, _f, _vp, _vp, _l, _vp, _vp]),

@@ -551,3 +551,40 @@ extern "C" int amds_quick_gelu_inplace(void* u, long ld, long rows, int cols, in
     AMDS_LAUNCH_CHECK("quick_gelu_inplace_kernel");
     return AMDS_OK;
 }
+
+// ---- amds_check_finite: the guard in front of the feature file (include/amdstamp.h) ----
+namespace amds {
+template <typename T>
+__global__ void __launch_bounds__(256) count_nonfinite_kernel(const T* __restrict__ x, long n, int* __restrict__ count) {
+    int bad = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = (float)x[i];
+        bad += !(fabsf(v) <= 3.402823466e38f);          // NaN compares false, +-inf exceeds FLT_MAX
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+}  // namespace amds
+
+extern "C" int amds_check_finite(const void* x, long n, int dtype, int* count_dev, int* count_host, void* stream) {
+    using namespace amds;
+    AMDS_REQUIRE(count_dev && count_host && n >= 0 && (x || n == 0), "amds_check_finite: bad arguments");
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16 || dtype == AMDS_F32, "amds_check_finite: dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    AMDS_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), st));
+    if (n > 0) {
+        const int grid = (int)((n + 256 * 8 - 1) / (256 * 8) < 2048 ? (n + 256 * 8 - 1) / (256 * 8) : 2048);
+        if (dtype == AMDS_F16) hipLaunchKernelGGL(count_nonfinite_kernel<_Float16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const _Float16*>(x), n, count_dev);
+        else if (dtype == AMDS_BF16) hipLaunchKernelGGL(count_nonfinite_kernel<__bf16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16*>(x), n, count_dev);
+        else hipLaunchKernelGGL(count_nonfinite_kernel<float>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float*>(x), n, count_dev);
+        AMDS_LAUNCH_CHECK("count_nonfinite_kernel");
+    }
+    AMDS_HIP(hipMemcpyAsync(count_host, count_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    AMDS_HIP(hipStreamSynchronize(st));
+    if (*count_host != 0) {
+        set_error("amds_check_finite: %d of %ld values are not finite (an intermediate left the 16-bit activation range)", *count_host, n);
+        return AMDS_ERR_RANGE;
+    }
+    return AMDS_OK;
+}

@@ -55,7 +55,7 @@ def hip_dinobloom_extractor(state_dict: dict[str, torch.Tensor], *, identifier: 
 class HipKeep(torch.nn.Module):
     """`KEEPImageModel` of the reference (src/stamp/preprocessing/extractor/keep.py:25-50): timm ViT-L/16 trunk, then `visual_head` (Linear, GELU,
     Linear) and an L2 normalisation -- trunk = the ViT-L/16 preset, head = ONE library call in exact fp32 (`amds_proj_head_l2norm`) on the trunk's
-    stored fp16 class features.  `state_dict`: the checkpoint's `visual.*` / `visual_head.*` entries (:83-88); LayerScale keys named `.ls1.weight`
+    fp32 class row (the reference's head sees the trunk's fp32 output, keep.py:44-49; rounding it to half first would add 2^-11 in front of a GELU MLP).  `state_dict`: the checkpoint's `visual.*` / `visual_head.*` entries (:83-88); LayerScale keys named `.ls1.weight`
     are accepted like the reference's `_remap_layerscale_keys` does (:53-59).  Output fp32 [B, projection_dim] (the reference's loop casts to half)."""
 
     def __init__(self, state_dict: dict[str, torch.Tensor], *, device="cuda", chunk: int = 1020, vit_cfg: ViTConfig | None = None) -> None:
@@ -80,7 +80,8 @@ class HipKeep(torch.nn.Module):
     @torch.no_grad()
     def forward(self, tiles: torch.Tensor) -> torch.Tensor:
         from . import _lib, ops
-        feats = self.vit(tiles)                                      # fp16 [B, dim]
+        _, toks = self.vit(tiles, return_tokens=True)                # fp32 [B, T, dim], final norm applied
+        feats = toks[:, 0].contiguous()                               # the class row, fp32 as the reference's head receives it
         B, dev = feats.shape[0], feats.device
         out = torch.empty(B, self.proj_dim, dtype=torch.float32, device=dev)
         lib = _lib.lib()

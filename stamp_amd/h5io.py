@@ -294,12 +294,50 @@ def _np(x) -> np.ndarray:
 
 def _pep440(stamp_version) -> str:
     """The reference parses `stamp_version` with `packaging.version.Version` (modeling/data.py:793-795): refuse anything it would choke on."""
-    from packaging.version import InvalidVersion, Version
-    try:
-        Version(str(stamp_version))
-    except InvalidVersion as e:
-        raise ValueError(f"stamp_version must be a PEP 440 version string (STAMP parses it with packaging.Version), got {stamp_version!r}") from e
+    if not _is_pep440(str(stamp_version)):
+        raise ValueError(f"stamp_version must be a PEP 440 version string (STAMP parses it with packaging.Version), got {stamp_version!r}")
     return str(stamp_version)
+
+
+def _version_newer(a: str, b: str) -> bool:
+    """a > b as the reference compares them (packaging's Version); without `packaging`: by release tuple, a pre- / dev-release below its release."""
+    try:
+        from packaging.version import Version
+        return Version(a) > Version(b)
+    except ImportError:
+        def key(v):
+            m = _is_pep440(v) and _PEP440_RE.match(v)
+            if not m:
+                raise ValueError(f"not a PEP 440 version: {v!r}")
+            rel = [int(x) for x in m.group("release").split(".")]
+            while len(rel) > 1 and rel[-1] == 0:
+                rel.pop()
+            return (int(m.group("epoch") or 0), tuple(rel), 0 if (m.group("dev") or m.group("pre")) else (2 if m.group("post") else 1))
+        return key(a) > key(b)
+
+
+# PEP 440, appendix B ("Parsing version strings with regular expressions"): what packaging.version.Version accepts.  Used when `packaging` is not
+# importable (a bare GPU box: h5min needs nothing but numpy, and so must the attribute check in front of it).
+_PEP440_RE = None
+
+
+def _is_pep440(v: str) -> bool:
+    try:
+        from packaging.version import InvalidVersion, Version
+    except ImportError:
+        global _PEP440_RE
+        if _PEP440_RE is None:
+            import re
+            _PEP440_RE = re.compile(
+                r"^\s*v?(?:(?:(?P<epoch>[0-9]+)!)?(?P<release>[0-9]+(?:\.[0-9]+)*)(?P<pre>[-_\.]?(?P<pre_l>alpha|a|beta|b|preview|pre|c|rc)[-_\.]?(?P<pre_n>[0-9]+)?)?"
+                r"(?P<post>(?:-(?P<post_n1>[0-9]+))|(?:[-_\.]?(?P<post_l>post|rev|r)[-_\.]?(?P<post_n2>[0-9]+)?))?"
+                r"(?P<dev>[-_\.]?(?P<dev_l>dev)[-_\.]?(?P<dev_n>[0-9]+)?)?)(?:\+(?P<local>[a-z0-9]+(?:[-_\.][a-z0-9]+)*))?\s*$", re.IGNORECASE)
+        return _PEP440_RE.match(v) is not None
+    try:
+        Version(v)
+        return True
+    except InvalidVersion:
+        return False
 
 
 def _build_attrs(amdstamp_version) -> dict:
@@ -382,9 +420,8 @@ def get_coords(datasets: dict[str, np.ndarray], attrs: dict) -> CoordsInfo:
     elif round(attrs.get("tile_size", _stride(coords))) == 224:   # historic format: coordinates in units of 256 um / 224 px
         tile_um, tile_px, coords_um = 256.0, 224, coords / 224 * 256
     if attrs.get("stamp_version"):                             # a file from a newer STAMP than the format this package speaks is refused (:793-799)
-        from packaging.version import Version
-        if Version(str(attrs["stamp_version"])) > Version(STAMP_FORMAT):
-            raise RuntimeError(f"features were extracted with a newer version of stamp, please update your stamp to at least version {Version(str(attrs['stamp_version']))}.")
+        if _version_newer(str(attrs["stamp_version"]), STAMP_FORMAT):
+            raise RuntimeError(f"features were extracted with a newer version of stamp, please update your stamp to at least version {attrs['stamp_version']}.")
     if not tile_px and "tile_size_px" in attrs:
         tile_px = int(attrs["tile_size_px"])
     if not tile_um or coords_um is None:

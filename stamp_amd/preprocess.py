@@ -78,7 +78,10 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     if not origins:
         return stats
     model = extractor.model
-    spb, kk, t = int(supertiles_per_batch), k * k, int(tile_size_px)
+    kk, t = k * k, int(tile_size_px)
+    # amds_compact_rows_u8 takes at most 4096 tiles per call: a low-resolution slide (k = 9 from mpp 2.25 on: 81 tiles per supertile) gets
+    # fewer supertiles per batch instead of an AMDS_ERR_INVALID on every batch
+    spb = max(1, min(int(supertiles_per_batch), 4096 // kk))
     chunk = int(encode_chunk or getattr(model, "chunk", 1020))
     row_bytes = t * t * 3
     # pinned ring: four batches (one being consumed, up to three being decoded)
@@ -203,6 +206,14 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
             cur = other
             encoded += m
 
+        # the encoder's own per-call guard (vit.HipViT.check: one read-back + synchronisation per call) is deferred: the slide's features are
+        # checked once, below, before anything is written
+        guarded = [m for m in model.modules() if hasattr(m, "defer_check")] if hasattr(model, "modules") else []
+        prev_defer = [m.defer_check for m in guarded]
+        for m in guarded:
+            m.defer_check = True
+            if hasattr(m, "range_diagnostics"):
+                m.range_diagnostics(reset=True)
         try:
             reader_done = False
             while not reader_done:
@@ -263,6 +274,8 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
             while kept_known - encoded > 0:
                 encode(min(chunk, kept_known - encoded))
         finally:
+            for m, d in zip(guarded, prev_defer):
+                m.defer_check = d
             stop.set()
             while th.is_alive():                        # unblock a producer waiting for a free buffer
                 try:
@@ -283,6 +296,27 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     feats = torch.cat([p[0] for p in feats_parts])
     coords = np.concatenate(coords_parts)
     stats["tiles_kept"] = int(feats.shape[0])
+    # Nothing non-finite reaches the file (the reference writes whatever its model returned, __init__.py:338-345).  A tile encoder with a safer
+    # packing to offer (vit.HipViT: LayerNorm un-folded / bf16) is moved one level up and the slide is run again; otherwise the slide raises and
+    # STAMP's per-slide try/except skips it (:328-336).
+    why = None
+    if not bool(torch.isfinite(feats).all()):
+        why = f"{int((~torch.isfinite(feats)).any(dim=1).sum())} of {feats.shape[0]} tiles have non-finite features"
+    else:
+        for m in guarded:      # finite, but rows with |mean| > 8 sigma went through a folded LayerNorm (vit.HipViT.call_verdict)
+            d = m.range_diagnostics(reset=True) if getattr(m, "safe_level", 1) == 0 and hasattr(m, "range_diagnostics") else {}
+            if d.get("rows_mean_over_8_sigma"):
+                why = f"{d['rows_mean_over_8_sigma']} rows with |mean| > 8 sigma entered a folded LayerNorm (precision loss ~ |mean| / sigma)"
+    if why is not None:
+        from .vit import FeatureRangeError
+        moved = [m.enable_safe_mode(why) for m in guarded if getattr(m, "check", "raise") == "fallback"]
+        if any(moved):
+            stats_retry = extract_slide(slide, extractor, output_path, slide_mpp=slide_mpp, tile_size_um=tile_size_um, tile_size_px=tile_size_px,
+                                        max_supertile_size_slide_px=max_supertile_size_slide_px, brightness_cutoff=brightness_cutoff, canny_cutoff=canny_cutoff,
+                                        max_workers=max_workers, supertiles_per_batch=supertiles_per_batch, encode_chunk=encode_chunk, device=device)
+            stats_retry["range_retries"] = stats_retry.get("range_retries", 0) + 1
+            return stats_retry
+        raise FeatureRangeError(f"extract_slide: {why} ({extractor.identifier}); nothing written")
     t_ = _time.perf_counter()
     _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px)
     stats["write_s"] = round(_time.perf_counter() - t_, 3)

@@ -13,6 +13,7 @@ up with: virchow2.py:34-39, uni2.py:17-34, reddino.py:40-45, uni.py:26-31).
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass, field, replace
 
@@ -115,6 +116,8 @@ PRESETS: dict[str, ViTConfig] = {
     # small shapes for tests
     "test_tiny": ViTConfig(dim=128, depth=2, heads=2, hidden=256),
     "test_tiny_swiglu": ViTConfig(dim=128, depth=2, heads=2, hidden=192, mlp="swiglu", reg_tokens=4, no_embed_class=True),
+    # the smallest shape the DEFAULT path of the full-size presets takes (LayerNorm folded, hi | lo residual planes, class-row tail: dim % 256 == 0)
+    "test_tiny_fold": ViTConfig(dim=256, depth=4, heads=4, hidden=512),
 }
 
 
@@ -190,13 +193,31 @@ def host_weights(cfg: ViTConfig, sd: dict[str, torch.Tensor]):
     return hw, keep
 
 
+class FeatureRangeError(RuntimeError):
+    """The features of a call hold non-finite values: an intermediate of the network left the range of the 16-bit activation format and no
+    safer packing is left to fall back to.  Raised instead of returning NaNs -- STAMP's per-slide try/except
+    (src/stamp/preprocessing/__init__.py:328-336) then logs and skips the slide instead of writing them into an .h5."""
+
+
 class HipViT(nn.Module):
     """timm VisionTransformer forward on libamdstamp; eval/inference only (tile extraction never trains)."""
 
     def __init__(self, cfg: ViTConfig, state_dict: dict[str, torch.Tensor], *, device="cuda",
                  act_dtype: torch.dtype = torch.float16, chunk: int = 1020, ln_fold: bool | None = None,
-                 patch_split: bool | None = None, exact: bool = False, fp8: bool = False, cls_tail: bool | None = None) -> None:
-        """exact=True (opt-in): the class-token row -- the only row the reference stores, `model(tiles)[:, 0].half()` -- is ALSO carried on
+                 patch_split: bool | None = None, exact: bool = False, fp8: bool = False, cls_tail: bool | None = None,
+                 check: str = "fallback") -> None:
+        """check: what happens when a call's features come out non-finite (`amds_check_finite`, one 4-byte read-back per call; the fast path
+        keeps the residual stream as two fp16 planes and un-normalised fp16 rows as GEMM operands, so a checkpoint whose residual stream
+        leaves +-65504 -- massive-activation channels -- overflows there, and every overflow reaches the class row as NaN):
+          "fallback" (default)  re-pack on a safer level and re-run the call, permanently for this object, with one warning:
+                                level 1 = LayerNorm un-folded, fp32 residual rows (same 16-bit operands otherwise);
+                                level 2 = bf16 activations on top (fp32 range, 8 bits of mantissa: outside the 1e-3 parity bar, said so in the warning);
+                                then FeatureRangeError.
+          "raise"               FeatureRangeError at once (the slide is skipped by STAMP's per-slide try/except).
+          "off"                 no check (benchmark A/B only).
+        The pipelined `preprocess.extract_slide` sets `defer_check` while it runs and checks the whole slide's features once, before the file is written.
+
+        exact=True (opt-in): the class-token row -- the only row the reference stores, `model(tiles)[:, 0].half()` -- is ALSO carried on
         an exact-fp32 class stream (fp32 MFMA, the original un-folded fp32 weights: include/amdstamp.h `amds_vit_exact_block`,
         csrc/vit_exact.hip) and written over the main path's class rows after every sub-layer.  Costs the fp32 weights in HBM (4 bytes per
         parameter of q / proj / fc1 / fc2) and ~10 % of the throughput; lowers the stored feature's error ~3x.
@@ -208,9 +229,17 @@ class HipViT(nn.Module):
         super().__init__()
         if cfg.dim % cfg.heads or cfg.dim // cfg.heads not in (64, 80):
             raise ValueError(f"head_dim must be 64 or 80 (dim={cfg.dim}, heads={cfg.heads})")
+        if check not in ("fallback", "raise", "off"):
+            raise ValueError(f"check must be 'fallback', 'raise' or 'off', not {check!r}")
         self.cfg = cfg
         self.act_dtype = act_dtype
         self.chunk = int(chunk)
+        self.check = check
+        self.defer_check = False        # set by a caller that checks the features itself, once, later (preprocess.extract_slide)
+        self.safe_level = 0             # 0 = as constructed; 1 / 2: see `check`
+        self._safe: "HipViT | None" = None
+        self._sd_ref = state_dict       # kept (by reference) for the safe re-pack
+        self._ctor = dict(device=device, chunk=chunk, patch_split=patch_split, exact=exact, cls_tail=cls_tail)
         self.overlap = False            # two chunks in flight on two streams (amds_vit_forward_overlapped)
         self.device_ = torch.device(device)
         if self.device_.type != "cuda":
@@ -356,9 +385,72 @@ class HipViT(nn.Module):
         u8 = ((tiles.float() * std + mean) * 255.0).round().clamp(0, 255).to(torch.uint8)
         return u8.permute(0, 2, 3, 1).contiguous()
 
+    # -- the guard in front of the feature file ----------------------------------------------------
+    def features_finite(self, feats: torch.Tensor) -> bool:
+        """`amds_check_finite` over a feature tensor on the GPU (synchronises the current stream)."""
+        if feats.numel() == 0:
+            return True
+        if getattr(self, "_cnt", None) is None:
+            self._cnt = torch.zeros(1, dtype=torch.int32, device=self.device_)
+        host = (C.c_int * 1)()
+        rc = _lib.lib().amds_check_finite(feats.data_ptr(), feats.numel(), {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[feats.dtype],
+                                          self._cnt.data_ptr(), host, torch.cuda.current_stream().cuda_stream)
+        if rc == _lib.ERR_RANGE:
+            return False
+        _lib.check(rc, "check_finite")
+        return True
+
+    def enable_safe_mode(self, why: str = "non-finite features") -> bool:
+        """Moves this object one level up the ladder of `check` (re-packs from the kept state_dict); False when there is no level left."""
+        import warnings
+        cur = self._safe if self._safe is not None else self
+        if self.fp8 or cur.act_dtype == torch.bfloat16 and not cur.ln_fold:
+            return False
+        if cur.ln_fold:
+            level, kw, what = 1, dict(act_dtype=cur.act_dtype, ln_fold=False), "LayerNorm un-folded, fp32 residual rows"
+        else:
+            level, kw, what = 2, dict(act_dtype=torch.bfloat16, ln_fold=False), "bf16 activations (fp32 range, 8-bit mantissa: outside the 1e-3 parity bar)"
+        if self.cfg.mlp == "quick_gelu" and level == 1:
+            level, kw, what = 2, dict(act_dtype=torch.bfloat16, ln_fold=False), "bf16 activations (fp32 range, 8-bit mantissa: outside the 1e-3 parity bar)"
+        warnings.warn(f"HipViT: {why} on the {'default' if self.safe_level == 0 else 'level-%d' % self.safe_level} path; re-packing on safe level {level}: "
+                      f"{what}.  Range counters of the folded LayerNorms: {self.range_diagnostics()}", RuntimeWarning, stacklevel=3)
+        self._safe = None
+        torch.cuda.empty_cache()
+        self._safe = HipViT(self.cfg, self._sd_ref, check="off", **kw, **self._ctor)
+        self.safe_level = level
+        return True
+
     @torch.no_grad()
     def forward(self, tiles: torch.Tensor, return_tokens: bool = False):
         """tiles: u8 [B,H,W,3] (preferred) or normalised float [B,3,H,W] on the GPU -> fp16 [B,D]."""
+        while True:
+            m = self._safe if self._safe is not None else self
+            m.chunk, m.overlap = self.chunk, self.overlap
+            out = m._forward(tiles, return_tokens)
+            if self.check == "off" or self.defer_check:
+                return out
+            why = self.call_verdict(out[0] if return_tokens else out)
+            if why is None:
+                return out
+            if self.check == "raise" or not self.enable_safe_mode(why):
+                raise FeatureRangeError(f"HipViT: {why} (safe level {self.safe_level}; range counters {self.range_diagnostics()})")
+
+    def call_verdict(self, feats: torch.Tensor) -> str | None:
+        """None when the features of the call(s) since the last verdict can be stored; otherwise the reason they cannot: non-finite values (an
+        intermediate overflowed the 16-bit activation format), or -- on the LayerNorm-folded path only -- rows whose |mean| exceeds 8 sigma entered a
+        folded LayerNorm (`amds_ln_rowstat_diag`): the folded form subtracts mean * colsum AFTER the product, which costs |mean| / sigma in
+        relative precision there (finite, but outside the parity bar).  Synchronises; resets the counters it read."""
+        if not self.features_finite(feats):
+            return "non-finite features: an intermediate of this checkpoint leaves the 16-bit activation range"
+        if self._safe is None and self.ln_fold and self._ws is not None and getattr(self, "_ws_chunk", None) is not None:
+            d = self.range_diagnostics(reset=False)
+            if d["rows_mean_over_8_sigma"]:
+                self._diag_view(self._ws_chunk).zero_()
+                return f"{d['rows_mean_over_8_sigma']} rows with |mean| > 8 sigma entered a folded LayerNorm (precision loss ~ |mean| / sigma)"
+        return None
+
+    @torch.no_grad()
+    def _forward(self, tiles: torch.Tensor, return_tokens: bool = False):
         if not tiles.is_cuda:
             raise RuntimeError("HipViT.forward needs tiles on the GPU (no CPU fallback)")
         c = self.cfg
@@ -461,6 +553,14 @@ def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate")
                    oracle differ by ~5e-7 (about 9x the fp32 epsilon) on ViT-L/14.  The parity bar is stated on it.
     init="stress": same but qkv gain 2 and LayerScale ~0.5 -> sharp attention, a CHAOTIC map: fp32 vs fp64 of the
                    oracle already differ by 1.1e-5 (180x epsilon), i.e. any rounding is amplified ~180x.
+    init="massive": "moderate" with the two statistics real DINOv2-family checkpoints are known for and random init lacks
+                   (Sun et al., "Massive Activations in LLMs" / Darcet et al., "Vision Transformers Need Registers"): (a) a few residual
+                   CHANNELS carrying values 1e2 ... 1e4 x the median -- three channels of the class token (1e2, 1e3, 1e4 from the embedding on,
+                   so the stored row itself is a massive-activation row through every block) and two channels of EVERY token switched on by the
+                   fc2 bias of the block at 2/3 depth (3e2, 3e3), so the late blocks' LayerNorms, operands and residual updates all see them;
+                   (b) LayerScale gammas log-uniform over [1e-5, 1] instead of ~0.3.  Everything stays inside fp16's range.
+    init="overflow": "massive" with one channel of every token driven past fp16's maximum (1e5) at 2/3 depth: the fast path cannot
+                   represent this residual stream -- its features must come out through the guard (`HipViT(check=...)`), never as NaN.
     """
     g = torch.Generator().manual_seed(seed)
     D, p = cfg.dim, cfg.patch
@@ -470,8 +570,9 @@ def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate")
     def rn(*shape, s=1.0):
         return torch.randn(*shape, generator=g) * s
 
-    assert init in ("timm", "moderate", "stress")
-    stress = init in ("stress", "moderate")
+    assert init in ("timm", "moderate", "stress", "massive", "overflow")
+    massive = init in ("massive", "overflow")
+    stress = init in ("stress", "moderate") or massive
     qgain, lsm = (2.0, 0.5) if init == "stress" else (1.0, 0.3)
     ws = (lambda fan_in: 1.0 / fan_in ** 0.5) if stress else (lambda fan_in: 0.02)
     bs = 0.1 if stress else 0.0
@@ -502,8 +603,21 @@ def random_vit_state_dict(cfg: ViTConfig, seed: int = 0, init: str = "moderate")
             sd[pre + "ls2.gamma"] = (lsm + rn(D, s=0.1 * lsm / 0.5)) if stress else torch.full((D,), 1e-5)
     sd["norm.weight"] = 1.0 + rn(D, s=0.2 if stress else 0.0)
     sd["norm.bias"] = rn(D, s=bs)
+    if massive:
+        ch = torch.randperm(D, generator=g)[:6].tolist()
+        for c_, v in zip(ch[:3], (1.0e2, -1.0e3, 1.0e4)):
+            sd["cls_token"][0, 0, c_] = v
+        k0 = (2 * cfg.depth) // 3
+        if cfg.layerscale:
+            for i in range(cfg.depth):
+                for n in ("ls1.gamma", "ls2.gamma"):
+                    sd[f"blocks.{i}.{n}"] = torch.exp(torch.rand(D, generator=g) * math.log(1.0e5) - math.log(1.0e5))     # log-uniform [1e-5, 1]
+        big = [(ch[3], 3.0e2), (ch[4], -3.0e3)] + ([(ch[5], 1.0e5)] if init == "overflow" else [])
+        for c_, v in big:      # the residual stream gains ls2[c] * fc2.bias[c] = v in channel c of every token
+            ls = float(sd[f"blocks.{k0}.ls2.gamma"][c_]) if cfg.layerscale else 1.0
+            sd[f"blocks.{k0}.mlp.fc2.bias"][c_] = v / ls
     return sd
 
 
-__all__ = ["ViTConfig", "PRESETS", "HipViT", "HipViTClsMean", "random_vit_state_dict", "packed_weight_bytes", "expected_state_dict_shapes",
+__all__ = ["ViTConfig", "PRESETS", "HipViT", "FeatureRangeError", "HipViTClsMean", "random_vit_state_dict", "packed_weight_bytes", "expected_state_dict_shapes",
            "validate_state_dict", "replace", "field"]

@@ -258,3 +258,34 @@ def test_get_coords_equals_the_references_own_function():
         ci = h5io.get_coords(ds, rec["attrs"])
         assert np.array_equal(np.asarray(ci.coords_um, dtype=np.float32), np.asarray(rec["coords_um"], dtype=np.float32)), name
         assert float(ci.tile_size_um) == rec["tile_size_um"] and ci.tile_size_px == rec["tile_size_px"], name
+
+
+def test_version_checks_without_packaging(monkeypatch):
+    """A bare GPU box may lack `packaging`: the PEP 440 check in front of every write and the newer-than comparison in get_coords fall back to
+    the PEP's own regular expression and a release-tuple comparison, with the same answers."""
+    import builtins
+
+    from packaging.version import InvalidVersion, Version
+
+    cases = ["2.4.0", "2.4.0.dev1", "1.0rc1", "v1.2", "abc", "2.4.0+local.1", "1..2", "2.5", "2.5.0.post1", "1!0.3", ""]
+    want = {}
+    for v in cases:
+        try:
+            Version(v)
+            want[v] = True
+        except InvalidVersion:
+            want[v] = False
+    real = builtins.__import__
+
+    def no_packaging(name, *a, **k):
+        if name.split(".")[0] == "packaging":
+            raise ImportError(name)
+        return real(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", no_packaging)
+    for v in cases:
+        assert h5io._is_pep440(v) == want[v], v
+    for a, b in (("2.5.0", "2.4.0"), ("2.4.0", "2.4.0"), ("2.4.0.dev3", "2.4.0"), ("2.4.0.post1", "2.4"), ("2.4", "2.4.0"), ("2.10", "2.9.1")):
+        assert h5io._version_newer(a, b) == (Version(a) > Version(b)), (a, b)
+    with pytest.raises(ValueError):
+        h5io._pep440("not a version")

@@ -204,3 +204,76 @@ def test_gigapath_extractor_runs_the_transform_in_front_of_the_trunk(gpu):
     ref = extract_features(torch.from_numpy(pil), sd, cfg).float()
     rel = ((out - ref).norm() / ref.norm()).item()
     assert out.shape == (4, 128) and rel < 1e-3, rel
+
+
+def _fake_slide(w, h, seed):
+    from PIL import Image
+    rgb = ot.synthetic_slide(w, h, seed)
+
+    class Slide:                                   # openslide's surface, as tools/make_golden.py::FakeSlide
+        dimensions = (w, h)
+        _im = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]), "RGBA")
+
+        def read_region(self, loc, level, size):
+            out = Image.new("RGBA", size, (0, 0, 0, 0))
+            out.paste(self._im.crop((loc[0], loc[1], min(loc[0] + size[0], w), min(loc[1] + size[1], h))), (0, 0))
+            return out
+
+        def get_thumbnail(self, size):
+            bg = Image.new("RGB", self._im.size, "#ffffff")
+            t = Image.composite(self._im, bg, self._im)
+            t.thumbnail(tuple(int(v) for v in size), Image.Resampling.LANCZOS)
+            return t
+    return Slide()
+
+
+def test_extract_slide_low_resolution_slide_many_tiles_per_supertile(gpu, tmp_path):
+    """mpp 4: k = floor(1024 * 4 / 256) = 16, 256 tiles per supertile -- the default 64 supertiles per batch would hand 16 384 tiles to one
+    compaction call (limit 4096): the batch is clamped instead, and the file equals the serial path's."""
+    from stamp_amd import h5io
+    from stamp_amd.extractor import hip_vit_extractor
+    from stamp_amd.preprocess import extract_slide, extract_slide_serial
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+
+    ex = hip_vit_extractor("test_tiny", random_vit_state_dict(PRESETS["test_tiny"], seed=3), device=gpu, chunk=64, identifier="amdstamp-test")
+    slide = _fake_slide(2304, 2048, 5)
+    a, b = tmp_path / "pipe.h5", tmp_path / "serial.h5"
+    st = extract_slide(slide, ex, a, slide_mpp=4.0, brightness_cutoff=250, canny_cutoff=None, device=gpu)
+    extract_slide_serial(slide, ex, b, slide_mpp=4.0, brightness_cutoff=250, canny_cutoff=None, supertiles_per_batch=2, device=gpu)
+    fa, ca, _ = h5io.read_tile_features(a)
+    fb, cb, _ = h5io.read_tile_features(b)
+    assert st["tiles_seen"] >= 2 * 256 and st["tiles_kept"] == fa.shape[0] > 0
+    assert np.array_equal(fa.view(np.uint16), fb.view(np.uint16)) and np.array_equal(ca.coords_um, cb.coords_um)
+
+
+def test_extract_slide_never_writes_non_finite_features(gpu, tmp_path):
+    """A checkpoint whose residual stream leaves fp16's range (random_vit_state_dict(init="overflow")): the pipelined path defers the encoder's
+    per-call guard, checks the slide's features once, moves the encoder to its safe packing and runs the slide again (one warning); with
+    check="raise" the slide raises and no file appears (STAMP's per-slide try/except skips it, preprocessing/__init__.py:328-336)."""
+    import warnings
+
+    from stamp_amd import h5io
+    from stamp_amd.extractor import Extractor, hip_vit_extractor, u8_tile_transform
+    from stamp_amd.preprocess import extract_slide, extract_slide_serial
+    from stamp_amd.vit import PRESETS, FeatureRangeError, HipViT, random_vit_state_dict
+
+    cfg = PRESETS["test_tiny_fold"]
+    sd = random_vit_state_dict(cfg, seed=13, init="overflow")
+    slide = _fake_slide(1536, 1024, 6)
+    strict = Extractor(model=HipViT(cfg, sd, device=gpu, chunk=16, check="raise"), transform=u8_tile_transform, identifier="strict")
+    with pytest.raises(FeatureRangeError):
+        extract_slide(slide, strict, tmp_path / "strict.h5", slide_mpp=0.5, brightness_cutoff=250, canny_cutoff=None, device=gpu)
+    assert not (tmp_path / "strict.h5").exists()
+    ex = hip_vit_extractor("test_tiny_fold", sd, device=gpu, chunk=16, identifier="amdstamp-test")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        st = extract_slide(slide, ex, tmp_path / "a.h5", slide_mpp=0.5, brightness_cutoff=250, canny_cutoff=None, device=gpu)
+    assert st["range_retries"] == 1 and ex.model.safe_level == 1 and sum("safe level 1" in str(x.message) for x in w) == 1
+    fa, ca, _ = h5io.read_tile_features(tmp_path / "a.h5")
+    assert fa.shape[0] == st["tiles_kept"] > 0 and np.isfinite(fa.astype(np.float32)).all()
+    ex2 = hip_vit_extractor("test_tiny_fold", sd, device=gpu, chunk=16, identifier="amdstamp-test")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        extract_slide_serial(slide, ex2, tmp_path / "b.h5", slide_mpp=0.5, brightness_cutoff=250, canny_cutoff=None, supertiles_per_batch=2, device=gpu)
+    fb, cb, _ = h5io.read_tile_features(tmp_path / "b.h5")
+    assert np.array_equal(fa.view(np.uint16), fb.view(np.uint16)) and np.array_equal(ca.coords_um, cb.coords_um)

@@ -173,18 +173,33 @@ def test_folded_layernorm_range_diagnostics(gpu):
     assert m.range_diagnostics() == {"rows_beyond_fp16_range_possible": 0, "rows_mean_over_8_sigma": 0} and torch.isfinite(f.float()).all()
     bad = {k: v.clone() for k, v in sd.items()}
     bad["blocks.0.attn.proj.bias"][7] = 3.0e5 / 0.3          # one massive channel after the first attention branch (LayerScale ~0.3)
-    mb = HipViT(cfg, bad, device=gpu, chunk=3)
+    mb = HipViT(cfg, bad, device=gpu, chunk=3, check="off")                                                    # (the guard off: what the default path would return)
     fb = mb(tiles)
     d = mb.range_diagnostics(reset=True)
     assert d["rows_beyond_fp16_range_possible"] >= 3 * cfg.tokens and not torch.isfinite(fb.float()).all()      # loud twice: counter AND non-finite features
     assert mb.range_diagnostics()["rows_beyond_fp16_range_possible"] == 0                                        # reset
     fu = HipViT(cfg, bad, device=gpu, chunk=3, ln_fold=False)(tiles)                                             # the stand-alone LayerNorm path is not affected
     assert torch.isfinite(fu.float()).all()
+    import warnings
+    with warnings.catch_warnings(record=True) as w:                                                              # the default: falls back to exactly that path
+        warnings.simplefilter("always")
+        md = HipViT(cfg, bad, device=gpu, chunk=3)
+        assert torch.equal(md(tiles), fu) and md.safe_level == 1 and len(w) == 1
     shifted = {k: v.clone() for k, v in sd.items()}
     shifted["blocks.0.attn.proj.bias"] += 60.0 / shifted["blocks.0.ls1.gamma"]       # every channel shifted by +60 after LayerScale: |mean| >> sigma
-    ms = HipViT(cfg, shifted, device=gpu, chunk=3)
-    ms(tiles)
-    assert ms.range_diagnostics()["rows_mean_over_8_sigma"] >= cfg.tokens
+    ms = HipViT(cfg, shifted, device=gpu, chunk=3, check="off")
+    fs = ms(tiles)
+    assert ms.range_diagnostics()["rows_mean_over_8_sigma"] >= cfg.tokens and torch.isfinite(fs.float()).all()
+    # finite but imprecise (the folded form loses |mean| / sigma in relative precision): the guard treats it like an overflow
+    from oracle.vit_tile_encoder import extract_features
+    ref = extract_features(tiles.cpu(), shifted, cfg).float()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        mg = HipViT(cfg, shifted, device=gpu, chunk=3)
+        fg = mg(tiles)
+    e_fold, e_guard = _rel(fs.cpu().float(), ref), _rel(fg.cpu().float(), ref)
+    print(f"|mean| ~ 60 sigma rows: folded path rel-L2 {e_fold:.3e}, guarded default (level {mg.safe_level}) {e_guard:.3e}")
+    assert mg.safe_level == 1 and len(w) == 1 and "8 sigma" in str(w[0].message) and e_guard < 1e-3
 
 
 def test_vit_large_bf16_matches_oracle(gpu):
