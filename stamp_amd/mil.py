@@ -401,8 +401,6 @@ def _bgemm(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer,
                                          torch.cuda.current_stream().cuda_stream), "bgemm_f32")
 
 
-
-
 class TransMIL(nn.Module):
     """Same constructor and state_dict keys as the reference TransMIL (trans_mil.py:286-326); fp32 on the HIP path.  Inference forward
     below; training (forward with saved intermediates + hand-derived backward) in stamp_amd/transmil_core.py, reached through one
@@ -426,69 +424,6 @@ class TransMIL(nn.Module):
     def _f(t):
         return t.detach().float().contiguous()
 
-    def _nystrom(self, y: torch.Tensor, layer: _TransLayerParams, x_res: torch.Tensor) -> None:
-        """x_res += NystromAttention(y)  (reference :81-163 with mask=None, eval; :258-263 residual)."""
-        import math
-
-        b, n, Cd = y.shape
-        H, m, iters = 8, Cd // 2, 6
-        d = Cd // H
-        rem = n % m
-        pad = (m - rem) if rem > 0 else 0
-        if pad:
-            y = torch.nn.functional.pad(y, (0, 0, pad, 0), value=0.0)                      # FRONT padding (:100)
-        np_ = n + pad
-        dev = y.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        attn = layer.attn
-        qkv = torch.empty(b, np_, 3 * Cd, **f32)
-        wq = self._f(attn.to_qkv.weight)
-        _bgemm(y.data_ptr(), Cd, 0, 0, wq.data_ptr(), Cd, 0, 0, True, qkv.data_ptr(), 3 * Cd, 0, 0, 1, 1, b * np_, 3 * Cd, Cd)
-        e4 = 4
-        qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + Cd * e4, qkv.data_ptr() + 2 * Cd * e4
-        sb, sh, ld = np_ * 3 * Cd, d, 3 * Cd
-        scale = d ** -0.5
-        l = math.ceil(n / m)
-        ql, kl = torch.empty(b, H, m, d, **f32), torch.empty(b, H, m, d, **f32)
-        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
-        _lib.check(lib.amds_landmark_mean(qp, sb, sh, ld, ql.data_ptr(), b, H, m, l, d, scale / l, st), "landmark_mean")
-        _lib.check(lib.amds_landmark_mean(kp, sb, sh, ld, kl.data_ptr(), b, H, m, l, d, 1.0 / l, st), "landmark_mean")
-        a1 = torch.empty(b, H, np_, m, **f32)
-        a2 = torch.empty(b, H, m, m, **f32)
-        a3 = torch.empty(b, H, m, np_, **f32)
-        _bgemm(qp, ld, sb, sh, kl.data_ptr(), d, H * m * d, m * d, True, a1.data_ptr(), m, H * np_ * m, np_ * m, b, H, np_, m, d, alpha=scale)
-        _bgemm(ql.data_ptr(), d, H * m * d, m * d, kl.data_ptr(), d, H * m * d, m * d, True, a2.data_ptr(), m, H * m * m, m * m, b, H, m, m, d)
-        _bgemm(ql.data_ptr(), d, H * m * d, m * d, kp, ld, sb, sh, True, a3.data_ptr(), np_, H * m * np_, m * np_, b, H, m, np_, d)
-        for t, cols in ((a1, m), (a2, m), (a3, np_)):
-            _lib.check(lib.amds_softmax_rows(t.data_ptr(), t.numel() // cols, cols, st), "softmax_rows")
-        # Moore-Penrose iteration (:23-37): z <- 0.25 z (13 I - xz (15 I - xz (7 I - xz))),  xz = x z
-        z, z2 = torch.empty_like(a2), torch.empty_like(a2)
-        xz, t1, t2 = torch.empty_like(a2), torch.empty_like(a2), torch.empty_like(a2)
-        scratch = torch.zeros(2, dtype=torch.int32, device=dev)
-        _lib.check(lib.amds_pinv_init(a2.data_ptr(), z.data_ptr(), b * H, m, scratch.data_ptr(), st), "pinv_init")
-        mm = m * m
-
-        def sq(A, B, Cm, alpha, diag):
-            _bgemm(A.data_ptr(), m, mm, 0, B.data_ptr(), m, mm, 0, False, Cm.data_ptr(), m, mm, 0, b * H, 1, m, m, m, alpha=alpha, diag=diag)
-        for _ in range(iters):
-            sq(a2, z, xz, 1.0, 0.0)
-            sq(a2, z, t1, -1.0, 7.0)          # 7I - xz
-            sq(xz, t1, t2, -1.0, 15.0)        # 15I - xz(7I - xz)
-            sq(xz, t2, t1, -1.0, 13.0)        # 13I - xz(...)
-            sq(z, t1, z2, 0.25, 0.0)
-            z, z2 = z2, z
-        av = torch.empty(b, H, m, d, **f32)                                                     # attn3 @ v
-        _bgemm(a3.data_ptr(), np_, H * m * np_, m * np_, vp, ld, sb, sh, False, av.data_ptr(), d, H * m * d, m * d, b, H, m, d, np_)
-        a1z = torch.empty(b, H, np_, m, **f32)                                                  # attn1 @ pinv
-        _bgemm(a1.data_ptr(), m, H * np_ * m, np_ * m, z.data_ptr(), m, H * mm, mm, False, a1z.data_ptr(), m, H * np_ * m, np_ * m, b, H, np_, m, m)
-        merged = torch.empty(b, np_, Cd, **f32)                                                 # heads merged: [b, n, (h d)]
-        _bgemm(a1z.data_ptr(), m, H * np_ * m, np_ * m, av.data_ptr(), d, H * m * d, m * d, False, merged.data_ptr(), Cd, np_ * Cd, d, b, H, np_, d, m)
-        wc = self._f(attn.res_conv.weight).reshape(H, -1)                                       # [H, 33]
-        _lib.check(lib.amds_dwconv_seq(vp, sb, sh, ld, wc.data_ptr(), merged.data_ptr(), np_ * Cd, d, Cd, b, H, np_, d, wc.shape[1], st), "dwconv_seq")
-        wo, bo = self._f(attn.to_out[0].weight), self._f(attn.to_out[0].bias)
-        # to_out on the LAST n rows of every bag (:155), accumulated into the residual stream
-        _bgemm(merged.data_ptr() + pad * Cd * e4, Cd, np_ * Cd, 0, wo.data_ptr(), Cd, 0, 0, True, x_res.data_ptr(), Cd, n * Cd, 0, b, 1, n, Cd, Cd,
-               bias=bo.data_ptr(), accumulate=True)
 
     def _get(self, dev):
         tensors = dict(self.named_parameters())
@@ -565,34 +500,6 @@ class TransMIL(nn.Module):
         _lib.check(lib.amds_transmil_forward(C.byref(cfg), C.byref(w), h.data_ptr(), ops._DT[h.dtype], logits.data_ptr(), Bb, T, ws.data_ptr(), ws.numel(),
                                              torch.cuda.current_stream().cuda_stream), "transmil_forward")
         return logits
-
-    def _forward_stepwise(self, h: torch.Tensor) -> torch.Tensor:
-        """The same forward, one library call per kernel from the host (what `forward` did before amds_transmil_forward existed): kept as the
-        cross-check of the C entry point in tests/ -- bit-identical logits."""
-        import math
-        Bb, T, F = h.shape
-        Cd = self.dim_hidden
-        x = ops.linear_f32(h.reshape(Bb * T, F).float().contiguous(), self._f(self._fc1[0].weight), self._f(self._fc1[0].bias), relu=True)
-        x = x.view(Bb, T, Cd)
-        side = int(math.ceil(math.sqrt(T)))
-        x = torch.cat([x, x[:, : side * side - T]], dim=1)                                       # wrap-pad with the FIRST tiles (:306-309)
-        x = torch.cat([self._f(self.cls_token).expand(Bb, -1, -1), x], dim=1).contiguous()        # [Bb, n, C]
-        n = x.shape[1]
-        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
-        for name in ("layer1", "pos", "layer2"):
-            if name == "pos":
-                y = torch.empty_like(x)
-                pl = self.pos_layer
-                w7, w5, w3 = (self._f(c.weight).reshape(Cd, -1) for c in (pl.proj, pl.proj1, pl.proj2))
-                _lib.check(lib.amds_ppeg(x.data_ptr(), y.data_ptr(), w7.data_ptr(), self._f(pl.proj.bias).data_ptr(), w5.data_ptr(),
-                                         self._f(pl.proj1.bias).data_ptr(), w3.data_ptr(), self._f(pl.proj2.bias).data_ptr(), Bb, side, side, Cd, st), "ppeg")
-                x = y
-                continue
-            layer = getattr(self, name)
-            y = ops.layernorm(x.view(Bb * n, Cd), self._f(layer.norm.weight), self._f(layer.norm.bias), 1e-5, torch.float32).view(Bb, n, Cd)
-            self._nystrom(y, layer, x)                                                           # x += attn(norm(x))
-        cls = ops.layernorm_rows(x.view(-1), Bb, Cd, n * Cd, self._f(self.norm.weight), self._f(self.norm.bias), 1e-5, torch.float32)
-        return ops.linear_f32(cls, self._f(self._fc2.weight), self._f(self._fc2.bias))
 
 
 class _TransMilBackward(torch.autograd.Function):

@@ -7,6 +7,8 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
+if str(ROOT / "tests") not in sys.path:          # tests/chains: the kernel-by-kernel launch chains the C entry points are checked against
+    sys.path.insert(0, str(ROOT / "tests"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 

@@ -265,6 +265,7 @@ def test_transmil_bag_1024_vs_oracle(gpu):
 def test_mil_vit_forward_one_call_equals_the_kernel_by_kernel_chain(gpu, alibi, masked, dims, bdt):
     """amds_mil_vit_forward (one C call: staging, class token, L layers, final norm, head) against the same kernels launched one by one from
     the host -- bit-identical logits, with the reference's odd test shapes (tests/test_model.py:9-32), padding masks, ALiBi, any bag dtype."""
+    from chains import mil_vit as chain
     from stamp_amd import mil_core
     F, D, H, FF = dims
     torch.manual_seed(F + D + int(alibi))
@@ -281,7 +282,7 @@ def test_mil_vit_forward_one_call_equals_the_kernel_by_kernel_chain(gpu, alibi, 
     pk = model._infer_pack(bags.device)
     with torch.no_grad():
         one = mil_core.forward_infer(pk, bags, coords, mask)
-        chain = mil_core.forward_infer_stepwise(pk, bags, coords, mask)
+        chain = chain.forward_infer_stepwise(pk, bags, coords, mask)
         again = model(bags, coords=coords, mask=mask)
     assert one.shape == (Bb, 3) and torch.isfinite(one).all()
     assert torch.equal(one, chain) and torch.equal(one, again)
@@ -325,7 +326,8 @@ def test_transmil_forward_one_call_equals_the_kernel_by_kernel_chain(gpu, Bb, T,
     bags = torch.randn(Bb, T, F).to(bdt).to(gpu)
     with torch.no_grad():
         one = model(bags)
-        chain = model._forward_stepwise(bags)
+        from chains.transmil import transmil_forward_stepwise
+        chain = transmil_forward_stepwise(model, bags)
     assert one.shape == (Bb, 3) and torch.isfinite(one).all() and torch.equal(one, chain)
     with torch.no_grad():
         model._fc2.bias.add_(1.0)                          # the cached device weights follow the parameters

@@ -359,6 +359,7 @@ def test_mil_vit_train_one_call_equals_the_kernel_by_kernel_chain(gpu, alibi, di
     """amds_mil_vit_train_forward / _backward (one C call each) against the same kernels launched one by one from the host: logits, every
     parameter gradient and the gradient w.r.t. the bags are bit-identical -- default and odd (padded) shapes, dropout live (same counter-based
     masks from the same seed), ALiBi, every bag dtype; a second backward from the same saved activations (Jacobian rows) reproduces the first."""
+    from chains import mil_vit as chain
     from stamp_amd import mil_core
     from stamp_amd.mil import VisionTransformer
     F, D, H, FF = dims
@@ -372,10 +373,10 @@ def test_mil_vit_train_one_call_equals_the_kernel_by_kernel_chain(gpu, alibi, di
     dlogits = torch.randn(Bb, 3, device=gpu)
     training = p_drop > 0
     lg1, sv1 = mil_core.forward_train(pk, bags, coords, training=training, seed=1234)
-    lg0, sv0 = mil_core.forward_train_stepwise(pk, bags, coords, training=training, seed=1234)
+    lg0, sv0 = chain.forward_train_stepwise(pk, bags, coords, training=training, seed=1234)
     assert torch.isfinite(lg1).all() and torch.equal(lg1, lg0)
     G1, db1 = mil_core.backward(pk, sv1, dlogits, need_params=True, need_bags=True)
-    G0, db0 = mil_core.backward_stepwise(pk, sv0, dlogits, need_params=True, need_bags=True)
+    G0, db0 = chain.backward_stepwise(pk, sv0, dlogits, need_params=True, need_bags=True)
     assert set(G1) == set(G0) and set(G1) == {k for k in sd if not mil_core.is_buffer(k)}
     for k in G0:
         assert G1[k].shape == G0[k].shape == sd[k].shape, k
@@ -413,3 +414,46 @@ def test_mil_vit_train_c_abi_guards(gpu):
     assert rc == -2 and b"arena" in lib.amds_last_error()
     with pytest.raises(RuntimeError, match="training pack"):
         mil_core.forward_train(model._infer_pack(torch.device(gpu)), bags, None, training=False)
+
+
+def test_fit_driven_from_a_directory_of_feature_files(gpu, tmp_path):
+    """`stamp train`'s data path end to end (reference modeling/train.py:455-477, 504-621): feature .h5 files on disk -> stamp_amd.bags
+    (patients -> fixed-size bags, shuffled batches for training; full bags, batch 1 for validation; inverse-frequency class weights) ->
+    `fit` around the HIP training step.  Two separable classes: the validation loss must fall, the best epoch's weights end up in the module.
+    And: the fixed-size bag gathered on the GPU (`BagDataset(device=...)`, amds_gather_rows) equals the host item bit for bit."""
+    import numpy as np
+
+    from stamp_amd import bags as B
+    from stamp_amd import h5io
+    from stamp_amd.mil import VisionTransformer
+    from stamp_amd.mil_train import HipMilVitTrainer, fit
+    rng = np.random.default_rng(0)
+    Fd, pdata = 64, []
+    for i in range(24):
+        label = "pos" if i % 3 else "neg"
+        files = []
+        for s in range(1 + i % 2):                                                  # one or two slides per patient
+            n = int(rng.integers(20, 90))
+            feats = (rng.standard_normal((n, Fd)) + (1.5 if label == "pos" else -1.5)).astype(np.float16)
+            coords = np.stack([rng.integers(0, 50, n), rng.integers(0, 50, n)], 1).astype(np.float32) * 256.0
+            p = tmp_path / f"p{i}_s{s}.h5"
+            h5io.write_tile_features(p, feats, coords, extractor="test", tile_size_um=256.0, tile_size_px=224, code_hash="0", stamp_version="2.4.0")
+            files.append(p)
+        pdata.append(B.PatientData(ground_truth=label, feature_files=files))
+    train, valid = pdata[:18], pdata[18:]
+    torch.manual_seed(0)
+    dl_t, cats = B.tile_bag_dataloader(patient_data=train, bag_size=32, task="classification", batch_size=6, shuffle=True, num_workers=0, transform=None)
+    dl_v, _ = B.tile_bag_dataloader(patient_data=valid, bag_size=None, task="classification", categories=cats, batch_size=1, shuffle=False, num_workers=0, transform=None)
+    assert cats == ["neg", "pos"]
+    w = B.class_weights(dl_t.dataset.ground_truths, cats)
+    assert torch.allclose(w, torch.tensor([2 / 3, 1 / 3]), atol=1e-6)                # 6 neg, 12 pos -> weights (N/6, N/12) normalised
+    model = VisionTransformer(dim_output=2, dim_input=Fd, dim_model=64, n_layers=1, n_heads=2, dim_feedforward=64, dropout=0.0, use_alibi=False)
+    tr = HipMilVitTrainer(model, device=gpu, max_lr=3e-3, total_steps=4 * len(dl_t), sched_interval="step", dropout=False)
+    hist = fit(tr, lambda: dl_t, lambda: dl_v, max_epochs=4, patience=8, class_weights=w)
+    assert all(np.isfinite(hist["validation_loss"])) and hist["validation_loss"][-1] < 0.5 * hist["validation_loss"][0], hist
+    # GPU-side gather of the fixed-size bag == the host item
+    ds_h = B.BagDataset(bags=[p.feature_files for p in train], bag_size=16, ground_truths=dl_t.dataset.ground_truths, transform=None, deterministic=True)
+    ds_d = B.BagDataset(bags=[p.feature_files for p in train], bag_size=16, ground_truths=dl_t.dataset.ground_truths, transform=None, deterministic=True, device=gpu)
+    for i in (0, 5, 17):
+        (bh, ch, nh, _), (bd, cd, nd, _) = ds_h[i], ds_d[i]
+        assert bd.is_cuda and torch.equal(bd.cpu(), bh) and torch.equal(cd.cpu(), ch) and nh == nd

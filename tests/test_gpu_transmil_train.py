@@ -128,14 +128,16 @@ def test_transmil_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, 
     get = model._get(torch.device(gpu))
     dlogits = torch.randn(Bb, 2, device=gpu)
     res = []
-    for level in (0, 1, 2):
-        tc.STEPWISE = level
+    from chains import transmil as chain
+    for level in (0, 1, 2):        # 0 = the whole-step C calls; 1 = host loop around amds_nystrom_attn_fwd / _bwd; 2 = every kernel from the host (tests/chains)
+        fwd, bwd = (tc.forward_train, tc.backward) if level == 0 else (chain.forward_train_stepwise, chain.backward_stepwise)
+        chain.NYSTROM_KERNEL_BY_KERNEL = level == 2
         try:
-            logits, saved = tc.forward_train(get, bags.to(gpu), (Fd, Cd, 2), training=train, seed=4321)
-            G, db = tc.backward(saved, dlogits, need_params=True, need_bags=True)
-            G2, db2 = tc.backward(saved, dlogits, need_params=False, need_bags=True)        # input gradient only, saved activations untouched
+            logits, saved = fwd(get, bags.to(gpu), (Fd, Cd, 2), training=train, seed=4321)
+            G, db = bwd(saved, dlogits, need_params=True, need_bags=True)
+            G2, db2 = bwd(saved, dlogits, need_params=False, need_bags=True)        # input gradient only, saved activations untouched
         finally:
-            tc.STEPWISE = 0
+            chain.NYSTROM_KERNEL_BY_KERNEL = False
         assert G2 == {} and torch.equal(db2, db)
         res.append((logits, G, db))
     l0, G0, d0 = res[2]

@@ -76,14 +76,15 @@ def load_by_path(modname: str, path: Path):
     return mod
 
 
-def exec_defs(path: Path, names: set[str], glb: dict) -> dict:
+def exec_defs(path: Path, names: set[str], glb: dict, inherit_future: bool = True) -> dict:
     """exec only the named top-level class/function definitions of a reference file (its module top imports
-    things that are absent here)."""
+    things that are absent here).  inherit_future=False: compile WITHOUT this file's `from __future__ import annotations` (a dataclass that
+    uses `_: KW_ONLY` needs the annotation evaluated)."""
     tree = ast.parse(path.read_text())
     body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
     missing = names - {n.name for n in body}
     assert not missing, missing
-    code = compile(ast.Module(body=body, type_ignores=[]), str(path), "exec")
+    code = compile(ast.Module(body=body, type_ignores=[]), str(path), "exec", dont_inherit=not inherit_future)
     exec(code, glb)
     return glb
 
@@ -614,6 +615,154 @@ def golden_bag() -> None:
     save("fixed_size_bag.npz", **out)
 
 
+
+def golden_bag_dataset() -> None:
+    """The reference's bag-building HOST layer, executed as it stands (src/stamp/modeling/data.py): `BagDataset.__getitem__` (:584-655: patient -> slide
+    files concatenated, `.float()`, transform, `_to_fixed_size_bag`), `_collate_to_tuple` / `_collate_multitarget` (:255-295), `_parse_targets` (:146-252)
+    and `_compute_class_weights_and_check_categories` (modeling/train.py:567-621).  data.py imports h5py at module top: `h5py.File(path, ...)` is a
+    stand-in that serves in-memory datasets / attributes (the same objects `golden_get_coords` hands to `get_coords`).  The fixture holds the files'
+    contents, the calls' arguments and what the reference returned -- tests/test_cpu_bags.py replays them through stamp_amd.bags over REAL .h5 files."""
+    import json
+    import logging
+    from collections import OrderedDict
+    from collections.abc import Callable, Iterable, Mapping, Sequence
+    from dataclasses import KW_ONLY, dataclass
+    from typing import Any, Dict, Generic, List, TypeVar, Union, cast
+
+    from packaging.version import Version
+    from torch.utils.data import DataLoader, Dataset
+
+    class DS:                                                        # h5py.Dataset stand-in
+        def __init__(self, arr):
+            self.arr = np.asarray(arr)
+            self.shape = self.arr.shape
+
+        def __getitem__(self, k):
+            return self.arr[k]
+
+    registry: dict = {}
+    opened: list = []
+
+    class FileStub(dict):
+        def __init__(self, path, mode="r", **kw):
+            ds, attrs = registry[str(path)]
+            super().__init__({k: DS(v) for k, v in ds.items()})
+            self.attrs, self.filename = dict(attrs), str(path)
+            opened.append(str(path))
+
+        def close(self):
+            pass
+
+    h5 = types.SimpleNamespace(Dataset=DS, File=FileStub)
+    T = torch.Tensor
+    glb = {"np": np, "torch": torch, "h5py": h5, "dataclass": dataclass, "KW_ONLY": KW_ONLY, "Version": Version, "stamp": types.SimpleNamespace(__version__="2.5.0"),
+           "cast": cast, "Tensor": T, "Microns": float, "TilePixels": int, "SlideMPP": float, "_logger": logging.getLogger("golden"), "Dataset": Dataset,
+           "DataLoader": DataLoader, "OrderedDict": OrderedDict, "Sequence": Sequence, "Iterable": Iterable, "Callable": Callable, "Mapping": Mapping, "Any": Any,
+           "Dict": Dict, "List": List, "Union": Union, "Generic": Generic, "FeaturePath": Path, "_BinaryIOLike": Any, "BagSize": int, "_Bag": T, "_Coordinates": T,
+           "_EncodedTarget": Any, "Bags": T, "CoordinatesBatch": T, "BagSizes": T, "EncodedTargets": T, "Category": str, "Task": str, "GroundTruthType": TypeVar("G"),
+           "PatientFeatureDataset": type("PatientFeatureDataset", (), {})}
+    exec_defs(REF / "modeling" / "data.py", {"CoordsInfo", "get_coords", "get_stride", "_to_fixed_size_bag", "BagDataset", "_collate_to_tuple", "_collate_multitarget",
+                                               "_parse_targets", "PatientData"}, glb, inherit_future=False)
+    exec_defs(REF / "modeling" / "train.py", {"_compute_class_weights_and_check_categories"}, glb)
+    rng = np.random.default_rng(11)
+    F = 12
+
+    def slide(n, fmt, dtype=np.float16):
+        grid = np.stack([rng.integers(0, 40, n), rng.integers(0, 30, n)], 1).astype(np.float32)
+        feats = rng.standard_normal((n, F)).astype(dtype)
+        if fmt == "current":
+            return {"feats": feats, "coords": grid * 256.0}, {"tile_size_um": 256.0, "tile_size_px": 224, "unit": "um", "stamp_version": "2.4.0"}
+        if fmt == "v2":
+            return {"feats": feats, "coords": grid * 128.0}, {"tile_size": 128.0, "unit": "um"}
+        if fmt == "historic":
+            return {"feats": feats, "coords": grid * 224.0}, {}
+        return {"patch_embeddings": feats}, {}                      # coords-less bypass (:743-757)
+    files = {"a1": slide(37, "current"), "a2": slide(5, "current"), "b1": slide(70, "v2", np.float32), "c1": slide(9, "historic"), "c2": slide(11, "historic"),
+             "c3": slide(3, "historic"), "d1": slide(20, "nocoords"), "e1": slide(64, "current")}
+    for k, (ds, attrs) in files.items():
+        registry[f"/feat/{k}.h5"] = (ds, attrs)
+    bags = [[Path("/feat/a1.h5"), Path("/feat/a2.h5")], [Path("/feat/b1.h5")], [Path("/feat/c1.h5"), Path("/feat/c2.h5"), Path("/feat/c3.h5")], [Path("/feat/d1.h5")],
+            [Path("/feat/e1.h5")]]
+    out: dict = {"files": {k: {"datasets": {n: {"dtype": str(v.dtype), "data": v.tolist()} for n, v in ds.items()}, "attrs": attrs} for k, (ds, attrs) in files.items()},
+                 "bags": [[p.stem for p in b] for b in bags], "cases": {}}
+    # ---- targets as the reference encodes them
+    PD = glb["PatientData"]
+    gts_cls = ["lum", "basal", "lum", "her2", "basal"]
+    pdata = [PD(ground_truth=g, feature_files=b) for g, b in zip(gts_cls, bags)]
+    y_cls, cats = glb["_parse_targets"](patient_data=pdata, task="classification", categories=None)
+    y_cls_fixed, cats_fixed = glb["_parse_targets"](patient_data=pdata, task="classification", categories=["her2", "lum", "basal", "normal"])
+    y_reg, _ = glb["_parse_targets"](patient_data=[PD(ground_truth=g, feature_files=b) for g, b in zip([1.5, None, -2.0, 0.25, 7.0], bags)], task="regression")
+    y_surv, _ = glb["_parse_targets"](patient_data=[PD(ground_truth=g, feature_files=b) for g, b in zip([(10.0, 1), (3.5, 0), None, ("nan", 1), (7, None)], bags)],
+                                      task="survival")
+    gts_multi = [{"sub": "lum", "grade": "g1"}, {"sub": "basal", "grade": None}, None, {"sub": "her2", "grade": "g3"}, {"sub": "lum", "grade": "g1"}]
+    y_multi, cats_multi = glb["_parse_targets"](patient_data=[PD(ground_truth=g, feature_files=b) for g, b in zip(gts_multi, bags)], task="classification")
+    out["targets"] = {"classification": {"gts": gts_cls, "encoded": y_cls.tolist(), "categories": list(cats)},
+                      "classification_fixed": {"categories_in": ["her2", "lum", "basal", "normal"], "encoded": y_cls_fixed.tolist(), "categories": list(cats_fixed)},
+                      "regression": {"gts": [1.5, None, -2.0, 0.25, 7.0], "encoded": [[None if np.isnan(v) else v for v in r] for r in y_reg.tolist()]},
+                      "survival": {"gts": [[10.0, 1], [3.5, 0], None, ["nan", 1], [7, None]], "encoded": [[None if np.isnan(v) else v for v in r] for r in y_surv.tolist()]},
+                      "multi": {"gts": gts_multi, "encoded": [{k: v.tolist() for k, v in d.items()} for d in y_multi], "categories": {k: list(v) for k, v in cats_multi.items()}}}
+    try:
+        glb["_parse_targets"](patient_data=[PD(ground_truth="x", feature_files=b) for b in bags], task="classification")
+    except ValueError as e:
+        out["targets"]["one_class_error"] = str(e)
+    # ---- items and batches
+    BD = glb["BagDataset"]
+
+    def item_rec(it):
+        bag, coords, n, tgt = it
+        return {"bag": bag.tolist(), "bag_dtype": str(bag.dtype), "coords": coords.tolist(), "n": int(n),
+                "target": ({k: v.tolist() for k, v in tgt.items()} if isinstance(tgt, dict) else torch.as_tensor(tgt).tolist())}
+    for name, kw, seed in (("det_16", dict(bag_size=16, deterministic=True), None), ("rand_16", dict(bag_size=16, deterministic=False), 99),
+                           ("rand_40", dict(bag_size=40, deterministic=False), 7), ("all", dict(bag_size=None), None)):
+        ds = BD(bags=bags, ground_truths=y_cls, transform=None, **kw)
+        if seed is not None:
+            torch.manual_seed(seed)
+        items = [ds[i] for i in range(len(bags))]
+        rec = {"kw": {k: v for k, v in kw.items()}, "seed": seed, "items": [item_rec(it) for it in items]}
+        if kw["bag_size"] is not None:
+            b, c, s, t = glb["_collate_to_tuple"](items)
+            rec["batch"] = {"bags_shape": list(b.shape), "coords_shape": list(c.shape), "bag_sizes": s.tolist(), "bag_sizes_dtype": str(s.dtype), "targets": t.tolist()}
+        out["cases"][name] = rec
+    # a transform, multi-target ground truths, scalar / 2-d targets through the collate's shape rule
+    ds = BD(bags=bags, bag_size=8, ground_truths=y_multi, transform=lambda x: x * 2.0 + 1.0, deterministic=True)
+    items = [ds[i] for i in range(len(bags))]
+    b, c, s, t = glb["_collate_multitarget"](items)
+    out["cases"]["multi_det_8_transform"] = {"items": [item_rec(it) for it in items], "batch": {"bags_shape": list(b.shape), "bag_sizes": s.tolist(),
+                                                                                             "targets": {k: v.tolist() for k, v in t.items()}}}
+    ds = BD(bags=bags, bag_size=4, ground_truths=y_surv, transform=None, deterministic=True)
+    items = [ds[i] for i in range(len(bags))]
+    fake = [(items[0][0], items[0][1], items[0][2], torch.tensor(3.0)), (items[1][0], items[1][1], items[1][2], torch.tensor([[1.0, 2.0]]).view(1, 2)[0, :1])]
+    _, _, _, tt = glb["_collate_to_tuple"](fake)
+    out["cases"]["collate_shapes"] = {"targets_in": [3.0, [1.0]], "targets_out": tt.tolist()}
+    # the handle cache: at most 128 open files, least recently used closed first (:596-612)
+    for i in range(140):
+        registry[f"/feat/many{i}.h5"] = files["a2"]
+    ds = BD(bags=[[Path(f"/feat/many{i}.h5")] for i in range(140)], bag_size=2, ground_truths=torch.zeros(140, 2), transform=None, deterministic=True)
+    opened.clear()
+    for i in list(range(140)) + [0, 139, 11]:
+        ds[i]
+    out["cases"]["handle_cache"] = {"opens": len(opened), "cached_after": len(ds._h5_handle_cache), "reopened": [Path(p).stem for p in opened[140:]]}
+    # ---- inverse-frequency class weights (train.py:567-621)
+    f = glb["_compute_class_weights_and_check_categories"]
+    big = torch.zeros(60, 3)
+    big[:30, 0] = 1
+    big[30:50, 1] = 1
+    big[50:, 2] = 1
+    dl = types.SimpleNamespace(dataset=BD(bags=[[]] * 60, ground_truths=big, transform=None))
+    w = f(train_dl=dl, feature_type="tile", train_categories=["a", "b", "c"])
+    dlm = types.SimpleNamespace(dataset=BD(bags=bags, ground_truths=y_multi, transform=None))
+    wm = f(train_dl=dlm, feature_type="tile", train_categories=cats_multi)
+    out["class_weights"] = {"single": {"ground_truths": big.tolist(), "weights": w.tolist()}, "multi": {k: [None if np.isnan(x) or np.isinf(x) else x for x in v.tolist()] for k, v in wm.items()},
+                            "multi_raw": {k: [repr(float(x)) for x in v.tolist()] for k, v in wm.items()}}
+    try:
+        f(train_dl=dl, feature_type="tile", train_categories=["only"])
+    except ValueError as e:
+        out["class_weights"]["one_category_error"] = str(e)
+    OUT.mkdir(parents=True, exist_ok=True)
+    (OUT / "bag_dataset.json").write_text(json.dumps(out))
+    print("wrote bag_dataset.json", (OUT / "bag_dataset.json").stat().st_size // 1024, "KiB")
+
+
 from oracle.tiling import synthetic_slide  # noqa: E402  (seeded generator shared with the tests)
 
 
@@ -845,6 +994,7 @@ def main() -> None:
     golden_transmil()
     golden_mlp_cox_transforms()
     golden_bag()
+    golden_bag_dataset()
     golden_ctranspath()
     golden_texture_gray()
     golden_tiling()
