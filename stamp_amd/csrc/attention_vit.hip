@@ -313,6 +313,7 @@ static int launch_attn(const void* qkv, void* out, int B, int Tn, int H, hipStre
 }
 
 int attention_vit257(const void* qkv, void* out, int B, int H, int dtype, hipStream_t st);       // attention_vit257.hip
+int attention_vit26x(const void* qkv, void* out, int B, int T, int H, int dtype, hipStream_t st);      // attention_vit26x.hip
 
 }  // namespace amds
 
@@ -327,6 +328,10 @@ extern "C" int amds_attention_vit(const void* qkv, void* out, int B, int T, int 
     // T = 257 (class token + 16 x 16 patches): the persistent double-buffered kernel; AMDS_ATTN_257=0 selects the one-shot kernel (A/B)
     static const bool use257 = getenv("AMDS_ATTN_257") ? atoi(getenv("AMDS_ATTN_257")) != 0 : true;
     if (use257 && T == 257 && (dtype == AMDS_F16 || dtype == AMDS_BF16)) return attention_vit257(qkv, out, B, H, dtype, st);
+    // T = 261 / 265 (class + 4 / 8 register tokens + 16 x 16 patches: Virchow2-like trunks at head_dim 64, UNI2-h, H-optimus): the same pipeline with
+    // the tail tokens as a ninth key tile and an R-row query operand (attention_vit26x.hip); AMDS_ATTN_26X=0 selects the one-shot kernel (A/B)
+    static const bool use26x = getenv("AMDS_ATTN_26X") ? atoi(getenv("AMDS_ATTN_26X")) != 0 : true;
+    if (use26x && (T == 261 || T == 265) && (dtype == AMDS_F16 || dtype == AMDS_BF16)) return attention_vit26x(qkv, out, B, T, H, dtype, st);
     if (dtype == AMDS_F16) return launch_attn<f16>(qkv, out, B, T, H, st);
     if (dtype == AMDS_BF16) return launch_attn<bf16>(qkv, out, B, T, H, st);
     set_error("amds_attention_vit: bad dtype %d", dtype);
