@@ -50,6 +50,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--act", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--overlap", type=int, default=0, help="1 = two chunks in flight on two streams")
     ap.add_argument("--fp8", action="store_true", help="headline run with HipViT(fp8=True): the blocks' Linears on the fp8 MFMA (opt-in, ~6 %% feature error)")
+    ap.add_argument("--check", default="fallback", choices=("fallback", "raise", "off"), help="HipViT's guard in front of the features (default: the product's default; 'off' for A/B)")
     ap.add_argument("--exact", action="store_true", help="headline run with HipViT(exact=True): the class-token rows also on an exact-fp32 stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only (for a ViT-only rocprofv3 kernel trace)")
@@ -597,7 +598,7 @@ def main() -> None:
     else:
         cfg = PRESETS[a.model]
         sd = random_vit_state_dict(cfg, seed=0, init="moderate")
-        model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk, exact=a.exact, fp8=a.fp8)
+        model = HipViT(cfg, sd, device=ctx.device, act_dtype=act, chunk=a.chunk, exact=a.exact, fp8=a.fp8, check=a.check)
         model.overlap = bool(a.overlap)
     g = torch.Generator().manual_seed(1234 + ctx.rank)
     tiles = torch.randint(0, 256, (a.tiles, cfg.img, cfg.img, 3), dtype=torch.uint8, generator=g).to(ctx.device)
@@ -641,7 +642,7 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary of the
     # two rocprofv3 --pmc passes over this same workload (profiles/*_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
     traffic, pmc_name = None, None
-    for pmc_file in (ROOT / "profiles" / "r03_pmc_gemm_traffic.json", ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
+    for pmc_file in (ROOT / "profiles" / "r04_pmc_gemm_traffic.json", ROOT / "profiles" / "r03_pmc_gemm_traffic.json", ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
         if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 1020 and pmc_file.is_file():
             try:
                 traffic, pmc_name = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"], pmc_file.name
@@ -679,6 +680,9 @@ def main() -> None:
                    "gflop_per_tile": round(cfg.matmul_flops_per_tile() / 1e9, 3),
                    # the last block's class-row tail (include/amdstamp.h amds_vit_weights.cls_tail): rows of the last block that nothing reads are not
                    # computed, so the whole-path fraction is priced on the products actually EXECUTED, not on the network's nominal count
+                   # the guard in front of the feature file runs INSIDE the timed region: amds_check_finite + the range counters of the folded LayerNorms,
+                   # one 4-byte read-back and stream synchronisation per call (stamp_amd.vit.HipViT.check; default "fallback")
+                   "guard": None if is_swin else f"check={model.check!r}: non-finite / |mean| > 8 sigma check per call, in the timed region; safe level {model.safe_level}",
                    "cls_tail": bool(tail_on), "residual_stream": "f16 hi|lo planes" if (not is_swin and planes_on) else "f32",
                    "gflop_per_tile_executed": round(flops_exec / 1e9, 3),
                    "whole_path_mfma_frac": round(value / ctx.world * flops_exec / 1e12 / MFMA_PEAK_TFLOPS, 4)},

@@ -949,6 +949,12 @@ int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, 
  *   dx = (add_skip ? dx : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma (+)= sum dy*xhat; dbeta (+)= sum dy */
 int amds_layernorm_train(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
                          float* mean, float* rstd, int rows, int cols, float eps, int out_dtype, void* stream);
+/* Same, and the rows x[.., 0 .. copy_cols) also go out unchanged into x_copy (row stride copy_row_stride): the training forward's
+ * `x_mid = x_in; x_mid += out_proj(attention(...))` (reference vision_tranformer.py:291-293: `x = x + ...` keeps the block input alive for autograd)
+ * without a device-to-device copy launch.  x_copy may be NULL (= amds_layernorm_train). */
+int amds_layernorm_train_copy(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
+                              float* mean, float* rstd, int rows, int cols, float eps, int out_dtype, float* x_copy, long copy_row_stride,
+                              int copy_cols, void* stream);
 size_t amds_layernorm_bwd_workspace_bytes(int rows, int cols);
 int amds_layernorm_bwd(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
                        const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,

@@ -284,6 +284,7 @@ PROTOTYPES = {
     "amds_colsum_workspace_bytes": (_sz, [_i, _i]),
     "amds_colsum": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amds_layernorm_train": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "amds_layernorm_train_copy": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp, _l, _i, _vp]),
     "amds_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "amds_layernorm_bwd": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "amds_gelu_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp]),

@@ -284,18 +284,18 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
             AMDS_HIP(hipMemsetAsync(h2, 0, (size_t)M * Dp * 2, st));
         }
         // x_mid = x_in + out_proj(attention(in_proj(LayerNorm(x_in))))      (:215-242, :291-292)
-        RC(amds_layernorm_train(x_in, Dp, Lw.ln1_w, Lw.ln1_b, h1, Dp, reinterpret_cast<float*>(sv + o.mu1), reinterpret_cast<float*>(sv + o.rs1), (int)M, D,
-                                1e-5f, BF, stream));
+        // (the LayerNorm kernel also writes x_mid = x_in, which the out-projection's residual epilogue then updates in place)
+        RC(amds_layernorm_train_copy(x_in, Dp, Lw.ln1_w, Lw.ln1_b, h1, Dp, reinterpret_cast<float*>(sv + o.mu1), reinterpret_cast<float*>(sv + o.rs1), (int)M, D,
+                                     1e-5f, BF, x_mid, Dp, Dp, stream));
         RC(gemm(h1, Dp, Lw.in_w, Dp, M, 3 * Da, Dp, AMDS_EPI_BIAS, qkv, 3 * Da, Lw.in_b, stream));
-        AMDS_HIP(hipMemcpyAsync(x_mid, x_in, (size_t)M * Dp * 4, hipMemcpyDeviceToDevice, st));
         if (d.alibi)
             RC(amds_attention_alibi_fwd_train(qkv, cc, Lw.inv_running_mean, Lw.bias_scale, att, sv + o.u_al, sv + o.osm, lse, Bb, S, Ha, BF, stream));
         else
             RC(amds_attention_fwd_train(qkv, att, lse, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         RC(gemm(att, Da, Lw.out_w, Da, M, Dp, Da, AMDS_EPI_RESIDUAL, x_mid, Dp, Lw.out_b, stream));
         // x_out = x_mid + Dropout(fc2(Dropout(GELU(fc1(LayerNorm(x_mid))))))   (:157-169, :293)
-        RC(amds_layernorm_train(x_mid, Dp, Lw.ln2_w, Lw.ln2_b, h2, Dp, reinterpret_cast<float*>(sv + o.mu2), reinterpret_cast<float*>(sv + o.rs2), (int)M, D,
-                                1e-5f, BF, stream));
+        RC(amds_layernorm_train_copy(x_mid, Dp, Lw.ln2_w, Lw.ln2_b, h2, Dp, reinterpret_cast<float*>(sv + o.mu2), reinterpret_cast<float*>(sv + o.rs2), (int)M, D,
+                                     1e-5f, BF, p_ff > 0.f ? nullptr : x_out, Dp, Dp, stream));      // (no dropout: x_out = x_mid here, fc2 adds into it)
         RC(gemm(h2, Dp, Lw.fc1_w, Dp, M, FFp, Dp, AMDS_EPI_BIAS, z, FFp, Lw.fc1_b, stream));
         RC(gelu_drop_fwd(z, u, M * FFp, BF, BF, p_ff, seed, 10 * l + 2, stream));
         if (p_ff > 0.f) {
@@ -303,7 +303,6 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
             RC(gemm(u, FFp, Lw.fc2_w, FFp, M, Dp, FFp, AMDS_EPI_BIAS_F32, y, Dp, Lw.fc2_b, stream));
             RC(amds_dropout_add(y, Dp, x_mid, Dp, x_out, Dp, M, Dp, p_ff, seed, 10 * l + 3, stream));
         } else {
-            AMDS_HIP(hipMemcpyAsync(x_out, x_mid, (size_t)M * Dp * 4, hipMemcpyDeviceToDevice, st));
             RC(gemm(u, FFp, Lw.fc2_w, FFp, M, Dp, FFp, AMDS_EPI_RESIDUAL, x_out, Dp, Lw.fc2_b, stream));
         }
     }
@@ -355,11 +354,21 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     auto colsum = [&](const void* x, long ld, float* out, long rows, int cols, int dt) {
         return amds_colsum(x, ld, out, (int)rows, cols, dt, 0, cs, wp.cs_bytes, stream);
     };
-    // [rows][cols] bf16 -> [cols][pitch] with the columns rows..pitch zeroed (the split-K contraction runs over the padded length)
+    // [rows][cols] bf16 -> [cols][pitch]; the columns rows..pitch must read as zeros (the split-K contraction runs over the padded length).  The
+    // transposes never write them, so they are zeroed ONCE per pitch for the widest matrix that will use the buffer (`zero_pads`) instead of in
+    // front of each of the 8 transposes of a layer (16 memset launches per step -> 4).
+    auto zero_pads = [&](void* dst, int max_cols, long rows, long pitch) -> int {
+        if (pitch > rows) AMDS_HIP(hipMemset2DAsync((char*)dst + rows * 2, pitch * 2, 0, (size_t)(pitch - rows) * 2, max_cols, st));
+        return AMDS_OK;
+    };
     auto transpose_pad = [&](const void* src, int cols, void* dst, long rows, long pitch) -> int {
-        if (pitch > rows) AMDS_HIP(hipMemset2DAsync((char*)dst + rows * 2, pitch * 2, 0, (size_t)(pitch - rows) * 2, cols, st));
         return amds_transpose16(src, cols, dst, pitch, (int)rows, cols, stream);
     };
+    const int wg_cols = std::max(std::max(3 * Da, FFp), Dp), wa_cols = std::max(std::max(std::max(FFp, Dp), Da), Fp);      // as plan_ws sized tg / ta
+    if (need_params && d.L > 0) {
+        RC(zero_pads(tg, wg_cols, M, Mp));
+        RC(zero_pads(ta, wa_cols, M, Mp));
+    }
     // dW[N][K] = dy^T x: contraction over the padded token dimension in split_k fp32 partials, summed deterministically
     auto wgrad = [&](const void* dyT, const void* xT, int Nn, int Kk, long Mpad, float* out) -> int {
         const long chunk = Mpad / split_k;
@@ -460,6 +469,8 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     AMDS_LAUNCH_CHECK("drop_cls_rows_kernel");
     RC(gelu_drop_bwd(sv + sp.zp, dxp, dzp, Mt * Dp, BF, AMDS_F32, BF, p_proj, seed, 1000, stream));
     if (need_params) {
+        RC(zero_pads(tg, Dp, Mt, Mtp));                   // the tile rows have their own pitch
+        RC(zero_pads(ta, Fp, Mt, Mtp));
         RC(transpose_pad(dzp, Dp, tg, Mt, Mtp));
         RC(transpose_pad(sv + sp.a, Fp, ta, Mt, Mtp));
         RC(wgrad(tg, ta, Dp, Fp, Mtp, G->proj_w));

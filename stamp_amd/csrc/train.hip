@@ -66,12 +66,12 @@ __global__ void __launch_bounds__(256) transpose16_vec_kernel(const uint16_t* __
 // 1.4 TB/s, and its second stage summed 257 partials serially in two blocks.)
 constexpr int CS_ROWS = 1024;
 template <typename TI>
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const TI* __restrict__ x, long ld, float* __restrict__ partial, int M, int N, int vec_ok) {
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const TI* __restrict__ x, long ld, float* __restrict__ partial, int M, int N, int vec_ok, int cs_rows) {
     typedef TI vec4 __attribute__((ext_vector_type(4)));
     __shared__ f32x4 red[16][16];
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n = blockIdx.x * 64 + cg * 4;
-    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    const int r0 = blockIdx.y * cs_rows, r1 = min(M, r0 + cs_rows);
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -125,7 +125,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 template <typename TO, int MAXV>
 __global__ void __launch_bounds__(256) ln_train_kernel(const float* __restrict__ x, long xs, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, TO* __restrict__ y, long ys,
-                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows, int cols, float eps) {
+                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows, int cols, float eps,
+                                                       float* __restrict__ xcopy, long xcs, int copy_cols) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -137,6 +138,15 @@ __global__ void __launch_bounds__(256) ln_train_kernel(const float* __restrict__
     for (int i = 0; i < MAXV; ++i) {
         const int c = i * 64 + lane;
         if (c < nv) { v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    if (xcopy) {      // the rows also go out unchanged (the residual GEMM that follows updates the copy in place): saves a device-to-device copy launch
+        float* cr = xcopy + (long)row * xcs;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) *reinterpret_cast<f32x4*>(cr + c * 4) = v[i];
+        }
+        for (int c = nv + lane; c < (copy_cols >> 2); c += 64) *reinterpret_cast<f32x4*>(cr + c * 4) = *reinterpret_cast<const f32x4*>(xr + c * 4);
     }
     const float mean = wave_sum(s) / (float)cols;
     float q = 0.f;
@@ -300,18 +310,23 @@ extern "C" size_t amds_colsum_workspace_bytes(int M, int N) { return (size_t)cdi
 extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     AMDS_REQUIRE(x && out && ws, "amds_colsum: null pointer");
     AMDS_REQUIRE(M > 0 && N > 0, "amds_colsum: bad shape");
-    const int nchunk = cdiv(M, CS_ROWS);
+    // up to 2 x CS_ROWS rows are ONE chunk (split-K partials: 32 rows; LayerNorm parameter-gradient partials: rows / 64; bags): without
+    // `accumulate` its "partial" IS the result and the second launch is skipped (30 -> 19 colsum_final launches per MIL training step)
+    const int nchunk = M <= 2 * CS_ROWS ? 1 : cdiv(M, CS_ROWS);
+    const int cs_rows = nchunk == 1 ? M : CS_ROWS;
     if (ws_bytes < (size_t)nchunk * N * 4) { set_error("amds_colsum: workspace too small"); return AMDS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
-    float* part = (float*)ws;
+    const bool direct = nchunk == 1 && !accumulate;
+    float* part = direct ? out : (float*)ws;
     const dim3 grid(cdiv(N, 64), nchunk);
     const int esz = in_dtype == AMDS_F32 ? 4 : 2;
     const int vec_ok = (ld % 4 == 0) && (((uintptr_t)x % (4 * esz)) == 0);      // 4-element vector loads need aligned rows
-    if (in_dtype == AMDS_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, ld, part, M, N, vec_ok);
-    else if (in_dtype == AMDS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, ld, part, M, N, vec_ok);
-    else if (in_dtype == AMDS_F16) hipLaunchKernelGGL((colsum_partial_kernel<f16>), grid, dim3(256), 0, st, (const f16*)x, ld, part, M, N, vec_ok);
+    if (in_dtype == AMDS_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, ld, part, M, N, vec_ok, cs_rows);
+    else if (in_dtype == AMDS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, ld, part, M, N, vec_ok, cs_rows);
+    else if (in_dtype == AMDS_F16) hipLaunchKernelGGL((colsum_partial_kernel<f16>), grid, dim3(256), 0, st, (const f16*)x, ld, part, M, N, vec_ok, cs_rows);
     else { set_error("amds_colsum: bad dtype"); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("colsum_partial_kernel");
+    if (direct) return AMDS_OK;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, out, nchunk, N, accumulate);
     AMDS_LAUNCH_CHECK("colsum_final_kernel");
     return AMDS_OK;
@@ -319,14 +334,22 @@ extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int
 
 extern "C" int amds_layernorm_train(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
                                     float* mean, float* rstd, int rows, int cols, float eps, int out_dtype, void* stream) {
+    return amds_layernorm_train_copy(x, x_row_stride, gamma, beta, y, y_row_stride, mean, rstd, rows, cols, eps, out_dtype, nullptr, 0, 0, stream);
+}
+
+extern "C" int amds_layernorm_train_copy(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
+                                         float* mean, float* rstd, int rows, int cols, float eps, int out_dtype, float* x_copy, long copy_row_stride,
+                                         int copy_cols, void* stream) {
     AMDS_REQUIRE(x && gamma && beta && y && mean && rstd, "amds_layernorm_train: null pointer");
+    AMDS_REQUIRE(!x_copy || (copy_cols >= cols && copy_cols % 4 == 0 && copy_cols <= x_row_stride && copy_cols <= copy_row_stride && x_copy != x),
+                 "amds_layernorm_train_copy: copy_cols=%d must be a multiple of 4 in [cols, row strides]", copy_cols);
     AMDS_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "amds_layernorm_train: cols=%d must be a multiple of 4 and <= 2048", cols);
     if (rows == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(cdiv(rows, 4)), block(256);
     // float4 slots per lane by row width (2 = 512 columns: the MIL heads): the same arithmetic in a quarter of the registers
 #define AMDS_LN_TRAIN(TO_, MV)                                                                                                                \
-    hipLaunchKernelGGL((ln_train_kernel<TO_, MV>), grid, block, 0, st, x, x_row_stride, gamma, beta, (TO_*)y, y_row_stride, mean, rstd, rows, cols, eps)
+    hipLaunchKernelGGL((ln_train_kernel<TO_, MV>), grid, block, 0, st, x, x_row_stride, gamma, beta, (TO_*)y, y_row_stride, mean, rstd, rows, cols, eps, x_copy, copy_row_stride, copy_cols)
 #define AMDS_LN_TRAIN_W(TO_)                                   \
     do {                                                       \
         if (cols <= 512) AMDS_LN_TRAIN(TO_, 2);                \
