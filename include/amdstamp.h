@@ -940,6 +940,13 @@ int amds_pinv_init_bwd(const float* x, const float* dz0, float* dx, int nmat, in
 int amds_gemm_batched(const void* A, long lda, long bsA, const void* W, long ldw, long bsW, int M, int N, int K,
                       int nbatch, int dtype, int epi, void* out, long ldo, long bsOut, const float* bias,
                       float acc_scale, void* stream);
+
+/* Weight-gradient partials straight from TOKEN-major operands (what autograd derives for `nn.Linear`: dW = dy^T x; reference
+ * src/stamp/modeling/models/__init__.py:239-279 -> loss.backward()): part[s][n][k] = sum over the tokens t of split s of dy[t][n] * x[t][k], fp32,
+ * s < split_k, each split = ceil(tokens / (64 split_k)) * 64 consecutive tokens (rows past `tokens` count as zeros).  dy [tokens][ld_dy], x [tokens][ld_x]
+ * 16-bit (dtype); N, K multiples of 256.  No transposed or padded copies of the operands: the kernel (id 15, csrc/gemm_4w16.h) reads 64-token row tiles
+ * into LDS and builds its MFMA fragments with gfx950's transpose read.  Sum the partials with amds_colsum(part, N*K, out, split_k, N*K, AMDS_F32, ...). */
+int amds_wgrad_tn(const void* dy, long ld_dy, const void* x, long ld_x, long tokens, int N, int K, int split_k, int dtype, float* part, void* stream);
 /* dst[c][r] = src[r][c] for 16-bit elements (dst leading dimension ld_dst >= R). */
 int amds_transpose16(const void* src, long ld_src, void* dst, long ld_dst, int R, int C, void* stream);
 /* out[n] (+)= sum_m x[m][n]; deterministic two-stage reduction (bias gradients, split-K partial sums). */

@@ -280,6 +280,7 @@ PROTOTYPES = {
     "amds_pinv_init_bwd_workspace_bytes": (_sz, [_i]),
     "amds_pinv_init_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_gemm_batched": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp]),
+    "amds_wgrad_tn": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp]),
     "amds_transpose16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
     "amds_colsum_workspace_bytes": (_sz, [_i, _i]),
     "amds_colsum": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

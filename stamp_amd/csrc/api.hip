@@ -293,6 +293,29 @@ extern "C" int amds_gemm_batched(const void* A, long lda, long bsA, const void* 
     return AMDS_ERR_INVALID;
 }
 
+// Weight-gradient partials straight from token-major operands (kernel id 15, gemm_4w16.h TN): part[s][n][k] = sum over the tokens t of split s of
+// dy[t][n] * x[t][k].  No transposed copies, no padded operands: token rows past `tokens` read as zeros through the buffer descriptors.
+extern "C" int amds_wgrad_tn(const void* dy, long ld_dy, const void* x, long ld_x, long tokens, int N, int K, int split_k, int dtype, float* part,
+                             void* stream) {
+    AMDS_REQUIRE(dy && x && part, "amds_wgrad_tn: null pointer");
+    AMDS_REQUIRE(tokens > 0 && N > 0 && K > 0 && split_k > 0 && split_k <= 65535, "amds_wgrad_tn: bad shape");
+    AMDS_REQUIRE(N % 256 == 0 && K % 256 == 0, "amds_wgrad_tn: needs N %% 256 == 0 and K %% 256 == 0 (N=%d K=%d)", N, K);
+    AMDS_REQUIRE(ld_dy % 8 == 0 && ld_x % 8 == 0 && ld_dy >= N && ld_x >= K, "amds_wgrad_tn: bad pitches");
+    AMDS_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)part & 15) == 0, "amds_wgrad_tn: pointers must be 16-byte aligned");
+    const long unit = 64L * split_k;
+    const long chunk = (tokens + unit - 1) / unit * 64;                 // tokens per split, a multiple of the K tile
+    AMDS_REQUIRE(tokens * std::max(ld_dy, ld_x) * 2 < (1L << 31), "amds_wgrad_tn: operand beyond the 2 GB a buffer descriptor addresses");
+    EpiArgs ep;
+    ep.out = part; ep.ldo = K; ep.bias = nullptr; ep.scale = nullptr; ep.pos = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.0f;
+    ep.bsA = chunk * ld_dy; ep.bsW = chunk * ld_x; ep.bsOut = (long)N * K; ep.nbatch = split_k; ep.ktot = tokens;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, 2.0 * tokens * (double)N * K, st);
+    if (dtype == AMDS_F16) return gemm_dispatch<f16>(15, AMDS_EPI_BIAS_F32, dy, ld_dy, x, ld_x, N, K, (int)chunk, ep, st);
+    if (dtype == AMDS_BF16) return gemm_dispatch<bf16>(15, AMDS_EPI_BIAS_F32, dy, ld_dy, x, ld_x, N, K, (int)chunk, ep, st);
+    set_error("amds_wgrad_tn: bad dtype %d", dtype);
+    return AMDS_ERR_INVALID;
+}
+
 // LayerNorm folded into the GEMMs around it (production kernel only): see include/amdstamp.h
 extern "C" int amds_gemm_lnfold(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int dtype, int epi, void* out,
                                 long ldo, const float* bias, const float* scale, void* xh, float* rowpart, const float* rowstat,

@@ -34,11 +34,18 @@ __device__ __forceinline__ f32x4 agpr_read(const f32x4& a) {
     return v;
 }
 
+// TN (kernel id 15, weight gradients): both operands are stored TOKEN-major -- A = dY [tokens][lda], W = X [tokens][ldw] -- and the contraction runs over the
+// tokens: C[M = dY columns][N = X columns] = sum_t dY[t][m] X[t][n], K = tokens per batch (split-K over blockIdx.y, fp32 partials).  A K tile is then 64 token
+// rows x 512 B per operand: the LDS-DMA image is [64 rows][32 chunks of 16 B] (lane-linear as ever; the 32-byte pair index of a row is XOR-ed with
+// g(row) = (row & 3) | ((row >> 1) & 4) on the source address), and a 16 x 32 MFMA fragment -- 8 consecutive TOKENS of one column per lane -- is two
+// ds_read_b64_tr_b16 (gfx950's transpose read: 16 lanes hand in 4 rows x 32 B and each gets one column of the 4 x 16 block; tools/ubench/tr16_probe.hip),
+// conflict-free by construction (a half-wave's 8 rows land in 8 different 32-byte bank slots).  No transposed copies of dY / X exist, and token rows past
+// ep.ktot are out of the buffer descriptors' range and read as 0 -- no padded operand, no memset.
 // PRL / PRS (AMDS_GEMM_PROBE builds only, kernel ids 21-23): the overlap probe of round 4.  Every K tile additionally issues PRL 16-byte
 // loads and PRS 16-byte stores per lane against a scratch region (ep.pos), spread behind the MFMAs of the third unit, and the K loop waits for
 // its operands with a COUNTED vmcnt so that this traffic stays in flight -- i.e. an epilogue's worth of HBM traffic perfectly overlapped with
 // the matrix pipe, on top of the unchanged real epilogue.  T(probe) - T(id 12) = what overlapped epilogue bytes would still cost.
-template <typename T, int EPI, int P3 = 6, int P0 = 6, bool SPREAD = true, int PRL = 0, int PRS = 0>
+template <typename T, int EPI, int P3 = 6, int P0 = 6, bool SPREAD = true, int PRL = 0, int PRS = 0, bool TN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, long ldw, int M, int N, int K,
                  EpiArgs ep, int tiles_m, int tiles_n) {
@@ -85,26 +92,34 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     // Buffer form (buffer_load_dwordx4 ... offen lds): one 32-bit byte offset per piece, constant over the K loop, the K
     // advance in the scalar offset, no vector address arithmetic in the loop; rows past M are out of range and read as 0.
     const int rows_a = min(BM, M - m0);
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(A + (long)m0 * lda), 0, (int)((((long)rows_a - 1) * lda + K) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(W + (long)n0 * ldw), 0, (int)(((long)(BN - 1) * ldw + K) * 2), 0x00020000);
+    // TN: the tokens of this batch that exist (the rest of the K range lies past num_records and reads as 0)
+    const long tn_valid = TN ? (ep.ktot > 0 ? min((long)K, ep.ktot - (long)blockIdx.y * K) : (long)K) : 0;
+    const __amdgpu_buffer_rsrc_t rsrc_a = TN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A + m0), 0, tn_valid > 0 ? (int)(((tn_valid - 1) * lda + BM) * 2) : 0, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A + (long)m0 * lda), 0, (int)((((long)rows_a - 1) * lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = TN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W + n0), 0, tn_valid > 0 ? (int)(((tn_valid - 1) * ldw + BN) * 2) : 0, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W + (long)n0 * ldw), 0, (int)(((long)(BN - 1) * ldw + K) * 2), 0x00020000);
     int voff[16];
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-        const int c = (it & 7) * NT + tid, row = c >> 3, cp = c & 7, sc = cp ^ ((row >> 1) & 7);
-        voff[it] = (int)(((long)row * (it < 8 ? lda : ldw) + sc * 8) * 2);
+        if constexpr (TN) {       // LDS position c = token row c >> 5, 16-byte chunk c & 31 of the tile's 512-byte row; the source chunk is the swizzled one
+            const int c = (it & 7) * NT + tid, row = c >> 5, pos = c & 31, g = (row & 3) | ((row >> 1) & 4);
+            voff[it] = (int)(((long)row * (it < 8 ? lda : ldw) + (pos ^ (g << 1)) * 8) * 2);
+        } else {
+            const int c = (it & 7) * NT + tid, row = c >> 3, cp = c & 7, sc = cp ^ ((row >> 1) & 7);
+            voff[it] = (int)(((long)row * (it < 8 ? lda : ldw) + sc * 8) * 2);
+        }
     }
     auto issue_pieces = [&](int kt, int lo, int hi_) {
         char* st = smem + (kt & 1) * STAGE;
-        const int koff = kt * BK * 2;
+        const int koff = TN ? kt * BK * (int)lda * 2 : kt * BK * 2;
+        const int koff_w = TN ? kt * BK * (int)ldw * 2 : koff;
 #pragma unroll
         for (int it = 0; it < 16; ++it)
             if (it >= lo && it < hi_) {
                 if (it < 8) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(st + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(st + A_BYTES + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(st + A_BYTES + ((it & 7) * NT + wave * 64) * 16), 16, voff[it], koff_w,
                                                              0, 0);
                 }
             }
@@ -156,15 +171,38 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     vec8 af[2][FI], wf[2][FJ];
     // fragments [lo, hi) of the 16 (8 A then 8 W) of k-half ks of tile kt into set s
+    // TN: lane (l15, kb) of a fragment hands in the address of 4 contiguous columns of token row 8 kb + (l15 >> 2) [+ 4 for the second read] and receives
+    // tokens 8 kb .. 8 kb + 3 [+ 4 ..] of column l15 of the 16-column block; the block's 32-byte pair sits at pair index (q ^ g), g as on the source side
+    const int tn_g = (l15 >> 2) | ((kb & 1) << 2);
+    const int tn_row = (kb * 8 + (l15 >> 2)) * 512 + (l15 & 1) * 8 + ((l15 >> 1) & 1) * 16;
     auto load_frags = [&](int kt, int ks, int s, int lo, int hi_) {
         const char* sb = smem + (kt & 1) * STAGE;
-        const int co = ((ks * 4 + kb) ^ swz) << 4;
+        if constexpr (TN) {
+            // Inline asm, not __builtin_amdgcn_ds_read_tr16_b64: the compiler treats the builtin as possibly aliasing the LDS-DMA writes in flight and puts
+            // an s_waitcnt vmcnt(0) in front of every pair of reads (2.2x the kernel's time).  The asm reads are invisible to its counters, so the
+            // K loop waits for them itself (lgkmcnt(0) where a fragment set is first used: k_tile below); the two halves of a fragment are written straight
+            // into the halves of its register quadruple (no moves: a move would read the registers before the data is there).
+            const unsigned base = (unsigned)(size_t)(sb + tn_row + ks * 32 * 512);
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q >= lo && q < hi_) {
-                if (q < 8) af[s][q] = *reinterpret_cast<const vec8*>(sb + a_off + q * 16 * ROWB + co);
-                else wf[s][q - 8] = *reinterpret_cast<const vec8*>(sb + w_off + (q - 8) * 16 * ROWB + co);
-            }
+            for (int q = 0; q < 16; ++q)
+                if (q >= lo && q < hi_) {
+                    const int qq = q & 7;
+                    const unsigned pq = base + (q < 8 ? 0 : A_BYTES) + ((q < 8 ? wm : wn) * 16 + 2 * (qq ^ tn_g)) * 16;
+                    u32x2 a0, a1;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0) : "v"(pq) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1) : "v"(pq) : "memory");
+                    const vec8 f = __builtin_bit_cast(vec8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+                    if (q < 8) af[s][qq] = f; else wf[s][qq] = f;
+                }
+        } else {
+            const int co = ((ks * 4 + kb) ^ swz) << 4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q >= lo && q < hi_) {
+                    if (q < 8) af[s][q] = *reinterpret_cast<const vec8*>(sb + a_off + q * 16 * ROWB + co);
+                    else wf[s][q - 8] = *reinterpret_cast<const vec8*>(sb + w_off + (q - 8) * 16 * ROWB + co);
+                }
+        }
     };
     // A unit = 32 MFMAs (set s, row blocks 4 ih .. 4 ih + 3, all 8 column blocks) with, behind the first NR of them, one fragment
     // read each (fragments rlo .. rlo + NR - 1 of k-half rks of tile rkt into set rs) and behind the next NC one LDS-DMA piece each
@@ -289,6 +327,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
 
     auto k_tile = [&](int kt, auto next_c, auto next2_c) {
         constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
+        if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // set 0 of this tile (read under the previous tile's last unit)
         if constexpr (SCHED == 0 && PRN > 0) {
             if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, Q3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
             if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, Q3 + Q0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
@@ -302,6 +341,7 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
         } else if constexpr (SCHED == 0) {
             if constexpr (NEXT) unit(0, 0, I8{}, kt, 1, 1, 0, IP0{}, kt + 1, Q3); else unit(0, 0, I8{}, kt, 1, 1, 0, I0{}, 0, 0);
             if constexpr (NEXT) unit(0, 1, I8{}, kt, 1, 1, 8, IP1{}, kt + 1, Q3 + Q0); else unit(0, 1, I8{}, kt, 1, 1, 8, I0{}, 0, 0);
+            if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // set 1 (read under the two units above)
             unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (last tile: no LDS-DMA request is outstanding)
@@ -658,14 +698,14 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
     }
 }
 
-template <typename T, int EPI, bool SPREAD = true, int P3 = 6, int P0 = 6, int PRL = 0, int PRS = 0>
+template <typename T, int EPI, bool SPREAD = true, int P3 = 6, int P0 = 6, int PRL = 0, int PRS = 0, bool TN = false>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st) {
     if constexpr (!epi_is_staged<EPI>() && EPI != AMDS_EPI_SWIGLU) {
         return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     } else {
         constexpr int LDS = 2 * (256 + 256) * 128;
-        auto kern = gemm_4w16_kernel<T, EPI, P3, P0, SPREAD, PRL, PRS>;
+        auto kern = gemm_4w16_kernel<T, EPI, P3, P0, SPREAD, PRL, PRS, TN>;
         EpiArgs epp = ep;
         if constexpr (PRL + PRS > 0) {      // probe scratch: one region per workgroup, never read by anything real
             static char* scratch = nullptr;

@@ -47,6 +47,9 @@ struct EpiArgs {
     float* rowpart = nullptr;
     const float* rowstat = nullptr;
     const float* colsum = nullptr;
+    // token-major operands (gemm_4w16.h TN, kernel id 15): number of token rows that exist in A / W counted from batch 0's first row; batch b contracts
+    // rows b K .. b K + K - 1 and those >= ktot read as zeros (0 = all K rows of every batch exist)
+    long ktot = 0;
 };
 
 template <int EPI>
@@ -416,7 +419,7 @@ static int launch_gemm_8p64(const void* A, long lda, const void* W, long ldw, in
 template <typename T, int EPI>
 static int launch_gemm_4w64(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w64.h
-template <typename T, int EPI, bool SPREAD, int P3, int P0, int PRL, int PRS>
+template <typename T, int EPI, bool SPREAD, int P3, int P0, int PRL, int PRS, bool TN>
 static int launch_gemm_4w16(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const EpiArgs& ep,
                             hipStream_t st);   // gemm_4w16.h
 
@@ -433,15 +436,19 @@ static int launch_gemm(int cfg, const void* A, long lda, const void* W, long ldw
                        const EpiArgs& ep, hipStream_t st) {
     if (cfg == 10 && N % 256 == 0 && ep.nbatch == 1) return launch_gemm_4w64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);
     if (cfg == 10) cfg = 8;
-    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 0>(A, lda, W, ldw, M, N, K, ep, st);
-    if (cfg == 13 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, -2, 0, 0, 0>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 12 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 0, false>(A, lda, W, ldw, M, N, K, ep, st);
+    if (cfg == 13 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, -2, 0, 0, 0, false>(A, lda, W, ldw, M, N, K, ep, st);
 #ifdef AMDS_GEMM_PROBE      // overlap probe of round 4 (gemm_4w16.h PRL / PRS; make PROBE=1): K-loop traffic of (0, 2) / (1, 1) / (4, 4) loads, stores per lane and K tile
     if constexpr (EPI == AMDS_EPI_BIAS || EPI == AMDS_EPI_BIAS_GELU || EPI == AMDS_EPI_RESIDUAL) {
-        if (cfg == 21 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 2>(A, lda, W, ldw, M, N, K, ep, st);
-        if (cfg == 22 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 1, 1>(A, lda, W, ldw, M, N, K, ep, st);
-        if (cfg == 23 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 4, 4>(A, lda, W, ldw, M, N, K, ep, st);
+        if (cfg == 21 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 2, false>(A, lda, W, ldw, M, N, K, ep, st);
+        if (cfg == 22 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 1, 1, false>(A, lda, W, ldw, M, N, K, ep, st);
+        if (cfg == 23 && N % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 4, 4, false>(A, lda, W, ldw, M, N, K, ep, st);
     }
 #endif
+    if constexpr (EPI == AMDS_EPI_BIAS_F32) {      // 15 = the token-major (TN) form of id 12: weight gradients straight from dY / X (gemm_4w16.h)
+        if (cfg == 15 && N % 256 == 0 && M % 256 == 0) return launch_gemm_4w16<T, EPI, true, 6, 6, 0, 0, true>(A, lda, W, ldw, M, N, K, ep, st);
+    }
+    if (cfg == 15) { set_error("amds_gemm: kernel 15 (token-major operands) takes the BIAS_F32 epilogue and M, N multiples of 256"); return AMDS_ERR_INVALID; }
     if (cfg == 12 || cfg == 13) cfg = 8;
 
     if (cfg == 8 && N % 256 == 0) return launch_gemm_8p64<T, EPI>(A, lda, W, ldw, M, N, K, ep, st);

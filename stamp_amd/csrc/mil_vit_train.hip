@@ -365,7 +365,9 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         return amds_transpose16(src, cols, dst, pitch, (int)rows, cols, stream);
     };
     const int wg_cols = std::max(std::max(3 * Da, FFp), Dp), wa_cols = std::max(std::max(std::max(FFp, Dp), Da), Fp);      // as plan_ws sized tg / ta
-    if (need_params && d.L > 0) {
+    // dW straight from the token-major dy / x (amds_wgrad_tn: no transposes, no padded copies); AMDS_WGRAD_TN=0: the transposed form (A/B)
+    static const bool use_tn = !(getenv("AMDS_WGRAD_TN") && atoi(getenv("AMDS_WGRAD_TN")) == 0);
+    if (need_params && d.L > 0 && !use_tn) {
         RC(zero_pads(tg, wg_cols, M, Mp));
         RC(zero_pads(ta, wa_cols, M, Mp));
     }
@@ -373,6 +375,11 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     auto wgrad = [&](const void* dyT, const void* xT, int Nn, int Kk, long Mpad, float* out) -> int {
         const long chunk = Mpad / split_k;
         RC(amds_gemm_batched(dyT, Mpad, chunk, xT, Mpad, chunk, Nn, Kk, (int)chunk, split_k, BF, AMDS_EPI_BIAS_F32, part, Kk, (long)Nn * Kk, nullptr, 1.0f, stream));
+        return amds_colsum(part, (long)Nn * Kk, out, split_k, Nn * Kk, AMDS_F32, 0, cs, wp.cs_bytes, stream);
+    };
+
+    auto wgrad_tn = [&](const void* dy, long ld_dy, const void* xx, long ld_x, long tokens, int Nn, int Kk, float* out) -> int {
+        RC(amds_wgrad_tn(dy, ld_dy, xx, ld_x, tokens, Nn, Kk, split_k, BF, part, stream));
         return amds_colsum(part, (long)Nn * Kk, out, split_k, Nn * Kk, AMDS_F32, 0, cs, wp.cs_bytes, stream);
     };
 
@@ -411,17 +418,23 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         else RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));
         RC(gemm(g16, Dp, Lw.fc2_wt, Dp, M, FFp, Dp, AMDS_EPI_BIAS, du, FFp, nullptr, stream));                              // du = dy W2
         if (need_params) {
-            RC(transpose_pad(g16, Dp, tg, M, Mp));
-            RC(transpose_pad(u, FFp, ta, M, Mp));
-            RC(wgrad(tg, ta, Dp, FFp, Mp, Gl->fc2_w));
+            if (use_tn) RC(wgrad_tn(g16, Dp, u, FFp, M, Dp, FFp, Gl->fc2_w));
+            else {
+                RC(transpose_pad(g16, Dp, tg, M, Mp));
+                RC(transpose_pad(u, FFp, ta, M, Mp));
+                RC(wgrad(tg, ta, Dp, FFp, Mp, Gl->fc2_w));
+            }
             RC(p_ff > 0.f ? colsum(g16, Dp, Gl->fc2_b, M, Dp, BF) : colsum(dx, Dp, Gl->fc2_b, M, Dp, AMDS_F32));
         }
         RC(gelu_drop_bwd(z, du, dz, M * FFp, BF, BF, BF, p_ff, seed, 10 * l + 2, stream));
         RC(gemm(dz, FFp, Lw.fc1_wt, FFp, M, Dp, FFp, AMDS_EPI_BIAS_F32, dh, Dp, nullptr, stream));                          // dh2 fp32
         if (need_params) {
-            RC(transpose_pad(dz, FFp, tg, M, Mp));
-            RC(transpose_pad(h2, Dp, ta, M, Mp));
-            RC(wgrad(tg, ta, FFp, Dp, Mp, Gl->fc1_w));
+            if (use_tn) RC(wgrad_tn(dz, FFp, h2, Dp, M, FFp, Dp, Gl->fc1_w));
+            else {
+                RC(transpose_pad(dz, FFp, tg, M, Mp));
+                RC(transpose_pad(h2, Dp, ta, M, Mp));
+                RC(wgrad(tg, ta, FFp, Dp, Mp, Gl->fc1_w));
+            }
             RC(colsum(dz, FFp, Gl->fc1_b, M, FFp, BF));
         }
         RC(amds_layernorm_bwd(dh, Dp, x_mid, Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, Dp, 1,
@@ -430,9 +443,12 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));                                                           // d(x_mid)
         RC(gemm(g16, Dp, Lw.out_wt, Dp, M, Da, Dp, AMDS_EPI_BIAS, datt, Da, nullptr, stream));
         if (need_params) {
-            RC(transpose_pad(g16, Dp, tg, M, Mp));
-            RC(transpose_pad(att, Da, ta, M, Mp));
-            RC(wgrad(tg, ta, Dp, Da, Mp, Gl->out_w));
+            if (use_tn) RC(wgrad_tn(g16, Dp, att, Da, M, Dp, Da, Gl->out_w));
+            else {
+                RC(transpose_pad(g16, Dp, tg, M, Mp));
+                RC(transpose_pad(att, Da, ta, M, Mp));
+                RC(wgrad(tg, ta, Dp, Da, Mp, Gl->out_w));
+            }
             RC(colsum(dx, Dp, Gl->out_b, M, Dp, AMDS_F32));
         }
         float* dqs = reinterpret_cast<float*>(wk + wp.dqs);
@@ -452,9 +468,12 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             RC(amds_attention_bwd_train(qkv, att, datt, lse, dqs, dqkv, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         }
         if (need_params) {
-            RC(transpose_pad(dqkv, 3 * Da, tg, M, Mp));
-            RC(transpose_pad(h1, Dp, ta, M, Mp));
-            RC(wgrad(tg, ta, 3 * Da, Dp, Mp, Gl->in_w));
+            if (use_tn) RC(wgrad_tn(dqkv, 3 * Da, h1, Dp, M, 3 * Da, Dp, Gl->in_w));
+            else {
+                RC(transpose_pad(dqkv, 3 * Da, tg, M, Mp));
+                RC(transpose_pad(h1, Dp, ta, M, Mp));
+                RC(wgrad(tg, ta, 3 * Da, Dp, Mp, Gl->in_w));
+            }
             RC(colsum(dqkv, 3 * Da, Gl->in_b, M, 3 * Da, BF));
         }
         RC(gemm(dqkv, 3 * Da, Lw.in_wt, 3 * Da, M, Dp, 3 * Da, AMDS_EPI_BIAS_F32, dh, Dp, nullptr, stream));                 // dh1 fp32
@@ -469,11 +488,14 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     AMDS_LAUNCH_CHECK("drop_cls_rows_kernel");
     RC(gelu_drop_bwd(sv + sp.zp, dxp, dzp, Mt * Dp, BF, AMDS_F32, BF, p_proj, seed, 1000, stream));
     if (need_params) {
-        RC(zero_pads(tg, Dp, Mt, Mtp));                   // the tile rows have their own pitch
-        RC(zero_pads(ta, Fp, Mt, Mtp));
-        RC(transpose_pad(dzp, Dp, tg, Mt, Mtp));
-        RC(transpose_pad(sv + sp.a, Fp, ta, Mt, Mtp));
-        RC(wgrad(tg, ta, Dp, Fp, Mtp, G->proj_w));
+        if (use_tn) RC(wgrad_tn(dzp, Dp, sv + sp.a, Fp, Mt, Dp, Fp, G->proj_w));
+        else {
+            RC(zero_pads(tg, Dp, Mt, Mtp));                   // the tile rows have their own pitch
+            RC(zero_pads(ta, Fp, Mt, Mtp));
+            RC(transpose_pad(dzp, Dp, tg, Mt, Mtp));
+            RC(transpose_pad(sv + sp.a, Fp, ta, Mt, Mtp));
+            RC(wgrad(tg, ta, Dp, Fp, Mtp, G->proj_w));
+        }
         RC(colsum(dzp, Dp, G->proj_b, Mt, Dp, BF));
     }
     if (dbags) RC(gemm(dzp, Dp, w.proj_wt, Dp, Mt, Fp, Dp, AMDS_EPI_BIAS_F32, dbags, Fp, nullptr, stream));                 // [Mt][Fp] fp32 (padded columns = 0)

@@ -177,3 +177,15 @@ def cdist_mean(coords: torch.Tensor) -> torch.Tensor:
     rows = torch.empty(B * T, 1, dtype=torch.float32, device=coords.device)
     _lib.check(_lib.lib().amds_cdist_rowsum(_p(coords.contiguous()), _p(rows), B, T, _stream()), "cdist_rowsum")
     return colsum(rows).reshape(()) / float(B * T * T)
+
+
+def wgrad_tn(dy: torch.Tensor, x: torch.Tensor, split_k: int = 32) -> torch.Tensor:
+    """dW [N, K] = dy^T x from TOKEN-major 16-bit operands dy [tokens, N], x [tokens, K] (rows may be views with a pitch): `amds_wgrad_tn` partials
+    (no transposed copies; include/amdstamp.h) summed by the deterministic column sum."""
+    _dev(dy, x)
+    assert dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.dtype == x.dtype and dy.stride(1) == 1 and x.stride(1) == 1
+    tokens, N = dy.shape
+    K = x.shape[1]
+    part = torch.empty(split_k, N, K, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().amds_wgrad_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), tokens, N, K, split_k, act_code(dy.dtype), _p(part), _stream()), "wgrad_tn")
+    return colsum(part.view(split_k, N * K)).view(N, K)

@@ -457,3 +457,31 @@ def test_fit_driven_from_a_directory_of_feature_files(gpu, tmp_path):
     for i in (0, 5, 17):
         (bh, ch, nh, _), (bd, cd, nd, _) = ds_h[i], ds_d[i]
         assert bd.is_cuda and torch.equal(bd.cpu(), bh) and torch.equal(cd.cpu(), ch) and nh == nd
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tokens,N,K,split_k,pitch", [(2048, 256, 256, 1, 0), (65600, 512, 512, 32, 0), (1000, 256, 512, 4, 64), (77, 512, 256, 2, 0), (4100, 768, 256, 8, 8),
+                                                      (3000, 256, 1536, 3, 0)])
+def test_wgrad_tn_token_major_operands(gpu, dt, tokens, N, K, split_k, pitch):
+    """amds_wgrad_tn (kernel id 15: LDS-DMA of 64-token row tiles + ds_read_b64_tr_b16 fragments) against fp64 dy^T x on the same 16-bit operands, and
+    BIT-identical to the form it replaces (two transposes with zeroed pad columns + the split-K batched GEMM + the same column sum): token counts that
+    are no multiple of 64 or of the split, pitched row views, one split, every tile position."""
+    g = torch.Generator().manual_seed(tokens + N + K)
+    dyb = (torch.randn(tokens, N + pitch, generator=g) * 0.5).to(gpu, dt)
+    xb = (torch.randn(tokens, K + pitch, generator=g) * 0.5).to(gpu, dt)
+    dy, x = dyb[:, :N], xb[:, pitch:pitch + K] if pitch % 8 == 0 else xb[:, :K]
+    got = T.wgrad_tn(dy, x, split_k)
+    ref = dy.double().t() @ x.double()
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6 * max(1.0, (tokens / 1000) ** 0.5), err                  # fp32 accumulation of exact products
+    # the replaced form: transposes (pad columns zero) -> split-K batched GEMM -> column sum
+    unit = 64 * split_k
+    Mp = (tokens + unit - 1) // unit * unit
+    dyT, xT = T.transpose16(dy.contiguous(), Mp), T.transpose16(x.contiguous(), Mp)
+    chunk = Mp // split_k
+    part = torch.empty(split_k, N, K, dtype=torch.float32, device=gpu)
+    _lib.check(_lib.lib().amds_gemm_batched(dyT.data_ptr(), Mp, chunk, xT.data_ptr(), Mp, chunk, N, K, chunk, split_k, ops.act_code(dt), _lib.EPI_BIAS_F32,
+                                            part.data_ptr(), K, N * K, None, 1.0, None), "gemm_batched")
+    old = T.colsum(part.view(split_k, N * K)).view(N, K)
+    assert torch.equal(got, old)
+    assert torch.equal(got, T.wgrad_tn(dy, x, split_k))
