@@ -966,6 +966,13 @@ size_t amds_layernorm_bwd_workspace_bytes(int rows, int cols);
 int amds_layernorm_bwd(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
                        const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
                        int rows, int cols, void* ws, size_t ws_bytes, void* stream);
+/* Same, and dx (after the skip add) also goes out as bf16 rows into dx_bf16 -- the operand of the GEMMs that take dx next -- multiplied by the mask and
+ * scale of dropout site (seed, stream_id) at rate p when p > 0 (the bits of amds_dropout_cast_bwd over a [rows][cols] tensor): the backward of
+ * `x = x + Dropout(...)` / of a plain residual add without a separate cast pass over dx.  dx_bf16 may be NULL (= amds_layernorm_bwd). */
+int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                            const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
+                            int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed,
+                            uint32_t stream_id, void* stream);
 /* exact-erf GELU on a stored pre-activation and its derivative (dz = du * gelu'(z)). */
 int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, void* stream);
 int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, void* stream);

@@ -288,6 +288,7 @@ PROTOTYPES = {
     "amds_layernorm_train_copy": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp, _l, _i, _vp]),
     "amds_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "amds_layernorm_bwd": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_layernorm_bwd_cast": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _l, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_gelu_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "amds_gelu_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "amds_attention_fwd_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -401,6 +401,7 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
                           dx, (long)S * Dp, 0, need_params ? G->norm_w : scratch_g, need_params ? G->norm_b : scratch_g + D, 0, Bb, D, lnb, wp.lnb_bytes,
                           stream));
 
+    const bool fused_cast = (D == Dp) && !(getenv("AMDS_LNBWD_CAST") && atoi(getenv("AMDS_LNBWD_CAST")) == 0);      // (pad columns of g16 would stay unwritten otherwise)
     for (int l = d.L - 1; l >= 0; --l) {
         const amds_mil_vit_layer& Lw = w.layers_host[l];
         const LayerOff& o = sp.layer[l];
@@ -414,8 +415,11 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         const void *h1 = sv + o.h1, *h2 = sv + o.h2, *qkv = sv + o.qkv, *att = sv + o.att, *z = sv + o.z, *u = sv + o.u;
         const float* lse = reinterpret_cast<const float*>(sv + o.lse);
         // ---- feed-forward branch ----------------------------------------------------------------------------------------------------------
-        if (p_ff > 0.f) RC(amds_dropout_cast_bwd(dx, Dp, g16, Dp, M, Dp, BF, p_ff, seed, 10 * l + 3, stream));
-        else RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));
+        // g16 = bf16(Dropout'(dx)): written by the LayerNorm backward that produced dx (layers below the top one, D == Dp), else by its own pass
+        if (!(fused_cast && l < d.L - 1)) {
+            if (p_ff > 0.f) RC(amds_dropout_cast_bwd(dx, Dp, g16, Dp, M, Dp, BF, p_ff, seed, 10 * l + 3, stream));
+            else RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));
+        }
         RC(gemm(g16, Dp, Lw.fc2_wt, Dp, M, FFp, Dp, AMDS_EPI_BIAS, du, FFp, nullptr, stream));                              // du = dy W2
         if (need_params) {
             if (use_tn) RC(wgrad_tn(g16, Dp, u, FFp, M, Dp, FFp, Gl->fc2_w));
@@ -437,10 +441,11 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             }
             RC(colsum(dz, FFp, Gl->fc1_b, M, FFp, BF));
         }
-        RC(amds_layernorm_bwd(dh, Dp, x_mid, Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, Dp, 1,
-                              need_params ? Gl->ln2_w : scratch_g, need_params ? Gl->ln2_b : scratch_g + D, 0, (int)M, D, lnb, wp.lnb_bytes, stream));
+        RC(amds_layernorm_bwd_cast(dh, Dp, x_mid, Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, Dp, 1,
+                                   need_params ? Gl->ln2_w : scratch_g, need_params ? Gl->ln2_b : scratch_g + D, 0, (int)M, D, lnb, wp.lnb_bytes,
+                                   fused_cast ? g16 : nullptr, Dp, 0.f, 0, 0, stream));
         // ---- attention branch -------------------------------------------------------------------------------------------------------------
-        RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));                                                           // d(x_mid)
+        if (!fused_cast) RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));                                         // d(x_mid) as bf16
         RC(gemm(g16, Dp, Lw.out_wt, Dp, M, Da, Dp, AMDS_EPI_BIAS, datt, Da, nullptr, stream));
         if (need_params) {
             if (use_tn) RC(wgrad_tn(g16, Dp, att, Da, M, Dp, Da, Gl->out_w));
@@ -477,8 +482,10 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             RC(colsum(dqkv, 3 * Da, Gl->in_b, M, 3 * Da, BF));
         }
         RC(gemm(dqkv, 3 * Da, Lw.in_wt, 3 * Da, M, Dp, 3 * Da, AMDS_EPI_BIAS_F32, dh, Dp, nullptr, stream));                 // dh1 fp32
-        RC(amds_layernorm_bwd(dh, Dp, x_in, Dp, reinterpret_cast<const float*>(sv + o.mu1), reinterpret_cast<const float*>(sv + o.rs1), Lw.ln1_w, dx, Dp, 1,
-                              need_params ? Gl->ln1_w : scratch_g, need_params ? Gl->ln1_b : scratch_g + D, 0, (int)M, D, lnb, wp.lnb_bytes, stream));
+        // (the layer below starts with g16 = bf16(Dropout'(dx)) at ITS feed-forward dropout site: written here, where dx is made)
+        RC(amds_layernorm_bwd_cast(dh, Dp, x_in, Dp, reinterpret_cast<const float*>(sv + o.mu1), reinterpret_cast<const float*>(sv + o.rs1), Lw.ln1_w, dx, Dp, 1,
+                                   need_params ? Gl->ln1_w : scratch_g, need_params ? Gl->ln1_b : scratch_g + D, 0, (int)M, D, lnb, wp.lnb_bytes,
+                                   (fused_cast && l > 0) ? g16 : nullptr, Dp, p_ff, seed, (uint32_t)(10 * (l - 1) + 3), stream));
     }
     // ---- class token, project_features ------------------------------------------------------------------------------------------------------
     if (need_params) RC(colsum(dx, (long)S * Dp, G->class_token, Bb, Dp, AMDS_F32));                                           // class-token rows

@@ -182,7 +182,8 @@ template <int MAXV>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, long dys, const float* __restrict__ x, long xs,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx, long dxs, int add_skip,
-                                                     float* __restrict__ dgp, float* __restrict__ dbp, int rows, int cols) {
+                                                     float* __restrict__ dgp, float* __restrict__ dbp, int rows, int cols,
+                                                     bf16* __restrict__ o16, long o16s, uint64_t dseed, uint32_t dsid, uint32_t dthr, float dscale) {
     extern __shared__ float red[];        // [2][4][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
@@ -225,6 +226,17 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rs * (gv[i][e] - s1 - xh[i][e] * s2);
                 *p = o;
+                if (o16) {      // the bf16 operand of the GEMMs that consume dx next, with the NEXT dropout site's mask when there is one (amds_dropout_cast_bwd's bits:
+                                // flat element index row * cols + column) -- the rows are in registers anyway, a separate cast pass re-reads them
+                    typedef bf16 bvec4 __attribute__((ext_vector_type(4)));
+                    bvec4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool keep = dthr == 0 || drop_keep_flat(dseed, dsid, (long)row * cols + c * 4 + e, dthr);
+                        w[e] = (bf16)(keep ? (dthr ? o[e] * dscale : o[e]) : 0.f);
+                    }
+                    *reinterpret_cast<bvec4*>(o16 + (long)row * o16s + c * 4) = w;
+                }
             }
         }
     }
@@ -370,7 +382,18 @@ extern "C" size_t amds_layernorm_bwd_workspace_bytes(int rows, int cols) { retur
 extern "C" int amds_layernorm_bwd(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
                                   const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
                                   int rows, int cols, void* ws, size_t ws_bytes, void* stream) {
+    return amds_layernorm_bwd_cast(dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, dx_stride, add_skip, dgamma, dbeta, accumulate_params, rows, cols, ws, ws_bytes,
+                                   nullptr, 0, 0.f, 0, 0, stream);
+}
+
+extern "C" int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                                       const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
+                                       int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed,
+                                       uint32_t stream_id, void* stream) {
     AMDS_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "amds_layernorm_bwd: null pointer");
+    AMDS_REQUIRE(!dx_bf16 || (dx_bf16_stride >= cols && dx_bf16_stride % 4 == 0 && p >= 0.f && p < 1.f), "amds_layernorm_bwd_cast: bad 16-bit output / rate");
+    const uint32_t dthr = (dx_bf16 && p > 0.f) ? drop_thr16(p) : 0;
+    const float dscale = dthr ? drop_scale(dthr) : 1.0f;
     AMDS_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "amds_layernorm_bwd: bad shape");
     if (ws_bytes < amds_layernorm_bwd_workspace_bytes(rows, cols)) { set_error("amds_layernorm_bwd: workspace too small"); return AMDS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
@@ -381,7 +404,7 @@ extern "C" int amds_layernorm_bwd(const float* dy, long dy_stride, const float* 
     const size_t cws_bytes = amds_colsum_workspace_bytes(nblk, cols);
 #define AMDS_LN_BWD(MV)                                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<MV>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, \
-                       dx_stride, add_skip, dgp, dbp, rows, cols)
+                       dx_stride, add_skip, dgp, dbp, rows, cols, (bf16*)dx_bf16, dx_bf16_stride, seed, stream_id, dthr, dscale)
     if (cols <= 512) AMDS_LN_BWD(2);
     else if (cols <= 1024) AMDS_LN_BWD(4);
     else AMDS_LN_BWD(8);
