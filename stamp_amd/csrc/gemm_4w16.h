@@ -181,7 +181,9 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
             // Inline asm, not __builtin_amdgcn_ds_read_tr16_b64: the compiler treats the builtin as possibly aliasing the LDS-DMA writes in flight and puts
             // an s_waitcnt vmcnt(0) in front of every pair of reads (2.2x the kernel's time).  The asm reads are invisible to its counters, so the
             // K loop waits for them itself (lgkmcnt(0) where a fragment set is first used: k_tile below); the two halves of a fragment are written straight
-            // into the halves of its register quadruple (no moves: a move would read the registers before the data is there).
+            // into the halves of its register quadruple (no moves: a move would read the registers before the data is there).  That property is the
+            // compiler's to break: tools/check_tn_isa.py checks it on the compiled kernel (tests/test_cpu_isa.py), the GPU tests hold the binary bit-identical
+            // to the transposed form; a first attempt to add compiler-visible MFMAs on these fragments (bias-gradient sums) made it move them early.
             const unsigned base = (unsigned)(size_t)(sb + tn_row + ks * 32 * 512);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
