@@ -203,18 +203,23 @@ class PackedVit:
         m["norm"] = (get("transformer.norm.weight").contiguous(), get("transformer.norm.bias").contiguous())
         m["head_w"], m["head_b"] = get("mlp_head.0.weight").contiguous(), get("mlp_head.0.bias").contiguous()
         self.m = m
-        cast = lambda w, dt=None: ops.cast_pad(w, w.shape[1], dt or self.act)  # noqa: E731
-        self.w: dict = {"proj_w": cast(m["proj_w"]), "layers": []}
-        self.wt: dict = {"layers": []}
+        # the 16-bit operand copies (and their transposes) are refreshed IN PLACE after every optimiser step: same buffers, no zero-fill launches, and the
+        # C structs built over them stay valid (they are rebuilt only when a master tensor moved: padded / stacked ones are fresh torch tensors)
+        old_w, old_wt = getattr(self, "w", None), getattr(self, "wt", None)
+        prev = lambda dct, *keys: (dct[keys[0]] if len(keys) == 1 else dct["layers"][keys[0]][keys[1]]) if dct is not None and len(dct.get("layers", ())) == d.L else None  # noqa: E731
+        cast = lambda w, dt, out: ops.cast_pad(w, w.shape[1], dt or self.act, out=out)  # noqa: E731
+        tr = lambda w, out: T.transpose16(w, out=out) if out is not None and out.shape == (w.shape[1], w.shape[0]) else T.transpose16(w)  # noqa: E731
+        new_w: dict = {"proj_w": cast(m["proj_w"], None, prev(old_w, "proj_w")), "layers": []}
+        new_wt: dict = {"layers": []}
         if self.train:
-            self.wt["proj_w"] = T.transpose16(self.w["proj_w"])
-        for Lm in m["layers"]:
+            new_wt["proj_w"] = tr(new_w["proj_w"], prev(old_wt, "proj_w") if old_wt and "proj_w" in old_wt else None)
+        for l, Lm in enumerate(m["layers"]):
             # ALiBi: the attention output is bf16 (range, see amds_attention_alibi), so its output projection runs on bf16 operands
-            Lw = {"in_w": cast(Lm["in_w"]), "out_w": cast(Lm["out_w"], BF if d.alibi else None), "fc1_w": cast(Lm["fc1_w"]),
-                  "fc2_w": cast(Lm["fc2_w"])}
-            self.w["layers"].append(Lw)
+            Lw = {k: cast(Lm[k], BF if (d.alibi and k == "out_w") else None, prev(old_w, l, k)) for k in ("in_w", "out_w", "fc1_w", "fc2_w")}
+            new_w["layers"].append(Lw)
             if self.train:
-                self.wt["layers"].append({k: T.transpose16(v) for k, v in Lw.items()})
+                new_wt["layers"].append({k: tr(v, prev(old_wt, l, k)) for k, v in Lw.items()})
+        self.w, self.wt = new_w, new_wt
         self._c = None
 
     def c_structs(self):

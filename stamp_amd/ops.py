@@ -49,12 +49,12 @@ def act_code(dtype: torch.dtype) -> int:
     return _DT[dtype]
 
 
-def cast_pad(src: torch.Tensor, ld_dst: int, dtype: torch.dtype) -> torch.Tensor:
-    """fp32 [rows, cols] -> dtype [rows, ld_dst] with zero padded columns."""
+def cast_pad(src: torch.Tensor, ld_dst: int, dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
+    """fp32 [rows, cols] -> dtype [rows, ld_dst] with zero padded columns (`out`: a buffer of that shape to refresh in place)."""
     _dev(src)
     src = src.contiguous().float()
     rows, cols = src.shape
-    dst = torch.empty(rows, ld_dst, dtype=dtype, device=src.device)
+    dst = out if out is not None and out.shape == (rows, ld_dst) and out.dtype == dtype and out.is_contiguous() else torch.empty(rows, ld_dst, dtype=dtype, device=src.device)
     _lib.check(_lib.lib().amds_cast_pad(_p(src), cols, _p(dst), ld_dst, rows, cols, _DT[dtype], _stream()), "cast_pad")
     return dst
 
