@@ -28,19 +28,34 @@ template <typename T>
 __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ dq_sum,
                                                             int Tn, int H, long total, const T* __restrict__ u = nullptr,
                                                             const float* __restrict__ bias_scale = nullptr, float* __restrict__ dbs_part = nullptr) {
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per (b, q, h)
-    if (wv >= total) return;
-    const int lane = threadIdx.x & 63;
-    const long bq = wv / H;
-    const int h = (int)(wv - bq * H);
-    const long off = bq * (long)H * 64 + h * 64 + lane;
-    const float g = Act<T>::to_f32(dout[off]);
-    const float osm = Act<T>::to_f32(o[off]);
-    float gu = 0.f;
-    if (u) gu = -g * Act<T>::to_f32(u[off]);
-    const float s = wave_sum(osm * g);
-    if (u) gu = wave_sum(gu);
-    if (lane == 0) {
+    // eight (b, q, h) rows per wave: 8 lanes x 16 bytes per 64-element row, the row sum over its 8 lanes by three DPP butterflies (one wave per row with
+    // 2-byte loads moved 1.3 TB/s: 104 us per call at 65 600 x 8 rows)
+    typedef typename Act<T>::vec8 vec8;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + ((threadIdx.x & 63) >> 3);
+    const int sub = threadIdx.x & 7;
+    const bool live = row < total;
+    const long r = live ? row : total - 1;
+    const long bq = r / H;
+    const int h = (int)(r - bq * H);
+    const long off = bq * (long)H * 64 + h * 64 + sub * 8;
+    const vec8 gv = *reinterpret_cast<const vec8*>(dout + off), ov = *reinterpret_cast<const vec8*>(o + off);
+    float s = 0.f, gu = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(Act<T>::to_f32(ov[e]), Act<T>::to_f32(gv[e]), s);
+    if (u) {
+        const vec8 uv = *reinterpret_cast<const vec8*>(u + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gu = fmaf(-Act<T>::to_f32(gv[e]), Act<T>::to_f32(uv[e]), gu);
+    }
+    auto sum8 = [](float v) {      // over the 8 lanes that share lane >> 3: xor 1, xor 2 (quad_perm), xor 7 (row_half_mirror)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+        return v;
+    };
+    s = sum8(s);
+    if (u) gu = sum8(gu);
+    if (sub == 0 && live) {
         const long b = bq / Tn;
         const int q = (int)(bq - b * Tn);
         dq_sum[(b * H + h) * (long)Tn + q] = s;
@@ -376,7 +391,7 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* dout, con
                            hipStream_t st, const void* u = nullptr, const float* coords = nullptr, const float* bias_scale = nullptr,
                            const float* dist_scale = nullptr, float* dbs_part = nullptr, float p_drop = 0.f, uint64_t seed = 0, uint32_t drop_stream = 0) {
     const long total = (long)B * T_ * H;
-    hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, (const T*)o, (const T*)dout, dq_sum, T_, H, total,
+    hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const T*)o, (const T*)dout, dq_sum, T_, H, total,
                        (const T*)u, bias_scale, dbs_part);
     AMDS_LAUNCH_CHECK("attn_bwd_prep_kernel");
     const dim3 grid((T_ + 127) / 128, H, B), block(256);

@@ -31,6 +31,83 @@ __global__ void gelu_dropout_bwd_kernel(const TZ* __restrict__ z, const TG* __re
         dz[i] = (TO)(drop_keep_flat(seed, stream, i, thr) ? (float)du[i] * d * scale : 0.f);
     }
 }
+// 8 elements per lane: 16-byte loads / stores on the 16-bit tensors, ONE hash per element pair (the scalar kernels above compute every pair's hash twice and
+// move 2 bytes per lane and instruction: 1.9-2.0 TB/s on tensors that HBM could stream at 5).  Same arithmetic per element -> same bits.
+template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_type(8))); };
+__device__ __forceinline__ void drop_keep8(uint64_t seed, uint32_t stream, long i0, uint32_t thr, bool (&keep)[8]) {
+    const uint32_t key = drop_rowkey(seed, stream, (uint64_t)(i0 >> 16));
+    const uint32_t p0 = (uint32_t)(i0 & 0xFFFF) >> 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t bits = drop_pair_bits(key, p0 + q);
+        keep[2 * q] = drop_keep(bits, 0, thr);
+        keep[2 * q + 1] = drop_keep(bits, 1, thr);
+    }
+}
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) gelu_dropout_fwd8_kernel(const TI* __restrict__ z, TO* __restrict__ u, long n8, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
+    typedef typename Vec8<TI>::type vi;
+    typedef typename Vec8<TO>::type vo;
+    long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; v < n8; v += stride) {
+        const vi a = reinterpret_cast<const vi*>(z)[v];
+        bool keep[8];
+        drop_keep8(seed, stream, v * 8, thr, keep);
+        vo o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = gelu_erf((float)a[e]);
+            o[e] = (TO)(keep[e] ? g * scale : 0.f);
+        }
+        reinterpret_cast<vo*>(u)[v] = o;
+    }
+}
+template <typename TZ, typename TG, typename TO>
+__global__ void __launch_bounds__(256) gelu_dropout_bwd8_kernel(const TZ* __restrict__ z, const TG* __restrict__ du, TO* __restrict__ dz, long n8, uint64_t seed,
+                                                                uint32_t stream, uint32_t thr, float scale) {
+    typedef typename Vec8<TZ>::type vz;
+    typedef typename Vec8<TG>::type vg;
+    typedef typename Vec8<TO>::type vo;
+    long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; v < n8; v += stride) {
+        const vz a = reinterpret_cast<const vz*>(z)[v];
+        const vg g = reinterpret_cast<const vg*>(du)[v];
+        bool keep[8];
+        drop_keep8(seed, stream, v * 8, thr, keep);
+        vo o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)a[e];
+            const float d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+            o[e] = (TO)(keep[e] ? (float)g[e] * d * scale : 0.f);
+        }
+        reinterpret_cast<vo*>(dz)[v] = o;
+    }
+}
+template <typename TO>
+__global__ void __launch_bounds__(256) dropout_cast_bwd8_kernel(const float* __restrict__ dx, long ldx, TO* __restrict__ dy, long ldy, long rows, int cols, uint64_t seed,
+                                                                uint32_t stream, uint32_t thr, float scale) {
+    typedef typename Vec8<TO>::type vo;
+    const long n8 = rows * cols / 8;
+    const int c8 = cols / 8;
+    long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; v < n8; v += stride) {
+        const long r = v / c8;
+        const int c = (int)(v - r * c8) * 8;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(dx + r * ldx + c), a1 = *reinterpret_cast<const f32x4*>(dx + r * ldx + c + 4);
+        bool keep[8];
+        drop_keep8(seed, stream, v * 8, thr, keep);
+        vo o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (TO)(keep[e] ? (e < 4 ? a0[e] : a1[e - 4]) * scale : 0.f);
+        *reinterpret_cast<vo*>(dy + r * ldy + c) = o;
+    }
+}
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 // rows x cols view with row pitches (the residual stream may be padded): element index = r * cols + c
 __global__ void dropout_add_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ xin, long ldx, float* __restrict__ xout, long ldo,
                                    long rows, int cols, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
@@ -85,7 +162,10 @@ extern "C" int amds_gelu_dropout_fwd(const void* z, void* u, long n, int in_dtyp
     hipStream_t st = (hipStream_t)stream;
     const uint32_t thr = drop_thr16(p);
     const float sc = drop_scale(thr);
-    if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n, seed, stream_id, thr, sc);
+    const bool v8 = n % 8 == 0 && al16(z) && al16(u);
+    if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16 && v8) hipLaunchKernelGGL((gelu_dropout_fwd8_kernel<bf16, bf16>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n / 8, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32 && v8) hipLaunchKernelGGL((gelu_dropout_fwd8_kernel<bf16, float>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const bf16*)z, (float*)u, n / 8, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n, seed, stream_id, thr, sc);
     else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (float*)u, n, seed, stream_id, thr, sc);
     else if (in_dtype == AMDS_F32 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<float, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const float*)z, (float*)u, n, seed, stream_id, thr, sc);
     else { set_error("amds_gelu_dropout_fwd: unsupported dtype pair"); return AMDS_ERR_INVALID; }
@@ -100,7 +180,12 @@ extern "C" int amds_gelu_dropout_bwd(const void* z, const void* du, void* dz, lo
     hipStream_t st = (hipStream_t)stream;
     const uint32_t thr = drop_thr16(p);
     const float sc = drop_scale(thr);
-    if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16)
+    const bool v8 = n % 8 == 0 && al16(z) && al16(du) && al16(dz);
+    if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16 && v8)
+        hipLaunchKernelGGL((gelu_dropout_bwd8_kernel<bf16, bf16, bf16>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n / 8, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_BF16 && v8)
+        hipLaunchKernelGGL((gelu_dropout_bwd8_kernel<bf16, float, bf16>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const bf16*)z, (const float*)du, (bf16*)dz, n / 8, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16)
         hipLaunchKernelGGL((gelu_dropout_bwd_kernel<bf16, bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n, seed, stream_id, thr, sc);
     else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_BF16)
         hipLaunchKernelGGL((gelu_dropout_bwd_kernel<bf16, float, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (const float*)du, (bf16*)dz, n, seed, stream_id, thr, sc);
@@ -128,7 +213,9 @@ extern "C" int amds_dropout_cast_bwd(const float* dx, long ldx, void* dy, long l
     if (rows == 0) return AMDS_OK;
     const uint32_t thr = drop_thr16(p);
     hipStream_t st = (hipStream_t)stream;
-    if (out_dtype == AMDS_BF16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<bf16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (bf16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
+    if (out_dtype == AMDS_BF16 && cols % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0 && al16(dx) && al16(dy))
+        hipLaunchKernelGGL((dropout_cast_bwd8_kernel<bf16>), dim3(grid1d_(rows * cols / 8)), dim3(256), 0, st, dx, ldx, (bf16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
+    else if (out_dtype == AMDS_BF16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<bf16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (bf16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else if (out_dtype == AMDS_F16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<f16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (f16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else if (out_dtype == AMDS_F32) hipLaunchKernelGGL((dropout_cast_bwd_kernel<float>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (float*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else { set_error("amds_dropout_cast_bwd: bad dtype"); return AMDS_ERR_INVALID; }
