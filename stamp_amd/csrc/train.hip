@@ -418,6 +418,8 @@ extern "C" int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const fl
 extern "C" int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, void* stream) {
     AMDS_REQUIRE(z && u && n >= 0, "amds_gelu_fwd: bad arguments");
     if (n == 0) return AMDS_OK;
+    // 16-bit input, n a multiple of 8: the 8-elements-per-lane kernel of dropout.hip at rate 0 (every element kept, scale exactly 1: same bits)
+    if (in_dtype == AMDS_BF16 && n % 8 == 0 && (((uintptr_t)z | (uintptr_t)u) & 15) == 0) return amds_gelu_dropout_fwd(z, u, n, in_dtype, out_dtype, 0.f, 0, 0, stream);
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n);
     else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_fwd_kernel<bf16, float>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (float*)u, n);
@@ -430,6 +432,8 @@ extern "C" int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int o
 extern "C" int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, void* stream) {
     AMDS_REQUIRE(z && du && dz && n >= 0, "amds_gelu_bwd: bad arguments");
     if (n == 0) return AMDS_OK;
+    if (z_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16 && n % 8 == 0 && (((uintptr_t)z | (uintptr_t)du | (uintptr_t)dz) & 15) == 0)
+        return amds_gelu_dropout_bwd(z, du, dz, n, z_dtype, du_dtype, dz_dtype, 0.f, 0, 0, stream);
     hipStream_t st = (hipStream_t)stream;
     if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16)
         hipLaunchKernelGGL((gelu_bwd_kernel<bf16, bf16, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n);
