@@ -24,7 +24,8 @@ constexpr int A7_K_BYTES = A7_KP * 128, A7_V_BYTES = 64 * A7_VS + 8 * 16, A7_T_B
 constexpr int A7_BUF = A7_K_BYTES + A7_V_BYTES + A7_T_BYTES;          // 70 656 B per item image
 constexpr int A7_PART = 68;                                           // one partial of the odd query's row: o[64] | max | sum | pad
 constexpr int A7_SCRATCH = 16 + 8 * 64 + 2 * 9 * A7_PART * 4;         // 16 zero bytes | P of the odd query, 32 keys per wave | partials x 2
-constexpr int A7_LDS = 2 * A7_BUF + A7_SCRATCH;                       // 146 736 B
+constexpr int A7_OUT = 8 * 2048;                                      // per wave: 16 output rows x 128 B, staged so that a row leaves as one 128-byte line
+constexpr int A7_LDS = 2 * A7_BUF + A7_SCRATCH + A7_OUT;              // 163 120 B
 
 // phase timeline for tools/ubench/attn257_trace.hip (compiled with -DA7_TRACE only): s_memtime of every wave of workgroup 0 at the phase
 // boundaries of its first items
@@ -75,6 +76,9 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
     const int vk0 = (vu >> 3) * 2;                                                                    // first key of the pair inside the part
     const int lv_off = A7_K_BYTES + ((vu & 7) * 8 + vhalf * 4) * VS + (vu & 7) * 16 + ((vk0 & ~12) | ((vk0 & 4) << 1) | ((vk0 & 8) >> 1)) * 2;
     auto part_load = [&](Part& pt, __amdgpu_buffer_rsrc_t rs, int c) {          // waits for nothing
+#if defined(A7_ABL) && (A7_ABL & 2)      // ablation: the next item's K / V rows are not fetched (registers keep their content)
+        if (c >= 0) return;
+#endif
         pt.k = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_k, c * 64 * ldb, 0);
         pt.v0 = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_v, c * 64 * ldb, 0);
         pt.v1 = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_v, c * 64 * ldb + ldb, 0);
@@ -187,6 +191,9 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
                 vec8 opnd[4];
                 auto ld = [&](int i) {                                   // operand of MFMA i: 0-7 = QK^T (K rows), 8-15 = P V (V^T rows)
                     if (i < 0 || i >= 16) return;
+#if defined(A7_ABL) && (A7_ABL & 4)      // ablation: no operand reads in the pipelined stages (stale registers)
+                    if (i >= 0) { asm volatile("" : "+v"(opnd[i & 3])); return; }
+#endif
                     if (i < 8) {
                         if (!HQ) return;
                         const int t = i & 1, ks = i >> 1;
@@ -199,6 +206,9 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
                     }
                 };
                 auto mf = [&](int i) {
+#if defined(A7_ABL) && (A7_ABL & 8)      // ablation: no MFMAs in the pipelined stages
+                    if (i >= 0) { asm volatile("" : "+v"(sn[i & 1]), "+v"(o[i & 1]) : "v"(opnd[i & 3])); return; }
+#endif
                     if (i < 8) {
                         if (!HQ) return;
                         const int t = i & 1, ks = i >> 1;
@@ -236,7 +246,11 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
                     if (sl >= 3 && sl < 14) {                             // three weights per slice, rounded to the operand type at once
 #pragma unroll
                         for (int f = 3 * (sl - 3); f < 3 * (sl - 3) + 3 && f < 32; ++f) {
+#if defined(A7_ABL) && (A7_ABL & 1)      // ablation (tools/ubench/attn257_abl.hip): no v_exp_f32 in the chunk softmax
+                            const float pw = fmaf(sc_[f >> 4][f & 15], sc, -mnew);
+#else
                             const float pw = __builtin_amdgcn_exp2f(fmaf(sc_[f >> 4][f & 15], sc, -mnew));
+#endif
                             ls += pw;
                             pout[f >> 4][(f >> 3) & 1][f & 7] = Act<T>::from_f32(pw);
                         }
@@ -312,16 +326,37 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
             }
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.0f / l;
-            T* orow = out + ((long)b * Tn + wave * 32 + l31) * Dm + h * 64;
+            // Output rows through 2 KB of LDS per wave, 16 queries at a time: the accumulators hold a query's 64 dims as 8-byte groups spread over the lane pair
+            // (l31, hi), and stored from there every store instruction of a wave hit 32 rows with 16 contiguous bytes each (8 such instructions per item; ablation
+            // tools/ubench/attn257_abl.hip bit 16: the stores cost 104 of the kernel's 595 us).  Staged [query][dim] (16-byte chunk index XOR query & 7) and read
+            // back row-wise, 8 consecutive lanes store one row's 128 bytes: 4 instructions of full lines per item; stores + staging now cost 80 us (595 -> 570).
+            char* so = smem + 2 * A7_BUF + A7_SCRATCH + wave * 2048;
+            T* obase = out + ((long)b * Tn + wave * 32) * Dm + h * 64;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int r = 0; r < 2; ++r) {
+                if ((l31 >> 4) == r) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    vec4 w;
+                    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
-                    *reinterpret_cast<vec4*>(orow + dt * 32 + 8 * g + 4 * hi) = w;
+                        for (int g = 0; g < 4; ++g) {
+                            vec4 w;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
+                            *reinterpret_cast<vec4*>(so + (l31 & 15) * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = w;
+                        }
                 }
+                asm volatile("" ::: "memory");                            // same wave, LDS in order: the reads below see the writes above
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int row = k * 8 + (lane >> 3), c = lane & 7;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(so + row * 128 + ((c ^ (row & 7)) << 4));
+#if defined(A7_ABL) && (A7_ABL & 16)     // ablation: the 256 main rows are not stored
+                    if (n_items < 0)
+#endif
+                    *reinterpret_cast<u32x4*>(obase + (long)(r * 16 + row) * Dm + c * 8) = v;
+                }
+                asm volatile("" ::: "memory");
+            }
         }
 
         A7_MARK(3);
