@@ -485,3 +485,38 @@ def test_wgrad_tn_token_major_operands(gpu, dt, tokens, N, K, split_k, pitch):
     old = T.colsum(part.view(split_k, N * K)).view(N, K)
     assert torch.equal(got, old)
     assert torch.equal(got, T.wgrad_tn(dy, x, split_k))
+
+
+@pytest.mark.parametrize("rows,D,Dp,p", [(1000, 512, 512, 0.5), (333, 256, 256, 0.0), (70, 192, 256, 0.25)])
+def test_layernorm_kernels_that_carry_a_second_output(gpu, rows, D, Dp, p):
+    """amds_layernorm_train_copy = amds_layernorm_train + a device-to-device copy of the (pitched) rows; amds_layernorm_bwd_cast = amds_layernorm_bwd +
+    amds_dropout_cast_bwd (p > 0) / amds_cast_pad (p = 0) of the dx it produced -- bit for bit, including the skip add and pad columns of the copy."""
+    import ctypes as C
+    lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.zeros(rows, Dp, device=gpu)
+    x[:, :D] = torch.randn(rows, D, generator=g).to(gpu) * 2 + 0.3
+    x[:, D:] = 7.0                                                       # pad columns travel with the copy
+    gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).to(gpu), (0.1 * torch.randn(D, generator=g)).to(gpu)
+    y0, m0, r0 = T.layernorm_train(x, gamma, beta, 1e-5, torch.bfloat16, rows=rows, row_stride=Dp, out=torch.zeros(rows, Dp, dtype=torch.bfloat16, device=gpu), ld_out=Dp)
+    y1 = torch.zeros(rows, Dp, dtype=torch.bfloat16, device=gpu)
+    m1, r1, xc = torch.empty(rows, device=gpu), torch.empty(rows, device=gpu), torch.full((rows, Dp), -1.0, device=gpu)
+    _lib.check(lib.amds_layernorm_train_copy(x.data_ptr(), Dp, gamma.data_ptr(), beta.data_ptr(), y1.data_ptr(), Dp, m1.data_ptr(), r1.data_ptr(), rows, D, 1e-5,
+                                             _lib.BF16, xc.data_ptr(), Dp, Dp, st), "ln_train_copy")
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1) and torch.equal(xc, x)
+    # backward: dx (with skip) + its bf16 (dropout-masked) copy
+    dy = torch.randn(rows, D, generator=g).to(gpu)
+    skip = torch.randn(rows, D, generator=g).to(gpu)
+    dg0, db0, dg1, db1 = (torch.empty(D, device=gpu) for _ in range(4))
+    dx0 = T.layernorm_bwd(dy, x, m0, r0, gamma, skip.clone(), True, dg0, db0, rows=rows, x_stride=Dp)
+    ref16 = torch.empty(rows, D, dtype=torch.bfloat16, device=gpu)
+    if p > 0:
+        _lib.check(lib.amds_dropout_cast_bwd(dx0.data_ptr(), D, ref16.data_ptr(), D, rows, D, _lib.BF16, p, 77, 13, st), "dropout_cast_bwd")
+    else:
+        ref16 = ops.cast_pad(dx0, D, torch.bfloat16)
+    dx1, got16 = skip.clone(), torch.empty(rows, D, dtype=torch.bfloat16, device=gpu)
+    nb = lib.amds_layernorm_bwd_workspace_bytes(rows, D)
+    ws = torch.empty(nb, dtype=torch.uint8, device=gpu)
+    _lib.check(lib.amds_layernorm_bwd_cast(dy.data_ptr(), D, x.data_ptr(), Dp, m0.data_ptr(), r0.data_ptr(), gamma.data_ptr(), dx1.data_ptr(), D, 1, dg1.data_ptr(),
+                                           db1.data_ptr(), 0, rows, D, ws.data_ptr(), nb, got16.data_ptr(), D, p, 77, 13, st), "ln_bwd_cast")
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(ref16.view(torch.int16), got16.view(torch.int16))
