@@ -123,7 +123,7 @@ class _OpenFiles:
         h = self.entries[path]
         if h is None:
             return h5io.read_file(path)
-        return {k: h[k][()] for k in h.keys()}, dict(h.attrs)
+        return h5io.read_open_h5py(h)
 
     @staticmethod
     def _open(path):

@@ -304,7 +304,8 @@ extern "C" int amds_wgrad_tn(const void* dy, long ld_dy, const void* x, long ld_
     AMDS_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)part & 15) == 0, "amds_wgrad_tn: pointers must be 16-byte aligned");
     const long unit = 64L * split_k;
     const long chunk = (tokens + unit - 1) / unit * 64;                 // tokens per split, a multiple of the K tile
-    AMDS_REQUIRE(tokens * std::max(ld_dy, ld_x) * 2 < (1L << 31), "amds_wgrad_tn: operand beyond the 2 GB a buffer descriptor addresses");
+    // every split has its own descriptor base (bsA / bsW below): only one split's span has to fit the 2 GB a buffer descriptor addresses
+    AMDS_REQUIRE((chunk + 63) * std::max(ld_dy, ld_x) * 2 < (1L << 31), "amds_wgrad_tn: one split's operand span is beyond the 2 GB a buffer descriptor addresses (raise split_k)");
     EpiArgs ep;
     ep.out = part; ep.ldo = K; ep.bias = nullptr; ep.scale = nullptr; ep.pos = nullptr; ep.np = ep.T = ep.P = 0; ep.acc_scale = 1.0f;
     ep.bsA = chunk * ld_dy; ep.bsW = chunk * ld_x; ep.bsOut = (long)N * K; ep.nbatch = split_k; ep.ktot = tokens;

@@ -27,18 +27,18 @@ _logger = logging.getLogger("stamp_amd")
 STAMP_FORMAT_VERSION = "2.5.0"
 AMDSTAMP_VERSION = "0.3"
 VERSION = STAMP_FORMAT_VERSION
-_HASH_RE = re.compile(r"^[0-9a-fA-F]{6,}$")
+# A trailing "-<at least six hex digits>" is the code hash STAMP appends to an extractor's name; everything in front of it is the name.
+_HASHED_NAME = re.compile(r"(?P<base>.*)-[0-9a-fA-F]{6,}")
 
 
 def resolve_extractor_name(name: str) -> str:
-    """The reference's `_resolve_extractor_name` (encoder/__init__.py:235-250): strip a trailing `-<hex hash>` and nothing else."""
+    """Behaviour of the reference's `_resolve_extractor_name` (encoder/__init__.py:235-250), pinned by tests/test_cpu_host.py against that
+    function's own answers: surrounding blanks go, one trailing `-<hex hash>` goes, nothing else changes; the empty string is an error."""
     if not name:
         raise ValueError("Empty extractor name")
-    name = str(name).strip()
-    if "-" not in name:
-        return name
-    base, suffix = name.rsplit("-", 1)
-    return base if _HASH_RE.match(suffix) else name
+    stripped = str(name).strip()
+    hashed = _HASHED_NAME.fullmatch(stripped)
+    return hashed["base"] if hashed else stripped
 
 
 def code_hash(directory: Path | None = None) -> str:
@@ -93,24 +93,28 @@ class HipGatedAttentionEncoder:
 
     # ---- the reference base class's file loops (encoder/__init__.py:42-229), on stamp_amd.h5io ---------------------------------------
     def _read_h5(self, h5_path: str):
-        """-> (feats [N, F] in self.precision, CoordsInfo, extractor name with a hash suffix stripped)  (:182-201)."""
-        if not os.path.exists(h5_path):
+        """-> (feats [N, F] in self.precision, CoordsInfo, extractor name without its hash suffix); what the reference's reader refuses
+        (:182-201) is refused here with the same exception types: a path that is absent, a suffix other than .h5, a file without an
+        `extractor` attribute."""
+        path = Path(h5_path)
+        if not path.exists():
             raise FileNotFoundError(f"File does not exist: {h5_path}")
-        if not str(h5_path).endswith(".h5"):
-            raise ValueError(f"File is not of type .h5: {os.path.basename(h5_path)}")
-        d, attrs = h5io.read_file(h5_path)
-        feats = torch.from_numpy(np.ascontiguousarray(d["feats"])).to(dtype=self.precision)
-        coords = h5io.get_coords(d, attrs)
-        extractor = attrs.get("extractor", "")
-        if extractor == "":
-            raise ValueError(f"Feature file does not have extractor's name in the metadata: {os.path.basename(h5_path)}")
-        return feats, coords, resolve_extractor_name(extractor)
+        if path.suffix != ".h5":
+            raise ValueError(f"File is not of type .h5: {path.name}")
+        datasets, attrs = h5io.read_file(h5_path)
+        named = attrs.get("extractor", "")
+        if named == "":
+            raise ValueError(f"Feature file does not have extractor's name in the metadata: {path.name}")
+        feats = torch.from_numpy(np.ascontiguousarray(datasets["feats"])).to(dtype=self.precision)
+        return feats, h5io.get_coords(datasets, attrs), resolve_extractor_name(named)
+
+    def _require_extractor(self, got: str, accepted, h5_path, what: str = "Features") -> None:
+        if got not in accepted:
+            raise ValueError(f"{what} must be extracted with one of {list(accepted)}. Features located in {h5_path} are extracted with {got}")
 
     def _validate_and_read_features(self, h5_path: str):
         feats, coords, extractor = self._read_h5(h5_path)
-        if extractor not in self.required_extractors:
-            raise ValueError(f"Features must be extracted with one of {self.required_extractors}. "
-                             f"Features located in {h5_path} are extracted with {extractor}")
+        self._require_extractor(extractor, self.required_extractors, h5_path)
         return feats, coords
 
     def _save_features_(self, output_path: Path, feats: np.ndarray, feat_type: str) -> None:
@@ -154,22 +158,36 @@ class HipGatedAttentionEncoder:
 
 
 def align_by_coords(ref_coords_um: np.ndarray, other_coords_um: np.ndarray, decimals: int = 5) -> np.ndarray:
-    """The reference's `_align_vir2_to_ctp_by_coords` (eagle.py:265-300) as a permutation: other[perm[i]] lies at ref[i]'s coordinate (rounded
-    to `decimals`); duplicates are matched in file order; a coordinate missing from `other`, or left over in it, raises ValueError."""
-    from collections import defaultdict, deque
-    ref = np.round(np.asarray(ref_coords_um, dtype=np.float64), decimals)
-    oth = np.round(np.asarray(other_coords_um, dtype=np.float64), decimals)
-    buckets: dict = defaultdict(deque)
-    for j, key in enumerate(map(tuple, oth)):
-        buckets[key].append(j)
-    perm = np.empty(ref.shape[0], dtype=np.int64)
-    for i, key in enumerate(map(tuple, ref)):
-        if not buckets[key]:
-            raise ValueError(f"Missing coord in other set: {key}")
-        perm[i] = buckets[key].popleft()
-    unused = sum(len(q) for q in buckets.values())
-    if unused != 0:
-        raise ValueError(f"virchow2 features contain {unused} extra coords not in ref.")
+    """Permutation `perm` with other[perm[i]] at ref[i]'s coordinate after rounding to `decimals` -- the contract of the reference's
+    `_align_vir2_to_ctp_by_coords` (eagle.py:265-300; pinned by tests/golden/eagle.npz): equal coordinates pair up in file order, a coordinate
+    of `ref` that `other` lacks (or has fewer times) raises ValueError, and so does any row of `other` left unmatched.
+
+    Vectorised: both sets are labelled by their row in the sorted union of distinct coordinates, then each side is ranked by a STABLE sort
+    on (label, file position); the k-th occurrence of a label in `ref` receives the k-th occurrence of it in `other`."""
+    ref = np.round(np.asarray(ref_coords_um, dtype=np.float64), decimals).reshape(len(ref_coords_um), -1)
+    oth = np.round(np.asarray(other_coords_um, dtype=np.float64), decimals).reshape(len(other_coords_um), -1)
+    n_ref, n_oth = ref.shape[0], oth.shape[0]
+    both = np.concatenate([ref, oth], axis=0) + 0.0                                  # + 0.0: -0.0 and 0.0 are one coordinate
+    _, label = np.unique(both, axis=0, return_inverse=True)
+    label = np.asarray(label).reshape(-1)
+    n_labels = int(label.max()) + 1 if label.size else 0
+    have = np.bincount(label[n_ref:], minlength=n_labels)
+    want = np.bincount(label[:n_ref], minlength=n_labels)
+    short = np.flatnonzero(want > have)
+    if short.size:
+        # report the first row of `ref` (file order) that cannot be served
+        seen = np.zeros(n_labels, dtype=np.int64)
+        for i in range(n_ref):
+            seen[label[i]] += 1
+            if seen[label[i]] > have[label[i]]:
+                raise ValueError(f"Missing coord in other set: {tuple(ref[i].tolist())}")
+    extra = int((have - want).sum())
+    if extra:
+        raise ValueError(f"virchow2 features contain {extra} extra coords not in ref.")
+    ref_order = np.argsort(label[:n_ref], kind="stable")
+    oth_order = np.argsort(label[n_ref:], kind="stable")
+    perm = np.empty(n_ref, dtype=np.int64)
+    perm[ref_order] = oth_order
     return perm
 
 

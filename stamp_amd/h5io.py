@@ -369,12 +369,18 @@ def read_file(path) -> tuple[dict[str, np.ndarray], dict]:
     be = backend()
     if be == "h5py":
         with _h5py.File(path, "r") as f:
-            d = {k: f[k][()] for k in ("feats", "coords", "patch_embeddings") if k in f}
-            a = {k: (v.decode() if isinstance(v, bytes) else (v.item() if hasattr(v, "item") else v)) for k, v in f.attrs.items()}
-        return d, a
+            return read_open_h5py(f)
     if be == "min":
         return h5min.read(path, want=("feats", "coords", "patch_embeddings"))
     return _c_read(str(path))
+
+
+def read_open_h5py(f) -> tuple[dict[str, np.ndarray], dict]:
+    """`read_file` on an h5py handle that is already open (stamp_amd.bags keeps handles open between reads, as the reference does): only the
+    three datasets STAMP reads, attributes normalised (bytes decoded, numpy scalars as Python scalars)."""
+    d = {k: f[k][()] for k in ("feats", "coords", "patch_embeddings") if k in f}
+    a = {k: (v.decode() if isinstance(v, bytes) else (v.item() if hasattr(v, "item") and getattr(v, "size", 1) == 1 else v)) for k, v in f.attrs.items()}
+    return d, a
 
 
 def feature_type(attrs: dict) -> str:

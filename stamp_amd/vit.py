@@ -237,7 +237,7 @@ class HipViT(nn.Module):
         self.check = check
         self.defer_check = False        # set by a caller that checks the features itself, once, later (preprocess.extract_slide)
         self.safe_level = 0             # 0 = as constructed; 1 / 2: see `check`
-        self._safe: "HipViT | None" = None
+        object.__setattr__(self, "_safe", None)     # "HipViT | None"; kept out of nn.Module's child registry: modules() / state_dict() see ONE ViT
         self._sd_ref = state_dict       # kept (by reference) for the safe re-pack
         self._ctor = dict(device=device, chunk=chunk, patch_split=patch_split, exact=exact, cls_tail=cls_tail)
         self.overlap = False            # two chunks in flight on two streams (amds_vit_forward_overlapped)
@@ -414,9 +414,13 @@ class HipViT(nn.Module):
             level, kw, what = 2, dict(act_dtype=torch.bfloat16, ln_fold=False), "bf16 activations (fp32 range, 8-bit mantissa: outside the 1e-3 parity bar)"
         warnings.warn(f"HipViT: {why} on the {'default' if self.safe_level == 0 else 'level-%d' % self.safe_level} path; re-packing on safe level {level}: "
                       f"{what}.  Range counters of the folded LayerNorms: {self.range_diagnostics()}", RuntimeWarning, stacklevel=3)
-        self._safe = None
+        # this object never runs its own image again: its packed weights (incl. an fp8 copy), workspace and the previous level's go before the re-pack
+        object.__setattr__(self, "_safe", None)
+        self._image = None
+        self._ws = None
+        self._ws_chunk = None
         torch.cuda.empty_cache()
-        self._safe = HipViT(self.cfg, self._sd_ref, check="off", **kw, **self._ctor)
+        object.__setattr__(self, "_safe", HipViT(self.cfg, self._sd_ref, check="off", **kw, **self._ctor))
         self.safe_level = level
         return True
 

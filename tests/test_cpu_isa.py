@@ -34,13 +34,19 @@ def test_checker_flags_an_early_use_and_accepts_a_waited_one():
 
 
 @pytest.mark.skipif(not Path(C.HIPCC).exists() or shutil.which("make") is None, reason="needs hipcc")
-def test_compiled_token_major_kernel_respects_its_own_waits():
+@pytest.mark.parametrize("name", ["gemm_bf16", "gemm_f16"])
+def test_compiled_token_major_kernel_respects_its_own_waits(name):
+    """Both instantiations, compiled with the flags the Makefile itself uses (read out of `make -pn`), the way its `.tn_ok` build step does."""
     import subprocess
     import tempfile
-    f = ROOT / "stamp_amd" / "csrc" / "gemm_bf16.hip"
+    db = subprocess.run(["make", "-C", str(ROOT), "-pn", "__no_such_target__"], capture_output=True, text=True).stdout
+    flags = next(line.split(":=", 1)[1].split() for line in db.splitlines() if line.startswith("HIPFLAGS :="))
+    assert "--offload-arch=gfx950" in flags and "-O3" in flags
+    assert f"{name}" in next(line for line in db.splitlines() if line.startswith("TN_SRCS :=")), "the Makefile no longer checks this file at build time"
+    f = ROOT / "stamp_amd" / "csrc" / f"{name}.hip"
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "k.s"
-        subprocess.run([C.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", str(out), f"-I{ROOT / 'include'}", str(f)],
-                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([C.HIPCC, *flags, "--cuda-device-only", "-S", "-o", str(out), str(f)],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
         errs = C.check(out.read_text())
     assert errs == [], errs[:5]

@@ -2,7 +2,9 @@
 builtin costs an s_waitcnt vmcnt(0) per read pair, profiles/r04_wgrad_tn.txt), so the compiler does not know the destination registers are filled
 asynchronously: the kernel is only correct as long as NOTHING touches a destination register between the read and the next `s_waitcnt lgkmcnt(0)` -- no move,
 no MFMA.  This script compiles the kernel to assembly and checks exactly that on the instruction stream of every TN kernel (linear scan; the K loop is
-straight-line code).   python tools/check_tn_isa.py [file.hip ...]   -> exit status 0 / 1"""
+straight-line code).   python tools/check_tn_isa.py [file.hip ...]   -> exit status 0 / 1
+                       python tools/check_tn_isa.py --asm file.s [...]  -> the same check on assembly the BUILD produced (the Makefile runs this on the -S
+                       output of the build's own HIPFLAGS for gemm_bf16.hip and gemm_f16.hip and fails the build on a violation)"""
 import re
 import subprocess
 import sys
@@ -62,6 +64,15 @@ def check(asm: str) -> list[str]:
 
 
 def main() -> int:
+    if len(sys.argv) > 1 and sys.argv[1] == "--asm":
+        rc = 0
+        for f in sys.argv[2:]:
+            errs = check(Path(f).read_text())
+            print(f"{Path(f).name}: {'token-major fragment reads ok' if not errs else str(len(errs)) + ' violation(s)'}")
+            for e in errs[:10]:
+                print("   ", e)
+            rc |= bool(errs)
+        return rc
     files = [Path(f) for f in sys.argv[1:]] or [ROOT / "stamp_amd" / "csrc" / "gemm_bf16.hip", ROOT / "stamp_amd" / "csrc" / "gemm_f16.hip"]
     rc = 0
     for f in files:
