@@ -239,6 +239,23 @@ int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtyp
  * [H][head_dim]. */
 int amds_attention_vit_hd(const void* qkv, void* out, int B, int T, int H, int head_dim, int dtype, void* stream);
 
+/* The qkv Linear AND the attention of a ViT block in one kernel, for T = 257 tokens (class token + 16 x 16 patches) and head_dim 64: timm
+ * Attention.forward's `qkv = self.qkv(x)` + `F.scaled_dot_product_attention(q, k, v)` -- what the reference runs inside `model(tiles)`,
+ * src/stamp/preprocessing/__init__.py:324-325 -- without q | k | v ever reaching HBM (csrc/qkv_attn257.hip).
+ *   x        act dtype [B*257][dim]: the rows entering the qkv Linear -- LayerNorm output, or, with the LayerNorm folded in (amds_gemm_lnfold's
+ *            consumer form), the un-normalised 16-bit rows together with rowstat [B*257][2] = (rstd, -mean*rstd) and colsum [3*dim];
+ *   w_qkv    act dtype [3*dim][dim] (torch Linear layout; q | k | v thirds, each [heads][64]), bias fp32 [3*dim];
+ *   qkv_tail act dtype [B*257][3*dim]: only row 256 of every tile is READ -- the q | k | v row of the tile's last token, computed beforehand by
+ *            the ordinary GEMM (the kernel's matrix phase covers the tile's first 256 tokens); nothing is written to it;
+ *   out      act dtype [B*257][dim]: softmax(q k^T / 8) v, heads concatenated -- bit for bit what amds_gemm_lnfold / amds_gemm (BIAS) followed by
+ *            amds_attention_vit writes.
+ * rowstat and colsum are both given or both NULL. */
+int amds_qkv_attention_vit257(const void* x, const void* w_qkv, const float* bias, const float* colsum, const float* rowstat, const void* qkv_tail,
+                              void* out, int B, int heads, int dim, int dtype, void* stream);
+/* Gathers row `row` of every group of T rows: src16 [B*T][D] 16-bit -> dst16 [B][D]; stat [B*T][2] fp32 -> dst_stat [B][2] (stat may be NULL).
+ * The rows of a tile's last token for the GEMM in front of amds_qkv_attention_vit257. */
+int amds_gather_token_rows16(const void* src16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, void* stream);
+
 /* Same contract for ANY T (K/V streamed through LDS in 64-key tiles, online softmax; the T x T matrix is never
  * materialised).  Used by the MIL heads: bags of 1024 tiles in training, whole slides (tens of thousands of
  * tiles) at deploy time (reference src/stamp/modeling/models/vision_tranformer.py:191, 217-227, mask=None path

@@ -1,0 +1,576 @@
+// qkv_attn257.hip -- the qkv Linear and the attention of a ViT block as ONE kernel for T = 257 tokens, head_dim 64: q / k / v never leave the chip.
+//
+// Why (DESIGN section 9, item 00 a): per block and chunk of 1020 tiles the qkv GEMM wrote 1.6 GB of q | k | v to HBM and the attention kernel
+// read them back -- 3.2 of the block's ~14 GB, in a regime where bytes cost time wherever they are put (profiles/r04_gemm_overlap_probe.txt).
+//
+// One persistent 256-thread workgroup per CU (four waves, one per SIMD, 512 registers each) walks items (tile b, head h):
+//   G phase  [q | k | v](256 x 192) = X_b[256 x D] . W_h[192 x D]^T on the production GEMM's K loop (gemm_4w16.h: two LDS stages of 128-byte rows
+//            filled by buffer-form LDS-DMA, inline-asm v_mfma_f32_16x16x32 with the accumulators pinned to AGPRs, one barrier per K tile of 64);
+//            wave (wm, wn) owns rows 128 wm .. + 127 and, of each of q, k, v, the 16-column blocks 2 wn, 2 wn + 1 (8 x 6 accumulator blocks).
+//            For the q and k blocks W is the MFMA "A" operand (a lane ends up with one token and 4 consecutive dims: a row-major image);
+//            for the v blocks the operands are SWAPPED (a lane ends up with one dim and 4 consecutive tokens): V^T comes out of the matrix
+//            pipe already transposed.
+//   hand-off the folded-LayerNorm epilogue of the qkv GEMM (acc * rstd[m] + colsum[n] * (-mean rstd)[m] + bias[n], rounded to the operand
+//            type -- the very values the unfused path stored) writes the K image, the V^T image and a Q image over the (now idle) stages,
+//            in the layouts attention_vit257.hip reads;
+//   S phase  that kernel's arithmetic, unchanged: each wave takes two blocks of 32 queries (online softmax over four chunks of 64 keys,
+//            software-pipelined inside the wave), the odd key as a rank-1 update, the odd query on the MFMA pipe as 32-key partials.
+// Token 256 of a tile (the odd one: 257 = 16 x 16 + 1) is not part of the 256-row G phase: its q | k | v row is computed beforehand by the ordinary GEMM
+// on the 1020 gathered rows (vit.hip) and read from HBM here (384 bytes per item).
+// Output: attention rows [B * 257][D] in the operand type, as attention_vit257.hip writes them.
+#include "common.h"
+#include <type_traits>
+
+namespace amds {
+
+constexpr int QA_XB = 256 * 128;                       // X part of a stage: 256 token rows x 128 B (K tile of 64)
+constexpr int QA_STAGE = (256 + 192) * 128;            // + 192 weight rows: 57 344 B
+constexpr int QA_VS = 576;                             // V^T rows: 8 key tiles x 64 B + 64 B skew room (attention_vit257.hip)
+constexpr int QA_KIMG = 0, QA_VIMG = 32768, QA_VBYTES = 64 * QA_VS + 8 * 16, QA_QIMG = QA_VIMG + QA_VBYTES;      // images alias the stages
+static_assert(QA_QIMG + 32768 <= 2 * QA_STAGE, "the K | V^T | Q images must fit the two stages they alias");
+constexpr int QA_PARTF = 68;                           // one partial of the odd query's row: o[64] | max | sum | pad
+constexpr int QA_ZERO = 2 * QA_STAGE;                  // 16 zero bytes
+constexpr int QA_PW = QA_ZERO + 16;                    // [8 query blocks][32] 16-bit softmax weights of the odd query
+constexpr int QA_PART = QA_PW + 8 * 64;                // [9][QA_PARTF] f32
+constexpr int QA_TAIL = QA_PART + 9 * QA_PARTF * 4;    // odd token: key | value | query in fp32 (3 x 64), the query again in 16 bit (128 B)
+constexpr int QA_RS = QA_TAIL + 3 * 64 * 4 + 128;      // (rstd, -mean rstd) of the item's 256 rows
+constexpr int QA_OUT = QA_RS + 256 * 8;                // per wave: 16 output rows x 128 B
+constexpr int QA_LDS = QA_OUT + 4 * 2048;
+static_assert(QA_RS % 16 == 0 && QA_OUT % 16 == 0 && QA_TAIL % 16 == 0 && QA_LDS <= 160 * 1024, "LDS map");
+
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ colsum,
+                   const float* __restrict__ rowstat, const T* __restrict__ qkv_tail, T* __restrict__ out, int B, int H, int D, int n_slots) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int Tn = 257, VS = QA_VS, ROWB = 128, FI = 8, FJ = 6, NM = 24;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kb = lane >> 4, l31 = lane & 31, hi = lane >> 5;
+    const int nk = D / 64;
+    const float sc = 0.125f * 1.44269504088896340736f;                // 1/sqrt(64) * log2(e)
+
+    char* sZero = smem + QA_ZERO;
+    char* sPw = smem + QA_PW;
+    float* sPart = reinterpret_cast<float*>(smem + QA_PART);
+    float* sT = reinterpret_cast<float*>(smem + QA_TAIL);
+    if (tid < 4) reinterpret_cast<float*>(sZero)[tid] = 0.f;
+
+    // ---- LDS-DMA addressing (gemm_4w16.h): 14 pieces of 16 bytes per thread and K tile, 8 of X and 6 of W; 16-byte chunk ^= (row >> 1) & 7 on the SOURCE
+    int voffx[8], voffw[6];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = it * 256 + tid, row = c >> 3, cp = c & 7, scn = cp ^ ((row >> 1) & 7);
+        voffx[it] = (row * D + scn * 8) * 2;
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {        // stage row r = 64 part + d (part 0 / 1 / 2 = q / k / v, d = dim): weight row part * D + h * 64 + d (h in the scalar offset)
+        const int c = it * 256 + tid, row = c >> 3, cp = c & 7, scn = cp ^ ((row >> 1) & 7);
+        voffw[it] = (((row >> 6) * D + (row & 63)) * D + scn * 8) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, 3 * D * D * 2, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_x = rsrc_w;
+    int wsoff = 0;
+    auto issue_pieces = [&](int kt, int lo, int hi_) {
+        char* st = smem + (kt & 1) * QA_STAGE;
+        const int koff = kt * 128;
+#pragma unroll
+        for (int it = 0; it < 14; ++it)
+            if (it >= lo && it < hi_) {
+                if (it < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)(st + (it * 256 + wave * 64) * 16), 16, voffx[it], koff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(st + QA_XB + ((it - 8) * 256 + wave * 64) * 16), 16, voffw[it - 8], koff + wsoff, 0, 0);
+            }
+    };
+    const int swz = (l15 >> 1) & 7;
+    const int a_off = (wm * 128 + l15) * ROWB;
+    int w_off[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) w_off[j] = QA_XB + ((j >> 1) * 64 + (2 * wn + (j & 1)) * 16 + l15) * ROWB;
+
+    vec8 af[2][FI], wf[2][FJ];
+    auto load_frags = [&](int kt, int ks, int s, int lo, int hi_) {
+        const char* sb = smem + (kt & 1) * QA_STAGE;
+        const int co = ((ks * 4 + kb) ^ swz) << 4;
+#pragma unroll
+        for (int q = 0; q < 14; ++q)
+            if (q >= lo && q < hi_) {
+                if (q < 8) af[s][q] = *reinterpret_cast<const vec8*>(sb + a_off + q * 16 * ROWB + co);
+                else wf[s][q - 8] = *reinterpret_cast<const vec8*>(sb + w_off[q - 8] + co);
+            }
+    };
+    f32x4 acc[FI][FJ];
+    // A unit = 24 MFMAs (set s, row blocks 4 ih .. 4 ih + 3, all 6 column blocks); behind them fragment reads and LDS-DMA pieces as in gemm_4w16.h
+    auto unit = [&](int s, int ih, auto nr_c, int rkt, int rks, int rs_, int rlo, auto nc_c, int ckt, int clo) {
+        constexpr int NR = decltype(nr_c)::value, NC = decltype(nc_c)::value;
+        constexpr int R_SPAN = NR >= 14 ? 14 : NM, C_LO = NR >= 14 ? 14 : 0, C_SPAN = NM - C_LO;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int i = ih * 4 + m / FJ, j = m % FJ;
+            if (j < 4) Act<T>::mfma16_agpr(wf[s][j], af[s][i], acc[i][j]);          // lane: token l15, dims 4 kb .. 4 kb + 3
+            else Act<T>::mfma16_agpr(af[s][i], wf[s][j], acc[i][j]);                // lane: dim l15, tokens 4 kb .. 4 kb + 3
+            if (NR > 0 && m < R_SPAN) {
+                const int r0 = m * NR / R_SPAN, r1 = (m + 1) * NR / R_SPAN;
+                if (r1 > r0) load_frags(rkt, rks, rs_, rlo + r0, rlo + r1);
+            }
+            if (NC > 0 && m >= C_LO && m < C_LO + C_SPAN) {
+                const int c0 = (m - C_LO) * NC / C_SPAN, c1 = (m - C_LO + 1) * NC / C_SPAN;
+                if (c1 > c0) issue_pieces(ckt, clo + c0, clo + c1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 4> I4;
+    typedef std::integral_constant<int, 5> I5;
+    typedef std::integral_constant<int, 7> I7;
+    typedef std::integral_constant<int, 14> I14;
+#define QA_BARRIER()                          \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+    // pieces of tile kt + 1: 0-3 in the last unit of tile kt - 1, 4-8 and 9-13 in the first two units of tile kt; waited for (vmcnt(0)) at 3/4 of tile kt
+    auto k_tile = [&](int kt, auto next_c, auto next2_c) {
+        constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
+        if constexpr (NEXT) unit(0, 0, I7{}, kt, 1, 1, 0, I5{}, kt + 1, 4); else unit(0, 0, I7{}, kt, 1, 1, 0, I0{}, 0, 0);
+        if constexpr (NEXT) unit(0, 1, I7{}, kt, 1, 1, 7, I5{}, kt + 1, 9); else unit(0, 1, I7{}, kt, 1, 1, 7, I0{}, 0, 0);
+        unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QA_BARRIER();
+        if constexpr (NEXT2) unit(1, 1, I14{}, kt + 1, 0, 0, 0, I4{}, kt + 2, 0);
+        else if constexpr (NEXT) unit(1, 1, I14{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
+        else unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
+    };
+
+    // ---- item order: an XCD's workgroups (blockIdx & 7 == xcd) take CONSECUTIVE slots, and 32 consecutive slots are 4 tiles x 8 heads: per round an
+    // XCD fetches 4 x 526 KB of X and 8 x 393 KB of W once and serves the other reads from its L2
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const bool oct = (H & 7) == 0;
+#pragma unroll 1
+    for (int round = 0;; ++round) {
+        const int u = (round * 8 + xcd) * per + wq;
+        if (u >= n_slots) break;
+        int b, h;
+        if (oct) {
+            const int per_quad = 4 * H, quad = u / per_quad, rem = u - quad * per_quad;
+            b = quad * 4 + ((rem & 31) >> 3);
+            h = (rem >> 5) * 8 + (rem & 7);
+        } else {
+            b = u / H;
+            h = u - b * H;
+        }
+        if (b >= B) continue;
+        const long row0 = (long)b * Tn;
+
+        // ================= G phase =================
+        rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X + row0 * D), 0, 256 * D * 2, 0x00020000);
+        wsoff = h * 64 * D * 2;
+        {   // small per-item operands first (they land under the first K tile's DMA): row statistics, the odd token's q | k | v
+            f32x2 rsv = f32x2{1.f, 0.f};
+            if (rowstat) rsv = *reinterpret_cast<const f32x2*>(rowstat + 2 * (row0 + tid));
+            const T* tp = qkv_tail + (row0 + 256) * 3 * D + h * 64 + lane;
+            const T tq = tp[0], tk = tp[D], tv = tp[2 * D];
+            __builtin_amdgcn_sched_barrier(0);
+            issue_pieces(0, 0, 14);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x2*>(smem + QA_RS + tid * 8) = rsv;
+            if (tid < 64) {
+                sT[tid] = Act<T>::to_f32(tk); sT[64 + tid] = Act<T>::to_f32(tv); sT[128 + tid] = Act<T>::to_f32(tq);
+                reinterpret_cast<T*>(sT + 192)[tid] = tq;
+            }
+        }
+        // (the initial values must BE in their AGPRs well before the first inline-asm MFMA reads them: gemm_4w16.h)
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            if (i == FI - 1) asm volatile("s_nop 7" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+            else asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QA_BARRIER();
+        load_frags(0, 0, 0, 0, 14);
+        issue_pieces(1, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        int kt = 0;
+        for (; kt < nk - 2; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
+        k_tile(kt++, std::true_type{}, std::false_type{});
+        // per-column (bias, colsum) of this wave's blocks: requested before the last K tile, which issues no LDS-DMA and waits for none
+        f32x4 cb[4], cs[4];
+        float cbv[2], csv[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = (j >> 1) * D + h * 64 + (2 * wn + (j & 1)) * 16 + 4 * kb;
+            cb[j] = *reinterpret_cast<const f32x4*>(bias + n);
+            cs[j] = colsum ? *reinterpret_cast<const f32x4*>(colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 2 * D + h * 64 + (2 * wn + j) * 16 + l15;
+            cbv[j] = bias[n];
+            csv[j] = colsum ? colsum[n] : 0.f;
+        }
+        k_tile(kt, std::false_type{}, std::false_type{});
+        QA_BARRIER();                  // every wave is done with the LDS stages
+        // MFMA result -> accumulator read hazard (gemm_4w16.h): keep every accumulator in its AGPR until the nops have run
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            if (i == 0) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+            else asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= hand-off: accumulators -> Q / K / V^T images =================
+        {
+            const char* sRS = smem + QA_RS;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int t = wm * 128 + i * 16 + l15;                              // q / k blocks: this lane's token
+                const f32x2 rs1 = *reinterpret_cast<const f32x2*>(sRS + t * 8);
+                const int rowb = t * 128, sw = (t >> 1) & 7;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[i][j][0]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(acc[i][j][1]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
+                    v = v * rs1[0] + (cs[j] * rs1[1] + cb[j]);
+                    const int c0 = (2 * wn + (j & 1)) * 16 + 4 * kb;                // first of the lane's 4 dims
+                    char* img = smem + (j < 2 ? QA_QIMG : QA_KIMG);
+                    *reinterpret_cast<vec4*>(img + rowb + (((c0 >> 3) ^ sw) << 4) + ((c0 >> 2) & 1) * 8) = Act<T>::from_f32x4(v);
+                }
+                const int t0 = wm * 128 + i * 16 + 4 * kb;                          // v blocks: this lane's 4 tokens
+                const f32x4 ra = *reinterpret_cast<const f32x4*>(sRS + t0 * 8), rb = *reinterpret_cast<const f32x4*>(sRS + t0 * 8 + 16);
+                const int pos = (t0 & ~12) | ((t0 & 4) << 1) | ((t0 & 8) >> 1);       // key order inside 16-groups: bits 2 <-> 3
+#pragma unroll
+                for (int j = 4; j < 6; ++j) {
+                    f32x4 v;
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[i][j][0]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(acc[i][j][1]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
+                    const float c_b = cbv[j - 4], c_s = csv[j - 4];
+                    v = f32x4{v[0] * ra[0] + (c_s * ra[1] + c_b), v[1] * ra[2] + (c_s * ra[3] + c_b), v[2] * rb[0] + (c_s * rb[1] + c_b),
+                              v[3] * rb[2] + (c_s * rb[3] + c_b)};
+                    const int d = (2 * wn + (j - 4)) * 16 + l15;
+                    *reinterpret_cast<vec4*>(smem + QA_VIMG + d * VS + (d >> 3) * 16 + pos * 2) = Act<T>::from_f32x4(v);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= S phase (attention_vit257.hip's arithmetic; each wave: query blocks 2 wave, 2 wave + 1) =================
+        const char* sK = smem + QA_KIMG;
+        const char* sVt = smem + QA_VIMG;
+        const char* sQ = smem + QA_QIMG;
+        const float* sKt = sT;
+        const float* sVl = sT + 64;
+        const float* sQt = sT + 128;
+        const int swz32 = (l31 >> 1) & 7;
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int vw = 2 * wave + rr;
+            vec8 qf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const vec8*>(sQ + (vw * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
+            {
+                f32x16 o[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+                float mrun = -INFINITY, l = 0.f;
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                auto stage = [&](auto has_pv_c, auto has_qk_c, int c, float alpha_prev, f32x16 (&sc_)[2], vec8 (&pout)[2][2], const vec8 (&pprev)[2][2],
+                                 f32x16 (&sn)[2]) {
+                    constexpr bool HP = decltype(has_pv_c)::value, HQ = decltype(has_qk_c)::value;
+                    vec8 opnd[4];
+                    auto ld = [&](int i) {                                   // operand of MFMA i: 0-7 = QK^T (K rows), 8-15 = P V (V^T rows)
+                        if (i < 0 || i >= 16) return;
+                        if (i < 8) {
+                            if (!HQ) return;
+                            const int t = i & 1, ks = i >> 1;
+                            opnd[i & 3] = *reinterpret_cast<const vec8*>(sK + (((c + 1) * 2 + t) * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
+                        } else {
+                            if (!HP) return;
+                            const int q = i - 8, t = q >> 2, ks = (q >> 1) & 1, dt = q & 1;
+                            const int pos = ((c - 1) * 2 + t) * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
+                            opnd[i & 3] = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                        }
+                    };
+                    auto mf = [&](int i) {
+                        if (i < 8) {
+                            if (!HQ) return;
+                            const int t = i & 1, ks = i >> 1;
+                            sn[t] = Act<T>::mfma32(opnd[i & 3], qf[ks], ks == 0 ? zero16 : sn[t]);
+                        } else {
+                            if (!HP) return;
+                            const int q = i - 8, t = q >> 2, ks = (q >> 1) & 1, dt = q & 1;
+                            o[dt] = Act<T>::mfma32(opnd[i & 3], pprev[t][ks], o[dt]);
+                        }
+                    };
+                    float mx = -INFINITY, mnew = 0.f, alpha = 0.f, ls = 0.f;
+                    ld(0);
+                    ld(1);
+#pragma unroll
+                    for (int sl = 0; sl < 16; ++sl) {
+                        ld(sl + 2);
+                        mf(sl);
+                        if (sl < 2) {
+#pragma unroll
+                            for (int f = 16 * sl; f < 16 * sl + 16; ++f) mx = fmaxf(mx, sc_[f >> 4][f & 15]);
+                        }
+                        if (sl == 2) {
+                            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                            mnew = fmaxf(mrun, mx * sc);
+                            alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                            mrun = mnew;
+                        }
+                        if ((sl == 2 || sl == 3) && HP) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[sl - 2][r] *= alpha_prev;
+                        }
+                        if (sl >= 3 && sl < 14) {
+#pragma unroll
+                            for (int f = 3 * (sl - 3); f < 3 * (sl - 3) + 3 && f < 32; ++f) {
+                                const float pw = __builtin_amdgcn_exp2f(fmaf(sc_[f >> 4][f & 15], sc, -mnew));
+                                ls += pw;
+                                pout[f >> 4][(f >> 3) & 1][f & 7] = Act<T>::from_f32(pw);
+                            }
+                        }
+                        if (sl == 14) l = l * alpha + ls;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    return alpha;
+                };
+                typedef std::true_type Y;
+                typedef std::false_type N_;
+                f32x16 sa[2], sb[2];
+                vec8 p0[2][2], p1[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    sa[t] = zero16;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const vec8 kf = *reinterpret_cast<const vec8*>(sK + (t * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
+                        sa[t] = Act<T>::mfma32(kf, qf[ks], sa[t]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float al0 = stage(N_{}, Y{}, 0, 0.f, sa, p0, p1, sb);
+                const float al1 = stage(Y{}, Y{}, 1, al0, sb, p1, p0, sa);
+                const float al2 = stage(Y{}, Y{}, 2, al1, sa, p0, p1, sb);
+                const float al3 = stage(Y{}, N_{}, 3, al2, sb, p1, p0, sa);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= al3;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                                 // P V of the last chunk
+                    const int t = i >> 2, ks = (i >> 1) & 1, dt = i & 1;
+                    const int pos = (6 + t) * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
+                    const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                    o[dt] = Act<T>::mfma32(vf, p1[t][ks], o[dt]);
+                }
+                {   // the odd key: rank-1 update of this block's 32 queries (dot product split over the lane pair)
+                    float dot = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const f32x4 k0 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8), k1 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dot = fmaf(Act<T>::to_f32(qf[ks][e]), k0[e], fmaf(Act<T>::to_f32(qf[ks][4 + e]), k1[e], dot));
+                    }
+                    dot += __shfl_xor(dot, 32, 64);
+                    const float st = dot * sc, mnew = fmaxf(mrun, st);
+                    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew), pt = __builtin_amdgcn_exp2f(st - mnew);
+                    mrun = mnew;
+                    l = l * alpha + (hi == 0 ? pt : 0.f);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 vv = *reinterpret_cast<const f32x4*>(sVl + dt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[dt][4 * g + e] = fmaf(o[dt][4 * g + e], alpha, pt * vv[e]);
+                        }
+                }
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.0f / l;
+                // output rows through 2 KB of LDS per wave, 16 queries at a time, so that a row leaves as one 128-byte line
+                char* so = smem + QA_OUT + wave * 2048;
+                T* obase = out + (row0 + vw * 32) * D + h * 64;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if ((l31 >> 4) == r) {
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                vec4 w;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
+                                *reinterpret_cast<vec4*>(so + (l31 & 15) * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = w;
+                            }
+                    }
+                    asm volatile("" ::: "memory");                            // same wave, LDS in order: the reads below see the writes above
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int row = k * 8 + (lane >> 3), c = lane & 7;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(so + row * 128 + ((c ^ (row & 7)) << 4));
+                        *reinterpret_cast<u32x4*>(obase + (long)(r * 16 + row) * D + c * 8) = v;
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+            // ---- the odd query against keys 32 vw .. 32 vw + 31 on the MFMA pipe: a partial (max, sum, o[64]) merged after the barrier ----
+            {
+                const char* sQh = reinterpret_cast<const char*>(sT + 192);
+                const char* qsrc = l31 == 0 ? sQh + hi * 16 : sZero;
+                const int qstep = l31 == 0 ? 32 : 0;
+                f32x16 s1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const vec8 qa = *reinterpret_cast<const vec8*>(qsrc + ks * qstep);
+                    const vec8 kf = *reinterpret_cast<const vec8*>(sK + (vw * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
+                    s1 = Act<T>::mfma32(qa, kf, s1);
+                }
+                const float sv = hi == 0 ? s1[0] * sc : -INFINITY;
+                const float mw = wave_max(sv);
+                const float pk = hi == 0 ? __builtin_amdgcn_exp2f(sv - mw) : 0.f;
+                const float lw = wave_sum(pk);
+                char* pw = sPw + vw * 64;
+                if (hi == 0) reinterpret_cast<T*>(pw)[(l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)] = Act<T>::from_f32(pk);      // the V^T image's key order
+                asm volatile("" ::: "memory");
+                const char* psrc = l31 == 0 ? pw + hi * 16 : sZero;
+                f32x16 oq[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oq[dt][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const vec8 pf = *reinterpret_cast<const vec8*>(psrc + ks * qstep);
+                    const int pos = vw * 32 + ks * 16 + hi * 8;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int d = dt * 32 + l31;
+                        const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                        oq[dt] = Act<T>::mfma32(vf, pf, oq[dt]);
+                    }
+                }
+                float* pp = sPart + vw * QA_PARTF;
+                if (l31 == 0) {                                           // column 0 of the product: 32 dims in lane 0, 32 in lane 32
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(pp + dt * 32 + 8 * g + 4 * hi) = f32x4{oq[dt][4 * g], oq[dt][4 * g + 1], oq[dt][4 * g + 2], oq[dt][4 * g + 3]};
+                    if (hi == 0) { pp[64] = mw; pp[65] = lw; }
+                }
+                if (vw == 1) {                                            // the odd key's term of that row as the ninth partial
+                    float* p8 = sPart + 8 * QA_PARTF;
+                    const float st = wave_sum(sQt[lane] * sKt[lane]) * sc;
+                    p8[lane] = sVl[lane];
+                    if (lane == 0) { p8[64] = st; p8[65] = 1.0f; }
+                }
+            }
+        }
+        __syncthreads();               // the images are free (the next item's first K tile overwrites them); the partials are complete
+        if (wave == 0) {               // the odd query's row out of its 9 partials
+            const float* pp = sPart;
+            float m = pp[64];
+#pragma unroll
+            for (int j = 1; j < 9; ++j) m = fmaxf(m, pp[j * QA_PARTF + 64]);
+            float lsum = 0.f, ov = 0.f;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float w = __builtin_amdgcn_exp2f(pp[j * QA_PARTF + 64] - m);
+                lsum = fmaf(w, pp[j * QA_PARTF + 65], lsum);
+                ov = fmaf(w, pp[j * QA_PARTF + lane], ov);
+            }
+            out[(row0 + 256) * D + h * 64 + lane] = Act<T>::from_f32(ov / lsum);
+        }
+    }
+#undef QA_BARRIER
+}
+
+// row `row` of every tile: 16-bit [B*T][D] -> [B][D], and its (rstd, -mean rstd) pair
+__global__ void gather_token_rows16_kernel(const uint16_t* __restrict__ src, const float* __restrict__ stat, uint16_t* __restrict__ dst, float* __restrict__ dstat,
+                                           int T, int D, int row) {
+    const long r = (long)blockIdx.x * T + row;
+    const u32x4* s = reinterpret_cast<const u32x4*>(src + r * D);
+    u32x4* d = reinterpret_cast<u32x4*>(dst + (long)blockIdx.x * D);
+    for (int i = threadIdx.x; i < D / 8; i += blockDim.x) d[i] = s[i];
+    if (stat && threadIdx.x < 2) dstat[2 * blockIdx.x + threadIdx.x] = stat[2 * r + threadIdx.x];
+}
+
+static int g_qa_cus = 0;
+
+template <typename T>
+static int launch_qkv_attn257(const void* X, const void* W, const float* bias, const float* colsum, const float* rowstat, const void* qkv_tail, void* out,
+                              int B, int H, int D, hipStream_t st) {
+    auto kern = qkv_attn257_kernel<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QA_LDS));
+        attr_set = true;
+    }
+    if (!g_qa_cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        AMDS_HIP(hipGetDevice(&dev));
+        AMDS_HIP(hipGetDeviceProperties(&p, dev));
+        g_qa_cus = p.multiProcessorCount;
+    }
+    const int n_slots = (H & 7) == 0 ? ((B + 3) / 4) * 4 * H : B * H;
+    int grid = g_qa_cus & ~7;                                   // a multiple of the 8 XCDs
+    if (grid < 8) grid = 8;
+    while (grid > 8 && (grid - 8) >= n_slots) grid -= 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), QA_LDS, st, (const T*)X, (const T*)W, bias, colsum, rowstat, (const T*)qkv_tail, (T*)out, B, H, D, n_slots);
+    AMDS_LAUNCH_CHECK("qkv_attn257_kernel");
+    return AMDS_OK;
+}
+
+}  // namespace amds
+
+using namespace amds;
+
+// see include/amdstamp.h
+extern "C" int amds_qkv_attention_vit257(const void* x, const void* w_qkv, const float* bias, const float* colsum, const float* rowstat, const void* qkv_tail,
+                                         void* out, int B, int heads, int dim, int dtype, void* stream) {
+    AMDS_REQUIRE(x && w_qkv && bias && qkv_tail && out, "amds_qkv_attention_vit257: null pointer");
+    AMDS_REQUIRE(B > 0 && heads > 0 && dim == heads * 64, "amds_qkv_attention_vit257: head_dim must be 64 (dim=%d, heads=%d)", dim, heads);
+    AMDS_REQUIRE(dim % 64 == 0 && dim >= 128, "amds_qkv_attention_vit257: dim=%d must be a multiple of 64, >= 128", dim);
+    AMDS_REQUIRE((long)3 * dim * dim * 2 < (1L << 31) && (long)256 * dim * 2 < (1L << 31), "amds_qkv_attention_vit257: dim=%d too large", dim);
+    AMDS_REQUIRE((colsum == nullptr) == (rowstat == nullptr), "amds_qkv_attention_vit257: rowstat and colsum go together (folded LayerNorm) or are both null");
+    AMDS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)bias & 15) == 0 &&
+                 (colsum == nullptr || ((uintptr_t)colsum & 15) == 0) && (rowstat == nullptr || ((uintptr_t)rowstat & 7) == 0),
+                 "amds_qkv_attention_vit257: pointers must be 16-byte aligned");
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_qkv_attention_vit257: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * B * 256 * 3.0 * dim * dim + 4.0 * B * heads * 257.0 * 257.0 * 64;
+    ProfScope prof(PROF_ATTN, flops, st);
+    return dtype == AMDS_F16 ? launch_qkv_attn257<f16>(x, w_qkv, bias, colsum, rowstat, qkv_tail, out, B, heads, dim, st)
+                             : launch_qkv_attn257<bf16>(x, w_qkv, bias, colsum, rowstat, qkv_tail, out, B, heads, dim, st);
+}
+
+extern "C" int amds_gather_token_rows16(const void* src16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, void* stream) {
+    AMDS_REQUIRE(src16 && dst16 && (stat == nullptr || dst_stat), "amds_gather_token_rows16: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0 && row >= 0 && row < T && D > 0 && D % 8 == 0, "amds_gather_token_rows16: bad shape B=%d T=%d D=%d row=%d", B, T, D, row);
+    AMDS_REQUIRE(((uintptr_t)src16 & 15) == 0 && ((uintptr_t)dst16 & 15) == 0, "amds_gather_token_rows16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_token_rows16_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)src16, stat, (uint16_t*)dst16, dst_stat, T, D, row);
+    AMDS_LAUNCH_CHECK("gather_token_rows16_kernel");
+    return AMDS_OK;
+}

@@ -137,6 +137,9 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     // (fp32: 24; the GEMM operands: 11).  AMDS_VIT_PLANES=0: fp32 rows + copy (A/B; read at every call).
     const bool planes_env = !(getenv("AMDS_VIT_PLANES") && atoi(getenv("AMDS_VIT_PLANES")) == 0);
     const bool planes = planes_env && fold && !ex && dt == AMDS_F16;
+    // qkv + attention fused (amds_qkv_attention_vit257): the default wherever its shape holds -- T = 257, head_dim 64 -- on the planes path; AMDS_VIT_QKVATTN=0: two launches (A/B)
+    const bool qa_env = !(getenv("AMDS_VIT_QKVATTN") && atoi(getenv("AMDS_VIT_QKVATTN")) == 0);
+    const bool fused_qa = qa_env && planes && T == 257 && hd == 64 && D >= 128 && (long)3 * D * D * 2 < (1L << 31);
     // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
     const amds_vit_fp8_block* f8 = w->fp8_host;
     if (f8) {
@@ -278,9 +281,19 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 continue;
             }
             if (planes) {      // hi plane (hq) = the A operand of qkv / fc1; attention writes h2q; proj / fc2 update (hq, loq) in place
+                if (fused_qa) {
+                    // qkv + attention as one kernel (qkv_attn257.hip): q | k | v of a tile's first 256 tokens stay on the chip; the q | k | v row of its
+                    // last token comes from the ordinary GEMM on the gathered rows (hcq / qcq: the class-stream buffers, idle before the last block)
+                    float* rst = qcq;
+                    AMDS_TRY(amds_gather_token_rows16(hq, rs, hcq, rst, q.nt, T, D, T - 1, s));
+                    AMDS_TRY(amds_gemm_lnfold(hcq, D, b.qkv_w, D, q.nt, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq + (size_t)(T - 1) * 3 * D * 2, (long)T * 3 * D, b.qkv_b,
+                                              nullptr, nullptr, nullptr, rst, b.qkv_colsum, s));
+                    AMDS_TRY(amds_qkv_attention_vit257(hq, b.qkv_w, b.qkv_b, b.qkv_colsum, rs, qkvq, h2q, q.nt, c->heads, D, dt, s));
+                } else {
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.qkv_w, D, n, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rs,
                                           b.qkv_colsum, s));
                 AMDS_TRY(amds_attention_vit_hd(qkvq, h2q, q.nt, T, c->heads, D / c->heads, dt, s));
+                }
                 AMDS_TRY(amds_gemm_lnfold_planes(h2q, D, b.proj_w, D, n, D, D, hq, loq, D, b.proj_b, ls1, rp, s));
                 AMDS_TRY(amds_ln_rowstat_diag(rp, n, NP, D, c->ln_eps, rs, diag, dt, s));
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.fc1_w, D, n, n_fc1, D, dt, epi1, mlpq, Hd, b.fc1_b, nullptr, nullptr, nullptr, rs, b.fc1_colsum, s));

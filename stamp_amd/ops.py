@@ -179,6 +179,38 @@ def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64)
     return out
 
 
+def gather_token_rows16(src: torch.Tensor, stat: torch.Tensor | None, B: int, T: int, row: int):
+    """Row `row` of every group of T rows of a 16-bit matrix [B*T, D] -> [B, D], with its row statistics [B*T, 2] -> [B, 2]."""
+    _dev(src, stat)
+    assert src.is_contiguous() and src.shape[0] == B * T and src.element_size() == 2
+    D = src.shape[1]
+    dst = torch.empty(B, D, dtype=src.dtype, device=src.device)
+    dstat = torch.empty(B, 2, dtype=torch.float32, device=src.device) if stat is not None else None
+    _lib.check(_lib.lib().amds_gather_token_rows16(_p(src), _p(stat), _p(dst), _p(dstat), B, T, D, row, _stream()), "gather_token_rows16")
+    return dst, dstat
+
+
+def qkv_attention_vit257(x: torch.Tensor, w_qkv: torch.Tensor, bias: torch.Tensor, B: int, H: int, *, rowstat=None, colsum=None, qkv_tail=None) -> torch.Tensor:
+    """The qkv Linear + attention of a ViT block as one kernel (T = 257, head_dim 64; include/amdstamp.h, amds_qkv_attention_vit257).  `qkv_tail`
+    [B*257, 3D] must hold the q | k | v row of every tile's token 256; when it is not given it is computed here the way vit.hip does it (gathered rows
+    through the ordinary GEMM)."""
+    _dev(x, w_qkv, bias, rowstat, colsum, qkv_tail)
+    D = H * 64
+    assert x.is_contiguous() and x.shape == (B * 257, D) and w_qkv.is_contiguous() and w_qkv.shape == (3 * D, D) and x.dtype == w_qkv.dtype
+    if qkv_tail is None:
+        qkv_tail = torch.empty(B * 257, 3 * D, dtype=x.dtype, device=x.device)
+        xt, st = gather_token_rows16(x, rowstat, B, 257, 256)
+        tail_rows = qkv_tail[256::257]
+        if rowstat is not None:
+            gemm_lnfold(xt, w_qkv, _lib.EPI_BIAS, out=tail_rows, bias=bias, rowstat=st, colsum=colsum)
+        else:
+            gemm(xt, w_qkv, _lib.EPI_BIAS, out=tail_rows, bias=bias, cfg=12)
+    out = torch.empty(B * 257, D, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().amds_qkv_attention_vit257(_p(x), _p(w_qkv), _p(bias), _p(colsum), _p(rowstat), _p(qkv_tail), _p(out), B, H, D, act_code(x.dtype),
+                                                    _stream()), "qkv_attention_vit257")
+    return out
+
+
 def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     """softmax(q k^T / 8) v for any T (streaming K/V kernel); qkv [B*T, 3*H*64] -> [B*T, H*64]."""
     _dev(qkv)
