@@ -28,15 +28,7 @@ constexpr int AX_BUF = AX_K_BYTES + AX_V_BYTES;                       // 71 808 
 constexpr int AX_PART = 68;                                           // one partial of a tail query's row: o[64] | max | sum | pad (272 B: 16-byte multiples)
 constexpr int ax_lds(int R) { return 2 * AX_BUF + 16 + 2 * 4 * R * AX_PART * 4; }
 
-// max over the 32 lanes that share lane >> 5 (the butterfly of half_wave_sum, common.h)
-__device__ __forceinline__ float half_wave_max(float v) {
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));
-    return v;
-}
+// (half_wave_max: common.h)
 
 template <typename T, int R>
 __global__ void __launch_bounds__(512) attn_vit26x_kernel(const T* __restrict__ qkv, T* __restrict__ out, int H, int n_items) {

@@ -62,6 +62,15 @@ template <> struct Act<f16> {
     static __device__ __forceinline__ void mfma16_agpr(vec8 a, vec8 b, f32x4& c) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
+    // result in architectural VGPRs (the builtin's accumulator may be placed in AGPRs, and every value a VALU instruction then reads costs a
+    // v_accvgpr_read): d = a b  /  d += a b.  Inline asm: the compiler's hazard recogniser does not see an MFMA here -- the CALLER keeps VALU
+    // reads of d a few hundred cycles away from the asm (scores consumed one pipeline stage later).
+    static __device__ __forceinline__ void mfma32_vgpr_zero(f32x16& d, vec8 a, vec8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma32_vgpr_acc(f32x16& d, vec8 a, vec8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
     // two v_cvt_pk_f16_f32 (element-wise conversion loops compile to v_cvt_f16_f32 + v_pack / v_alignbit: 2.5x the instructions)
     static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
@@ -81,6 +90,15 @@ template <> struct Act<bf16> {
     }
     static __device__ __forceinline__ void mfma16_agpr(vec8 a, vec8 b, f32x4& c) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    // result in architectural VGPRs (the builtin's accumulator may be placed in AGPRs, and every value a VALU instruction then reads costs a
+    // v_accvgpr_read): d = a b  /  d += a b.  Inline asm: the compiler's hazard recogniser does not see an MFMA here -- the CALLER keeps VALU
+    // reads of d a few hundred cycles away from the asm (scores consumed one pipeline stage later).
+    static __device__ __forceinline__ void mfma32_vgpr_zero(f32x16& d, vec8 a, vec8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma32_vgpr_acc(f32x16& d, vec8 a, vec8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
     static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
@@ -199,6 +217,16 @@ __device__ __forceinline__ f32x2 half_wave_sum8(const f32x2 (&v)[8], int lane) {
     c += f32x2{dpp(c[0], XOR1{}), dpp(c[1], XOR1{})};
     c += f32x2{dpp(c[0], XOR2{}), dpp(c[1], XOR2{})};
     return c;
+}
+
+// maximum over the 32 lanes that share lane >> 5 (the butterfly of half_wave_sum: four DPP steps and one ds_swizzle, no ds_bpermute round trips)
+__device__ __forceinline__ float half_wave_max(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));
+    return v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -26,17 +26,32 @@ namespace amds {
 constexpr int QA_XB = 256 * 128;                       // X part of a stage: 256 token rows x 128 B (K tile of 64)
 constexpr int QA_STAGE = (256 + 192) * 128;            // + 192 weight rows: 57 344 B
 constexpr int QA_VS = 576;                             // V^T rows: 8 key tiles x 64 B + 64 B skew room (attention_vit257.hip)
-constexpr int QA_KIMG = 0, QA_VIMG = 32768, QA_VBYTES = 64 * QA_VS + 8 * 16, QA_QIMG = QA_VIMG + QA_VBYTES;      // images alias the stages
-static_assert(QA_QIMG + 32768 <= 2 * QA_STAGE, "the K | V^T | Q images must fit the two stages they alias");
+// The images alias the stages: stage 1 (odd K tiles, the LAST tile of an item) = the K | V^T region, stage 0 (even K tiles, the FIRST tile of an item) starts
+// at the Q image.  The Q image is dead once every wave holds its query fragments (one barrier into the S phase), so the next item's first K tile is
+// requested into stage 0 while the S phase still reads K and V^T: the item-to-item pipeline never drains.
+constexpr int QA_KIMG = 0, QA_VIMG = 32768, QA_VBYTES = 64 * QA_VS + 8 * 16, QA_QIMG = QA_VIMG + QA_VBYTES;
+constexpr int QA_S1 = 0, QA_S0 = QA_QIMG;
+static_assert(QA_S1 + QA_STAGE <= QA_S0, "the stages must not overlap");
 constexpr int QA_PARTF = 68;                           // one partial of the odd query's row: o[64] | max | sum | pad
-constexpr int QA_ZERO = 2 * QA_STAGE;                  // 16 zero bytes
+constexpr int QA_ZERO = QA_S0 + QA_STAGE;              // 16 zero bytes
 constexpr int QA_PW = QA_ZERO + 16;                    // [8 query blocks][32] 16-bit softmax weights of the odd query
 constexpr int QA_PART = QA_PW + 8 * 64;                // [9][QA_PARTF] f32
 constexpr int QA_TAIL = QA_PART + 9 * QA_PARTF * 4;    // odd token: key | value | query in fp32 (3 x 64), the query again in 16 bit (128 B)
 constexpr int QA_RS = QA_TAIL + 3 * 64 * 4 + 128;      // (rstd, -mean rstd) of the item's 256 rows
-constexpr int QA_OUT = QA_RS + 256 * 8;                // per wave: 16 output rows x 128 B
-constexpr int QA_LDS = QA_OUT + 4 * 2048;
+constexpr int QA_OUT = QA_RS + 256 * 8;                // per wave: 32 output rows x 128 B
+constexpr int QA_LDS = QA_OUT + 4 * 4096;
 static_assert(QA_RS % 16 == 0 && QA_OUT % 16 == 0 && QA_TAIL % 16 == 0 && QA_LDS <= 160 * 1024, "LDS map");
+
+// phase timeline for tools/ubench/qa257_trace.hip (compiled with -DQA_TRACE only): s_memtime of the four waves of workgroup 0 at the phase boundaries
+#ifdef QA_TRACE
+__device__ unsigned long long qa_trace[32 * 12 * 4];
+#define QA_MARK(k)                                                                                                          \
+    do {                                                                                                                    \
+        if (blockIdx.x == 0 && lane == 0 && round < 32) qa_trace[(round * 12 + (k)) * 4 + wave] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define QA_MARK(k) do { } while (0)
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -76,7 +91,7 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
     __amdgpu_buffer_rsrc_t rsrc_x = rsrc_w;
     int wsoff = 0;
     auto issue_pieces = [&](int kt, int lo, int hi_) {
-        char* st = smem + (kt & 1) * QA_STAGE;
+        char* st = smem + ((kt & 1) ? QA_S1 : QA_S0);
         const int koff = kt * 128;
 #pragma unroll
         for (int it = 0; it < 14; ++it)
@@ -93,7 +108,7 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
 
     vec8 af[2][FI], wf[2][FJ];
     auto load_frags = [&](int kt, int ks, int s, int lo, int hi_) {
-        const char* sb = smem + (kt & 1) * QA_STAGE;
+        const char* sb = smem + ((kt & 1) ? QA_S1 : QA_S0);
         const int co = ((ks * 4 + kb) ^ swz) << 4;
 #pragma unroll
         for (int q = 0; q < 14; ++q)
@@ -124,8 +139,6 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
         }
     };
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 4> I4;
-    typedef std::integral_constant<int, 5> I5;
     typedef std::integral_constant<int, 7> I7;
     typedef std::integral_constant<int, 14> I14;
 #define QA_BARRIER()                          \
@@ -134,29 +147,39 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
         __builtin_amdgcn_s_barrier();         \
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
-    // pieces of tile kt + 1: 0-3 in the last unit of tile kt - 1, 4-8 and 9-13 in the first two units of tile kt; waited for (vmcnt(0)) at 3/4 of tile kt
+    // pieces of tile kt + 1: 0 .. P3 - 1 in the last unit of tile kt - 1, then P0 and P1 in the first two units of tile kt; waited for (vmcnt(0)) at 3/4 of tile kt
+#ifndef QA_P3
+#define QA_P3 4
+#endif
+#ifndef QA_P0
+#define QA_P0 5
+#endif
+    constexpr int P3 = QA_P3, P0 = QA_P0, P1 = 14 - P3 - P0;
+    static_assert(P3 >= 0 && P3 <= 10 && P0 >= 0 && P1 >= 0, "LDS-DMA piece split");
+    typedef std::integral_constant<int, P3> IP3;
+    typedef std::integral_constant<int, P0> IP0;
+    typedef std::integral_constant<int, P1> IP1;
     auto k_tile = [&](int kt, auto next_c, auto next2_c) {
         constexpr bool NEXT = decltype(next_c)::value, NEXT2 = decltype(next2_c)::value;
-        if constexpr (NEXT) unit(0, 0, I7{}, kt, 1, 1, 0, I5{}, kt + 1, 4); else unit(0, 0, I7{}, kt, 1, 1, 0, I0{}, 0, 0);
-        if constexpr (NEXT) unit(0, 1, I7{}, kt, 1, 1, 7, I5{}, kt + 1, 9); else unit(0, 1, I7{}, kt, 1, 1, 7, I0{}, 0, 0);
+        if constexpr (NEXT) unit(0, 0, I7{}, kt, 1, 1, 0, IP0{}, kt + 1, P3); else unit(0, 0, I7{}, kt, 1, 1, 0, I0{}, 0, 0);
+        if constexpr (NEXT) unit(0, 1, I7{}, kt, 1, 1, 7, IP1{}, kt + 1, P3 + P0); else unit(0, 1, I7{}, kt, 1, 1, 7, I0{}, 0, 0);
         unit(1, 0, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         QA_BARRIER();
-        if constexpr (NEXT2) unit(1, 1, I14{}, kt + 1, 0, 0, 0, I4{}, kt + 2, 0);
+        if constexpr (NEXT2) unit(1, 1, I14{}, kt + 1, 0, 0, 0, IP3{}, kt + 2, 0);
         else if constexpr (NEXT) unit(1, 1, I14{}, kt + 1, 0, 0, 0, I0{}, 0, 0);
         else unit(1, 1, I0{}, 0, 0, 0, 0, I0{}, 0, 0);
     };
 
     // ---- item order: an XCD's workgroups (blockIdx & 7 == xcd) take CONSECUTIVE slots, and 32 consecutive slots are 4 tiles x 8 heads: per round an
-    // XCD fetches 4 x 526 KB of X and 8 x 393 KB of W once and serves the other reads from its L2
+    // XCD fetches 4 x 526 KB of X and 8 x 393 KB of W once and serves the other reads from its L2.  (With H % 8 == 0 a workgroup keeps its head for the
+    // whole launch and walks tiles: slot -> tile is monotonic, so the first slot past the batch ends the walk.)
     const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, per = gridDim.x >> 3;
     const bool oct = (H & 7) == 0;
-#pragma unroll 1
-    for (int round = 0;; ++round) {
+    auto slot_item = [&](int round, int& b, int& h) {
         const int u = (round * 8 + xcd) * per + wq;
-        if (u >= n_slots) break;
-        int b, h;
+        if (u >= n_slots) return false;
         if (oct) {
             const int per_quad = 4 * H, quad = u / per_quad, rem = u - quad * per_quad;
             b = quad * 4 + ((rem & 31) >> 3);
@@ -165,30 +188,42 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
             b = u / H;
             h = u - b * H;
         }
-        if (b >= B) continue;
-        const long row0 = (long)b * Tn;
-
-        // ================= G phase =================
-        rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X + row0 * D), 0, 256 * D * 2, 0x00020000);
+        return b < B;
+    };
+    auto point_at = [&](int b, int h) {          // the LDS-DMA descriptors of item (b, h)
+        rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X + (long)b * Tn * D), 0, 256 * D * 2, 0x00020000);
         wsoff = h * 64 * D * 2;
-        {   // small per-item operands first (they land under the first K tile's DMA): row statistics, the odd token's q | k | v
-            f32x2 rsv = f32x2{1.f, 0.f};
-            if (rowstat) rsv = *reinterpret_cast<const f32x2*>(rowstat + 2 * (row0 + tid));
-            const T* tp = qkv_tail + (row0 + 256) * 3 * D + h * 64 + lane;
-            const T tq = tp[0], tk = tp[D], tv = tp[2 * D];
-            __builtin_amdgcn_sched_barrier(0);
-            issue_pieces(0, 0, 14);
-            __builtin_amdgcn_sched_barrier(0);
+    };
+    // hand-off addresses: lane-only, four of them; everything else is an immediate offset (block row 16 i -> 2048 B of a row-major image, 32 B of a V^T row)
+    const int ho_sw = (l15 >> 1) & 7;
+    int ho_qk[2], ho_v[2];
 #pragma unroll
-            for (int i = 0; i < FI; ++i)
+    for (int jj = 0; jj < 2; ++jj) {
+        const int c0 = (2 * wn + jj) * 16 + 4 * kb;                                      // first of the lane's 4 dims in a q / k block
+        ho_qk[jj] = (wm * 128 + l15) * 128 + (((c0 >> 3) ^ ho_sw) << 4) + ((c0 >> 2) & 1) * 8;
+        const int d = (2 * wn + jj) * 16 + l15, t0 = wm * 128 + 4 * kb;                  // a v block: dim d, tokens t0 + 16 i .. + 3
+        ho_v[jj] = QA_VIMG + d * VS + (d >> 3) * 16 + ((t0 & ~12) | ((t0 & 4) << 1) | ((t0 & 8) >> 1)) * 2;      // key order inside 16-groups: bits 2 <-> 3
+    }
+    const int ho_rs1 = QA_RS + (wm * 128 + l15) * 8, ho_rs4 = QA_RS + (wm * 128 + 4 * kb) * 8;
+
+    int b = 0, h = 0;
+    bool have = slot_item(0, b, h);
+    if (have) {
+        point_at(b, h);
+        issue_pieces(0, 0, 14);
+    }
+#pragma unroll 1
+    for (int round = 0; have; ++round) {
+        const long row0 = (long)b * Tn;
+        int nb = 0, nh = 0;
+        const bool have_next = slot_item(round + 1, nb, nh);
+
+        QA_MARK(0);
+        // ================= G phase (K tile 0 was requested during the previous item's S phase) =================
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x2*>(smem + QA_RS + tid * 8) = rsv;
-            if (tid < 64) {
-                sT[tid] = Act<T>::to_f32(tk); sT[64 + tid] = Act<T>::to_f32(tv); sT[128 + tid] = Act<T>::to_f32(tq);
-                reinterpret_cast<T*>(sT + 192)[tid] = tq;
-            }
-        }
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // (the initial values must BE in their AGPRs well before the first inline-asm MFMA reads them: gemm_4w16.h)
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
@@ -196,10 +231,16 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
             else asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K tile 0
         QA_BARRIER();
+        QA_MARK(1);
+        // small per-item operands (row statistics, the odd token's q | k | v): requested now, written to LDS after the K loop
+        f32x2 rsv = f32x2{1.f, 0.f};
+        if (rowstat) rsv = *reinterpret_cast<const f32x2*>(rowstat + 2 * (row0 + tid));
+        const T* tp = qkv_tail + (row0 + 256) * 3 * D + h * 64 + lane;
+        const T tq = tp[0], tk = tp[D], tv = tp[2 * D];
         load_frags(0, 0, 0, 0, 14);
-        issue_pieces(1, 0, 4);
+        issue_pieces(1, 0, P3);
         __builtin_amdgcn_sched_barrier(0);
         int kt = 0;
         for (; kt < nk - 2; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
@@ -220,7 +261,13 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
             csv[j] = colsum ? colsum[n] : 0.f;
         }
         k_tile(kt, std::false_type{}, std::false_type{});
-        QA_BARRIER();                  // every wave is done with the LDS stages
+        *reinterpret_cast<f32x2*>(smem + QA_RS + tid * 8) = rsv;
+        if (tid < 64) {
+            sT[tid] = Act<T>::to_f32(tk); sT[64 + tid] = Act<T>::to_f32(tv); sT[128 + tid] = Act<T>::to_f32(tq);
+            reinterpret_cast<T*>(sT + 192)[tid] = tq;
+        }
+        QA_BARRIER();                  // every wave is done with the LDS stages; the row statistics are in place
+        QA_MARK(2);
         // MFMA result -> accumulator read hazard (gemm_4w16.h): keep every accumulator in its AGPR until the nops have run
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
@@ -230,264 +277,305 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= hand-off: accumulators -> Q / K / V^T images =================
-        {
-            const char* sRS = smem + QA_RS;
 #pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const int t = wm * 128 + i * 16 + l15;                              // q / k blocks: this lane's token
-                const f32x2 rs1 = *reinterpret_cast<const f32x2*>(sRS + t * 8);
-                const int rowb = t * 128, sw = (t >> 1) & 7;
+        for (int i = 0; i < FI; ++i) {
+            const f32x2 rs1 = *reinterpret_cast<const f32x2*>(smem + ho_rs1 + i * 128);                 // q / k blocks: this lane's token 16 i + l15
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v;
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[i][j][0]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(acc[i][j][1]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
-                    v = v * rs1[0] + (cs[j] * rs1[1] + cb[j]);
-                    const int c0 = (2 * wn + (j & 1)) * 16 + 4 * kb;                // first of the lane's 4 dims
-                    char* img = smem + (j < 2 ? QA_QIMG : QA_KIMG);
-                    *reinterpret_cast<vec4*>(img + rowb + (((c0 >> 3) ^ sw) << 4) + ((c0 >> 2) & 1) * 8) = Act<T>::from_f32x4(v);
-                }
-                const int t0 = wm * 128 + i * 16 + 4 * kb;                          // v blocks: this lane's 4 tokens
-                const f32x4 ra = *reinterpret_cast<const f32x4*>(sRS + t0 * 8), rb = *reinterpret_cast<const f32x4*>(sRS + t0 * 8 + 16);
-                const int pos = (t0 & ~12) | ((t0 & 4) << 1) | ((t0 & 8) >> 1);       // key order inside 16-groups: bits 2 <-> 3
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[i][j][0]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(acc[i][j][1]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
+                v = v * rs1[0] + (cs[j] * rs1[1] + cb[j]);
+                *reinterpret_cast<vec4*>(smem + (j < 2 ? QA_QIMG : QA_KIMG) + ho_qk[j & 1] + i * 2048) = Act<T>::from_f32x4(v);
+            }
+            const f32x4 ra = *reinterpret_cast<const f32x4*>(smem + ho_rs4 + i * 128), rb = *reinterpret_cast<const f32x4*>(smem + ho_rs4 + i * 128 + 16);
 #pragma unroll
-                for (int j = 4; j < 6; ++j) {
-                    f32x4 v;
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[i][j][0]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(acc[i][j][1]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
-                    const float c_b = cbv[j - 4], c_s = csv[j - 4];
-                    v = f32x4{v[0] * ra[0] + (c_s * ra[1] + c_b), v[1] * ra[2] + (c_s * ra[3] + c_b), v[2] * rb[0] + (c_s * rb[1] + c_b),
-                              v[3] * rb[2] + (c_s * rb[3] + c_b)};
-                    const int d = (2 * wn + (j - 4)) * 16 + l15;
-                    *reinterpret_cast<vec4*>(smem + QA_VIMG + d * VS + (d >> 3) * 16 + pos * 2) = Act<T>::from_f32x4(v);
-                }
+            for (int j = 4; j < 6; ++j) {                                                            // v blocks: this lane's tokens 16 i + 4 kb .. + 3
+                f32x4 v;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[i][j][0]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(acc[i][j][1]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
+                const float c_b = cbv[j - 4], c_s = csv[j - 4];
+                v = f32x4{v[0] * ra[0] + (c_s * ra[1] + c_b), v[1] * ra[2] + (c_s * ra[3] + c_b), v[2] * rb[0] + (c_s * rb[1] + c_b),
+                          v[3] * rb[2] + (c_s * rb[3] + c_b)};
+                *reinterpret_cast<vec4*>(smem + ho_v[j - 4] + i * 32) = Act<T>::from_f32x4(v);
             }
         }
+        QA_MARK(3);
         __syncthreads();
+        QA_MARK(4);
 
-        // ================= S phase (attention_vit257.hip's arithmetic; each wave: query blocks 2 wave, 2 wave + 1) =================
+        // ================= S phase (each wave: query blocks 2 wave, 2 wave + 1) =================
         const char* sK = smem + QA_KIMG;
         const char* sVt = smem + QA_VIMG;
         const char* sQ = smem + QA_QIMG;
         const float* sKt = sT;
         const float* sVl = sT + 64;
         const float* sQt = sT + 128;
+        int ols = lane;
+        asm volatile("" : "+v"(ols));
+        const int l31 = ols & 31, hi = ols >> 5;
         const int swz32 = (l31 >> 1) & 7;
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
-            const int vw = 2 * wave + rr;
-            vec8 qf[4];
+        // Both query blocks of the wave go through ONE instruction stream: a wave alone on its SIMD has nobody to hide its dependent MFMA / VALU latencies
+        // behind; two independent blocks in every slice do that for each other, and every K / V^T operand fragment is read from LDS once for both.
+        // Softmax in TWO passes over the 8 key tiles instead of an online one: pass 1 = Q K^T on the (otherwise idle) matrix pipe for the row maxima only;
+        // pass 2 = Q K^T again, p = exp2(s * scale - max), P V, and the row sums as one more product of P against a ones operand.  No running maximum, hence
+        // no rescaling of the output accumulators, which never leave the AGPRs; one key tile (16 scores per lane) in flight instead of two, which is what
+        // lets two blocks fit the 256 architectural VGPRs; the score products land in VGPRs (inline asm) so the softmax reads them without v_accvgpr_read.
+        constexpr int NB = 2;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        vec8 qf[NB][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const vec8*>(sQ + (vw * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
-            {
-                f32x16 o[2];
+        for (int r = 0; r < NB; ++r)
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+            for (int ks = 0; ks < 4; ++ks) qf[r][ks] = *reinterpret_cast<const vec8*>(sQ + ((2 * wave + r) * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        QA_BARRIER();                  // every wave holds its queries: the Q image (= the head of stage 0) is free
+        if (have_next) point_at(nb, nh);
+        auto k_frag = [&](int t, int ks) { return *reinterpret_cast<const vec8*>(sK + (t * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4)); };
+        auto v_frag = [&](int t, int ks, int dt) {
+            const int pos = t * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
+            return *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+        };
+        float mrow[NB], pt[NB];
+        {   // ---- pass 1: row maxima.  Iteration t issues tile t + 1's eight products, each followed by a quarter of tile t's maxima; the next item's first
+            // K tile is requested on the way, two LDS-DMA pieces per iteration
+            f32x16 sA[NB], sB[NB];
+            float mx[NB];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-                float mrun = -INFINITY, l = 0.f;
-                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                auto stage = [&](auto has_pv_c, auto has_qk_c, int c, float alpha_prev, f32x16 (&sc_)[2], vec8 (&pout)[2][2], const vec8 (&pprev)[2][2],
-                                 f32x16 (&sn)[2]) {
-                    constexpr bool HP = decltype(has_pv_c)::value, HQ = decltype(has_qk_c)::value;
-                    vec8 opnd[4];
-                    auto ld = [&](int i) {                                   // operand of MFMA i: 0-7 = QK^T (K rows), 8-15 = P V (V^T rows)
-                        if (i < 0 || i >= 16) return;
-                        if (i < 8) {
-                            if (!HQ) return;
-                            const int t = i & 1, ks = i >> 1;
-                            opnd[i & 3] = *reinterpret_cast<const vec8*>(sK + (((c + 1) * 2 + t) * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
-                        } else {
-                            if (!HP) return;
-                            const int q = i - 8, t = q >> 2, ks = (q >> 1) & 1, dt = q & 1;
-                            const int pos = ((c - 1) * 2 + t) * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
-                            opnd[i & 3] = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
-                        }
-                    };
-                    auto mf = [&](int i) {
-                        if (i < 8) {
-                            if (!HQ) return;
-                            const int t = i & 1, ks = i >> 1;
-                            sn[t] = Act<T>::mfma32(opnd[i & 3], qf[ks], ks == 0 ? zero16 : sn[t]);
-                        } else {
-                            if (!HP) return;
-                            const int q = i - 8, t = q >> 2, ks = (q >> 1) & 1, dt = q & 1;
-                            o[dt] = Act<T>::mfma32(opnd[i & 3], pprev[t][ks], o[dt]);
-                        }
-                    };
-                    float mx = -INFINITY, mnew = 0.f, alpha = 0.f, ls = 0.f;
-                    ld(0);
-                    ld(1);
+            for (int r = 0; r < NB; ++r) mx[r] = -INFINITY;
 #pragma unroll
-                    for (int sl = 0; sl < 16; ++sl) {
-                        ld(sl + 2);
-                        mf(sl);
-                        if (sl < 2) {
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 kf = k_frag(0, ks);
 #pragma unroll
-                            for (int f = 16 * sl; f < 16 * sl + 16; ++f) mx = fmaxf(mx, sc_[f >> 4][f & 15]);
-                        }
-                        if (sl == 2) {
-                            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                            mnew = fmaxf(mrun, mx * sc);
-                            alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-                            mrun = mnew;
-                        }
-                        if ((sl == 2 || sl == 3) && HP) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) o[sl - 2][r] *= alpha_prev;
-                        }
-                        if (sl >= 3 && sl < 14) {
-#pragma unroll
-                            for (int f = 3 * (sl - 3); f < 3 * (sl - 3) + 3 && f < 32; ++f) {
-                                const float pw = __builtin_amdgcn_exp2f(fmaf(sc_[f >> 4][f & 15], sc, -mnew));
-                                ls += pw;
-                                pout[f >> 4][(f >> 3) & 1][f & 7] = Act<T>::from_f32(pw);
-                            }
-                        }
-                        if (sl == 14) l = l * alpha + ls;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    return alpha;
-                };
-                typedef std::true_type Y;
-                typedef std::false_type N_;
-                f32x16 sa[2], sb[2];
-                vec8 p0[2][2], p1[2][2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    sa[t] = zero16;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const vec8 kf = *reinterpret_cast<const vec8*>(sK + (t * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
-                        sa[t] = Act<T>::mfma32(kf, qf[ks], sa[t]);
-                    }
+                for (int r = 0; r < NB; ++r) {
+                    if (ks == 0) Act<T>::mfma32_vgpr_zero(sA[r], kf, qf[r][ks]); else Act<T>::mfma32_vgpr_acc(sA[r], kf, qf[r][ks]);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto iter = [&](int t, f32x16 (&cur)[NB], f32x16 (&nxt)[NB]) {
+                vec8 kf[4];
+                if (t + 1 < 8) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) kf[ks] = k_frag(t + 1, ks);
+                }
+                if (have_next && t < 7) issue_pieces(0, 2 * t, 2 * t + 2);
+                if (t == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // tile 0's chain has nothing in front of its first reader
                 __builtin_amdgcn_sched_barrier(0);
-                const float al0 = stage(N_{}, Y{}, 0, 0.f, sa, p0, p1, sb);
-                const float al1 = stage(Y{}, Y{}, 1, al0, sb, p1, p0, sa);
-                const float al2 = stage(Y{}, Y{}, 2, al1, sa, p0, p1, sb);
-                const float al3 = stage(Y{}, N_{}, 3, al2, sb, p1, p0, sa);
+                // (a quarter of the maxima behind each pair of products, one pair late: the first VALU read of `cur` comes four MFMA issues after the asm that wrote it)
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) {
+                    if (t + 1 < 8 && ks < 4) {
+#pragma unroll
+                        for (int r = 0; r < NB; ++r) {
+                            if (ks == 0) Act<T>::mfma32_vgpr_zero(nxt[r], kf[ks], qf[r][ks]); else Act<T>::mfma32_vgpr_acc(nxt[r], kf[ks], qf[r][ks]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (the maxima stay BEHIND this slice's products)
+                    if (ks >= 1) {
+#pragma unroll
+                        for (int r = 0; r < NB; ++r)
+#pragma unroll
+                            for (int e = 4 * (ks - 1); e < 4 * ks; ++e) mx[r] = fmaxf(mx[r], cur[r][e]);
+                        // opaque to the optimiser: max is associative, and left alone the whole 256-leaf reduction is re-associated and sunk behind the last tile --
+                        // every tile's scores then stay live (spills, and copies of the asm MFMAs' outputs taken right behind them: stale values)
+                        asm volatile("" : "+v"(mx[0]), "+v"(mx[1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t == 6) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // ... nor has tile 7's
+            };
+            iter(0, sA, sB); iter(1, sB, sA); iter(2, sA, sB); iter(3, sB, sA); iter(4, sA, sB); iter(5, sB, sA); iter(6, sA, sB); iter(7, sB, sA);
+            // the odd key's score (dot product split over the lane pair) joins the maximum
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                float dot = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f32x4 k0 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8), k1 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dot = fmaf(Act<T>::to_f32(qf[r][ks][e]), k0[e], fmaf(Act<T>::to_f32(qf[r][ks][4 + e]), k1[e], dot));
+                }
+                dot += __shfl_xor(dot, 32, 64);
+                mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 32, 64));
+                const float st = dot * sc;
+                mrow[r] = fmaxf(mx[r] * sc, st);
+                pt[r] = __builtin_amdgcn_exp2f(st - mrow[r]);
+            }
+        }
+        QA_MARK(7);
+        {   // ---- pass 2: stage t = Q K^T of tile t + 1 (MFMAs 0-7), P V of tile t - 1 (8-15) and its row sums (16-19) beside the exponentials of tile t, in 20 slices
+            f32x16 o[NB][2], lsum[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                lsum[r] = zero16;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[r][dt] = zero16;
+            }
+            vec8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = Act<T>::from_f32(1.0f);
+            auto stage = [&](auto has_pv_c, auto has_qk_c, int t, f32x16 (&scur)[NB], f32x16 (&snext)[NB], vec8 (&pout)[NB][2], const vec8 (&pprev)[NB][2]) {
+                constexpr bool HP = decltype(has_pv_c)::value, HQ = decltype(has_qk_c)::value;
+                vec8 opnd[4];
+                auto ld = [&](int j) {                                   // operand j of this stage: 0-3 = K rows of tile t + 1 (ks = j), 4-7 = V^T rows of tile t - 1
+                    if (j < 0 || j >= 8) return;
+                    if (j < 4) { if (HQ) opnd[j & 3] = k_frag(t + 1, j); }
+                    else if (HP) opnd[j & 3] = v_frag(t - 1, (j - 4) >> 1, (j - 4) & 1);
+                };
+                auto mf = [&](int i) {                                   // MFMA i < 16: operand i >> 1, block i & 1; 16-19: row sums of P (ks = (i - 16) >> 1)
+                    const int j = i >> 1, r = i & 1;
+                    if (i >= 16) { if (HP) lsum[r] = Act<T>::mfma32(ones, pprev[r][j - 8], lsum[r]); }
+                    else if (j < 4) {
+                        if (HQ) { if (j == 0) Act<T>::mfma32_vgpr_zero(snext[r], opnd[j & 3], qf[r][j]); else Act<T>::mfma32_vgpr_acc(snext[r], opnd[j & 3], qf[r][j]); }
+                    } else if (HP) o[r][(j - 4) & 1] = Act<T>::mfma32(opnd[j & 3], pprev[r][(j - 4) >> 1], o[r][(j - 4) & 1]);
+                };
+                ld(0);
+                ld(1);
+#pragma unroll
+                for (int sl = 0; sl < 20; ++sl) {
+                    if ((sl & 1) == 0) ld((sl >> 1) + 2);
+                    mf(sl);
+                    if (sl >= 2 && sl < 18) {                             // two weights per slice, rounded to the operand type at once
+#pragma unroll
+                        for (int f = 2 * (sl - 2); f < 2 * (sl - 2) + 2; ++f) {
+                            const int r = f >> 4, e = f & 15;
+                            pout[r][e >> 3][e & 7] = Act<T>::from_f32(__builtin_amdgcn_exp2f(fmaf(scur[r][e], sc, -mrow[r])));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            typedef std::true_type Y;
+            typedef std::false_type N_;
+            f32x16 sA[NB], sB[NB];
+            vec8 pA[NB][2], pB[NB][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 kf = k_frag(0, ks);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    if (ks == 0) Act<T>::mfma32_vgpr_zero(sA[r], kf, qf[r][ks]); else Act<T>::mfma32_vgpr_acc(sA[r], kf, qf[r][ks]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // stage 0 reads sA with nothing in between: let the chain finish (72 wait states)
+            stage(N_{}, Y{}, 0, sA, sB, pA, pB);
+            stage(Y{}, Y{}, 1, sB, sA, pB, pA);
+            stage(Y{}, Y{}, 2, sA, sB, pA, pB);
+            stage(Y{}, Y{}, 3, sB, sA, pB, pA);
+            stage(Y{}, Y{}, 4, sA, sB, pA, pB);
+            stage(Y{}, Y{}, 5, sB, sA, pB, pA);
+            stage(Y{}, Y{}, 6, sA, sB, pA, pB);
+            stage(Y{}, N_{}, 7, sB, sA, pB, pA);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                 // P V and the row sums of the last tile
+                const vec8 vf = v_frag(7, j >> 1, j & 1);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) o[r][j & 1] = Act<T>::mfma32(vf, pB[r][j >> 1], o[r][j & 1]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < NB; ++r) lsum[r] = Act<T>::mfma32(ones, pB[r][ks], lsum[r]);
+            QA_MARK(8);
+            {   // normalise (+ the odd key's rank-1 term: its value row, 8 x 4 dims per lane, is read once for both blocks) and store: a wave's 32 output rows of
+                // a block go through 4 KB of LDS so that a row leaves as one 128-byte line (attention_vit257.hip), all 64 lanes in every instruction
+                f32x4 vv[2][4];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= al3;
+                    for (int g = 0; g < 4; ++g) vv[dt][g] = *reinterpret_cast<const f32x4*>(sVl + dt * 32 + 8 * g + 4 * hi);
+                char* so = smem + QA_OUT + wave * 4096;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {                                 // P V of the last chunk
-                    const int t = i >> 2, ks = (i >> 1) & 1, dt = i & 1;
-                    const int pos = (6 + t) * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
-                    const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
-                    o[dt] = Act<T>::mfma32(vf, p1[t][ks], o[dt]);
-                }
-                {   // the odd key: rank-1 update of this block's 32 queries (dot product split over the lane pair)
-                    float dot = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const f32x4 k0 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8), k1 = *reinterpret_cast<const f32x4*>(sKt + (ks * 2 + hi) * 8 + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dot = fmaf(Act<T>::to_f32(qf[ks][e]), k0[e], fmaf(Act<T>::to_f32(qf[ks][4 + e]), k1[e], dot));
-                    }
-                    dot += __shfl_xor(dot, 32, 64);
-                    const float st = dot * sc, mnew = fmaxf(mrun, st);
-                    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew), pt = __builtin_amdgcn_exp2f(st - mnew);
-                    mrun = mnew;
-                    l = l * alpha + (hi == 0 ? pt : 0.f);
+                for (int r = 0; r < NB; ++r) {
+                    const int vw = 2 * wave + r;
+                    const float inv = __builtin_amdgcn_rcpf(lsum[r][0] + pt[r]), ptn = pt[r] * inv;      // every row of the ones product holds the query's sum over all 256 keys
+                    T* obase = out + (row0 + vw * 32) * D + h * 64;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const f32x4 vv = *reinterpret_cast<const f32x4*>(sVl + dt * 32 + 8 * g + 4 * hi);
+                            vec4 w;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[dt][4 * g + e] = fmaf(o[dt][4 * g + e], alpha, pt * vv[e]);
+                            for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(fmaf(o[r][dt][4 * g + e], inv, ptn * vv[dt][g][e]));
+                            *reinterpret_cast<vec4*>(so + l31 * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = w;
                         }
-                }
-                l += __shfl_xor(l, 32, 64);
-                const float inv = 1.0f / l;
-                // output rows through 2 KB of LDS per wave, 16 queries at a time, so that a row leaves as one 128-byte line
-                char* so = smem + QA_OUT + wave * 2048;
-                T* obase = out + (row0 + vw * 32) * D + h * 64;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if ((l31 >> 4) == r) {
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                vec4 w;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) w[e] = Act<T>::from_f32(o[dt][4 * g + e] * inv);
-                                *reinterpret_cast<vec4*>(so + (l31 & 15) * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = w;
-                            }
-                    }
                     asm volatile("" ::: "memory");                            // same wave, LDS in order: the reads below see the writes above
+                    u32x4 ov[4];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int row = k * 8 + (lane >> 3), c = lane & 7;
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(so + row * 128 + ((c ^ (row & 7)) << 4));
-                        *reinterpret_cast<u32x4*>(obase + (long)(r * 16 + row) * D + c * 8) = v;
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = k * 8 + (lane >> 3), cc = lane & 7;
+                        ov[k] = *reinterpret_cast<const u32x4*>(so + row * 128 + ((cc ^ (row & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = k * 8 + (lane >> 3), cc = lane & 7;
+                        *reinterpret_cast<u32x4*>(obase + (long)row * D + cc * 8) = ov[k];
                     }
                     asm volatile("" ::: "memory");
                 }
             }
-            // ---- the odd query against keys 32 vw .. 32 vw + 31 on the MFMA pipe: a partial (max, sum, o[64]) merged after the barrier ----
-            {
-                const char* sQh = reinterpret_cast<const char*>(sT + 192);
-                const char* qsrc = l31 == 0 ? sQh + hi * 16 : sZero;
-                const int qstep = l31 == 0 ? 32 : 0;
-                f32x16 s1;
+        }
+        QA_MARK(9);
+        // ---- the odd query against keys 32 vw .. 32 vw + 31 on the MFMA pipe: a partial (max, sum, o[64]) per query block, merged after the barrier.
+        // Both blocks step by step together; the 32-lane reductions are DPP butterflies (six ds_bpermute round trips each cost a lone wave 4 k cycles per item)
+        {
+            const char* sQh = reinterpret_cast<const char*>(sT + 192);
+            const char* qsrc = l31 == 0 ? sQh + hi * 16 : sZero;
+            const int qstep = l31 == 0 ? 32 : 0;
+            f32x16 s1[NB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 qa = *reinterpret_cast<const vec8*>(qsrc + ks * qstep);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const vec8 qa = *reinterpret_cast<const vec8*>(qsrc + ks * qstep);
-                    const vec8 kf = *reinterpret_cast<const vec8*>(sK + (vw * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz32) << 4));
-                    s1 = Act<T>::mfma32(qa, kf, s1);
-                }
-                const float sv = hi == 0 ? s1[0] * sc : -INFINITY;
-                const float mw = wave_max(sv);
-                const float pk = hi == 0 ? __builtin_amdgcn_exp2f(sv - mw) : 0.f;
-                const float lw = wave_sum(pk);
-                char* pw = sPw + vw * 64;
-                if (hi == 0) reinterpret_cast<T*>(pw)[(l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)] = Act<T>::from_f32(pk);      // the V^T image's key order
-                asm volatile("" ::: "memory");
-                const char* psrc = l31 == 0 ? pw + hi * 16 : sZero;
-                f32x16 oq[2];
+                for (int r = 0; r < NB; ++r) s1[r] = Act<T>::mfma32(qa, k_frag(2 * wave + r, ks), ks == 0 ? zero16 : s1[r]);
+            }
+            float mw[NB], lw[NB];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+            for (int r = 0; r < NB; ++r) {
+                const float sv = hi == 0 ? s1[r][0] * sc : -INFINITY;
+                mw[r] = half_wave_max(sv);
+                const float pk = hi == 0 ? __builtin_amdgcn_exp2f(sv - mw[r]) : 0.f;
+                lw[r] = half_wave_sum(pk);
+                if (hi == 0) reinterpret_cast<T*>(sPw + (2 * wave + r) * 64)[(l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)] = Act<T>::from_f32(pk);      // the V^T image's key order
+            }
+            asm volatile("" ::: "memory");                                // same wave, LDS in order: the reads below see the writes above
+            f32x16 oq[NB][2];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oq[dt][r] = 0.f;
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int r = 0; r < NB; ++r) {
+                    const char* psrc = l31 == 0 ? sPw + (2 * wave + r) * 64 + hi * 16 : sZero;
                     const vec8 pf = *reinterpret_cast<const vec8*>(psrc + ks * qstep);
-                    const int pos = vw * 32 + ks * 16 + hi * 8;
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int d = dt * 32 + l31;
-                        const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
-                        oq[dt] = Act<T>::mfma32(vf, pf, oq[dt]);
-                    }
+                    for (int dt = 0; dt < 2; ++dt) oq[r][dt] = Act<T>::mfma32(v_frag(2 * wave + r, ks, dt), pf, ks == 0 ? zero16 : oq[r][dt]);
                 }
-                float* pp = sPart + vw * QA_PARTF;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                float* pp = sPart + (2 * wave + r) * QA_PARTF;
                 if (l31 == 0) {                                           // column 0 of the product: 32 dims in lane 0, 32 in lane 32
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<f32x4*>(pp + dt * 32 + 8 * g + 4 * hi) = f32x4{oq[dt][4 * g], oq[dt][4 * g + 1], oq[dt][4 * g + 2], oq[dt][4 * g + 3]};
-                    if (hi == 0) { pp[64] = mw; pp[65] = lw; }
-                }
-                if (vw == 1) {                                            // the odd key's term of that row as the ninth partial
-                    float* p8 = sPart + 8 * QA_PARTF;
-                    const float st = wave_sum(sQt[lane] * sKt[lane]) * sc;
-                    p8[lane] = sVl[lane];
-                    if (lane == 0) { p8[64] = st; p8[65] = 1.0f; }
+                            *reinterpret_cast<f32x4*>(pp + dt * 32 + 8 * g + 4 * hi) = f32x4{oq[r][dt][4 * g], oq[r][dt][4 * g + 1], oq[r][dt][4 * g + 2], oq[r][dt][4 * g + 3]};
+                    if (hi == 0) { pp[64] = mw[r]; pp[65] = lw[r]; }
                 }
             }
+            if (wave == 0) {                                              // the odd key's term of that row as the ninth partial
+                float* p8 = sPart + 8 * QA_PARTF;
+                float st = half_wave_sum(sQt[lane] * sKt[lane]);
+                st = (st + __shfl_xor(st, 32, 64)) * sc;
+                p8[lane] = sVl[lane];
+                if (lane == 0) { p8[64] = st; p8[65] = 1.0f; }
+            }
         }
-        __syncthreads();               // the images are free (the next item's first K tile overwrites them); the partials are complete
+        QA_MARK(5);
+        __syncthreads();               // the K | V^T images are free (the next item's second K tile overwrites them); the partials are complete
         if (wave == 0) {               // the odd query's row out of its 9 partials
             const float* pp = sPart;
             float m = pp[64];
@@ -502,6 +590,10 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
             }
             out[(row0 + 256) * D + h * 64 + lane] = Act<T>::from_f32(ov / lsum);
         }
+        QA_MARK(6);
+        have = have_next;
+        b = nb;
+        h = nh;
     }
 #undef QA_BARRIER
 }

@@ -1,6 +1,6 @@
 """amds_qkv_attention_vit257 (csrc/qkv_attn257.hip): the qkv Linear and the attention of a ViT block as one kernel, against the two launches it replaces
-(amds_gemm_lnfold / amds_gemm + amds_attention_vit) -- same operand rounding, same K order, same softmax arithmetic: bit for bit -- and against a plain
-fp32 torch restatement of timm's Attention.forward (what the reference runs inside `model(tiles)`, src/stamp/preprocessing/__init__.py:324-325)."""
+(amds_gemm_lnfold / amds_gemm + amds_attention_vit) -- q | k | v are the same bits (same operand rounding, same K order); the softmax is taken in two
+passes instead of online, so the outputs agree to rounding, not bit for bit -- and against a plain fp32 torch restatement of timm's Attention.forward (what the reference runs inside `model(tiles)`, src/stamp/preprocessing/__init__.py:324-325)."""
 import os
 
 import pytest
@@ -53,8 +53,10 @@ def test_fused_equals_the_two_launches_it_replaces(B, H, dtype, fold):
     ref = _torch_ref(x.cpu(), w.cpu(), bias.cpu(), rowstat.cpu() if fold else None, colsum, B, H)
     rel = ((got.float().cpu() - ref).norm() / ref.norm()).item()
     assert rel < (2e-3 if dtype == torch.float16 else 1.5e-2), rel
-    diff = (got.float() - want.float()).abs().max().item()
-    assert torch.equal(got, want), f"fused differs from gemm + attention: max abs {diff:.3e}"
+    rel2 = ((got.float() - want.float()).norm() / want.float().norm()).item()
+    assert rel2 < (6e-4 if dtype == torch.float16 else 5e-3), f"fused vs gemm + attention: rel-L2 {rel2:.3e}"
+    want_rel = ((want.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 1.25 * want_rel + 1e-5, (rel, want_rel)          # no further from the fp32 restatement than the two launches are
 
 
 def test_fused_is_deterministic_and_independent_of_the_batch_it_travels_in():
@@ -71,7 +73,8 @@ def test_fused_is_deterministic_and_independent_of_the_batch_it_travels_in():
 
 
 def test_tile_encoder_features_do_not_change_with_the_fused_kernel():
-    """HipViT (ViT-L/14 shapes, reduced depth) with the fused kernel (default) and with AMDS_VIT_QKVATTN=0: the stored features are the same bits."""
+    """HipViT (ViT-L/14 shapes, reduced depth) with the fused kernel (default) and with AMDS_VIT_QKVATTN=0: the stored features agree to a fraction of the
+    1e-3 parity budget (two-pass vs online softmax rounding)."""
     import dataclasses
     from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
     dev = torch.device("cuda:0")
@@ -91,4 +94,5 @@ def test_tile_encoder_features_do_not_change_with_the_fused_kernel():
         else:
             os.environ["AMDS_VIT_QKVATTN"] = old
     assert torch.isfinite(b.float()).all()
-    assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+    rel = ((a.float() - b.float()).norm() / a.float().norm()).item()
+    assert rel < 4e-4, rel
