@@ -137,8 +137,11 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     // (fp32: 24; the GEMM operands: 11).  AMDS_VIT_PLANES=0: fp32 rows + copy (A/B; read at every call).
     const bool planes_env = !(getenv("AMDS_VIT_PLANES") && atoi(getenv("AMDS_VIT_PLANES")) == 0);
     const bool planes = planes_env && fold && !ex && dt == AMDS_F16;
-    // qkv + attention fused (amds_qkv_attention_vit257): the default wherever its shape holds -- T = 257, head_dim 64 -- on the planes path; AMDS_VIT_QKVATTN=0: two launches (A/B)
-    const bool qa_env = !(getenv("AMDS_VIT_QKVATTN") && atoi(getenv("AMDS_VIT_QKVATTN")) == 0);
+    // qkv + attention fused (amds_qkv_attention_vit257; T = 257, head_dim 64, planes path): OPT-IN with AMDS_VIT_QKVATTN=1.  Round 5 built it to keep
+    // 3.2 GB of q | k | v per block off HBM and measured 2 040 us (+ 50 us for the last token's rows) against 2 070 us for the two launches, 0.7 % SLOWER in
+    // situ (profiles/r05_qkv_attn_fused_ab.txt): a 256 x 192 tile's K loop costs what the 256 x 256 GEMM costs with its epilogue, and the attention phase
+    // on one wave per SIMD what the stand-alone kernel costs with its HBM staging.  Kept for the A/B and as the parity-tested form of the idea.
+    const bool qa_env = getenv("AMDS_VIT_QKVATTN") && atoi(getenv("AMDS_VIT_QKVATTN")) == 1;
     const bool fused_qa = qa_env && planes && T == 257 && hd == 64 && D >= 128 && (long)3 * D * D * 2 < (1L << 31);
     // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
     const amds_vit_fp8_block* f8 = w->fp8_host;

@@ -73,8 +73,8 @@ def test_fused_is_deterministic_and_independent_of_the_batch_it_travels_in():
 
 
 def test_tile_encoder_features_do_not_change_with_the_fused_kernel():
-    """HipViT (ViT-L/14 shapes, reduced depth) with the fused kernel (default) and with AMDS_VIT_QKVATTN=0: the stored features agree to a fraction of the
-    1e-3 parity budget (two-pass vs online softmax rounding)."""
+    """HipViT (ViT-L/14 shapes, reduced depth) with the fused kernel (opt-in: AMDS_VIT_QKVATTN=1) and without: the stored features agree to a fraction of
+    the 1e-3 parity budget (two-pass vs online softmax rounding)."""
     import dataclasses
     from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
     dev = torch.device("cuda:0")
