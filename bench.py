@@ -400,6 +400,42 @@ def slide_leg(model, dev, n_tiles: int) -> dict:
     return out
 
 
+def slides_leg(model, dev, sides=(24, 70, 32, 48, 36, 60, 28, 44, 40, 52)) -> dict:
+    """the rank's slide LIST as one pipeline (`stamp_amd.preprocess.extract_slides`): ten synthetic slide objects of 2.3 k - 19.6 k tiles
+    (supertile grids of `sides`^2, mpp 0.5: 4 tiles per supertile; 72 k tiles in all) -> ten feature files, wall clock from the call to the last file on
+    disk; next to it the same slides one `extract_slide` call after the other (each paying its start-up and drain), and a bit-for-bit comparison of
+    the two sets of files."""
+    import tempfile
+
+    from stamp_amd import h5io
+    from stamp_amd.extractor import Extractor, u8_tile_transform
+    from stamp_amd.preprocess import SlideJob, extract_slide, extract_slides
+    ex = Extractor(model=model, transform=u8_tile_transform, identifier="amdstamp-bench")
+    workers = min(32, os.cpu_count() or 8)
+    slides = [SyntheticSlide(s * 1024, s * 1024, seed=20 + i) for i, s in enumerate(sides)]
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        extract_slides([SlideJob(SyntheticSlide(8 * 1024, 8 * 1024, seed=5), td / "warm.h5", 0.5)], ex, max_workers=workers, device=dev)
+        t0 = time.perf_counter()
+        res = extract_slides([SlideJob(sl, td / f"p{i}.h5", 0.5, f"slide{i}") for i, sl in enumerate(slides)], ex, max_workers=workers, device=dev)
+        el = time.perf_counter() - t0
+        kept = sum(r.get("tiles_kept", 0) for r in res)
+        t1 = time.perf_counter()
+        kept1 = 0
+        for i, sl in enumerate(slides):
+            kept1 += extract_slide(sl, ex, td / f"s{i}.h5", slide_mpp=0.5, max_workers=workers, device=dev)["tiles_kept"]
+        el1 = time.perf_counter() - t1
+        same = True
+        for i in range(len(slides)):
+            fa, ca, _ = h5io.read_tile_features(td / f"p{i}.h5")
+            fb, cb, _ = h5io.read_tile_features(td / f"s{i}.h5")
+            same = same and bool(np.array_equal(fa.view(np.uint16), fb.view(np.uint16)) and np.array_equal(ca.coords_um, cb.coords_um))
+    return {"metric": "tiles/s over a LIST of slide objects to their feature files, one pipeline across slides (extract_slides)", "value": round(kept / el, 1),
+            "unit": "tiles/s", "slides": len(slides), "tiles_per_slide": [4 * s * s for s in sides], "tiles_kept": kept, "seconds": round(el, 2),
+            "statuses": sorted({r["status"] for r in res}), "host_wait_for_reader_s": res[0].get("wait_reader_s"),
+            "one_extract_slide_call_per_slide": round(kept1 / el1, 1), "files_identical_to_per_slide_calls": same, "reader_threads": workers}
+
+
 def drop_in_b64_leg(model, cfg, dev, n_batches: int = 48) -> dict:
     """The reference's own loop, literally (preprocessing/__init__.py:315-327): batches of 64 from host memory,
     ``model(tiles.to(device)).detach().half().cpu()``, one synchronous round trip per batch."""
@@ -773,6 +809,11 @@ def main() -> None:
             line["slide_synthetic"]["vs_min_of_reader_and_encoder"] = round(line["slide_synthetic"]["value"] / min(value, line["slide_synthetic"]["reader_only"]), 4)
         except Exception as e:
             line["slide_synthetic"] = {"error": repr(e)[:300]}
+        try:
+            line["slides_synthetic"] = slides_leg(model, ctx.device)
+            line["slides_synthetic"]["vs_hbm_resident"] = round(line["slides_synthetic"]["value"] / value, 4)
+        except Exception as e:
+            line["slides_synthetic"] = {"error": repr(e)[:300]}
     if single and not is_swin and not a.exact and not a.fp8 and cfg.dim % 256 == 0 and cfg.hidden % 256 == 0:
         # the opt-in fp8 variant (BASELINE.json configs[4]: "fp8 MFMA weights") on the same workload: HipViT(fp8=True), csrc/gemm_fp8.hip; its own
         # roofline fraction is against the 5 PFLOP/s dense fp8 peak; what it costs in accuracy is in tests/test_gpu_fp8.py / DESIGN.md section 5

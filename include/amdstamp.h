@@ -603,6 +603,12 @@ int amds_compact_rows_u8(const uint8_t* src, long row_bytes, const float* score,
 /* After the first m rows of an accumulation buffer went to the encoder: rows [m, *count_dev) of src move to the front of dst (at most
  * max_rows of them: the launch geometry) and *count_dev -= m, all in stream order and without the host knowing the fill level. */
 int amds_compact_shift_u8(const uint8_t* src, uint8_t* dst, long row_bytes, int m, int max_rows, int* count_dev, void* stream);
+/* n_words 32-bit words from device memory to HOST-MAPPED (pinned) memory, written by a kernel's stores over the host link -- not by a copy command:
+ * a device-to-host copy that waits for an encoder call sits in the copy queue and holds up the host-to-device copies of the next tiles submitted after it
+ * (stamp_amd/preprocess.py).  zero_src: the source words are cleared behind the copy (event counters read and reset in stream order).  The pipelined
+ * slide loop exports feature rows (fp16 pairs) and the folded LayerNorms' range counters this way; reference: `model(tiles).half().cpu()`,
+ * src/stamp/preprocessing/__init__.py:324-327. */
+int amds_export_words(void* src_dev, void* dst_host_mapped, long n_words, int zero_src, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TICON tile contextualiser in the form the reference's extractor uses it (src/stamp/preprocessing/extractor/ticon.py:691-718

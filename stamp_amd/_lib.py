@@ -193,6 +193,7 @@ PROTOTYPES = {
     "amds_ln_rowstat_diag": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "amds_vit_workspace_diag_offset": (_sz, [_vp, _i]),
     "amds_check_finite": (_i, [_vp, _l, _i, _vp, _vp, _vp]),
+    "amds_export_words": (_i, [_vp, _vp, _l, _i, _vp]),
     "amds_ln_stats_cast": (_i, [_vp, _l, _i, _i, _f, _vp, _l, _vp, _i, _vp]),
     "amds_gemm_lnfold_planes": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp]),
     "amds_ln_stats_split": (_i, [_vp, _l, _i, _i, _f, _vp, _vp, _l, _vp, _vp]),

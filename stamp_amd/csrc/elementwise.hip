@@ -588,3 +588,25 @@ extern "C" int amds_check_finite(const void* x, long n, int dtype, int* count_de
     }
     return AMDS_OK;
 }
+
+// ---- amds_export_words: device words -> host-mapped (pinned) memory by a KERNEL's stores (include/amdstamp.h) ----
+namespace amds {
+__global__ void __launch_bounds__(256) export_words_kernel(unsigned* __restrict__ src, unsigned* __restrict__ dst, long n, int zero_src) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        dst[i] = src[i];
+        if (zero_src) src[i] = 0u;
+    }
+}
+}  // namespace amds
+
+extern "C" int amds_export_words(void* src_dev, void* dst_host_mapped, long n_words, int zero_src, void* stream) {
+    using namespace amds;
+    AMDS_REQUIRE(src_dev && dst_host_mapped && n_words >= 0, "amds_export_words: bad arguments");
+    AMDS_REQUIRE(((uintptr_t)src_dev & 3) == 0 && ((uintptr_t)dst_host_mapped & 3) == 0, "amds_export_words: pointers must be 4-byte aligned");
+    if (n_words == 0) return AMDS_OK;
+    const long g = (n_words + 255) / 256;
+    hipLaunchKernelGGL(export_words_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned*>(src_dev),
+                       reinterpret_cast<unsigned*>(dst_host_mapped), n_words, zero_src);
+    AMDS_LAUNCH_CHECK("export_words_kernel");
+    return AMDS_OK;
+}

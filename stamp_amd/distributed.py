@@ -119,3 +119,47 @@ def max_over_ranks(ctx: DistCtx, value: float) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=ctx.device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def slide_tile_counts(ctx: DistCtx, jobs, *, tile_size_um: float = 256.0, tile_size_px: int = 224, max_supertile_size_slide_px: int = 2 ** 10,
+                      brightness_cutoff: int | None = 240) -> list[int]:
+    """Foreground tile count of every slide of the job list -- the cost LPT sharding balances (SURVEY.md 8e "Partitioning"): the number of supertiles that
+    survive the thumbnail's brightness cut (`tiling.foreground_coords`, reference tiling.py:250-277) x tiles per supertile.  Rank r looks at slides
+    r, r + world, ... (a thumbnail each: host I/O) and ONE control-plane all-reduce of the int64 counts (disjoint supports) makes the list complete on every rank; a slide
+    that cannot be opened counts 0 (it fails again, and is logged, when its owner extracts it)."""
+    from . import tiling
+    counts = torch.zeros(len(jobs), dtype=torch.int64)
+    for i in range(ctx.rank, len(jobs), ctx.world):
+        job = jobs[i]
+        try:
+            slide = job.slide() if isinstance(job.slide, type) or (callable(job.slide) and not hasattr(job.slide, "read_region")) else job.slide
+            geo = tiling.supertile_geometry(job.slide_mpp, tile_size_um, tile_size_px, max_supertile_size_slide_px)
+            dims = tuple(int(v) for v in slide.dimensions)
+            gw, gh = tiling.thumbnail_size(dims, geo.supertile_size_slide_px)
+            n = len(tiling.foreground_coords(dims, slide.get_thumbnail((2 * gw, 2 * gh)), geo.supertile_size_slide_px, brightness_cutoff))
+            counts[i] = n * geo.tiles_per_side ** 2
+            if slide is not job.slide and hasattr(slide, "close"):
+                slide.close()
+        except Exception:
+            counts[i] = 0
+    if ctx.world > 1:
+        counts = counts.to(ctx.device)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)          # disjoint supports: the sum IS the gathered list
+        counts = counts.cpu()
+    return [int(v) for v in counts]
+
+
+def extract_slides_sharded(ctx: DistCtx, jobs, extractor, *, runner=None, tile_counts: list[int] | None = None, **kw):
+    """A node's extraction job (BASELINE.json configs[3]): every rank takes its LPT share of the slide list and runs `preprocess.extract_slides` on it --
+    no data-path collective; slide-level features are gathered afterwards, once, by `gather_slide_embeddings`.  Returns (the global indices this rank
+    owned, its per-slide results in that order).  `runner(jobs, extractor, **kw) -> list[dict]` replaces `extract_slides` (tests on CPU ranks)."""
+    if runner is None:
+        from .preprocess import extract_slides as runner
+    geo_kw = {k: kw[k] for k in ("tile_size_um", "tile_size_px", "max_supertile_size_slide_px", "brightness_cutoff") if k in kw}
+    counts = tile_counts if tile_counts is not None else slide_tile_counts(ctx, jobs, **geo_kw)
+    mine = shard_slides(counts, ctx.world)[ctx.rank]
+    # largest first inside the share as well: the pipeline's tail (the last, partly filled encoder chunk) then belongs to a small slide
+    mine_run = sorted(mine, key=lambda i: (-counts[i], i))
+    res = runner([jobs[i] for i in mine_run], extractor, **kw)
+    by_idx = dict(zip(mine_run, res))
+    return mine, [by_idx[i] for i in mine]

@@ -363,3 +363,420 @@ def extract_slide_serial(slide, extractor: Extractor, output_path, *, slide_mpp:
                              tile_size_um=tile_size_um, tile_size_px=tile_size_px, code_hash=code_hash()[:8], stamp_version=STAMP_FORMAT_VERSION,
                              amdstamp_version=AMDSTAMP_VERSION)
     return stats
+
+
+# ============================================================================================================================================
+# The rank's loop over slides (reference src/stamp/preprocessing/__init__.py:269-286 loop + skip-existing, :328-336 per-slide try / except,
+# :338-367 one .h5 per slide) as ONE pipeline over all of them.
+# ============================================================================================================================================
+import dataclasses as _dc
+import logging as _logging
+from typing import Any, Callable, Iterable
+
+_log = _logging.getLogger("stamp_amd")
+
+
+@_dc.dataclass
+class SlideJob:
+    """One slide of a rank's list.  `slide`: an object with openslide's `dimensions` / `read_region` / `get_thumbnail`, or a zero-argument
+    callable (a function, a functools.partial, a class) that opens one -- called in the reader thread when the slide's turn comes, so opening slide i + 1 (and its thumbnail) happens
+    under slide i's GPU work; an opened object that has `close()` is closed when its last region has been read."""
+    slide: Any
+    output_path: Any
+    slide_mpp: float
+    name: str = ""
+
+
+@_dc.dataclass
+class _Plan:
+    idx: int
+    slide: Any
+    S: int
+    k: int
+    spb: int
+    origins: list
+    coords: np.ndarray          # float64 [n_supertiles * k * k, 2], yield order
+    opened_here: bool
+
+
+@torch.inference_mode()
+def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_um: float = 256.0, tile_size_px: int = 224,
+                   max_supertile_size_slide_px: int = 2 ** 10, brightness_cutoff: int | None = 240, canny_cutoff: float | None = 0.02,
+                   max_workers: int = 8, supertiles_per_batch: int = 64, encode_chunk: int | None = None, device="cuda", skip_existing: bool = True,
+                   on_slide_done: Callable[[int, dict], None] | None = None) -> list[dict]:
+    """Every job's slide -> its feature `.h5`, the files `extract_slide` writes bit for bit, as ONE pipeline: the reader threads, the pinned
+    ring, the device ring, the accumulation buffer and the encoder calls are shared by all slides, so slide i + 1 is opened, thumbnailed and read
+    under slide i's last encoder calls, and an encoder chunk takes the tail of one slide together with the head of the next (a tile's features do
+    not depend on the batch it travels in: tests/test_gpu_vit.py).  `extract_slide` per slide pays its start-up and its drain every time
+    (0.82 of the encoder's rate on 20 k-tile slides, a third of it on 1 k-tile ones).
+
+    Per slide, as the reference: an existing output is skipped (`skip_existing`, :277-283); a slide without foreground tiles writes nothing
+    (:338-340); ANY exception while opening / reading / checking / writing it is logged and the loop goes on (:328-336) -- that includes
+    `FeatureRangeError`: features are checked per slide before they are written (non-finite values; rows with |mean| > 8 sigma through a folded
+    LayerNorm, counted per encoder call), and a slide that fails the check goes through `extract_slide` alone afterwards, which moves the
+    encoder to a safer packing or raises.  Returns one dict per job, in job order: {"status": "written" | "skipped" | "empty" | "failed", ...}."""
+    import queue
+    import threading
+    import time as _time
+
+    from . import _lib, ops
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("extract_slides runs on the GPU only (no CPU fallback)")
+    jobs = list(jobs)
+    results: list[dict] = [{"status": "pending", "name": j.name or str(j.output_path)} for j in jobs]
+    if not jobs:
+        return results
+    model = extractor.model
+    t = int(tile_size_px)
+    row_bytes = t * t * 3
+    chunk = int(encode_chunk or getattr(model, "chunk", 1020))
+    geos = [tiling.supertile_geometry(j.slide_mpp, tile_size_um, tile_size_px, max_supertile_size_slide_px) for j in jobs]
+    spbs = [max(1, min(int(supertiles_per_batch), 4096 // (g.tiles_per_side ** 2))) for g in geos]
+    max_rgba = max(s * g.supertile_size_slide_px ** 2 * 4 for s, g in zip(spbs, geos))          # bytes of one batch of supertiles
+    max_tiles = max(s * g.tiles_per_side ** 2 for s, g in zip(spbs, geos))                        # tiles one batch can yield
+    n_buf = max(2, min(4, (4 << 30) // max_rgba))
+    host = [torch.empty(max_rgba, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
+    host_np = [h.numpy() for h in host]
+    buf_free: "queue.Queue[int]" = queue.Queue()
+    for i in range(n_buf):
+        buf_free.put(i)
+    buf_ev: list = [None] * n_buf
+    ready: "queue.Queue" = queue.Queue(maxsize=n_buf + 4)
+    stop = threading.Event()
+    t_begin = _time.perf_counter()
+
+    def plan_slide(idx: int) -> _Plan | None:
+        job, geo = jobs[idx], geos[idx]
+        slide = job.slide() if isinstance(job.slide, type) or (callable(job.slide) and not hasattr(job.slide, "read_region")) else job.slide
+        S, k = geo.supertile_size_slide_px, geo.tiles_per_side
+        dims = tuple(int(v) for v in slide.dimensions)
+        gw, gh = tiling.thumbnail_size(dims, S)
+        origins = tiling.foreground_coords(dims, slide.get_thumbnail((2 * gw, 2 * gh)), S, brightness_cutoff)
+        og = np.asarray(origins, dtype=np.float64).reshape(-1, 2) * job.slide_mpp
+        off = np.array([(x * tile_size_um, y * tile_size_um) for y in range(k) for x in range(k)], dtype=np.float64)
+        coords = (og[:, None, :] + off[None, :, :]).reshape(-1, 2)
+        return _Plan(idx, slide, S, k, spbs[idx], origins, coords, slide is not job.slide)
+
+    def producer():
+        # one pool of reader threads for the whole list; batches are handed over in order; at most n_buf of them are being decoded at any time
+        try:
+            inflight: list = []
+            with futures.ThreadPoolExecutor(max_workers) as pool:
+                def hand_over():
+                    kind, payload, futs0 = inflight.pop(0)
+                    err = None
+                    for fu in futs0:
+                        try:
+                            fu.result()
+                        except BaseException as e:          # a region that cannot be read fails ITS slide, not the loop
+                            err = err or e
+                    if kind == "batch" and err is not None:
+                        buf_free.put(payload[2])
+                        ready.put(("slide_error", payload[0], err))
+                    else:
+                        ready.put((kind,) + payload)
+                for idx, job in enumerate(jobs):
+                    if stop.is_set():
+                        return
+                    if skip_existing and Path(job.output_path).exists():
+                        inflight.append(("skipped", (idx,), []))
+                        continue
+                    try:
+                        plan = plan_slide(idx)
+                    except BaseException as e:
+                        inflight.append(("slide_error", (idx, e), []))
+                        continue
+                    inflight.append(("slide", (plan,), []))
+                    for bi, i in enumerate(range(0, len(plan.origins), plan.spb)):
+                        if stop.is_set():
+                            return
+                        while len([x for x in inflight if x[0] == "batch"]) >= n_buf:
+                            hand_over()
+                        b = buf_free.get()
+                        if stop.is_set():
+                            return
+                        if buf_ev[b] is not None:
+                            buf_ev[b].synchronize()
+                        batch = plan.origins[i:i + plan.spb]
+                        view = host_np[b][: len(batch) * plan.S * plan.S * 4].reshape(len(batch), plan.S, plan.S, 4)
+
+                        def fill(j, o, view=view, plan=plan):
+                            view[j][...] = _region_array(plan.slide, o[0], o[1], plan.S)
+                        inflight.append(("batch", (idx, bi, b, len(batch)), [pool.submit(fill, j, o) for j, o in enumerate(batch)]))
+                    inflight.append(("slide_read", (idx,), []))
+                while inflight:
+                    hand_over()
+            ready.put(("end",))
+        except BaseException as e:
+            ready.put(("fatal", e))
+
+    with torch.cuda.device(dev):
+        cs = torch.cuda.current_stream()
+        h2d = torch.cuda.Stream()
+        cap = 2 * chunk + max_tiles
+        acc = [torch.empty(cap, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_dev = max(n_buf, min(-(-3 * chunk // max_tiles) + 2, (8 << 30) // max_rgba))
+        d_rgba = [torch.empty(max_rgba, dtype=torch.uint8, device=dev) for _ in range(n_dev)]
+        d_tiles = [torch.empty(max_tiles, t, t, 3, dtype=torch.uint8, device=dev) for _ in range(n_dev)]
+        ws_bytes = max(_lib.lib().amds_supertiles_to_tiles_workspace_bytes(s, g.supertile_size_slide_px, g.tiles_per_side, t) for s, g in zip(spbs, geos))
+        d_ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        d_done: list = [None] * n_dev
+        slot_ring = torch.empty(64, max_tiles, dtype=torch.int32).pin_memory()          # keep decisions of the batches in flight
+        slot_busy = [False] * slot_ring.shape[0]
+        guarded = [m for m in model.modules() if hasattr(m, "defer_check")] if hasattr(model, "modules") else []
+        prev_defer = [m.defer_check for m in guarded]
+        for m in guarded:
+            m.defer_check = True
+            if hasattr(m, "range_diagnostics"):
+                m.range_diagnostics(reset=True)
+        diag_ring = torch.zeros(256, 2, dtype=torch.int32).pin_memory()
+        cs.synchronize()
+
+        # ---- bookkeeping.  Kept tiles form ONE global sequence (slide after slide, supertile order inside a slide); a slide owns rows
+        # [first, first + kept) of it; encoder call c covers rows [enc_lo[c], enc_lo[c] + m) and lands in its own pinned block.
+        st: dict[int, dict] = {}                      # per announced slide
+        order: list[int] = []                         # slides in pipeline order (announced, not finalised)
+        pending: list = []                            # (slot index, rows, event, slide idx, coords slice): decisions not yet on the host
+        kept_known = encoded = unknown = 0
+        calls: list = []                              # (row_lo, m, pinned block, event, diag slot)
+        free_blocks: list = []
+        batch_no = 0
+        writer = futures.ThreadPoolExecutor(1)
+        write_futs: list = []
+        deferred: list[int] = []                      # slides whose features failed the check: through extract_slide afterwards
+
+        def absorb(block: bool) -> None:
+            nonlocal kept_known, unknown
+            while pending and (block or pending[0][2].query()):
+                slot, rows, ev, sidx, cu = pending.pop(0)
+                if block:
+                    ev.synchronize()
+                sl = slot_ring[slot, :rows].numpy()
+                if (sl == -2).any():
+                    raise RuntimeError("extract_slides: accumulation buffer overflow")
+                keep = sl >= 0
+                s = st[sidx]
+                if s["first"] is None:
+                    s["first"] = kept_known
+                s["coords"].append(cu[keep])
+                nk = int(keep.sum())
+                s["kept"] += nk
+                s["decided"] += 1
+                kept_known += nk
+                unknown -= rows
+                slot_busy[slot] = False
+
+        def encode(m: int) -> None:
+            nonlocal cur, encoded
+            f = model(acc[cur][:m]).detach()
+            if f.dtype != torch.float16:
+                f = f.half()
+            f = f.contiguous()
+            blk = free_blocks.pop() if free_blocks and free_blocks[-1].shape[1] == f.shape[1] else torch.empty(chunk, f.shape[1], dtype=torch.float16).pin_memory()
+            # the rows reach the host through a kernel's stores (amds_export_words): no copy command behind the encoder in front of the next H2D copies
+            _lib.check(_lib.lib().amds_export_words(f.data_ptr(), blk.data_ptr(), m * f.shape[1] // 2, 0, cs.cuda_stream), "export_words")
+            dslot = len(calls) % diag_ring.shape[0]
+            has_diag = any(getattr(g, "export_range_counters", None) and g.export_range_counters(diag_ring[dslot]) for g in guarded)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            calls.append((encoded, m, blk, ev, dslot if has_diag else -1, f))
+            other = 1 - cur
+            _lib.check(_lib.lib().amds_compact_shift_u8(acc[cur].data_ptr(), acc[other].data_ptr(), row_bytes, m, cap - m, count.data_ptr(), cs.cuda_stream),
+                       "compact_shift")
+            cur = other
+            encoded += m
+
+        def finalize_ready(block: bool) -> None:
+            """Slides (in order) whose decisions are all known and whose rows have all been encoded AND have arrived: check + write on the writer thread."""
+            while order:
+                sidx = order[0]
+                s = st[sidx]
+                if not s["read_done"] or s["decided"] < s["batches"]:
+                    return
+                lo = s["first"] if s["first"] is not None else kept_known
+                hi = lo + s["kept"]
+                if encoded < hi:
+                    return
+                mine = [c for c in calls if c[0] < hi and c[0] + c[1] > lo]
+                for c in mine:
+                    if not c[3].query():
+                        if not block:
+                            return
+                        c[3].synchronize()
+                order.pop(0)
+                parts = [c[2][max(lo, c[0]) - c[0]: min(hi, c[0] + c[1]) - c[0]] for c in mine]
+                feats = torch.cat(parts) if len(parts) > 1 else (parts[0].clone() if parts else torch.empty(0, 0, dtype=torch.float16))
+                big_mean = sum(int(diag_ring[c[4], 1]) for c in mine if c[4] >= 0)
+                coords = np.concatenate(s["coords"]) if s["coords"] else np.zeros((0, 2))
+                # blocks no unfinalised slide needs any more go back to the pool
+                floor = hi
+                keep_calls = []
+                for c in calls:
+                    if c[0] + c[1] <= floor:
+                        free_blocks.append(c[2])
+                    else:
+                        keep_calls.append(c)
+                calls[:] = keep_calls
+                write_futs.append(writer.submit(_finish_slide, sidx, s, feats, coords, big_mean))
+
+        def _finish_slide(sidx, s, feats, coords, big_mean):
+            job = jobs[sidx]
+            r = results[sidx]
+            r.update(supertiles=s["supertiles"], tiles_seen=s["seen"], tiles_kept=int(feats.shape[0]))
+            try:
+                if s["error"] is not None:
+                    raise s["error"]
+                if feats.shape[0] == 0:
+                    r["status"] = "empty"
+                elif not bool(torch.isfinite(feats).all()) or big_mean:
+                    r["status"] = "recheck"
+                    r["why"] = (f"{int((~torch.isfinite(feats)).any(dim=1).sum())} of {feats.shape[0]} tiles have non-finite features" if not big_mean
+                                else f"{big_mean} rows with |mean| > 8 sigma entered a folded LayerNorm in the encoder calls of this slide")
+                else:
+                    _write(job.output_path, feats, coords, extractor, tile_size_um, tile_size_px)
+                    r["status"] = "written"
+            except BaseException as e:            # the reference logs and goes on (:328-336)
+                r["status"] = "failed"
+                r["error"] = repr(e)
+                _log.exception(f"Failed extracting features from {r['name']}")
+            finally:
+                if s["plan"] is not None and s["plan"].opened_here and hasattr(s["plan"].slide, "close"):
+                    try:
+                        s["plan"].slide.close()
+                    except Exception:
+                        pass
+                    s["plan"].slide = None
+            if on_slide_done is not None:
+                on_slide_done(sidx, r)
+
+        cur = 0
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        wait_reader = 0.0
+        try:
+            done = False
+            while not done:
+                absorb(False)
+                while kept_known - encoded >= chunk:
+                    encode(chunk)
+                finalize_ready(False)
+                if kept_known - encoded + unknown + max_tiles > cap or all(slot_busy):
+                    absorb(True)
+                    continue
+                t_ = _time.perf_counter()
+                try:
+                    item = ready.get(timeout=0.002)
+                except queue.Empty:
+                    wait_reader += _time.perf_counter() - t_
+                    continue
+                wait_reader += _time.perf_counter() - t_
+                kind = item[0]
+                if kind == "end":
+                    done = True
+                elif kind == "fatal":
+                    raise item[1]
+                elif kind == "skipped":
+                    results[item[1]]["status"] = "skipped"
+                    if on_slide_done is not None:
+                        on_slide_done(item[1], results[item[1]])
+                elif kind == "slide":
+                    plan = item[1]
+                    st[plan.idx] = {"plan": plan, "first": None, "kept": 0, "seen": 0, "decided": 0, "batches": 0, "read_done": False, "error": None, "coords": [],
+                                    "supertiles": len(plan.origins)}
+                    order.append(plan.idx)
+                elif kind == "slide_read":
+                    st[item[1]]["read_done"] = True
+                elif kind == "slide_error":
+                    sidx, err = item[1], item[2]
+                    if sidx not in st:
+                        st[sidx] = {"plan": None, "first": None, "kept": 0, "seen": 0, "decided": 0, "batches": 0, "read_done": True, "error": err, "coords": [], "supertiles": 0}
+                        order.append(sidx)
+                    else:
+                        st[sidx]["error"] = st[sidx]["error"] or err
+                elif kind == "batch":
+                    _, sidx, bi, b, nb = item
+                    s = st[sidx]
+                    plan = s["plan"]
+                    kk, S, k = plan.k * plan.k, plan.S, plan.k
+                    if s["error"] is not None:           # the slide already failed: its remaining batches are dropped
+                        buf_free.put(b)
+                        continue
+                    ds = batch_no % n_dev
+                    nbytes = nb * S * S * 4
+                    with torch.cuda.stream(h2d):
+                        if d_done[ds] is not None:
+                            h2d.wait_event(d_done[ds])
+                        rgba = d_rgba[ds][:nbytes].view(nb, S, S, 4)
+                        rgba.copy_(host[b][:nbytes].view(nb, S, S, 4), non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(h2d)
+                        buf_ev[b] = ev
+                        buf_free.put(b)
+                    cs.wait_event(ev)
+                    tiles = tiling.supertiles_to_tiles(rgba, k, t, out=d_tiles[ds], workspace=d_ws)
+                    frac = ops.tile_edge_fraction(tiles, 40, 100) if canny_cutoff is not None else None
+                    slot = slot_busy.index(False)
+                    slot_busy[slot] = True
+                    rows = tiles.shape[0]
+                    _lib.check(_lib.lib().amds_compact_rows_u8(tiles.data_ptr(), row_bytes, None if frac is None else frac.data_ptr(), float(canny_cutoff or 0.0),
+                                                               acc[cur].data_ptr(), cap, count.data_ptr(), slot_ring[slot].data_ptr(), rows, cs.cuda_stream), "compact_rows")
+                    ev2 = torch.cuda.Event()
+                    ev2.record(cs)
+                    d_done[ds] = ev2
+                    pending.append((slot, rows, ev2, sidx, plan.coords[bi * plan.spb * kk: bi * plan.spb * kk + nb * kk]))
+                    s["batches"] += 1
+                    s["seen"] += rows
+                    unknown += rows
+                    batch_no += 1
+            absorb(True)
+            while kept_known - encoded > 0:
+                encode(min(chunk, kept_known - encoded))
+            finalize_ready(True)
+            for sidx in list(order):                    # slides announced but never completed (a reader failure in the middle): their error is reported
+                s = st[sidx]
+                if s["error"] is None:
+                    s["error"] = RuntimeError("slide left incomplete by the pipeline")
+                s["read_done"] = True
+                s["decided"] = s["batches"]
+            finalize_ready(True)
+        finally:
+            for m, d in zip(guarded, prev_defer):
+                m.defer_check = d
+            stop.set()
+            while th.is_alive():
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    pass
+                buf_free.put(0)
+                th.join(timeout=0.05)
+            for fu in write_futs:
+                fu.result()
+            writer.shutdown()
+        cs.synchronize()
+    # slides whose features failed the check: alone through extract_slide, which moves the encoder to a safer packing (and re-runs) or raises
+    for sidx, r in enumerate(results):
+        if r["status"] != "recheck":
+            continue
+        job = jobs[sidx]
+        try:
+            slide = job.slide() if isinstance(job.slide, type) or (callable(job.slide) and not hasattr(job.slide, "read_region")) else job.slide
+            r2 = extract_slide(slide, extractor, job.output_path, slide_mpp=job.slide_mpp, tile_size_um=tile_size_um, tile_size_px=tile_size_px,
+                               max_supertile_size_slide_px=max_supertile_size_slide_px, brightness_cutoff=brightness_cutoff, canny_cutoff=canny_cutoff,
+                               max_workers=max_workers, supertiles_per_batch=supertiles_per_batch, encode_chunk=encode_chunk, device=device)
+            r.update(r2)
+            r["status"] = "written" if Path(job.output_path).exists() else "empty"
+        except BaseException as e:
+            r["status"] = "failed"
+            r["error"] = repr(e)
+            _log.exception(f"Failed extracting features from {r['name']}")
+        if on_slide_done is not None:
+            on_slide_done(sidx, r)
+    total = _time.perf_counter() - t_begin
+    for r in results:
+        r.setdefault("status", "failed")
+    results[0]["pipeline_s"] = round(total, 3)
+    results[0]["wait_reader_s"] = round(wait_reader, 3)
+    return results

@@ -370,6 +370,18 @@ class HipViT(nn.Module):
             d.zero_()
         return {"rows_beyond_fp16_range_possible": int(out[0]), "rows_mean_over_8_sigma": int(out[1])}
 
+    def export_range_counters(self, dst_pinned: torch.Tensor) -> bool:
+        """The two range counters (see `range_diagnostics`) -> two int32 of PINNED host memory, in stream order, by a kernel's stores (no copy command,
+        no synchronisation), and reset: how a caller that keeps many encoder calls in flight (preprocess.extract_slides) learns, later, what each call
+        counted.  False when this object has no counters (LayerNorm not folded, overlapped schedule, safe mode)."""
+        m = self._safe if self._safe is not None else self
+        if m is not self or self._ws is None or not self.ln_fold or getattr(self, "_ws_chunk", None) is None:
+            return False
+        assert dst_pinned.dtype == torch.int32 and dst_pinned.numel() >= 2 and dst_pinned.is_pinned()
+        _lib.check(_lib.lib().amds_export_words(self._diag_view(self._ws_chunk).data_ptr(), dst_pinned.data_ptr(), 2, 1, torch.cuda.current_stream().cuda_stream),
+                   "export_words")
+        return True
+
     def _as_u8_hwc(self, tiles: torch.Tensor) -> torch.Tensor:
         c = self.cfg
         if tiles.dtype == torch.uint8:

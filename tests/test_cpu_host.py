@@ -440,3 +440,90 @@ def test_gelu_polynomial_in_the_kernel_header_is_what_the_fit_script_derives():
     assert float(re.search(r"GELU_XMAX = ([0-9.]+)f", hdr).group(1)) == float(re.search(r"GELU_XMAX = ([0-9.]+)", out).group(1))
     m = re.search(r"x\^2 form.*residue at the clamp ([0-9.e+-]+);.*max error / \|x\| = ([0-9.e+-]+);", out)
     assert float(m.group(1)) < 2.5e-8 and float(m.group(2)) < 1.4e-5
+
+
+_SLIDES_WORKER = r"""
+import os, sys, json
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, os.environ["REPO"])
+from PIL import Image
+from stamp_amd import distributed as D, h5io
+from stamp_amd.preprocess import SlideJob
+ctx = D.init_from_env(prefer_gpu=False)
+out = Path(os.environ["OUT"])
+
+def make_slide(i):                                        # a slide object whose foreground grows with i: thumbnails only (no GPU on this host)
+    w = h = 1024 * (2 + i % 5)
+    class S:
+        dimensions = (w, h)
+        def get_thumbnail(self, size):
+            im = Image.new("RGB", tuple(int(v) for v in size), "#ffffff")
+            px = im.load()
+            for y in range(im.size[1]):
+                for x in range(max(1, im.size[0] * (i % 5 + 1) // 6)):
+                    px[x, y] = (120, 60, 140)
+            return im
+        def read_region(self, *a):
+            raise AssertionError("the stand-in runner does not read regions")
+    return S
+
+jobs = [SlideJob(make_slide(i), out / f"slide{i:02d}.h5", 0.5, f"slide{i:02d}") for i in range(11)]
+jobs[4] = SlideJob(lambda: (_ for _ in ()).throw(OSError("unreadable slide")), out / "slide04.h5", 0.5, "slide04")
+(out / "slide07.h5").write_bytes(b"already there") if ctx.rank == 0 else None
+D.barrier(ctx)
+
+def runner(my_jobs, extractor, **kw):                     # stands in for preprocess.extract_slides on a host without a GPU: same contract
+    res = []
+    for j in my_jobs:
+        r = {"name": j.name}
+        try:
+            if Path(j.output_path).exists():
+                r["status"] = "skipped"
+            else:
+                s = j.slide()
+                n = int(s.dimensions[0]) // 1024
+                feats = torch.full((n, 8), float(int(j.name[-2:])), dtype=torch.float16)
+                h5io.write_tile_features(Path(j.output_path), feats, np.zeros((n, 2), np.float32), extractor="standin", tile_size_um=256.0, tile_size_px=224,
+                                         code_hash="0", stamp_version="2.5.0", amdstamp_version="0")
+                r["status"] = "written"
+        except Exception as e:
+            r["status"] = "failed"; r["error"] = repr(e)
+        res.append(r)
+    return res
+
+counts = D.slide_tile_counts(ctx, jobs, brightness_cutoff=224)
+assert counts[4] == 0 and all(c > 0 for i, c in enumerate(counts) if i != 4), counts
+mine, res = D.extract_slides_sharded(ctx, jobs, None, runner=runner, tile_counts=counts, brightness_cutoff=224)
+shares = D.shard_slides(counts, ctx.world)
+assert mine == shares[ctx.rank] and sorted(sum(shares, [])) == list(range(11))
+loads = [sum(counts[i] for i in sh) for sh in shares]
+assert max(loads) - min(loads) <= max(counts), loads       # LPT: no rank is more than one slide behind
+status = {i: r["status"] for i, r in zip(mine, res)}
+for i in mine:
+    assert status[i] == ("failed" if i == 4 else "skipped" if i == 7 else "written"), (i, status)
+# slide encoder stand-in (mean of the tile features) on the slides this rank wrote, then the ONE data-path collective
+ids = [i for i in mine if status[i] == "written"]
+emb = torch.stack([torch.from_numpy(h5io.read_tile_features(out / f"slide{i:02d}.h5")[0].astype(np.float32)).mean(0) for i in ids]) if ids else torch.zeros(0, 8)
+table = D.gather_slide_embeddings(ctx, emb, torch.tensor(ids, dtype=torch.int64), len(jobs))
+expect = torch.stack([torch.full((8,), float(i)) if i not in (4, 7) else torch.zeros(8) for i in range(11)])
+assert torch.equal(table, expect), table
+D.barrier(ctx)
+print("rank", ctx.rank, "ok")
+"""
+
+
+def test_extract_slides_sharded_gloo_world2(tmp_path):
+    """The node-level job of BASELINE.json configs[3] on two CPU ranks: foreground tile counts by thumbnail (one control-plane all-reduce), LPT shares, every
+    rank runs its share through the `extract_slides` contract (a stand-in runner: no GPU here) with skip-existing and per-slide failures, slide
+    embeddings of the written files, ONE all-gather -- the table is the same on both ranks and complete."""
+    script = tmp_path / "sl.py"
+    script.write_text(_SLIDES_WORKER)
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, REPO=str(ROOT), OUT=str(out), MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o

@@ -277,3 +277,84 @@ def test_extract_slide_never_writes_non_finite_features(gpu, tmp_path):
         extract_slide_serial(slide, ex2, tmp_path / "b.h5", slide_mpp=0.5, brightness_cutoff=250, canny_cutoff=None, supertiles_per_batch=2, device=gpu)
     fb, cb, _ = h5io.read_tile_features(tmp_path / "b.h5")
     assert np.array_equal(fa.view(np.uint16), fb.view(np.uint16)) and np.array_equal(ca.coords_um, cb.coords_um)
+
+
+def _fake_slide(w, h, seed, broken_after=None):
+    """openslide's surface over a synthetic image (tools/make_golden.py::FakeSlide); `broken_after`: read_region fails from that call on."""
+    from PIL import Image
+    rgb = ot.synthetic_slide(w, h, seed)
+    im = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]), "RGBA")
+
+    class Slide:
+        dimensions = (w, h)
+        calls = 0
+        closed = False
+
+        def read_region(self, loc, level, size):
+            type(self).calls += 1
+            if broken_after is not None and type(self).calls > broken_after:
+                raise OSError("cannot read region")
+            out = Image.new("RGBA", size, (0, 0, 0, 0))
+            out.paste(im.crop((loc[0], loc[1], min(loc[0] + size[0], w), min(loc[1] + size[1], h))), (0, 0))
+            return out
+
+        def get_thumbnail(self, size):
+            bg = Image.new("RGB", im.size, "#ffffff")
+            t = Image.composite(im, bg, im)
+            t.thumbnail(tuple(int(v) for v in size), Image.Resampling.LANCZOS)
+            return t
+
+        def close(self):
+            type(self).closed = True
+    return Slide
+
+
+def test_extract_slides_one_pipeline_writes_the_files_of_per_slide_calls(gpu, tmp_path):
+    """`extract_slides`: the rank's loop (reference preprocessing/__init__.py:269-286, 328-367) as one pipeline over all slides -- encoder chunks span
+    slide boundaries, slide i + 1 is read under slide i's encoder calls -- writes, per slide, the file `extract_slide` writes: bit for bit, whatever
+    the chunk / batch geometry and also when the slides differ in resolution; an existing output is skipped; a slide whose regions cannot be read is
+    logged and skipped while its neighbours come out intact; a slide without foreground writes nothing."""
+    from stamp_amd import h5io
+    from stamp_amd.extractor import hip_vit_extractor
+    from stamp_amd.preprocess import SlideJob, extract_slide, extract_slides
+    from stamp_amd.vit import PRESETS, random_vit_state_dict
+
+    cfg = PRESETS["test_tiny"]
+    ex = hip_vit_extractor("test_tiny", random_vit_state_dict(cfg, seed=3), device=gpu, chunk=8, identifier="amdstamp-test")
+    spec = [(2100, 1500, 11, 0.5), (1300, 2600, 12, 0.5), (3000, 1100, 13, 1.0), (900, 900, 14, 0.5), (2048, 2048, 15, 0.5)]
+    classes = [_fake_slide(w, h, seed) for w, h, seed, _ in spec]
+    ref_dir, out_dir = tmp_path / "ref", tmp_path / "out"
+    for canny, chunk, spb in ((None, 7, 3), (0.02, 12, 2), (None, 10_000, 16), (0.02, 5, 64)):
+        for d in (ref_dir, out_dir):
+            if d.exists():
+                for f in d.iterdir():
+                    f.unlink()
+        for i, (cls, (_, _, _, mpp)) in enumerate(zip(classes, spec)):
+            extract_slide(cls(), ex, ref_dir / f"s{i}.h5", slide_mpp=mpp, brightness_cutoff=224, canny_cutoff=canny, device=gpu)
+        broken = _fake_slide(1800, 1800, 21, broken_after=3)
+        blank = type("Blank", (), {"dimensions": (1500, 1500), "read_region": None,
+                                   "get_thumbnail": lambda self, size: __import__("PIL.Image").Image.new("RGB", tuple(int(v) for v in size), "#ffffff")})
+        jobs = [SlideJob(classes[0], out_dir / "s0.h5", spec[0][3], "s0"),            # a callable (the class): opened by the pipeline, closed when read
+                SlideJob(classes[1](), out_dir / "s1.h5", spec[1][3], "s1"),
+                SlideJob(broken(), out_dir / "broken.h5", 0.5, "broken"),
+                SlideJob(classes[2](), out_dir / "s2.h5", spec[2][3], "s2"),
+                SlideJob(blank(), out_dir / "blank.h5", 0.5, "blank"),
+                SlideJob(classes[3](), out_dir / "s3.h5", spec[3][3], "s3"),
+                SlideJob(classes[4](), out_dir / "s4.h5", spec[4][3], "s4")]
+        out_dir.mkdir(exist_ok=True)
+        h5io.write_tile_features(out_dir / "s3.h5", torch.zeros(1, cfg.dim, dtype=torch.float16), np.zeros((1, 2), np.float32), extractor="x", tile_size_um=256.0,
+                                 tile_size_px=224, code_hash="0", stamp_version="2.5.0", amdstamp_version="0")
+        done = []
+        res = extract_slides(jobs, ex, brightness_cutoff=224, canny_cutoff=canny, supertiles_per_batch=spb, encode_chunk=chunk, max_workers=3, device=gpu,
+                             on_slide_done=lambda i, r: done.append(i))
+        assert [r["status"] for r in res] == ["written", "written", "failed", "written", "empty", "skipped", "written"], [(r["status"], r.get("error")) for r in res]
+        assert "cannot read region" in res[2]["error"] and not (out_dir / "broken.h5").exists() and not (out_dir / "blank.h5").exists()
+        assert sorted(done) == list(range(7)) and classes[0].closed
+        for i in (0, 1, 2, 4):
+            fr, cr, ar = h5io.read_tile_features(ref_dir / f"s{i}.h5")
+            fp, cp, ap = h5io.read_tile_features(out_dir / f"s{i}.h5")
+            assert np.array_equal(fp.view(np.uint16), fr.view(np.uint16)) and np.array_equal(cp.coords_um, cr.coords_um), (canny, chunk, spb, i)
+            assert ap["extractor"] == ar["extractor"] and ap["tile_size_px"] == ar["tile_size_px"]
+            assert res[[0, 1, 3, None, 6][i]]["tiles_kept"] == fr.shape[0]
+        f3, _, _ = h5io.read_tile_features(out_dir / "s3.h5")
+        assert f3.shape[0] == 1                                  # the existing file was left alone
