@@ -435,7 +435,7 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
     spbs = [max(1, min(int(supertiles_per_batch), 4096 // (g.tiles_per_side ** 2))) for g in geos]
     max_rgba = max(s * g.supertile_size_slide_px ** 2 * 4 for s, g in zip(spbs, geos))          # bytes of one batch of supertiles
     max_tiles = max(s * g.tiles_per_side ** 2 for s, g in zip(spbs, geos))                        # tiles one batch can yield
-    n_buf = max(2, min(4, (4 << 30) // max_rgba))
+    n_buf = max(2, min(6, (4 << 30) // max_rgba))          # one batch being copied, up to five being decoded
     host = [torch.empty(max_rgba, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
     host_np = [h.numpy() for h in host]
     buf_free: "queue.Queue[int]" = queue.Queue()
@@ -595,7 +595,11 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                 s = st[sidx]
                 if not s["read_done"] or s["decided"] < s["batches"]:
                     return
-                lo = s["first"] if s["first"] is not None else kept_known
+                if s["first"] is None:                 # no batch of it was ever absorbed (no foreground; failed before its first batch): it owns no rows
+                    order.pop(0)
+                    write_futs.append(writer.submit(_finish_slide, sidx, s, torch.empty(0, 0, dtype=torch.float16), np.zeros((0, 2)), 0))
+                    continue
+                lo = s["first"]
                 hi = lo + s["kept"]
                 if encoded < hi:
                     return
