@@ -972,9 +972,24 @@ int amds_gemm_batched(const void* A, long lda, long bsA, const void* W, long ldw
 int amds_wgrad_tn(const void* dy, long ld_dy, const void* x, long ld_x, long tokens, int N, int K, int split_k, int dtype, float* part, void* stream);
 /* dst[c][r] = src[r][c] for 16-bit elements (dst leading dimension ld_dst >= R). */
 int amds_transpose16(const void* src, long ld_src, void* dst, long ld_dst, int R, int C, void* stream);
+/* The 16-bit operand refresh behind an optimiser step, ALL matrices in one launch (the MIL `vit` head kept ~20 amds_cast_pad / amds_transpose16 launches
+ * per step for it): for every entry, dst[r][c] = (dtype) src[r][c] and -- when dst_t is not NULL -- dst_t[c][r] = the same value, rows x cols fp32 -> 16-bit,
+ * both multiples of 64, leading dimensions in elements, 16-byte aligned.  At most 32 entries per call.  Reference step: the optimiser behind
+ * `LitMilClassificationMixin` (src/stamp/modeling/models/__init__.py:239-279); the copies exist because the MFMA GEMMs read 16-bit operands. */
+typedef struct amds_cast_entry {
+    const float* src; long ld_src;
+    void* dst; long ld_dst;
+    void* dst_t; long ld_dst_t;
+    int rows, cols, dtype;          /* AMDS_F16 or AMDS_BF16 */
+} amds_cast_entry;
+int amds_cast_transpose_multi(const amds_cast_entry* entries_host, int n, void* stream);
 /* out[n] (+)= sum_m x[m][n]; deterministic two-stage reduction (bias gradients, split-K partial sums). */
 size_t amds_colsum_workspace_bytes(int M, int N);
 int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* out_i[e] = sum over s < rows of part_i[s * count_i + e], e < count_i, for up to 32 (part, out, count) triples in ONE launch, with the association of
+ * amds_colsum(part_i, count_i, out_i, rows, count_i, AMDS_F32, ...) (same bits): the split-K partials of every weight gradient of a backward pass
+ * (amds_wgrad_tn) summed behind the last of them instead of one reduction launch per matrix.  counts: multiples of 4; pointers 16-byte aligned. */
+int amds_sum_partials_multi(const float* const* parts_host, float* const* outs_host, const long* counts_host, int n, int rows, void* stream);
 /* LayerNorm forward that also stores mean / rstd per row (fp32), and its backward:
  *   dx = (add_skip ? dx : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma (+)= sum dy*xhat; dbeta (+)= sum dy */
 int amds_layernorm_train(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,

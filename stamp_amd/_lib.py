@@ -62,6 +62,11 @@ class VitHostWeights(C.Structure):
 PACK_LNFOLD, PACK_PATCH_SPLIT, PACK_EXACT, PACK_CLS_TAIL = 1, 2, 4, 8
 
 
+class CastEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld_src", C.c_long), ("dst", C.c_void_p), ("ld_dst", C.c_long), ("dst_t", C.c_void_p), ("ld_dst_t", C.c_long),
+                ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int)]
+
+
 class MilVitCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_feats", "dim", "heads", "ff", "classes", "layers", "alibi", "dtype")]
 
@@ -285,8 +290,10 @@ PROTOTYPES = {
     "amds_gemm_batched": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp]),
     "amds_wgrad_tn": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp]),
     "amds_transpose16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
+    "amds_cast_transpose_multi": (_i, [C.POINTER(CastEntry), _i, _vp]),
     "amds_colsum_workspace_bytes": (_sz, [_i, _i]),
     "amds_colsum": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_sum_partials_multi": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_l), _i, _i, _vp]),
     "amds_layernorm_train": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp]),
     "amds_layernorm_train_copy": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp, _l, _i, _vp]),
     "amds_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),

@@ -79,7 +79,7 @@ void plan_saved(const Dims& d, SavedPlan* p) {
 
 struct WsPlan {
     long Mp, Mtp;
-    size_t dx, dh, g16, du, dz, datt, dqkv, tg, ta, part, cs, lnb, dqs, dbsp, dbst, gsc, dcls, dlt, dxp, dzp, total;
+    size_t dx, dh, g16, du, dz, datt, dqkv, tg, ta, part, part_all, cs, lnb, dqs, dbsp, dbst, gsc, dcls, dlt, dxp, dzp, total;
     size_t cs_bytes, lnb_bytes;
 };
 
@@ -104,6 +104,9 @@ void plan_ws(const Dims& d, int split_k, WsPlan* p) {
     p->ta = take((size_t)wa * Mpp * 2);
     const size_t nk = std::max(std::max((size_t)3 * d.Da * d.Dp, (size_t)d.FFp * d.Dp), std::max((size_t)d.Dp * d.Da, (size_t)d.Dp * d.Fp));
     p->part = take(nk * split_k * 4);
+    // one region of split-K partials per weight gradient: they are all summed by ONE launch behind the last of them (amds_sum_partials_multi)
+    const size_t all_w = (size_t)d.Dp * d.Fp + (size_t)d.L * ((size_t)3 * d.Da * d.Dp + (size_t)d.Dp * d.Da + 2 * (size_t)d.FFp * d.Dp);
+    p->part_all = take(all_w * split_k * 4);
     size_t cs = amds_colsum_workspace_bytes(split_k, (int)std::min<size_t>(nk, 0x7fffffff));
     const int widths[] = {d.Dp, d.FFp, 3 * d.Da, d.Ha, d.C};
     for (int w : widths) cs = std::max(cs, amds_colsum_workspace_bytes((int)d.M, w));
@@ -378,7 +381,21 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         return amds_colsum(part, (long)Nn * Kk, out, split_k, Nn * Kk, AMDS_F32, 0, cs, wp.cs_bytes, stream);
     };
 
+    // (TN form: every weight gradient keeps its own region of partials; one launch sums them all at the end -- 9 reduction launches per step -> 1, same bits.
+    //  AMDS_WGRAD_DEFER=0: summed one by one, on the spot)
+    static const bool defer = !(getenv("AMDS_WGRAD_DEFER") && atoi(getenv("AMDS_WGRAD_DEFER")) == 0);
+    const float* def_part[32];
+    float* def_out[32];
+    long def_count[32];
+    int n_def = 0;
+    float* part_next = reinterpret_cast<float*>(wk + wp.part_all);
     auto wgrad_tn = [&](const void* dy, long ld_dy, const void* xx, long ld_x, long tokens, int Nn, int Kk, float* out) -> int {
+        if (defer && n_def < 32 && ((long)Nn * Kk) % 4 == 0 && ((uintptr_t)out & 15) == 0) {
+            RC(amds_wgrad_tn(dy, ld_dy, xx, ld_x, tokens, Nn, Kk, split_k, BF, part_next, stream));
+            def_part[n_def] = part_next; def_out[n_def] = out; def_count[n_def] = (long)Nn * Kk; ++n_def;
+            part_next += (size_t)Nn * Kk * split_k;
+            return AMDS_OK;
+        }
         RC(amds_wgrad_tn(dy, ld_dy, xx, ld_x, tokens, Nn, Kk, split_k, BF, part, stream));
         return amds_colsum(part, (long)Nn * Kk, out, split_k, Nn * Kk, AMDS_F32, 0, cs, wp.cs_bytes, stream);
     };
@@ -506,5 +523,6 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         RC(colsum(dzp, Dp, G->proj_b, Mt, Dp, BF));
     }
     if (dbags) RC(gemm(dzp, Dp, w.proj_wt, Dp, Mt, Fp, Dp, AMDS_EPI_BIAS_F32, dbags, Fp, nullptr, stream));                 // [Mt][Fp] fp32 (padded columns = 0)
+    if (n_def > 0) RC(amds_sum_partials_multi(def_part, def_out, def_count, n_def, split_k, stream));
     return AMDS_OK;
 }

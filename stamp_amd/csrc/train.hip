@@ -318,6 +318,130 @@ extern "C" int amds_transpose16(const void* src, long ld_src, void* dst, long ld
     return AMDS_OK;
 }
 
+// ---- amds_cast_transpose_multi: fp32 masters -> 16-bit operand copies + their transposes, every matrix of a model in ONE launch ----
+namespace amds {
+struct CastTable {
+    amds_cast_entry e[32];
+    int tile0[33];          // first 64 x 64 tile of entry i in the launch's tile sequence
+    int n;
+};
+template <typename TO>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef TO v2 __attribute__((ext_vector_type(2)));
+    v2 p;
+    p[0] = (TO)a;
+    p[1] = (TO)b;
+    return __builtin_bit_cast(uint32_t, p);
+}
+__global__ void __launch_bounds__(256) cast_transpose_multi_kernel(CastTable tb) {
+    __shared__ uint32_t t[64 * 33];
+    int ei = 0;
+    while (ei + 1 < tb.n && (int)blockIdx.x >= tb.tile0[ei + 1]) ++ei;
+    const amds_cast_entry& e = tb.e[ei];
+    const int tl = blockIdx.x - tb.tile0[ei], tc = e.cols / 64;
+    const int r0 = (tl / tc) * 64, c0 = (tl % tc) * 64;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(e.dst);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u, r = i >> 3, ch = i & 7;
+        const float* sp = e.src + (long)(r0 + r) * e.ld_src + c0 + ch * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+        u32x4 v;
+        if (e.dtype == AMDS_F16) v = u32x4{pack2<f16>(a[0], a[1]), pack2<f16>(a[2], a[3]), pack2<f16>(b[0], b[1]), pack2<f16>(b[2], b[3])};
+        else v = u32x4{pack2<bf16>(a[0], a[1]), pack2<bf16>(a[2], a[3]), pack2<bf16>(b[0], b[1]), pack2<bf16>(b[2], b[3])};
+        *reinterpret_cast<u32x4*>(dst + (long)(r0 + r) * e.ld_dst + c0 + ch * 8) = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[r * 33 + ch * 4 + q] = v[q];
+    }
+    if (e.dst_t == nullptr) return;
+    __syncthreads();
+    const uint16_t* th = reinterpret_cast<const uint16_t*>(t);
+    uint16_t* dt = reinterpret_cast<uint16_t*>(e.dst_t);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u, c = i >> 3, rg = i & 7;     // output row c, its elements r = rg*8 .. rg*8+7
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = th[(rg * 8 + 2 * q) * 66 + c], hi = th[(rg * 8 + 2 * q + 1) * 66 + c];
+            o[q] = lo | (hi << 16);
+        }
+        *reinterpret_cast<u32x4*>(dt + (long)(c0 + c) * e.ld_dst_t + r0 + rg * 8) = o;
+    }
+}
+}  // namespace amds
+
+extern "C" int amds_cast_transpose_multi(const amds_cast_entry* entries_host, int n, void* stream) {
+    AMDS_REQUIRE(entries_host && n > 0 && n <= 32, "amds_cast_transpose_multi: 1 .. 32 entries (n=%d)", n);
+    CastTable tb;
+    tb.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const amds_cast_entry& e = entries_host[i];
+        AMDS_REQUIRE(e.src && e.dst && e.rows > 0 && e.cols > 0 && e.rows % 64 == 0 && e.cols % 64 == 0, "amds_cast_transpose_multi: entry %d: rows / cols must be multiples of 64", i);
+        AMDS_REQUIRE(e.ld_src >= e.cols && e.ld_dst >= e.cols && e.ld_src % 4 == 0 && e.ld_dst % 8 == 0 && (e.dst_t == nullptr || (e.ld_dst_t >= e.rows && e.ld_dst_t % 8 == 0)),
+                     "amds_cast_transpose_multi: entry %d: bad leading dimensions", i);
+        AMDS_REQUIRE(((uintptr_t)e.src & 15) == 0 && ((uintptr_t)e.dst & 15) == 0 && ((uintptr_t)e.dst_t & 15) == 0, "amds_cast_transpose_multi: entry %d: pointers must be 16-byte aligned", i);
+        AMDS_REQUIRE(e.dtype == AMDS_F16 || e.dtype == AMDS_BF16, "amds_cast_transpose_multi: entry %d: dtype %d", i, e.dtype);
+        tb.e[i] = e;
+        tb.tile0[i] = tiles;
+        tiles += (e.rows / 64) * (e.cols / 64);
+    }
+    tb.tile0[n] = tiles;
+    hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, tb);
+    AMDS_LAUNCH_CHECK("cast_transpose_multi_kernel");
+    return AMDS_OK;
+}
+
+// ---- amds_sum_partials_multi: out_i[e] = sum over s of part_i[s][e] for EVERY weight gradient of a backward pass in one launch ----
+namespace amds {
+struct SumTable {
+    const float* part[32];
+    float* out[32];
+    long count[32];          // elements of entry i (a multiple of 4)
+    long vec0[33];           // first float4 of entry i in the launch's sequence
+    int n, rows;
+};
+// the association of amds_colsum's one-chunk path (16 row lanes, each adding its rows r, r + 16, r + 32, ... in order; the lanes added in order): the same bits
+__global__ void __launch_bounds__(256) sum_partials_multi_kernel(SumTable tb) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= tb.vec0[tb.n]) return;
+    int ei = 0;
+    while (ei + 1 < tb.n && v >= tb.vec0[ei + 1]) ++ei;
+    const long e = (v - tb.vec0[ei]) * 4;
+    const float* p = tb.part[ei] + e;
+    const long ld = tb.count[ei];
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 16 && k < tb.rows; ++k) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = k; r < tb.rows; r += 16) a += *reinterpret_cast<const f32x4*>(p + (long)r * ld);
+        s += a;
+    }
+    *reinterpret_cast<f32x4*>(tb.out[ei] + e) = s;
+}
+}  // namespace amds
+
+extern "C" int amds_sum_partials_multi(const float* const* parts_host, float* const* outs_host, const long* counts_host, int n, int rows, void* stream) {
+    AMDS_REQUIRE(parts_host && outs_host && counts_host && n > 0 && n <= 32 && rows > 0 && rows <= 2048, "amds_sum_partials_multi: 1 .. 32 entries of 1 .. 2048 partial rows (n=%d rows=%d)", n, rows);
+    SumTable tb;
+    tb.n = n;
+    tb.rows = rows;
+    long vecs = 0;
+    for (int i = 0; i < n; ++i) {
+        AMDS_REQUIRE(parts_host[i] && outs_host[i] && counts_host[i] > 0 && counts_host[i] % 4 == 0, "amds_sum_partials_multi: entry %d: count must be a positive multiple of 4", i);
+        AMDS_REQUIRE(((uintptr_t)parts_host[i] & 15) == 0 && ((uintptr_t)outs_host[i] & 15) == 0, "amds_sum_partials_multi: entry %d: pointers must be 16-byte aligned", i);
+        tb.part[i] = parts_host[i];
+        tb.out[i] = outs_host[i];
+        tb.count[i] = counts_host[i];
+        tb.vec0[i] = vecs;
+        vecs += counts_host[i] / 4;
+    }
+    tb.vec0[n] = vecs;
+    hipLaunchKernelGGL(sum_partials_multi_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tb);
+    AMDS_LAUNCH_CHECK("sum_partials_multi_kernel");
+    return AMDS_OK;
+}
+
 extern "C" size_t amds_colsum_workspace_bytes(int M, int N) { return (size_t)cdiv(M, CS_ROWS) * N * 4; }
 extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     AMDS_REQUIRE(x && out && ws, "amds_colsum: null pointer");
@@ -333,6 +457,8 @@ extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int
     const dim3 grid(cdiv(N, 64), nchunk);
     const int esz = in_dtype == AMDS_F32 ? 4 : 2;
     const int vec_ok = (ld % 4 == 0) && (((uintptr_t)x % (4 * esz)) == 0);      // 4-element vector loads need aligned rows
+    // (Round 5 tried the second stage inside the first launch -- the block that arrives last for its 64 columns adds the chunk partials: the
+    //  agent-scope fence that makes the partials of the other XCDs' L2s visible costs ~100 us per launch on this 8-XCD part, 6x the launch it saves.)
     if (in_dtype == AMDS_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, ld, part, M, N, vec_ok, cs_rows);
     else if (in_dtype == AMDS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, ld, part, M, N, vec_ok, cs_rows);
     else if (in_dtype == AMDS_F16) hipLaunchKernelGGL((colsum_partial_kernel<f16>), grid, dim3(256), 0, st, (const f16*)x, ld, part, M, N, vec_ok, cs_rows);

@@ -207,18 +207,41 @@ class PackedVit:
         # C structs built over them stay valid (they are rebuilt only when a master tensor moved: padded / stacked ones are fresh torch tensors)
         old_w, old_wt = getattr(self, "w", None), getattr(self, "wt", None)
         prev = lambda dct, *keys: (dct[keys[0]] if len(keys) == 1 else dct["layers"][keys[0]][keys[1]]) if dct is not None and len(dct.get("layers", ())) == d.L else None  # noqa: E731
-        cast = lambda w, dt, out: ops.cast_pad(w, w.shape[1], dt or self.act, out=out)  # noqa: E731
-        tr = lambda w, out: T.transpose16(w, out=out) if out is not None and out.shape == (w.shape[1], w.shape[0]) else T.transpose16(w)  # noqa: E731
-        new_w: dict = {"proj_w": cast(m["proj_w"], None, prev(old_w, "proj_w")), "layers": []}
+        # ONE launch for all of it (amds_cast_transpose_multi: cast + transposed copy per matrix, 9 matrices for the default head; the per-matrix
+        # amds_cast_pad / amds_transpose16 pairs were ~20 launches of every training step); a matrix whose padded shape is not a multiple of 64 keeps them
+        batch: list = []
+
+        def cast(w, dt, out, out_t, want_t):
+            dt = dt or self.act
+            w = w.contiguous().float()
+            R, Cc = w.shape
+            dst = out if out is not None and out.shape == (R, Cc) and out.dtype == dt and out.is_contiguous() else torch.empty(R, Cc, dtype=dt, device=w.device)
+            dst_t = None
+            if want_t:
+                dst_t = out_t if out_t is not None and out_t.shape == (Cc, R) and out_t.dtype == dt and out_t.is_contiguous() else torch.empty(Cc, R, dtype=dt, device=w.device)
+            if R % 64 == 0 and Cc % 64 == 0:
+                batch.append((w, dst, dst_t))
+            else:
+                ops.cast_pad(w, Cc, dt, out=dst)
+                if want_t:
+                    T.transpose16(dst, out=dst_t)
+            return dst, dst_t
+
+        new_w: dict = {"layers": []}
         new_wt: dict = {"layers": []}
+        new_w["proj_w"], pt = cast(m["proj_w"], None, prev(old_w, "proj_w"), prev(old_wt, "proj_w") if old_wt and "proj_w" in old_wt else None, self.train)
         if self.train:
-            new_wt["proj_w"] = tr(new_w["proj_w"], prev(old_wt, "proj_w") if old_wt and "proj_w" in old_wt else None)
+            new_wt["proj_w"] = pt
         for l, Lm in enumerate(m["layers"]):
             # ALiBi: the attention output is bf16 (range, see amds_attention_alibi), so its output projection runs on bf16 operands
-            Lw = {k: cast(Lm[k], BF if (d.alibi and k == "out_w") else None, prev(old_w, l, k)) for k in ("in_w", "out_w", "fc1_w", "fc2_w")}
+            Lw, Lt = {}, {}
+            for k in ("in_w", "out_w", "fc1_w", "fc2_w"):
+                Lw[k], Lt[k] = cast(Lm[k], BF if (d.alibi and k == "out_w") else None, prev(old_w, l, k), prev(old_wt, l, k) if self.train else None, self.train)
             new_w["layers"].append(Lw)
             if self.train:
-                new_wt["layers"].append({k: tr(v, prev(old_wt, l, k)) for k, v in Lw.items()})
+                new_wt["layers"].append(Lt)
+        if batch:
+            T.cast_transpose_multi(batch)
         self.w, self.wt = new_w, new_wt
         self._c = None
 

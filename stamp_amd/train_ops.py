@@ -19,6 +19,22 @@ def transpose16(src: torch.Tensor, ld_dst: int | None = None, out: torch.Tensor 
     return out
 
 
+def cast_transpose_multi(entries: list) -> None:
+    """entries: (src fp32 [R, C], dst 16-bit [R, >= C], dst_t 16-bit [C, >= R] or None): every 16-bit operand copy (and transposed copy) of a model's
+    weight matrices refreshed from the fp32 masters in ONE launch per 32 matrices (`amds_cast_transpose_multi`); R, C multiples of 64."""
+    import ctypes as C
+    for i in range(0, len(entries), 32):
+        chunk = entries[i:i + 32]
+        arr = (_lib.CastEntry * len(chunk))()
+        for j, (src, dst, dst_t) in enumerate(chunk):
+            _dev(src, dst, dst_t)
+            assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and dst.shape[0] == src.shape[0] and dst.stride(1) == 1
+            assert dst_t is None or (dst_t.dtype == dst.dtype and dst_t.shape[0] == src.shape[1] and dst_t.stride(1) == 1)
+            arr[j] = _lib.CastEntry(_p(src), src.stride(0), _p(dst), dst.stride(0), _p(dst_t), dst_t.stride(0) if dst_t is not None else 0, src.shape[0], src.shape[1],
+                                    act_code(dst.dtype))
+        _lib.check(_lib.lib().amds_cast_transpose_multi(arr, len(chunk), _stream()), "cast_transpose_multi")
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
     _dev(x)
     assert x.dim() == 2 and x.stride(1) == 1
