@@ -255,6 +255,11 @@ int amds_qkv_attention_vit257(const void* x, const void* w_qkv, const float* bia
 /* Gathers row `row` of every group of T rows: src16 [B*T][D] 16-bit -> dst16 [B][D]; stat [B*T][2] fp32 -> dst_stat [B][2] (stat may be NULL).
  * The rows of a tile's last token for the GEMM in front of amds_qkv_attention_vit257. */
 int amds_gather_token_rows16(const void* src16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, void* stream);
+/* The same gather with the LayerNorm applied on the way (normalize != 0): dst16[b] = round16((src16 + lo16)[b*T + row] * stat[..][0] + stat[..][1]) -- the
+ * normalised row (gamma / beta live in the folded weights), from both planes of a two-plane residual stream when lo16 is given -- so that a PLAIN
+ * GEMM on 128-row tiles can compute the q | k | v rows of the 1020 last tokens (48 workgroups of the 256-row kernel took 35 us for it). */
+int amds_gather_token_rows16_ex(const void* src16, const void* lo16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, int dtype,
+                                int normalize, void* stream);
 
 /* Same contract for ANY T (K/V streamed through LDS in 64-key tiles, online softmax; the T x T matrix is never
  * materialised).  Used by the MIL heads: bags of 1024 tiles in training, whole slides (tens of thousands of

@@ -213,6 +213,7 @@ PROTOTYPES = {
     "amds_attention_vit_hd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_qkv_attention_vit257": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_gather_token_rows16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_gather_token_rows16_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_attention_alibi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_vit_workspace_bytes": (_sz, [C.POINTER(VitCfg), _i]),
     "amds_vit_forward": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),

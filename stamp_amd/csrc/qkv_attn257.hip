@@ -288,6 +288,7 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
                 asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(acc[i][j][2]));
                 asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(acc[i][j][3]));
                 v = v * rs1[0] + (cs[j] * rs1[1] + cb[j]);
+                if (j < 2) v *= sc;                 // q leaves pre-scaled by log2(e) / sqrt(64): the score products ARE the exp2 arguments (up to the row maximum)
                 *reinterpret_cast<vec4*>(smem + (j < 2 ? QA_QIMG : QA_KIMG) + ho_qk[j & 1] + i * 2048) = Act<T>::from_f32x4(v);
             }
             const f32x4 ra = *reinterpret_cast<const f32x4*>(smem + ho_rs4 + i * 128), rb = *reinterpret_cast<const f32x4*>(smem + ho_rs4 + i * 128 + 16);
@@ -401,9 +402,10 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
                 }
                 dot += __shfl_xor(dot, 32, 64);
                 mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 32, 64));
-                const float st = dot * sc;
-                mrow[r] = fmaxf(mx[r] * sc, st);
-                pt[r] = __builtin_amdgcn_exp2f(st - mrow[r]);
+                // (softmax is invariant under the shift: ANY common value near the maximum does; this one is representable in the operand type because it
+                //  enters pass 2 through the matrix pipe, as a fifth k-step (-shift) x 1 of every score product)
+                mrow[r] = Act<T>::to_f32(Act<T>::from_f32(fmaxf(mx[r], dot)));
+                pt[r] = __builtin_amdgcn_exp2f(dot - mrow[r]);
             }
         }
         QA_MARK(7);
@@ -418,32 +420,46 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
             vec8 ones;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ones[e] = Act<T>::from_f32(1.0f);
+            // the shift as a fifth k-step of every score product: K side = 1 in k-slot 0, Q side = -shift of the lane's query in k-slot 0, zeros elsewhere
+            vec8 kaug, qaug[NB];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kaug[e] = Act<T>::from_f32(e == 0 && hi == 0 ? 1.0f : 0.0f);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) qaug[r][e] = Act<T>::from_f32(e == 0 && hi == 0 ? -mrow[r] : 0.0f);
+            }
             auto stage = [&](auto has_pv_c, auto has_qk_c, int t, f32x16 (&scur)[NB], f32x16 (&snext)[NB], vec8 (&pout)[NB][2], const vec8 (&pprev)[NB][2]) {
                 constexpr bool HP = decltype(has_pv_c)::value, HQ = decltype(has_qk_c)::value;
                 vec8 opnd[4];
-                auto ld = [&](int j) {                                   // operand j of this stage: 0-3 = K rows of tile t + 1 (ks = j), 4-7 = V^T rows of tile t - 1
-                    if (j < 0 || j >= 8) return;
-                    if (j < 4) { if (HQ) opnd[j & 3] = k_frag(t + 1, j); }
-                    else if (HP) opnd[j & 3] = v_frag(t - 1, (j - 4) >> 1, (j - 4) & 1);
+                auto ld = [&](int q) {                                   // LDS operand q of this stage: 0-3 = K rows of tile t + 1 (ks = q), 4-7 = V^T rows of tile t - 1
+                    if (q < 0 || q >= 8) return;
+                    if (q < 4) { if (HQ) opnd[q & 3] = k_frag(t + 1, q); }
+                    else if (HP) opnd[q & 3] = v_frag(t - 1, (q - 4) >> 1, (q - 4) & 1);
                 };
-                auto mf = [&](int i) {                                   // MFMA i < 16: operand i >> 1, block i & 1; 16-19: row sums of P (ks = (i - 16) >> 1)
-                    const int j = i >> 1, r = i & 1;
-                    if (i >= 16) { if (HP) lsum[r] = Act<T>::mfma32(ones, pprev[r][j - 8], lsum[r]); }
-                    else if (j < 4) {
-                        if (HQ) { if (j == 0) Act<T>::mfma32_vgpr_zero(snext[r], opnd[j & 3], qf[r][j]); else Act<T>::mfma32_vgpr_acc(snext[r], opnd[j & 3], qf[r][j]); }
-                    } else if (HP) o[r][(j - 4) & 1] = Act<T>::mfma32(opnd[j & 3], pprev[r][(j - 4) >> 1], o[r][(j - 4) & 1]);
+                auto mf = [&](int i) {                                   // MFMAs 0-9: scores (k-steps 0-3 + the shift), 10-17: P V, 18-21: row sums of P; block i & 1
+                    const int r = i & 1;
+                    if (i < 10) {
+                        const int j = i >> 1;
+                        if (!HQ) return;
+                        if (j == 0) Act<T>::mfma32_vgpr_zero(snext[r], opnd[0], qf[r][0]);
+                        else if (j < 4) Act<T>::mfma32_vgpr_acc(snext[r], opnd[j & 3], qf[r][j]);
+                        else Act<T>::mfma32_vgpr_acc(snext[r], kaug, qaug[r]);
+                    } else if (i < 18) {
+                        const int q = (i - 10) >> 1;
+                        if (HP) o[r][q & 1] = Act<T>::mfma32(opnd[q & 3], pprev[r][q >> 1], o[r][q & 1]);
+                    } else if (HP) lsum[r] = Act<T>::mfma32(ones, pprev[r][(i - 18) >> 1], lsum[r]);
                 };
                 ld(0);
                 ld(1);
 #pragma unroll
-                for (int sl = 0; sl < 20; ++sl) {
-                    if ((sl & 1) == 0) ld((sl >> 1) + 2);
+                for (int sl = 0; sl < 22; ++sl) {
+                    if ((sl & 1) == 0 && sl <= 10) ld((sl >> 1) + 2);
                     mf(sl);
-                    if (sl >= 2 && sl < 18) {                             // two weights per slice, rounded to the operand type at once
+                    if (sl >= 2 && sl < 18) {                             // two weights per slice, rounded to the operand type at once: the score IS the exp2 argument
 #pragma unroll
                         for (int f = 2 * (sl - 2); f < 2 * (sl - 2) + 2; ++f) {
                             const int r = f >> 4, e = f & 15;
-                            pout[r][e >> 3][e & 7] = Act<T>::from_f32(__builtin_amdgcn_exp2f(fmaf(scur[r][e], sc, -mrow[r])));
+                            pout[r][e >> 3][e & 7] = Act<T>::from_f32(__builtin_amdgcn_exp2f(scur[r][e]));
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -461,6 +477,8 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
                     if (ks == 0) Act<T>::mfma32_vgpr_zero(sA[r], kf, qf[r][ks]); else Act<T>::mfma32_vgpr_acc(sA[r], kf, qf[r][ks]);
                 }
             }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) Act<T>::mfma32_vgpr_acc(sA[r], kaug, qaug[r]);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // stage 0 reads sA with nothing in between: let the chain finish (72 wait states)
             stage(N_{}, Y{}, 0, sA, sB, pA, pB);
@@ -527,13 +545,26 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
             const char* sQh = reinterpret_cast<const char*>(sT + 192);
             const char* qsrc = l31 == 0 ? sQh + hi * 16 : sZero;
             const int qstep = l31 == 0 ? 32 : 0;
-            f32x16 s1[NB];
+            // every LDS operand of this section is requested up front (a lone wave pays each round trip in full): the query's four fragments, the K rows of both
+            // blocks, and the V^T rows the P V products will need once the weights exist
+            vec8 qa[4], kfo[NB][4], vfo[NB][2][2];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const vec8 qa = *reinterpret_cast<const vec8*>(qsrc + ks * qstep);
+                qa[ks] = *reinterpret_cast<const vec8*>(qsrc + ks * qstep);
 #pragma unroll
-                for (int r = 0; r < NB; ++r) s1[r] = Act<T>::mfma32(qa, k_frag(2 * wave + r, ks), ks == 0 ? zero16 : s1[r]);
+                for (int r = 0; r < NB; ++r) kfo[r][ks] = k_frag(2 * wave + r, ks);
             }
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) vfo[r][ks][dt] = v_frag(2 * wave + r, ks, dt);
+            f32x16 s1[NB];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < NB; ++r) s1[r] = Act<T>::mfma32(qa[ks], kfo[r][ks], ks == 0 ? zero16 : s1[r]);
             float mw[NB], lw[NB];
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
@@ -552,7 +583,7 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
                     const char* psrc = l31 == 0 ? sPw + (2 * wave + r) * 64 + hi * 16 : sZero;
                     const vec8 pf = *reinterpret_cast<const vec8*>(psrc + ks * qstep);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) oq[r][dt] = Act<T>::mfma32(v_frag(2 * wave + r, ks, dt), pf, ks == 0 ? zero16 : oq[r][dt]);
+                    for (int dt = 0; dt < 2; ++dt) oq[r][dt] = Act<T>::mfma32(vfo[r][ks][dt], pf, ks == 0 ? zero16 : oq[r][dt]);
                 }
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
@@ -598,14 +629,25 @@ qkv_attn257_kernel(const T* __restrict__ X, const T* __restrict__ W, const float
 #undef QA_BARRIER
 }
 
-// row `row` of every tile: 16-bit [B*T][D] -> [B][D], and its (rstd, -mean rstd) pair
-__global__ void gather_token_rows16_kernel(const uint16_t* __restrict__ src, const float* __restrict__ stat, uint16_t* __restrict__ dst, float* __restrict__ dstat,
-                                           int T, int D, int row) {
-    const long r = (long)blockIdx.x * T + row;
-    const u32x4* s = reinterpret_cast<const u32x4*>(src + r * D);
-    u32x4* d = reinterpret_cast<u32x4*>(dst + (long)blockIdx.x * D);
-    for (int i = threadIdx.x; i < D / 8; i += blockDim.x) d[i] = s[i];
-    if (stat && threadIdx.x < 2) dstat[2 * blockIdx.x + threadIdx.x] = stat[2 * r + threadIdx.x];
+// row `row` of every tile: 16-bit [B*T][D] -> [B][D], and its (rstd, -mean rstd) pair; with `lo` (the second plane of a two-plane residual stream) and
+// `normalize`, the gathered row leaves as the LayerNorm's normalised value (hi + lo) * rstd - mean * rstd, rounded once -- gamma and beta live in the
+// folded weights -- so that a PLAIN GEMM (any kernel family) can follow
+template <typename T>
+__global__ void gather_token_rows16_kernel(const T* __restrict__ src, const T* __restrict__ lo, const float* __restrict__ stat, T* __restrict__ dst,
+                                           float* __restrict__ dstat, int Tt, int D, int row, int normalize) {
+    const long r = (long)blockIdx.x * Tt + row;
+    if (!normalize) {
+        const u32x4* s = reinterpret_cast<const u32x4*>(src + r * D);
+        u32x4* d = reinterpret_cast<u32x4*>(dst + (long)blockIdx.x * D);
+        for (int i = threadIdx.x; i < D / 8; i += blockDim.x) d[i] = s[i];
+        if (stat && threadIdx.x < 2) dstat[2 * blockIdx.x + threadIdx.x] = stat[2 * r + threadIdx.x];
+        return;
+    }
+    const float a = stat[2 * r], b = stat[2 * r + 1];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float x = Act<T>::to_f32(src[r * D + i]) + (lo ? Act<T>::to_f32(lo[r * D + i]) : 0.f);
+        dst[(long)blockIdx.x * D + i] = Act<T>::from_f32(fmaf(x, a, b));
+    }
 }
 
 static int g_qa_cus = 0;
@@ -659,10 +701,18 @@ extern "C" int amds_qkv_attention_vit257(const void* x, const void* w_qkv, const
 }
 
 extern "C" int amds_gather_token_rows16(const void* src16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, void* stream) {
-    AMDS_REQUIRE(src16 && dst16 && (stat == nullptr || dst_stat), "amds_gather_token_rows16: null pointer");
+    return amds_gather_token_rows16_ex(src16, nullptr, stat, dst16, dst_stat, B, T, D, row, AMDS_F16, 0, stream);
+}
+
+extern "C" int amds_gather_token_rows16_ex(const void* src16, const void* lo16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, int dtype,
+                                           int normalize, void* stream) {
+    AMDS_REQUIRE(src16 && dst16 && (normalize ? stat != nullptr : (stat == nullptr || dst_stat)), "amds_gather_token_rows16: null pointer");
     AMDS_REQUIRE(B > 0 && T > 0 && row >= 0 && row < T && D > 0 && D % 8 == 0, "amds_gather_token_rows16: bad shape B=%d T=%d D=%d row=%d", B, T, D, row);
     AMDS_REQUIRE(((uintptr_t)src16 & 15) == 0 && ((uintptr_t)dst16 & 15) == 0, "amds_gather_token_rows16: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(gather_token_rows16_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)src16, stat, (uint16_t*)dst16, dst_stat, T, D, row);
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_gather_token_rows16: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AMDS_F16) hipLaunchKernelGGL(gather_token_rows16_kernel<f16>, dim3(B), dim3(128), 0, st, (const f16*)src16, (const f16*)lo16, stat, (f16*)dst16, dst_stat, T, D, row, normalize);
+    else hipLaunchKernelGGL(gather_token_rows16_kernel<bf16>, dim3(B), dim3(128), 0, st, (const bf16*)src16, (const bf16*)lo16, stat, (bf16*)dst16, dst_stat, T, D, row, normalize);
     AMDS_LAUNCH_CHECK("gather_token_rows16_kernel");
     return AMDS_OK;
 }

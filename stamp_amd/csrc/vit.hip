@@ -287,10 +287,11 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 if (fused_qa) {
                     // qkv + attention as one kernel (qkv_attn257.hip): q | k | v of a tile's first 256 tokens stay on the chip; the q | k | v row of its
                     // last token comes from the ordinary GEMM on the gathered rows (hcq / qcq: the class-stream buffers, idle before the last block)
-                    float* rst = qcq;
-                    AMDS_TRY(amds_gather_token_rows16(hq, rs, hcq, rst, q.nt, T, D, T - 1, s));
-                    AMDS_TRY(amds_gemm_lnfold(hcq, D, b.qkv_w, D, q.nt, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq + (size_t)(T - 1) * 3 * D * 2, (long)T * 3 * D, b.qkv_b,
-                                              nullptr, nullptr, nullptr, rst, b.qkv_colsum, s));
+                    // (the gathered rows leave normalised -- (hi + lo) rstd - mean rstd, gamma / beta are in the folded weights -- and go through the 128 x 128
+                    //  GEMM family, always: 192 workgroups instead of 48 of the 256-row kernel, and a tile's features do not depend on the batch it travels in)
+                    AMDS_TRY(amds_gather_token_rows16_ex(hq, loq, rs, hcq, nullptr, q.nt, T, D, T - 1, dt, 1, s));
+                    AMDS_TRY(amds_gemm_ex(0, hcq, D, b.qkv_w, D, q.nt, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq + (size_t)(T - 1) * 3 * D * 2, (long)T * 3 * D, b.qkv_b, nullptr,
+                                          nullptr, 0, 0, 0, 1.0f, s));
                     AMDS_TRY(amds_qkv_attention_vit257(hq, b.qkv_w, b.qkv_b, b.qkv_colsum, rs, qkvq, h2q, q.nt, c->heads, D, dt, s));
                 } else {
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.qkv_w, D, n, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rs,

@@ -1,6 +1,7 @@
 """amds_qkv_attention_vit257 (csrc/qkv_attn257.hip): the qkv Linear and the attention of a ViT block as one kernel, against the two launches it replaces
-(amds_gemm_lnfold / amds_gemm + amds_attention_vit) -- q | k | v are the same bits (same operand rounding, same K order); the softmax is taken in two
-passes instead of online, so the outputs agree to rounding, not bit for bit -- and against a plain fp32 torch restatement of timm's Attention.forward (what the reference runs inside `model(tiles)`, src/stamp/preprocessing/__init__.py:324-325)."""
+(amds_gemm_lnfold / amds_gemm + amds_attention_vit) -- k | v are the same bits (same operand rounding, same K order), q is rounded after the softmax
+scale instead of before it, and the softmax is taken in two passes instead of online, so the outputs agree to rounding, not bit for bit -- and against a
+plain fp32 torch restatement of timm's Attention.forward (what the reference runs inside `model(tiles)`, src/stamp/preprocessing/__init__.py:324-325)."""
 import os
 
 import pytest
@@ -27,11 +28,13 @@ def _case(B, H, dtype, seed, fold=True):
 
 
 def _torch_ref(x, w, bias, rowstat, colsum, B, H):
+    """fp32 throughout (the operands as given; NO rounding of q | k | v: the fused kernel rounds q * scale where the two launches round q -- two
+    equally valid 16-bit roundings, and a reference that applied one of them would favour that path)."""
     D = H * 64
     xf, wf = x.float(), w.float()
     if rowstat is not None:
         xf = xf * rowstat[:, :1] + rowstat[:, 1:]               # (x - mean) rstd: gamma / beta live in w / bias
-    qkv = (xf @ wf.t() + bias).to(x.dtype).float().view(B, 257, 3, H, 64).permute(2, 0, 3, 1, 4)
+    qkv = (xf @ wf.t() + bias).view(B, 257, 3, H, 64).permute(2, 0, 3, 1, 4)
     a = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) / 8.0, -1) @ qkv[2]
     return a.permute(0, 2, 1, 3).reshape(B * 257, D)
 
@@ -54,7 +57,7 @@ def test_fused_equals_the_two_launches_it_replaces(B, H, dtype, fold):
     rel = ((got.float().cpu() - ref).norm() / ref.norm()).item()
     assert rel < (2e-3 if dtype == torch.float16 else 1.5e-2), rel
     rel2 = ((got.float() - want.float()).norm() / want.float().norm()).item()
-    assert rel2 < (6e-4 if dtype == torch.float16 else 5e-3), f"fused vs gemm + attention: rel-L2 {rel2:.3e}"
+    assert rel2 < (1e-3 if dtype == torch.float16 else 8e-3), f"fused vs gemm + attention: rel-L2 {rel2:.3e}"
     want_rel = ((want.float().cpu() - ref).norm() / ref.norm()).item()
     assert rel < 1.25 * want_rel + 1e-5, (rel, want_rel)          # no further from the fp32 restatement than the two launches are
 
