@@ -1,6 +1,6 @@
 # Evidence of a round, one gpurun call:  gpurun --timeout 3000 -- 'bash tools/prof_round.sh r04'
 # Writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
