@@ -52,6 +52,18 @@ def hip_dinobloom_extractor(state_dict: dict[str, torch.Tensor], *, identifier: 
     return Extractor(model=HipViT(PRESETS["dinobloom_s"], state_dict, device=device, chunk=chunk), transform=u8_tile_transform, identifier=identifier)
 
 
+def _cls_rows_f32(vit, tiles: torch.Tensor) -> torch.Tensor:
+    """fp32 class rows [B, dim] of the final-norm'd token tensor.  The token tensor is asked for one encoder chunk at a time: [chunk, T, dim] fp32 is
+    ~1 GB at 1020 tiles of a ViT-L, [B, T, dim] for a whole slide's tiles would not fit."""
+    step = max(1, int(vit.chunk))
+    rows = []
+    for i in range(0, max(tiles.shape[0], 1), step):
+        _, toks = vit(tiles[i:i + step], return_tokens=True)
+        rows.append(toks[:, 0].contiguous())
+        del toks
+    return rows[0] if len(rows) == 1 else torch.cat(rows)
+
+
 class HipKeep(torch.nn.Module):
     """`KEEPImageModel` of the reference (src/stamp/preprocessing/extractor/keep.py:25-50): timm ViT-L/16 trunk, then `visual_head` (Linear, GELU,
     Linear) and an L2 normalisation -- trunk = the ViT-L/16 preset, head = ONE library call in exact fp32 (`amds_proj_head_l2norm`) on the trunk's
@@ -80,8 +92,7 @@ class HipKeep(torch.nn.Module):
     @torch.no_grad()
     def forward(self, tiles: torch.Tensor) -> torch.Tensor:
         from . import _lib, ops
-        _, toks = self.vit(tiles, return_tokens=True)                # fp32 [B, T, dim], final norm applied
-        feats = toks[:, 0].contiguous()                               # the class row, fp32 as the reference's head receives it
+        feats = _cls_rows_f32(self.vit, tiles)                         # the class row, fp32 as the reference's head receives it (final norm applied)
         B, dev = feats.shape[0], feats.device
         out = torch.empty(B, self.proj_dim, dtype=torch.float32, device=dev)
         lib = _lib.lib()
@@ -134,8 +145,7 @@ class HipPlip(torch.nn.Module):
     @torch.no_grad()
     def forward(self, tiles: torch.Tensor) -> torch.Tensor:
         from . import ops
-        _, toks = self.vit(tiles, return_tokens=True)                 # fp32 [B, T, D], post_layernorm applied
-        return ops.linear_f32(toks[:, 0].contiguous(), self.proj, None)
+        return ops.linear_f32(_cls_rows_f32(self.vit, tiles), self.proj, None)      # class rows in fp32, post_layernorm applied
 
 
 def hip_plip_extractor(state_dict: dict[str, torch.Tensor], *, identifier: str = "plip", device="cuda", chunk: int = 1020) -> Extractor:
