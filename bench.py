@@ -678,7 +678,7 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary of the
     # two rocprofv3 --pmc passes over this same workload (profiles/*_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
     traffic, pmc_name = None, None
-    for pmc_file in (ROOT / "profiles" / "r04_pmc_gemm_traffic.json", ROOT / "profiles" / "r03_pmc_gemm_traffic.json", ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
+    for pmc_file in (ROOT / "profiles" / "r05_pmc_gemm_traffic.json", ROOT / "profiles" / "r04_pmc_gemm_traffic.json", ROOT / "profiles" / "r03_pmc_gemm_traffic.json", ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
         if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 1020 and pmc_file.is_file():
             try:
                 traffic, pmc_name = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"], pmc_file.name
