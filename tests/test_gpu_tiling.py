@@ -363,3 +363,38 @@ def test_extract_slides_one_pipeline_writes_the_files_of_per_slide_calls(gpu, tm
             assert res[[0, 1, 3, None, 6][i]]["tiles_kept"] == fr.shape[0]
         f3, _, _ = h5io.read_tile_features(out_dir / "s3.h5")
         assert f3.shape[0] == 1                                  # the existing file was left alone
+
+
+def test_extract_slides_never_writes_non_finite_features(gpu, tmp_path):
+    """The multi-slide pipeline keeps the single-slide guarantee: with an overflowing checkpoint (random_vit_state_dict(init="overflow")) every slide's rows
+    fail the per-slide check, nothing is written by the pipeline itself, and each slide goes through `extract_slide` alone afterwards -- which moves the
+    encoder to its safe packing once (one warning) and writes finite features equal to the serial path's; with check="raise" every slide is reported
+    failed, no file appears, and the loop still returns (STAMP logs and goes on, preprocessing/__init__.py:328-336)."""
+    import warnings
+
+    from stamp_amd import h5io
+    from stamp_amd.extractor import Extractor, hip_vit_extractor, u8_tile_transform
+    from stamp_amd.preprocess import SlideJob, extract_slide_serial, extract_slides
+    from stamp_amd.vit import PRESETS, HipViT, random_vit_state_dict
+
+    cfg = PRESETS["test_tiny_fold"]
+    sd = random_vit_state_dict(cfg, seed=13, init="overflow")
+    slides = [_fake_slide(1536, 1024, 6), _fake_slide(1024, 2048, 7)]
+    strict = Extractor(model=HipViT(cfg, sd, device=gpu, chunk=16, check="raise"), transform=u8_tile_transform, identifier="strict")
+    res = extract_slides([SlideJob(s, tmp_path / f"strict{i}.h5", 0.5, f"strict{i}") for i, s in enumerate(slides)], strict, brightness_cutoff=250, canny_cutoff=None, device=gpu)
+    assert [r["status"] for r in res] == ["failed", "failed"] and all("FeatureRangeError" in r["error"] for r in res)
+    assert not any((tmp_path / f"strict{i}.h5").exists() for i in range(2))
+    ex = hip_vit_extractor("test_tiny_fold", sd, device=gpu, chunk=16, identifier="amdstamp-test")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = extract_slides([SlideJob(s, tmp_path / f"a{i}.h5", 0.5, f"a{i}") for i, s in enumerate(slides)], ex, brightness_cutoff=250, canny_cutoff=None, device=gpu)
+    assert [r["status"] for r in res] == ["written", "written"] and ex.model.safe_level == 1 and sum("safe level 1" in str(x.message) for x in w) == 1
+    ex2 = hip_vit_extractor("test_tiny_fold", sd, device=gpu, chunk=16, identifier="amdstamp-test")
+    for i, s in enumerate(slides):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            extract_slide_serial(s, ex2, tmp_path / f"b{i}.h5", slide_mpp=0.5, brightness_cutoff=250, canny_cutoff=None, supertiles_per_batch=2, device=gpu)
+        fa, ca, _ = h5io.read_tile_features(tmp_path / f"a{i}.h5")
+        fb, cb, _ = h5io.read_tile_features(tmp_path / f"b{i}.h5")
+        assert fa.shape[0] > 0 and np.isfinite(fa.astype(np.float32)).all()
+        assert np.array_equal(fa.view(np.uint16), fb.view(np.uint16)) and np.array_equal(ca.coords_um, cb.coords_um)
