@@ -10,13 +10,17 @@
 //            For the q and k blocks W is the MFMA "A" operand (a lane ends up with one token and 4 consecutive dims: a row-major image);
 //            for the v blocks the operands are SWAPPED (a lane ends up with one dim and 4 consecutive tokens): V^T comes out of the matrix
 //            pipe already transposed.
-//   hand-off the folded-LayerNorm epilogue of the qkv GEMM (acc * rstd[m] + colsum[n] * (-mean rstd)[m] + bias[n], rounded to the operand
-//            type -- the very values the unfused path stored) writes the K image, the V^T image and a Q image over the (now idle) stages,
-//            in the layouts attention_vit257.hip reads;
-//   S phase  that kernel's arithmetic, unchanged: each wave takes two blocks of 32 queries (online softmax over four chunks of 64 keys,
-//            software-pipelined inside the wave), the odd key as a rank-1 update, the odd query on the MFMA pipe as 32-key partials.
-// Token 256 of a tile (the odd one: 257 = 16 x 16 + 1) is not part of the 256-row G phase: its q | k | v row is computed beforehand by the ordinary GEMM
+//   hand-off the folded-LayerNorm epilogue of the qkv GEMM (acc * rstd[m] + colsum[n] * (-mean rstd)[m] + bias[n]; k and v rounded to the operand type as the
+//            unfused path stores them, q multiplied by log2(e) / sqrt(64) first) writes the K image, the V^T image and a Q image over the (now idle) stages,
+//            in the layouts attention_vit257.hip reads.  Stage 0 sits on the Q image: once every wave holds its query fragments the NEXT item's first
+//            K tile is requested into it, under the S phase.
+//   S phase  each wave takes its two blocks of 32 queries in ONE instruction stream; softmax in two passes over the 8 key tiles (pass 1: Q K^T for the row
+//            maxima; pass 2: Q K^T again with the shift subtracted inside the product, p = exp2(score), P V, row sums against a ones operand); the odd
+//            key as a rank-1 term at the end, the odd query on the MFMA pipe as 32-key partials merged after the item's barrier.
+// Token 256 of a tile (the odd one: 257 = 16 x 16 + 1) is not part of the 256-row G phase: its q | k | v row is computed beforehand by an ordinary GEMM
 // on the 1020 gathered rows (vit.hip) and read from HBM here (384 bytes per item).
+// STATUS (round 5): parity-tested (tests/test_gpu_qkv_attn.py), 1.7 % faster than the two launches alone, 0.8 % slower inside the encoder -- opt-in
+// (AMDS_VIT_QKVATTN=1); the measurements and the reasons are in profiles/r05_qkv_attn_fused_ab.txt and DESIGN.md section 4.14.
 // Output: attention rows [B * 257][D] in the operand type, as attention_vit257.hip writes them.
 #include "common.h"
 #include <type_traits>
