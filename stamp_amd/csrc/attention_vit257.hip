@@ -376,10 +376,20 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
                 const vec8 kf = *reinterpret_cast<const vec8*>(sK + (wave * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
                 s1 = Act<T>::mfma32(qa, kf, s1);
             }
+            // (the 32 scores sit in the hi == 0 half: 32-lane DPP butterflies instead of two 6-step ds_bpermute chains; the V^T operands of the products below are
+            //  requested before the reductions, not behind them)
+            vec8 vfo[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int pos = wave * 32 + ks * 16 + hi * 8, d = dt * 32 + l31;
+                    vfo[ks][dt] = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
+                }
             const float sv = hi == 0 ? s1[0] * sc : -INFINITY;
-            const float mw = wave_max(sv);
+            const float mw = half_wave_max(sv);
             const float pk = hi == 0 ? __builtin_amdgcn_exp2f(sv - mw) : 0.f;
-            const float lw = wave_sum(pk);
+            const float lw = half_wave_sum(pk);
             char* pw = sPw + wave * 64;
             if (hi == 0) reinterpret_cast<T*>(pw)[(l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)] = Act<T>::from_f32(pk);      // the V^T image's key order
             asm volatile("" ::: "memory");                            // same wave, LDS in order: the reads below see the writes above
@@ -392,13 +402,8 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const vec8 pf = *reinterpret_cast<const vec8*>(psrc + ks * qstep);
-                const int pos = wave * 32 + ks * 16 + hi * 8;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + l31;
-                    const vec8 vf = *reinterpret_cast<const vec8*>(sVt + d * VS + (d >> 3) * 16 + pos * 2);
-                    oq[dt] = Act<T>::mfma32(vf, pf, oq[dt]);
-                }
+                for (int dt = 0; dt < 2; ++dt) oq[dt] = Act<T>::mfma32(vfo[ks][dt], pf, oq[dt]);
             }
             float* pp = sPart + (cur * 9 + wave) * A7_PART;
             if (l31 == 0) {                                           // column 0 of the product: 32 dims in lane 0, 32 in lane 32
@@ -411,7 +416,8 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
             }
             if (wave == 1) {                                          // the odd key's term of that row as the ninth partial
                 float* p8 = sPart + (cur * 9 + 8) * A7_PART;
-                const float st = wave_sum(sQt[lane] * sKt[lane]) * sc;
+                float st = half_wave_sum(sQt[lane] * sKt[lane]);
+                st = (st + __shfl_xor(st, 32, 64)) * sc;
                 p8[lane] = sVl[lane];
                 if (lane == 0) { p8[64] = st; p8[65] = 1.0f; }
             }
