@@ -108,6 +108,29 @@ __global__ void __launch_bounds__(256) dropout_cast_bwd8_kernel(const float* __r
 }
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// the same, 8 elements per lane: 16-byte accesses, one hash per element pair (drop_keep8) -- the bits of the scalar form
+__global__ void __launch_bounds__(256) dropout_add8_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ xin, long ldx, float* __restrict__ xout, long ldo,
+                                                           long rows, int cols, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
+    const long n8 = rows * cols / 8;
+    const int c8 = cols / 8;
+    long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; v < n8; v += stride) {
+        const long r = v / c8;
+        const int c = (int)(v - r * c8) * 8;
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + r * ldy + c), y1 = *reinterpret_cast<const f32x4*>(y + r * ldy + c + 4);
+        f32x4 x0 = *reinterpret_cast<const f32x4*>(xin + r * ldx + c), x1 = *reinterpret_cast<const f32x4*>(xin + r * ldx + c + 4);
+        bool keep[8];
+        drop_keep8(seed, stream, v * 8, thr, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x0[e] = x0[e] + (keep[e] ? y0[e] * scale : 0.f);
+            x1[e] = x1[e] + (keep[4 + e] ? y1[e] * scale : 0.f);
+        }
+        *reinterpret_cast<f32x4*>(xout + r * ldo + c) = x0;
+        *reinterpret_cast<f32x4*>(xout + r * ldo + c + 4) = x1;
+    }
+}
 // rows x cols view with row pitches (the residual stream may be padded): element index = r * cols + c
 __global__ void dropout_add_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ xin, long ldx, float* __restrict__ xout, long ldo,
                                    long rows, int cols, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
@@ -201,8 +224,12 @@ extern "C" int amds_dropout_add(const float* y, long ldy, const float* x_in, lon
     AMDS_REQUIRE(y && x_in && x_out && rows >= 0 && cols > 0 && ldy >= cols && ldx >= cols && ldo >= cols && DROP_ARGS_OK(p), "amds_dropout_add: bad arguments");
     if (rows == 0) return AMDS_OK;
     const uint32_t thr = drop_thr16(p);
-    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1d_(rows * cols)), dim3(256), 0, (hipStream_t)stream, y, ldy, x_in, ldx, x_out, ldo, rows, cols, seed,
-                       stream_id, thr, drop_scale(thr));
+    if (cols % 8 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && al16(y) && al16(x_in) && al16(x_out))
+        hipLaunchKernelGGL(dropout_add8_kernel, dim3(grid1d_(rows * cols / 8)), dim3(256), 0, (hipStream_t)stream, y, ldy, x_in, ldx, x_out, ldo, rows, cols, seed,
+                           stream_id, thr, drop_scale(thr));
+    else
+        hipLaunchKernelGGL(dropout_add_kernel, dim3(grid1d_(rows * cols)), dim3(256), 0, (hipStream_t)stream, y, ldy, x_in, ldx, x_out, ldo, rows, cols, seed,
+                           stream_id, thr, drop_scale(thr));
     AMDS_LAUNCH_CHECK("dropout_add_kernel");
     return AMDS_OK;
 }
