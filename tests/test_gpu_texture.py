@@ -91,3 +91,28 @@ def test_macenko_normalisation_vs_oracle(gpu):
     assert torch.equal(macenko_normalize(torch.from_numpy(tiles).to(gpu)).cpu(), torch.from_numpy(out))       # histogram atomics are integer: deterministic
     with pytest.raises(RuntimeError, match="GPU"):
         macenko_normalize(torch.from_numpy(tiles))
+
+
+def test_quad_kernel_and_byte_kernel_agree_bit_for_bit(gpu, tmp_path):
+    """The production kernel (four pixels per thread, candidate worklist) and the byte-at-a-time kernel it replaced (AMDS_CANNY_QUAD=0, read once per process:
+    run in a child process) give the same fraction, edge map and grey map -- both are held to the oracle above; this pins them to each other on more tiles."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    from scipy import ndimage
+    base = rng.normal(size=(12, 224, 224))
+    sm = np.stack([ndimage.gaussian_filter(b, s) for b, s in zip(base, (0.5, 1, 1.5, 2, 2.5, 3, 4, 5, 6, 8, 10, 14))])
+    sm = (sm - sm.min((1, 2), keepdims=True)) / (np.ptp(sm, axis=(1, 2), keepdims=True))
+    tiles = (np.stack([sm, sm ** 2, 1 - sm], -1) * np.array([255, 220, 160]) + rng.normal(0, 3, (12, 224, 224, 3))).clip(0, 255).astype(np.uint8)
+    np.save(tmp_path / "tiles.npy", tiles)
+    frac, edges, gray = ops.tile_edge_fraction(torch.from_numpy(tiles).to(gpu), 40, 100, return_maps=True)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, sys.argv[1]); from stamp_amd import ops\n"
+            "t = torch.from_numpy(np.load(sys.argv[2] + '/tiles.npy')).cuda()\n"
+            "f, e, g = ops.tile_edge_fraction(t, 40, 100, return_maps=True)\n"
+            "np.savez(sys.argv[2] + '/old.npz', f=f.cpu().numpy(), e=e.cpu().numpy(), g=g.cpu().numpy())\n")
+    root = str(Path(__file__).resolve().parent.parent)
+    subprocess.run([sys.executable, "-c", code, root, str(tmp_path)], check=True, env=dict(os.environ, AMDS_CANNY_QUAD="0"), timeout=300)
+    z = np.load(tmp_path / "old.npz")
+    assert np.array_equal(z["e"], edges.cpu().numpy()) and np.array_equal(z["g"], gray.cpu().numpy()) and np.array_equal(z["f"], frac.cpu().numpy())
+    assert 0 < (z["e"] > 0).mean() < 1
