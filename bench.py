@@ -433,7 +433,8 @@ def slides_leg(model, dev, sides=(24, 70, 32, 48, 36, 60, 28, 44, 40, 52)) -> di
     return {"metric": "tiles/s over a LIST of slide objects to their feature files, one pipeline across slides (extract_slides)", "value": round(kept / el, 1),
             "unit": "tiles/s", "slides": len(slides), "tiles_per_slide": [4 * s * s for s in sides], "tiles_kept": kept, "seconds": round(el, 2),
             "statuses": sorted({r["status"] for r in res}), "host_wait_for_reader_s": res[0].get("wait_reader_s"),
-            "one_extract_slide_call_per_slide": round(kept1 / el1, 1), "files_identical_to_per_slide_calls": same, "reader_threads": workers}
+            "one_extract_slide_call_per_slide": round(kept1 / el1, 1), "files_identical_to_per_slide_calls": same, "reader_threads": workers,
+            **({"trace": res[0]["trace"], "per_slide": [(r.get("plan_s"), r.get("planned_at_s"), r.get("finish_s"), r.get("finished_at_s")) for r in res]} if "trace" in res[0] else {})}
 
 
 def drop_in_b64_leg(model, cfg, dev, n_batches: int = 48) -> dict:

@@ -16,6 +16,7 @@ reference yields in thread-completion order, :346, which is why its tests sort b
 """
 from __future__ import annotations
 
+import os
 from concurrent import futures
 from pathlib import Path
 
@@ -35,6 +36,19 @@ def _region_array(slide, x: int, y: int, s: int) -> np.ndarray:
     if im.mode != "RGBA":              # openslide hands out RGBA already: no second 4 MB copy under the GIL
         im = im.convert("RGBA")
     return np.asarray(im, dtype=np.uint8)
+
+
+def _nonfinite_rows(feats: torch.Tensor) -> int:
+    """Rows of a host feature matrix that hold a NaN or an infinity.  fp16 is tested on its bits (exponent all ones): torch's CPU `isfinite` on a half tensor
+    converts element by element -- 0.27 s for 2 304 x 1 024 values, on the thread that competes with the reader threads for the interpreter."""
+    if feats.numel() == 0:
+        return 0
+    if feats.dtype == torch.float16 and feats.device.type == "cpu":
+        mag = feats.contiguous().numpy().view(np.uint16) & 0x7FFF          # |x| as an integer: finite <=> below the all-ones exponent
+        if int(mag.max()) < 0x7C00:
+            return 0
+        return int((mag.max(axis=1) >= 0x7C00).sum())
+    return int((~torch.isfinite(feats)).any(dim=1).sum())
 
 
 def _write(output_path, feats, coords, extractor, tile_size_um, tile_size_px):
@@ -300,8 +314,9 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     # packing to offer (vit.HipViT: LayerNorm un-folded / bf16) is moved one level up and the slide is run again; otherwise the slide raises and
     # STAMP's per-slide try/except skips it (:328-336).
     why = None
-    if not bool(torch.isfinite(feats).all()):
-        why = f"{int((~torch.isfinite(feats)).any(dim=1).sum())} of {feats.shape[0]} tiles have non-finite features"
+    n_bad = _nonfinite_rows(feats)
+    if n_bad:
+        why = f"{n_bad} of {feats.shape[0]} tiles have non-finite features"
     else:
         for m in guarded:      # finite, but rows with |mean| > 8 sigma went through a folded LayerNorm (vit.HipViT.call_verdict)
             d = m.range_diagnostics(reset=True) if getattr(m, "safe_level", 1) == 0 and hasattr(m, "range_diagnostics") else {}
@@ -483,7 +498,10 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                         inflight.append(("skipped", (idx,), []))
                         continue
                     try:
+                        t_pl = _time.perf_counter()
                         plan = plan_slide(idx)
+                        results[idx]["plan_s"] = round(_time.perf_counter() - t_pl, 3)
+                        results[idx]["planned_at_s"] = round(_time.perf_counter() - t_begin, 3)
                     except BaseException as e:
                         inflight.append(("slide_error", (idx, e), []))
                         continue
@@ -568,9 +586,18 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                 unknown -= rows
                 slot_busy[slot] = False
 
+        trace_ev: list = [] if os.environ.get("AMDS_SLIDES_TRACE") else None       # (start, end) events around every encoder call: GPU time between calls
+
         def encode(m: int) -> None:
             nonlocal cur, encoded
+            if trace_ev is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(cs)
             f = model(acc[cur][:m]).detach()
+            if trace_ev is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(cs)
+                trace_ev.append((e0, e1, _time.perf_counter() - t_begin, m))
             if f.dtype != torch.float16:
                 f = f.half()
             f = f.contiguous()
@@ -628,15 +655,16 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
         def _finish_slide(sidx, s, feats, coords, big_mean):
             job = jobs[sidx]
             r = results[sidx]
+            t_fin = _time.perf_counter()
             r.update(supertiles=s["supertiles"], tiles_seen=s["seen"], tiles_kept=int(feats.shape[0]))
             try:
                 if s["error"] is not None:
                     raise s["error"]
                 if feats.shape[0] == 0:
                     r["status"] = "empty"
-                elif not bool(torch.isfinite(feats).all()) or big_mean:
+                elif (n_bad := _nonfinite_rows(feats)) or big_mean:
                     r["status"] = "recheck"
-                    r["why"] = (f"{int((~torch.isfinite(feats)).any(dim=1).sum())} of {feats.shape[0]} tiles have non-finite features" if not big_mean
+                    r["why"] = (f"{n_bad} of {feats.shape[0]} tiles have non-finite features" if not big_mean
                                 else f"{big_mean} rows with |mean| > 8 sigma entered a folded LayerNorm in the encoder calls of this slide")
                 else:
                     _write(job.output_path, feats, coords, extractor, tile_size_um, tile_size_px)
@@ -652,6 +680,8 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                     except Exception:
                         pass
                     s["plan"].slide = None
+            r["finish_s"] = round(_time.perf_counter() - t_fin, 3)
+            r["finished_at_s"] = round(_time.perf_counter() - t_begin, 3)
             if on_slide_done is not None:
                 on_slide_done(sidx, r)
 
@@ -779,6 +809,12 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
         if on_slide_done is not None:
             on_slide_done(sidx, r)
     total = _time.perf_counter() - t_begin
+    if trace_ev:
+        enc = [a.elapsed_time(b) for a, b, _, _ in trace_ev]
+        gaps = [trace_ev[i][1].elapsed_time(trace_ev[i + 1][0]) for i in range(len(trace_ev) - 1)]
+        results[0]["trace"] = {"encoder_calls": len(enc), "encoder_ms": round(sum(enc), 1), "between_calls_ms": round(sum(gaps), 1),
+                               "first_call_enqueued_at_s": round(trace_ev[0][2], 3), "largest_gaps_ms": sorted((round(g, 1), i) for i, g in enumerate(gaps))[-8:],
+                               "median_gap_ms": round(sorted(gaps)[len(gaps) // 2], 2) if gaps else None}
     for r in results:
         r.setdefault("status", "failed")
     results[0]["pipeline_s"] = round(total, 3)
