@@ -496,7 +496,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
         model = mil if not alibi else HipMil(dropout=0.25, use_alibi=True, **kw).eval()
         crd = (torch.rand(64, 1024, 2, generator=torch.Generator().manual_seed(2)) * 4e4).to(ctx.device) if alibi else None
         trn = HipMilVitTrainer(model, device=ctx.device, total_steps=100, sched_interval="step", dropout=drop)
-        dt, (ltr, _) = timeit(lambda: trn.step(bags, tg, cw, coords=crd), 4)
+        dt, (ltr, _) = timeit(lambda: trn.step(bags, tg, cw, coords=crd), 16, warm=3)       # 16 steps (0.12 s): four were dominated by the first step's clock ramp
         sec[key] = {"metric": f"MIL bags/s (vit head{' with ALiBi' if alibi else ''}, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands, "
                               + ("all dropout sites off)" if drop is False else "train-mode dropout as the reference: 0.25 / 0.25 / 0.5 / 0.5)"),
                     "value": round(64 / dt, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltr))}
