@@ -38,6 +38,33 @@ def _region_array(slide, x: int, y: int, s: int) -> np.ndarray:
     return np.asarray(im, dtype=np.uint8)
 
 
+# Pinned staging buffers are kept between calls: pinning is a driver call that walks the pages (~0.15 s for the 1 GB ring of one extract_slide call --
+# 4 % of a 20 k-tile slide), and a rank calls these functions once per slide / once per list.  Buffers go back to the pool only after the call has
+# synchronised its streams; at most _PIN_POOL_MAX bytes are kept.
+_PIN_POOL: dict[int, list] = {}
+_PIN_POOL_MAX = 6 << 30
+_pin_lock = __import__("threading").Lock()
+
+
+def _pinned_take(nbytes: int) -> torch.Tensor:
+    """A pinned uint8 buffer of at least nbytes (rounded up to 1 MiB)."""
+    size = max(1, -(-int(nbytes) // (1 << 20))) << 20
+    with _pin_lock:
+        lst = _PIN_POOL.get(size)
+        if lst:
+            return lst.pop()
+    return torch.empty(size, dtype=torch.uint8).pin_memory()
+
+
+def _pinned_give(bufs) -> None:
+    with _pin_lock:
+        held = sum(k * len(v) for k, v in _PIN_POOL.items())
+        for b in bufs:
+            if b is not None and held + b.numel() <= _PIN_POOL_MAX:
+                _PIN_POOL.setdefault(b.numel(), []).append(b)
+                held += b.numel()
+
+
 def _nonfinite_rows(feats: torch.Tensor) -> int:
     """Rows of a host feature matrix that hold a NaN or an infinity.  fp16 is tested on its bits (exponent all ones): torch's CPU `isfinite` on a half tensor
     converts element by element -- 0.27 s for 2 304 x 1 024 values, on the thread that competes with the reader threads for the interpreter."""
@@ -101,7 +128,8 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
     # pinned ring: four batches (one being consumed, up to three being decoded)
     n_buf = 4
     n_buf = max(2, min(n_buf, (4 << 30) // (spb * S * S * 4), -(-len(origins) // spb) + 1))       # <= 4 GB of pinned memory, not more slots than batches
-    host = [torch.empty(spb, S, S, 4, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
+    host_raw = [_pinned_take(spb * S * S * 4) for _ in range(n_buf)]
+    host = [h[: spb * S * S * 4].view(spb, S, S, 4) for h in host_raw]
     host_np = [h.numpy() for h in host]               # the reader threads write through numpy views (no torch state in worker threads)
     buf_free: "queue.Queue[int]" = queue.Queue()
     for i in range(n_buf):
@@ -168,7 +196,8 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
         n_batches = (len(origins) + spb - 1) // spb
         slots_ring = torch.empty(n_batches, spb * kk, dtype=torch.int32).pin_memory()
         feat_dim = int(getattr(getattr(model, "cfg", None), "out_dim", 0) or getattr(getattr(model, "cfg", None), "dim", 0) or 0)
-        feats_host = torch.empty(len(origins) * kk, feat_dim, dtype=torch.float16).pin_memory() if feat_dim else None
+        feats_raw = _pinned_take(len(origins) * kk * feat_dim * 2) if feat_dim else None
+        feats_host = feats_raw[: len(origins) * kk * feat_dim * 2].view(torch.float16).view(len(origins) * kk, feat_dim) if feat_dim else None
         # micrometre coordinates of every tile of every foreground supertile, in yield order (tiling.py:237-246), vectorised
         og = np.asarray(origins, dtype=np.float64) * slide_mpp                                  # [n, 2] (x, y)
         off = np.array([(x * tile_size_um, y * tile_size_um) for y in range(k) for x in range(k)], dtype=np.float64)
@@ -306,8 +335,10 @@ def extract_slide(slide, extractor: Extractor, output_path, *, slide_mpp: float,
         coords_parts = kept_coords
         stats["pipeline_s"] = round(_time.perf_counter() - t_begin - stats["setup_s"], 3)
     if not feats_parts:
+        _pinned_give(host_raw + [feats_raw])
         return stats
-    feats = torch.cat([p[0] for p in feats_parts])
+    feats = torch.cat([p[0] for p in feats_parts]) if len(feats_parts) > 1 else feats_parts[0][0].clone()
+    _pinned_give(host_raw + [feats_raw])              # (every stream that touched them has been synchronised; `feats` is a copy)
     coords = np.concatenate(coords_parts)
     stats["tiles_kept"] = int(feats.shape[0])
     # Nothing non-finite reaches the file (the reference writes whatever its model returned, __init__.py:338-345).  A tile encoder with a safer
@@ -451,7 +482,7 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
     max_rgba = max(s * g.supertile_size_slide_px ** 2 * 4 for s, g in zip(spbs, geos))          # bytes of one batch of supertiles
     max_tiles = max(s * g.tiles_per_side ** 2 for s, g in zip(spbs, geos))                        # tiles one batch can yield
     n_buf = max(2, min(6, (4 << 30) // max_rgba))          # one batch being copied, up to five being decoded
-    host = [torch.empty(max_rgba, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
+    host = [_pinned_take(max_rgba) for _ in range(n_buf)]
     host_np = [h.numpy() for h in host]
     buf_free: "queue.Queue[int]" = queue.Queue()
     for i in range(n_buf):
@@ -790,6 +821,8 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                 fu.result()
             writer.shutdown()
         cs.synchronize()
+        h2d.synchronize()
+    _pinned_give(host)
     # slides whose features failed the check: alone through extract_slide, which moves the encoder to a safer packing (and re-runs) or raises
     for sidx, r in enumerate(results):
         if r["status"] != "recheck":
