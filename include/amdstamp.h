@@ -995,6 +995,20 @@ int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, 
  * amds_colsum(part_i, count_i, out_i, rows, count_i, AMDS_F32, ...) (same bits): the split-K partials of every weight gradient of a backward pass
  * (amds_wgrad_tn) summed behind the last of them instead of one reduction launch per matrix.  counts: multiples of 4; pointers 16-byte aligned. */
 int amds_sum_partials_multi(const float* const* parts_host, float* const* outs_host, const long* counts_host, int n, int rows, void* stream);
+/* Column sums a backward pass can postpone, summed by ONE launch behind the last of them (the MIL `vit` step kept 21 small reduction launches for
+ * LayerNorm parameter gradients, bias gradients' second stages, the head bias and the class token; reference step: `loss.backward()` of
+ * src/stamp/modeling/models/__init__.py:239-279).  kind 0: out[n] = sum over r < rows of x[r * ld + n], fp32, rows <= 2048 -- the bits of
+ * amds_colsum(x, ld, out, rows, cols, AMDS_F32, 0, ...).  kind 1: out[n] = the second stage of amds_colsum over `rows` chunk partials
+ * x[c * cols + n] written by amds_colsum_partials (which reports the chunk count) -- amds_colsum_partials + a kind-1 entry = amds_colsum, same bits.
+ * At most 32 entries per call. */
+typedef struct amds_colsum_entry {
+    const float* x;
+    float* out;
+    long ld;                 /* kind 0: row stride of x in elements (>= cols); kind 1: ignored */
+    int rows, cols, kind;
+} amds_colsum_entry;
+int amds_colsum_partials(const void* x, long ld, float* part, int M, int N, int in_dtype, int* nchunk_out, void* stream);
+int amds_colsum_multi(const amds_colsum_entry* entries_host, int n, void* stream);
 /* LayerNorm forward that also stores mean / rstd per row (fp32), and its backward:
  *   dx = (add_skip ? dx : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma (+)= sum dy*xhat; dbeta (+)= sum dy */
 int amds_layernorm_train(const float* x, long x_row_stride, const float* gamma, const float* beta, void* y, long y_row_stride,
@@ -1016,6 +1030,11 @@ int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const float* x, lon
                             const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
                             int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed,
                             uint32_t stream_id, void* stream);
+/* amds_layernorm_bwd_cast without its two parameter-gradient reductions: the per-64-row partials go to dgamma_part / dbeta_part, fp32
+ * [ceil(rows / 64)][cols] each, for the caller to sum when it likes (kind-0 entries of amds_colsum_multi: ceil(rows / 64) rows of `cols`). */
+int amds_layernorm_bwd_partials(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                                const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma_part, float* dbeta_part,
+                                int rows, int cols, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed, uint32_t stream_id, void* stream);
 /* exact-erf GELU on a stored pre-activation and its derivative (dz = du * gelu'(z)). */
 int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, void* stream);
 int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, void* stream);

@@ -67,6 +67,10 @@ class CastEntry(C.Structure):
                 ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int)]
 
 
+class ColsumEntry(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("ld", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("kind", C.c_int)]
+
+
 class MilVitCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_feats", "dim", "heads", "ff", "classes", "layers", "alibi", "dtype")]
 
@@ -294,11 +298,14 @@ PROTOTYPES = {
     "amds_cast_transpose_multi": (_i, [C.POINTER(CastEntry), _i, _vp]),
     "amds_colsum_workspace_bytes": (_sz, [_i, _i]),
     "amds_colsum": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_colsum_partials": (_i, [_vp, _l, _vp, _i, _i, _i, C.POINTER(_i), _vp]),
+    "amds_colsum_multi": (_i, [C.POINTER(ColsumEntry), _i, _vp]),
     "amds_sum_partials_multi": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_l), _i, _i, _vp]),
     "amds_layernorm_train": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp]),
     "amds_layernorm_train_copy": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _i, _vp, _l, _i, _vp]),
     "amds_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "amds_layernorm_bwd": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_layernorm_bwd_partials": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _l, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_layernorm_bwd_cast": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _l, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_gelu_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "amds_gelu_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),

@@ -79,8 +79,8 @@ void plan_saved(const Dims& d, SavedPlan* p) {
 
 struct WsPlan {
     long Mp, Mtp;
-    size_t dx, dh, g16, du, dz, datt, dqkv, tg, ta, part, part_all, cs, lnb, dqs, dbsp, dbst, gsc, dcls, dlt, dxp, dzp, total;
-    size_t cs_bytes, lnb_bytes;
+    size_t dx, dh, g16, du, dz, datt, dqkv, tg, ta, part, part_all, cs, lnb, sums, dqs, dbsp, dbst, gsc, dcls, dlt, dxp, dzp, total;
+    size_t cs_bytes, lnb_bytes, sums_bytes;
 };
 
 void plan_ws(const Dims& d, int split_k, WsPlan* p) {
@@ -114,6 +114,15 @@ void plan_ws(const Dims& d, int split_k, WsPlan* p) {
     p->cs = take(p->cs_bytes);
     p->lnb_bytes = std::max<size_t>(amds_layernorm_bwd_workspace_bytes((int)d.M, d.D), 4);
     p->lnb = take(p->lnb_bytes);
+    // the column sums the backward postpones to ONE launch at its end (amds_colsum_multi): per-64-row partials of every LayerNorm's parameter gradients
+    // and the chunk partials of every bias gradient, each in its own region
+    {
+        const size_t nblk = (M + 63) / 64, nch = (M + 1023) / 1024 + 1;
+        size_t b = (size_t)(2 * d.L + 1) * 2 * al(nblk * d.D * 4);
+        b += (size_t)d.L * (2 * al(nch * d.Dp * 4) + al(nch * d.FFp * 4) + al(nch * 3 * d.Da * 4) + al(nch * d.Ha * 4)) + al(nch * d.Dp * 4);
+        p->sums_bytes = b + 4096;
+        p->sums = take(p->sums_bytes);
+    }
     p->dqs = take((size_t)d.Bb * d.Ha * d.S * 4);
     p->dbsp = take((size_t)d.Bb * d.Ha * d.S * 4);
     p->dbst = take(M * d.Ha * 4);
@@ -354,8 +363,70 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     void* cs = wk + wp.cs;
     void* lnb = wk + wp.lnb;
 
-    auto colsum = [&](const void* x, long ld, float* out, long rows, int cols, int dt) {
+    // Column sums whose results nobody reads before the end of the backward are postponed: first stages (where there is one) on the spot, everything else
+    // as entries of ONE amds_colsum_multi launch at the end (21 small launches per step -> 1 for two layers, same bits).  AMDS_COLSUM_DEFER=0: on the spot.
+    static const bool defer_sums = !(getenv("AMDS_COLSUM_DEFER") && atoi(getenv("AMDS_COLSUM_DEFER")) == 0);
+    amds_colsum_entry sum_e[32];
+    int n_sum = 0;
+    size_t sums_used = 0;
+    auto flush_sums = [&]() -> int {
+        sums_used = 0;
+        if (n_sum == 0) return AMDS_OK;
+        const int n = n_sum;
+        n_sum = 0;
+        return amds_colsum_multi(sum_e, n, stream);
+    };
+    auto take_sums = [&](size_t bytes, int entries, float** out) -> int {          // a region that lives until the next flush; nullptr: does not fit at all
+        bytes = al(bytes);
+        *out = nullptr;
+        if (bytes > wp.sums_bytes) return AMDS_OK;
+        if (sums_used + bytes > wp.sums_bytes || n_sum + entries > 32) RC(flush_sums());
+        *out = reinterpret_cast<float*>(wk + wp.sums + sums_used);
+        sums_used += bytes;
+        return AMDS_OK;
+    };
+    // `stable`: x is not written again before the end of the backward (a one-chunk fp32 sum can then read it from the postponed launch)
+    auto colsum = [&](const void* x, long ld, float* out, long rows, int cols, int dt, bool stable = false) -> int {
+        if (defer_sums) {
+            if (rows <= 2048) {
+                if (stable && dt == AMDS_F32) {
+                    if (n_sum + 1 > 32) RC(flush_sums());
+                    sum_e[n_sum++] = amds_colsum_entry{reinterpret_cast<const float*>(x), out, ld, (int)rows, cols, 0};
+                    return AMDS_OK;
+                }
+            } else {
+                float* pr;
+                RC(take_sums((size_t)((rows + 1023) / 1024) * cols * 4, 1, &pr));
+                if (pr) {
+                    int nchunk = 0;
+                    RC(amds_colsum_partials(x, ld, pr, (int)rows, cols, dt, &nchunk, stream));
+                    sum_e[n_sum++] = amds_colsum_entry{pr, out, (long)cols, nchunk, cols, 1};
+                    return AMDS_OK;
+                }
+            }
+        }
         return amds_colsum(x, ld, out, (int)rows, cols, dt, 0, cs, wp.cs_bytes, stream);
+    };
+    // LayerNorm backward; its parameter-gradient partials are summed at the end (or not at all when nobody asked for parameter gradients)
+    auto ln_bwd = [&](const float* dy, long dys, const float* x, long xs, const float* mu, const float* rs, const float* gamma, float* dxo, long dxs, int add_skip,
+                      float* dgamma, float* dbeta, long rows, void* dx16, long ld16, float p, uint32_t sid) -> int {
+        const long nblk = (rows + 63) / 64;
+        if (!need_params) {
+            float* sc = reinterpret_cast<float*>(lnb);           // (sized for the two partial planes + a reduction workspace)
+            return amds_layernorm_bwd_partials(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, sc, sc + (size_t)nblk * D, (int)rows, D, dx16, ld16, p, seed, sid, stream);
+        }
+        if (defer_sums && nblk <= 2048) {
+            float* pr;
+            RC(take_sums((size_t)2 * al((size_t)nblk * D * 4), 2, &pr));
+            if (pr) {
+                float* pb = reinterpret_cast<float*>(reinterpret_cast<char*>(pr) + al((size_t)nblk * D * 4));
+                RC(amds_layernorm_bwd_partials(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, pr, pb, (int)rows, D, dx16, ld16, p, seed, sid, stream));
+                sum_e[n_sum++] = amds_colsum_entry{pr, dgamma, (long)D, (int)nblk, D, 0};
+                sum_e[n_sum++] = amds_colsum_entry{pb, dbeta, (long)D, (int)nblk, D, 0};
+                return AMDS_OK;
+            }
+        }
+        return amds_layernorm_bwd_cast(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, dgamma, dbeta, 0, (int)rows, D, lnb, wp.lnb_bytes, dx16, ld16, p, seed, sid, stream);
     };
     // [rows][cols] bf16 -> [cols][pitch]; the columns rows..pitch must read as zeros (the split-K contraction runs over the padded length).  The
     // transposes never write them, so they are zeroed ONCE per pitch for the widest matrix that will use the buffer (`zero_pads`) instead of in
@@ -409,14 +480,13 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         hipLaunchKernelGGL(transpose_f32_small_kernel, dim3((Bb * C + 255) / 256), dim3(256), 0, st, dlogits, dlt, Bb, C);
         AMDS_LAUNCH_CHECK("transpose_f32_small_kernel");
         RC(amds_bgemm_f32(dlt, Bb, 0, 0, clsn, D, 0, 0, 0, G->head_w, D, 0, 0, 1, 1, C, D, Bb, 1.0f, 0.0f, nullptr, 0, stream));      // dW_head = dlogits^T clsn
-        RC(colsum(dlogits, C, G->head_b, Bb, C, AMDS_F32));
+        RC(colsum(dlogits, C, G->head_b, Bb, C, AMDS_F32, true));                                                      // (the caller's tensor)
     }
     RC(amds_bgemm_f32(dlogits, C, 0, 0, w.head_w, D, 0, 0, 0, dcls, D, 0, 0, 1, 1, Bb, D, C, 1.0f, 0.0f, nullptr, 0, stream));           // dclsn = dlogits W_head
     AMDS_HIP(hipMemsetAsync(dx, 0, (size_t)M * Dp * 4, st));
     float* scratch_g = reinterpret_cast<float*>(wk + wp.gsc);       // LayerNorm's backward always produces dgamma / dbeta
-    RC(amds_layernorm_bwd(dcls, D, x_last, (long)S * Dp, reinterpret_cast<const float*>(sv + sp.muf), reinterpret_cast<const float*>(sv + sp.rsf), w.norm_w,
-                          dx, (long)S * Dp, 0, need_params ? G->norm_w : scratch_g, need_params ? G->norm_b : scratch_g + D, 0, Bb, D, lnb, wp.lnb_bytes,
-                          stream));
+    RC(ln_bwd(dcls, D, x_last, (long)S * Dp, reinterpret_cast<const float*>(sv + sp.muf), reinterpret_cast<const float*>(sv + sp.rsf), w.norm_w,
+              dx, (long)S * Dp, 0, need_params ? G->norm_w : scratch_g, need_params ? G->norm_b : scratch_g + D, Bb, nullptr, 0, 0.f, 0));
 
     const bool fused_cast = (D == Dp) && !(getenv("AMDS_LNBWD_CAST") && atoi(getenv("AMDS_LNBWD_CAST")) == 0);      // (pad columns of g16 would stay unwritten otherwise)
     for (int l = d.L - 1; l >= 0; --l) {
@@ -458,9 +528,8 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             }
             RC(colsum(dz, FFp, Gl->fc1_b, M, FFp, BF));
         }
-        RC(amds_layernorm_bwd_cast(dh, Dp, x_mid, Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, Dp, 1,
-                                   need_params ? Gl->ln2_w : scratch_g, need_params ? Gl->ln2_b : scratch_g + D, 0, (int)M, D, lnb, wp.lnb_bytes,
-                                   fused_cast ? g16 : nullptr, Dp, 0.f, 0, 0, stream));
+        RC(ln_bwd(dh, Dp, x_mid, Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, Dp, 1,
+                  need_params ? Gl->ln2_w : scratch_g, need_params ? Gl->ln2_b : scratch_g + D, M, fused_cast ? g16 : nullptr, Dp, 0.f, 0));
         // ---- attention branch -------------------------------------------------------------------------------------------------------------
         if (!fused_cast) RC(amds_cast_pad(dx, Dp, g16, Dp, (int)M, Dp, BF, stream));                                         // d(x_mid) as bf16
         RC(gemm(g16, Dp, Lw.out_wt, Dp, M, Da, Dp, AMDS_EPI_BIAS, datt, Da, nullptr, stream));
@@ -500,12 +569,12 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         }
         RC(gemm(dqkv, 3 * Da, Lw.in_wt, 3 * Da, M, Dp, 3 * Da, AMDS_EPI_BIAS_F32, dh, Dp, nullptr, stream));                 // dh1 fp32
         // (the layer below starts with g16 = bf16(Dropout'(dx)) at ITS feed-forward dropout site: written here, where dx is made)
-        RC(amds_layernorm_bwd_cast(dh, Dp, x_in, Dp, reinterpret_cast<const float*>(sv + o.mu1), reinterpret_cast<const float*>(sv + o.rs1), Lw.ln1_w, dx, Dp, 1,
-                                   need_params ? Gl->ln1_w : scratch_g, need_params ? Gl->ln1_b : scratch_g + D, 0, (int)M, D, lnb, wp.lnb_bytes,
-                                   (fused_cast && l > 0) ? g16 : nullptr, Dp, p_ff, seed, (uint32_t)(10 * (l - 1) + 3), stream));
+        RC(ln_bwd(dh, Dp, x_in, Dp, reinterpret_cast<const float*>(sv + o.mu1), reinterpret_cast<const float*>(sv + o.rs1), Lw.ln1_w, dx, Dp, 1,
+                  need_params ? Gl->ln1_w : scratch_g, need_params ? Gl->ln1_b : scratch_g + D, M, (fused_cast && l > 0) ? g16 : nullptr, Dp, p_ff,
+                  (uint32_t)(10 * (l - 1) + 3)));
     }
     // ---- class token, project_features ------------------------------------------------------------------------------------------------------
-    if (need_params) RC(colsum(dx, (long)S * Dp, G->class_token, Bb, Dp, AMDS_F32));                                           // class-token rows
+    if (need_params) RC(colsum(dx, (long)S * Dp, G->class_token, Bb, Dp, AMDS_F32, true));                                     // class-token rows (dx is final here)
     float* dxp = reinterpret_cast<float*>(wk + wp.dxp);
     void* dzp = wk + wp.dzp;
     hipLaunchKernelGGL(drop_cls_rows_kernel, dim3((unsigned)Mt), dim3(128), 0, st, dx, dxp, Dp, d.Tn);
@@ -524,5 +593,6 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     }
     if (dbags) RC(gemm(dzp, Dp, w.proj_wt, Dp, Mt, Fp, Dp, AMDS_EPI_BIAS_F32, dbags, Fp, nullptr, stream));                 // [Mt][Fp] fp32 (padded columns = 0)
     if (n_def > 0) RC(amds_sum_partials_multi(def_part, def_out, def_count, n_def, split_k, stream));
+    RC(flush_sums());
     return AMDS_OK;
 }

@@ -66,12 +66,12 @@ __global__ void __launch_bounds__(256) transpose16_vec_kernel(const uint16_t* __
 // 1.4 TB/s, and its second stage summed 257 partials serially in two blocks.)
 constexpr int CS_ROWS = 1024;
 template <typename TI>
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const TI* __restrict__ x, long ld, float* __restrict__ partial, int M, int N, int vec_ok, int cs_rows) {
+__device__ __forceinline__ void colsum_block(const TI* __restrict__ x, long ld, float* __restrict__ partial, int M, int N, int vec_ok, int cs_rows, int bx, int by) {
     typedef TI vec4 __attribute__((ext_vector_type(4)));
     __shared__ f32x4 red[16][16];
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int n = blockIdx.x * 64 + cg * 4;
-    const int r0 = blockIdx.y * cs_rows, r1 = min(M, r0 + cs_rows);
+    const int n = bx * 64 + cg * 4;
+    const int r0 = by * cs_rows, r1 = min(M, r0 + cs_rows);
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -104,11 +104,14 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const TI* __restric
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][c >> 2][c & 3];
-        if (blockIdx.x * 64 + c < N) partial[(long)blockIdx.y * N + blockIdx.x * 64 + c] = s;
+        if (bx * 64 + c < N) partial[(long)by * N + bx * 64 + c] = s;
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunk, int N, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+template <typename TI>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const TI* __restrict__ x, long ld, float* __restrict__ partial, int M, int N, int vec_ok, int cs_rows) {
+    colsum_block<TI>(x, ld, partial, M, N, vec_ok, cs_rows, blockIdx.x, blockIdx.y);
+}
+__device__ __forceinline__ void colsum_final_cols(const float* __restrict__ partial, float* __restrict__ out, int nchunk, int N, int accumulate, int n) {
     if (n >= N) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int c = 0;
@@ -119,6 +122,27 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
     for (; c < nchunk; ++c) s0 += partial[(long)c * N + n];
     const float s = (s0 + s1) + (s2 + s3);
     out[n] = accumulate ? out[n] + s : s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunk, int N, int accumulate) {
+    colsum_final_cols(partial, out, nchunk, N, accumulate, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// Many small column sums as ONE launch (amds_colsum_multi): entry i owns the blocks [block0[i], block0[i + 1]); kind 0 = the one-chunk sum of
+// amds_colsum (64 columns per block), kind 1 = the second stage over chunk partials (256 columns per block).  The arithmetic of the two single-entry
+// kernels above, block for block: the same bits.
+struct ColsumTable {
+    const float* x[32];
+    float* out[32];
+    long ld[32];
+    int rows[32], cols[32], kind[32], vec_ok[32];
+    int block0[33];
+    int n;
+};
+__global__ void __launch_bounds__(256) colsum_multi_kernel(ColsumTable tb) {
+    int ei = 0;
+    while (ei + 1 < tb.n && (int)blockIdx.x >= tb.block0[ei + 1]) ++ei;
+    const int bx = (int)blockIdx.x - tb.block0[ei];
+    if (tb.kind[ei] == 0) colsum_block<float>(tb.x[ei], tb.ld[ei], tb.out[ei], tb.rows[ei], tb.cols[ei], tb.vec_ok[ei], tb.rows[ei], bx, 0);
+    else colsum_final_cols(tb.x[ei], tb.out[ei], tb.rows[ei], tb.cols[ei], 0, bx * 256 + (int)threadIdx.x);
 }
 
 // ---- LayerNorm forward with saved statistics ---------------------------------------------------------------------------
@@ -443,17 +467,9 @@ extern "C" int amds_sum_partials_multi(const float* const* parts_host, float* co
 }
 
 extern "C" size_t amds_colsum_workspace_bytes(int M, int N) { return (size_t)cdiv(M, CS_ROWS) * N * 4; }
-extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    AMDS_REQUIRE(x && out && ws, "amds_colsum: null pointer");
-    AMDS_REQUIRE(M > 0 && N > 0, "amds_colsum: bad shape");
-    // up to 2 x CS_ROWS rows are ONE chunk (split-K partials: 32 rows; LayerNorm parameter-gradient partials: rows / 64; bags): without
-    // `accumulate` its "partial" IS the result and the second launch is skipped (30 -> 19 colsum_final launches per MIL training step)
-    const int nchunk = M <= 2 * CS_ROWS ? 1 : cdiv(M, CS_ROWS);
+// stage 1 of amds_colsum alone: part[c][n] = sum of the rows of chunk c (chunks of CS_ROWS rows; up to 2 x CS_ROWS rows are ONE chunk)
+static int colsum_stage1(const void* x, long ld, float* part, int M, int N, int in_dtype, int nchunk, hipStream_t st) {
     const int cs_rows = nchunk == 1 ? M : CS_ROWS;
-    if (ws_bytes < (size_t)nchunk * N * 4) { set_error("amds_colsum: workspace too small"); return AMDS_ERR_WORKSPACE; }
-    hipStream_t st = (hipStream_t)stream;
-    const bool direct = nchunk == 1 && !accumulate;
-    float* part = direct ? out : (float*)ws;
     const dim3 grid(cdiv(N, 64), nchunk);
     const int esz = in_dtype == AMDS_F32 ? 4 : 2;
     const int vec_ok = (ld % 4 == 0) && (((uintptr_t)x % (4 * esz)) == 0);      // 4-element vector loads need aligned rows
@@ -464,9 +480,54 @@ extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int
     else if (in_dtype == AMDS_F16) hipLaunchKernelGGL((colsum_partial_kernel<f16>), grid, dim3(256), 0, st, (const f16*)x, ld, part, M, N, vec_ok, cs_rows);
     else { set_error("amds_colsum: bad dtype"); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("colsum_partial_kernel");
-    if (direct) return AMDS_OK;
+    return AMDS_OK;
+}
+static inline int colsum_chunks(int M) { return M <= 2 * CS_ROWS ? 1 : cdiv(M, CS_ROWS); }
+
+extern "C" int amds_colsum(const void* x, long ld, float* out, int M, int N, int in_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(x && out && ws, "amds_colsum: null pointer");
+    AMDS_REQUIRE(M > 0 && N > 0, "amds_colsum: bad shape");
+    // up to 2 x CS_ROWS rows are ONE chunk (split-K partials: 32 rows; LayerNorm parameter-gradient partials: rows / 64; bags): without
+    // `accumulate` its "partial" IS the result and the second launch is skipped (30 -> 19 colsum_final launches per MIL training step)
+    const int nchunk = colsum_chunks(M);
+    if (ws_bytes < (size_t)nchunk * N * 4) { set_error("amds_colsum: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool direct = nchunk == 1 && !accumulate;
+    float* part = direct ? out : (float*)ws;
+    int rc = colsum_stage1(x, ld, part, M, N, in_dtype, nchunk, st);
+    if (rc != AMDS_OK || direct) return rc;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, out, nchunk, N, accumulate);
     AMDS_LAUNCH_CHECK("colsum_final_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_colsum_partials(const void* x, long ld, float* part, int M, int N, int in_dtype, int* nchunk_out, void* stream) {
+    AMDS_REQUIRE(x && part && nchunk_out, "amds_colsum_partials: null pointer");
+    AMDS_REQUIRE(M > 0 && N > 0, "amds_colsum_partials: bad shape");
+    const int nchunk = colsum_chunks(M);
+    *nchunk_out = nchunk;
+    return colsum_stage1(x, ld, part, M, N, in_dtype, nchunk, (hipStream_t)stream);
+}
+
+extern "C" int amds_colsum_multi(const amds_colsum_entry* entries_host, int n, void* stream) {
+    AMDS_REQUIRE(entries_host && n > 0 && n <= 32, "amds_colsum_multi: 1 .. 32 entries (n=%d)", n);
+    ColsumTable tb;
+    tb.n = n;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const amds_colsum_entry& e = entries_host[i];
+        AMDS_REQUIRE(e.x && e.out && e.rows > 0 && e.cols > 0 && (e.kind == 0 || e.kind == 1), "amds_colsum_multi: entry %d: bad pointers / shape / kind", i);
+        AMDS_REQUIRE(e.kind == 1 || (e.rows <= 2 * CS_ROWS && e.ld >= e.cols), "amds_colsum_multi: entry %d: a direct sum takes at most %d rows (got %d) and ld >= cols", i, 2 * CS_ROWS, e.rows);
+        tb.x[i] = e.x; tb.out[i] = e.out; tb.ld[i] = e.kind == 0 ? e.ld : e.cols;
+        tb.rows[i] = e.rows; tb.cols[i] = e.cols; tb.kind[i] = e.kind;
+        tb.vec_ok[i] = (e.ld % 4 == 0) && (((uintptr_t)e.x % 16) == 0);
+        tb.block0[i] = (int)blocks;
+        blocks += e.kind == 0 ? cdiv(e.cols, 64) : cdiv(e.cols, 256);
+        AMDS_REQUIRE(blocks < (1L << 30), "amds_colsum_multi: too many columns");
+    }
+    tb.block0[n] = (int)blocks;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb);
+    AMDS_LAUNCH_CHECK("colsum_multi_kernel");
     return AMDS_OK;
 }
 
@@ -512,31 +573,43 @@ extern "C" int amds_layernorm_bwd(const float* dy, long dy_stride, const float* 
                                    nullptr, 0, 0.f, 0, 0, stream);
 }
 
-extern "C" int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
-                                       const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
-                                       int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed,
-                                       uint32_t stream_id, void* stream) {
-    AMDS_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "amds_layernorm_bwd: null pointer");
+extern "C" int amds_layernorm_bwd_partials(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                                           const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma_part, float* dbeta_part,
+                                           int rows, int cols, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma_part && dbeta_part, "amds_layernorm_bwd: null pointer");
     AMDS_REQUIRE(!dx_bf16 || (dx_bf16_stride >= cols && dx_bf16_stride % 4 == 0 && p >= 0.f && p < 1.f), "amds_layernorm_bwd_cast: bad 16-bit output / rate");
     const uint32_t dthr = (dx_bf16 && p > 0.f) ? drop_thr16(p) : 0;
     const float dscale = dthr ? drop_scale(dthr) : 1.0f;
     AMDS_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "amds_layernorm_bwd: bad shape");
-    if (ws_bytes < amds_layernorm_bwd_workspace_bytes(rows, cols)) { set_error("amds_layernorm_bwd: workspace too small"); return AMDS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const int nblk = cdiv(rows, 64);
-    float* dgp = (float*)ws;
-    float* dbp = dgp + (size_t)nblk * cols;
-    char* cws = (char*)(dbp + (size_t)nblk * cols);
-    const size_t cws_bytes = amds_colsum_workspace_bytes(nblk, cols);
 #define AMDS_LN_BWD(MV)                                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<MV>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, \
-                       dx_stride, add_skip, dgp, dbp, rows, cols, (bf16*)dx_bf16, dx_bf16_stride, seed, stream_id, dthr, dscale)
+                       dx_stride, add_skip, dgamma_part, dbeta_part, rows, cols, (bf16*)dx_bf16, dx_bf16_stride, seed, stream_id, dthr, dscale)
     if (cols <= 512) AMDS_LN_BWD(2);
     else if (cols <= 1024) AMDS_LN_BWD(4);
     else AMDS_LN_BWD(8);
 #undef AMDS_LN_BWD
     AMDS_LAUNCH_CHECK("ln_bwd_kernel");
-    int rc = amds_colsum(dgp, cols, dgamma, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
+    return AMDS_OK;
+}
+
+extern "C" int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
+                                       const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
+                                       int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed,
+                                       uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(dgamma && dbeta && ws, "amds_layernorm_bwd: null pointer");
+    AMDS_REQUIRE(rows > 0 && cols > 0, "amds_layernorm_bwd: bad shape");
+    if (ws_bytes < amds_layernorm_bwd_workspace_bytes(rows, cols)) { set_error("amds_layernorm_bwd: workspace too small"); return AMDS_ERR_WORKSPACE; }
+    const int nblk = cdiv(rows, 64);
+    float* dgp = (float*)ws;
+    float* dbp = dgp + (size_t)nblk * cols;
+    char* cws = (char*)(dbp + (size_t)nblk * cols);
+    const size_t cws_bytes = amds_colsum_workspace_bytes(nblk, cols);
+    int rc = amds_layernorm_bwd_partials(dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, dx_stride, add_skip, dgp, dbp, rows, cols, dx_bf16, dx_bf16_stride, p, seed,
+                                         stream_id, stream);
+    if (rc != AMDS_OK) return rc;
+    rc = amds_colsum(dgp, cols, dgamma, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
     if (rc != AMDS_OK) return rc;
     return amds_colsum(dbp, cols, dbeta, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
 }

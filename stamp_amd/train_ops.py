@@ -35,6 +35,33 @@ def cast_transpose_multi(entries: list) -> None:
         _lib.check(_lib.lib().amds_cast_transpose_multi(arr, len(chunk), _stream()), "cast_transpose_multi")
 
 
+def colsum_multi(xs: list[torch.Tensor]) -> list[torch.Tensor]:
+    """Column sums of several matrices (fp32 with at most 2048 rows summed directly; anything else through its chunk partials) finished by ONE launch per 32
+    matrices (`amds_colsum_multi`): the bits of `colsum` on each, which is how the MIL `vit` backward finishes its LayerNorm / bias / class-token gradients."""
+    lib = _lib.lib()
+    outs, keep = [], []
+    entries = []
+    for x in xs:
+        _dev(x)
+        assert x.dim() == 2 and x.stride(1) == 1
+        M, N = x.shape
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+        outs.append(out)
+        if M <= 2048 and x.dtype == torch.float32:
+            entries.append(_lib.ColsumEntry(_p(x), _p(out), x.stride(0), M, N, 0))
+        else:
+            part = torch.empty(max(lib.amds_colsum_workspace_bytes(M, N), 4 * N), dtype=torch.uint8, device=x.device)
+            keep.append(part)
+            nchunk = _lib.C.c_int(0)
+            _lib.check(lib.amds_colsum_partials(_p(x), x.stride(0), _p(part), M, N, _DT[x.dtype], _lib.C.byref(nchunk), _stream()), "colsum_partials")
+            entries.append(_lib.ColsumEntry(_p(part), _p(out), N, nchunk.value, N, 1))
+    for i in range(0, len(entries), 32):
+        chunk = entries[i:i + 32]
+        arr = (_lib.ColsumEntry * len(chunk))(*chunk)
+        _lib.check(lib.amds_colsum_multi(arr, len(chunk), _stream()), "colsum_multi")
+    return outs
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
     _dev(x)
     assert x.dim() == 2 and x.stride(1) == 1

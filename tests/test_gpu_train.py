@@ -19,6 +19,25 @@ def test_transpose_colsum(gpu):
     assert torch.equal(T.colsum(x), s)                # deterministic
 
 
+def test_colsum_multi_is_colsum_bit_for_bit(gpu):
+    """amds_colsum_multi finishes many column sums with one launch: direct sums of small fp32 matrices (also pitched rows, odd widths) and the second
+    stage over amds_colsum_partials' chunk partials -- the bits of amds_colsum on every matrix."""
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(1025, 512, generator=g).to(gpu),                       # LayerNorm parameter-gradient partials of 65 600 rows
+          torch.randn(64, 2, generator=g).to(gpu),                           # head bias: two columns, unaligned rows
+          torch.randn(64, 1025 * 512, generator=g).to(gpu)[:, :512],         # class-token rows: a pitched view
+          torch.randn(2048, 300, generator=g).to(gpu),
+          torch.randn(65600, 512, generator=g).to(gpu, torch.bfloat16),      # bias gradients over 16-bit tensors: 65 chunks
+          torch.randn(65600, 1536, generator=g).to(gpu, torch.bfloat16),
+          torch.randn(4100, 130, generator=g).to(gpu),                       # fp32, 5 chunks, scalar column tail
+          torch.randn(1, 64, generator=g).to(gpu)]
+    xs = xs * 5                                                              # 40 entries: two launches
+    got = T.colsum_multi(xs)
+    for x, s in zip(xs, got):
+        assert torch.equal(s, T.colsum(x)), tuple(x.shape)
+        assert (s.cpu().double() - x.double().sum(0).cpu()).abs().max() < 2e-2 * max(1.0, (x.shape[0] / 1000) ** 0.5)
+
+
 @pytest.mark.parametrize("R,C,ld", [(128, 64, None), (1024, 512, None), (640, 2048, 704), (64 * 1025, 512, None)])
 def test_transpose_vector_path(gpu, R, C, ld):
     """R and C multiples of 64 take the 16-byte-per-lane kernel; `ld` = a padded destination pitch."""
