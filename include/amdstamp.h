@@ -842,6 +842,17 @@ int amds_barspoon_forward(const amds_barspoon_cfg* cfg_host, const amds_barspoon
  * TransMIL building blocks (reference src/stamp/modeling/models/trans_mil.py), fp32 throughout
  * ---------------------------------------------------------------------------------------------- */
 
+/* Precision of the fp32 batched products below -- the library's counterpart of `torch.set_float32_matmul_precision`, which the reference sets to "high"
+ * before every training run (src/stamp/modeling/train.py:519) and to "medium" for deployment (src/stamp/modeling/deploy.py:398).  Process-wide, like torch's.
+ *   AMDS_MATMUL_HIGHEST (default): fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32), exact products.
+ *   AMDS_MATMUL_HIGH: every operand value as the sum of two bf16 numbers, three bf16 MFMAs per product (hi hi + hi lo + lo hi), fp32 accumulate: ~16 mantissa
+ *     bits per factor -- one of the two implementations torch documents for "high" (the other, TF32, keeps 10).
+ * Applies to amds_bgemm_f32's tiled kernels (every product of the TransMIL / Nystrom paths, the MLP heads' training GEMMs); the 64 x 64 fallback kernel for
+ * small or unaligned products and everything that is not a matrix product stay exact. */
+#define AMDS_MATMUL_HIGHEST 0
+#define AMDS_MATMUL_HIGH 1
+int amds_set_matmul_precision(int level);
+int amds_get_matmul_precision(void);
 /* Batched fp32 GEMM on the exact-fp32 MFMA: for z = (o, i), o < outer, i < inner:
  *   C[o,i] (+)= diag*I + alpha * A[o,i] * op(B[o,i]) + bias[n];  op(B) = B^T if transb (B stored [N][K]) else B ([K][N]).
  * Operand z starts at base + o*s?o + i*s?i (elements), so head slices of a packed qkv tensor are addressed in place.

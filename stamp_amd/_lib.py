@@ -292,6 +292,8 @@ PROTOTYPES = {
     "amds_topk_rows_mean": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp]),
     "amds_pinv_init_bwd_workspace_bytes": (_sz, [_i]),
     "amds_pinv_init_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "amds_set_matmul_precision": (_i, [_i]),
+    "amds_get_matmul_precision": (_i, []),
     "amds_gemm_batched": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp]),
     "amds_wgrad_tn": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp]),
     "amds_transpose16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),

@@ -10,6 +10,7 @@
 //   amds_dwconv_seq       depth-wise (per head) 33-tap convolution along the sequence, added in place (:150-151)
 //   amds_ppeg             x + dw7x7(x) + dw5x5(x) + dw3x3(x) on the sqrt(T) x sqrt(T) token grid (:274-283)
 #include "common.h"
+#include <atomic>
 
 namespace amds {
 
@@ -93,7 +94,21 @@ __global__ void __launch_bounds__(256) bgemm_f32_kernel(const float* __restrict_
 // aligned operands; the 64 x 64 kernel above remains the fallback.
 // WM x WN = 4 waves: 2 x 2 -> 128 x 128 tile; 4 x 1 -> 256 x 64 (products with N <= 64: the per-head d = 64 outputs would leave half of
 // a 128-wide tile empty); 1 x 4 -> 64 x 256 (M <= 64).
-template <int TRANSB, int TRANSA = 0, int WM = 2, int WN = 2>
+// X3 = 1 (amds_set_matmul_precision(AMDS_MATMUL_HIGH)): every fp32 operand value as the sum of two bf16 numbers, the product as three bf16 MFMAs
+// (hi hi + hi lo + lo hi, fp32 accumulate: ~16 mantissa bits) -- what `torch.set_float32_matmul_precision("high")` names ("treat each float32 number as the
+// sum of two bfloat16 numbers"), which the reference sets before every training run (src/stamp/modeling/train.py:519; deploy.py:398 asks for "medium").
+// Same loaders, same fp32 LDS images; a fragment (8 k values of a row) is split in registers on its way to the matrix pipe: 12 MFMAs of 32 cycles per 16-deep
+// K step and wave instead of 32 of 64 cycles (v_mfma_f32_32x32x2_f32).
+__device__ __forceinline__ void split_bf16x2(const f32x4 (&f)[2], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = f[e >> 2][e & 3];
+        const bf16 h = (bf16)x;
+        hi[e] = h;
+        lo[e] = (bf16)(x - (float)h);
+    }
+}
+template <int TRANSB, int TRANSA = 0, int WM = 2, int WN = 2, int X3 = 0>
 __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restrict__ A, int lda, long sAo, long sAi,
                                                             const float* __restrict__ B, int ldb, long sBo, long sBi,
                                                             float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
@@ -222,6 +237,22 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
             frag(TA{}, sA, wm * 64 + i * 32 + l31, LKA, fa[i]);
             frag(TBK{}, sB, wn * 64 + i * 32 + l31, LKB, fb[i]);
         }
+        if constexpr (X3) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split_bf16x2(fa[i], ah[i], al[i]);
+                split_bf16x2(fb[i], bh[i], bl[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        } else {
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp)
 #pragma unroll
@@ -229,6 +260,7 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kp >> 2][kp & 3], fb[j][kp >> 2][kp & 3], acc[i][j], 0, 0, 0);
+        }
         __syncthreads();
     }
     };
@@ -836,6 +868,15 @@ extern "C" int amds_pinv_init_bwd(const float* x, const float* dz0, float* dx, i
     return AMDS_OK;
 }
 
+// process-wide, like torch's flag: the precision of the fp32 batched products (amds_bgemm_f32's 128 x 128 / 256 x 64 / 64 x 256 tile kernels)
+static std::atomic<int> g_matmul_precision{AMDS_MATMUL_HIGHEST};
+extern "C" int amds_set_matmul_precision(int level) {
+    AMDS_REQUIRE(level == AMDS_MATMUL_HIGHEST || level == AMDS_MATMUL_HIGH, "amds_set_matmul_precision: level must be AMDS_MATMUL_HIGHEST (0) or AMDS_MATMUL_HIGH (1), got %d", level);
+    g_matmul_precision.store(level, std::memory_order_relaxed);
+    return AMDS_OK;
+}
+extern "C" int amds_get_matmul_precision(void) { return g_matmul_precision.load(std::memory_order_relaxed); }
+
 extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                               float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                               float diag, const float* bias, int accumulate, void* stream) {
@@ -853,9 +894,14 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
         const dim3 grid3(cdiv(N, shape == 1 ? 64 : shape == 2 ? 256 : 128), cdiv(M, shape == 1 ? 256 : shape == 2 ? 64 : 128), outer * inner);
         const int vec = vec_ok ? 1 : 0;
         static const int xcd = [] { const char* e = getenv("AMDS_BGEMM_XCD"); return e ? atoi(e) : 1; }();      // 0: launch order (A/B)
+        const bool x3 = g_matmul_precision.load(std::memory_order_relaxed) != AMDS_MATMUL_HIGHEST;
 #define AMDS_BG(TB, TA, WM_, WN_)                                                                                                              \
-    hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
-                       inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd)
+    do {                                                                                                                                       \
+        if (x3) hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_, 1>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
+                                   inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd);                                                  \
+        else hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_, 0>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
+                                inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd);                                                     \
+    } while (0)
 #define AMDS_BG_SHAPE(TB, TA)                                     \
     do {                                                          \
         if (shape == 1) AMDS_BG(TB, TA, 4, 1);                    \

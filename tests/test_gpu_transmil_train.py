@@ -97,6 +97,58 @@ def test_transmil_train_mode_dropout_and_optimizer(gpu):
     assert sum(losses[-3:]) < sum(losses[:3])
 
 
+@pytest.mark.parametrize("Z,M,N,K", [(6, 256, 64, 1280), (3, 130, 70, 52), (1, 512, 1024, 1024), (16, 256, 256, 256), (4, 64, 512, 64), (2, 1280, 256, 64)])
+@pytest.mark.parametrize("transa,transb", [(False, False), (False, True), (True, False), (True, True)])
+def test_bgemm_f32_high_precision_mode(gpu, Z, M, N, K, transa, transb):
+    """`set_float32_matmul_precision("high")` (the reference's training setting, train.py:519): fp32 operands as hi + lo bf16, three bf16 MFMAs per product.
+    Stated tolerance: 2e-5 relative L2 against the fp64 product (measured ~2e-6: 16+ mantissa bits per factor; TF32, torch's other form of "high", gives
+    ~3e-4) on every tile shape and operand layout; values spanning 2^+-20 (the split has the exponent range of fp32, unlike an fp16 split); alpha / diag /
+    accumulate epilogue unchanged; the level is restored by the context manager and "highest" stays bit-identical to the default."""
+    from stamp_amd import ops
+    from stamp_amd import transmil_core as tc
+    g = torch.Generator().manual_seed(Z * 7 + M + K)
+    A = (torch.randn(Z, K, M, generator=g) if transa else torch.randn(Z, M, K, generator=g))
+    B = (torch.randn(Z, N, K, generator=g) if transb else torch.randn(Z, K, N, generator=g))
+    A = (A * torch.exp2(torch.randint(-20, 21, (Z, 1, 1), generator=g).float())).to(gpu)
+    B = B.to(gpu)
+    Ad = A.double().transpose(1, 2) if transa else A.double()
+    want = Ad @ (B.double().transpose(1, 2) if transb else B.double())
+    exact = tc._mm(A, B, transb, transa=transa)
+    assert ops.get_float32_matmul_precision() == "highest"
+    with ops.float32_matmul_precision("high"):
+        assert ops.get_float32_matmul_precision() == "high"
+        out = tc._mm(A, B, transb, transa=transa)
+        assert torch.equal(out, tc._mm(A, B, transb, transa=transa))          # deterministic
+    assert ops.get_float32_matmul_precision() == "highest"
+    assert torch.equal(exact, tc._mm(A, B, transb, transa=transa))
+    for z in range(Z):                                                         # per batch: the batches differ by 2^40 in scale
+        e = ((out[z].double() - want[z]).norm() / want[z].norm()).item()
+        assert e < 2e-5, (z, e)
+        assert ((exact[z].double() - want[z]).norm() / want[z].norm()).item() < 2e-6
+
+
+@pytest.mark.parametrize("Bb,Tn,Fd,Cd", [(3, 300, 128, 128), (2, 1024, 1024, 512)])
+def test_transmil_backward_high_precision_mode(gpu, Bb, Tn, Fd, Cd):
+    """The TransMIL training step with the reference's own matmul setting ("high", train.py:519): logits and every gradient against fp64 autograd.
+    Stated tolerance 2e-4 relative L2 per gradient (measured <= 3.5e-5; six cubic pinv iterations amplify the products' 2^-17 rounding; TF32 -- what the reference gets from
+    the same setting on an NVIDIA part -- would be 30x coarser per product)."""
+    from stamp_amd import ops
+    model, bags, targets = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn)
+    ref_loss, ref_logits, ref_g, ref_dx = _oracle(model, bags, targets)
+    model = model.to(gpu).eval()
+    x = bags.to(gpu).requires_grad_(True)
+    with ops.float32_matmul_precision("high"):
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits, targets.to(gpu))
+        loss.backward()
+    assert abs(loss.item() - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
+    assert (logits.detach().cpu().double() - ref_logits).abs().max() < 2e-3 * max(1.0, ref_logits.abs().max().item())
+    worst = sorted([(_rel(p.grad.cpu(), ref_g[n]), n) for n, p in model.named_parameters()] + [(_rel(x.grad.cpu(), ref_dx), "bags")], reverse=True)
+    print(f"TransMIL high {Bb}x{Tn}x{Fd} hidden {Cd}: largest gradient errors", [(round(a, 7), b) for a, b in worst[:5]])
+    for rel, n in worst:
+        assert rel < 2e-4, (n, rel)
+
+
 @pytest.mark.parametrize("Z,M,N,K", [(6, 256, 64, 1280), (3, 130, 70, 50), (1, 512, 1024, 1024)])
 @pytest.mark.parametrize("transb", [False, True])
 def test_bgemm_f32_transposed_a_and_split_k_wgrad(gpu, Z, M, N, K, transb):
