@@ -1,7 +1,9 @@
 // transmil.hip -- building blocks of the TransMIL head, all in fp32 like the reference:
 // reference src/stamp/modeling/models/trans_mil.py -- NystromAttention.forward :81-163, moore_penrose_iter_pinv :23-37,
 // PPEG.forward :274-283.  The Nystrom pseudo-inverse iteration is numerically touchy (6 cubic iterations on softmax
-// matrices), so every matmul here runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).
+// matrices), so by default every matmul here runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain);
+// under torch.set_float32_matmul_precision("high") -- which the reference sets before training, train.py:519 -- the tiled
+// products take fp32 operands as hi + lo bf16 and three bf16 MFMAs each (amds_set_matmul_precision, bgemm_x3_kernel below).
 //   amds_bgemm_f32        C[z] = diag*I + alpha * A[z] op(B[z])   batched over (outer, inner) with separate strides,
 //                         op(B) = B^T (B stored [N][K], "x y^T" products) or B (stored [K][N])
 //   amds_softmax_rows     in-place row softmax, any row length
@@ -297,6 +299,184 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
         if (interior) store(std::true_type{}, std::false_type{});
         else store(std::false_type{}, std::false_type{});
     }
+}
+
+// ---- amds_set_matmul_precision(AMDS_MATMUL_HIGH), aligned products: the split happens ONCE per element, on its way into LDS ---------------------------------
+// bgemm_f32_big_kernel<.., X3 = 1> splits every fragment in every wave that reads it, keeps fp32 LDS images, 16-deep K steps and two barriers per step: it is bound by
+// that, not by its 12 MFMAs per step (1.6x the fp32 kernel).  Here: K steps of 32, global -> registers -> (hi | lo) bf16 images, double-buffered (one barrier per
+// step), a fragment = 8 consecutive k of a row as ONE ds_read_b128 (row-major operands: [row][32 k], pitch 80 B) or four ds_read_b32 of (k, k + 1) pairs
+// (k-major operands: [16 k pairs][rows + 8][2], written as ds_write_b128 of four rows' pairs: a thread fetches the float4 of k and of k + 1).  Only products whose
+// tiles are all interior and aligned (M % BM == N % BN == K % 32 == 0, float4 loads) come here -- every Nystrom / pinv / projection shape; the rest stays on the
+// kernel above.  Same epilogue (alpha, + diag I, bias, accumulate), same tile shapes and XCD order.
+template <int TRANSB, int TRANSA, int WM, int WN>
+__global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__ A, int lda, long sAo, long sAi, const float* __restrict__ B, int ldb, long sBo,
+                                                       long sBi, float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner, int M, int N, int K, float alpha,
+                                                       float diag, const float* __restrict__ bias, int accumulate, int xcd) {
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
+    constexpr int TRA = TRANSA, TRB = TRANSB ? 0 : 1;
+    constexpr int PR = 80;                                           // row-major image: bytes per row (64 + 16: ds_read_b128 of 16 consecutive rows hit 16 bank groups)
+    constexpr int IMG_A = TRA ? 16 * (BM + 8) * 4 : BM * PR, IMG_B = TRB ? 16 * (BN + 8) * 4 : BN * PR;      // bytes of ONE (hi or lo) image
+    constexpr int STAGE = 2 * IMG_A + 2 * IMG_B;
+    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;    // float4 per thread and K step
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd) {                                                       // (as bgemm_f32_big_kernel)
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+        const int L = bx + gx * (by + gy * bz), q = total >> 3, r = total & 7, x = L & 7;
+        const int Lp = x * q + min(x, r) + (L >> 3);
+        bx = Lp % gx;
+        const int t = Lp / gx;
+        by = t % gy;
+        bz = t / gy;
+    }
+    const int zo = bz / inner, zi = bz - zo * inner;
+    A += zo * sAo + zi * sAi;
+    B += zo * sBo + zi * sBi;
+    Cm += zo * sCo + zi * sCi;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int wm = wave / WN, wn = wave % WN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NA], rb[NB];
+    // row-major source: piece c = (row, 4 k); k-major source: pieces come in pairs (k, k + 1) of the same four rows
+    auto gload_op = [&](auto tr_c, auto n_c, f32x4* r, const float* P, int ld, int r0, int k0, auto rt_c) {
+        constexpr int TR = decltype(tr_c)::value, NP = decltype(n_c)::value, RT = decltype(rt_c)::value;
+        if constexpr (TR) {
+#pragma unroll
+            for (int it = 0; it < NP / 2; ++it) {
+                const int c = it * 256 + tid, kp = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
+                const float* src = P + (long)(k0 + 2 * kp) * ld + r0 + q4;
+                r[2 * it] = *reinterpret_cast<const f32x4*>(src);
+                r[2 * it + 1] = *reinterpret_cast<const f32x4*>(src + ld);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NP; ++it) {
+                const int c = it * 256 + tid, row = c >> 3, c4 = (c & 7) * 4;
+                r[it] = *reinterpret_cast<const f32x4*>(P + (long)(r0 + row) * ld + k0 + c4);
+            }
+        }
+    };
+    auto split4 = [&](const f32x4& v, bf16x4& h, bf16x4& l) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16 t = (bf16)v[e];
+            h[e] = t;
+            l[e] = (bf16)(v[e] - (float)t);
+        }
+    };
+    auto lstore_op = [&](auto tr_c, auto n_c, const f32x4* r, char* Sh, char* Sl, auto rt_c) {
+        constexpr int TR = decltype(tr_c)::value, NP = decltype(n_c)::value, RT = decltype(rt_c)::value;
+        if constexpr (TR) {
+#pragma unroll
+            for (int it = 0; it < NP / 2; ++it) {
+                const int c = it * 256 + tid, kp = c / (RT / 4), q4 = (c % (RT / 4)) * 4;
+                bf16x4 h0, l0, h1, l1;
+                split4(r[2 * it], h0, l0);
+                split4(r[2 * it + 1], h1, l1);
+                bf16x8 wh, wl;                                       // four rows' (k, k + 1) pairs
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wh[2 * e] = h0[e]; wh[2 * e + 1] = h1[e]; wl[2 * e] = l0[e]; wl[2 * e + 1] = l1[e]; }
+                *reinterpret_cast<bf16x8*>(Sh + (kp * (RT + 8) + q4) * 4) = wh;
+                *reinterpret_cast<bf16x8*>(Sl + (kp * (RT + 8) + q4) * 4) = wl;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NP; ++it) {
+                const int c = it * 256 + tid, row = c >> 3, c4 = (c & 7) * 4;
+                bf16x4 h, l;
+                split4(r[it], h, l);
+                *reinterpret_cast<bf16x4*>(Sh + row * PR + c4 * 2) = h;
+                *reinterpret_cast<bf16x4*>(Sl + row * PR + c4 * 2) = l;
+            }
+        }
+    };
+    auto frag = [&](auto tr_c, const char* S, int row, int s16, auto rt_c) -> bf16x8 {       // k = s16 * 16 + hi * 8 + (0 .. 7) of one row
+        constexpr int TR = decltype(tr_c)::value, RT = decltype(rt_c)::value;
+        if constexpr (TR) {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const unsigned*>(S + ((s16 * 8 + hi * 4 + j) * (RT + 8) + row) * 4);
+            return __builtin_bit_cast(bf16x8, w);
+        } else {
+            return *reinterpret_cast<const bf16x8*>(S + row * PR + s16 * 32 + hi * 16);
+        }
+    };
+    typedef std::integral_constant<int, TRA> TA;
+    typedef std::integral_constant<int, TRB> TBK;
+    typedef std::integral_constant<int, NA> CA;
+    typedef std::integral_constant<int, NB> CB;
+    typedef std::integral_constant<int, BM> RA;
+    typedef std::integral_constant<int, BN> RB;
+    auto stage_ptr = [&](int st, int which) { return smem + st * STAGE + (which == 0 ? 0 : which == 1 ? IMG_A : which == 2 ? 2 * IMG_A : 2 * IMG_A + IMG_B); };
+    gload_op(TA{}, CA{}, ra, A, lda, m0, 0, RA{});
+    gload_op(TBK{}, CB{}, rb, B, ldb, n0, 0, RB{});
+    lstore_op(TA{}, CA{}, ra, stage_ptr(0, 0), stage_ptr(0, 1), RA{});
+    lstore_op(TBK{}, CB{}, rb, stage_ptr(0, 2), stage_ptr(0, 3), RB{});
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = k0 + BK < K;
+        if (more) {
+            gload_op(TA{}, CA{}, ra, A, lda, m0, k0 + BK, RA{});
+            gload_op(TBK{}, CB{}, rb, B, ldb, n0, k0 + BK, RB{});
+        }
+        const char *sAh = stage_ptr(cur, 0), *sAl = stage_ptr(cur, 1), *sBh = stage_ptr(cur, 2), *sBl = stage_ptr(cur, 3);
+#pragma unroll
+        for (int s16 = 0; s16 < 2; ++s16) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = frag(TA{}, sAh, wm * 64 + i * 32 + l31, s16, RA{});
+                al[i] = frag(TA{}, sAl, wm * 64 + i * 32 + l31, s16, RA{});
+                bh[i] = frag(TBK{}, sBh, wn * 64 + i * 32 + l31, s16, RB{});
+                bl[i] = frag(TBK{}, sBl, wn * 64 + i * 32 + l31, s16, RB{});
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            lstore_op(TA{}, CA{}, ra, stage_ptr(cur ^ 1, 0), stage_ptr(cur ^ 1, 1), RA{});
+            lstore_op(TBK{}, CB{}, rb, stage_ptr(cur ^ 1, 2), stage_ptr(cur ^ 1, 3), RB{});
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    auto store = [&](auto diag_c) {
+        constexpr bool DG = decltype(diag_c)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            const float bn = bias ? bias[n] : 0.f;
+            float* cn = Cm + n;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = alpha * acc[i][j][r] + bn;
+                    if (DG) v += m == n ? diag : 0.f;
+                    if (accumulate) v += cn[(long)m * ldc];
+                    cn[(long)m * ldc] = v;
+                }
+        }
+    };
+    if (diag != 0.f) store(std::true_type{});
+    else store(std::false_type{});
 }
 
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long rows, int cols) {
@@ -908,6 +1088,28 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
         else if (shape == 2) AMDS_BG(TB, TA, 1, 4);               \
         else AMDS_BG(TB, TA, 2, 2);                               \
     } while (0)
+        // "high": products made of whole aligned tiles go to the kernel that splits on the way into LDS (AMDS_BGEMM_X3_LDS=0: the in-register split, A/B)
+        static const bool x3_lds = !(getenv("AMDS_BGEMM_X3_LDS") && atoi(getenv("AMDS_BGEMM_X3_LDS")) == 0);
+        const int bm = shape == 1 ? 256 : shape == 2 ? 64 : 128, bn = shape == 1 ? 64 : shape == 2 ? 256 : 128;
+        if (x3 && x3_lds && vec_ok && M % bm == 0 && N % bn == 0 && K % 32 == 0) {
+#define AMDS_BX(TB, TA, WM_, WN_) \
+    hipLaunchKernelGGL((bgemm_x3_kernel<TB, TA, WM_, WN_>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, \
+                       diag, bias, accumulate, xcd)
+#define AMDS_BX_SHAPE(TB, TA)                                     \
+    do {                                                          \
+        if (shape == 1) AMDS_BX(TB, TA, 4, 1);                    \
+        else if (shape == 2) AMDS_BX(TB, TA, 1, 4);               \
+        else AMDS_BX(TB, TA, 2, 2);                               \
+    } while (0)
+            if (transb && transa) AMDS_BX_SHAPE(1, 1);
+            else if (transb) AMDS_BX_SHAPE(1, 0);
+            else if (transa) AMDS_BX_SHAPE(0, 1);
+            else AMDS_BX_SHAPE(0, 0);
+#undef AMDS_BX_SHAPE
+#undef AMDS_BX
+            AMDS_LAUNCH_CHECK("bgemm_x3_kernel");
+            return AMDS_OK;
+        }
         if (transb && transa) AMDS_BG_SHAPE(1, 1);
         else if (transb) AMDS_BG_SHAPE(1, 0);
         else if (transa) AMDS_BG_SHAPE(0, 1);

@@ -396,6 +396,7 @@ class _PPEGParams(nn.Module):
 
 def _bgemm(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha=1.0, diag=0.0,
            bias=None, accumulate=False):
+    ops.sync_float32_matmul_precision()
     _lib.check(_lib.lib().amds_bgemm_f32(A, lda, sAo, sAi, B, ldb, sBo, sBi, 1 if transb else 0, Cm, ldc, sCo, sCi, outer, inner,
                                          M, N, K, alpha, diag, bias, 1 if accumulate else 0,
                                          torch.cuda.current_stream().cuda_stream), "bgemm_f32")
@@ -497,6 +498,7 @@ class TransMIL(nn.Module):
             _lib.check(-1, "transmil_workspace_bytes")
         ws = ops.scratch("transmil", dev, need)
         logits = torch.empty(Bb, self.n_classes, dtype=torch.float32, device=dev)
+        ops.sync_float32_matmul_precision()
         _lib.check(lib.amds_transmil_forward(C.byref(cfg), C.byref(w), h.data_ptr(), ops._DT[h.dtype], logits.data_ptr(), Bb, T, ws.data_ptr(), ws.numel(),
                                              torch.cuda.current_stream().cuda_stream), "transmil_forward")
         return logits

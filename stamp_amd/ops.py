@@ -49,36 +49,32 @@ def act_code(dtype: torch.dtype) -> int:
     return _DT[dtype]
 
 
-_MATMUL_LEVELS = {"highest": 0, "high": 1, "medium": 1}        # "medium" (bf16 x 1 in torch) is served by the more exact "high" form
-
-
-def set_float32_matmul_precision(precision: str) -> None:
-    """The library's `torch.set_float32_matmul_precision` (process-wide): "highest" = exact fp32 MFMA products (default), "high" = every fp32 operand as the sum
-    of two bf16 numbers, three bf16 MFMAs per product (one of torch's two documented forms of "high"; >= 16 mantissa bits against TF32's 10).  The reference
-    sets "high" before training (`src/stamp/modeling/train.py:519`) and "medium" before deployment (`deploy.py:398`); affects `amds_bgemm_f32`'s tiled
-    kernels: TransMIL / Nystrom products and the MLP heads' training GEMMs."""
-    if precision not in _MATMUL_LEVELS:
-        raise ValueError(f"precision must be one of {sorted(_MATMUL_LEVELS)}, got {precision!r}")
-    _lib.check(_lib.lib().amds_set_matmul_precision(_MATMUL_LEVELS[precision]), "set_matmul_precision")
-
-
-def get_float32_matmul_precision() -> str:
-    return "high" if _lib.lib().amds_get_matmul_precision() == 1 else "highest"
+def sync_float32_matmul_precision() -> str:
+    """Forward torch's process-wide `torch.get_float32_matmul_precision()` to the library (`amds_set_matmul_precision`): "highest" (torch's default) = exact
+    fp32 MFMA products; "high" / "medium" = every fp32 operand as the sum of two bf16 numbers, three bf16 MFMAs per product (one of torch's two documented
+    forms of "high"; >= 16 mantissa bits against TF32's 10).  The reference sets "high" before training (`src/stamp/modeling/train.py:519`) and "medium"
+    before deployment (`deploy.py:398`), so a drop-in run gets the bf16 x 3 products exactly where the reference asked torch for cheaper ones.  Called by every
+    host entry point in front of `amds_bgemm_f32` (TransMIL / Nystrom, the MLP heads' training GEMMs)."""
+    level = torch.get_float32_matmul_precision()
+    _lib.check(_lib.lib().amds_set_matmul_precision(0 if level == "highest" else 1), "set_matmul_precision")
+    return level
 
 
 class float32_matmul_precision:
-    """`with ops.float32_matmul_precision("high"): ...` -- sets the level and restores the previous one on exit."""
+    """`with ops.float32_matmul_precision("high"): ...` -- sets torch's flag (which the library follows) and restores the previous level on exit."""
 
     def __init__(self, precision: str):
         self.precision = precision
 
     def __enter__(self):
-        self.prev = get_float32_matmul_precision()
-        set_float32_matmul_precision(self.precision)
+        self.prev = torch.get_float32_matmul_precision()
+        torch.set_float32_matmul_precision(self.precision)
+        sync_float32_matmul_precision()
         return self
 
     def __exit__(self, *exc):
-        set_float32_matmul_precision(self.prev)
+        torch.set_float32_matmul_precision(self.prev)
+        sync_float32_matmul_precision()
         return False
 
 

@@ -33,6 +33,7 @@ def _bg(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, in
         transa=False):
     """transa: A is stored [K][M] with pitch lda and the product is A^T B (no explicit transpose: the kernel transposes while staging)."""
     p = lambda t: t if isinstance(t, int) else t.data_ptr()  # noqa: E731
+    ops.sync_float32_matmul_precision()
     _lib.check(_lib.lib().amds_bgemm_f32(p(A), lda, sAo, sAi, p(B), ldb, sBo, sBi, (1 if transb else 0) | (2 if transa else 0), p(Cm), ldc, sCo, sCi, outer, inner,
                                          M, N, K, alpha, diag, None if bias is None else p(bias), 1 if accumulate else 0, ops._stream()), "bgemm_f32")
 
@@ -100,6 +101,7 @@ def nystrom_forward(y: torch.Tensor, P: _Nys, x_res: torch.Tensor, p_drop: float
         _lib.check(-1, "nystrom_attn_saved_bytes")
     arena = torch.empty(need, dtype=torch.uint8, device=y.device)
     L = _layer_struct(P)
+    ops.sync_float32_matmul_precision()
     _lib.check(lib.amds_nystrom_attn_fwd(C.byref(L), Cd, y.data_ptr(), x_res.data_ptr(), b, n, float(p_drop), int(seed) & (2 ** 64 - 1), int(sid),
                                          arena.data_ptr(), arena.numel(), ops._stream()), "nystrom_attn_fwd")
     return dict(arena=arena, n=n, p_drop=p_drop, seed=seed, sid=sid)
@@ -127,6 +129,7 @@ def nystrom_backward(S: dict, P: _Nys, dx: torch.Tensor, need_params: bool = Tru
                                G["attn.res_conv.weight"].data_ptr())
     L = _layer_struct(P)
     arena = S["arena"]
+    ops.sync_float32_matmul_precision()
     _lib.check(lib.amds_nystrom_attn_bwd(C.byref(L), Cd, dx.data_ptr(), dy.data_ptr(), C.byref(gc) if gc is not None else None, b, n, float(S["p_drop"]),
                                          int(S["seed"]) & (2 ** 64 - 1), int(S["sid"]), arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel(), ops._stream()),
                "nystrom_attn_bwd")
@@ -175,6 +178,7 @@ def forward_train(get, bags: torch.Tensor, dims: tuple[int, int, int], *, traini
     arena = torch.empty(need, dtype=torch.uint8, device=dev)
     logits = torch.empty(Bb, Cc, dtype=torch.float32, device=dev)
     p_out = P_OUT if training else 0.0
+    ops.sync_float32_matmul_precision()
     _lib.check(lib.amds_transmil_train_forward(C.byref(cfg), C.byref(w), bags.data_ptr(), ops._DT[bags.dtype], p_out, int(seed) & (2 ** 64 - 1), logits.data_ptr(), Bb, Tn,
                                                arena.data_ptr(), arena.numel(), ops._stream()), "transmil_train_forward")
     return logits, dict(arena=arena, cfg=cfg, w=w, keep=keep, shape=(Bb, Tn, Fd), dims=dims, p_out=p_out, seed=seed)
@@ -210,6 +214,7 @@ def backward(saved: dict, dlogits: torch.Tensor, *, need_params: bool = True, ne
             gc.layer[i] = _lib.TransMilLayerGrads(*[t.data_ptr() for t in L.values()])
     dbags = torch.empty(Bb * Tn, Fd, **f32) if need_bags else None
     arena = saved["arena"]
+    ops.sync_float32_matmul_precision()
     _lib.check(lib.amds_transmil_train_backward(C.byref(saved["cfg"]), C.byref(saved["w"]), dlogits.data_ptr(), saved["p_out"], int(saved["seed"]) & (2 ** 64 - 1), Bb, Tn,
                                                 arena.data_ptr(), arena.numel(), C.byref(gc) if gc is not None else None, dbags.data_ptr() if dbags is not None else None,
                                                 ws.data_ptr(), ws.numel(), ops._stream()), "transmil_train_backward")

@@ -100,7 +100,7 @@ def test_transmil_train_mode_dropout_and_optimizer(gpu):
 @pytest.mark.parametrize("Z,M,N,K", [(6, 256, 64, 1280), (3, 130, 70, 52), (1, 512, 1024, 1024), (16, 256, 256, 256), (4, 64, 512, 64), (2, 1280, 256, 64)])
 @pytest.mark.parametrize("transa,transb", [(False, False), (False, True), (True, False), (True, True)])
 def test_bgemm_f32_high_precision_mode(gpu, Z, M, N, K, transa, transb):
-    """`set_float32_matmul_precision("high")` (the reference's training setting, train.py:519): fp32 operands as hi + lo bf16, three bf16 MFMAs per product.
+    """`torch.set_float32_matmul_precision("high")` (the reference's training setting, train.py:519; the library follows torch's flag): fp32 operands as hi + lo bf16, three bf16 MFMAs per product.
     Stated tolerance: 2e-5 relative L2 against the fp64 product (measured ~2e-6: 16+ mantissa bits per factor; TF32, torch's other form of "high", gives
     ~3e-4) on every tile shape and operand layout; values spanning 2^+-20 (the split has the exponent range of fp32, unlike an fp16 split); alpha / diag /
     accumulate epilogue unchanged; the level is restored by the context manager and "highest" stays bit-identical to the default."""
@@ -114,12 +114,12 @@ def test_bgemm_f32_high_precision_mode(gpu, Z, M, N, K, transa, transb):
     Ad = A.double().transpose(1, 2) if transa else A.double()
     want = Ad @ (B.double().transpose(1, 2) if transb else B.double())
     exact = tc._mm(A, B, transb, transa=transa)
-    assert ops.get_float32_matmul_precision() == "highest"
+    assert torch.get_float32_matmul_precision() == "highest"
     with ops.float32_matmul_precision("high"):
-        assert ops.get_float32_matmul_precision() == "high"
+        assert torch.get_float32_matmul_precision() == "high"
         out = tc._mm(A, B, transb, transa=transa)
         assert torch.equal(out, tc._mm(A, B, transb, transa=transa))          # deterministic
-    assert ops.get_float32_matmul_precision() == "highest"
+    assert torch.get_float32_matmul_precision() == "highest"
     assert torch.equal(exact, tc._mm(A, B, transb, transa=transa))
     for z in range(Z):                                                         # per batch: the batches differ by 2^40 in scale
         e = ((out[z].double() - want[z]).norm() / want[z].norm()).item()

@@ -2,8 +2,7 @@ import sys, time, torch
 sys.path.insert(0, "/root/repo")
 from stamp_amd.mil import TransMIL
 import os
-from stamp_amd import ops
-ops.set_float32_matmul_precision(os.environ.get('AMDS_MATMUL', 'high'))      # the reference's training setting; AMDS_MATMUL=highest: exact fp32
+torch.set_float32_matmul_precision(os.environ.get('AMDS_MATMUL', 'high'))      # the reference's training setting (train.py:519), which the library follows; AMDS_MATMUL=highest: exact fp32
 tm = TransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().cuda()
 for B in (8, 32, 64):
     bags = torch.randn(B, 1024, 1024, device="cuda")

@@ -8,8 +8,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from stamp_amd.mil import TransMIL
 import os
-from stamp_amd import ops
-ops.set_float32_matmul_precision(os.environ.get('AMDS_MATMUL', 'high'))      # the reference's training setting; AMDS_MATMUL=highest: exact fp32  # noqa: E402
+torch.set_float32_matmul_precision(os.environ.get('AMDS_MATMUL', 'high'))      # the reference's training setting (train.py:519), which the library follows; AMDS_MATMUL=highest: exact fp32  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
