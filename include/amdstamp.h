@@ -847,8 +847,9 @@ int amds_barspoon_forward(const amds_barspoon_cfg* cfg_host, const amds_barspoon
  *   AMDS_MATMUL_HIGHEST (default): fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32), exact products.
  *   AMDS_MATMUL_HIGH: every operand value as the sum of two bf16 numbers, three bf16 MFMAs per product (hi hi + hi lo + lo hi), fp32 accumulate: ~16 mantissa
  *     bits per factor -- one of the two implementations torch documents for "high" (the other, TF32, keeps 10).
- * Applies to amds_bgemm_f32's tiled kernels (every product of the TransMIL / Nystrom paths, the MLP heads' training GEMMs); the 64 x 64 fallback kernel for
- * small or unaligned products and everything that is not a matrix product stay exact. */
+ * Applies to amds_bgemm_f32's tiled kernels as the MIL heads call them (every product of the TransMIL / Nystrom paths, the MLP heads' training GEMMs, the
+ * heads' own small products); the 64 x 64 fallback kernel for small or unaligned products, everything that is not a matrix product, and the feature-extraction
+ * paths that promise exact fp32 (the tile encoder's exact class-token stream, TICON, barspoon's class side) stay exact at every level. */
 #define AMDS_MATMUL_HIGHEST 0
 #define AMDS_MATMUL_HIGH 1
 int amds_set_matmul_precision(int level);

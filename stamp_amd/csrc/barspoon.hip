@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) cross_attention_kernel(const float* __res
 
 inline int bg(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int tflags, float* Cm, int ldc, long sCo, long sCi,
               int outer, int inner, int M, int N, int K, float alpha, const float* bias, int accumulate, void* st) {
-    return amds_bgemm_f32(A, lda, sAo, sAi, B, ldb, sBo, sBi, tflags, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, 0.0f, bias, accumulate, st);
+    return bgemm_f32_exact(A, lda, sAo, sAi, B, ldb, sBo, sBi, tflags, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, 0.0f, bias, accumulate, st);
 }
 
 }  // namespace

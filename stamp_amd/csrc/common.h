@@ -298,4 +298,7 @@ struct ProfScope {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// amds_bgemm_f32 on the exact-fp32 MFMA whatever amds_set_matmul_precision says (transmil.hip): for the paths that promise exact fp32
+int bgemm_f32_exact(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb, float* Cm, int ldc, long sCo, long sCi,
+                    int outer, int inner, int M, int N, int K, float alpha, float diag, const float* bias, int accumulate, void* stream);
 }  // namespace amds

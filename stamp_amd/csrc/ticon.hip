@@ -88,11 +88,11 @@ extern "C" int amds_ticon_tile_forward(const amds_ticon_weights* w_host, const v
                      "amds_ticon_tile_forward: incomplete weights of block %d", l);
         RC(amds_layernorm(x, D, b.ln1_w, b.ln1_b, t, D, B, D, 1e-5f, AMDS_F32, stream));
         RC(amds_linear_f32(t, b.v_w, b.v_b, u, B, D, D, 0, stream));                                                       // one key: attention = value
-        RC(amds_bgemm_f32(u, D, 0, 0, b.proj_w, D, 0, 0, 1, x, D, 0, 0, 1, 1, B, D, D, 1.0f, 0.0f, b.proj_b, 1, stream));    // x += g1 * proj(v)
+        RC(bgemm_f32_exact(u, D, 0, 0, b.proj_w, D, 0, 0, 1, x, D, 0, 0, 1, 1, B, D, D, 1.0f, 0.0f, b.proj_b, 1, stream));    // x += g1 * proj(v)
         RC(amds_layernorm(x, D, b.ln2_w, b.ln2_b, t, D, B, D, 1e-5f, AMDS_F32, stream));
         RC(amds_linear_f32(t, b.fc1_w, b.fc1_b, u, B, Hh, D, 0, stream));
         RC(amds_mlp_act_f32(u, Hh, B, H2, 1, stream));                                                                     // u[:, :H2] = silu(x1) * x2
-        RC(amds_bgemm_f32(u, Hh, 0, 0, b.fc2_w, H2, 0, 0, 1, x, D, 0, 0, 1, 1, B, D, H2, 1.0f, 0.0f, b.fc2_b, 1, stream));   // x += g2 * fc2(.)
+        RC(bgemm_f32_exact(u, Hh, 0, 0, b.fc2_w, H2, 0, 0, 1, x, D, 0, 0, 1, 1, B, D, H2, 1.0f, 0.0f, b.fc2_b, 1, stream));   // x += g2 * fc2(.)
     }
     return amds_layernorm(x, D, w.norm_w, w.norm_b, out, D, B, D, 1e-5f, out_dtype, stream);
 }

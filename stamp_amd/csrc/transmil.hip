@@ -1057,9 +1057,26 @@ extern "C" int amds_set_matmul_precision(int level) {
 }
 extern "C" int amds_get_matmul_precision(void) { return g_matmul_precision.load(std::memory_order_relaxed); }
 
+static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
+                        float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
+                        float diag, const float* bias, int accumulate, void* stream);
 extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                               float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                               float diag, const float* bias, int accumulate, void* stream) {
+    return bgemm_f32_at(g_matmul_precision.load(std::memory_order_relaxed), A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag,
+                        bias, accumulate, stream);
+}
+// the feature-extraction paths that promise exact fp32 (the ViT's exact class-token stream, TICON, barspoon's class side) do not follow the process-wide level
+namespace amds {
+int bgemm_f32_exact(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb, float* Cm, int ldc, long sCo, long sCi,
+                    int outer, int inner, int M, int N, int K, float alpha, float diag, const float* bias, int accumulate, void* stream) {
+    return bgemm_f32_at(AMDS_MATMUL_HIGHEST, A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag, bias, accumulate, stream);
+}
+}  // namespace amds
+static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
+                        float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
+                        float diag, const float* bias, int accumulate, void* stream) {
+    using namespace amds;
     AMDS_REQUIRE(A && B && Cm, "amds_bgemm_f32: null pointer");
     AMDS_REQUIRE(outer > 0 && inner > 0 && (long)outer * inner <= 65535 && M > 0 && N > 0 && K > 0, "amds_bgemm_f32: bad sizes");
     hipStream_t st = (hipStream_t)stream;
@@ -1074,7 +1091,7 @@ extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const
         const dim3 grid3(cdiv(N, shape == 1 ? 64 : shape == 2 ? 256 : 128), cdiv(M, shape == 1 ? 256 : shape == 2 ? 64 : 128), outer * inner);
         const int vec = vec_ok ? 1 : 0;
         static const int xcd = [] { const char* e = getenv("AMDS_BGEMM_XCD"); return e ? atoi(e) : 1; }();      // 0: launch order (A/B)
-        const bool x3 = g_matmul_precision.load(std::memory_order_relaxed) != AMDS_MATMUL_HIGHEST;
+        const bool x3 = precision != AMDS_MATMUL_HIGHEST;
 #define AMDS_BG(TB, TA, WM_, WN_)                                                                                                              \
     do {                                                                                                                                       \
         if (x3) hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_, 1>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \

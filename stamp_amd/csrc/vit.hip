@@ -218,7 +218,7 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
         float *xcq = xc + (size_t)q.t0 * D, *hcq = hc + (size_t)q.t0 * D, *qcq = qc + (size_t)q.t0 * D, *ocq = oc + (size_t)q.t0 * D;
         float* ucq = uc + (size_t)q.t0 * 2 * Hd;
         auto lin32 = [&](const float* A, int lda, const float* Wt, int K, float* Cm, int ldc, int N, const float* bias, int acc) {
-            return amds_bgemm_f32(A, lda, 0, 0, Wt, K, 0, 0, 1, Cm, ldc, 0, 0, 1, 1, q.nt, N, K, 1.0f, 0.0f, bias, acc, s);
+            return bgemm_f32_exact(A, lda, 0, 0, Wt, K, 0, 0, 1, Cm, ldc, 0, 0, 1, 1, q.nt, N, K, 1.0f, 0.0f, bias, acc, s);
         };
         if (ex) AMDS_TRY(amds_vit_cls_gather(xq, xcq, q.nt, T, D, s));
         if (planes) AMDS_TRY(amds_ln_stats_split(xq, D, n, D, c->ln_eps, hq, loq, D, rs, s));
