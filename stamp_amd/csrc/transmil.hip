@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
 // ---- amds_set_matmul_precision(AMDS_MATMUL_HIGH), aligned products: the split happens ONCE per element, on its way into LDS ---------------------------------
 // bgemm_f32_big_kernel<.., X3 = 1> splits every fragment in every wave that reads it, keeps fp32 LDS images, 16-deep K steps and two barriers per step: it is bound by
 // that, not by its 12 MFMAs per step (1.6x the fp32 kernel).  Here: K steps of 32, global -> registers -> (hi | lo) bf16 images, double-buffered (one barrier per
-// step), a fragment = 8 consecutive k of a row as ONE ds_read_b128 (row-major operands: [row][32 k], pitch 80 B) or four ds_read_b32 of (k, k + 1) pairs
+// step), a fragment = 8 consecutive k of a row as ONE ds_read_b128 (row-major operands: [row][32 k], 64 B rows, chunk-swizzled) or four ds_read_b32 of (k, k + 1) pairs
 // (k-major operands: [16 k pairs][rows + 8][2], written as ds_write_b128 of four rows' pairs: a thread fetches the float4 of k and of k + 1).  Only products whose
 // tiles are all interior and aligned (M % BM == N % BN == K % 32 == 0, float4 loads) come here -- every Nystrom / pinv / projection shape; the rest stays on the
 // kernel above.  Same epilogue (alpha, + diag I, bias, accumulate), same tile shapes and XCD order.
@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
     constexpr int TRA = TRANSA, TRB = TRANSB ? 0 : 1;
-    constexpr int PR = 80;                                           // row-major image: bytes per row (64 + 16: ds_read_b128 of 16 consecutive rows hit 16 bank groups)
+    constexpr int PR = 64;                                           // row-major image: bytes per row, no padding: the 16-byte chunk index is XORed with (row >> 2) & 3, so the
+                                                                     // ds_read_b128 of 16 consecutive rows hit 16 different bank groups (pitch 80 B did too, but cost the second workgroup per CU)
     constexpr int IMG_A = TRA ? 16 * (BM + 8) * 4 : BM * PR, IMG_B = TRB ? 16 * (BN + 8) * 4 : BN * PR;      // bytes of ONE (hi or lo) image
     constexpr int STAGE = 2 * IMG_A + 2 * IMG_B;
     constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;    // float4 per thread and K step
@@ -394,8 +395,9 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
                 const int c = it * 256 + tid, row = c >> 3, c4 = (c & 7) * 4;
                 bf16x4 h, l;
                 split4(r[it], h, l);
-                *reinterpret_cast<bf16x4*>(Sh + row * PR + c4 * 2) = h;
-                *reinterpret_cast<bf16x4*>(Sl + row * PR + c4 * 2) = l;
+                const int off = row * PR + (((c4 >> 3) ^ ((row >> 2) & 3)) << 4) + (c4 & 7) * 2;
+                *reinterpret_cast<bf16x4*>(Sh + off) = h;
+                *reinterpret_cast<bf16x4*>(Sl + off) = l;
             }
         }
     };
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
             for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const unsigned*>(S + ((s16 * 8 + hi * 4 + j) * (RT + 8) + row) * 4);
             return __builtin_bit_cast(bf16x8, w);
         } else {
-            return *reinterpret_cast<const bf16x8*>(S + row * PR + s16 * 32 + hi * 16);
+            return *reinterpret_cast<const bf16x8*>(S + row * PR + (((s16 * 2 + hi) ^ ((row >> 2) & 3)) << 4));
         }
     };
     typedef std::integral_constant<int, TRA> TA;
