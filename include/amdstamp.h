@@ -863,6 +863,10 @@ int amds_get_matmul_precision(void);
 int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                    float* C, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                    float diag, const float* bias, int accumulate, void* stream);
+/* The same product with TWO outputs: C = alpha A op(B) + diag I and C2 = alpha2 A op(B) + diag2 I (C2 laid out like C; no bias, no accumulate): the Moore-Penrose
+ * iteration's `xz = x @ z` and `7 I - xz` (reference src/stamp/modeling/models/trans_mil.py:31-33) from one pass over the operands; bits of two amds_bgemm_f32 calls. */
+int amds_bgemm_f32_dual(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb, float* C, float* C2, int ldc,
+                        long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha, float diag, float alpha2, float diag2, void* stream);
 /* In-place softmax over the last dim of a contiguous [rows][cols] fp32 matrix (trans_mil.py:145). */
 int amds_softmax_rows(float* x, long rows, int cols, void* stream);
 /* Landmarks: out[z][j][c] = scale * sum_{t<l} x[z][j*l + t][c] (trans_mil.py:114-124, mask=None). */

@@ -276,6 +276,7 @@ PROTOTYPES = {
     "amds_mil_vit_train_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "amds_mil_vit_train_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _sz, _vp]),
     "amds_bgemm_f32": (_i, [_vp, _i, _l, _l, _vp, _i, _l, _l, _i, _vp, _i, _l, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp]),
+    "amds_bgemm_f32_dual": (_i, [_vp, _i, _l, _l, _vp, _i, _l, _l, _i, _vp, _vp, _i, _l, _l, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp]),
     "amds_softmax_rows": (_i, [_vp, _l, _i, _vp]),
     "amds_landmark_mean": (_i, [_vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "amds_pinv_init": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -143,6 +143,16 @@ inline int bg(const float* A, int lda, long sAo, long sAi, const float* B, int l
     return amds_bgemm_f32(A, lda, sAo, sAi, B, ldb, sBo, sBi, tflags, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag, bias, accumulate, st);
 }
 // batched product of contiguous [Z][M][K] (or [Z][K][M], tflags & 2) with [Z][K][N] (or [Z][N][K], tflags & 1) -> [Z][M][N]
+// square m x m products with two outputs (amds_bgemm_f32_dual)
+int mm2(const float* A, const float* B, float* C1, float* C2, long Z, int m, float alpha, float diag, float alpha2, float diag2, void* st) {
+    const long mmn = (long)m * m;
+    for (long z0 = 0; z0 < Z; z0 += 32768) {
+        const int nz = (int)std::min<long>(32768, Z - z0);
+        RC(amds_bgemm_f32_dual(A + z0 * mmn, m, mmn, 0, B + z0 * mmn, m, mmn, 0, 0, C1 + z0 * mmn, C2 + z0 * mmn, m, mmn, 0, nz, 1, m, m, m, alpha, diag, alpha2, diag2, st));
+    }
+    return AMDS_OK;
+}
+
 int mm(const float* A, const float* B, int tflags, float* Cm, long Z, int M, int N, int K, float alpha, float diag, int accumulate, void* st) {
     const int lda = (tflags & 2) ? M : K, ldb = (tflags & 1) ? K : N;
     for (long z0 = 0; z0 < Z; z0 += 32768) {                       // gridDim.z limit of one launch
@@ -223,8 +233,7 @@ extern "C" int amds_nystrom_attn_fwd(const amds_transmil_layer* w_host, int dim,
     for (int k = 0; k < ITERS; ++k) {                                                    // (:29-35), every iterate kept for the backward
         const float* z = at(s.zs, k);
         float *A = at(s.A, k), *T1 = at(s.T1, k), *T2 = at(s.T2, k), *T3 = at(s.T3, k);
-        RC(mm(a2, z, 0, A, Z, m, m, m, 1.0f, 0.0f, 0, stream));
-        RC(mm(a2, z, 0, T1, Z, m, m, m, -1.0f, 7.0f, 0, stream));
+        RC(mm2(a2, z, A, T1, Z, m, 1.0f, 0.0f, -1.0f, 7.0f, stream));                    // A = a2 z and T1 = 7 I - A from one product
         RC(mm(A, T1, 0, T2, Z, m, m, m, -1.0f, 15.0f, 0, stream));
         RC(mm(A, T2, 0, T3, Z, m, m, m, -1.0f, 13.0f, 0, stream));
         RC(mm(z, T3, 0, at(s.zs, k + 1), Z, m, m, m, 0.25f, 0.0f, 0, stream));

@@ -89,6 +89,9 @@ __global__ void __launch_bounds__(256) bgemm_f32_kernel(const float* __restrict_
     }
 }
 
+// second output of the same product (amds_bgemm_f32_dual): C2 = alpha2 * A op(B) + diag2 * I, laid out like C
+struct BgDual { float* c2; float alpha2, diag2; };
+
 // 128 x 128 tile variant for the large batched products (Nystrom pinv iterations 256^3, q k_l^T, projections): each wave owns
 // 64 x 64 = 2 x 2 MFMA fragments, so one LDS operand read feeds two MFMAs; the LDS image is [row][k parity][k / 2] so that the
 // 8 values a lane needs per 16-deep k-tile (k = hi, hi + 2, ...) are two ds_read_b128; global loads are float4 and the next
@@ -110,12 +113,12 @@ __device__ __forceinline__ void split_bf16x2(const f32x4 (&f)[2], bf16x8& hi, bf
         lo[e] = (bf16)(x - (float)h);
     }
 }
-template <int TRANSB, int TRANSA = 0, int WM = 2, int WN = 2, int X3 = 0>
+template <int TRANSB, int TRANSA = 0, int WM = 2, int WN = 2, int X3 = 0, bool DUAL = false>
 __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restrict__ A, int lda, long sAo, long sAi,
                                                             const float* __restrict__ B, int ldb, long sBo, long sBi,
                                                             float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner,
                                                             int M, int N, int K, float alpha, float diag,
-                                                            const float* __restrict__ bias, int accumulate, int vec, int xcd) {
+                                                            const float* __restrict__ bias, int accumulate, int vec, int xcd, BgDual dual) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16, LDT = 20;
     constexpr int ITA = BM * 4 / 256, ITB = BN * 4 / 256;          // float4 pieces per thread and K step
@@ -146,6 +149,7 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
     A += zo * sAo + zi * sAi;
     B += zo * sBo + zi * sBi;
     Cm += zo * sCo + zi * sCi;
+    if constexpr (DUAL) dual.c2 += zo * sCo + zi * sCi;
     const int m0 = by * BM, n0 = bx * BN;
     const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[2][2];
@@ -299,6 +303,25 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
         if (interior) store(std::true_type{}, std::false_type{});
         else store(std::false_type{}, std::false_type{});
     }
+    if constexpr (DUAL) {                                            // the same product's second output, alpha2 * P + diag2 * I, as a pass of its own
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= N) continue;
+            float* cn = dual.c2 + n;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < M) {
+                        float v = dual.alpha2 * acc[i][j][r] + 0.f;
+                        v += m == n ? dual.diag2 : 0.f;
+                        cn[(long)m * ldc] = v;
+                    }
+                }
+        }
+    }
 }
 
 // ---- amds_set_matmul_precision(AMDS_MATMUL_HIGH), aligned products: the split happens ONCE per element, on its way into LDS ---------------------------------
@@ -308,10 +331,10 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
 // (k-major operands: [16 k pairs][rows + 8][2], written as ds_write_b128 of four rows' pairs: a thread fetches the float4 of k and of k + 1).  Only products whose
 // tiles are all interior and aligned (M % BM == N % BN == K % 32 == 0, float4 loads) come here -- every Nystrom / pinv / projection shape; the rest stays on the
 // kernel above.  Same epilogue (alpha, + diag I, bias, accumulate), same tile shapes and XCD order.
-template <int TRANSB, int TRANSA, int WM, int WN>
+template <int TRANSB, int TRANSA, int WM, int WN, bool DUAL = false>
 __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__ A, int lda, long sAo, long sAi, const float* __restrict__ B, int ldb, long sBo,
                                                        long sBi, float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner, int M, int N, int K, float alpha,
-                                                       float diag, const float* __restrict__ bias, int accumulate, int xcd) {
+                                                       float diag, const float* __restrict__ bias, int accumulate, int xcd, BgDual dual) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
     constexpr int TRA = TRANSA, TRB = TRANSB ? 0 : 1;
@@ -337,6 +360,7 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
     A += zo * sAo + zi * sAi;
     B += zo * sBo + zi * sBi;
     Cm += zo * sCo + zi * sCi;
+    if constexpr (DUAL) dual.c2 += zo * sCo + zi * sCi;
     const int m0 = by * BM, n0 = bx * BN;
     const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[2][2];
@@ -479,6 +503,22 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
     };
     if (diag != 0.f) store(std::true_type{});
     else store(std::false_type{});
+    if constexpr (DUAL) {                                            // second output of the same product
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* cn = dual.c2 + n0 + wn * 64 + j * 32 + l31;
+            const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = dual.alpha2 * acc[i][j][r] + 0.f;
+                    v += m == n ? dual.diag2 : 0.f;
+                    cn[(long)m * ldc] = v;
+                }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, long rows, int cols) {
@@ -1061,7 +1101,7 @@ extern "C" int amds_get_matmul_precision(void) { return g_matmul_precision.load(
 
 static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                         float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
-                        float diag, const float* bias, int accumulate, void* stream);
+                        float diag, const float* bias, int accumulate, void* stream, amds::BgDual dual = amds::BgDual{nullptr, 0.f, 0.f});
 extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                               float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                               float diag, const float* bias, int accumulate, void* stream) {
@@ -1075,9 +1115,18 @@ int bgemm_f32_exact(const float* A, int lda, long sAo, long sAi, const float* B,
     return bgemm_f32_at(AMDS_MATMUL_HIGHEST, A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag, bias, accumulate, stream);
 }
 }  // namespace amds
+// C = alpha A op(B) + diag I and, from the SAME product, C2 = alpha2 A op(B) + diag2 I (same layout as C): the pinv iteration's A = a2 z and T1 = 7 I - A
+// (reference trans_mil.py:31-33) as one launch instead of two -- the second product re-read both operands (0.27 GB at the bench shape) for the same
+// accumulators.  Bits of the two separate calls.
+extern "C" int amds_bgemm_f32_dual(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb, float* Cm, float* C2, int ldc,
+                                   long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha, float diag, float alpha2, float diag2, void* stream) {
+    AMDS_REQUIRE(C2 && C2 != Cm, "amds_bgemm_f32_dual: the second output must be a different buffer");
+    return bgemm_f32_at(g_matmul_precision.load(std::memory_order_relaxed), A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag,
+                        nullptr, 0, stream, amds::BgDual{C2, alpha2, diag2});
+}
 static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                         float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
-                        float diag, const float* bias, int accumulate, void* stream) {
+                        float diag, const float* bias, int accumulate, void* stream, amds::BgDual dual) {
     using namespace amds;
     AMDS_REQUIRE(A && B && Cm, "amds_bgemm_f32: null pointer");
     AMDS_REQUIRE(outer > 0 && inner > 0 && (long)outer * inner <= 65535 && M > 0 && N > 0 && K > 0, "amds_bgemm_f32: bad sizes");
@@ -1094,12 +1143,30 @@ static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long s
         const int vec = vec_ok ? 1 : 0;
         static const int xcd = [] { const char* e = getenv("AMDS_BGEMM_XCD"); return e ? atoi(e) : 1; }();      // 0: launch order (A/B)
         const bool x3 = precision != AMDS_MATMUL_HIGHEST;
+        if (dual.c2 && (transb || transa || shape != 0)) {               // the one-launch form exists for the plain 128 x 128 product (the pinv iteration's)
+            int rc = bgemm_f32_at(precision, A, lda, sAo, sAi, B, ldb, sBo, sBi, transb | (transa ? 2 : 0), Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag, bias, accumulate, stream);
+            if (rc != AMDS_OK) return rc;
+            return bgemm_f32_at(precision, A, lda, sAo, sAi, B, ldb, sBo, sBi, transb | (transa ? 2 : 0), dual.c2, ldc, sCo, sCi, outer, inner, M, N, K, dual.alpha2, dual.diag2, nullptr, 0, stream);
+        }
+        if (dual.c2) {
+            if (x3 && vec_ok && M % 128 == 0 && N % 128 == 0 && K % 32 == 0)
+                hipLaunchKernelGGL((bgemm_x3_kernel<0, 0, 2, 2, true>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias,
+                                   accumulate, xcd, dual);
+            else if (x3)
+                hipLaunchKernelGGL((bgemm_f32_big_kernel<0, 0, 2, 2, 1, true>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag,
+                                   bias, accumulate, vec, xcd, dual);
+            else
+                hipLaunchKernelGGL((bgemm_f32_big_kernel<0, 0, 2, 2, 0, true>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag,
+                                   bias, accumulate, vec, xcd, dual);
+            AMDS_LAUNCH_CHECK("bgemm dual");
+            return AMDS_OK;
+        }
 #define AMDS_BG(TB, TA, WM_, WN_)                                                                                                              \
     do {                                                                                                                                       \
         if (x3) hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_, 1>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
-                                   inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd);                                                  \
+                                   inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd, dual);                                            \
         else hipLaunchKernelGGL((bgemm_f32_big_kernel<TB, TA, WM_, WN_, 0>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, \
-                                inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd);                                                     \
+                                inner, M, N, K, alpha, diag, bias, accumulate, vec, xcd, dual);                                               \
     } while (0)
 #define AMDS_BG_SHAPE(TB, TA)                                     \
     do {                                                          \
@@ -1113,7 +1180,7 @@ static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long s
         if (x3 && x3_lds && vec_ok && M % bm == 0 && N % bn == 0 && K % 32 == 0) {
 #define AMDS_BX(TB, TA, WM_, WN_) \
     hipLaunchKernelGGL((bgemm_x3_kernel<TB, TA, WM_, WN_>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, \
-                       diag, bias, accumulate, xcd)
+                       diag, bias, accumulate, xcd, dual)
 #define AMDS_BX_SHAPE(TB, TA)                                     \
     do {                                                          \
         if (shape == 1) AMDS_BX(TB, TA, 4, 1);                    \
@@ -1142,6 +1209,11 @@ static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long s
     if (transb) hipLaunchKernelGGL((bgemm_f32_kernel<1>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
     else hipLaunchKernelGGL((bgemm_f32_kernel<0>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, diag, bias, accumulate);
     AMDS_LAUNCH_CHECK("bgemm_f32_kernel");
+    if (dual.c2) {            // (small / unaligned products: the second output as a second launch)
+        if (transb) hipLaunchKernelGGL((bgemm_f32_kernel<1>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, dual.c2, ldc, sCo, sCi, inner, M, N, K, dual.alpha2, dual.diag2, nullptr, 0);
+        else hipLaunchKernelGGL((bgemm_f32_kernel<0>), grid, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, dual.c2, ldc, sCo, sCi, inner, M, N, K, dual.alpha2, dual.diag2, nullptr, 0);
+        AMDS_LAUNCH_CHECK("bgemm_f32_kernel");
+    }
     return AMDS_OK;
 }
 

@@ -146,8 +146,7 @@ int nystrom(const TmPlan& p, const amds_transmil_layer& L, const float* y, float
         return bg(A, m, mm, 0, B, m, mm, 0, 0, Cm, m, mm, 0, b * H, 1, m, m, m, alpha, diag, nullptr, 0, stream);
     };
     for (int it = 0; it < ITERS; ++it) {
-        RC(sq(a2, z, xz, 1.0f, 0.0f));
-        RC(sq(a2, z, t1, -1.0f, 7.0f));
+        RC(amds_bgemm_f32_dual(a2, m, mm, 0, z, m, mm, 0, 0, xz, t1, m, mm, 0, b * H, 1, m, m, m, 1.0f, 0.0f, -1.0f, 7.0f, stream));      // xz and 7 I - xz from one product
         RC(sq(xz, t1, t2, -1.0f, 15.0f));
         RC(sq(xz, t2, t1, -1.0f, 13.0f));
         RC(sq(z, t1, z2, 0.25f, 0.0f));
