@@ -6,7 +6,7 @@ OBJ   := build/obj
 LIB   := stamp_amd/lib/libamdstamp.so
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS))
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(if $(PROBE),-DAMDS_GEMM_PROBE,)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(if $(PROBE),-DAMDS_GEMM_PROBE,) $(if $(GELU_DEG),-DAMDS_GELU_DEG=$(GELU_DEG),)
 
 all: $(LIB)
 

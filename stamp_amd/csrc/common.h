@@ -133,10 +133,25 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // (2.2e-6 |x|) was 100x finer than a 16-bit output can hold, and this epilogue's VALU work is un-overlapped (one wave per SIMD): per pair of
 // outputs 2 v_med3 + 1 v_pk_mul (t) + 8 v_pk_fma (Horner) + 1 v_pk_fma + 1 v_pk_mul, against 2 + 2 + 2 + 11 + 3 before; fc1's launch 2 353 -> 2 230 us.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int GELU_DEG = 8;
+// Round 5 (verdict r04 item 1 (f)): the degree as a build-time switch for the A/B of profiles/r05_gelu_degree_ab.txt (-DAMDS_GELU_DEG=7 / 6: |gelu error| <= 1.9e-4 /
+// 7.8e-4 = 10 % / 40 % of half an fp16 ulp where it is largest, one / two packed fma fewer per pair of outputs); coefficients: tools/gelu_poly_fit.py 3.0 <degree>.
+#ifndef AMDS_GELU_DEG
+#define AMDS_GELU_DEG 8
+#endif
+constexpr int GELU_DEG = AMDS_GELU_DEG;
 constexpr float GELU_XMAX = 4.242640495300293f;
+#if AMDS_GELU_DEG == 8
 constexpr float GELU_R[GELU_DEG + 1] = {3.989038765e-01f, -6.635002047e-02f, 9.821003303e-03f, -1.110561891e-03f, 9.383271390e-05f,
                                         -5.674323347e-06f, 2.286626994e-07f, -5.434610983e-09f, 5.714419563e-11f};
+#elif AMDS_GELU_DEG == 7
+constexpr float GELU_R[GELU_DEG + 1] = {3.987607062e-01f, -6.595215201e-02f, 9.502778761e-03f, -9.971429827e-04f, 7.251269562e-05f,
+                                        -3.410153795e-06f, 9.214582519e-08f, -1.077705258e-09f};
+#elif AMDS_GELU_DEG == 6
+constexpr float GELU_R[GELU_DEG + 1] = {3.982334733e-01f, -6.480728090e-02f, 8.793668821e-03f, -8.053584024e-04f, 4.606616494e-05f,
+                                        -1.466691856e-06f, 1.968182417e-08f};
+#else
+#error "AMDS_GELU_DEG must be 6, 7 or 8"
+#endif
 // the same polynomial on NC independent 2-vectors, Horner steps interleaved across them: one wave per SIMD (4-wave GEMM) has
 // nobody to hide the dependent v_pk_fma latency behind, so a single chain runs at a fraction of the VALU rate
 template <int NC>
