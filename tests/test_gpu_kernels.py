@@ -365,9 +365,10 @@ def test_gemm_lnfold_producer(gpu, dt, M, N, K, use_scale):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [12, -1])
 def test_gelu_epilogue_polynomial_over_its_whole_range(gpu, cfg):
-    """The BIAS_GELU epilogue evaluates erf by a degree-8 polynomial in x^2 (common.h, tools/gelu_poly_fit.py).  A GEMM with an identity
+    """The BIAS_GELU epilogue evaluates erf by a degree-7 polynomial in x^2 (common.h, tools/gelu_poly_fit.py; round 5: degree 8 -> 7, profiles/r05_gelu_degree_ab.txt).  A GEMM with an identity
     weight and the test values as bias puts exact pre-activations into the accumulators: a dense sweep of [-8, 8], the clamp points +-3 sqrt2,
-    and massive values.  Bars: |error| <= 1.5e-5 |x| + half an fp16 ulp of the result inside; beyond the clamp 0 (negative side, to 5e-8 |x|) or x."""
+    and massive values.  Bars: |error| <= 5e-5 |x| (measured 4.6e-5: a tenth of half an fp16 ulp where it is largest) + half an fp16 ulp of the result inside; beyond the
+    clamp 0 (negative side, to 5e-8 |x|) or x."""
     import math
     N = K = 256
     xs = torch.cat([torch.linspace(-8, 8, 256 * 1021), torch.tensor([-3 * math.sqrt(2), 3 * math.sqrt(2), -4.2426, 4.2427, -6.0, 6.0, -30.0, 30.0, -1e3, 1e3, -6e4, 6e4, 0.0, -0.0])])
@@ -386,7 +387,7 @@ def test_gelu_epilogue_polynomial_over_its_whole_range(gpu, cfg):
     ref = torch.nn.functional.gelu(x)
     half_ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, device=gpu, dtype=torch.float64)) * 2.0 ** -11
     err = (out - ref).abs()
-    assert bool((err <= 1.5e-5 * x.abs() + 1.01 * half_ulp).all()), float((err - 1.5e-5 * x.abs() - half_ulp).max())
+    assert bool((err <= 5e-5 * x.abs() + 1.01 * half_ulp).all()), float((err - 5e-5 * x.abs() - half_ulp).max())
     neg_tail, pos_tail = x < -4.3, x > 4.3
     assert bool((out[neg_tail].abs() <= 5e-8 * x[neg_tail].abs() + 6e-8).all()) and torch.equal(out[pos_tail], x[pos_tail].half().double())
     assert torch.isfinite(out).all()
