@@ -105,6 +105,25 @@ template <> struct Act<bf16> {
     static __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
 };
 
+// v_fma_mix_f32 with 16-bit sources taken straight from the halves of packed registers (the compiler folds fma(fpext a, 1, fpext b) to two conversions + an add):
+//   mix_add_hh<HA, HB>(a, b) = float(half HA of a) + float(half HB of b);   mix_sub_fh<HC>(v, c) = v - float(half HC of c).   fp16 only (no bf16 form).
+template <int HA, int HB>
+__device__ __forceinline__ float mix_add_hh(unsigned a, unsigned b) {
+    float d;
+    if constexpr (HA == 0 && HB == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (HA == 1 && HB == 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (HA == 0 && HB == 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int HC>
+__device__ __forceinline__ float mix_sub_fh(float v, unsigned c) {
+    float d;
+    if constexpr (HC == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(c), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(c), "v"(v));
+    return d;
+}
+
 // exact-erf GELU (nn.GELU default), evaluated in fp32
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

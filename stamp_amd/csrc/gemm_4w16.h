@@ -549,9 +549,16 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                         for (int u = 0; u < 8; ++u) {
                             if constexpr (PL) {
                                 const u32x4 o = __builtin_bit_cast(u32x4, old[b8][u]);
-                                const f32x4 ph = __builtin_convertvector(__builtin_bit_cast(vec4, u32x2{o[0], o[1]}), f32x4);
-                                const f32x4 pl = __builtin_convertvector(__builtin_bit_cast(vec4, u32x2{o[2], o[3]}), f32x4);
-                                v[u] += ph + pl;
+                                // (hi + lo is exact in fp32.  fp16 planes: one v_fma_mix_f32 per element forms it straight from the two 16-bit halves -- the
+                                //  conversions were 2 of the ~9 vector instructions per element of this un-overlapped epilogue; same bits)
+                                const vec4 h4 = __builtin_bit_cast(vec4, u32x2{o[0], o[1]}), l4 = __builtin_bit_cast(vec4, u32x2{o[2], o[3]});
+                                f32x4 old4;
+                                if constexpr (std::is_same<T, f16>::value) {
+                                    old4 = f32x4{mix_add_hh<0, 0>(o[0], o[2]), mix_add_hh<1, 1>(o[0], o[2]), mix_add_hh<0, 0>(o[1], o[3]), mix_add_hh<1, 1>(o[1], o[3])};
+                                } else {
+                                    old4 = __builtin_convertvector(h4, f32x4) + __builtin_convertvector(l4, f32x4);
+                                }
+                                v[u] += old4;
                             } else {
                                 v[u] += old[b8][u];
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), rsrc_o, offu[b8 & 1][u] + rowoff, 0, 0);
@@ -566,7 +573,14 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                                 const vec4 c = Act<T>::from_f32x4(v[u]);
                                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, c), rsrc_h, (offu[b8 & 1][u] + rowoff) >> 1, 0, 0);
                                 if constexpr (PL) {
-                                    const vec4 cl = Act<T>::from_f32x4(v[u] - __builtin_convertvector(c, f32x4));
+                                    f32x4 rest;
+                                    if constexpr (std::is_same<T, f16>::value) {                  // v - hi, exact: one v_fma_mix_f32 per element
+                                        const u32x2 cu = __builtin_bit_cast(u32x2, c);
+                                        rest = f32x4{mix_sub_fh<0>(v[u][0], cu[0]), mix_sub_fh<1>(v[u][1], cu[0]), mix_sub_fh<0>(v[u][2], cu[1]), mix_sub_fh<1>(v[u][3], cu[1])};
+                                    } else {
+                                        rest = v[u] - __builtin_convertvector(c, f32x4);
+                                    }
+                                    const vec4 cl = Act<T>::from_f32x4(rest);
                                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cl), rsrc_l, (offu[b8 & 1][u] + rowoff) >> 1, 0, 0);
                                 }
                                 ss[u] = f32x2{(v[u][0] + v[u][1]) + (v[u][2] + v[u][3]),
