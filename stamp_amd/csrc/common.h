@@ -200,6 +200,13 @@ __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
 // x * sigmoid(x) for 16-bit outputs: v_rcp_f32 (1 ulp) instead of the IEEE division `x / (1 + e)` expands to (v_div_scale x 2, v_rcp, 5 fma,
 // v_div_fmas, v_div_fixup: 11 of the 17 VALU instructions per output of the SWIGLU epilogue, which is un-overlapped like the GELU one)
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// silu(g) * v on two outputs at once: the multiply in front of v_exp_f32, the + 1 behind it and both products as packed instructions (2 + 2 transcendental
+// instructions per pair instead of 4 + 2 + 2; the SWIGLU epilogue is un-overlapped vector work like the GELU one).  exp(-g) = exp2(g * (-log2 e)).
+__device__ __forceinline__ f32x2 silu_mul2(f32x2 g, f32x2 v) {
+    const f32x2 a = g * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2{1.0f, 1.0f};
+    return g * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])} * v;
+}
 
 // Sum over the 32 lanes that share lane >> 5; every lane gets the total.  Every step is an XOR butterfly (lane ^ 1, ^ 2, ^ 7, ^ 15, ^ 16:
 // quad_perm, row_half_mirror, row_mirror, ds_swizzle -- five independent masks), so the association tree is a fixed partition of the

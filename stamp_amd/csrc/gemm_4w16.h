@@ -442,8 +442,10 @@ gemm_4w16_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, lon
                         vl = vl * as + bv;
                     }
                     f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = silu(gt[e]) * vl[e];
+                    {
+                        const f32x2 o01 = silu_mul2(f32x2{gt[0], gt[1]}, f32x2{vl[0], vl[1]}), o23 = silu_mul2(f32x2{gt[2], gt[3]}, f32x2{vl[2], vl[3]});
+                        o = f32x4{o01[0], o01[1], o23[0], o23[1]};
+                    }
                     const int hcol = wn * 64 + q * 32 + t * 16 + 4 * kb;          // hidden column inside the tile (0..127)
                     const int chunk = hcol >> 3, half = ((hcol >> 2) & 1) * 8;
                     *reinterpret_cast<vec4*>(smem + row * 256 + ((chunk ^ (row & 15)) << 4) + half) = Act<T>::from_f32x4(o);
