@@ -167,6 +167,43 @@ def test_mlp_linear_heads_train_like_torch(gpu, shape):
     assert _rel(lin.fc.weight.grad, rl.weight.grad) < 2e-5 and _rel(lin.fc.bias.grad, rl.bias.grad) < 2e-5 and _rel(xa2.grad, xb2.grad) < 2e-5
 
 
+def test_mlp_head_training_follows_torchs_matmul_precision(gpu):
+    """Under `torch.set_float32_matmul_precision("high")` -- what the reference's `train_model_` sets (modeling/train.py:519) -- the heads' backward GEMMs
+    (dx = dz W, dW = dz^T x on `amds_bgemm_f32`) run as bf16 x 3 products: gradients within 1e-4 relative L2 of an fp64 reference (measured ~1e-6; TF32, the other
+    form of "high", would be ~1e-3), the forward (`amds_linear_f32`, not a tiled product) unchanged bit for bit, and "highest" restored on exit = the default's bits."""
+    from stamp_amd import ops
+    from stamp_amd.mil import MLP
+    torch.manual_seed(5)
+    x0 = torch.randn(1024, 768)
+    hip = MLP(dropout=0.0, dim_input=768, dim_hidden=256, dim_output=2, num_layers=3).to(gpu).train()
+    targets = torch.nn.functional.one_hot(torch.arange(1024) % 2, 2).float().to(gpu)
+
+    def grads():
+        for p in hip.parameters():
+            p.grad = None
+        x = x0.to(gpu).requires_grad_(True)
+        y = hip(x)
+        torch.nn.functional.cross_entropy(y, targets).backward()
+        return y.detach(), [p.grad.clone() for p in hip.parameters()] + [x.grad.clone()]
+
+    y_exact, g_exact = grads()
+    with ops.float32_matmul_precision("high"):
+        y_high, g_high = grads()
+    y_again, g_again = grads()
+    assert torch.equal(y_exact, y_high) and torch.equal(y_exact, y_again)
+    assert all(torch.equal(a, b) for a, b in zip(g_exact, g_again))
+    ref = torch.nn.Sequential(*[torch.nn.Linear(m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else type(m)() for m in hip.mlp
+                                if not isinstance(m, torch.nn.Dropout)]).double()
+    ref.load_state_dict({f"{i}.{n}": p.detach().cpu().double() for i, k in enumerate(j for j, m in enumerate(hip.mlp) if not isinstance(m, torch.nn.Dropout))
+                         for n, p in hip.mlp[k].named_parameters()})
+    xr = x0.double().requires_grad_(True)
+    torch.nn.functional.cross_entropy(ref(xr), targets.cpu().double()).backward()
+    g_ref = [p.grad for p in ref.parameters()] + [xr.grad]
+    for gh, ge, gr in zip(g_high, g_exact, g_ref):
+        assert _rel(gh.cpu().double(), gr) < 1e-4 and _rel(ge.cpu().double(), gr) < 2e-5, (tuple(gr.shape), _rel(gh.cpu().double(), gr))
+    assert any(not torch.equal(a, b) for a, b in zip(g_exact, g_high))          # the level did reach the kernels
+
+
 def test_mlp_head_dropout_is_the_references_placement(gpu):
     """Train mode: Dropout(p) after every hidden ReLU (mlp.py:27-30), none after the last Linear.  With the keep masks the library drew
     (exported by `dropout_masks`) applied to a torch copy, output and gradients agree; eval mode has no dropout; seeds differ -> outputs differ;
