@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     uint32_t rowkey = 0;
     if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qc));
 
+    const bool wave_live = qblk * 128 + wave * 32 < Tn;
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -144,6 +145,9 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
         const char* sK = smem + buf * FA_STAGE;
         const char* sV = sK + FA_K_BYTES;
         const char* sM = smem + 2 * FA_STAGE + buf * FA_KT;
+        // A wave whose 32 queries all lie past the sequence (T = 1025 = 8 blocks of 128 + ONE query: three of the ninth block's four waves) only helps staging:
+        // its issue slots go to the workgroup that shares the CU (the ninth block was 11 % of the launch for 0.1 % of the queries)
+        if (wave_live) {
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -254,6 +258,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                     if constexpr (ALIBI) o2[dt] = Act<T>::mfma32(vf, bf, o2[dt]);
                 }
             }
+        }
         if (j + 1 < ntile) stage_store(buf ^ 1);
         __syncthreads();
     }

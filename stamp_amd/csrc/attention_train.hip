@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
     const float sc = 0.125f * 1.44269504088896340736f;
     const int swz = (l31 >> 1) & 7;
 
+    const bool wave_live = kblk * 128 + wave * 32 < Tn;
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
         const char* sQt = sG + BT_ROW_BYTES;
         const char* sGt = sQt + BT_TR_BYTES;
         const float* sL = reinterpret_cast<const float*>(sGt + BT_TR_BYTES);
+        if (wave_live)                                      // (a wave whose 32 keys all lie past the sequence only helps staging: T = 1025's ninth block)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x16 s, dp;
@@ -326,6 +328,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
     const float sc = 0.125f * 1.44269504088896340736f;
     const int swz = (l31 >> 1) & 7;
 
+    const bool wave_live = qblk * 128 + wave * 32 < Tn;
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -335,6 +338,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
         const char* sK = smem + buf * STAGE;
         const char* sV = sK + BT_ROW_BYTES;
         const char* sKt = sV + BT_ROW_BYTES;
+        if (wave_live)                                      // (a wave whose 32 queries all lie past the sequence only helps staging: T = 1025's ninth block)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x16 s, dp;
