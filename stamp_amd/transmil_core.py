@@ -38,6 +38,22 @@ def _bg(A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, in
                                          M, N, K, alpha, diag, None if bias is None else p(bias), 1 if accumulate else 0, ops._stream()), "bgemm_f32")
 
 
+def _mm_dual(A: torch.Tensor, B: torch.Tensor, alpha: float, diag: float, alpha2: float, diag2: float, transb: bool = False, transa: bool = False):
+    """One batched product, two outputs: (alpha A op(B) + diag I, alpha2 A op(B) + diag2 I) -- `amds_bgemm_f32_dual` (the pinv iteration's `xz` and `7 I - xz`,
+    reference trans_mil.py:31-33); the bits of two `_mm` calls."""
+    if transa:
+        Z, K, M = A.shape
+    else:
+        Z, M, K = A.shape
+    N = B.shape[1] if transb else B.shape[2]
+    c1 = torch.empty(Z, M, N, dtype=torch.float32, device=A.device)
+    c2 = torch.empty_like(c1)
+    ops.sync_float32_matmul_precision()
+    _lib.check(_lib.lib().amds_bgemm_f32_dual(A.data_ptr(), A.shape[2], M * K, 0, B.data_ptr(), B.shape[2], B.shape[1] * B.shape[2], 0, (1 if transb else 0) | (2 if transa else 0),
+                                              c1.data_ptr(), c2.data_ptr(), N, M * N, 0, Z, 1, M, N, K, alpha, diag, alpha2, diag2, ops._stream()), "bgemm_f32_dual")
+    return c1, c2
+
+
 def _mm(A: torch.Tensor, B: torch.Tensor, transb: bool, out: torch.Tensor | None = None, alpha: float = 1.0, diag: float = 0.0, accumulate: bool = False,
         transa: bool = False):
     """Batched product of contiguous [Z, M, K] (or [Z, K, M] if transa) with [Z, K, N] (or [Z, N, K] if transb) -> [Z, M, N]."""

@@ -127,6 +127,29 @@ def test_bgemm_f32_high_precision_mode(gpu, Z, M, N, K, transa, transb):
         assert ((exact[z].double() - want[z]).norm() / want[z].norm()).item() < 2e-6
 
 
+@pytest.mark.parametrize("Z,M,N,K,transa,transb", [(7, 256, 256, 256, False, False), (3, 130, 70, 52, False, False), (2, 40, 40, 40, False, False),
+                                                     (4, 256, 256, 64, False, True), (2, 128, 384, 96, True, False)])
+@pytest.mark.parametrize("precision", ["highest", "high"])
+def test_bgemm_f32_dual_is_two_products_bit_for_bit(gpu, Z, M, N, K, transa, transb, precision):
+    """amds_bgemm_f32_dual (the pinv iteration's `xz = x @ z` and `7 I - xz` from one pass over the operands, reference trans_mil.py:31-33) against two
+    amds_bgemm_f32 calls: the one-launch form (plain 128 x 128 tiles, both precisions), ragged tiles, the small-product fallback and the layouts that take two
+    launches -- every output bit-identical, diagonal term included (square and non-square)."""
+    from stamp_amd import ops
+    from stamp_amd import transmil_core as tc
+    g = torch.Generator().manual_seed(Z + M + K)
+    A = (torch.randn(Z, K, M, generator=g) if transa else torch.randn(Z, M, K, generator=g)).to(gpu)
+    B = (torch.randn(Z, N, K, generator=g) if transb else torch.randn(Z, K, N, generator=g)).to(gpu)
+    with ops.float32_matmul_precision(precision):
+        c1, c2 = tc._mm_dual(A, B, 1.0, 0.0, -1.0, 7.0, transb=transb, transa=transa)
+        w1 = tc._mm(A, B, transb, transa=transa)
+        w2 = tc._mm(A, B, transb, alpha=-1.0, diag=7.0, transa=transa)
+    assert torch.equal(c1, w1) and torch.equal(c2, w2)
+    Ad = A.double().transpose(1, 2) if transa else A.double()
+    want = Ad @ (B.double().transpose(1, 2) if transb else B.double())
+    eye = torch.eye(M, N, dtype=torch.float64, device=gpu)
+    assert ((c2.double() - (7.0 * eye - want)).norm() / want.norm()).item() < 2e-5
+
+
 @pytest.mark.parametrize("Bb,Tn,Fd,Cd", [(3, 300, 128, 128), (2, 1024, 1024, 512)])
 def test_transmil_backward_high_precision_mode(gpu, Bb, Tn, Fd, Cd):
     """The TransMIL training step with the reference's own matmul setting ("high", train.py:519): logits and every gradient against fp64 autograd.
