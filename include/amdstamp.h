@@ -266,6 +266,10 @@ int amds_gather_token_rows16_ex(const void* src16, const void* lo16, const float
  * tiles) at deploy time (reference src/stamp/modeling/models/vision_tranformer.py:191, 217-227, mask=None path
  * of src/stamp/modeling/models/__init__.py:286-313). */
 int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
+/* ONE query row per (bag, head) against all T keys / values of the bag as stored in the packed qkv tensor [B*T][3*H*64] (16-bit): out[b][h*64..] = softmax(q[b][h*64..] K_b,h^T / 8) V_b,h,
+ * fp32 arithmetic, 16-bit q [B][ldq] and out [B][ldo].  The class token's attention in the LAST block of the MIL `vit` head, whose other rows nothing reads (reference
+ * src/stamp/modeling/models/vision_tranformer.py: the head takes `x[:, 0]` behind the last block).  T <= 32768. */
+int amds_attention_row(const void* q, long ldq, const void* qkv, void* out, long ldo, int B, int T, int H, int dtype, void* stream);
 
 /* ALiBi variant of the reference's MultiHeadALiBi (src/stamp/modeling/models/vision_tranformer.py:42-74, eval mode):
  *   out = softmax(q k^T / 8) v  -  head_scale[h] * cdist(coords_q, coords_k) v        (bias applied AFTER the softmax)

@@ -213,6 +213,7 @@ PROTOTYPES = {
     "amds_swin_mlp192": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
     "amds_pack_swiglu_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "amds_attention_vit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "amds_attention_row": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "amds_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_vit_hd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_qkv_attention_vit257": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -292,6 +292,84 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     }
 }
 
+
+// ---- ONE query row per (bag, head) against all keys / values of the bag: the class token's attention in the LAST layer of the MIL `vit` head -----------------
+// The head reads only the class token's final row (reference vision_tranformer.py: `self.mlp_head(x[:, 0])` behind the last block), so the last block needs keys and
+// values of every token but queries, output projection and MLP of the class rows alone (amds_mil_vit_forward).  One 256-thread workgroup per (bag, head): scores
+// (thread = key, the 128-byte key row against the query in registers) into LDS, block maximum and sum, then the weighted value sum with thread = (4 dims, one of 16 key
+// phases) and a 16-way LDS reduction.  fp32 throughout; q [B][ldq] and out [B][ldo] are 16-bit rows of the heads' 64-channel slices.
+template <typename T>
+__global__ void __launch_bounds__(256) attn_row_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ qkv, T* __restrict__ out, long ldo, int Tn, int H) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    extern __shared__ __attribute__((aligned(16))) float sS[];          // [Tn] scores -> weights | [16][64] partial outputs | [8] reductions
+    float* sRed = sS + ((Tn + 3) & ~3);
+    float* sW = sRed + 16 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int Dm = H * 64;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * 64;
+    float qf[64];
+    {
+        const T* qrow = q + (long)b * ldq + h * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const vec8 v = *reinterpret_cast<const vec8*>(qrow + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[c * 8 + e] = Act<T>::to_f32(v[e]);
+        }
+    }
+    const float sc = 0.125f * 1.44269504088896340736f;
+    float mx = -INFINITY;
+    for (int key = tid; key < Tn; key += 256) {
+        const T* krow = base + (long)key * ld + Dm;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const vec8 v = *reinterpret_cast<const vec8*>(krow + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                a0 = fmaf(qf[c * 8 + e], Act<T>::to_f32(v[e]), a0);
+                a1 = fmaf(qf[c * 8 + e + 1], Act<T>::to_f32(v[e + 1]), a1);
+            }
+        }
+        const float sv = (a0 + a1) * sc;
+        sS[key] = sv;
+        mx = fmaxf(mx, sv);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sW[wave] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(sW[0], sW[1]), fmaxf(sW[2], sW[3]));
+    float ls = 0.f;
+    for (int key = tid; key < Tn; key += 256) {
+        const float pw = __builtin_amdgcn_exp2f(sS[key] - m);
+        sS[key] = pw;
+        ls += pw;
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) sW[4 + wave] = ls;
+    __syncthreads();
+    const float l = (sW[4] + sW[5]) + (sW[6] + sW[7]);
+    const int d4 = (tid & 15) * 4, ph = tid >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int key = ph; key < Tn; key += 16) {
+        const vec4 v = *reinterpret_cast<const vec4*>(base + (long)key * ld + 2 * Dm + d4);
+        const float pw = sS[key];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(pw, Act<T>::to_f32(v[e]), acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(sRed + ph * 64 + d4) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o += sRed[k * 64 + tid];
+        out[(long)b * ldo + h * 64 + tid] = Act<T>::from_f32(o / l);
+    }
+}
+
 }  // namespace amds
 
 using namespace amds;
@@ -307,6 +385,26 @@ extern "C" int amds_attention(const void* qkv, void* out, int B, int T, int H, i
     else if (dtype == AMDS_BF16) hipLaunchKernelGGL((attn_flash_kernel<bf16, false>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, T, H, nullptr, nullptr, nullptr);
     else { set_error("amds_attention: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("attn_flash_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_row(const void* q, long ldq, const void* qkv, void* out, long ldo, int B, int T, int H, int dtype, void* stream) {
+    AMDS_REQUIRE(q && qkv && out, "amds_attention_row: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && T <= 32768 && H > 0 && H <= 65535 && B <= 65535 && ldq >= H * 64 && ldo >= H * 64 && ldq % 8 == 0, "amds_attention_row: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)((T + 3) & ~3) + 16 * 64 + 8) * 4;
+    static bool attr_set[2] = {false, false};
+    const int ti = dtype == AMDS_F16 ? 0 : 1;
+    if (dtype != AMDS_F16 && dtype != AMDS_BF16) { set_error("amds_attention_row: bad dtype %d", dtype); return AMDS_ERR_INVALID; }
+    if (!attr_set[ti]) {
+        if (ti == 0) AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        else AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        attr_set[ti] = true;
+    }
+    if (ti == 0) hipLaunchKernelGGL((attn_row_kernel<f16>), dim3(H, B), dim3(256), lds, st, (const f16*)q, ldq, (const f16*)qkv, (f16*)out, ldo, T, H);
+    else hipLaunchKernelGGL((attn_row_kernel<bf16>), dim3(H, B), dim3(256), lds, st, (const bf16*)q, ldq, (const bf16*)qkv, (bf16*)out, ldo, T, H);
+    AMDS_LAUNCH_CHECK("attn_row_kernel");
     return AMDS_OK;
 }
 

@@ -155,11 +155,36 @@ extern "C" int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds
     AMDS_LAUNCH_CHECK("prefix_cls_kernel");
     if (Dp != D) AMDS_HIP(hipMemsetAsync(h, 0, (size_t)M * Dp * 2, st));      // LayerNorm writes the first D columns only
 
+    // AMDS_MIL_CLS_TAIL=0: every row of the last block (A/B).  Not with ALiBi / padding masks (their attention variants have no one-query form).
+    static const bool tail_env = !(getenv("AMDS_MIL_CLS_TAIL") && atoi(getenv("AMDS_MIL_CLS_TAIL")) == 0);
+    const bool cls_tail = tail_env && !c.alibi && !mask && S <= 32768 && (long)(Bb - 1) * S * Dp * 4 < (1L << 31);
     for (int l = 0; l < c.layers && rc == AMDS_OK; ++l) {
         const amds_mil_vit_layer& L = w.layers_host[l];
         AMDS_REQUIRE(L.ln1_w && L.ln1_b && L.in_w && L.in_b && L.out_w && L.out_b && L.ln2_w && L.ln2_b && L.fc1_w && L.fc1_b && L.fc2_w && L.fc2_b &&
                      (!c.alibi || L.head_scale), "amds_mil_vit_forward: incomplete weights of layer %d", l);
         if ((rc = amds_layernorm(x, Dp, L.ln1_w, L.ln1_b, h, Dp, (int)M, D, 1e-5f, dt, stream)) != AMDS_OK) break;
+        if (cls_tail && l == c.layers - 1) {
+            // Class-row tail: the head reads x[:, 0] behind this block and nothing else (reference vision_tranformer.py: `self.mlp_head(x[:, 0])`), so the block
+            // computes keys | values of every token, and query, attention, output projection and MLP of the class rows alone (row b * S of the token-major
+            // tensors: a row pitch of S * Dp addresses them in place).  The other rows of x keep the previous block's values; nothing reads them.
+            const int esz = 2;
+            const char* w_kv = reinterpret_cast<const char*>(L.in_w) + (size_t)p.Da * Dp * esz;
+            char* qkv_kv = reinterpret_cast<char*>(qkv) + (size_t)p.Da * esz;
+            if ((rc = amds_gemm(h, Dp, w_kv, Dp, (int)M, 2 * p.Da, Dp, dt, AMDS_EPI_BIAS, qkv_kv, 3 * p.Da, L.in_b + p.Da, nullptr, nullptr, 0, 0, 0, 1.0f,
+                                stream)) != AMDS_OK) break;
+            char* qc = reinterpret_cast<char*>(att);                          // [Bb][Da] queries | [Bb][Da] attention outputs (the att buffer is idle)
+            char* oc = qc + (size_t)Bb * p.Da * esz;
+            if ((rc = amds_gemm(h, (long)S * Dp, L.in_w, Dp, Bb, p.Da, Dp, dt, AMDS_EPI_BIAS, qc, p.Da, L.in_b, nullptr, nullptr, 0, 0, 0, 1.0f,
+                                stream)) != AMDS_OK) break;
+            if ((rc = amds_attention_row(qc, p.Da, qkv, oc, p.Da, Bb, S, p.Ha, dt, stream)) != AMDS_OK) break;
+            if ((rc = amds_gemm(oc, p.Da, L.out_w, p.Da, Bb, Dp, p.Da, dt, AMDS_EPI_RESIDUAL, x, (long)S * Dp, L.out_b, nullptr, nullptr, 0, 0, 0, 1.0f,
+                                stream)) != AMDS_OK) break;
+            if ((rc = amds_layernorm(x, (long)S * Dp, L.ln2_w, L.ln2_b, h, Dp, Bb, D, 1e-5f, dt, stream)) != AMDS_OK) break;      // (h's first Bb rows: its LN1 rows are consumed)
+            if ((rc = amds_gemm(h, Dp, L.fc1_w, Dp, Bb, p.FFp, Dp, dt, AMDS_EPI_BIAS_GELU, u, p.FFp, L.fc1_b, nullptr, nullptr, 0, 0, 0, 1.0f,
+                                stream)) != AMDS_OK) break;
+            rc = amds_gemm(u, p.FFp, L.fc2_w, p.FFp, Bb, Dp, p.FFp, dt, AMDS_EPI_RESIDUAL, x, (long)S * Dp, L.fc2_b, nullptr, nullptr, 0, 0, 0, 1.0f, stream);
+            continue;
+        }
         if ((rc = amds_gemm(h, Dp, L.in_w, Dp, (int)M, 3 * p.Da, Dp, dt, AMDS_EPI_BIAS, qkv, 3 * p.Da, L.in_b, nullptr, nullptr, 0, 0, 0, 1.0f,
                             stream)) != AMDS_OK) break;
         if (c.alibi)        // output bf16 (range of the distance term), so the output projection runs on bf16 operands

@@ -249,6 +249,16 @@ def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     return out
 
 
+def attention_row(q: torch.Tensor, qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+    """One query row per (bag, head) -- q [B, H*64] (16-bit) -- against all T keys / values of the packed qkv [B*T, 3*H*64]: the class token's attention in the
+    last block of the MIL `vit` head (`amds_attention_row`).  -> [B, H*64]."""
+    _dev(q, qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * T, 3 * H * 64) and q.shape == (B, H * 64) and q.dtype == qkv.dtype and q.stride(1) == 1
+    out = torch.empty(B, H * 64, dtype=qkv.dtype, device=qkv.device)
+    _lib.check(_lib.lib().amds_attention_row(_p(q), q.stride(0), _p(qkv), _p(out), H * 64, B, T, H, act_code(qkv.dtype), _stream()), "attention_row")
+    return out
+
+
 def attention_alibi(qkv: torch.Tensor, coords: torch.Tensor, head_scale: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     """softmax(q k^T/8) v - head_scale[h] * cdist(coords, coords) v; coords fp32 [B,T,2], head_scale fp32 [H]."""
     _dev(qkv, coords, head_scale)

@@ -48,8 +48,22 @@ def forward_infer_stepwise(pk: PackedVit, bags: torch.Tensor, coords: torch.Tens
         pad = torch.cat([mask.new_zeros(Bb, 1), mask], dim=1).to(dev, torch.uint8).contiguous()      # class token never padded (:356-358)
     hbuf = torch.zeros(M, d.Dp, dtype=act, device=dev) if d.Dp != d.D else None
     lib, st = _lib.lib(), ops._stream()
-    for Lm, Lw in zip(pk.m["layers"], pk.w["layers"]):
+    import os
+    cls_tail = os.environ.get("AMDS_MIL_CLS_TAIL", "1") != "0" and not d.alibi and pad is None
+    n_layers = len(pk.m["layers"])
+    for li, (Lm, Lw) in enumerate(zip(pk.m["layers"], pk.w["layers"])):
         h = _ln(x, M, d.D, d.Dp, *Lm["ln1"], act, d.Dp, hbuf)
+        if cls_tail and li == n_layers - 1:      # class-row tail of the last block (csrc/mil_vit.hip): k | v of all tokens, the rest on the class rows alone
+            qkv = torch.empty(M, 3 * d.Da, dtype=act, device=dev)
+            ops.gemm(h, Lw["in_w"][d.Da:], _lib.EPI_BIAS, bias=Lm["in_b"][d.Da:], out=qkv[:, d.Da:])
+            hc, xc = h.view(Bb, S, d.Dp)[:, 0], x.view(Bb, S, d.Dp)[:, 0]
+            qc = ops.gemm(hc, Lw["in_w"][:d.Da], _lib.EPI_BIAS, bias=Lm["in_b"][:d.Da])
+            oc = ops.attention_row(qc, qkv, Bb, S, d.Ha)
+            ops.gemm(oc, Lw["out_w"], _lib.EPI_RESIDUAL, bias=Lm["out_b"], out=xc)
+            h2 = _ln(x, Bb, d.D, S * d.Dp, *Lm["ln2"], act, d.Dp, hbuf[:Bb] if hbuf is not None else None)
+            u = ops.gemm(h2, Lw["fc1_w"], _lib.EPI_BIAS_GELU, bias=Lm["fc1_b"])
+            ops.gemm(u, Lw["fc2_w"], _lib.EPI_RESIDUAL, bias=Lm["fc2_b"], out=xc)
+            continue
         qkv = ops.gemm(h, Lw["in_w"], _lib.EPI_BIAS, bias=Lm["in_b"])
         if d.alibi:
             scale = (Lm["bias_scale"] * Lm["inv_rm"]).contiguous()

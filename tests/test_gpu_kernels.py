@@ -239,6 +239,26 @@ def test_attention_streaming_any_length(gpu, dt, B, T, H):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,H", [(3, 1025, 8), (2, 212, 4), (1, 1, 1), (5, 63, 2), (2, 5000, 3)])
+def test_attention_row_is_the_class_tokens_row_of_the_full_attention(gpu, dt, B, T, H):
+    """amds_attention_row: ONE query per (bag, head) against all keys / values of the packed qkv -- the class token's attention in the last block of the MIL `vit`
+    head, whose other rows nothing reads (vision_tranformer.py: the head takes x[:, 0]).  Against fp64 softmax(q k^T / 8) v on the same 16-bit inputs (its weights
+    stay fp32: closer than the streaming kernel's row), and within the streaming kernel's own tolerance of that kernel's row 0; deterministic."""
+    g = torch.Generator().manual_seed(B * 100 + T + H)
+    D = H * 64
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(gpu, dt)
+    q = qkv.view(B, T, 3 * D)[:, 0, :D]                                   # the class rows' queries, in place (row pitch T * 3 D)
+    out = ops.attention_row(q, qkv, B, T, H)
+    qq, k, v = qkv.double().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(qq[:, :, :1] @ k.transpose(-1, -2) / 8.0, -1) @ v).reshape(B, D)
+    tol = 2 * _eps(dt) * max(1.0, ref.abs().max().item())
+    assert (out.double() - ref).abs().max().item() < tol
+    full = ops.attention(qkv, B, T, H).view(B, T, D)[:, 0]
+    assert (out.double() - full.double()).abs().max().item() < 4 * _eps(dt) * max(1.0, ref.abs().max().item())
+    assert torch.equal(out, ops.attention_row(q, qkv, B, T, H))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,T,H", [(2, 261, 16), (1, 257, 2), (3, 100, 1), (1, 288, 3), (2, 33, 2)])
 def test_attention_vit_head_dim_80(gpu, dt, B, T, H):
     g = torch.Generator().manual_seed(B * 31 + T + H)
