@@ -270,6 +270,20 @@ int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, v
  * fp32 arithmetic, 16-bit q [B][ldq] and out [B][ldo].  The class token's attention in the LAST block of the MIL `vit` head, whose other rows nothing reads (reference
  * src/stamp/modeling/models/vision_tranformer.py: the head takes `x[:, 0]` behind the last block).  T <= 32768. */
 int amds_attention_row(const void* q, long ldq, const void* qkv, void* out, long ldo, int B, int T, int H, int dtype, void* stream);
+/* The same for query row `qrow` of every bag IN PLACE of the token-major tensors, in the training forward's form and its backward -- for a block of which only
+ * that row is read afterwards (the last block of the MIL `vit` head: `self.mlp_head(x[:, 0])`, reference src/stamp/modeling/models/vision_tranformer.py):
+ *   fwd: out[(b T + qrow)][h*64..] = (M o softmax(q k^T / 8)) v with dropout p on the probabilities (the bits amds_attention_fwd_train draws for that row),
+ *        lse[(b H + h) T + qrow] as amds_attention_fwd_lse; the other rows of out and lse are not touched.
+ *   bwd: the WHOLE dqkv [B*T][3*H*64] of a block whose other query rows carry no gradient: dK, dV of every token (rank-1 in the one query), dQ zero but for
+ *        row qrow.  out / dout: the [B*T][H*64] tensors (only row qrow of each bag is read). */
+int amds_attention_row_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int qrow, int dtype, float p, uint64_t seed,
+                                 uint32_t stream_id, void* stream);
+int amds_attention_row_bwd_train(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T, int H, int qrow,
+                                 int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
+/* Process-wide switch (default 1; AMDS_MIL_CLS_TAIL=0 in the environment starts at 0): the MIL `vit` head's last block computed for the class rows alone where the
+ * block's other rows are dead (amds_mil_vit_forward without ALiBi / mask; the attention of amds_mil_vit_train_forward / _backward without ALiBi). */
+int amds_set_mil_cls_tail(int on);
+int amds_get_mil_cls_tail(void);
 
 /* ALiBi variant of the reference's MultiHeadALiBi (src/stamp/modeling/models/vision_tranformer.py:42-74, eval mode):
  *   out = softmax(q k^T / 8) v  -  head_scale[h] * cdist(coords_q, coords_k) v        (bias applied AFTER the softmax)

@@ -214,6 +214,10 @@ PROTOTYPES = {
     "amds_pack_swiglu_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "amds_attention_vit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_row": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "amds_attention_row_fwd_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, C.c_uint32, _vp]),
+    "amds_attention_row_bwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, C.c_uint32, _vp]),
+    "amds_set_mil_cls_tail": (_i, [_i]),
+    "amds_get_mil_cls_tail": (_i, []),
     "amds_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_vit_hd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_qkv_attention_vit257": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

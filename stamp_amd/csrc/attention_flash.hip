@@ -298,8 +298,12 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
 // values of every token but queries, output projection and MLP of the class rows alone (amds_mil_vit_forward).  One 256-thread workgroup per (bag, head): scores
 // (thread = key, the 128-byte key row against the query in registers) into LDS, block maximum and sum, then the weighted value sum with thread = (4 dims, one of 16 key
 // phases) and a 16-way LDS reduction.  fp32 throughout; q [B][ldq] and out [B][ldo] are 16-bit rows of the heads' 64-channel slices.
-template <typename T>
-__global__ void __launch_bounds__(256) attn_row_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ qkv, T* __restrict__ out, long ldo, int Tn, int H) {
+// DROP / lse: the training forward's form (amds_attention_fwd_train for query row `qrow` of every bag): dropout on the attention probabilities with the bits of
+// the blocked kernel (row key of (bag, head, qrow), one hash per key pair), the log2-domain log-sum-exp of the UNdropped softmax into lse[(b H + h) T + qrow].
+template <typename T, bool DROP = false>
+__global__ void __launch_bounds__(256) attn_row_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ qkv, T* __restrict__ out, long ldo, int Tn, int H,
+                                                       float* __restrict__ lse = nullptr, int qrow = 0, uint64_t seed = 0, uint32_t drop_stream = 0,
+                                                       uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     extern __shared__ __attribute__((aligned(16))) float sS[];          // [Tn] scores -> weights | [16][64] partial outputs | [8] reductions
@@ -352,11 +356,15 @@ __global__ void __launch_bounds__(256) attn_row_kernel(const T* __restrict__ q, 
     if (lane == 0) sW[4 + wave] = ls;
     __syncthreads();
     const float l = (sW[4] + sW[5]) + (sW[6] + sW[7]);
+    if (lse && tid == 0) lse[((long)b * H + h) * Tn + qrow] = m + log2f(l);
+    uint32_t rowkey = 0;
+    if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qrow));
     const int d4 = (tid & 15) * 4, ph = tid >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int key = ph; key < Tn; key += 16) {
         const vec4 v = *reinterpret_cast<const vec4*>(base + (long)key * ld + 2 * Dm + d4);
-        const float pw = sS[key];
+        float pw = sS[key];
+        if constexpr (DROP) pw = drop_keep(drop_pair_bits(rowkey, (uint32_t)key >> 1), key & 1, thr16) ? pw * keep_scale : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(pw, Act<T>::to_f32(v[e]), acc[e]);
     }
@@ -367,6 +375,100 @@ __global__ void __launch_bounds__(256) attn_row_kernel(const T* __restrict__ q, 
 #pragma unroll
         for (int k = 0; k < 16; ++k) o += sRed[k * 64 + tid];
         out[(long)b * ldo + h * 64 + tid] = Act<T>::from_f32(o / l);
+    }
+}
+
+
+// Backward of the one-query attention above for query row `qrow` of every bag, when NO other query row of the block has a gradient (the last block of the MIL
+// `vit` head): the whole dqkv tensor of the block in one pass -- dK_k = dS_k q / 8 and dV_k = (M o P)_k dO are rank-1 in the one query, dQ is zero but for that
+// row.  dS_k = P_k (M_k dP_k - D), dP_k = dO . v_k, D = dO . O (O the dropped output, as stored), P from the saved log-sum-exp; M regenerated from the counters.
+template <typename T, bool DROP>
+__global__ void __launch_bounds__(256) attn_row_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ o, long ldo, const T* __restrict__ dout, long ldd,
+                                                           const float* __restrict__ lse, T* __restrict__ dqkv, int Tn, int H, int qrow, uint64_t seed,
+                                                           uint32_t drop_stream, uint32_t thr16, float keep_scale) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    extern __shared__ __attribute__((aligned(16))) float sS[];          // [Tn] dS | [16][64] partial dq
+    float* sRed = sS + ((Tn + 3) & ~3);
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int Dm = H * 64;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * 64;
+    T* dbase = dqkv + (long)b * Tn * ld + h * 64;
+    float qf[64], gf[64];
+    float Dq = 0.f;
+    {
+        const T* qr = base + (long)qrow * ld;
+        const T* gr = dout + (long)b * ldd + h * 64;
+        const T* orow = o + (long)b * ldo + h * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const vec8 qv = *reinterpret_cast<const vec8*>(qr + c * 8), gv = *reinterpret_cast<const vec8*>(gr + c * 8), ov = *reinterpret_cast<const vec8*>(orow + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qf[c * 8 + e] = Act<T>::to_f32(qv[e]);
+                gf[c * 8 + e] = Act<T>::to_f32(gv[e]);
+                Dq = fmaf(gf[c * 8 + e], Act<T>::to_f32(ov[e]), Dq);
+            }
+        }
+    }
+    const float sc = 0.125f * 1.44269504088896340736f;
+    const float L = lse[((long)b * H + h) * Tn + qrow];
+    uint32_t rowkey = 0;
+    if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qrow));
+    for (int key = tid; key < Tn; key += 256) {
+        const T* krow = base + (long)key * ld + Dm;
+        vec8 vv[8];
+        float s0 = 0.f, s1 = 0.f, p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const vec8 kv = *reinterpret_cast<const vec8*>(krow + c * 8);
+            vv[c] = *reinterpret_cast<const vec8*>(krow + Dm + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                s0 = fmaf(qf[c * 8 + e], Act<T>::to_f32(kv[e]), s0);
+                s1 = fmaf(qf[c * 8 + e + 1], Act<T>::to_f32(kv[e + 1]), s1);
+                p0 = fmaf(gf[c * 8 + e], Act<T>::to_f32(vv[c][e]), p0);
+                p1 = fmaf(gf[c * 8 + e + 1], Act<T>::to_f32(vv[c][e + 1]), p1);
+            }
+        }
+        const float pk = __builtin_amdgcn_exp2f((s0 + s1) * sc - L);
+        float mk = 1.f;
+        if constexpr (DROP) mk = drop_keep(drop_pair_bits(rowkey, (uint32_t)key >> 1), key & 1, thr16) ? keep_scale : 0.f;
+        const float dS = pk * (mk * (p0 + p1) - Dq), pw = pk * mk, dk = dS * 0.125f;
+        sS[key] = dS;
+        T* drow = dbase + (long)key * ld;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            vec8 wq, wk, wv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wq[e] = (T)0.f;
+                wk[e] = Act<T>::from_f32(dk * qf[c * 8 + e]);
+                wv[e] = Act<T>::from_f32(pw * gf[c * 8 + e]);
+            }
+            if (key != qrow) *reinterpret_cast<vec8*>(drow + c * 8) = wq;          // (the query row's own dQ is written below)
+            *reinterpret_cast<vec8*>(drow + Dm + c * 8) = wk;
+            *reinterpret_cast<vec8*>(drow + 2 * Dm + c * 8) = wv;
+        }
+    }
+    __syncthreads();
+    const int d4 = (tid & 15) * 4, ph = tid >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int key = ph; key < Tn; key += 16) {
+        const vec4 kv = *reinterpret_cast<const vec4*>(base + (long)key * ld + Dm + d4);
+        const float dS = sS[key];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(dS, Act<T>::to_f32(kv[e]), acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(sRed + ph * 64 + d4) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float dq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dq += sRed[k * 64 + tid];
+        dbase[(long)qrow * ld + tid] = Act<T>::from_f32(dq * 0.125f);
     }
 }
 
@@ -405,6 +507,57 @@ extern "C" int amds_attention_row(const void* q, long ldq, const void* qkv, void
     if (ti == 0) hipLaunchKernelGGL((attn_row_kernel<f16>), dim3(H, B), dim3(256), lds, st, (const f16*)q, ldq, (const f16*)qkv, (f16*)out, ldo, T, H);
     else hipLaunchKernelGGL((attn_row_kernel<bf16>), dim3(H, B), dim3(256), lds, st, (const bf16*)q, ldq, (const bf16*)qkv, (bf16*)out, ldo, T, H);
     AMDS_LAUNCH_CHECK("attn_row_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_row_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int qrow, int dtype, float p, uint64_t seed,
+                                            uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(qkv && out && lse, "amds_attention_row_fwd_train: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && T <= 32768 && H > 0 && H <= 65535 && B <= 65535 && qrow >= 0 && qrow < T && p >= 0.f && p < 1.f,
+                 "amds_attention_row_fwd_train: bad arguments B=%d T=%d H=%d row=%d p=%f", B, T, H, qrow, p);
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_attention_row_fwd_train: bad dtype %d", dtype);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)((T + 3) & ~3) + 16 * 64 + 8) * 4;
+    const long Dm = (long)H * 64, ldq = (long)T * 3 * Dm, ldo = (long)T * Dm;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const float ks = p > 0.f ? drop_scale(thr) : 1.f;
+    static bool attr[4] = {false, false, false, false};
+#define AMDS_ROW_FWD(TT, DR, IDX)                                                                                                                         \
+    do {                                                                                                                                                  \
+        if (!attr[IDX]) { AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_kernel<TT, DR>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr[IDX] = true; } \
+        hipLaunchKernelGGL((attn_row_kernel<TT, DR>), dim3(H, B), dim3(256), lds, st, (const TT*)qkv + (long)qrow * 3 * Dm, ldq, (const TT*)qkv,          \
+                           (TT*)out + (long)qrow * Dm, ldo, T, H, lse, qrow, seed, stream_id, thr, ks);                                                   \
+    } while (0)
+    if (dtype == AMDS_F16) { if (p > 0.f) AMDS_ROW_FWD(f16, true, 0); else AMDS_ROW_FWD(f16, false, 1); }
+    else { if (p > 0.f) AMDS_ROW_FWD(bf16, true, 2); else AMDS_ROW_FWD(bf16, false, 3); }
+#undef AMDS_ROW_FWD
+    AMDS_LAUNCH_CHECK("attn_row_kernel<train>");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_row_bwd_train(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T, int H, int qrow,
+                                            int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(qkv && out && dout && lse && dqkv, "amds_attention_row_bwd_train: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0 && T <= 32768 && H > 0 && H <= 65535 && B <= 65535 && qrow >= 0 && qrow < T && p >= 0.f && p < 1.f,
+                 "amds_attention_row_bwd_train: bad arguments B=%d T=%d H=%d row=%d p=%f", B, T, H, qrow, p);
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_attention_row_bwd_train: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)((T + 3) & ~3) + 16 * 64) * 4;
+    const long Dm = (long)H * 64, ldo = (long)T * Dm;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const float ks = p > 0.f ? drop_scale(thr) : 1.f;
+    static bool attr[4] = {false, false, false, false};
+#define AMDS_ROW_BWD(TT, DR, IDX)                                                                                                                         \
+    do {                                                                                                                                                  \
+        if (!attr[IDX]) { AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_bwd_kernel<TT, DR>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr[IDX] = true; } \
+        hipLaunchKernelGGL((attn_row_bwd_kernel<TT, DR>), dim3(H, B), dim3(256), lds, st, (const TT*)qkv, (const TT*)out + (long)qrow * Dm, ldo,          \
+                           (const TT*)dout + (long)qrow * Dm, ldo, lse, (TT*)dqkv, T, H, qrow, seed, stream_id, thr, ks);                                 \
+    } while (0)
+    if (dtype == AMDS_F16) { if (p > 0.f) AMDS_ROW_BWD(f16, true, 0); else AMDS_ROW_BWD(f16, false, 1); }
+    else { if (p > 0.f) AMDS_ROW_BWD(bf16, true, 2); else AMDS_ROW_BWD(bf16, false, 3); }
+#undef AMDS_ROW_BWD
+    AMDS_LAUNCH_CHECK("attn_row_bwd_kernel");
     return AMDS_OK;
 }
 

@@ -302,7 +302,13 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
         RC(gemm(h1, Dp, Lw.in_w, Dp, M, 3 * Da, Dp, AMDS_EPI_BIAS, qkv, 3 * Da, Lw.in_b, stream));
         if (d.alibi)
             RC(amds_attention_alibi_fwd_train(qkv, cc, Lw.inv_running_mean, Lw.bias_scale, att, sv + o.u_al, sv + o.osm, lse, Bb, S, Ha, BF, stream));
-        else
+        else if (l == d.L - 1 && S <= 32768 && amds_get_mil_cls_tail()) {
+            // The head reads the class row of the last block and nothing else (reference vision_tranformer.py: `self.mlp_head(x[:, 0])`): only that query's
+            // attention is computed (amds_attention_row_fwd_train: the bits of the dropout the blocked kernel draws for row 0); the other rows of `att` are
+            // zeros -- they still pass through the block's GEMMs (finite, unread), and carry no gradient back.
+            AMDS_HIP(hipMemsetAsync(att, 0, (size_t)M * Da * 2, st));
+            RC(amds_attention_row_fwd_train(qkv, att, lse, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
+        } else
             RC(amds_attention_fwd_train(qkv, att, lse, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         RC(gemm(att, Da, Lw.out_w, Da, M, Dp, Da, AMDS_EPI_RESIDUAL, x_mid, Dp, Lw.out_b, stream));
         // x_out = x_mid + Dropout(fc2(Dropout(GELU(fc1(LayerNorm(x_mid))))))   (:157-169, :293)
@@ -555,6 +561,10 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
                 AMDS_LAUNCH_CHECK("head_part_rows_kernel");
                 RC(colsum(dbst, Ha, Gl->bias_scale, M, Ha, AMDS_F32));
             }
+        } else if (l == d.L - 1 && S <= 32768 && amds_get_mil_cls_tail()) {
+            // (the forward computed the class query's attention alone: every other row of datt is exactly zero -- dx of the last block lives on the class rows --
+            //  so dK / dV are rank-1 in that query and dQ is zero elsewhere: one pass instead of the two blocked kernels)
+            RC(amds_attention_row_bwd_train(qkv, att, datt, lse, dqkv, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
         } else {
             RC(amds_attention_bwd_train(qkv, att, datt, lse, dqs, dqkv, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         }

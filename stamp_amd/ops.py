@@ -249,6 +249,14 @@ def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     return out
 
 
+def set_mil_cls_tail(on: bool) -> bool:
+    """Process-wide switch of the MIL `vit` head's class-row tail (`amds_set_mil_cls_tail`; default on): returns the previous setting."""
+    lib = _lib.lib()
+    prev = bool(lib.amds_get_mil_cls_tail())
+    _lib.check(lib.amds_set_mil_cls_tail(1 if on else 0), "set_mil_cls_tail")
+    return prev
+
+
 def attention_row(q: torch.Tensor, qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     """One query row per (bag, head) -- q [B, H*64] (16-bit) -- against all T keys / values of the packed qkv [B*T, 3*H*64]: the class token's attention in the
     last block of the MIL `vit` head (`amds_attention_row`).  -> [B, H*64]."""
