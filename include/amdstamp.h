@@ -1115,6 +1115,14 @@ int amds_dropout_add(const float* y, long ldy, const float* x_in, long ldx, floa
                      uint64_t seed, uint32_t stream_id, void* stream);
 int amds_dropout_cast_bwd(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, int out_dtype, float p, uint64_t seed,
                           uint32_t stream_id, void* stream);
+/* The four element-wise dropout sites on `rows` pitched rows whose LOGICAL row index is r * row_mul (the class rows b * S of the MIL `vit` head's last block, of which
+ * nothing else is read): the mask of element (r, c) is the one the functions above draw for element (r * row_mul, c) of the full tensor.  bf16 tensors; p = 0: no mask. */
+int amds_gelu_dropout_fwd_rows(const void* z, long ldz, void* u, long ldu, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id, void* stream);
+int amds_gelu_dropout_bwd_rows(const void* z, long ldz, const void* du, long ldu, void* dz, long lddz, long rows, int cols, long row_mul, float p, uint64_t seed,
+                               uint32_t stream_id, void* stream);
+int amds_dropout_add_rows(const float* y, long ldy, const float* x_in, long ldx, float* x_out, long ldo, long rows, int cols, long row_mul, float p, uint64_t seed,
+                          uint32_t stream_id, void* stream);
+int amds_dropout_cast_bwd_rows(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id, void* stream);
 int amds_dropout_mask(uint8_t* mask, long n, float p, uint64_t seed, uint32_t stream_id, void* stream);
 int amds_attention_dropout_mask(uint8_t* mask, int B, int H, int T, float p, uint64_t seed, uint32_t stream_id, void* stream);
 /* rowsum[b*T + q] = sum_k |coords[b,q] - coords[b,k]|: the batch statistic `_RunningMeanScaler` needs (mean of torch.cdist). */

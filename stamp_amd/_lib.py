@@ -330,6 +330,10 @@ PROTOTYPES = {
     "amds_gelu_dropout_fwd": (_i, [_vp, _vp, _l, _i, _i, _f, _u64, _u32, _vp]),
     "amds_gelu_dropout_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _f, _u64, _u32, _vp]),
     "amds_dropout_add": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _f, _u64, _u32, _vp]),
+    "amds_gelu_dropout_fwd_rows": (_i, [_vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),
+    "amds_gelu_dropout_bwd_rows": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),
+    "amds_dropout_add_rows": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),
+    "amds_dropout_cast_bwd_rows": (_i, [_vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_dropout_cast_bwd": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _f, _u64, _u32, _vp]),
     "amds_dropout_mask": (_i, [_vp, _l, _f, _u64, _u32, _vp]),
     "amds_attention_dropout_mask": (_i, [_vp, _i, _i, _i, _f, _u64, _u32, _vp]),

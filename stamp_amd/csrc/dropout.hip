@@ -7,6 +7,7 @@
 //   amds_dropout_add               x_out = x_in + drop(y)          (second feed-forward dropout + residual add)
 //   amds_dropout_cast_bwd          dy16 = (16-bit) drop'(dx)       (gradient entering fc2's backward GEMMs)
 //   amds_dropout_mask / amds_attention_dropout_mask   the masks themselves as u8, for the parity tests
+#include <algorithm>
 #include "common.h"
 
 namespace amds {
@@ -171,12 +172,103 @@ __global__ void attn_dropout_mask_kernel(uint8_t* __restrict__ m, int H, int Tn,
 
 static inline int grid1d_(long n) { return (int)min((long)8192, (n + 255) / 256); }
 
+// ---- the same four element-wise sites on a FEW rows of the tensor (pitched, logical row = r * row_mul): the class rows of the MIL `vit` head's last block, whose other
+// rows nothing reads.  The mask of element (r, c) is that of element (r * row_mul, c) of the full [rows * row_mul][cols] tensor -- the bits the kernels above draw there.
+template <typename TZ, typename TO>
+__global__ void gelu_dropout_fwd_rows_kernel(const TZ* __restrict__ z, long ldz, TO* __restrict__ u, long ldu, long rows, int cols, long row_mul, uint64_t seed,
+                                             uint32_t stream, uint32_t thr, float scale) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float g = gelu_erf((float)z[r * ldz + c]);
+        u[r * ldu + c] = (TO)(drop_keep_flat(seed, stream, r * row_mul * cols + c, thr) ? g * scale : 0.f);
+    }
+}
+template <typename TZ, typename TG, typename TO>
+__global__ void gelu_dropout_bwd_rows_kernel(const TZ* __restrict__ z, long ldz, const TG* __restrict__ du, long ldu, TO* __restrict__ dz, long lddz, long rows, int cols,
+                                             long row_mul, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float x = (float)z[r * ldz + c];
+        const float d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+        dz[r * lddz + c] = (TO)(drop_keep_flat(seed, stream, r * row_mul * cols + c, thr) ? (float)du[r * ldu + c] * d * scale : 0.f);
+    }
+}
+__global__ void dropout_add_rows_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ xin, long ldx, float* __restrict__ xout, long ldo, long rows,
+                                        int cols, long row_mul, uint64_t seed, uint32_t stream, uint32_t thr, float scale) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = y[r * ldy + c];
+        xout[r * ldo + c] = xin[r * ldx + c] + (drop_keep_flat(seed, stream, r * row_mul * cols + c, thr) ? v * scale : 0.f);
+    }
+}
+template <typename TO>
+__global__ void dropout_cast_bwd_rows_kernel(const float* __restrict__ dx, long ldx, TO* __restrict__ dy, long ldy, long rows, int cols, long row_mul, uint64_t seed,
+                                             uint32_t stream, uint32_t thr, float scale) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        dy[r * ldy + c] = (TO)(drop_keep_flat(seed, stream, r * row_mul * cols + c, thr) ? dx[r * ldx + c] * scale : 0.f);
+    }
+}
 }  // namespace amds
 
 using namespace amds;
 
 #define DROP_ARGS_OK(p) ((p) >= 0.f && (p) < 1.f)
 
+
+// p = 0: plain GELU / its derivative / a plain add / a plain cast (threshold 0 keeps everything at scale 1).  bf16 tensors (the MIL training step's operand type).
+extern "C" int amds_gelu_dropout_fwd_rows(const void* z, long ldz, void* u, long ldu, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id,
+                                          void* stream) {
+    AMDS_REQUIRE(z && u && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_gelu_dropout_fwd_rows: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
+    hipLaunchKernelGGL((gelu_dropout_fwd_rows_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, ldz, (bf16*)u, ldu, rows, cols, row_mul, seed,
+                       stream_id, thr, thr ? drop_scale(thr) : 1.0f);
+    AMDS_LAUNCH_CHECK("gelu_dropout_fwd_rows_kernel");
+    return AMDS_OK;
+}
+extern "C" int amds_gelu_dropout_bwd_rows(const void* z, long ldz, const void* du, long ldu, void* dz, long lddz, long rows, int cols, long row_mul, float p,
+                                          uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(z && du && dz && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_gelu_dropout_bwd_rows: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
+    hipLaunchKernelGGL((gelu_dropout_bwd_rows_kernel<bf16, bf16, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, ldz, (const bf16*)du, ldu, (bf16*)dz,
+                       lddz, rows, cols, row_mul, seed, stream_id, thr, thr ? drop_scale(thr) : 1.0f);
+    AMDS_LAUNCH_CHECK("gelu_dropout_bwd_rows_kernel");
+    return AMDS_OK;
+}
+extern "C" int amds_dropout_add_rows(const float* y, long ldy, const float* x_in, long ldx, float* x_out, long ldo, long rows, int cols, long row_mul, float p,
+                                     uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(y && x_in && x_out && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_dropout_add_rows: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
+    hipLaunchKernelGGL(dropout_add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, x_in, ldx, x_out, ldo, rows, cols, row_mul, seed, stream_id, thr,
+                       thr ? drop_scale(thr) : 1.0f);
+    AMDS_LAUNCH_CHECK("dropout_add_rows_kernel");
+    return AMDS_OK;
+}
+extern "C" int amds_dropout_cast_bwd_rows(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id,
+                                          void* stream) {
+    AMDS_REQUIRE(dx && dy && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_dropout_cast_bwd_rows: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
+    hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (bf16*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,
+                       thr ? drop_scale(thr) : 1.0f);
+    AMDS_LAUNCH_CHECK("dropout_cast_bwd_rows_kernel");
+    return AMDS_OK;
+}
 extern "C" float amds_dropout_keep_scale(float p) { return drop_scale(drop_thr16(p)); }
 
 extern "C" int amds_gelu_dropout_fwd(const void* z, void* u, long n, int in_dtype, int out_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream) {

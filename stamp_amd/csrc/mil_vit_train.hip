@@ -209,6 +209,11 @@ int gelu_drop_bwd(const void* z, const void* du, void* dz, long n, int zdt, int 
 constexpr int CFG_TRAIN = -2;      // amds_gemm_ex: by shape, ragged last row tile as its own small launch (M = bags x 1025 is never a multiple of 256)
 constexpr int BF = AMDS_BF16;
 
+// the last block on its class rows alone (amds_set_mil_cls_tail; not with ALiBi: its attention has no one-query form; pitched rows must fit the 32-bit descriptors)
+bool cls_tail(const Dims& d) {
+    return amds_get_mil_cls_tail() && !d.alibi && d.L > 0 && d.S <= 32768 && (long)(d.Bb + 1) * d.S * std::max(d.FFp, 3 * d.Da) * 4 < (1L << 31);
+}
+
 int gemm(const void* A, long lda, const void* W, long ldw, long M, int N, int K, int epi, void* out, long ldo, const float* bias, void* st) {
     return amds_gemm_ex(CFG_TRAIN, A, lda, W, ldw, (int)M, N, K, BF, epi, out, ldo, bias, nullptr, nullptr, 0, 0, 0, 1.0f, st);
 }
@@ -299,16 +304,34 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
         // (the LayerNorm kernel also writes x_mid = x_in, which the out-projection's residual epilogue then updates in place)
         RC(amds_layernorm_train_copy(x_in, Dp, Lw.ln1_w, Lw.ln1_b, h1, Dp, reinterpret_cast<float*>(sv + o.mu1), reinterpret_cast<float*>(sv + o.rs1), (int)M, D,
                                      1e-5f, BF, x_mid, Dp, Dp, stream));
+        if (cls_tail(d) && l == d.L - 1) {
+            // Class-row tail.  The head reads the class row of the last block and nothing else (reference vision_tranformer.py: `self.mlp_head(x[:, 0])`), so this
+            // block computes keys | values of every token and -- on the class rows alone, addressed in place by a row pitch of S rows -- the query, its attention
+            // (amds_attention_row_fwd_train), the output projection and the MLP.  Dropout draws the bits the full block draws for those rows (row_mul = S).
+            // The other rows of att / x_mid's update / h2 / z / u / x_out are never written and never read; they carry no gradient back.
+            const long pS = S;
+            RC(gemm(h1, Dp, reinterpret_cast<const char*>(Lw.in_w) + (size_t)Da * Dp * 2, Dp, M, 2 * Da, Dp, AMDS_EPI_BIAS, reinterpret_cast<char*>(qkv) + (size_t)Da * 2,
+                    3 * Da, Lw.in_b + Da, stream));
+            RC(gemm(h1, pS * Dp, Lw.in_w, Dp, Bb, Da, Dp, AMDS_EPI_BIAS, qkv, pS * 3 * Da, Lw.in_b, stream));
+            RC(amds_attention_row_fwd_train(qkv, att, lse, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
+            RC(gemm(att, pS * Da, Lw.out_w, Da, Bb, Dp, Da, AMDS_EPI_RESIDUAL, x_mid, pS * Dp, Lw.out_b, stream));
+            RC(amds_layernorm_train_copy(x_mid, pS * Dp, Lw.ln2_w, Lw.ln2_b, h2, pS * Dp, reinterpret_cast<float*>(sv + o.mu2), reinterpret_cast<float*>(sv + o.rs2), Bb, D,
+                                         1e-5f, BF, p_ff > 0.f ? nullptr : x_out, pS * Dp, Dp, stream));
+            RC(gemm(h2, pS * Dp, Lw.fc1_w, Dp, Bb, FFp, Dp, AMDS_EPI_BIAS, z, pS * FFp, Lw.fc1_b, stream));
+            RC(amds_gelu_dropout_fwd_rows(z, pS * FFp, u, pS * FFp, Bb, FFp, pS, p_ff, seed, 10 * l + 2, stream));
+            if (p_ff > 0.f) {
+                float* y = reinterpret_cast<float*>(sv + sp.y);
+                RC(gemm(u, pS * FFp, Lw.fc2_w, FFp, Bb, Dp, FFp, AMDS_EPI_BIAS_F32, y, Dp, Lw.fc2_b, stream));
+                RC(amds_dropout_add_rows(y, Dp, x_mid, pS * Dp, x_out, pS * Dp, Bb, Dp, pS, p_ff, seed, 10 * l + 3, stream));
+            } else {
+                RC(gemm(u, pS * FFp, Lw.fc2_w, FFp, Bb, Dp, FFp, AMDS_EPI_RESIDUAL, x_out, pS * Dp, Lw.fc2_b, stream));
+            }
+            continue;
+        }
         RC(gemm(h1, Dp, Lw.in_w, Dp, M, 3 * Da, Dp, AMDS_EPI_BIAS, qkv, 3 * Da, Lw.in_b, stream));
         if (d.alibi)
             RC(amds_attention_alibi_fwd_train(qkv, cc, Lw.inv_running_mean, Lw.bias_scale, att, sv + o.u_al, sv + o.osm, lse, Bb, S, Ha, BF, stream));
-        else if (l == d.L - 1 && S <= 32768 && amds_get_mil_cls_tail()) {
-            // The head reads the class row of the last block and nothing else (reference vision_tranformer.py: `self.mlp_head(x[:, 0])`): only that query's
-            // attention is computed (amds_attention_row_fwd_train: the bits of the dropout the blocked kernel draws for row 0); the other rows of `att` are
-            // zeros -- they still pass through the block's GEMMs (finite, unread), and carry no gradient back.
-            AMDS_HIP(hipMemsetAsync(att, 0, (size_t)M * Da * 2, st));
-            RC(amds_attention_row_fwd_train(qkv, att, lse, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
-        } else
+        else
             RC(amds_attention_fwd_train(qkv, att, lse, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         RC(gemm(att, Da, Lw.out_w, Da, M, Dp, Da, AMDS_EPI_RESIDUAL, x_mid, Dp, Lw.out_b, stream));
         // x_out = x_mid + Dropout(fc2(Dropout(GELU(fc1(LayerNorm(x_mid))))))   (:157-169, :293)
@@ -507,6 +530,32 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         const float* x_mid = reinterpret_cast<const float*>(sv + o.x_mid);
         const void *h1 = sv + o.h1, *h2 = sv + o.h2, *qkv = sv + o.qkv, *att = sv + o.att, *z = sv + o.z, *u = sv + o.u;
         const float* lse = reinterpret_cast<const float*>(sv + o.lse);
+        const bool tail = cls_tail(d) && l == d.L - 1;
+        if (tail) {
+            // Class-row tail (see the forward): dx of the last block lives on the class rows; its MLP, second LayerNorm and output projection are differentiated on
+            // those Bb rows alone (row pitch S rows, dropout bits of the full tensors' rows b * S).
+            const long pS = S;
+            RC(amds_dropout_cast_bwd_rows(dx, pS * Dp, g16, pS * Dp, Bb, Dp, pS, p_ff, seed, (uint32_t)(10 * l + 3), stream));
+            RC(gemm(g16, pS * Dp, Lw.fc2_wt, Dp, Bb, FFp, Dp, AMDS_EPI_BIAS, du, pS * FFp, nullptr, stream));
+            if (need_params) {
+                RC(wgrad_tn(g16, pS * Dp, u, pS * FFp, Bb, Dp, FFp, Gl->fc2_w));
+                RC(p_ff > 0.f ? colsum(g16, pS * Dp, Gl->fc2_b, Bb, Dp, BF) : colsum(dx, pS * Dp, Gl->fc2_b, Bb, Dp, AMDS_F32));
+            }
+            RC(amds_gelu_dropout_bwd_rows(z, pS * FFp, du, pS * FFp, dz, pS * FFp, Bb, FFp, pS, p_ff, seed, (uint32_t)(10 * l + 2), stream));
+            RC(gemm(dz, pS * FFp, Lw.fc1_wt, FFp, Bb, Dp, FFp, AMDS_EPI_BIAS_F32, dh, pS * Dp, nullptr, stream));
+            if (need_params) {
+                RC(wgrad_tn(dz, pS * FFp, h2, pS * Dp, Bb, FFp, Dp, Gl->fc1_w));
+                RC(colsum(dz, pS * FFp, Gl->fc1_b, Bb, FFp, BF));
+            }
+            RC(ln_bwd(dh, pS * Dp, x_mid, pS * Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, pS * Dp, 1,
+                      need_params ? Gl->ln2_w : scratch_g, need_params ? Gl->ln2_b : scratch_g + D, Bb, fused_cast ? g16 : nullptr, pS * Dp, 0.f, 0));
+            if (!fused_cast) RC(amds_dropout_cast_bwd_rows(dx, pS * Dp, g16, pS * Dp, Bb, Dp, pS, 0.f, 0, 0, stream));            // d(x_mid) as bf16
+            RC(gemm(g16, pS * Dp, Lw.out_wt, Dp, Bb, Da, Dp, AMDS_EPI_BIAS, datt, pS * Da, nullptr, stream));
+            if (need_params) {
+                RC(wgrad_tn(g16, pS * Dp, att, pS * Da, Bb, Dp, Da, Gl->out_w));
+                RC(colsum(dx, pS * Dp, Gl->out_b, Bb, Dp, AMDS_F32));
+            }
+        } else {
         // ---- feed-forward branch ----------------------------------------------------------------------------------------------------------
         // g16 = bf16(Dropout'(dx)): written by the LayerNorm backward that produced dx (layers below the top one, D == Dp), else by its own pass
         if (!(fused_cast && l < d.L - 1)) {
@@ -548,6 +597,7 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             }
             RC(colsum(dx, Dp, Gl->out_b, M, Dp, AMDS_F32));
         }
+        }
         float* dqs = reinterpret_cast<float*>(wk + wp.dqs);
         if (d.alibi) {
             float* dbsp = reinterpret_cast<float*>(wk + wp.dbsp);
@@ -561,9 +611,8 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
                 AMDS_LAUNCH_CHECK("head_part_rows_kernel");
                 RC(colsum(dbst, Ha, Gl->bias_scale, M, Ha, AMDS_F32));
             }
-        } else if (l == d.L - 1 && S <= 32768 && amds_get_mil_cls_tail()) {
-            // (the forward computed the class query's attention alone: every other row of datt is exactly zero -- dx of the last block lives on the class rows --
-            //  so dK / dV are rank-1 in that query and dQ is zero elsewhere: one pass instead of the two blocked kernels)
+        } else if (tail) {
+            // (only the class query has an output and a gradient: dK / dV are rank-1 in it, dQ is zero elsewhere -- one pass instead of the two blocked kernels)
             RC(amds_attention_row_bwd_train(qkv, att, datt, lse, dqkv, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
         } else {
             RC(amds_attention_bwd_train(qkv, att, datt, lse, dqs, dqkv, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
