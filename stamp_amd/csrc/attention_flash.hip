@@ -293,6 +293,14 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
 }
 
 
+// sum over the 8 lanes that share lane >> 3 (every lane gets it): xor 1, xor 2 (quad_perm), xor 7 (row_half_mirror)
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
 // ---- ONE query row per (bag, head) against all keys / values of the bag: the class token's attention in the LAST layer of the MIL `vit` head -----------------
 // The head reads only the class token's final row (reference vision_tranformer.py: `self.mlp_head(x[:, 0])` behind the last block), so the last block needs keys and
 // values of every token but queries, output projection and MLP of the class rows alone (amds_mil_vit_forward).  One 256-thread workgroup per (bag, head): scores
@@ -314,32 +322,24 @@ __global__ void __launch_bounds__(256) attn_row_kernel(const T* __restrict__ q, 
     const int Dm = H * 64;
     const long ld = 3L * Dm;
     const T* base = qkv + (long)b * Tn * ld + h * 64;
-    float qf[64];
+    // scores: eight lanes per key, one 16-byte chunk of the 128-byte key row each (a wave reads eight whole rows per instruction), the dot product summed over
+    // the eight lanes by DPP.  (One key per thread -- 64 lanes on 64 different rows per instruction -- ran at 2.9 TB/s.)
+    const int sub = tid & 7, kk = tid >> 3;
+    float qc[8];
     {
-        const T* qrow = q + (long)b * ldq + h * 64;
+        const vec8 v = *reinterpret_cast<const vec8*>(q + (long)b * ldq + h * 64 + sub * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const vec8 v = *reinterpret_cast<const vec8*>(qrow + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[c * 8 + e] = Act<T>::to_f32(v[e]);
-        }
+        for (int e = 0; e < 8; ++e) qc[e] = Act<T>::to_f32(v[e]);
     }
     const float sc = 0.125f * 1.44269504088896340736f;
     float mx = -INFINITY;
-    for (int key = tid; key < Tn; key += 256) {
-        const T* krow = base + (long)key * ld + Dm;
-        float a0 = 0.f, a1 = 0.f;
+    for (int key = kk; key < Tn; key += 32) {
+        const vec8 v = *reinterpret_cast<const vec8*>(base + (long)key * ld + Dm + sub * 8);
+        float a0 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const vec8 v = *reinterpret_cast<const vec8*>(krow + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                a0 = fmaf(qf[c * 8 + e], Act<T>::to_f32(v[e]), a0);
-                a1 = fmaf(qf[c * 8 + e + 1], Act<T>::to_f32(v[e + 1]), a1);
-            }
-        }
-        const float sv = (a0 + a1) * sc;
-        sS[key] = sv;
+        for (int e = 0; e < 8; ++e) a0 = fmaf(qc[e], Act<T>::to_f32(v[e]), a0);
+        const float sv = sum8_dpp(a0) * sc;
+        if (sub == 0) sS[key] = sv;
         mx = fmaxf(mx, sv);
     }
     mx = wave_max(mx);
@@ -396,62 +396,53 @@ __global__ void __launch_bounds__(256) attn_row_bwd_kernel(const T* __restrict__
     const long ld = 3L * Dm;
     const T* base = qkv + (long)b * Tn * ld + h * 64;
     T* dbase = dqkv + (long)b * Tn * ld + h * 64;
-    float qf[64], gf[64];
+    // eight lanes per key, one 16-byte chunk of each 128-byte row (q, k, v in; dQ, dK, dV out): whole rows per instruction, the two dot products by DPP
+    const int sub = tid & 7, kk = tid >> 3;
+    float qc[8], gc[8];
     float Dq = 0.f;
     {
-        const T* qr = base + (long)qrow * ld;
-        const T* gr = dout + (long)b * ldd + h * 64;
-        const T* orow = o + (long)b * ldo + h * 64;
+        const vec8 qv = *reinterpret_cast<const vec8*>(base + (long)qrow * ld + sub * 8);
+        const vec8 gv = *reinterpret_cast<const vec8*>(dout + (long)b * ldd + h * 64 + sub * 8);
+        const vec8 ov = *reinterpret_cast<const vec8*>(o + (long)b * ldo + h * 64 + sub * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const vec8 qv = *reinterpret_cast<const vec8*>(qr + c * 8), gv = *reinterpret_cast<const vec8*>(gr + c * 8), ov = *reinterpret_cast<const vec8*>(orow + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                qf[c * 8 + e] = Act<T>::to_f32(qv[e]);
-                gf[c * 8 + e] = Act<T>::to_f32(gv[e]);
-                Dq = fmaf(gf[c * 8 + e], Act<T>::to_f32(ov[e]), Dq);
-            }
+        for (int e = 0; e < 8; ++e) {
+            qc[e] = Act<T>::to_f32(qv[e]);
+            gc[e] = Act<T>::to_f32(gv[e]);
+            Dq = fmaf(gc[e], Act<T>::to_f32(ov[e]), Dq);
         }
+        Dq = sum8_dpp(Dq);
     }
     const float sc = 0.125f * 1.44269504088896340736f;
     const float L = lse[((long)b * H + h) * Tn + qrow];
     uint32_t rowkey = 0;
     if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qrow));
-    for (int key = tid; key < Tn; key += 256) {
-        const T* krow = base + (long)key * ld + Dm;
-        vec8 vv[8];
-        float s0 = 0.f, s1 = 0.f, p0 = 0.f, p1 = 0.f;
+    for (int key = kk; key < Tn; key += 32) {
+        const T* krow = base + (long)key * ld + Dm + sub * 8;
+        const vec8 kv = *reinterpret_cast<const vec8*>(krow), vv = *reinterpret_cast<const vec8*>(krow + Dm);
+        float s0 = 0.f, p0 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const vec8 kv = *reinterpret_cast<const vec8*>(krow + c * 8);
-            vv[c] = *reinterpret_cast<const vec8*>(krow + Dm + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                s0 = fmaf(qf[c * 8 + e], Act<T>::to_f32(kv[e]), s0);
-                s1 = fmaf(qf[c * 8 + e + 1], Act<T>::to_f32(kv[e + 1]), s1);
-                p0 = fmaf(gf[c * 8 + e], Act<T>::to_f32(vv[c][e]), p0);
-                p1 = fmaf(gf[c * 8 + e + 1], Act<T>::to_f32(vv[c][e + 1]), p1);
-            }
+        for (int e = 0; e < 8; ++e) {
+            s0 = fmaf(qc[e], Act<T>::to_f32(kv[e]), s0);
+            p0 = fmaf(gc[e], Act<T>::to_f32(vv[e]), p0);
         }
-        const float pk = __builtin_amdgcn_exp2f((s0 + s1) * sc - L);
+        s0 = sum8_dpp(s0);
+        p0 = sum8_dpp(p0);
+        const float pk = __builtin_amdgcn_exp2f(s0 * sc - L);
         float mk = 1.f;
         if constexpr (DROP) mk = drop_keep(drop_pair_bits(rowkey, (uint32_t)key >> 1), key & 1, thr16) ? keep_scale : 0.f;
-        const float dS = pk * (mk * (p0 + p1) - Dq), pw = pk * mk, dk = dS * 0.125f;
-        sS[key] = dS;
-        T* drow = dbase + (long)key * ld;
+        const float dS = pk * (mk * p0 - Dq), pw = pk * mk, dk = dS * 0.125f;
+        if (sub == 0) sS[key] = dS;
+        T* drow = dbase + (long)key * ld + sub * 8;
+        vec8 wq, wk, wv;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            vec8 wq, wk, wv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                wq[e] = (T)0.f;
-                wk[e] = Act<T>::from_f32(dk * qf[c * 8 + e]);
-                wv[e] = Act<T>::from_f32(pw * gf[c * 8 + e]);
-            }
-            if (key != qrow) *reinterpret_cast<vec8*>(drow + c * 8) = wq;          // (the query row's own dQ is written below)
-            *reinterpret_cast<vec8*>(drow + Dm + c * 8) = wk;
-            *reinterpret_cast<vec8*>(drow + 2 * Dm + c * 8) = wv;
+        for (int e = 0; e < 8; ++e) {
+            wq[e] = (T)0.f;
+            wk[e] = Act<T>::from_f32(dk * qc[e]);
+            wv[e] = Act<T>::from_f32(pw * gc[e]);
         }
+        if (key != qrow) *reinterpret_cast<vec8*>(drow) = wq;                      // (the query row's own dQ is written below)
+        *reinterpret_cast<vec8*>(drow + Dm) = wk;
+        *reinterpret_cast<vec8*>(drow + 2 * Dm) = wv;
     }
     __syncthreads();
     const int d4 = (tid & 15) * 4, ph = tid >> 4;
