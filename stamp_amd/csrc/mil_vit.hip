@@ -160,9 +160,10 @@ extern "C" int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds
     AMDS_LAUNCH_CHECK("prefix_cls_kernel");
     if (Dp != D) AMDS_HIP(hipMemsetAsync(h, 0, (size_t)M * Dp * 2, st));      // LayerNorm writes the first D columns only
 
-    // amds_set_mil_cls_tail(0) / AMDS_MIL_CLS_TAIL=0: every row of the last block (A/B, tests).  Not with ALiBi / padding masks (their attention variants have no
-    // one-query form).
-    const bool cls_tail = amds_get_mil_cls_tail() && !c.alibi && !mask && S <= 32768 && (long)(Bb - 1) * S * Dp * 4 < (1L << 31);
+    // amds_set_mil_cls_tail(0) / AMDS_MIL_CLS_TAIL=0: every row of the last block (A/B, tests).  Not with ALiBi (its attention has no one-query form).  A padding
+    // mask changes nothing for the class query: the reference's mask blocks (padded query, padded key) pairs and the class token as a KEY of the tile queries
+    // (vision_tranformer.py:356-368) -- the class token is never padded, so its own row attends to every key, exactly the unmasked one-query attention.
+    const bool cls_tail = amds_get_mil_cls_tail() && !c.alibi && S <= 32768 && (long)(Bb - 1) * S * Dp * 4 < (1L << 31);
     for (int l = 0; l < c.layers && rc == AMDS_OK; ++l) {
         const amds_mil_vit_layer& L = w.layers_host[l];
         AMDS_REQUIRE(L.ln1_w && L.ln1_b && L.in_w && L.in_b && L.out_w && L.out_b && L.ln2_w && L.ln2_b && L.fc1_w && L.fc1_b && L.fc2_w && L.fc2_b &&
