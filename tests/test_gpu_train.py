@@ -456,6 +456,44 @@ def test_mil_vit_train_class_row_tail_equals_the_full_last_block(gpu, dims, p_dr
     assert _rel2(dbt, dbf) < 8e-3
 
 
+@pytest.mark.parametrize("L,Bb,Tn,p_drop", [(1, 1, 1, 0.0), (1, 2, 300, 0.25), (3, 2, 65, 0.1), (2, 5, 2, 0.0)])
+def test_mil_vit_class_row_tail_edge_shapes(gpu, L, Bb, Tn, p_drop):
+    """The class-row tail on the shapes its row pitches could get wrong: a single block (the tail IS the model), one bag, one tile per bag (S = 2), three blocks; training
+    step and deploy forward, tail against full block (logits 1e-2; gradients 2e-2 relative L2 -- a dozen token rows average the bf16 rounding of the two paths less than
+    65 600 do; a wrong pitch or mask index gives O(1) -- + an absolute floor for tensors that are numerically zero); and the input
+    gradient alone (`need_params=False`: the heat-map path)."""
+    from stamp_amd import mil_core, ops
+    from stamp_amd.mil import VisionTransformer
+    torch.manual_seed(L * 100 + Tn)
+    model = VisionTransformer(dim_output=2, dim_input=256, dim_model=256, n_layers=L, n_heads=4, dim_feedforward=256, dropout=p_drop, use_alibi=False).eval()
+    sd = {k: v.detach().to(gpu, torch.float32) for k, v in model.state_dict().items()}
+    pk = mil_core.PackedVit(model.dims, lambda n: sd[n], torch.bfloat16, train=True)
+    bags = torch.randn(Bb, Tn, 256).half().to(gpu)
+    dlogits = torch.randn(Bb, 2, device=gpu)
+    res = {}
+    was = ops.set_mil_cls_tail(True)
+    try:
+        for tail in (True, False):
+            ops.set_mil_cls_tail(tail)
+            lg, sv = mil_core.forward_train(pk, bags, None, training=p_drop > 0, seed=5)
+            G, db = mil_core.backward(pk, sv, dlogits, need_params=True, need_bags=True)
+            _, db_only = mil_core.backward(pk, sv, dlogits, need_params=False, need_bags=True)
+            with torch.no_grad():
+                dep = model.to(gpu)(bags, coords=None, mask=None)
+            res[tail] = (lg.clone(), {k: v.clone() for k, v in G.items()}, db.clone(), db_only.clone(), dep.clone())
+    finally:
+        ops.set_mil_cls_tail(was)
+    (lt, Gt, dbt, dbot, dept), (lf, Gf, dbf, dbof, depf) = res[True], res[False]
+    assert torch.isfinite(lt).all() and torch.isfinite(dept).all()
+    assert (lt - lf).abs().max().item() < 1e-2 * max(1.0, lf.abs().max().item()) and (dept - depf).abs().max().item() < 1e-2 * max(1.0, depf.abs().max().item())
+    for k in Gf:
+        assert torch.isfinite(Gt[k]).all(), k
+        err = (Gt[k].double() - Gf[k].double()).norm().item()
+        assert err < 2e-2 * Gf[k].double().norm().item() + 1e-5, (k, err, Gf[k].norm().item())
+    assert (dbt.double() - dbf.double()).norm().item() < 2e-2 * dbf.double().norm().item() + 1e-5
+    assert (dbot.double() - dbof.double()).norm().item() < 2e-2 * dbof.double().norm().item() + 1e-5
+
+
 def _rel2(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 
