@@ -895,6 +895,9 @@ int amds_pinv_init(const float* x, float* z, int nmat, int n, void* scratch8, vo
 /* out[z][t][c] += sum_k w[i][k] v[z][t+k-taps/2][c]: per-head depth-wise conv along the sequence (trans_mil.py:71-78,150-151). */
 int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, const float* w, float* out, long soo, long soi, int ldo,
                     int outer, int inner, int n, int d, int taps, void* stream);
+/* The same convolution for ONE position `row` of every sequence: out[z][c] += sum_k w[i][k] v[z][row+k-taps/2][c], out compact (strides soo / soi per outer / inner index). */
+int amds_dwconv_seq_row(const float* v, long svo, long svi, int ldv, const float* w, float* out, long soo, long soi, int outer, int inner, int n, int d,
+                        int taps, int row, void* stream);
 /* PPEG: y = x + dw7x7(x) + dw5x5(x) + dw3x3(x) on the H x W token grid, class token passed through (trans_mil.py:274-283).
  * x, y: [B][1+H*W][C]; w7 [C][49], w5 [C][25], w3 [C][9], biases [C]. */
 int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,

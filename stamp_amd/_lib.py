@@ -285,6 +285,7 @@ PROTOTYPES = {
     "amds_softmax_rows": (_i, [_vp, _l, _i, _vp]),
     "amds_landmark_mean": (_i, [_vp, _l, _l, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "amds_pinv_init": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "amds_dwconv_seq_row": (_i, [_vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_dwconv_seq": (_i, [_vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_ppeg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_softmax_rows_bwd": (_i, [_vp, _vp, _l, _i, _vp]),

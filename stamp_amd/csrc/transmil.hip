@@ -625,6 +625,23 @@ __global__ void dwconv_seq_kernel(const float* __restrict__ v, long svo, long sv
     out[zo * soo + zi * soi + (long)t * ldo + c] += s;
 }
 
+// the same sum for ONE position `row` of every sequence, into a compact [z][d] output (the class token's row of TransMIL's second layer, of which nothing else is read)
+__global__ void dwconv_seq_row_kernel(const float* __restrict__ v, long svo, long svi, int ldv, const float* __restrict__ w, float* __restrict__ out, long soo, long soi,
+                                      int inner, int n, int d, int taps, int row) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const float* p = v + zo * svo + zi * svi + c;
+    const float* wk = w + (long)zi * taps;
+    const int pad = taps / 2;
+    float s = 0.f;
+    for (int k = 0; k < taps; ++k) {
+        const int tt = row + k - pad;
+        if (tt >= 0 && tt < n) s = fmaf(wk[k], p[(long)tt * ldv], s);
+    }
+    out[zo * soo + zi * soi + c] += s;
+}
+
 // The same sum with a register window: a lane owns one channel and TT consecutive positions, loads its TT + TAPS - 1 inputs once (a wave
 // reads 64 consecutive channels per position: 256-byte segments) and runs the TAPS x TT multiply-adds out of registers with the taps in
 // scalar registers.  (The one-thread-per-output form above issues TAPS dependent loads per output: 1.05 ms for the 64 x 8 x 1280 x 64 values of
@@ -1270,6 +1287,15 @@ extern "C" int amds_dwconv_seq(const float* v, long svo, long svi, int ldv, cons
     hipLaunchKernelGGL(dwconv_seq_kernel, dim3(cdiv((long)n * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, v, svo, svi, ldv, w,
                        out, soo, soi, ldo, inner, n, d, taps);
     AMDS_LAUNCH_CHECK("dwconv_seq_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_dwconv_seq_row(const float* v, long svo, long svi, int ldv, const float* w, float* out, long soo, long soi, int outer, int inner, int n, int d,
+                                   int taps, int row, void* stream) {
+    AMDS_REQUIRE(v && w && out, "amds_dwconv_seq_row: null pointer");
+    AMDS_REQUIRE(outer > 0 && inner > 0 && (long)outer * inner <= 65535 && n > 0 && d > 0 && taps > 0 && (taps & 1) && row >= 0 && row < n, "amds_dwconv_seq_row: bad arguments");
+    hipLaunchKernelGGL(dwconv_seq_row_kernel, dim3(cdiv(d, 64), outer * inner), dim3(64), 0, (hipStream_t)stream, v, svo, svi, ldv, w, out, soo, soi, inner, n, d, taps, row);
+    AMDS_LAUNCH_CHECK("dwconv_seq_row_kernel");
     return AMDS_OK;
 }
 

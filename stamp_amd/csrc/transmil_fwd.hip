@@ -109,7 +109,10 @@ int bg(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, lon
 }
 
 // x_res += to_out(NystromAttention(y))   (:81-163 with mask = None, eval mode; residual :263)
-int nystrom(const TmPlan& p, const amds_transmil_layer& L, const float* y, float* x_res, int b, char* wk, void* stream) {
+// cls_only: the caller reads the class token's row of x_res and nothing else (the second TransLayer: `self.norm(h)[:, 0]`, trans_mil.py:319-323) -- attn1, attn1 z,
+// (attn1 z)(attn3 v), the residual convolution and to_out are computed for that one row per bag (row `pad` of the front-padded sequence); landmarks, attn2 and its
+// pseudo-inverse, attn3 and attn3 v need every token and stay as they are.
+int nystrom(const TmPlan& p, const amds_transmil_layer& L, const float* y, float* x_res, int b, char* wk, void* stream, bool cls_only = false) {
     hipStream_t st = (hipStream_t)stream;
     const int Cd = p.Cd, H = HEADS, m = p.m, d = p.d, n = p.n, np = p.np, pad = p.pad, l = p.l;
     const float* yp = y;
@@ -131,10 +134,13 @@ int nystrom(const TmPlan& p, const amds_transmil_layer& L, const float* y, float
     RC(amds_landmark_mean(kp, sb, sh, ld, kl, b, H, m, l, d, (float)(1.0 / l), stream));
     float *a1 = reinterpret_cast<float*>(wk + p.a1), *a2 = reinterpret_cast<float*>(wk + p.a2), *a3 = reinterpret_cast<float*>(wk + p.a3);
     const long md = (long)m * d, mm = (long)m * m, nm = (long)np * m;
+    const long hm = (long)H * m;
+    if (cls_only) RC(bg(qp + (size_t)pad * ld, ld, sb, sh, kl, d, H * md, md, 1, a1, m, hm, m, b, H, 1, m, d, scale, 0.0f, nullptr, 0, stream));      // the class row of sim1
+    else
     RC(bg(qp, ld, sb, sh, kl, d, H * md, md, 1, a1, m, H * nm, nm, b, H, np, m, d, scale, 0.0f, nullptr, 0, stream));              // sim1 = q kl^T (:126-128)
     RC(bg(ql, d, H * md, md, kl, d, H * md, md, 1, a2, m, H * mm, mm, b, H, m, m, d, 1.0f, 0.0f, nullptr, 0, stream));             // sim2 = ql kl^T
     RC(bg(ql, d, H * md, md, kp, ld, sb, sh, 1, a3, np, H * nm, nm, b, H, m, np, d, 1.0f, 0.0f, nullptr, 0, stream));              // sim3 = ql k^T
-    RC(amds_softmax_rows(a1, (long)b * H * np, m, stream));                                                                        // :145
+    RC(amds_softmax_rows(a1, cls_only ? (long)b * H : (long)b * H * np, m, stream));                                               // :145
     RC(amds_softmax_rows(a2, (long)b * H * m, m, stream));
     RC(amds_softmax_rows(a3, (long)b * H * m, np, stream));
     // Moore-Penrose iteration (:23-37): z <- 0.25 z (13 I - xz (15 I - xz (7 I - xz))),  xz = x z
@@ -154,6 +160,12 @@ int nystrom(const TmPlan& p, const amds_transmil_layer& L, const float* y, float
     }
     float *av = reinterpret_cast<float*>(wk + p.av), *a1z = reinterpret_cast<float*>(wk + p.a1z), *merged = reinterpret_cast<float*>(wk + p.merged);
     RC(bg(a3, np, H * nm, nm, vp, ld, sb, sh, 0, av, d, H * md, md, b, H, m, d, np, 1.0f, 0.0f, nullptr, 0, stream));               // attn3 v
+    if (cls_only) {
+        RC(bg(a1, m, hm, m, z, m, H * mm, mm, 0, a1z, m, hm, m, b, H, 1, m, m, 1.0f, 0.0f, nullptr, 0, stream));                     // one row of attn1 pinv
+        RC(bg(a1z, m, hm, m, av, d, H * md, md, 0, merged, Cd, Cd, d, b, H, 1, d, m, 1.0f, 0.0f, nullptr, 0, stream));               // merged: [b][Cd], the class rows
+        RC(amds_dwconv_seq_row(vp, sb, sh, ld, L.conv_w, merged, Cd, d, b, H, np, d, CONV_K, pad, stream));
+        return bg(merged, Cd, Cd, 0, L.out_w, Cd, 0, 0, 1, x_res, Cd, (long)n * Cd, 0, b, 1, 1, Cd, Cd, 1.0f, 0.0f, L.out_b, 1, stream);
+    }
     RC(bg(a1, m, H * nm, nm, z, m, H * mm, mm, 0, a1z, m, H * nm, nm, b, H, np, m, m, 1.0f, 0.0f, nullptr, 0, stream));             // attn1 pinv
     RC(bg(a1z, m, H * nm, nm, av, d, H * md, md, 0, merged, Cd, (long)np * Cd, d, b, H, np, d, m, 1.0f, 0.0f, nullptr, 0, stream)); // heads merged (:148-153)
     RC(amds_dwconv_seq(vp, sb, sh, ld, L.conv_w, merged, (long)np * Cd, d, Cd, b, H, np, d, CONV_K, stream));                       // + res_conv(v) (:151)
@@ -214,7 +226,7 @@ extern "C" int amds_transmil_forward(const amds_transmil_cfg* cfg_host, const am
     RC(amds_ppeg(x, y, w.ppeg_w7, w.ppeg_b7, w.ppeg_w5, w.ppeg_b5, w.ppeg_w3, w.ppeg_b3, Bb, p.side, p.side, Cd, stream));
     std::swap(x, y);
     RC(amds_layernorm(x, Cd, w.layer[1].norm_w, w.layer[1].norm_b, y, Cd, Bb * n, Cd, 1e-5f, AMDS_F32, stream));
-    RC(nystrom(p, w.layer[1], y, x, Bb, wk, stream));
+    RC(nystrom(p, w.layer[1], y, x, Bb, wk, stream, amds_get_mil_cls_tail() != 0));      // (amds_set_mil_cls_tail(0): every row, A/B and the chain tests)
     // final LayerNorm on the class-token rows, _fc2 (:322-325)
     float* cls = reinterpret_cast<float*>(wk + p.cls);
     RC(amds_layernorm(x, (long)n * Cd, w.norm_w, w.norm_b, cls, Cd, Bb, Cd, 1e-5f, AMDS_F32, stream));

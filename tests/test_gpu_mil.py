@@ -361,11 +361,20 @@ def test_transmil_forward_one_call_equals_the_kernel_by_kernel_chain(gpu, Bb, T,
     torch.manual_seed(T + Cd)
     model = TransMIL(dim_output=3, dim_input=F, dim_hidden=Cd).eval().to(gpu)
     bags = torch.randn(Bb, T, F).to(bdt).to(gpu)
+    from stamp_amd import ops
     with torch.no_grad():
-        one = model(bags)
-        from chains.transmil import transmil_forward_stepwise
-        chain = transmil_forward_stepwise(model, bags)
+        tail = model(bags)                                 # default: the second layer's class row alone (csrc/transmil_fwd.hip)
+        was = ops.set_mil_cls_tail(False)
+        try:
+            one = model(bags)
+            from chains.transmil import transmil_forward_stepwise
+            chain = transmil_forward_stepwise(model, bags)
+        finally:
+            ops.set_mil_cls_tail(was)
     assert one.shape == (Bb, 3) and torch.isfinite(one).all() and torch.equal(one, chain)
+    # the head reads `self.norm(h)[:, 0]` behind the second TransLayer (trans_mil.py:319-323): attn1, attn1 pinv, the merge, the residual convolution and to_out for
+    # that row alone give the full layer's logits to fp32 rounding (one-row products take another kernel of the same exact-fp32 family)
+    assert torch.isfinite(tail).all() and (tail - one).abs().max().item() < 1e-4 * max(1.0, one.abs().max().item())
     with torch.no_grad():
         model._fc2.bias.add_(1.0)                          # the cached device weights follow the parameters
         assert torch.allclose(model(bags), one + 1.0, atol=1e-5)
