@@ -671,13 +671,45 @@ typedef struct {
     const float* a_w;   const float* a_b;    /* [D][L], [D]   attention_net.3.attention_a.0 */
     const float* b_w;   const float* b_b;    /* [D][L], [D]   attention_net.3.attention_b.0 */
     const float* c_w;   const float* c_b;    /* [1][D], [1]   attention_net.3.attention_c */
+    const float* packed;                     /* optional: amds_gated_attn_pack's image of fc_w / a_w / b_w (amds_gated_attn_packed_floats floats), or NULL --
+                                              * the fused entries then pack into their workspace on every call (one more launch) */
 } amds_gap_weights;
+
+/* The fused pooling kernels read fc_w, a_w and b_w from a tile-ordered copy (each LDS tile image one contiguous run; csrc/gap_fused.hip).  Pack once per set
+ * of weights and pass the buffer in amds_gap_weights.packed.  0 floats <=> the shape is not one the fused kernels take. */
+size_t amds_gated_attn_packed_floats(int F, int L, int D);
+int amds_gated_attn_pack(const amds_gap_weights* w_host, float* packed, int F, int L, int D, void* stream);
 
 size_t amds_gated_attn_pool_workspace_bytes(int N, int F, int L, int D);
 /* x: fp32 [N][F]; out: fp32 [F] = softmax_N(A) @ x  ("WSI_feature"); attn_raw: fp32 [N] (may be NULL).
- * fp32 arithmetic throughout (the reference runs this encoder in fp32, chief.py:117). */
+ * fp32 arithmetic throughout (the reference runs this encoder in fp32, chief.py:117).  One launch (csrc/gap_fused.hip) when
+ * amds_gated_attn_pool_batched_supported(F, L, D) -- CHIEF's two size_args are -- else the six-launch form below. */
 int amds_gated_attn_pool(const float* x, const amds_gap_weights* w_host, float* out, float* attn_raw,
                          int N, int F, int L, int D, void* ws, size_t ws_bytes, void* stream);
+
+/* MANY bags in one launch -- what the reference's per-slide loop (src/stamp/encoding/encoder/__init__.py:42-118 `encode_slides_`, chief.py:119-127
+ * `_generate_slide_embedding`, :129-135 the patient concatenation) and EAGLE's scoring pass (eagle.py:96-118) hand over when the feature matrices of
+ * several slides are resident: x = their rows concatenated [total_rows][F]; row_offsets (DEVICE, int64 [bags + 1], row_offsets[0] = 0,
+ * row_offsets[bags] = total_rows) delimits the bags; out [bags][F]; attn_raw [total_rows] or NULL.  Every bag must be non-empty (the reference raises
+ * on an empty feature matrix; the row of an empty bag is left untouched here).  Same arithmetic per bag as amds_gated_attn_pool; the result
+ * is reproducible run to run (no atomics on data; partials merge in a fixed order).  Shapes: amds_gated_attn_pool_batched_supported (L = 256 or
+ * 512, F and D multiples of 16).  row_offsets may be NULL when bags == 1.
+ * mode: AMDS_GAP_AUTO picks the decomposition by the total row count -- up to 8192 rows a workgroup owns 16 rows and its four waves split the hidden
+ * units (every SIMD of the chip busy on a single small bag), beyond that a workgroup owns 64 rows and a wave 16 of them end to end (weights shared
+ * through LDS; 0.8 of the fp32 MFMA peak on large batches).  The two associate the gate pre-activation sums differently (last-bit differences);
+ * AMDS_GAP_SLAB / AMDS_GAP_SPLIT force one (SPLIT: at most 12288 rows in total, F % 32 == 0, D % 64 == 0) -- with a forced mode a bag's result does
+ * not depend on what else is in the batch. */
+enum { AMDS_GAP_AUTO = 0, AMDS_GAP_SLAB = 1, AMDS_GAP_SPLIT = 2 };
+int amds_gated_attn_pool_batched_supported(int F, int L, int D);
+size_t amds_gated_attn_pool_batched_workspace_bytes(long total_rows, int bags, int F, int L, int D);
+int amds_gated_attn_pool_batched(const float* x, const long long* row_offsets, int bags, long total_rows, const amds_gap_weights* w_host, float* out,
+                                 float* attn_raw, int F, int L, int D, int mode, void* ws, size_t ws_bytes, void* stream);
+
+/* The six-launch form (two exact-fp32 GEMMs through HBM, gate, softmax statistics, partial pooling, reduce; csrc/gap.hip): any F, L multiple of 4.
+ * amds_gated_attn_pool falls back to it for shapes the fused kernel does not take; exported for the A/B in tools/gap_only.py. */
+size_t amds_gated_attn_pool_unfused_workspace_bytes(int N, int F, int L, int D);
+int amds_gated_attn_pool_unfused(const float* x, const amds_gap_weights* w_host, float* out, float* attn_raw,
+                                 int N, int F, int L, int D, void* ws, size_t ws_bytes, void* stream);
 
 /* EAGLE's tile selection (reference src/stamp/encoding/encoder/eagle.py:106-118: `torch.topk(attention_raw, min(25, N))`, then the mean of
  * the matching rows of the aggregation features): idx_out[r], r < k, = index of the r-th largest score (ties: the lower index first),

@@ -171,7 +171,7 @@ class SwinWeights(C.Structure):
 
 
 class GapWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b")]
+    _fields_ = [(n, C.c_void_p) for n in ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b", "packed")]
 
 
 _vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
@@ -342,6 +342,13 @@ PROTOTYPES = {
     "amds_adamw": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp]),
     "amds_gated_attn_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amds_gated_attn_pool": (_i, [_vp, C.POINTER(GapWeights), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_gated_attn_pool_batched_supported": (_i, [_i, _i, _i]),
+    "amds_gated_attn_packed_floats": (_sz, [_i, _i, _i]),
+    "amds_gated_attn_pack": (_i, [C.POINTER(GapWeights), _vp, _i, _i, _i, _vp]),
+    "amds_gated_attn_pool_batched_workspace_bytes": (_sz, [_l, _i, _i, _i, _i]),
+    "amds_gated_attn_pool_batched": (_i, [_vp, _vp, _i, _l, C.POINTER(GapWeights), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amds_gated_attn_pool_unfused_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "amds_gated_attn_pool_unfused": (_i, [_vp, C.POINTER(GapWeights), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -1,4 +1,6 @@
-// gap.hip -- gated-attention pooling of a bag of tile features (CHIEF slide encoder).
+// gap.hip -- gated-attention pooling of a bag of tile features (CHIEF slide encoder): the SIX-LAUNCH form (two exact-fp32 GEMMs through HBM, gate,
+// softmax statistics, partial pooling, reduce).  Since round 6 the product path is the single fused launch of gap_fused.hip; this form serves the
+// shapes the fused kernel does not take (L not 256 / 512, F or D not a multiple of 16) and stays callable as amds_gated_attn_pool_unfused for A/B.
 // Reference: src/stamp/encoding/encoder/chief.py:74-89 (CHIEFModel.forward), :255-275 (Attn_Net_Gated).
 //   h   = relu(x Wfc^T + bfc)                 [N, L]
 //   A_n = Wc (tanh(Wa h_n + ba) * sigmoid(Wb h_n + bb)) + bc
@@ -151,20 +153,49 @@ using namespace amds;
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" size_t amds_gated_attn_pool_workspace_bytes(int N, int F, int L, int D) {
+namespace amds {
+bool gap_fused_supported(const float* x, const amds_gap_weights* w, int F, int L, int D);
+size_t gap_fused_workspace_bytes(long total_rows, int bags, int F, int L, int D);
+int gap_fused_launch(const float* x, const long long* off_dev, int bags, long total_rows, const amds_gap_weights* w, float* out, float* attn_raw, int F,
+                     int L, int D, int mode, void* ws, size_t ws_bytes, hipStream_t st);
+}  // namespace amds
+
+extern "C" size_t amds_gated_attn_pool_unfused_workspace_bytes(int N, int F, int L, int D) {
     if (N <= 0 || F <= 0 || L <= 0 || D <= 0) return 0;
     const size_t nch = (size_t)(N + 127) / 128;
     return al256((size_t)N * L * 4) + al256((size_t)N * 2 * D * 4) + al256((size_t)2 * D * L * 4) + al256((size_t)2 * D * 4) +
            al256((size_t)N * 4) + al256(64) + al256(nch * F * 4);
 }
 
+// enough for either form: the caller sizes the workspace before the weights' alignment is known
+extern "C" size_t amds_gated_attn_pool_workspace_bytes(int N, int F, int L, int D) {
+    if (N <= 0 || F <= 0 || L <= 0 || D <= 0) return 0;
+    if (amds_gated_attn_pool_batched_supported(F, L, D)) {
+        const size_t a = gap_fused_workspace_bytes(N, 1, F, L, D);
+        return a;       // misaligned pointers are rejected there, not silently rerouted (torch / hipMalloc allocations are 256-byte aligned)
+    }
+    return amds_gated_attn_pool_unfused_workspace_bytes(N, F, L, D);
+}
+
 extern "C" int amds_gated_attn_pool(const float* x, const amds_gap_weights* w, float* out, float* attn_raw, int N, int F,
                                     int L, int D, void* ws, size_t ws_bytes, void* stream) {
     AMDS_REQUIRE(x && w && out && ws, "amds_gated_attn_pool: null pointer");
     AMDS_REQUIRE(N > 0 && F > 0 && L > 0 && D > 0, "amds_gated_attn_pool: empty bag or bad dims (N=%d F=%d L=%d D=%d)", N, F, L, D);
+    AMDS_REQUIRE(w->fc_w && w->fc_b && w->a_w && w->a_b && w->b_w && w->b_b && w->c_w && w->c_b, "amds_gated_attn_pool: incomplete weights");
+    if (amds_gated_attn_pool_batched_supported(F, L, D)) {
+        AMDS_REQUIRE(gap_fused_supported(x, w, F, L, D), "amds_gated_attn_pool: x and the weight arrays must be 16-byte aligned");
+        return gap_fused_launch(x, nullptr, 1, N, w, out, attn_raw, F, L, D, AMDS_GAP_AUTO, ws, ws_bytes, (hipStream_t)stream);
+    }
+    return amds_gated_attn_pool_unfused(x, w, out, attn_raw, N, F, L, D, ws, ws_bytes, stream);
+}
+
+extern "C" int amds_gated_attn_pool_unfused(const float* x, const amds_gap_weights* w, float* out, float* attn_raw, int N, int F,
+                                            int L, int D, void* ws, size_t ws_bytes, void* stream) {
+    AMDS_REQUIRE(x && w && out && ws, "amds_gated_attn_pool: null pointer");
+    AMDS_REQUIRE(N > 0 && F > 0 && L > 0 && D > 0, "amds_gated_attn_pool: empty bag or bad dims (N=%d F=%d L=%d D=%d)", N, F, L, D);
     AMDS_REQUIRE(F % 4 == 0 && L % 4 == 0, "amds_gated_attn_pool: F and L must be multiples of 4");
     AMDS_REQUIRE(w->fc_w && w->fc_b && w->a_w && w->a_b && w->b_w && w->b_b && w->c_w && w->c_b, "amds_gated_attn_pool: incomplete weights");
-    const size_t need = amds_gated_attn_pool_workspace_bytes(N, F, L, D);
+    const size_t need = amds_gated_attn_pool_unfused_workspace_bytes(N, F, L, D);
     if (ws_bytes < need) {
         set_error("amds_gated_attn_pool: workspace %zu < required %zu bytes", ws_bytes, need);
         return AMDS_ERR_WORKSPACE;

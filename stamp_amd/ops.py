@@ -403,20 +403,109 @@ def tile_normalize_u8(tiles: torch.Tensor, mean, std) -> torch.Tensor:
     return out
 
 
-def gated_attn_pool(x: torch.Tensor, weights: dict[str, torch.Tensor], return_attn: bool = False):
-    """x fp32 [N,F]; weights: fc_w/fc_b/a_w/a_b/b_w/b_b/c_w/c_b fp32 device tensors -> out [F] (+ A_raw [N])."""
+_GAP_KEYS = ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b")
+_gap_ws: dict = {}
+
+
+def _gap_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """One grow-only workspace per device and stream for the pooling entries (they are called once per slide: a fresh allocation per call was the round-5 form)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _gap_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _gap_ws[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+    return ws
+
+
+_gap_packed: dict = {}
+
+
+def _gap_weights(weights: dict[str, torch.Tensor], pack: bool = True):
+    """The C struct for a weights dict.  The fused kernels' tile-ordered copy of fc_w / a_w / b_w (amds_gated_attn_pack) is made once per set of tensors and
+    kept while they are unchanged (data pointers and torch's in-place version counters)."""
+    for k in _GAP_KEYS:
+        assert weights[k].dtype == torch.float32 and weights[k].is_contiguous(), k
+    gw = _lib.GapWeights(**{k: _p(weights[k]) for k in _GAP_KEYS})
+    F, L, D = weights["fc_w"].shape[1], weights["fc_w"].shape[0], weights["a_w"].shape[0]
+    n = _lib.lib().amds_gated_attn_packed_floats(F, L, D) if pack else 0
+    if n:
+        big = [weights[k] for k in ("fc_w", "a_w", "b_w")]
+        key = tuple(t.data_ptr() for t in big)
+        ver = tuple(t._version for t in big)
+        hit = _gap_packed.get(key)
+        if hit is None or hit[0] != ver:
+            pk = torch.empty(n, dtype=torch.float32, device=big[0].device)
+            _lib.check(_lib.lib().amds_gated_attn_pack(C.byref(gw), _p(pk), F, L, D, _stream()), "gated_attn_pack")
+            if len(_gap_packed) > 16:
+                _gap_packed.clear()
+            hit = _gap_packed[key] = (ver, pk, big)          # `big` keeps the tensors alive: a freed pointer cannot be mistaken for these weights
+        gw.packed = _p(hit[1])
+    return gw
+
+
+GAP_MODES = {"auto": 0, "slab": 1, "split": 2}      # include/amdstamp.h AMDS_GAP_*
+
+
+def gated_attn_pool(x: torch.Tensor, weights: dict[str, torch.Tensor], return_attn: bool = False, fused: bool = True, mode: str = "auto"):
+    """x fp32 [N,F]; weights: fc_w/fc_b/a_w/a_b/b_w/b_b/c_w/c_b fp32 device tensors -> out [F] (+ A_raw [N]).  One launch (csrc/gap_fused.hip) for CHIEF's
+    shapes; fused=False asks for the six-launch form (csrc/gap.hip) -- the A/B of tools/gap_only.py; mode "slab" / "split" forces one decomposition of the
+    fused launch (through the batched entry with one bag)."""
     _dev(x, *weights.values())
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    if mode != "auto":
+        assert fused
+        r = gated_attn_pool_batched(x, [x.shape[0]], weights, return_attn=return_attn, mode=mode, offsets=False)
+        return (r[0][0], r[1]) if return_attn else r[0]
     N, F = x.shape
     L, D = weights["fc_w"].shape[0], weights["a_w"].shape[0]
     lib = _lib.lib()
-    nbytes = lib.amds_gated_attn_pool_workspace_bytes(N, F, L, D)
-    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
-    gw = _lib.GapWeights(**{k: _p(weights[k]) for k in ("fc_w", "fc_b", "a_w", "a_b", "b_w", "b_b", "c_w", "c_b")})
+    sz, fn = ((lib.amds_gated_attn_pool_workspace_bytes, lib.amds_gated_attn_pool) if fused else
+              (lib.amds_gated_attn_pool_unfused_workspace_bytes, lib.amds_gated_attn_pool_unfused))
+    nbytes = sz(N, F, L, D)
+    ws = _gap_workspace(x.device, nbytes)
+    gw = _gap_weights(weights, pack=fused)
     out = torch.empty(F, dtype=torch.float32, device=x.device)
     araw = torch.empty(N, dtype=torch.float32, device=x.device) if return_attn else None
-    _lib.check(lib.amds_gated_attn_pool(_p(x), C.byref(gw), _p(out), _p(araw), N, F, L, D, _p(ws), nbytes, _stream()),
-               "gated_attn_pool")
+    _lib.check(fn(_p(x), C.byref(gw), _p(out), _p(araw), N, F, L, D, _p(ws), nbytes, _stream()), "gated_attn_pool")
+    return (out, araw) if return_attn else out
+
+
+def gated_attn_pool_batched_supported(F: int, L: int, D: int) -> bool:
+    return bool(_lib.lib().amds_gated_attn_pool_batched_supported(F, L, D))
+
+
+def gated_attn_pool_batched(x: torch.Tensor, lengths, weights: dict[str, torch.Tensor], return_attn: bool = False, offsets=None, mode: str = "auto"):
+    """MANY bags in one launch.  x fp32 [sum(lengths), F] = the bags' rows concatenated (a [B, N, F] batch is the special case lengths = [N] * B);
+    lengths: host ints, all > 0 (the reference raises on an empty feature matrix); offsets: the matching int64 device tensor [B + 1] if the caller
+    already holds it (False: a single bag, no table).  -> out [B, F] (+ A_raw [sum(lengths)]).  mode: "auto" picks the decomposition by the total row count
+    (include/amdstamp.h); with "slab" / "split" forced, each bag's result is bit-for-bit the one it gets alone."""
+    _dev(x, *weights.values())
+    lengths = [int(n) for n in lengths]
+    if not lengths or min(lengths) <= 0:
+        raise ValueError(f"every bag needs at least one row, got lengths {lengths[:8]}{'...' if len(lengths) > 8 else ''}")
+    if x.dim() == 3:
+        assert len(lengths) == x.shape[0] and all(n == x.shape[1] for n in lengths)
+        x = x.reshape(-1, x.shape[-1])
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    total, F = x.shape
+    assert total == sum(lengths), f"{total} rows for lengths summing to {sum(lengths)}"
+    B = len(lengths)
+    L, D = weights["fc_w"].shape[0], weights["a_w"].shape[0]
+    lib = _lib.lib()
+    if offsets is False:
+        assert B == 1
+        offsets = None
+    else:
+        if offsets is None:
+            offsets = torch.tensor([0] + lengths, dtype=torch.int64).cumsum(0).to(x.device)
+        assert offsets.dtype == torch.int64 and offsets.numel() == B + 1 and offsets.is_contiguous()
+        _dev(offsets)
+    nbytes = lib.amds_gated_attn_pool_batched_workspace_bytes(total, B, F, L, D)
+    ws = _gap_workspace(x.device, nbytes)
+    gw = _gap_weights(weights)
+    out = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    araw = torch.empty(total, dtype=torch.float32, device=x.device) if return_attn else None
+    _lib.check(lib.amds_gated_attn_pool_batched(_p(x), _p(offsets), B, total, C.byref(gw), _p(out), _p(araw), F, L, D, GAP_MODES[mode], _p(ws), nbytes,
+                                                _stream()), "gated_attn_pool_batched")
     return (out, araw) if return_attn else out
 
 

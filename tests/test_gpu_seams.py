@@ -50,6 +50,83 @@ def test_gated_attention_sizes_vs_oracle(gpu, N):
     assert torch.equal(out, out2)          # deterministic (no atomics)
 
 
+def _gap_sd(F, L, D, seed):
+    from oracle.gated_attention import KEYS
+
+    g = torch.Generator().manual_seed(seed)
+    return {KEYS["fc_w"]: torch.randn(L, F, generator=g) / F ** 0.5, KEYS["fc_b"]: torch.randn(L, generator=g) * 0.1,
+            KEYS["a_w"]: torch.randn(D, L, generator=g) / L ** 0.5, KEYS["a_b"]: torch.randn(D, generator=g) * 0.1,
+            KEYS["b_w"]: torch.randn(D, L, generator=g) / L ** 0.5, KEYS["b_b"]: torch.randn(D, generator=g) * 0.1,
+            KEYS["c_w"]: torch.randn(1, D, generator=g) * 2, KEYS["c_b"]: torch.randn(1, generator=g)}, g
+
+
+@pytest.mark.parametrize("mode", ["slab", "split", "auto"])
+@pytest.mark.parametrize("dims", [(768, 512, 256), (384, 256, 256)])
+def test_gated_attention_batched_ragged_vs_oracle(gpu, dims, mode):
+    """Many bags in ONE launch (amds_gated_attn_pool_batched): ragged lengths around the 16- / 64-row unit edges, against the oracle per bag; with a
+    forced decomposition bit-equal to the bag pooled alone (a bag's result must not depend on its neighbours); bit-stable run to run (the merge of a
+    bag's partials is in unit order whichever workgroup arrives last).  "slab" / "auto" also take a slide-sized bag."""
+    from oracle.gated_attention import KEYS, gated_attention_pool
+    from stamp_amd import ops
+
+    F, L, D = dims
+    sd, g = _gap_sd(F, L, D, seed=F)
+    lens = [1, 64, 2, 63, 65, 128, 300, 1, 1024, 129, 17, 7, 191, 640, 15, 16] + ([5000] if mode != "split" else [])
+    xs = [torch.randn(n, F, generator=g) for n in lens]
+    w = {k: sd[v].to(gpu).contiguous() for k, v in KEYS.items()}
+    xcat = torch.cat(xs).to(gpu)
+    out, araw = ops.gated_attn_pool_batched(xcat, lens, w, return_attn=True, mode=mode)
+    assert out.shape == (len(lens), F) and araw.shape == (sum(lens),)
+    o = 0
+    for i, (n, x) in enumerate(zip(lens, xs)):
+        ref = gated_attention_pool(x, sd)
+        np.testing.assert_allclose(araw[o:o + n].cpu().numpy(), ref["attention_raw"].reshape(-1).numpy(), rtol=1e-4, atol=1e-4, err_msg=f"bag {i} (N={n})")
+        # 3e-5: the oracle's own fp32 error on a 5000-row softmax (3.4e-5 against fp64, tools/scratch notes in DESIGN.md section 4.15)
+        np.testing.assert_allclose(out[i].cpu().numpy(), ref["WSI_feature"].reshape(-1).numpy(), rtol=1e-4, atol=3e-5, err_msg=f"bag {i} (N={n})")
+        if mode != "auto":
+            one, a1 = ops.gated_attn_pool(xcat[o:o + n], w, return_attn=True, mode=mode)
+            assert torch.equal(one, out[i]) and torch.equal(a1, araw[o:o + n]), f"bag {i} (N={n}) differs from the bag pooled alone"
+        o += n
+    for _ in range(3):
+        assert torch.equal(ops.gated_attn_pool_batched(xcat, lens, w, mode=mode), out)
+    # a [B, N, F] batch is the special case of equal lengths
+    xb = torch.randn(5, 200, F, generator=g).to(gpu)
+    ob = ops.gated_attn_pool_batched(xb, [200] * 5, w, mode=mode)
+    for i in range(5):
+        one = ops.gated_attn_pool(xb[i], w, mode="split" if mode == "auto" else mode)        # 1000 rows in total: "auto" is the split form
+        assert torch.equal(ob[i], one)
+    with pytest.raises(ValueError):
+        ops.gated_attn_pool_batched(xcat[:10], [10, 0], w)
+    if mode == "split":
+        with pytest.raises(RuntimeError, match="split form"):
+            ops.gated_attn_pool_batched(torch.zeros(13000, F, device=gpu), [13000], w, mode="split")
+
+
+def test_gated_attention_fused_vs_six_launch_and_fallback_shape(gpu):
+    """The fused launch against the six-launch form it replaces (same exact-fp32 products, different association), and a shape the fused kernel does
+    not take (L = 320) still served -- by the six-launch form -- and still within the oracle's bars."""
+    from oracle.gated_attention import KEYS, gated_attention_pool
+    from stamp_amd import ops
+
+    for (F, L, D), N in (((768, 512, 256), 1500), ((384, 256, 256), 90)):
+        sd, g = _gap_sd(F, L, D, seed=N)
+        x = torch.randn(N, F, generator=g).to(gpu)
+        w = {k: sd[v].to(gpu).contiguous() for k, v in KEYS.items()}
+        ou, au = ops.gated_attn_pool(x, w, return_attn=True, fused=False)
+        for mode in ("slab", "split"):
+            of, af = ops.gated_attn_pool(x, w, return_attn=True, mode=mode)
+            assert ((of - ou).norm() / ou.norm()).item() < 5e-6 and (af - au).abs().max().item() < 2e-5, mode      # fp32 round-off class: same products, other association
+    F, L, D, N = 200, 320, 72, 333
+    assert not ops.gated_attn_pool_batched_supported(F, L, D)
+    sd, g = _gap_sd(F, L, D, seed=5)
+    x = torch.randn(N, F, generator=g)
+    w = {k: sd[v].to(gpu).contiguous() for k, v in KEYS.items()}
+    ref = gated_attention_pool(x, sd)
+    out, araw = ops.gated_attn_pool(x.to(gpu), w, return_attn=True)
+    np.testing.assert_allclose(araw.cpu().numpy(), ref["attention_raw"].reshape(-1).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), ref["WSI_feature"].reshape(-1).numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_extractor_seam(gpu):
     from oracle.vit_tile_encoder import extract_features
     from stamp_amd.extractor import Extractor, extract_tiles, hip_vit_extractor, u8_tile_transform
