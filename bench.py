@@ -463,6 +463,97 @@ def drop_in_b64_leg(model, cfg, dev, n_batches: int = 48) -> dict:
             "unit": "tiles/s", "batches": n_batches, "hbm_resident_b64": round(64 * n_batches / el2, 1), "finite": bool(torch.isfinite(f.float()).all())}
 
 
+class ClockPowerSampler:
+    """Shader clock and socket power of this rank's GPU while a timed block runs, read from the amdgpu hwmon files (freq1_input in Hz, power1_input in
+    microwatts; a few microseconds per read) by a thread every 20 ms.  Lets a reader tell a slow box (clock, power cap) from a regression: round 5's
+    driver line read 3 % under the builder's leases with nothing on the line to say why.  Best effort: any failure leaves the fields None."""
+
+    def __init__(self, local_rank: int = 0, period: float = 0.02):
+        import glob
+        self.files = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        if cards:
+            f = cards[min(local_rank, len(cards) - 1)]
+            self.files = (f, f.replace("freq1_input", "power1_input"))
+        self.period, self.samples, self._stop, self._th = period, [], False, None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                mhz = int(open(self.files[0]).read()) / 1e6
+                try:
+                    w = int(open(self.files[1]).read()) / 1e6
+                except Exception:
+                    w = None
+                self.samples.append((mhz, w))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.files:
+            import threading
+            self.samples, self._stop = [], False
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def summary(self) -> dict:
+        clk = [c for c, _ in self.samples]
+        pw = [w for _, w in self.samples if w is not None]
+        return {"sclk_mhz": round(sum(clk) / len(clk), 1) if clk else None, "sclk_mhz_min": round(min(clk), 1) if clk else None,
+                "socket_w": round(sum(pw) / len(pw), 1) if pw else None, "socket_w_max": round(max(pw), 1) if pw else None, "samples": len(clk)}
+
+
+def gated_pool_leg(dev) -> dict:
+    """GPU leg of the gated-attention pooling: bags/s, us per bag, launches per bag, fraction of the fp32-MFMA and HBM roofs (tools/gap_only.py is the longer A/B)."""
+    from stamp_amd import ops
+
+    N, F_, L, Dd = 1024, 768, 512, 256
+    g = torch.Generator().manual_seed(5)
+    w = {"fc_w": torch.randn(L, F_, generator=g) / F_ ** 0.5, "fc_b": torch.zeros(L), "a_w": torch.randn(Dd, L, generator=g) / L ** 0.5, "a_b": torch.zeros(Dd),
+         "b_w": torch.randn(Dd, L, generator=g) / L ** 0.5, "b_b": torch.zeros(Dd), "c_w": torch.randn(1, Dd, generator=g) / Dd ** 0.5, "c_b": torch.zeros(1)}
+    w = {k: v.to(dev).contiguous() for k, v in w.items()}
+    B = 256
+    xb = torch.randn(B, N, F_, generator=g).to(dev)
+    offs = (torch.arange(B + 1, dtype=torch.int64) * N).to(dev)
+    flop, byts = 2.0 * N * (F_ * L + 2 * L * Dd), 4.0 * N * F_
+    F32_PEAK, HBM = 157.3e12, 6.29e12          # /opt/skills/guides/MI355X_MICROARCH.md: exact-fp32 MFMA peak; achievable HBM (float4 copy)
+
+    def ev(fn, reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / reps
+
+    def row(dt, bags, launches):
+        return {"bags_per_s": round(bags / dt, 1), "us_per_bag": round(dt / bags * 1e6, 2), "launches_per_bag": launches,
+                "tflops": round(bags * flop / dt / 1e12, 2), "frac_f32_mfma_peak": round(bags * flop / dt / F32_PEAK, 4), "frac_hbm_6p29": round(bags * byts / dt / HBM, 4)}
+
+    dt_b = ev(lambda: ops.gated_attn_pool_batched(xb, [N] * B, w, offsets=offs), 20)
+    dt_1 = ev(lambda: ops.gated_attn_pool(xb[0], w), 200)
+    dt_6 = ev(lambda: ops.gated_attn_pool(xb[0], w, fused=False), 200)
+    ob = ops.gated_attn_pool_batched(xb, [N] * B, w, offsets=offs)
+    o6 = torch.stack([ops.gated_attn_pool(xb[i], w, fused=False) for i in (0, B - 1)])
+    rel = ((ob[[0, B - 1]] - o6).norm() / o6.norm()).item()
+    return {"metric": "gated-attention pooling bags/s (CHIEF Attn_Net_Gated + softmax pooling, bags of 1024 x 768 fp32, exact-fp32 MFMA), 256 bags per launch",
+            "value": round(B / dt_b, 1), "unit": "bags/s", "gflop_per_bag": round(flop / 1e9, 4), "mb_per_bag": round(byts / 1e6, 3),
+            "batched_256": row(dt_b, B, "1/256 kernel + 1/256 memset"), "one_bag_per_call": row(dt_1, 1, "1 kernel + 1 memset"),
+            "six_launch_form_one_bag_per_call": row(dt_6, 1, "6 kernels + 4 copies"), "rel_l2_fused_vs_six_launch": float(f"{rel:.2e}"),
+            "finite": bool(torch.isfinite(ob).all())}
+
+
 def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     """BASELINE.json's secondary metric, MIL bags/s (bags of 1024 x 1024-d, batch 64), and the in-tree tile encoder."""
     from stamp_amd.mil import TransMIL as HipTransMIL
@@ -569,6 +660,13 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
                                  "value": round(time.perf_counter() - t0c, 3), "unit": "s", "higher_is_better": False,
                                  "validation_loss_finite": bool(all(v == v for v in hist["validation_loss"]))}
     del cb, tr1
+    # Gated-attention pooling (CHIEF, chief.py:74-89) on the GPU: bags of 1024 x 768 fp32 -- the workload of cpu_baseline.mil.gated_attention_pool.
+    # One bag per call (what the reference's per-slide loop issues), 256 bags per launch (amds_gated_attn_pool_batched), and the six-launch form the fused
+    # kernel replaced; exact fp32 throughout (v_mfma_f32_16x16x4_f32: 157.3 TF peak).  Algorithmic work per bag: 1.342 GFLOP, 3.146 MB (x read once).
+    try:
+        sec["gated_attention_pool"] = gated_pool_leg(ctx.device)
+    except Exception as e:
+        sec["gated_attention_pool"] = {"error": repr(e)[:300]}
     if not is_swin:     # the reference's in-tree tile encoder, same tile shape
         scfg = SWIN_PRESETS["ctranspath"]
         sw = HipSwin(scfg, random_swin_state_dict(scfg, 0), device=ctx.device, chunk=a.swin_chunk)
@@ -665,17 +763,31 @@ def main() -> None:
         step()
     lib.amds_profile_reset(actx)
     lib.amds_profile_enable(actx, 1)
+    sampler = ClockPowerSampler(int(os.environ.get("LOCAL_RANK", "0")))
     D.barrier(ctx)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    D.barrier(ctx)
-    elapsed = time.perf_counter() - t0
+    with sampler:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        D.barrier(ctx)
+        elapsed = time.perf_counter() - t0
     lib.amds_profile_enable(actx, 0)
     elapsed = D.max_over_ranks(ctx, elapsed)
     assert torch.isfinite(out.float()).all()
+    clock0 = sampler.summary()
+
+    def headline_block() -> dict:
+        """The headline region again (same K steps, same synchronisation), for the per-block list: single-GPU line only."""
+        torch.cuda.synchronize()
+        with sampler:
+            t = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t
+        return {"tiles_per_s": round(a.tiles * a.steps / el, 1), **sampler.summary()}
 
     # roofline of the dominant kernel (the MFMA GEMM), from HIP events recorded around every launch of it
     ms, n, work = C.c_double(), C.c_long(), C.c_double()
@@ -733,7 +845,11 @@ def main() -> None:
                    "guard": None if is_swin else f"check={model.check!r}: non-finite / |mean| > 8 sigma check per call, in the timed region; safe level {model.safe_level}",
                    "cls_tail": bool(tail_on), "residual_stream": "f16 hi|lo planes" if (not is_swin and planes_on) else "f32",
                    "gflop_per_tile_executed": round(flops_exec / 1e9, 3),
-                   "whole_path_mfma_frac": round(value / ctx.world * flops_exec / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                   "whole_path_mfma_frac": round(value / ctx.world * flops_exec / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                   # shader clock / socket power of rank 0's GPU during the timed region (hwmon freq1_input / power1_input every 20 ms): `value` above is
+                   # block 0; the single-GPU line re-times the same K steps after the end-to-end leg and at the very end (blocks_tiles_per_s, median_block)
+                   "sclk_mhz": clock0["sclk_mhz"], "sclk_mhz_min": clock0["sclk_mhz_min"], "socket_w": clock0["socket_w"], "socket_w_max": clock0["socket_w_max"],
+                   "clock_power_samples": clock0["samples"], "blocks_tiles_per_s": [round(value / ctx.world, 1)], "blocks": [{"tiles_per_s": round(value / ctx.world, 1), **clock0}]},
         "roofline": {"kernel": "MFMA GEMMs (gemm_tn_kernel 128x96 / 128x128 tiles where N is not a multiple of 256, gemm_4w16_kernel in stage 4 and the stage-3 MLP)" if is_swin else
                                ("gemm_4w16_kernel (256x256x64 tiles, 4 waves with 128x128 wave tiles, v_mfma_f32_16x16x32, buffer-form LDS-DMA, fused LDS-staged epilogues"
                                 + ("; LayerNorm folded in: proj / fc2 also emit row sums, qkv / fc1 apply the row statistics" if getattr(model, "ln_fold", False) else "")
@@ -756,6 +872,16 @@ def main() -> None:
             line["end_to_end"] = end_to_end_leg(model, cfg, ctx.device, a.e2e_tiles, a.swin_chunk if is_swin else a.chunk, a.e2e_warmup)
         except Exception as e:
             line["end_to_end"] = {"error": repr(e)[:300]}
+
+    def add_block() -> None:
+        try:
+            b = headline_block()
+            line["config"]["blocks"].append(b)
+            line["config"]["blocks_tiles_per_s"].append(b["tiles_per_s"])
+        except Exception as e:
+            line["config"]["blocks"].append({"error": repr(e)[:200]})
+    if single:
+        add_block()          # block 1: after the end-to-end leg
     if single and not is_swin and not a.exact:
         # the opt-in exact class-token mode on the same workload (HipViT(exact=True), csrc/vit_exact.hip): what it costs, next to what it buys
         # (tests/test_gpu_vit.py: fp16 CLS feature error 5-8e-4 -> 3-4e-4)
@@ -862,6 +988,9 @@ def main() -> None:
             line["secondary"] = secondary_metrics(ctx, a, tiles, is_swin)
         except Exception as e:      # the headline metric must still be printed
             line["secondary"] = {"error": repr(e)[:300]}
+        add_block()          # block 2: the last GPU work of the run
+        bl = sorted(line["config"]["blocks_tiles_per_s"])
+        line["config"]["median_block_tiles_per_s"] = bl[len(bl) // 2] if bl else None
     if ctx.is_main and ctx.world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds, swin=is_swin)
         if not a.no_secondary:

@@ -91,6 +91,19 @@ class HipGatedAttentionEncoder:
     def _generate_patient_embedding(self, feats_list: list, device=None, **kwargs) -> np.ndarray:
         return self._generate_slide_embedding(torch.cat([f.to(self.device) for f in feats_list], dim=0))
 
+    @torch.no_grad()
+    def _generate_slide_embeddings(self, feats_list: list) -> np.ndarray:
+        """Several slides in ONE launch (amds_gated_attn_pool_batched): [len(feats_list), F].  Row i is what `_generate_slide_embedding(feats_list[i])`
+        returns, up to the last-bit difference between the two decompositions of the fused kernel (include/amdstamp.h AMDS_GAP_AUTO)."""
+        for f in feats_list:
+            if f.dim() != 2 or f.shape[0] == 0:
+                raise ValueError(f"expected a non-empty [N, F] feature matrix, got {tuple(f.shape)}")
+        F, L, D = self.weights["fc_w"].shape[1], self.weights["fc_w"].shape[0], self.weights["a_w"].shape[0]
+        if len(feats_list) == 1 or not ops.gated_attn_pool_batched_supported(F, L, D):
+            return np.stack([self._generate_slide_embedding(f) for f in feats_list])
+        x = torch.cat([f.to(self.device, torch.float32) for f in feats_list], dim=0).contiguous()
+        return ops.gated_attn_pool_batched(x, [f.shape[0] for f in feats_list], self.weights).detach().cpu().numpy()
+
     # ---- the reference base class's file loops (encoder/__init__.py:42-229), on stamp_amd.h5io ---------------------------------------
     def _read_h5(self, h5_path: str):
         """-> (feats [N, F] in self.precision, CoordsInfo, extractor name without its hash suffix); what the reference's reader refuses
@@ -121,12 +134,23 @@ class HipGatedAttentionEncoder:
         h5io.write_slide_features(output_path, feats, encoder=str(self.identifier), precision=str(self.precision), code_hash=code_hash()[:8],
                                   stamp_version=STAMP_FORMAT_VERSION, feat_type=feat_type, amdstamp_version=AMDSTAMP_VERSION)
 
-    def encode_slides_(self, output_dir: Path, feat_dir: Path, device=None, generate_hash: bool = True, **kwargs) -> None:
+    def encode_slides_(self, output_dir: Path, feat_dir: Path, device=None, generate_hash: bool = True, batch_slides: int = 32,
+                       batch_rows: int = 1 << 19, **kwargs) -> None:
         """One slide-level .h5 per tile-level .h5 under feat_dir, folder structure kept, existing outputs skipped, files whose extractor
-        is not accepted reported and skipped (:42-93)."""
+        is not accepted reported and skipped (:42-93).  The reference embeds one slide per iteration; here up to `batch_slides` slides (or
+        `batch_rows` tiles) are read, pooled in ONE launch and written -- same files, same order.  batch_slides=1 is the per-slide loop."""
         encode_dir = Path(output_dir) / (f"{self.identifier}-slide-{code_hash()[:8]}" if generate_hash else f"{self.identifier}-slide")
         os.makedirs(encode_dir, exist_ok=True)
         feat_dir = Path(feat_dir)
+        pending: list = []
+
+        def flush() -> None:
+            if pending:
+                embs = self._generate_slide_embeddings([f for _, f in pending])
+                for (path, _), emb in zip(pending, embs):
+                    self._save_features_(path, emb, "slide")
+                pending.clear()
+
         for h5_path in sorted(feat_dir.rglob("*.h5")):
             output_path = (encode_dir / h5_path.relative_to(feat_dir)).with_suffix(".h5")
             if output_path.exists():
@@ -137,7 +161,17 @@ class HipGatedAttentionEncoder:
             except ValueError as e:
                 _logger.warning(str(e))
                 continue
-            self._save_features_(output_path, self._generate_slide_embedding(feats, device, coords=coords), "slide")
+            if type(self)._generate_slide_embedding is not HipGatedAttentionEncoder._generate_slide_embedding:
+                # a subclass with its own per-slide arithmetic (coords, second feature file): the per-slide loop
+                self._save_features_(output_path, self._generate_slide_embedding(feats, device, coords=coords), "slide")
+                continue
+            if feats.dim() != 2 or feats.shape[0] == 0:
+                flush()
+                raise ValueError(f"expected a non-empty [N, F] feature matrix, got {tuple(feats.shape)}")
+            pending.append((output_path, feats))
+            if len(pending) >= max(1, batch_slides) or sum(f.shape[0] for _, f in pending) >= batch_rows:
+                flush()
+        flush()
 
     def encode_patients_(self, output_dir: Path, feat_dir: Path, patient_to_files: dict[str, list[str]], device=None, generate_hash: bool = True,
                          **kwargs) -> None:

@@ -580,7 +580,7 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
             m.defer_check = True
             if hasattr(m, "range_diagnostics"):
                 m.range_diagnostics(reset=True)
-        diag_ring = torch.zeros(256, 2, dtype=torch.int32).pin_memory()
+        diag_ring = torch.zeros(256, max(1, len(guarded)), 2, dtype=torch.int32).pin_memory()          # [call slot][guarded module][2 counters]
         cs.synchronize()
 
         # ---- bookkeeping.  Kept tiles form ONE global sequence (slide after slide, supertile order inside a slide); a slide owns rows
@@ -590,6 +590,7 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
         pending: list = []                            # (slot index, rows, event, slide idx, coords slice): decisions not yet on the host
         kept_known = encoded = unknown = 0
         calls: list = []                              # (row_lo, m, pinned block, event, diag slot)
+        n_calls = 0                                   # encoder calls so far: `calls` is pruned, its length is not a sequence number
         free_blocks: list = []
         batch_no = 0
         writer = futures.ThreadPoolExecutor(1)
@@ -620,7 +621,7 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
         trace_ev: list = [] if os.environ.get("AMDS_SLIDES_TRACE") else None       # (start, end) events around every encoder call: GPU time between calls
 
         def encode(m: int) -> None:
-            nonlocal cur, encoded
+            nonlocal cur, encoded, n_calls
             if trace_ev is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record(cs)
@@ -633,10 +634,18 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                 f = f.half()
             f = f.contiguous()
             blk = free_blocks.pop() if free_blocks and free_blocks[-1].shape[1] == f.shape[1] else torch.empty(chunk, f.shape[1], dtype=torch.float16).pin_memory()
+            # amds_export_words moves 32-bit words: an odd fp16 count would leave the last feature of the last row behind (stale in a reused block)
+            assert f.shape[1] % 2 == 0 and m <= blk.shape[0] and f.data_ptr() % 4 == 0, (tuple(f.shape), m, tuple(blk.shape))
             # the rows reach the host through a kernel's stores (amds_export_words): no copy command behind the encoder in front of the next H2D copies
             _lib.check(_lib.lib().amds_export_words(f.data_ptr(), blk.data_ptr(), m * f.shape[1] // 2, 0, cs.cuda_stream), "export_words")
-            dslot = len(calls) % diag_ring.shape[0]
-            has_diag = any(getattr(g, "export_range_counters", None) and g.export_range_counters(diag_ring[dslot]) for g in guarded)
+            # one ring slot per call, by a MONOTONIC call number (len(calls) shrinks when finalize_ready prunes: a retained call's slot would be handed out
+            # again and its counters overwritten -- a silent miss of that call's |mean| > 8 sigma count); a retained call must not be lapped either
+            assert len(calls) < diag_ring.shape[0], "extract_slides: more encoder calls await finalisation than the range-counter ring holds"
+            dslot = n_calls % diag_ring.shape[0]
+            n_calls += 1
+            diag_ring[dslot].zero_()
+            # every guarded module exports (and resets) its own counters: a list, not any(), which stops at the first True
+            has_diag = any([bool(getattr(g, "export_range_counters", None) and g.export_range_counters(diag_ring[dslot, gi])) for gi, g in enumerate(guarded)])
             ev = torch.cuda.Event()
             ev.record(cs)
             calls.append((encoded, m, blk, ev, dslot if has_diag else -1, f))
@@ -670,7 +679,7 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                 order.pop(0)
                 parts = [c[2][max(lo, c[0]) - c[0]: min(hi, c[0] + c[1]) - c[0]] for c in mine]
                 feats = torch.cat(parts) if len(parts) > 1 else (parts[0].clone() if parts else torch.empty(0, 0, dtype=torch.float16))
-                big_mean = sum(int(diag_ring[c[4], 1]) for c in mine if c[4] >= 0)
+                big_mean = sum(int(diag_ring[c[4], :, 1].sum()) for c in mine if c[4] >= 0)
                 coords = np.concatenate(s["coords"]) if s["coords"] else np.zeros((0, 2))
                 # blocks no unfinalised slide needs any more go back to the pool
                 floor = hi
@@ -835,6 +844,8 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
                                max_workers=max_workers, supertiles_per_batch=supertiles_per_batch, encode_chunk=encode_chunk, device=device)
             r.update(r2)
             r["status"] = "written" if Path(job.output_path).exists() else "empty"
+            if slide is not job.slide and hasattr(slide, "close"):          # opened here (a factory): closed here
+                slide.close()
         except BaseException as e:
             r["status"] = "failed"
             r["error"] = repr(e)

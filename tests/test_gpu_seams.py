@@ -241,6 +241,12 @@ def test_encoder_file_loop_on_h5_files(gpu, tmp_path):
     ref = gated_attention_pool(slides["a/s1"].float(), sd)["WSI_feature"].reshape(-1)
     assert a["feat_type"] == "slide" and a["encoder"] == "chief" and a["precision"] == "torch.float32" and d["feats"].shape == (F_,)
     assert np.abs(d["feats"] - ref.numpy()).max() < 1e-4 * max(1.0, float(ref.abs().max()))
+    # the slides above went through ONE batched launch; the reference's one-slide-per-iteration loop writes the same files
+    enc.encode_slides_(tmp_path / "out1", feat_dir, gpu, generate_hash=False, batch_slides=1)
+    for rel in outs:
+        d1, a1 = h5io.read_file(tmp_path / "out1" / rel)
+        db, ab = h5io.read_file(out_dir / rel)
+        assert a1["feat_type"] == ab["feat_type"] and np.abs(d1["feats"] - db["feats"]).max() < 2e-6
     before = (out_dir / "chief-slide" / "s2.h5").stat().st_mtime_ns
     enc.encode_slides_(out_dir, feat_dir, gpu, generate_hash=False)                    # second run: everything exists, nothing rewritten
     assert (out_dir / "chief-slide" / "s2.h5").stat().st_mtime_ns == before
