@@ -122,7 +122,7 @@ def max_over_ranks(ctx: DistCtx, value: float) -> float:
 
 
 def slide_tile_counts(ctx: DistCtx, jobs, *, tile_size_um: float = 256.0, tile_size_px: int = 224, max_supertile_size_slide_px: int = 2 ** 10,
-                      brightness_cutoff: int | None = 240) -> list[int]:
+                      brightness_cutoff: int | None = 240, default_slide_mpp: float | None = None) -> list[int]:
     """Foreground tile count of every slide of the job list -- the cost LPT sharding balances (SURVEY.md 8e "Partitioning"): the number of supertiles that
     survive the thumbnail's brightness cut (`tiling.foreground_coords`, reference tiling.py:250-277) x tiles per supertile.  Rank r looks at slides
     r, r + world, ... (a thumbnail each: host I/O) and ONE control-plane all-reduce of the int64 counts (disjoint supports) makes the list complete on every rank; a slide
@@ -133,7 +133,8 @@ def slide_tile_counts(ctx: DistCtx, jobs, *, tile_size_um: float = 256.0, tile_s
         job = jobs[i]
         try:
             slide = job.slide() if isinstance(job.slide, type) or (callable(job.slide) and not hasattr(job.slide, "read_region")) else job.slide
-            geo = tiling.supertile_geometry(job.slide_mpp, tile_size_um, tile_size_px, max_supertile_size_slide_px)
+            mpp = job.slide_mpp if job.slide_mpp is not None else tiling.get_slide_mpp(slide, default_mpp=default_slide_mpp)     # (tiling.py:409-446)
+            geo = tiling.supertile_geometry(mpp, tile_size_um, tile_size_px, max_supertile_size_slide_px)
             dims = tuple(int(v) for v in slide.dimensions)
             gw, gh = tiling.thumbnail_size(dims, geo.supertile_size_slide_px)
             n = len(tiling.foreground_coords(dims, slide.get_thumbnail((2 * gw, 2 * gh)), geo.supertile_size_slide_px, brightness_cutoff))
@@ -155,7 +156,7 @@ def extract_slides_sharded(ctx: DistCtx, jobs, extractor, *, runner=None, tile_c
     owned, its per-slide results in that order).  `runner(jobs, extractor, **kw) -> list[dict]` replaces `extract_slides` (tests on CPU ranks)."""
     if runner is None:
         from .preprocess import extract_slides as runner
-    geo_kw = {k: kw[k] for k in ("tile_size_um", "tile_size_px", "max_supertile_size_slide_px", "brightness_cutoff") if k in kw}
+    geo_kw = {k: kw[k] for k in ("tile_size_um", "tile_size_px", "max_supertile_size_slide_px", "brightness_cutoff", "default_slide_mpp") if k in kw}
     counts = tile_counts if tile_counts is not None else slide_tile_counts(ctx, jobs, **geo_kw)
     mine = shard_slides(counts, ctx.world)[ctx.rank]
     # largest first inside the share as well: the pipeline's tail (the last, partly filled encoder chunk) then belongs to a small slide

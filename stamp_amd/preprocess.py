@@ -429,7 +429,7 @@ class SlideJob:
     under slide i's GPU work; an opened object that has `close()` is closed when its last region has been read."""
     slide: Any
     output_path: Any
-    slide_mpp: float
+    slide_mpp: float | None          # None: looked up in the slide's metadata (tiling.get_slide_mpp, the reference's get_slide_mpp_) before the pipeline starts
     name: str = ""
 
 
@@ -445,11 +445,33 @@ class _Plan:
     opened_here: bool
 
 
+def resolve_slide_mpps(jobs, default_mpp: float | None = None) -> tuple[list, dict]:
+    """Jobs with `slide_mpp=None` get theirs from the slide's metadata (`tiling.get_slide_mpp`; a factory is opened, read and closed).  Returns (the job list
+    with None in place of every job whose resolution could not be determined, {index: repr(error)})."""
+    out, failed = [], {}
+    for i, j in enumerate(jobs):
+        if j.slide_mpp is not None:
+            out.append(j)
+            continue
+        s = None
+        try:
+            s = j.slide() if isinstance(j.slide, type) or (callable(j.slide) and not hasattr(j.slide, "read_region")) else j.slide
+            out.append(_dc.replace(j, slide_mpp=tiling.get_slide_mpp(s, default_mpp=default_mpp)))
+        except Exception as e:
+            _log.exception(f"Failed reading the resolution of {j.name or j.output_path}")
+            out.append(None)
+            failed[i] = repr(e)
+        finally:
+            if s is not None and s is not j.slide and hasattr(s, "close"):
+                s.close()
+    return out, failed
+
+
 @torch.inference_mode()
 def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_um: float = 256.0, tile_size_px: int = 224,
                    max_supertile_size_slide_px: int = 2 ** 10, brightness_cutoff: int | None = 240, canny_cutoff: float | None = 0.02,
                    max_workers: int = 8, supertiles_per_batch: int = 64, encode_chunk: int | None = None, device="cuda", skip_existing: bool = True,
-                   on_slide_done: Callable[[int, dict], None] | None = None) -> list[dict]:
+                   on_slide_done: Callable[[int, dict], None] | None = None, default_slide_mpp: float | None = None) -> list[dict]:
     """Every job's slide -> its feature `.h5`, the files `extract_slide` writes bit for bit, as ONE pipeline: the reader threads, the pinned
     ring, the device ring, the accumulation buffer and the encoder calls are shared by all slides, so slide i + 1 is opened, thumbnailed and read
     under slide i's last encoder calls, and an encoder chunk takes the tail of one slide together with the head of the next (a tile's features do
@@ -470,6 +492,22 @@ def extract_slides(jobs: Iterable[SlideJob], extractor: Extractor, *, tile_size_
     if dev.type != "cuda":
         raise RuntimeError("extract_slides runs on the GPU only (no CPU fallback)")
     jobs = list(jobs)
+    if any(j.slide_mpp is None for j in jobs):
+        # `stamp preprocess` reads the resolution out of the slide (reference __init__.py:288-291 -> tiling.get_slide_mpp_); a slide whose metadata has none
+        # (and no default_slide_mpp) fails like any other per-slide error and the rest goes through the pipeline
+        known, failed = resolve_slide_mpps(jobs, default_slide_mpp)
+        idx = [i for i, j in enumerate(known) if j is not None]
+        sub = extract_slides([known[i] for i in idx], extractor, tile_size_um=tile_size_um, tile_size_px=tile_size_px,
+                             max_supertile_size_slide_px=max_supertile_size_slide_px, brightness_cutoff=brightness_cutoff, canny_cutoff=canny_cutoff,
+                             max_workers=max_workers, supertiles_per_batch=supertiles_per_batch, encode_chunk=encode_chunk, device=device, skip_existing=skip_existing,
+                             on_slide_done=None if on_slide_done is None else (lambda k, r: on_slide_done(idx[k], r)))
+        out = [{"status": "failed", "name": j.name or str(j.output_path), "error": failed.get(i, "")} for i, j in enumerate(jobs)]
+        for k, i in enumerate(idx):
+            out[i] = sub[k]
+        if on_slide_done is not None:
+            for i in failed:
+                on_slide_done(i, out[i])
+        return out
     results: list[dict] = [{"status": "pending", "name": j.name or str(j.output_path)} for j in jobs]
     if not jobs:
         return results

@@ -20,6 +20,62 @@ import torch
 from . import _lib, ops
 
 
+class MPPExtractionError(Exception):
+    """No microns-per-pixel value anywhere in the slide's metadata and no default given (the reference's exception of the same name, tiling.py:46-50)."""
+
+
+def _mpp_from_property(props) -> float | None:
+    v = props.get("openslide.mpp-x")                       # openslide.PROPERTY_NAME_MPP_X
+    return None if v is None else float(v)
+
+
+def _mpp_from_comment(props) -> float | None:
+    import re
+    hit = re.search(r"<PixelSizeMicrons>(.*?)</PixelSizeMicrons>", props.get("openslide.comment", "") or "")
+    return float(hit.group(1)) if hit else None
+
+
+def _mpp_from_image_description(props) -> float | None:
+    """OME-style XML in the TIFF ImageDescription: PhysicalSizeX of the first <Pixels> of the first <Image>; anything malformed counts as 'not there'."""
+    text = props.get("tiff.ImageDescription") or None
+    if text is None:
+        return None
+    try:
+        from xml.dom import minidom
+        root = minidom.parseString(text).documentElement
+        return float(root.getElementsByTagName("Image")[0].getElementsByTagName("Pixels")[0].getAttribute("PhysicalSizeX"))
+    except Exception:
+        return None
+
+
+def get_slide_mpp(slide, *, default_mpp: float | None = None) -> float:
+    """Microns per pixel of a slide, looked up where the reference's `get_slide_mpp_` looks, in its order (tiling.py:409-446): the `openslide.mpp-x` property;
+    `<PixelSizeMicrons>` in `openslide.comment`; `PhysicalSizeX` in the OME XML of `tiff.ImageDescription`; then `default_mpp` (with a warning); else
+    MPPExtractionError.  `slide`: an object with a `properties` mapping (an opened openslide slide), such a mapping itself, or a path (opened with
+    openslide, which this package does not depend on otherwise).  As in the reference, a source that yields 0 counts as absent for the later sources."""
+    import logging
+    import os
+    opened = None
+    if isinstance(slide, (str, os.PathLike)):
+        import openslide                                     # reference behaviour for a path; ImportError says what is missing
+        slide = opened = openslide.open_slide(slide)
+    try:
+        props = slide if hasattr(slide, "get") and not hasattr(slide, "properties") else slide.properties
+        if props.get("openslide.mpp-x") is not None:
+            mpp = _mpp_from_property(props)                  # (the reference takes this value as it is, even 0)
+        else:
+            mpp = _mpp_from_comment(props) or _mpp_from_image_description(props)
+    finally:
+        if opened is not None and hasattr(opened, "close"):
+            opened.close()
+    if mpp:
+        return float(mpp)
+    if default_mpp:
+        logging.getLogger("stamp").warning(f"could not infer slide MPP from metadata, using {default_mpp} instead.")
+        return float(default_mpp)
+    raise MPPExtractionError()
+
+
 @dataclass(frozen=True)
 class SupertileGeometry:
     tile_size_slide_px: int          # one tile's side in level-0 pixels, ceil(tile_size_um / mpp)            (tiling.py:311)

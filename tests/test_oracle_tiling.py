@@ -87,3 +87,49 @@ def test_product_coefficients_equal_oracles():
         ob, ok = ot.precompute_coeffs(a, b)
         pb, pk = pt.resize_coefficients(a, b)
         assert np.array_equal(ob, pb) and np.array_equal(ok, pk)
+
+
+def test_get_slide_mpp_matches_reference_fixture():
+    """`tiling.get_slide_mpp` against the reference's own `get_slide_mpp_` (tiling.py:409-475) run on the same property mappings
+    (tests/golden/slide_mpp.json, tools/make_golden.py:golden_slide_mpp): every source, their precedence, malformed XML, the default, the error."""
+    import json
+    import types
+    from pathlib import Path
+
+    import pytest
+
+    from stamp_amd.tiling import MPPExtractionError, get_slide_mpp
+
+    cases = json.loads((Path(__file__).parent / "golden" / "slide_mpp.json").read_text())
+    assert len(cases) == 16
+    for name, rec in cases.items():
+        for slide in (types.SimpleNamespace(properties=rec["properties"]), rec["properties"]):          # an opened slide, or its property mapping
+            if "error" in rec:
+                assert rec["error"] == "MPPExtractionError"
+                with pytest.raises(MPPExtractionError):
+                    get_slide_mpp(slide, default_mpp=rec["default_mpp"])
+            else:
+                assert get_slide_mpp(slide, default_mpp=rec["default_mpp"]) == rec["mpp"], name
+
+
+def test_resolve_slide_mpps_fills_missing_resolutions():
+    import types
+
+    from stamp_amd.preprocess import SlideJob, resolve_slide_mpps
+
+    closed = []
+
+    class Fake:
+        def __init__(self, props):
+            self.properties = props
+
+        def close(self):
+            closed.append(self)
+
+    jobs = [SlideJob(lambda: Fake({"openslide.mpp-x": "0.25"}), "a.h5", None, "a"), SlideJob(Fake({}), "b.h5", 0.5, "b"),
+            SlideJob(lambda: Fake({}), "c.h5", None, "c"), SlideJob(types.SimpleNamespace(properties={"openslide.comment": "<PixelSizeMicrons>0.4</PixelSizeMicrons>"}), "d.h5", None)]
+    known, failed = resolve_slide_mpps(jobs)
+    assert [None if j is None else j.slide_mpp for j in known] == [0.25, 0.5, None, 0.4] and list(failed) == [2] and "MPPExtractionError" in failed[2]
+    assert len(closed) == 2                                   # the two slides opened here were closed here
+    known, failed = resolve_slide_mpps(jobs, default_mpp=1.0)
+    assert [j.slide_mpp for j in known] == [0.25, 0.5, 1.0, 0.4] and not failed

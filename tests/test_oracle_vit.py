@@ -123,3 +123,52 @@ def test_oracle_sdpa_path_equals_explicit_attention():
     _, a = extract_features(tiles, sd, cfg, return_tokens=True)
     _, b = extract_features(tiles, sd, cfg, return_tokens=True, sdpa=True)
     torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
+def _hf_vit_to_timm(hf_sd, depth):
+    """HF `ViTModel` (Google ViT: class token + one learned position row per token, pre-LN blocks, NO LayerScale, GELU MLP -- the
+    architecture of timm `vit_large_patch16_224` behind the reference's uni.py:26-31 / keep.py:29-37) -> timm names.  Re-labelling only."""
+    sd = {"patch_embed.proj.weight": hf_sd["embeddings.patch_embeddings.projection.weight"],
+          "patch_embed.proj.bias": hf_sd["embeddings.patch_embeddings.projection.bias"],
+          "cls_token": hf_sd["embeddings.cls_token"], "pos_embed": hf_sd["embeddings.position_embeddings"],
+          "norm.weight": hf_sd["layernorm.weight"], "norm.bias": hf_sd["layernorm.bias"]}
+    for i in range(depth):
+        h, t = f"layers.{i}.", f"blocks.{i}."
+        sd[t + "norm1.weight"], sd[t + "norm1.bias"] = hf_sd[h + "layernorm_before.weight"], hf_sd[h + "layernorm_before.bias"]
+        sd[t + "norm2.weight"], sd[t + "norm2.bias"] = hf_sd[h + "layernorm_after.weight"], hf_sd[h + "layernorm_after.bias"]
+        a = h + "attention."
+        sd[t + "attn.qkv.weight"] = torch.cat([hf_sd[a + "q_proj.weight"], hf_sd[a + "k_proj.weight"], hf_sd[a + "v_proj.weight"]])
+        sd[t + "attn.qkv.bias"] = torch.cat([hf_sd[a + "q_proj.bias"], hf_sd[a + "k_proj.bias"], hf_sd[a + "v_proj.bias"]])
+        sd[t + "attn.proj.weight"], sd[t + "attn.proj.bias"] = hf_sd[a + "o_proj.weight"], hf_sd[a + "o_proj.bias"]
+        for n in ("fc1", "fc2"):
+            sd[t + f"mlp.{n}.weight"], sd[t + f"mlp.{n}.bias"] = hf_sd[h + f"mlp.{n}.weight"], hf_sd[h + f"mlp.{n}.bias"]
+    return sd
+
+
+@pytest.mark.parametrize("shape", [(128, 3, 2, 256), (192, 2, 3, 768)])
+def test_oracle_matches_hf_vit(shape):
+    """A SECOND independent witness for the oracle, on the branch Dinov2 cannot reach: patch 16 (196 + 1 tokens) and no LayerScale -- HF `ViTModel`
+    (transformers' Google-ViT implementation; timm's `vit_large_patch16_224` of uni.py:26-31 / keep.py:29-37 is this architecture)."""
+    from transformers import ViTConfig as HFViTConfig
+    from transformers import ViTModel
+
+    dim, depth, heads, hidden = shape
+    torch.manual_seed(11)
+    model = ViTModel(HFViTConfig(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=hidden, image_size=224, patch_size=16,
+                                 hidden_act="gelu", layer_norm_eps=1e-6, qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
+                     add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    hf_sd = {k: v.detach() for k, v in model.state_dict().items()}
+    if "layers.0.attention.q_proj.weight" not in hf_sd:
+        pytest.skip("this transformers version names ViTModel's parameters differently")
+    cfg = ViTConfig(patch=16, dim=dim, depth=depth, heads=heads, hidden=hidden, mlp="gelu", reg_tokens=0, no_embed_class=False, layerscale=False, ln_eps=1e-6)
+    sd = _hf_vit_to_timm(hf_sd, depth)
+    tiles = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(12))
+    x = tile_transform(tiles, cfg.mean, cfg.std)
+    with torch.no_grad():
+        ref = model(pixel_values=x).last_hidden_state
+        got = vit_tokens(x, sd, cfg)
+    assert got.shape == ref.shape == (2, 197, dim)
+    torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4)

@@ -978,6 +978,44 @@ def golden_texture_gray() -> None:
     save("texture_gray.npz", tiles=tiles, gray=gray)
 
 
+def golden_slide_mpp() -> None:
+    """The reference's `get_slide_mpp_` / `_extract_mpp_from_comments` / `_extract_mpp_from_metadata` (src/stamp/preprocessing/tiling.py:409-475) on slide
+    stand-ins that carry only a `properties` mapping (the one thing the functions read; openslide itself is absent: the module constant
+    PROPERTY_NAME_MPP_X is handed in with openslide-python's value).  Cases: every source, their precedence, malformed XML, nothing at all +- a default."""
+    import json
+    import logging
+    import re
+    from xml.dom import minidom
+
+    class MPPExtractionError(Exception):
+        pass
+
+    glb = {"openslide": types.SimpleNamespace(PROPERTY_NAME_MPP_X="openslide.mpp-x", AbstractSlide=object, open_slide=None), "Path": Path, "SlideMPP": float,
+           "re": re, "minidom": minidom, "_logger": logging.getLogger("golden"), "MPPExtractionError": MPPExtractionError}
+    exec_defs(REF / "preprocessing" / "tiling.py", {"get_slide_mpp_", "_extract_mpp_from_comments", "_extract_mpp_from_metadata"}, glb)
+    ome = '<OME><Image ID="Image:0"><Pixels PhysicalSizeX="0.4991" PhysicalSizeY="0.4991" SizeX="10"/></Image><Image><Pixels PhysicalSizeX="7.9"/></Image></OME>'
+    cases = {"property": {"openslide.mpp-x": "0.2522", "openslide.comment": "<PixelSizeMicrons>0.9</PixelSizeMicrons>"},
+             "comment": {"openslide.comment": "Aperio x|<PixelSizeMicrons>0.345</PixelSizeMicrons>|more"},
+             "ome_xml": {"tiff.ImageDescription": ome},
+             "comment_before_xml": {"openslide.comment": "<PixelSizeMicrons>0.5</PixelSizeMicrons>", "tiff.ImageDescription": ome},
+             "bad_xml": {"tiff.ImageDescription": "not xml at all"},
+             "xml_without_pixels": {"tiff.ImageDescription": "<OME><Image/></OME>"},
+             "empty_comment": {"openslide.comment": ""},
+             "nothing": {}}
+    out = {}
+    for name, props in cases.items():
+        for default in (None, 0.75):
+            rec = {"properties": props, "default_mpp": default}
+            try:
+                rec["mpp"] = float(glb["get_slide_mpp_"](types.SimpleNamespace(properties=props), default_mpp=default))
+            except Exception as e:  # noqa: BLE001
+                rec["error"] = type(e).__name__
+            out[f"{name}|{default}"] = rec
+    OUT.mkdir(parents=True, exist_ok=True)
+    (OUT / "slide_mpp.json").write_text(json.dumps(out))
+    print("wrote slide_mpp.json", {k: v.get("mpp", v.get("error")) for k, v in out.items()})
+
+
 def main() -> None:
     install_shims()
     golden_chief()
@@ -999,6 +1037,7 @@ def main() -> None:
     golden_texture_gray()
     golden_tiling()
     golden_tile_cache()
+    golden_slide_mpp()
 
 
 if __name__ == "__main__":
