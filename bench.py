@@ -583,15 +583,22 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
                 "gflop_per_bag_fwd": 11.83, "finite": bool(torch.isfinite(lg).all())})
     tg = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
     cw = torch.tensor([0.5, 0.5])
+    # The trainer follows torch's float32_matmul_precision like the TransMIL products do; the reference sets "high" before training (src/stamp/modeling/train.py:519):
+    # fp16 operands (TF32's 10 explicit mantissa bits) + a static loss scale -- the value of every leg; "medium" = bf16 operands (the only mode before round 6) beside it.
     for key, alibi, drop in (("train", False, None), ("train_no_dropout", False, False), ("train_alibi", True, None)):
         model = mil if not alibi else HipMil(dropout=0.25, use_alibi=True, **kw).eval()
         crd = (torch.rand(64, 1024, 2, generator=torch.Generator().manual_seed(2)) * 4e4).to(ctx.device) if alibi else None
-        trn = HipMilVitTrainer(model, device=ctx.device, total_steps=100, sched_interval="step", dropout=drop)
-        dt, (ltr, _) = timeit(lambda: trn.step(bags, tg, cw, coords=crd), 16, warm=3)       # 16 steps (0.12 s): four were dominated by the first step's clock ramp
-        sec[key] = {"metric": f"MIL bags/s (vit head{' with ALiBi' if alibi else ''}, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, bf16 operands, "
-                              + ("all dropout sites off)" if drop is False else "train-mode dropout as the reference: 0.25 / 0.25 / 0.5 / 0.5)"),
-                    "value": round(64 / dt, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(ltr))}
-        del trn
+        vals = {}
+        for prec in ("high", "medium"):
+            trn = HipMilVitTrainer(model, device=ctx.device, total_steps=100, sched_interval="step", dropout=drop, precision=prec)
+            dt, (ltr, _) = timeit(lambda: trn.step(bags, tg, cw, coords=crd), 16, warm=3)       # 16 steps (0.12 s): four were dominated by the first step's clock ramp
+            vals[prec] = (round(64 / dt, 1), bool(torch.isfinite(ltr)))
+            del trn
+        sec[key] = {"metric": f"MIL bags/s (vit head{' with ALiBi' if alibi else ''}, fwd + bwd + AdamW, bags of 1024 x 1024-d, batch 64, float32_matmul_precision 'high' as the "
+                              "reference's train_model_ sets it: fp16 operands (10 explicit mantissa bits, the TF32 class), loss scale 2^10, fp32 accumulation / residual stream / "
+                              "gradients; " + ("all dropout sites off)" if drop is False else "train-mode dropout as the reference: 0.25 / 0.25 / 0.5 / 0.5)"),
+                    "value": vals["high"][0], "unit": "bags/s", "loss_finite": vals["high"][1], "medium_bf16_operands": vals["medium"][0],
+                    "medium_loss_finite": vals["medium"][1]}
     # BASELINE.json configs[4], the buildable part: Cox-survival head at bag scale -- `vit` head with dim_output = 1 on bags of 1024 x 768-d
     # (CONCH1.5 / TITAN feature width), Efron partial likelihood as LitTileSurvival.training_step (models/__init__.py:751-776), targets as
     # tests/random_data.py:173-175; fwd + bwd + AdamW, train-mode dropout
@@ -600,10 +607,10 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     sbags = torch.randn(64, 1024, 768, generator=gs).half().to(ctx.device)
     stg = torch.stack([torch.rand(64, generator=gs) * 1970 + 30, (torch.rand(64, generator=gs) < 0.7).float()], 1)
     sv = HipMil(dropout=0.25, use_alibi=False, dim_output=1, dim_input=768, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512).eval()
-    trn = HipMilVitTrainer(sv, device=ctx.device, total_steps=100, sched_interval="step")
+    trn = HipMilVitTrainer(sv, device=ctx.device, total_steps=100, sched_interval="step", precision="high")
     dt, (lsv, _) = timeit(lambda: trn.step(sbags, stg, loss_fn=L.cox_survival_loss), 4)
     sec["survival"] = {"metric": "MIL bags/s (Cox-survival `vit` head, dim_output 1, Efron partial likelihood, fwd + bwd + AdamW, bags of 1024 x 768-d, batch 64, "
-                                 "bf16 operands, train-mode dropout)", "value": round(64 / dt, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(lsv))}
+                                 "float32_matmul_precision 'high': fp16 operands, loss scale 2^10; train-mode dropout)", "value": round(64 / dt, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(lsv))}
     del trn, sbags
     tm = HipTransMIL(dim_output=2, dim_input=1024, dim_hidden=512).eval().to(ctx.device)
     bags_f = bags.float()
@@ -653,7 +660,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     c1 = HipMil(dim_output=2, dim_input=2048, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512, dropout=0.25, use_alibi=False)
     cb = torch.rand(64, 256, 2048, device=ctx.device).half()
     ct = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
-    tr1 = HipMilVitTrainer(c1, device=ctx.device, total_steps=2, sched_interval="step")
+    tr1 = HipMilVitTrainer(c1, device=ctx.device, total_steps=2, sched_interval="step", precision="high")
     hist = mil_fit(tr1, lambda: [(cb[:51], None, None, ct[:51])], lambda: [(cb[i:i + 1], None, None, ct[i:i + 1]) for i in range(51, 64)], max_epochs=2, patience=16)
     torch.cuda.synchronize()
     sec["config1_two_epochs"] = {"metric": "wall seconds, BASELINE.json configs[0]: 64 bags x 256 tiles x 2048-d, `vit` head, 2 epochs (train step over 51 bags + 13 validation forwards each)",

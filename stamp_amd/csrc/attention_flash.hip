@@ -600,6 +600,21 @@ extern "C" int amds_attention_alibi_fwd_train(const void* qkv, const float* coor
     return AMDS_OK;
 }
 
+// the same with out / U / Osm in the operand type itself (dtype = AMDS_F16: the training step at float32_matmul_precision "high"; AMDS_BF16 = the entry above)
+int amds::attention_alibi_fwd_train_dt(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale, void* out, void* u, void* osm,
+                                       float* lse, int B, int T, int H, int dtype, void* stream) {
+    if (dtype != AMDS_F16) return amds_attention_alibi_fwd_train(qkv, coords, inv_running_mean, bias_scale, out, u, osm, lse, B, T, H, dtype, stream);
+    AMDS_REQUIRE(qkv && coords && inv_running_mean && bias_scale && out && u && osm && lse, "amds_attention_alibi_fwd_train: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_fwd_train: bad shape B=%d T=%d H=%d", B, T, H);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, H, B), block(256);
+    ProfScope prof(PROF_ATTN, 6.0 * B * H * (double)T * T * 64, st);
+    hipLaunchKernelGGL((attn_flash_kernel<f16, true, f16>), grid, block, 0, st, (const f16*)qkv, (f16*)out, T, H, coords, inv_running_mean, lse, bias_scale, (f16*)u, (f16*)osm);
+    AMDS_LAUNCH_CHECK("attn_flash_kernel<alibi,train,f16>");
+    return AMDS_OK;
+}
+
 // `mask != None` forward of the reference (vision_tranformer.py:355-381; pinned by the reference's tests/test_model.py:28-32): pad u8 [B][T]
 // with the class token included at t = 0 (never padded).  See the kernel comment for the literal blocking rule.
 extern "C" int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int mask_heads, int dtype, void* stream) {

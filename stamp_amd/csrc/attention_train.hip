@@ -473,6 +473,17 @@ extern "C" int amds_attention_alibi_bwd(const void* qkv, const void* osm, const 
     return launch_attn_bwd<bf16>(qkv, osm, dout, lse, dq_sum_ws, dqkv, B, T, H, st, u, coords, bias_scale, dist_scale, dbs_part);
 }
 
+// the same on fp16 tensors (dtype = AMDS_F16; AMDS_BF16 = the entry above)
+int amds::attention_alibi_bwd_dt(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords, const float* bias_scale,
+                                 const float* dist_scale, float* dq_sum_ws, float* dbs_part, void* dqkv, int B, int T, int H, int dtype, void* stream) {
+    if (dtype != AMDS_F16) return amds_attention_alibi_bwd(qkv, osm, u, dout, lse, coords, bias_scale, dist_scale, dq_sum_ws, dbs_part, dqkv, B, T, H, stream);
+    AMDS_REQUIRE(qkv && osm && u && dout && lse && coords && bias_scale && dist_scale && dq_sum_ws && dbs_part && dqkv, "amds_attention_alibi_bwd: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_bwd: bad shape B=%d T=%d H=%d", B, T, H);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_ATTN, 10.0 * B * H * (double)T * T * 64, st);
+    return launch_attn_bwd<f16>(qkv, osm, dout, lse, dq_sum_ws, dqkv, B, T, H, st, u, coords, bias_scale, dist_scale, dbs_part);
+}
+
 extern "C" int amds_cdist_rowsum(const float* coords, float* rowsum, int B, int T, void* stream) {
     AMDS_REQUIRE(coords && rowsum, "amds_cdist_rowsum: null pointer");
     AMDS_REQUIRE(B > 0 && T > 0, "amds_cdist_rowsum: bad shape");

@@ -341,6 +341,22 @@ struct ProfScope {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// dtype-taking forms of C entries whose ABI fixes bf16 (the MIL `vit` training step at float32_matmul_precision "high" runs them on fp16 tensors)
+int gelu_dropout_fwd_rows_dt(const void* z, long ldz, void* u, long ldu, long rows, int cols, long row_mul, int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
+int gelu_dropout_bwd_rows_dt(const void* z, long ldz, const void* du, long ldu, void* dz, long lddz, long rows, int cols, long row_mul, int dtype, float p, uint64_t seed,
+                             uint32_t stream_id, void* stream);
+int dropout_cast_bwd_rows_dt(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
+int layernorm_bwd_partials_dt(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd, const float* gamma, float* dx,
+                              long dx_stride, int add_skip, float* dgamma_part, float* dbeta_part, int rows, int cols, void* dx16, long dx16_stride, int dx16_dtype, float p,
+                              uint64_t seed, uint32_t stream_id, void* stream);
+int attention_alibi_fwd_train_dt(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale, void* out, void* u, void* osm, float* lse,
+                                 int B, int T, int H, int dtype, void* stream);
+int attention_alibi_bwd_dt(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords, const float* bias_scale,
+                           const float* dist_scale, float* dq_sum_ws, float* dbs_part, void* dqkv, int B, int T, int H, int dtype, void* stream);
+int layernorm_bwd_cast_dt(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd, const float* gamma, float* dx, long dx_stride,
+                          int add_skip, float* dgamma, float* dbeta, int accumulate_params, int rows, int cols, void* ws, size_t ws_bytes, void* dx16, long dx16_stride,
+                          int dx16_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
+
 // amds_bgemm_f32 on the exact-fp32 MFMA whatever amds_set_matmul_precision says (transmil.hip): for the paths that promise exact fp32
 int bgemm_f32_exact(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb, float* Cm, int ldc, long sCo, long sCi,
                     int outer, int inner, int M, int N, int K, float alpha, float diag, const float* bias, int accumulate, void* stream);

@@ -224,28 +224,45 @@ using namespace amds;
 #define DROP_ARGS_OK(p) ((p) >= 0.f && (p) < 1.f)
 
 
-// p = 0: plain GELU / its derivative / a plain add / a plain cast (threshold 0 keeps everything at scale 1).  bf16 tensors (the MIL training step's operand type).
-extern "C" int amds_gelu_dropout_fwd_rows(const void* z, long ldz, void* u, long ldu, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id,
-                                          void* stream) {
-    AMDS_REQUIRE(z && u && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_gelu_dropout_fwd_rows: bad arguments");
+// p = 0: plain GELU / its derivative / a plain add / a plain cast (threshold 0 keeps everything at scale 1).  The C entries take bf16 tensors (the MIL training
+// step's operand type at float32_matmul_precision "medium"); the *_dt forms (csrc-internal, common.h) also take fp16 (the step's operand type at "high").
+int amds::gelu_dropout_fwd_rows_dt(const void* z, long ldz, void* u, long ldu, long rows, int cols, long row_mul, int dtype, float p, uint64_t seed, uint32_t stream_id,
+                                   void* stream) {
+    AMDS_REQUIRE(z && u && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f && (dtype == AMDS_BF16 || dtype == AMDS_F16), "amds_gelu_dropout_fwd_rows: bad arguments");
     if (rows == 0) return AMDS_OK;
     const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
     const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
-    hipLaunchKernelGGL((gelu_dropout_fwd_rows_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, ldz, (bf16*)u, ldu, rows, cols, row_mul, seed,
-                       stream_id, thr, thr ? drop_scale(thr) : 1.0f);
+    if (dtype == AMDS_BF16)
+        hipLaunchKernelGGL((gelu_dropout_fwd_rows_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, ldz, (bf16*)u, ldu, rows, cols, row_mul, seed,
+                           stream_id, thr, thr ? drop_scale(thr) : 1.0f);
+    else
+        hipLaunchKernelGGL((gelu_dropout_fwd_rows_kernel<f16, f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)z, ldz, (f16*)u, ldu, rows, cols, row_mul, seed,
+                           stream_id, thr, thr ? drop_scale(thr) : 1.0f);
     AMDS_LAUNCH_CHECK("gelu_dropout_fwd_rows_kernel");
+    return AMDS_OK;
+}
+extern "C" int amds_gelu_dropout_fwd_rows(const void* z, long ldz, void* u, long ldu, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id,
+                                          void* stream) {
+    return gelu_dropout_fwd_rows_dt(z, ldz, u, ldu, rows, cols, row_mul, AMDS_BF16, p, seed, stream_id, stream);
+}
+int amds::gelu_dropout_bwd_rows_dt(const void* z, long ldz, const void* du, long ldu, void* dz, long lddz, long rows, int cols, long row_mul, int dtype, float p,
+                                   uint64_t seed, uint32_t stream_id, void* stream) {
+    AMDS_REQUIRE(z && du && dz && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f && (dtype == AMDS_BF16 || dtype == AMDS_F16), "amds_gelu_dropout_bwd_rows: bad arguments");
+    if (rows == 0) return AMDS_OK;
+    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
+    const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
+    if (dtype == AMDS_BF16)
+        hipLaunchKernelGGL((gelu_dropout_bwd_rows_kernel<bf16, bf16, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, ldz, (const bf16*)du, ldu, (bf16*)dz,
+                           lddz, rows, cols, row_mul, seed, stream_id, thr, thr ? drop_scale(thr) : 1.0f);
+    else
+        hipLaunchKernelGGL((gelu_dropout_bwd_rows_kernel<f16, f16, f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)z, ldz, (const f16*)du, ldu, (f16*)dz,
+                           lddz, rows, cols, row_mul, seed, stream_id, thr, thr ? drop_scale(thr) : 1.0f);
+    AMDS_LAUNCH_CHECK("gelu_dropout_bwd_rows_kernel");
     return AMDS_OK;
 }
 extern "C" int amds_gelu_dropout_bwd_rows(const void* z, long ldz, const void* du, long ldu, void* dz, long lddz, long rows, int cols, long row_mul, float p,
                                           uint64_t seed, uint32_t stream_id, void* stream) {
-    AMDS_REQUIRE(z && du && dz && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_gelu_dropout_bwd_rows: bad arguments");
-    if (rows == 0) return AMDS_OK;
-    const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
-    const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
-    hipLaunchKernelGGL((gelu_dropout_bwd_rows_kernel<bf16, bf16, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, ldz, (const bf16*)du, ldu, (bf16*)dz,
-                       lddz, rows, cols, row_mul, seed, stream_id, thr, thr ? drop_scale(thr) : 1.0f);
-    AMDS_LAUNCH_CHECK("gelu_dropout_bwd_rows_kernel");
-    return AMDS_OK;
+    return gelu_dropout_bwd_rows_dt(z, ldz, du, ldu, dz, lddz, rows, cols, row_mul, AMDS_BF16, p, seed, stream_id, stream);
 }
 extern "C" int amds_dropout_add_rows(const float* y, long ldy, const float* x_in, long ldx, float* x_out, long ldo, long rows, int cols, long row_mul, float p,
                                      uint64_t seed, uint32_t stream_id, void* stream) {
@@ -258,16 +275,24 @@ extern "C" int amds_dropout_add_rows(const float* y, long ldy, const float* x_in
     AMDS_LAUNCH_CHECK("dropout_add_rows_kernel");
     return AMDS_OK;
 }
-extern "C" int amds_dropout_cast_bwd_rows(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id,
-                                          void* stream) {
-    AMDS_REQUIRE(dx && dy && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f, "amds_dropout_cast_bwd_rows: bad arguments");
+int amds::dropout_cast_bwd_rows_dt(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, int dtype, float p, uint64_t seed, uint32_t stream_id,
+                                   void* stream) {
+    AMDS_REQUIRE(dx && dy && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f && (dtype == AMDS_BF16 || dtype == AMDS_F16), "amds_dropout_cast_bwd_rows: bad arguments");
     if (rows == 0) return AMDS_OK;
     const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
     const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
-    hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (bf16*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,
-                       thr ? drop_scale(thr) : 1.0f);
+    if (dtype == AMDS_BF16)
+        hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (bf16*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,
+                           thr ? drop_scale(thr) : 1.0f);
+    else
+        hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (f16*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,
+                           thr ? drop_scale(thr) : 1.0f);
     AMDS_LAUNCH_CHECK("dropout_cast_bwd_rows_kernel");
     return AMDS_OK;
+}
+extern "C" int amds_dropout_cast_bwd_rows(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, float p, uint64_t seed, uint32_t stream_id,
+                                          void* stream) {
+    return dropout_cast_bwd_rows_dt(dx, ldx, dy, ldy, rows, cols, row_mul, AMDS_BF16, p, seed, stream_id, stream);
 }
 extern "C" float amds_dropout_keep_scale(float p) { return drop_scale(drop_thr16(p)); }
 
@@ -282,6 +307,10 @@ extern "C" int amds_gelu_dropout_fwd(const void* z, void* u, long n, int in_dtyp
     else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32 && v8) hipLaunchKernelGGL((gelu_dropout_fwd8_kernel<bf16, float>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const bf16*)z, (float*)u, n / 8, seed, stream_id, thr, sc);
     else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n, seed, stream_id, thr, sc);
     else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<bf16, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (float*)u, n, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F16 && v8) hipLaunchKernelGGL((gelu_dropout_fwd8_kernel<f16, f16>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const f16*)z, (f16*)u, n / 8, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F32 && v8) hipLaunchKernelGGL((gelu_dropout_fwd8_kernel<f16, float>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const f16*)z, (float*)u, n / 8, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F16) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<f16, f16>), dim3(grid1d_(n)), dim3(256), 0, st, (const f16*)z, (f16*)u, n, seed, stream_id, thr, sc);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<f16, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const f16*)z, (float*)u, n, seed, stream_id, thr, sc);
     else if (in_dtype == AMDS_F32 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_dropout_fwd_kernel<float, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const float*)z, (float*)u, n, seed, stream_id, thr, sc);
     else { set_error("amds_gelu_dropout_fwd: unsupported dtype pair"); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("gelu_dropout_fwd_kernel");
@@ -304,6 +333,14 @@ extern "C" int amds_gelu_dropout_bwd(const void* z, const void* du, void* dz, lo
         hipLaunchKernelGGL((gelu_dropout_bwd_kernel<bf16, bf16, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n, seed, stream_id, thr, sc);
     else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_BF16)
         hipLaunchKernelGGL((gelu_dropout_bwd_kernel<bf16, float, bf16>), dim3(grid1d_(n)), dim3(256), 0, st, (const bf16*)z, (const float*)du, (bf16*)dz, n, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_F16 && du_dtype == AMDS_F16 && dz_dtype == AMDS_F16 && v8)
+        hipLaunchKernelGGL((gelu_dropout_bwd8_kernel<f16, f16, f16>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const f16*)z, (const f16*)du, (f16*)dz, n / 8, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_F16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F16 && v8)
+        hipLaunchKernelGGL((gelu_dropout_bwd8_kernel<f16, float, f16>), dim3(grid1d_(n / 8)), dim3(256), 0, st, (const f16*)z, (const float*)du, (f16*)dz, n / 8, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_F16 && du_dtype == AMDS_F16 && dz_dtype == AMDS_F16)
+        hipLaunchKernelGGL((gelu_dropout_bwd_kernel<f16, f16, f16>), dim3(grid1d_(n)), dim3(256), 0, st, (const f16*)z, (const f16*)du, (f16*)dz, n, seed, stream_id, thr, sc);
+    else if (z_dtype == AMDS_F16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F16)
+        hipLaunchKernelGGL((gelu_dropout_bwd_kernel<f16, float, f16>), dim3(grid1d_(n)), dim3(256), 0, st, (const f16*)z, (const float*)du, (f16*)dz, n, seed, stream_id, thr, sc);
     else if (z_dtype == AMDS_F32 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F32)
         hipLaunchKernelGGL((gelu_dropout_bwd_kernel<float, float, float>), dim3(grid1d_(n)), dim3(256), 0, st, (const float*)z, (const float*)du, (float*)dz, n, seed, stream_id, thr, sc);
     else { set_error("amds_gelu_dropout_bwd: unsupported dtype combination"); return AMDS_ERR_INVALID; }
@@ -335,6 +372,8 @@ extern "C" int amds_dropout_cast_bwd(const float* dx, long ldx, void* dy, long l
     if (out_dtype == AMDS_BF16 && cols % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0 && al16(dx) && al16(dy))
         hipLaunchKernelGGL((dropout_cast_bwd8_kernel<bf16>), dim3(grid1d_(rows * cols / 8)), dim3(256), 0, st, dx, ldx, (bf16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else if (out_dtype == AMDS_BF16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<bf16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (bf16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
+    else if (out_dtype == AMDS_F16 && cols % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0 && al16(dx) && al16(dy))
+        hipLaunchKernelGGL((dropout_cast_bwd8_kernel<f16>), dim3(grid1d_(rows * cols / 8)), dim3(256), 0, st, dx, ldx, (f16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else if (out_dtype == AMDS_F16) hipLaunchKernelGGL((dropout_cast_bwd_kernel<f16>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (f16*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else if (out_dtype == AMDS_F32) hipLaunchKernelGGL((dropout_cast_bwd_kernel<float>), dim3(grid1d_(rows * cols)), dim3(256), 0, st, dx, ldx, (float*)dy, ldy, rows, cols, seed, stream_id, thr, drop_scale(thr));
     else { set_error("amds_dropout_cast_bwd: bad dtype"); return AMDS_ERR_INVALID; }

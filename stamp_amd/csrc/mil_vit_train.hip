@@ -3,7 +3,9 @@
 // Forward = the train-mode forward of the reference's VisionTransformer (src/stamp/modeling/models/vision_tranformer.py:332-384 with the
 // Dropout sites of :157-169, :191, :314-318 live); backward = what autograd derives from it (the reference calls loss.backward() through
 // Lightning, src/stamp/modeling/models/__init__.py:239-279).  Both are launch sequences over the kernels the library exposes one by one
-// (include/amdstamp.h, "MIL training step"): bf16 MFMA operands, fp32 accumulation / residual stream / gradients.  The activations the
+// (include/amdstamp.h, "MIL training step"): 16-bit MFMA operands -- bf16 (8 mantissa bits: torch's float32_matmul_precision "medium") or fp16 (11: the TF32 class torch's
+// "high" asks for, which the reference sets before training, train.py:519; the caller scales the loss, see stamp_amd/mil_train.py) by cfg.dtype -- fp32 accumulation /
+// residual stream / gradients.  The activations the
 // backward needs live in ONE caller-owned arena (`saved`), gradients are written in the PADDED weight layout into caller-owned fp32
 // buffers (amds_mil_vit_grads); the ALiBi running-mean update (:24-29) happens before the forward and stays with the caller.
 // Nothing is allocated and the host never waits for the device.
@@ -26,6 +28,7 @@ struct Dims {
     int F, D, H, FF, C, L, alibi;
     int Fp, Dp, FFp, Ha, Da, S, Bb, Tn;
     long M, Mt;
+    int dt;          // AMDS_BF16 or AMDS_F16: the type of every 16-bit tensor of the step (weights' operand copies, saved activations, 16-bit gradients)
 };
 
 struct SavedPlan {
@@ -40,7 +43,8 @@ int make_dims(const amds_mil_vit_cfg* c, int Bb, int Tn, Dims* d) {
     AMDS_REQUIRE(c->dim % c->heads == 0, "amds_mil_vit_train: dim_model=%d has to be divisible by n_heads=%d", c->dim, c->heads);
     AMDS_REQUIRE(c->dim / c->heads <= 64 && c->dim % 4 == 0, "amds_mil_vit_train: needs head_dim <= 64 and dim_model %% 4 == 0 (dim_model=%d, n_heads=%d)",
                  c->dim, c->heads);
-    AMDS_REQUIRE(c->dtype == AMDS_BF16, "amds_mil_vit_train: the training step runs on bf16 operands (cfg.dtype = AMDS_BF16)");
+    AMDS_REQUIRE(c->dtype == AMDS_BF16 || c->dtype == AMDS_F16, "amds_mil_vit_train: the training step runs on bf16 or fp16 operands (cfg.dtype = AMDS_BF16 / AMDS_F16)");
+    d->dt = c->dtype;
     AMDS_REQUIRE(Bb > 0 && Tn > 0, "amds_mil_vit_train: bad shape bags=%d tiles=%d", Bb, Tn);
     d->F = c->n_feats; d->D = c->dim; d->H = c->heads; d->FF = c->ff; d->C = c->classes; d->L = c->layers; d->alibi = c->alibi != 0;
     d->Fp = up(d->F, 256); d->Dp = up(d->D, 256); d->FFp = up(d->FF, 256); d->Ha = up(d->H, 4); d->Da = 64 * d->Ha;
@@ -134,14 +138,14 @@ void plan_ws(const Dims& d, int split_k, WsPlan* p) {
     p->total = off;
 }
 
-template <typename TI>
-__global__ void __launch_bounds__(256) stage_bags_bf16_kernel(const TI* __restrict__ src, long ld_src, bf16* __restrict__ dst, int Fp, long total, int F) {
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) stage_bags_bf16_kernel(const TI* __restrict__ src, long ld_src, TO* __restrict__ dst, int Fp, long total, int F) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
         const long r = i / Fp;
         const int c = (int)(i - r * Fp);
-        dst[i] = c < F ? (bf16)(float)src[r * ld_src + c] : (bf16)0.f;
+        dst[i] = c < F ? (TO)(float)src[r * ld_src + c] : (TO)0.f;
     }
 }
 
@@ -207,15 +211,14 @@ int gelu_drop_bwd(const void* z, const void* du, void* dz, long n, int zdt, int 
     } while (0)
 
 constexpr int CFG_TRAIN = -2;      // amds_gemm_ex: by shape, ragged last row tile as its own small launch (M = bags x 1025 is never a multiple of 256)
-constexpr int BF = AMDS_BF16;
 
 // the last block on its class rows alone (amds_set_mil_cls_tail; not with ALiBi: its attention has no one-query form; pitched rows must fit the 32-bit descriptors)
 bool cls_tail(const Dims& d) {
     return amds_get_mil_cls_tail() && !d.alibi && d.L > 0 && d.S <= 32768 && (long)(d.Bb + 1) * d.S * std::max(d.FFp, 3 * d.Da) * 4 < (1L << 31);
 }
 
-int gemm(const void* A, long lda, const void* W, long ldw, long M, int N, int K, int epi, void* out, long ldo, const float* bias, void* st) {
-    return amds_gemm_ex(CFG_TRAIN, A, lda, W, ldw, (int)M, N, K, BF, epi, out, ldo, bias, nullptr, nullptr, 0, 0, 0, 1.0f, st);
+int gemm_dt(int dt, const void* A, long lda, const void* W, long ldw, long M, int N, int K, int epi, void* out, long ldo, const float* bias, void* st) {
+    return amds_gemm_ex(CFG_TRAIN, A, lda, W, ldw, (int)M, N, K, dt, epi, out, ldo, bias, nullptr, nullptr, 0, 0, 0, 1.0f, st);
 }
 
 }  // namespace
@@ -260,6 +263,10 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
     AMDS_REQUIRE(((uintptr_t)saved & 255) == 0, "amds_mil_vit_train_forward: arena must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* sv = reinterpret_cast<char*>(saved);
+    const int BF = d.dt;                                       // (the name dates from the bf16-only step)
+    auto gemm = [&](const void* A, long lda, const void* W, long ldw, long Mr, int N, int K, int epi, void* out, long ldo, const float* bias, void* s2) -> int {
+        return gemm_dt(BF, A, lda, W, ldw, Mr, N, K, epi, out, ldo, bias, s2);
+    };
     const float p_proj = drop_host->p_proj, p_ff = drop_host->p_ff, p_att = d.alibi ? 0.f : drop_host->p_att;
     const uint64_t seed = drop_host->seed;
     const long M = d.M, Mt = d.Mt;
@@ -267,14 +274,22 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
 
     // ---- project_features: Linear -> GELU -> Dropout (:314-318, :342), bags staged as bf16 operand rows ---------------------------------
     void* a = sv + sp.a;
-    if (bags_dtype == AMDS_F16 && Fp == d.F) RC(amds_convert_f16_bf16(bags, a, Mt * Fp, stream));
-    else if (bags_dtype == AMDS_BF16 && Fp == d.F) AMDS_HIP(hipMemcpyAsync(a, bags, (size_t)Mt * Fp * 2, hipMemcpyDeviceToDevice, st));
+    if (bags_dtype == AMDS_F16 && BF == AMDS_BF16 && Fp == d.F) RC(amds_convert_f16_bf16(bags, a, Mt * Fp, stream));
+    else if (bags_dtype == BF && Fp == d.F) AMDS_HIP(hipMemcpyAsync(a, bags, (size_t)Mt * Fp * 2, hipMemcpyDeviceToDevice, st));       // already the operand type
     else {
         const long total = Mt * Fp;
         const int grid = (int)std::min<long>(8192, (total + 255) / 256);
-        if (bags_dtype == AMDS_F32) hipLaunchKernelGGL((stage_bags_bf16_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)bags, (long)d.F, (bf16*)a, Fp, total, d.F);
-        else if (bags_dtype == AMDS_F16) hipLaunchKernelGGL((stage_bags_bf16_kernel<f16>), dim3(grid), dim3(256), 0, st, (const f16*)bags, (long)d.F, (bf16*)a, Fp, total, d.F);
-        else hipLaunchKernelGGL((stage_bags_bf16_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)bags, (long)d.F, (bf16*)a, Fp, total, d.F);
+#define AMDS_STAGE(TI, TO) hipLaunchKernelGGL((stage_bags_bf16_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)bags, (long)d.F, (TO*)a, Fp, total, d.F)
+        if (BF == AMDS_BF16) {
+            if (bags_dtype == AMDS_F32) AMDS_STAGE(float, bf16);
+            else if (bags_dtype == AMDS_F16) AMDS_STAGE(f16, bf16);
+            else AMDS_STAGE(bf16, bf16);
+        } else {
+            if (bags_dtype == AMDS_F32) AMDS_STAGE(float, f16);
+            else if (bags_dtype == AMDS_F16) AMDS_STAGE(f16, f16);
+            else AMDS_STAGE(bf16, f16);
+        }
+#undef AMDS_STAGE
         AMDS_LAUNCH_CHECK("stage_bags_bf16_kernel");
     }
     void* zp = sv + sp.zp;
@@ -318,7 +333,7 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
             RC(amds_layernorm_train_copy(x_mid, pS * Dp, Lw.ln2_w, Lw.ln2_b, h2, pS * Dp, reinterpret_cast<float*>(sv + o.mu2), reinterpret_cast<float*>(sv + o.rs2), Bb, D,
                                          1e-5f, BF, p_ff > 0.f ? nullptr : x_out, pS * Dp, Dp, stream));
             RC(gemm(h2, pS * Dp, Lw.fc1_w, Dp, Bb, FFp, Dp, AMDS_EPI_BIAS, z, pS * FFp, Lw.fc1_b, stream));
-            RC(amds_gelu_dropout_fwd_rows(z, pS * FFp, u, pS * FFp, Bb, FFp, pS, p_ff, seed, 10 * l + 2, stream));
+            RC(gelu_dropout_fwd_rows_dt(z, pS * FFp, u, pS * FFp, Bb, FFp, pS, BF, p_ff, seed, 10 * l + 2, stream));
             if (p_ff > 0.f) {
                 float* y = reinterpret_cast<float*>(sv + sp.y);
                 RC(gemm(u, pS * FFp, Lw.fc2_w, FFp, Bb, Dp, FFp, AMDS_EPI_BIAS_F32, y, Dp, Lw.fc2_b, stream));
@@ -330,7 +345,7 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
         }
         RC(gemm(h1, Dp, Lw.in_w, Dp, M, 3 * Da, Dp, AMDS_EPI_BIAS, qkv, 3 * Da, Lw.in_b, stream));
         if (d.alibi)
-            RC(amds_attention_alibi_fwd_train(qkv, cc, Lw.inv_running_mean, Lw.bias_scale, att, sv + o.u_al, sv + o.osm, lse, Bb, S, Ha, BF, stream));
+            RC(attention_alibi_fwd_train_dt(qkv, cc, Lw.inv_running_mean, Lw.bias_scale, att, sv + o.u_al, sv + o.osm, lse, Bb, S, Ha, BF, stream));
         else
             RC(amds_attention_fwd_train(qkv, att, lse, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         RC(gemm(att, Da, Lw.out_w, Da, M, Dp, Da, AMDS_EPI_RESIDUAL, x_mid, Dp, Lw.out_b, stream));
@@ -381,6 +396,10 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
     hipStream_t st = (hipStream_t)stream;
     const char* sv = reinterpret_cast<const char*>(saved);
     char* wk = reinterpret_cast<char*>(ws);
+    const int BF = d.dt;
+    auto gemm = [&](const void* A, long lda, const void* W, long ldw, long Mr, int N, int K, int epi, void* out, long ldo, const float* bias, void* s2) -> int {
+        return gemm_dt(BF, A, lda, W, ldw, Mr, N, K, epi, out, ldo, bias, s2);
+    };
     const float p_proj = drop_host->p_proj, p_ff = drop_host->p_ff, p_att = d.alibi ? 0.f : drop_host->p_att;
     const uint64_t seed = drop_host->seed;
     const long M = d.M, Mt = d.Mt, Mp = wp.Mp, Mtp = wp.Mtp;
@@ -442,20 +461,20 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         const long nblk = (rows + 63) / 64;
         if (!need_params) {
             float* sc = reinterpret_cast<float*>(lnb);           // (sized for the two partial planes + a reduction workspace)
-            return amds_layernorm_bwd_partials(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, sc, sc + (size_t)nblk * D, (int)rows, D, dx16, ld16, p, seed, sid, stream);
+            return layernorm_bwd_partials_dt(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, sc, sc + (size_t)nblk * D, (int)rows, D, dx16, ld16, BF, p, seed, sid, stream);
         }
         if (defer_sums && nblk <= 2048) {
             float* pr;
             RC(take_sums((size_t)2 * al((size_t)nblk * D * 4), 2, &pr));
             if (pr) {
                 float* pb = reinterpret_cast<float*>(reinterpret_cast<char*>(pr) + al((size_t)nblk * D * 4));
-                RC(amds_layernorm_bwd_partials(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, pr, pb, (int)rows, D, dx16, ld16, p, seed, sid, stream));
+                RC(layernorm_bwd_partials_dt(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, pr, pb, (int)rows, D, dx16, ld16, BF, p, seed, sid, stream));
                 sum_e[n_sum++] = amds_colsum_entry{pr, dgamma, (long)D, (int)nblk, D, 0};
                 sum_e[n_sum++] = amds_colsum_entry{pb, dbeta, (long)D, (int)nblk, D, 0};
                 return AMDS_OK;
             }
         }
-        return amds_layernorm_bwd_cast(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, dgamma, dbeta, 0, (int)rows, D, lnb, wp.lnb_bytes, dx16, ld16, p, seed, sid, stream);
+        return layernorm_bwd_cast_dt(dy, dys, x, xs, mu, rs, gamma, dxo, dxs, add_skip, dgamma, dbeta, 0, (int)rows, D, lnb, wp.lnb_bytes, dx16, ld16, BF, p, seed, sid, stream);
     };
     // [rows][cols] bf16 -> [cols][pitch]; the columns rows..pitch must read as zeros (the split-K contraction runs over the padded length).  The
     // transposes never write them, so they are zeroed ONCE per pitch for the widest matrix that will use the buffer (`zero_pads`) instead of in
@@ -535,13 +554,13 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             // Class-row tail (see the forward): dx of the last block lives on the class rows; its MLP, second LayerNorm and output projection are differentiated on
             // those Bb rows alone (row pitch S rows, dropout bits of the full tensors' rows b * S).
             const long pS = S;
-            RC(amds_dropout_cast_bwd_rows(dx, pS * Dp, g16, pS * Dp, Bb, Dp, pS, p_ff, seed, (uint32_t)(10 * l + 3), stream));
+            RC(dropout_cast_bwd_rows_dt(dx, pS * Dp, g16, pS * Dp, Bb, Dp, pS, BF, p_ff, seed, (uint32_t)(10 * l + 3), stream));
             RC(gemm(g16, pS * Dp, Lw.fc2_wt, Dp, Bb, FFp, Dp, AMDS_EPI_BIAS, du, pS * FFp, nullptr, stream));
             if (need_params) {
                 RC(wgrad_tn(g16, pS * Dp, u, pS * FFp, Bb, Dp, FFp, Gl->fc2_w));
                 RC(p_ff > 0.f ? colsum(g16, pS * Dp, Gl->fc2_b, Bb, Dp, BF) : colsum(dx, pS * Dp, Gl->fc2_b, Bb, Dp, AMDS_F32));
             }
-            RC(amds_gelu_dropout_bwd_rows(z, pS * FFp, du, pS * FFp, dz, pS * FFp, Bb, FFp, pS, p_ff, seed, (uint32_t)(10 * l + 2), stream));
+            RC(gelu_dropout_bwd_rows_dt(z, pS * FFp, du, pS * FFp, dz, pS * FFp, Bb, FFp, pS, BF, p_ff, seed, (uint32_t)(10 * l + 2), stream));
             RC(gemm(dz, pS * FFp, Lw.fc1_wt, FFp, Bb, Dp, FFp, AMDS_EPI_BIAS_F32, dh, pS * Dp, nullptr, stream));
             if (need_params) {
                 RC(wgrad_tn(dz, pS * FFp, h2, pS * Dp, Bb, FFp, Dp, Gl->fc1_w));
@@ -549,7 +568,7 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             }
             RC(ln_bwd(dh, pS * Dp, x_mid, pS * Dp, reinterpret_cast<const float*>(sv + o.mu2), reinterpret_cast<const float*>(sv + o.rs2), Lw.ln2_w, dx, pS * Dp, 1,
                       need_params ? Gl->ln2_w : scratch_g, need_params ? Gl->ln2_b : scratch_g + D, Bb, fused_cast ? g16 : nullptr, pS * Dp, 0.f, 0));
-            if (!fused_cast) RC(amds_dropout_cast_bwd_rows(dx, pS * Dp, g16, pS * Dp, Bb, Dp, pS, 0.f, 0, 0, stream));            // d(x_mid) as bf16
+            if (!fused_cast) RC(dropout_cast_bwd_rows_dt(dx, pS * Dp, g16, pS * Dp, Bb, Dp, pS, BF, 0.f, 0, 0, stream));            // d(x_mid) as bf16
             RC(gemm(g16, pS * Dp, Lw.out_wt, Dp, Bb, Da, Dp, AMDS_EPI_BIAS, datt, pS * Da, nullptr, stream));
             if (need_params) {
                 RC(wgrad_tn(g16, pS * Dp, att, pS * Da, Bb, Dp, Da, Gl->out_w));
@@ -602,8 +621,8 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         if (d.alibi) {
             float* dbsp = reinterpret_cast<float*>(wk + wp.dbsp);
             AMDS_REQUIRE(Lw.head_scale && Lw.bias_scale, "amds_mil_vit_train_backward: layer %d has no ALiBi scales", l);     // head_scale = dist_scale
-            RC(amds_attention_alibi_bwd(qkv, sv + o.osm, sv + o.u_al, datt, lse, reinterpret_cast<const float*>(sv + sp.cc), Lw.bias_scale, Lw.head_scale, dqs, dbsp,
-                                        dqkv, Bb, S, Ha, stream));
+            RC(attention_alibi_bwd_dt(qkv, sv + o.osm, sv + o.u_al, datt, lse, reinterpret_cast<const float*>(sv + sp.cc), Lw.bias_scale, Lw.head_scale, dqs, dbsp,
+                                      dqkv, Bb, S, Ha, BF, stream));
             if (need_params) {
                 float* dbst = reinterpret_cast<float*>(wk + wp.dbst);
                 const long n = (long)Bb * Ha * S;

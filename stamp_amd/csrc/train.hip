@@ -202,12 +202,12 @@ __global__ void __launch_bounds__(256) ln_train_kernel(const float* __restrict__
 
 // ---- LayerNorm backward: one wave per row; 64 rows per block; per-block partial d(gamma), d(beta) ----------------------------
 //   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dx_io = (add_skip ? dx_io : 0) + dx
-template <int MAXV>
+template <int MAXV, typename T16 = bf16>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, long dys, const float* __restrict__ x, long xs,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx, long dxs, int add_skip,
                                                      float* __restrict__ dgp, float* __restrict__ dbp, int rows, int cols,
-                                                     bf16* __restrict__ o16, long o16s, uint64_t dseed, uint32_t dsid, uint32_t dthr, float dscale) {
+                                                     T16* __restrict__ o16, long o16s, uint64_t dseed, uint32_t dsid, uint32_t dthr, float dscale) {
     extern __shared__ float red[];        // [2][4][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
@@ -252,12 +252,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
                 *p = o;
                 if (o16) {      // the bf16 operand of the GEMMs that consume dx next, with the NEXT dropout site's mask when there is one (amds_dropout_cast_bwd's bits:
                                 // flat element index row * cols + column) -- the rows are in registers anyway, a separate cast pass re-reads them
-                    typedef bf16 bvec4 __attribute__((ext_vector_type(4)));
+                    typedef T16 bvec4 __attribute__((ext_vector_type(4)));
                     bvec4 w;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const bool keep = dthr == 0 || drop_keep_flat(dseed, dsid, (long)row * cols + c * 4 + e, dthr);
-                        w[e] = (bf16)(keep ? (dthr ? o[e] * dscale : o[e]) : 0.f);
+                        w[e] = (T16)(keep ? (dthr ? o[e] * dscale : o[e]) : 0.f);
                     }
                     *reinterpret_cast<bvec4*>(o16 + (long)row * o16s + c * 4) = w;
                 }
@@ -576,16 +576,30 @@ extern "C" int amds_layernorm_bwd(const float* dy, long dy_stride, const float* 
 extern "C" int amds_layernorm_bwd_partials(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd,
                                            const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma_part, float* dbeta_part,
                                            int rows, int cols, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    return layernorm_bwd_partials_dt(dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, dx_stride, add_skip, dgamma_part, dbeta_part, rows, cols, dx_bf16, dx_bf16_stride,
+                                     AMDS_BF16, p, seed, stream_id, stream);
+}
+
+int amds::layernorm_bwd_partials_dt(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                    long dx_stride, int add_skip, float* dgamma_part, float* dbeta_part, int rows, int cols, void* dx_bf16, long dx_bf16_stride,
+                                    int dx16_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream) {
     AMDS_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma_part && dbeta_part, "amds_layernorm_bwd: null pointer");
+    AMDS_REQUIRE(dx16_dtype == AMDS_BF16 || dx16_dtype == AMDS_F16, "amds_layernorm_bwd: the 16-bit copy is bf16 or fp16");
     AMDS_REQUIRE(!dx_bf16 || (dx_bf16_stride >= cols && dx_bf16_stride % 4 == 0 && p >= 0.f && p < 1.f), "amds_layernorm_bwd_cast: bad 16-bit output / rate");
     const uint32_t dthr = (dx_bf16 && p > 0.f) ? drop_thr16(p) : 0;
     const float dscale = dthr ? drop_scale(dthr) : 1.0f;
     AMDS_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "amds_layernorm_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = cdiv(rows, 64);
-#define AMDS_LN_BWD(MV)                                                                                                                     \
-    hipLaunchKernelGGL((ln_bwd_kernel<MV>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, \
-                       dx_stride, add_skip, dgamma_part, dbeta_part, rows, cols, (bf16*)dx_bf16, dx_bf16_stride, seed, stream_id, dthr, dscale)
+#define AMDS_LN_BWD(MV)                                                                                                                                \
+    do {                                                                                                                                               \
+        if (dx16_dtype == AMDS_F16)                                                                                                                    \
+            hipLaunchKernelGGL((ln_bwd_kernel<MV, f16>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, \
+                               dx_stride, add_skip, dgamma_part, dbeta_part, rows, cols, (f16*)dx_bf16, dx_bf16_stride, seed, stream_id, dthr, dscale);  \
+        else                                                                                                                                           \
+            hipLaunchKernelGGL((ln_bwd_kernel<MV, bf16>), dim3(nblk), dim3(256), (size_t)8 * cols * 4, st, dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, \
+                               dx_stride, add_skip, dgamma_part, dbeta_part, rows, cols, (bf16*)dx_bf16, dx_bf16_stride, seed, stream_id, dthr, dscale); \
+    } while (0)
     if (cols <= 512) AMDS_LN_BWD(2);
     else if (cols <= 1024) AMDS_LN_BWD(4);
     else AMDS_LN_BWD(8);
@@ -598,6 +612,13 @@ extern "C" int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const fl
                                        const float* gamma, float* dx, long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params,
                                        int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16, long dx_bf16_stride, float p, uint64_t seed,
                                        uint32_t stream_id, void* stream) {
+    return layernorm_bwd_cast_dt(dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, dx_stride, add_skip, dgamma, dbeta, accumulate_params, rows, cols, ws, ws_bytes, dx_bf16,
+                                 dx_bf16_stride, AMDS_BF16, p, seed, stream_id, stream);
+}
+
+int amds::layernorm_bwd_cast_dt(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                long dx_stride, int add_skip, float* dgamma, float* dbeta, int accumulate_params, int rows, int cols, void* ws, size_t ws_bytes, void* dx_bf16,
+                                long dx_bf16_stride, int dx16_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream) {
     AMDS_REQUIRE(dgamma && dbeta && ws, "amds_layernorm_bwd: null pointer");
     AMDS_REQUIRE(rows > 0 && cols > 0, "amds_layernorm_bwd: bad shape");
     if (ws_bytes < amds_layernorm_bwd_workspace_bytes(rows, cols)) { set_error("amds_layernorm_bwd: workspace too small"); return AMDS_ERR_WORKSPACE; }
@@ -606,8 +627,8 @@ extern "C" int amds_layernorm_bwd_cast(const float* dy, long dy_stride, const fl
     float* dbp = dgp + (size_t)nblk * cols;
     char* cws = (char*)(dbp + (size_t)nblk * cols);
     const size_t cws_bytes = amds_colsum_workspace_bytes(nblk, cols);
-    int rc = amds_layernorm_bwd_partials(dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, dx_stride, add_skip, dgp, dbp, rows, cols, dx_bf16, dx_bf16_stride, p, seed,
-                                         stream_id, stream);
+    int rc = layernorm_bwd_partials_dt(dy, dy_stride, x, x_stride, mean, rstd, gamma, dx, dx_stride, add_skip, dgp, dbp, rows, cols, dx_bf16, dx_bf16_stride, dx16_dtype, p,
+                                       seed, stream_id, stream);
     if (rc != AMDS_OK) return rc;
     rc = amds_colsum(dgp, cols, dgamma, nblk, cols, AMDS_F32, accumulate_params, cws, cws_bytes, stream);
     if (rc != AMDS_OK) return rc;
@@ -618,10 +639,13 @@ extern "C" int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int o
     AMDS_REQUIRE(z && u && n >= 0, "amds_gelu_fwd: bad arguments");
     if (n == 0) return AMDS_OK;
     // 16-bit input, n a multiple of 8: the 8-elements-per-lane kernel of dropout.hip at rate 0 (every element kept, scale exactly 1: same bits)
-    if (in_dtype == AMDS_BF16 && n % 8 == 0 && (((uintptr_t)z | (uintptr_t)u) & 15) == 0) return amds_gelu_dropout_fwd(z, u, n, in_dtype, out_dtype, 0.f, 0, 0, stream);
+    if ((in_dtype == AMDS_BF16 || in_dtype == AMDS_F16) && n % 8 == 0 && (((uintptr_t)z | (uintptr_t)u) & 15) == 0)
+        return amds_gelu_dropout_fwd(z, u, n, in_dtype, out_dtype, 0.f, 0, 0, stream);
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == AMDS_BF16 && out_dtype == AMDS_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (bf16*)u, n);
     else if (in_dtype == AMDS_BF16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_fwd_kernel<bf16, float>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (float*)u, n);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F16) hipLaunchKernelGGL((gelu_fwd_kernel<f16, f16>), dim3(grid1d(n)), dim3(256), 0, st, (const f16*)z, (f16*)u, n);
+    else if (in_dtype == AMDS_F16 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_fwd_kernel<f16, float>), dim3(grid1d(n)), dim3(256), 0, st, (const f16*)z, (float*)u, n);
     else if (in_dtype == AMDS_F32 && out_dtype == AMDS_F32) hipLaunchKernelGGL((gelu_fwd_kernel<float, float>), dim3(grid1d(n)), dim3(256), 0, st, (const float*)z, (float*)u, n);
     else { set_error("amds_gelu_fwd: unsupported dtype pair"); return AMDS_ERR_INVALID; }
     AMDS_LAUNCH_CHECK("gelu_fwd_kernel");
@@ -631,13 +655,18 @@ extern "C" int amds_gelu_fwd(const void* z, void* u, long n, int in_dtype, int o
 extern "C" int amds_gelu_bwd(const void* z, const void* du, void* dz, long n, int z_dtype, int du_dtype, int dz_dtype, void* stream) {
     AMDS_REQUIRE(z && du && dz && n >= 0, "amds_gelu_bwd: bad arguments");
     if (n == 0) return AMDS_OK;
-    if (z_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16 && n % 8 == 0 && (((uintptr_t)z | (uintptr_t)du | (uintptr_t)dz) & 15) == 0)
+    if (((z_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16) || (z_dtype == AMDS_F16 && dz_dtype == AMDS_F16)) && n % 8 == 0 &&
+        (((uintptr_t)z | (uintptr_t)du | (uintptr_t)dz) & 15) == 0)
         return amds_gelu_dropout_bwd(z, du, dz, n, z_dtype, du_dtype, dz_dtype, 0.f, 0, 0, stream);
     hipStream_t st = (hipStream_t)stream;
     if (z_dtype == AMDS_BF16 && du_dtype == AMDS_BF16 && dz_dtype == AMDS_BF16)
         hipLaunchKernelGGL((gelu_bwd_kernel<bf16, bf16, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (const bf16*)du, (bf16*)dz, n);
     else if (z_dtype == AMDS_BF16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_BF16)
         hipLaunchKernelGGL((gelu_bwd_kernel<bf16, float, bf16>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16*)z, (const float*)du, (bf16*)dz, n);
+    else if (z_dtype == AMDS_F16 && du_dtype == AMDS_F16 && dz_dtype == AMDS_F16)
+        hipLaunchKernelGGL((gelu_bwd_kernel<f16, f16, f16>), dim3(grid1d(n)), dim3(256), 0, st, (const f16*)z, (const f16*)du, (f16*)dz, n);
+    else if (z_dtype == AMDS_F16 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F16)
+        hipLaunchKernelGGL((gelu_bwd_kernel<f16, float, f16>), dim3(grid1d(n)), dim3(256), 0, st, (const f16*)z, (const float*)du, (f16*)dz, n);
     else if (z_dtype == AMDS_F32 && du_dtype == AMDS_F32 && dz_dtype == AMDS_F32)
         hipLaunchKernelGGL((gelu_bwd_kernel<float, float, float>), dim3(grid1d(n)), dim3(256), 0, st, (const float*)z, (const float*)du, (float*)dz, n);
     else { set_error("amds_gelu_bwd: unsupported dtype combination"); return AMDS_ERR_INVALID; }

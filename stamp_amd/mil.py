@@ -94,7 +94,11 @@ class _MilVitBackward(torch.autograd.Function):
 
     @staticmethod
     def forward(dlogits, holder, need_params, need_bags, names):
-        G, dbags = mil_core.backward(holder.pk, holder.saved, dlogits, need_params=need_params, need_bags=need_bags)
+        sc = getattr(holder, "loss_scale", 1.0)        # fp16 operands ("high"): the 16-bit gradient tensors carry a static power-of-two scale (mil_train.py)
+        G, dbags = mil_core.backward(holder.pk, holder.saved, dlogits * sc if sc != 1.0 else dlogits, need_params=need_params, need_bags=need_bags)
+        if sc != 1.0:
+            dbags = dbags * (1.0 / sc) if need_bags else dbags
+            G = {k: v * (1.0 / sc) for k, v in G.items()} if need_params else G
         outs = [dbags if need_bags else dlogits.new_zeros(())]
         outs += [G[n].contiguous() for n in names] if need_params else []
         return tuple(outs)
@@ -129,9 +133,11 @@ class _MilVitFunction(torch.autograd.Function):
             t = P[name] if name in P else model.get_buffer(name)
             return t.detach().to(dev, torch.float32)
 
-        pk = PackedVit(model.dims, get, torch.bfloat16, train=True)
+        # operand type by torch's own flag, as HipMilVitTrainer: "medium" -> bf16; "high" (the reference's training setting, train.py:519) / "highest" -> fp16
+        act = torch.bfloat16 if torch.get_float32_matmul_precision() == "medium" else torch.float16
+        pk = PackedVit(model.dims, get, act, train=True)
         logits, saved = mil_core.forward_train(pk, bags.detach(), None if coords is None else coords.detach(), training=training, seed=seed)
-        holder.pk, holder.saved = pk, saved
+        holder.pk, holder.saved, holder.loss_scale = pk, saved, (1.0 if act == torch.bfloat16 else 1024.0)
         return logits
 
     @staticmethod

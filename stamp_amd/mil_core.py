@@ -233,10 +233,12 @@ class PackedVit:
         if self.train:
             new_wt["proj_w"] = pt
         for l, Lm in enumerate(m["layers"]):
-            # ALiBi: the attention output is bf16 (range, see amds_attention_alibi), so its output projection runs on bf16 operands
+            # ALiBi inference: the attention output is bf16 (range, see amds_attention_alibi), so its output projection runs on bf16 operands; the training
+            # step keeps every 16-bit tensor in ITS operand type (fp16 at float32_matmul_precision "high": amds::attention_alibi_fwd_train_dt)
             Lw, Lt = {}, {}
             for k in ("in_w", "out_w", "fc1_w", "fc2_w"):
-                Lw[k], Lt[k] = cast(Lm[k], BF if (d.alibi and k == "out_w") else None, prev(old_w, l, k), prev(old_wt, l, k) if self.train else None, self.train)
+                Lw[k], Lt[k] = cast(Lm[k], BF if (d.alibi and k == "out_w" and not self.train) else None, prev(old_w, l, k), prev(old_wt, l, k) if self.train else None,
+                                    self.train)
             new_w["layers"].append(Lw)
             if self.train:
                 new_wt["layers"].append(Lt)
@@ -369,8 +371,8 @@ def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None
     """-> (logits fp32 [Bb, C], saved).  `training` switches the dropout sites on (the running means are the caller's job).
     ONE library call (amds_mil_vit_train_forward, csrc/mil_vit_train.hip); `saved` holds the activation arena the backward reads."""
     d = pk.dims
-    if not pk.train or pk.act != BF:
-        raise RuntimeError("forward_train needs a training pack (PackedVit(..., torch.bfloat16, train=True))")
+    if not pk.train or pk.act not in (BF, torch.float16):
+        raise RuntimeError("forward_train needs a training pack (PackedVit(..., torch.bfloat16 or torch.float16, train=True))")
     if bags.dim() != 3 or bags.shape[-1] != d.F:
         raise ValueError(f"bags must be [batch, tile, {d.F}], got {tuple(bags.shape)}")
     ops._dev(bags)

@@ -19,9 +19,14 @@ Mirrors what `stamp train` does for tile-level models:
   batch size 1, :467-477), early stopping with `patience` on the validation loss (mode min), the best epoch's weights restored
   at the end (`shutil.copy(best_model_path)` + reload).
 
-Mixed precision (stated, not hidden): bf16 MFMA operands for activations, weights and gradients (fp32 exponent range, so no loss
-scaling), fp32 accumulation, fp32 residual stream and its gradient, fp32 LayerNorm / softmax statistics, fp32 master weights,
-gradients and Adam moments.  The loss on the [batch, classes] logits is the one tiny piece left to torch.
+Mixed precision (stated, not hidden): 16-bit MFMA operands for activations, weights and gradients, fp32 accumulation, fp32 residual
+stream and its gradient, fp32 LayerNorm / softmax statistics, fp32 master weights, gradients and Adam moments.  WHICH 16-bit type
+follows torch's own flag, like the TransMIL head's products do: the reference calls `torch.set_float32_matmul_precision("high")` before
+training (src/stamp/modeling/train.py:519) -- TF32-class products, 10 explicit mantissa bits per operand -- so under "high" (and
+"highest") the operands are **fp16** (10 explicit bits, like TF32) and the loss is scaled by a static 2^10 on its way into the backward
+(fp16's exponent range; the fp32 gradients are un-scaled before AdamW); under "medium" (bf16 products in torch's own wording) they are
+**bf16** (8 bits, fp32's exponent range, no loss scaling) -- the only mode before round 6.  `precision=` overrides the flag.
+The loss on the [batch, classes] logits is the one tiny piece left to torch.
 """
 from __future__ import annotations
 
@@ -79,11 +84,19 @@ class OneCycleClock:
 class HipMilVitTrainer:
     def __init__(self, model: VisionTransformer, *, device="cuda", max_lr: float = 1e-4, div_factor: float = 25.0,
                  total_steps: int = 1000, weight_decay: float = 0.01, split_k: int = 32, dropout: bool | None = None,
-                 sched_interval: str = "epoch") -> None:
+                 sched_interval: str = "epoch", precision: str | None = None, loss_scale: float = 1024.0) -> None:
         """dropout: None = as the reference's train mode (live when the model's rates are > 0; the feed-forward rate is always 0.5);
         False = all dropout sites off (deterministic steps, e.g. for parity tests against autograd).
         sched_interval: "epoch" (default; what Lightning does with the reference's bare scheduler, see the module docstring: call
-        `epoch_end()` after every epoch -- `fit` does) or "step" (OneCycle advanced after every optimiser step)."""
+        `epoch_end()` after every epoch -- `fit` does) or "step" (OneCycle advanced after every optimiser step).
+        precision: None = torch.get_float32_matmul_precision() at construction ("high" under the reference's train_model_, train.py:519); "high" /
+        "highest" -> fp16 operands + static loss scale `loss_scale`; "medium" -> bf16 operands, no scaling (module docstring)."""
+        self.precision = precision or torch.get_float32_matmul_precision()
+        if self.precision not in ("medium", "high", "highest"):
+            raise ValueError(f"precision must be 'medium', 'high' or 'highest', got {self.precision!r}")
+        self.act = BF if self.precision == "medium" else torch.float16
+        # fp16 gradients: a static power-of-two scale on dlogits (exact) lifts the 16-bit gradient tensors out of fp16's subnormal range; un-scaled in fp32
+        self.loss_scale = 1.0 if self.act == BF else float(loss_scale)
         self.model = model
         self.dims = model.dims
         self.alibi = bool(model.use_alibi)
@@ -110,7 +123,7 @@ class HipMilVitTrainer:
         self._stat_idx = torch.tensor([self.offs[k][0] for k in stat], dtype=torch.long, device=self.dev)
         self.clock = OneCycleClock(total_steps, max_lr, div_factor, sched_interval)
         self._lrs, self._b1s = self.clock.lrs, self.clock.b1s
-        self.pk = PackedVit(self.dims, self.p, BF, train=True)
+        self.pk = PackedVit(self.dims, self.p, self.act, train=True)
 
     # ---- parameter views ------------------------------------------------------------------------------------------------
     def p(self, name: str) -> torch.Tensor:
@@ -179,10 +192,14 @@ class HipMilVitTrainer:
             dlogits = torch.autograd.grad(loss, lg, allow_unused=True)[0] if loss.requires_grad else None
         if dlogits is None:      # e.g. a Cox batch without events (cox.py:219-224 returns a constant 0): nothing to learn from, no step
             return loss.detach(), logits
+        if self.loss_scale != 1.0:
+            dlogits = dlogits * self.loss_scale
         G, _ = mil_core.backward(self.pk, saved, dlogits, need_params=True, need_bags=False, split_k=self.split_k, grad_views=self.g)
         for k, gk in G.items():          # (unpadded geometries: the library wrote into the flat buffer's views themselves -- nothing to copy)
             if gk.data_ptr() != self.g(k).data_ptr():
                 self.g(k).copy_(gk)
+        if self.loss_scale != 1.0:
+            self.G.mul_(1.0 / self.loss_scale)
         # ---- AdamW + OneCycleLR ---------------------------------------------------------------------------------------------------
         if dist_on:
             average_gradients(self.G)

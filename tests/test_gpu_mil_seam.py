@@ -287,13 +287,16 @@ def test_training_step_with_dropout_matches_oracle_given_the_same_masks(gpu, ali
 
 
 # ---- bench-size and configs[0]-shaped training parity -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["high", "medium"])
 @pytest.mark.parametrize("alibi", [False, True])
-def test_bench_size_training_step_matches_autograd(gpu, alibi):
+def test_bench_size_training_step_matches_autograd(gpu, alibi, precision):
     """BASELINE.json configs[2] geometry: bags of 1024 tiles x 1024-d, dim_model 512, 8 heads, feed-forward 512, 2 layers, split-K 32
     (the bench's settings; batch 4 so that the fp64 oracle finishes in seconds).  Loss, logits and EVERY parameter gradient against
-    fp64 autograd through the pinned oracle.  Stated bars (bf16 MFMA operands): loss / logits 1e-2, each gradient <= 1.5e-2 relative
-    L2 with and without ALiBi (measured <= 5.8e-3); the per-layer vector of the 8 scalar bias_scale gradients <= 2e-2 (measured 5.6e-3;
-    q/k encoders measured against 5 % of the sibling value-encoder gradient)."""
+    fp64 autograd through the pinned oracle, at both levels of torch's float32_matmul_precision the trainer follows:
+    "high" (what the reference sets before training, train.py:519: fp16 operands = TF32's 10 explicit mantissa bits, loss scale 2^10): loss / logits 2e-3,
+    each gradient <= 1e-3 relative L2 (measured <= 6.9e-4 without, 8.8e-4 with ALiBi), bias_scale vector <= 1.5e-3 (6.8e-4);
+    "medium" (bf16 operands, the only mode before round 6): loss / logits 1e-2, each gradient <= 1.5e-2 (measured <= 5.8e-3), bias_scale <= 2e-2.
+    (q/k encoders are measured against 5 % of the sibling value-encoder gradient.)"""
     torch.manual_seed(21)
     Bb, Tn, Fd, C, H = 4, 1024, 1024, 2, 8
     model = VisionTransformer(dim_output=C, dim_input=Fd, dim_model=512, n_layers=2, n_heads=H, dim_feedforward=512, dropout=0.0, use_alibi=alibi)
@@ -303,7 +306,8 @@ def test_bench_size_training_step_matches_autograd(gpu, alibi):
     coords = (torch.rand(Bb, Tn, 2) * 4e4 / 256).round() * 256
     targets = torch.nn.functional.one_hot(torch.arange(Bb) % 2, 2).float()
     weights = torch.tensor([0.6, 0.4])
-    tr = HipMilVitTrainer(model, device=gpu, split_k=32, dropout=False)
+    tr = HipMilVitTrainer(model, device=gpu, split_k=32, dropout=False, precision=precision)
+    assert tr.act == (torch.float16 if precision == "high" else torch.bfloat16)
     loss, logits = tr.step(bags.to(gpu), targets, weights, update=False, coords=coords.to(gpu))
     sd = dict(sd0)
     if alibi:
@@ -317,8 +321,9 @@ def test_bench_size_training_step_matches_autograd(gpu, alibi):
     ref = mil_vit_forward(bags.double(), coords.double(), None, params, n_heads=H, use_alibi=alibi, dtype=torch.float64)
     ref_loss = torch.nn.functional.cross_entropy(ref, targets.double(), weight=weights.double())
     ref_loss.backward()
-    assert abs(loss.item() - ref_loss.item()) < 1e-2 * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
-    assert (logits.cpu().double() - ref.detach()).abs().max() < 1e-2 * max(1.0, ref.abs().max().item())
+    fwd_bar = 2e-3 if precision == "high" else 1e-2
+    assert abs(loss.item() - ref_loss.item()) < fwd_bar * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    assert (logits.cpu().double() - ref.detach()).abs().max() < fwd_bar * max(1.0, ref.abs().max().item())
     report = []
     bsg: dict = {}
     for k in tr.names:
@@ -338,9 +343,12 @@ def test_bench_size_training_step_matches_autograd(gpu, alibi):
     for layer, (a, b) in bsg.items():
         report.append((_rel(torch.cat(a), torch.cat(b)), layer + ".mhsa.attentions.*.bias_scale"))
     report.sort(reverse=True)
-    print(f"bench-size step, alibi={alibi}: largest gradient errors", [(round(a, 4), b) for a, b in report[:6]])
+    print(f"bench-size step, alibi={alibi}, precision={precision}: largest gradient errors", [(round(a, 5), b) for a, b in report[:6]])
     for rel, k in report:
-        bar = 2e-2 if k.endswith("bias_scale") else 1.5e-2          # measured on the MI355X: <= 5.8e-3 without, <= 5.6e-3 with ALiBi
+        if precision == "high":
+            bar = 1.5e-3 if k.endswith("bias_scale") else 1e-3
+        else:
+            bar = 2e-2 if k.endswith("bias_scale") else 1.5e-2      # measured on the MI355X: <= 5.8e-3 without, <= 5.6e-3 with ALiBi
         assert rel < bar, (k, rel)
 
 
