@@ -239,28 +239,6 @@ int amds_attention_vit(const void* qkv, void* out, int B, int T, int H, int dtyp
  * [H][head_dim]. */
 int amds_attention_vit_hd(const void* qkv, void* out, int B, int T, int H, int head_dim, int dtype, void* stream);
 
-/* The qkv Linear AND the attention of a ViT block in one kernel, for T = 257 tokens (class token + 16 x 16 patches) and head_dim 64: timm
- * Attention.forward's `qkv = self.qkv(x)` + `F.scaled_dot_product_attention(q, k, v)` -- what the reference runs inside `model(tiles)`,
- * src/stamp/preprocessing/__init__.py:324-325 -- without q | k | v ever reaching HBM (csrc/qkv_attn257.hip).
- *   x        act dtype [B*257][dim]: the rows entering the qkv Linear -- LayerNorm output, or, with the LayerNorm folded in (amds_gemm_lnfold's
- *            consumer form), the un-normalised 16-bit rows together with rowstat [B*257][2] = (rstd, -mean*rstd) and colsum [3*dim];
- *   w_qkv    act dtype [3*dim][dim] (torch Linear layout; q | k | v thirds, each [heads][64]), bias fp32 [3*dim];
- *   qkv_tail act dtype [B*257][3*dim]: only row 256 of every tile is READ -- the q | k | v row of the tile's last token, computed beforehand by
- *            the ordinary GEMM (the kernel's matrix phase covers the tile's first 256 tokens); nothing is written to it;
- *   out      act dtype [B*257][dim]: softmax(q k^T / 8) v, heads concatenated -- bit for bit what amds_gemm_lnfold / amds_gemm (BIAS) followed by
- *            amds_attention_vit writes.
- * rowstat and colsum are both given or both NULL. */
-int amds_qkv_attention_vit257(const void* x, const void* w_qkv, const float* bias, const float* colsum, const float* rowstat, const void* qkv_tail,
-                              void* out, int B, int heads, int dim, int dtype, void* stream);
-/* Gathers row `row` of every group of T rows: src16 [B*T][D] 16-bit -> dst16 [B][D]; stat [B*T][2] fp32 -> dst_stat [B][2] (stat may be NULL).
- * The rows of a tile's last token for the GEMM in front of amds_qkv_attention_vit257. */
-int amds_gather_token_rows16(const void* src16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, void* stream);
-/* The same gather with the LayerNorm applied on the way (normalize != 0): dst16[b] = round16((src16 + lo16)[b*T + row] * stat[..][0] + stat[..][1]) -- the
- * normalised row (gamma / beta live in the folded weights), from both planes of a two-plane residual stream when lo16 is given -- so that a PLAIN
- * GEMM on 128-row tiles can compute the q | k | v rows of the 1020 last tokens (48 workgroups of the 256-row kernel took 35 us for it). */
-int amds_gather_token_rows16_ex(const void* src16, const void* lo16, const float* stat, void* dst16, float* dst_stat, int B, int T, int D, int row, int dtype,
-                                int normalize, void* stream);
-
 /* Same contract for ANY T (K/V streamed through LDS in 64-key tiles, online softmax; the T x T matrix is never
  * materialised).  Used by the MIL heads: bags of 1024 tiles in training, whole slides (tens of thousands of
  * tiles) at deploy time (reference src/stamp/modeling/models/vision_tranformer.py:191, 217-227, mask=None path
@@ -282,8 +260,8 @@ int amds_attention_row_bwd_train(const void* qkv, const void* out, const void* d
                                  int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
 /* Process-wide switch (default 1; AMDS_MIL_CLS_TAIL=0 in the environment starts at 0): the MIL `vit` head's last block computed for the class rows alone where the
  * block's other rows are dead (amds_mil_vit_forward without ALiBi / mask; the attention of amds_mil_vit_train_forward / _backward without ALiBi). */
-int amds_set_mil_cls_tail(int on);
-int amds_get_mil_cls_tail(void);
+int amds_set_mil_cls_tail(amds_ctx* ctx, int on);
+int amds_get_mil_cls_tail(amds_ctx* ctx);
 
 /* ALiBi variant of the reference's MultiHeadALiBi (src/stamp/modeling/models/vision_tranformer.py:42-74, eval mode):
  *   out = softmax(q k^T / 8) v  -  head_scale[h] * cdist(coords_q, coords_k) v        (bias applied AFTER the softmax)
@@ -798,15 +776,19 @@ int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds_mil_vit_we
 
 /* The TRAINING step of the same head, forward and backward as one call each (reference: the train-mode forward of
  * vision_tranformer.py:332-384 with its Dropout sites :157-169, :191, :314-318 live, and loss.backward() through it,
- * src/stamp/modeling/models/__init__.py:239-279).  cfg.dtype must be AMDS_BF16 (bf16 MFMA operands, fp32 accumulation, residual stream
- * and gradients).  Dropout masks are counter-based functions of (seed, site, element): the backward regenerates them from the same
+ * src/stamp/modeling/models/__init__.py:239-279).  cfg.dtype = AMDS_BF16 or AMDS_F16: the type of EVERY 16-bit tensor of the step (operand copies of the
+ * weights, saved activations, 16-bit gradients); fp32 accumulation, residual stream and gradients.  bf16 = torch's float32_matmul_precision "medium"; fp16
+ * (10 explicit mantissa bits, the TF32 class) = "high", which the reference sets before training (src/stamp/modeling/train.py:519) -- the caller then
+ * multiplies dlogits by a power of two (1024 in stamp_amd/mil_train.py) and divides the gradients by it.  Dropout masks are counter-based functions of (seed, site, element): the backward regenerates them from the same
  * amds_mil_vit_dropout.  The ALiBi running means (:24-29) are updated by the caller BEFORE the forward (amds_cdist_rowsum). */
 typedef struct {
     float p_proj;       /* project_features' Dropout = the constructor's `dropout`                    :314-318 */
     float p_att;        /* nn.MultiheadAttention's dropout = the constructor's `dropout` (ignored when cfg.alibi)  :191 */
     float p_ff;         /* feed_forward's two Dropouts (0.5: the reference never forwards `dropout` to them)       :157-169, :268-271 */
     uint64_t seed;
-} amds_mil_vit_dropout;  /* all zero = eval-mode arithmetic with saved activations (parity tests against autograd) */
+    int cls_tail;       /* the last block on its class rows alone: 1 / 0 = yes / no, the SAME value for a forward and the backwards that read its arena
+                         * (the arena's layout depends on it); -1 = each call asks the context (amds_get_mil_cls_tail) -- only safe if nobody toggles it between */
+} amds_mil_vit_dropout;  /* p = 0, seed = 0 = eval-mode arithmetic with saved activations (parity tests against autograd) */
 
 /* fp32 device buffers in the PADDED layout of the weights they belong to (amds_mil_vit_layer / _weights); the caller slices the
  * reference shapes out of them (padding rows / columns / heads receive zeros or don't-care values). */
@@ -902,8 +884,8 @@ int amds_barspoon_forward(const amds_barspoon_cfg* cfg_host, const amds_barspoon
  * paths that promise exact fp32 (the tile encoder's exact class-token stream, TICON, barspoon's class side) stay exact at every level. */
 #define AMDS_MATMUL_HIGHEST 0
 #define AMDS_MATMUL_HIGH 1
-int amds_set_matmul_precision(int level);
-int amds_get_matmul_precision(void);
+int amds_set_matmul_precision(amds_ctx* ctx, int level);
+int amds_get_matmul_precision(amds_ctx* ctx);
 /* Batched fp32 GEMM on the exact-fp32 MFMA: for z = (o, i), o < outer, i < inner:
  *   C[o,i] (+)= diag*I + alpha * A[o,i] * op(B[o,i]) + bias[n];  op(B) = B^T if transb (B stored [N][K]) else B ([K][N]).
  * Operand z starts at base + o*s?o + i*s?i (elements), so head slices of a packed qkv tensor are addressed in place.

@@ -86,7 +86,7 @@ class MilVitWeights(C.Structure):
 
 
 class MilVitDropout(C.Structure):
-    _fields_ = [("p_proj", C.c_float), ("p_att", C.c_float), ("p_ff", C.c_float), ("seed", C.c_uint64)]
+    _fields_ = [("p_proj", C.c_float), ("p_att", C.c_float), ("p_ff", C.c_float), ("seed", C.c_uint64), ("cls_tail", C.c_int)]
 
 
 class MilVitLayerGrads(C.Structure):
@@ -216,13 +216,10 @@ PROTOTYPES = {
     "amds_attention_row": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "amds_attention_row_fwd_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_attention_row_bwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, C.c_uint32, _vp]),
-    "amds_set_mil_cls_tail": (_i, [_i]),
-    "amds_get_mil_cls_tail": (_i, []),
+    "amds_set_mil_cls_tail": (_i, [_vp, _i]),
+    "amds_get_mil_cls_tail": (_i, [_vp]),
     "amds_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_attention_vit_hd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "amds_qkv_attention_vit257": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "amds_gather_token_rows16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "amds_gather_token_rows16_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amds_attention_alibi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "amds_vit_workspace_bytes": (_sz, [C.POINTER(VitCfg), _i]),
     "amds_vit_forward": (_i, [C.POINTER(VitCfg), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -299,8 +296,8 @@ PROTOTYPES = {
     "amds_topk_rows_mean": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp]),
     "amds_pinv_init_bwd_workspace_bytes": (_sz, [_i]),
     "amds_pinv_init_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "amds_set_matmul_precision": (_i, [_i]),
-    "amds_get_matmul_precision": (_i, []),
+    "amds_set_matmul_precision": (_i, [_vp, _i]),
+    "amds_get_matmul_precision": (_i, [_vp]),
     "amds_gemm_batched": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp]),
     "amds_wgrad_tn": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp]),
     "amds_transpose16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),

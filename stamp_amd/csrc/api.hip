@@ -32,6 +32,9 @@ struct amds_ctx {
     long dropped = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // settings of THIS context (round 6: they were process-wide atomics -- two trainers in one process with different torch flags shared one value)
+    std::atomic<int> matmul_precision{AMDS_MATMUL_HIGHEST};      // amds_set_matmul_precision
+    std::atomic<int> mil_cls_tail{-1};                           // amds_set_mil_cls_tail; -1 = the AMDS_MIL_CLS_TAIL environment default
 };
 namespace amds {
 std::atomic<int> g_prof_any{0};
@@ -153,6 +156,52 @@ extern "C" int amds_ctx_device(const amds_ctx* c) { return c ? c->device : -1; }
 
 // the context of the calling thread's current device, if the host created one (amds_create); nullptr otherwise
 amds_ctx* amds::ctx_of_current_device() { return current_ctx(); }
+
+// ---- per-context settings: read through the context of the calling thread's current device (the one its streams belong to); a process that never
+// created a context for the device gets the defaults
+static int cls_tail_env_default() {
+    static const int v = (getenv("AMDS_MIL_CLS_TAIL") && atoi(getenv("AMDS_MIL_CLS_TAIL")) == 0) ? 0 : 1;
+    return v;
+}
+int amds::ctx_matmul_precision() {
+    amds_ctx* c = current_ctx();
+    return c ? c->matmul_precision.load(std::memory_order_relaxed) : AMDS_MATMUL_HIGHEST;
+}
+int amds::ctx_mil_cls_tail() {
+    amds_ctx* c = current_ctx();
+    const int v = c ? c->mil_cls_tail.load(std::memory_order_relaxed) : -1;
+    return v < 0 ? cls_tail_env_default() : v;
+}
+// multiprocessor count of the current device, looked up once per DEVICE (round 5 kept one process-wide number per kernel family)
+int amds::device_cu_count() {
+    static std::atomic<int> cus[MAX_DEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        v = p.multiProcessorCount;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" int amds_set_matmul_precision(amds_ctx* ctx, int level) {
+    AMDS_REQUIRE(ctx, "amds_set_matmul_precision: null context");
+    AMDS_REQUIRE(level == AMDS_MATMUL_HIGHEST || level == AMDS_MATMUL_HIGH, "amds_set_matmul_precision: level must be AMDS_MATMUL_HIGHEST (0) or AMDS_MATMUL_HIGH (1), got %d", level);
+    ctx->matmul_precision.store(level, std::memory_order_relaxed);
+    return AMDS_OK;
+}
+extern "C" int amds_get_matmul_precision(amds_ctx* ctx) { return ctx ? ctx->matmul_precision.load(std::memory_order_relaxed) : AMDS_MATMUL_HIGHEST; }
+extern "C" int amds_set_mil_cls_tail(amds_ctx* ctx, int on) {
+    AMDS_REQUIRE(ctx, "amds_set_mil_cls_tail: null context");
+    ctx->mil_cls_tail.store(on ? 1 : 0, std::memory_order_relaxed);
+    return AMDS_OK;
+}
+extern "C" int amds_get_mil_cls_tail(amds_ctx* ctx) {
+    const int v = ctx ? ctx->mil_cls_tail.load(std::memory_order_relaxed) : -1;
+    return v < 0 ? cls_tail_env_default() : v;
+}
 
 // side stream + fork / join events of the overlapped schedule, created on first use on the context's device
 int amds::ctx_side_stream(amds_ctx* c, hipStream_t* side, hipEvent_t* ev_in, hipEvent_t* ev_out) {

@@ -444,7 +444,6 @@ __global__ void __launch_bounds__(512) attn_vit257_kernel(const T* __restrict__ 
     if (wave == 0) merge_odd(cur ^ 1, item - (int)gridDim.x);        // the last item's odd query (its barrier is the loop's last one)
 }
 
-static int g_a7_cus = 0;
 
 template <typename T>
 static int launch_attn257(const void* qkv, void* out, int B, int H, hipStream_t st) {
@@ -454,15 +453,10 @@ static int launch_attn257(const void* qkv, void* out, int B, int H, hipStream_t 
         AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, A7_LDS));
         attr_set = true;
     }
-    if (!g_a7_cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        AMDS_HIP(hipGetDevice(&dev));
-        AMDS_HIP(hipGetDeviceProperties(&p, dev));
-        g_a7_cus = p.multiProcessorCount;
-    }
+    const int n_cus = device_cu_count();
+    AMDS_REQUIRE(n_cus > 0, "attention: cannot read the device's multiprocessor count");
     const int n_items = B * H;
-    hipLaunchKernelGGL(kern, dim3(min(n_items, g_a7_cus)), dim3(512), A7_LDS, st, (const T*)qkv, (T*)out, H, n_items);
+    hipLaunchKernelGGL(kern, dim3(min(n_items, n_cus)), dim3(512), A7_LDS, st, (const T*)qkv, (T*)out, H, n_items);
     AMDS_LAUNCH_CHECK("attn_vit257_kernel");
     return AMDS_OK;
 }

@@ -447,7 +447,6 @@ __global__ void __launch_bounds__(512) attn_vit26x_kernel(const T* __restrict__ 
     if (wave >= 4) merge_item(cur ^ 1, item - (int)gridDim.x);       // the last item's tail queries (its barrier is the loop's last one)
 }
 
-static int g_ax_cus = 0;
 
 template <typename T, int R>
 static int launch_attn26x(const void* qkv, void* out, int B, int H, hipStream_t st) {
@@ -459,15 +458,10 @@ static int launch_attn26x(const void* qkv, void* out, int B, int H, hipStream_t 
         AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    if (!g_ax_cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        AMDS_HIP(hipGetDevice(&dev));
-        AMDS_HIP(hipGetDeviceProperties(&p, dev));
-        g_ax_cus = p.multiProcessorCount;
-    }
+    const int n_cus = device_cu_count();
+    AMDS_REQUIRE(n_cus > 0, "attention: cannot read the device's multiprocessor count");
     const int n_items = B * H;
-    hipLaunchKernelGGL(kern, dim3(min(n_items, g_ax_cus)), dim3(512), LDS, st, (const T*)qkv, (T*)out, H, n_items);
+    hipLaunchKernelGGL(kern, dim3(min(n_items, n_cus)), dim3(512), LDS, st, (const T*)qkv, (T*)out, H, n_items);
     AMDS_LAUNCH_CHECK("attn_vit26x_kernel");
     return AMDS_OK;
 }

@@ -62,15 +62,6 @@ template <> struct Act<f16> {
     static __device__ __forceinline__ void mfma16_agpr(vec8 a, vec8 b, f32x4& c) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
-    // result in architectural VGPRs (the builtin's accumulator may be placed in AGPRs, and every value a VALU instruction then reads costs a
-    // v_accvgpr_read): d = a b  /  d += a b.  Inline asm: the compiler's hazard recogniser does not see an MFMA here -- the CALLER keeps VALU
-    // reads of d a few hundred cycles away from the asm (scores consumed one pipeline stage later).
-    static __device__ __forceinline__ void mfma32_vgpr_zero(f32x16& d, vec8 a, vec8 b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
-    }
-    static __device__ __forceinline__ void mfma32_vgpr_acc(f32x16& d, vec8 a, vec8 b) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
-    }
     static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
     // two v_cvt_pk_f16_f32 (element-wise conversion loops compile to v_cvt_f16_f32 + v_pack / v_alignbit: 2.5x the instructions)
     static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
@@ -90,15 +81,6 @@ template <> struct Act<bf16> {
     }
     static __device__ __forceinline__ void mfma16_agpr(vec8 a, vec8 b, f32x4& c) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    }
-    // result in architectural VGPRs (the builtin's accumulator may be placed in AGPRs, and every value a VALU instruction then reads costs a
-    // v_accvgpr_read): d = a b  /  d += a b.  Inline asm: the compiler's hazard recogniser does not see an MFMA here -- the CALLER keeps VALU
-    // reads of d a few hundred cycles away from the asm (scores consumed one pipeline stage later).
-    static __device__ __forceinline__ void mfma32_vgpr_zero(f32x16& d, vec8 a, vec8 b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
-    }
-    static __device__ __forceinline__ void mfma32_vgpr_acc(f32x16& d, vec8 a, vec8 b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
     static __device__ __forceinline__ vec4 from_f32x4(f32x4 v) { return __builtin_convertvector(v, vec4); }
@@ -333,6 +315,9 @@ int prof_begin(int kind, double work, hipStream_t st, amds_ctx** ctx_out);
 void prof_end(amds_ctx* ctx, int slot, hipStream_t st);
 int ctx_side_stream(amds_ctx* c, hipStream_t* side, hipEvent_t* ev_in, hipEvent_t* ev_out);
 amds_ctx* ctx_of_current_device();
+int ctx_matmul_precision();      // of the current device's context (AMDS_MATMUL_HIGHEST without one)
+int ctx_mil_cls_tail();          // of the current device's context (the AMDS_MIL_CLS_TAIL environment default without one)
+int device_cu_count();           // multiprocessor count of the current device, cached per device
 struct ProfScope {
     hipStream_t st; amds_ctx* ctx = nullptr; int slot = -1;
     ProfScope(int kind, double work, hipStream_t s) : st(s) { if (g_prof_any.load(std::memory_order_relaxed) > 0) slot = prof_begin(kind, work, s, &ctx); }

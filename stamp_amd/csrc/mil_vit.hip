@@ -95,10 +95,6 @@ extern "C" size_t amds_mil_vit_workspace_bytes(const amds_mil_vit_cfg* cfg_host,
     return p.total;
 }
 
-static std::atomic<int> g_mil_cls_tail{(getenv("AMDS_MIL_CLS_TAIL") && atoi(getenv("AMDS_MIL_CLS_TAIL")) == 0) ? 0 : 1};
-extern "C" int amds_set_mil_cls_tail(int on) { g_mil_cls_tail.store(on ? 1 : 0, std::memory_order_relaxed); return AMDS_OK; }
-extern "C" int amds_get_mil_cls_tail(void) { return g_mil_cls_tail.load(std::memory_order_relaxed); }
-
 extern "C" int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds_mil_vit_weights* w_host, const void* bags, int bags_dtype,
                                     const float* coords, const uint8_t* mask, float* logits, int n_bags, int n_tiles, void* ws, size_t ws_bytes,
                                     void* stream) {
@@ -163,7 +159,7 @@ extern "C" int amds_mil_vit_forward(const amds_mil_vit_cfg* cfg_host, const amds
     // amds_set_mil_cls_tail(0) / AMDS_MIL_CLS_TAIL=0: every row of the last block (A/B, tests).  Not with ALiBi (its attention has no one-query form).  A padding
     // mask changes nothing for the class query: the reference's mask blocks (padded query, padded key) pairs and the class token as a KEY of the tile queries
     // (vision_tranformer.py:356-368) -- the class token is never padded, so its own row attends to every key, exactly the unmasked one-query attention.
-    const bool cls_tail = amds_get_mil_cls_tail() && !c.alibi && S <= 32768 && (long)(Bb - 1) * S * Dp * 4 < (1L << 31);
+    const bool cls_tail = ctx_mil_cls_tail() && !c.alibi && S <= 32768 && (long)(Bb - 1) * S * Dp * 4 < (1L << 31);
     for (int l = 0; l < c.layers && rc == AMDS_OK; ++l) {
         const amds_mil_vit_layer& L = w.layers_host[l];
         AMDS_REQUIRE(L.ln1_w && L.ln1_b && L.in_w && L.in_b && L.out_w && L.out_b && L.ln2_w && L.ln2_b && L.fc1_w && L.fc1_b && L.fc2_w && L.fc2_b &&

@@ -212,9 +212,15 @@ int gelu_drop_bwd(const void* z, const void* du, void* dz, long n, int zdt, int 
 
 constexpr int CFG_TRAIN = -2;      // amds_gemm_ex: by shape, ragged last row tile as its own small launch (M = bags x 1025 is never a multiple of 256)
 
-// the last block on its class rows alone (amds_set_mil_cls_tail; not with ALiBi: its attention has no one-query form; pitched rows must fit the 32-bit descriptors)
-bool cls_tail(const Dims& d) {
-    return amds_get_mil_cls_tail() && !d.alibi && d.L > 0 && d.S <= 32768 && (long)(d.Bb + 1) * d.S * std::max(d.FFp, 3 * d.Da) * 4 < (1L << 31);
+// the last block on its class rows alone (amds_mil_vit_dropout.cls_tail, else the context's amds_set_mil_cls_tail; not with ALiBi: its attention has no one-query
+// form).  The pitched rows (a class row every S rows) must fit the 32-bit buffer descriptors of the GEMMs AND of the token-major weight-gradient kernel, which spans
+// chunk + 63 rows of pitch S * width 16-bit elements per split (amds_wgrad_tn: chunk = 64 for Bb <= 64 split_k) -- a bag of 8192 tiles with dim_feedforward 2048 passes
+// the first bound and not the second: such shapes take the full-block path.
+bool cls_tail(const Dims& d, int want) {
+    const bool on = want < 0 ? ctx_mil_cls_tail() != 0 : want != 0;
+    const long wide = std::max(std::max(d.FFp, 3 * d.Da), d.Dp);
+    const long chunk = (d.Bb + 63) / 64 * 64;
+    return on && !d.alibi && d.L > 0 && d.S <= 32768 && (long)(d.Bb + 1) * d.S * wide * 4 < (1L << 31) && (chunk + 63) * d.S * wide * 2 < (1L << 31);
 }
 
 int gemm_dt(int dt, const void* A, long lda, const void* W, long ldw, long M, int N, int K, int epi, void* out, long ldo, const float* bias, void* st) {
@@ -319,7 +325,7 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
         // (the LayerNorm kernel also writes x_mid = x_in, which the out-projection's residual epilogue then updates in place)
         RC(amds_layernorm_train_copy(x_in, Dp, Lw.ln1_w, Lw.ln1_b, h1, Dp, reinterpret_cast<float*>(sv + o.mu1), reinterpret_cast<float*>(sv + o.rs1), (int)M, D,
                                      1e-5f, BF, x_mid, Dp, Dp, stream));
-        if (cls_tail(d) && l == d.L - 1) {
+        if (cls_tail(d, drop_host->cls_tail) && l == d.L - 1) {
             // Class-row tail.  The head reads the class row of the last block and nothing else (reference vision_tranformer.py: `self.mlp_head(x[:, 0])`), so this
             // block computes keys | values of every token and -- on the class rows alone, addressed in place by a row pitch of S rows -- the query, its attention
             // (amds_attention_row_fwd_train), the output projection and the MLP.  Dropout draws the bits the full block draws for those rows (row_mul = S).
@@ -549,7 +555,7 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         const float* x_mid = reinterpret_cast<const float*>(sv + o.x_mid);
         const void *h1 = sv + o.h1, *h2 = sv + o.h2, *qkv = sv + o.qkv, *att = sv + o.att, *z = sv + o.z, *u = sv + o.u;
         const float* lse = reinterpret_cast<const float*>(sv + o.lse);
-        const bool tail = cls_tail(d) && l == d.L - 1;
+        const bool tail = cls_tail(d, drop_host->cls_tail) && l == d.L - 1;
         if (tail) {
             // Class-row tail (see the forward): dx of the last block lives on the class rows; its MLP, second LayerNorm and output projection are differentiated on
             // those Bb rows alone (row pitch S rows, dropout bits of the full tensors' rows b * S).

@@ -1107,22 +1107,15 @@ extern "C" int amds_pinv_init_bwd(const float* x, const float* dz0, float* dx, i
     return AMDS_OK;
 }
 
-// process-wide, like torch's flag: the precision of the fp32 batched products (amds_bgemm_f32's 128 x 128 / 256 x 64 / 64 x 256 tile kernels)
-static std::atomic<int> g_matmul_precision{AMDS_MATMUL_HIGHEST};
-extern "C" int amds_set_matmul_precision(int level) {
-    AMDS_REQUIRE(level == AMDS_MATMUL_HIGHEST || level == AMDS_MATMUL_HIGH, "amds_set_matmul_precision: level must be AMDS_MATMUL_HIGHEST (0) or AMDS_MATMUL_HIGH (1), got %d", level);
-    g_matmul_precision.store(level, std::memory_order_relaxed);
-    return AMDS_OK;
-}
-extern "C" int amds_get_matmul_precision(void) { return g_matmul_precision.load(std::memory_order_relaxed); }
-
+// the precision of the fp32 batched products (amds_bgemm_f32's 128 x 128 / 256 x 64 / 64 x 256 tile kernels) is a setting of the device's CONTEXT
+// (amds_set_matmul_precision(ctx, level), api.hip); the Python side forwards torch's process-wide flag before every call
 static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                         float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                         float diag, const float* bias, int accumulate, void* stream, amds::BgDual dual = amds::BgDual{nullptr, 0.f, 0.f});
 extern "C" int amds_bgemm_f32(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,
                               float* Cm, int ldc, long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha,
                               float diag, const float* bias, int accumulate, void* stream) {
-    return bgemm_f32_at(g_matmul_precision.load(std::memory_order_relaxed), A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag,
+    return bgemm_f32_at(amds::ctx_matmul_precision(), A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag,
                         bias, accumulate, stream);
 }
 // the feature-extraction paths that promise exact fp32 (the ViT's exact class-token stream, TICON, barspoon's class side) do not follow the process-wide level
@@ -1138,7 +1131,7 @@ int bgemm_f32_exact(const float* A, int lda, long sAo, long sAi, const float* B,
 extern "C" int amds_bgemm_f32_dual(const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb, float* Cm, float* C2, int ldc,
                                    long sCo, long sCi, int outer, int inner, int M, int N, int K, float alpha, float diag, float alpha2, float diag2, void* stream) {
     AMDS_REQUIRE(C2 && C2 != Cm, "amds_bgemm_f32_dual: the second output must be a different buffer");
-    return bgemm_f32_at(g_matmul_precision.load(std::memory_order_relaxed), A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag,
+    return bgemm_f32_at(amds::ctx_matmul_precision(), A, lda, sAo, sAi, B, ldb, sBo, sBi, transb, Cm, ldc, sCo, sCi, outer, inner, M, N, K, alpha, diag,
                         nullptr, 0, stream, amds::BgDual{C2, alpha2, diag2});
 }
 static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long sAi, const float* B, int ldb, long sBo, long sBi, int transb,

@@ -226,7 +226,7 @@ extern "C" int amds_transmil_forward(const amds_transmil_cfg* cfg_host, const am
     RC(amds_ppeg(x, y, w.ppeg_w7, w.ppeg_b7, w.ppeg_w5, w.ppeg_b5, w.ppeg_w3, w.ppeg_b3, Bb, p.side, p.side, Cd, stream));
     std::swap(x, y);
     RC(amds_layernorm(x, Cd, w.layer[1].norm_w, w.layer[1].norm_b, y, Cd, Bb * n, Cd, 1e-5f, AMDS_F32, stream));
-    RC(nystrom(p, w.layer[1], y, x, Bb, wk, stream, amds_get_mil_cls_tail() != 0));      // (amds_set_mil_cls_tail(0): every row, A/B and the chain tests)
+    RC(nystrom(p, w.layer[1], y, x, Bb, wk, stream, ctx_mil_cls_tail() != 0));      // (amds_set_mil_cls_tail(0): every row, A/B and the chain tests)
     // final LayerNorm on the class-token rows, _fc2 (:322-325)
     float* cls = reinterpret_cast<float*>(wk + p.cls);
     RC(amds_layernorm(x, (long)n * Cd, w.norm_w, w.norm_b, cls, Cd, Bb, Cd, 1e-5f, AMDS_F32, stream));

@@ -137,12 +137,8 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
     // (fp32: 24; the GEMM operands: 11).  AMDS_VIT_PLANES=0: fp32 rows + copy (A/B; read at every call).
     const bool planes_env = !(getenv("AMDS_VIT_PLANES") && atoi(getenv("AMDS_VIT_PLANES")) == 0);
     const bool planes = planes_env && fold && !ex && dt == AMDS_F16;
-    // qkv + attention fused (amds_qkv_attention_vit257; T = 257, head_dim 64, planes path): OPT-IN with AMDS_VIT_QKVATTN=1.  Round 5 built it to keep
-    // 3.2 GB of q | k | v per block off HBM and measured 2 040 us (+ 50 us for the last token's rows) against 2 070 us for the two launches, 0.7 % SLOWER in
-    // situ (profiles/r05_qkv_attn_fused_ab.txt): a 256 x 192 tile's K loop costs what the 256 x 256 GEMM costs with its epilogue, and the attention phase
-    // on one wave per SIMD what the stand-alone kernel costs with its HBM staging.  Kept for the A/B and as the parity-tested form of the idea.
-    const bool qa_env = getenv("AMDS_VIT_QKVATTN") && atoi(getenv("AMDS_VIT_QKVATTN")) == 1;
-    const bool fused_qa = qa_env && planes && T == 257 && hd == 64 && D >= 128 && (long)3 * D * D * 2 < (1L << 31);
+    // (qkv + attention as ONE kernel -- q | k | v never in HBM -- was built in round 5, is parity-green and 0.8 % slower in situ: profiles/r05_qkv_attn_fused_ab.txt;
+    //  the kernel, its check and its A/B scripts live in tools/ubench/attic/qkv_attn257/ since round 6.)
     // opt-in fp8 GEMMs (gemm_fp8.hip): plain (un-folded) weights, GELU MLP
     const amds_vit_fp8_block* f8 = w->fp8_host;
     if (f8) {
@@ -284,20 +280,9 @@ static int vit_chunk(const amds_vit_cfg* c, const amds_vit_weights* w, const Vit
                 continue;
             }
             if (planes) {      // hi plane (hq) = the A operand of qkv / fc1; attention writes h2q; proj / fc2 update (hq, loq) in place
-                if (fused_qa) {
-                    // qkv + attention as one kernel (qkv_attn257.hip): q | k | v of a tile's first 256 tokens stay on the chip; the q | k | v row of its
-                    // last token comes from the ordinary GEMM on the gathered rows (hcq / qcq: the class-stream buffers, idle before the last block)
-                    // (the gathered rows leave normalised -- (hi + lo) rstd - mean rstd, gamma / beta are in the folded weights -- and go through the 128 x 128
-                    //  GEMM family, always: 192 workgroups instead of 48 of the 256-row kernel, and a tile's features do not depend on the batch it travels in)
-                    AMDS_TRY(amds_gather_token_rows16_ex(hq, loq, rs, hcq, nullptr, q.nt, T, D, T - 1, dt, 1, s));
-                    AMDS_TRY(amds_gemm_ex(0, hcq, D, b.qkv_w, D, q.nt, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq + (size_t)(T - 1) * 3 * D * 2, (long)T * 3 * D, b.qkv_b, nullptr,
-                                          nullptr, 0, 0, 0, 1.0f, s));
-                    AMDS_TRY(amds_qkv_attention_vit257(hq, b.qkv_w, b.qkv_b, b.qkv_colsum, rs, qkvq, h2q, q.nt, c->heads, D, dt, s));
-                } else {
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.qkv_w, D, n, 3 * D, D, dt, AMDS_EPI_BIAS, qkvq, 3 * D, b.qkv_b, nullptr, nullptr, nullptr, rs,
                                           b.qkv_colsum, s));
                 AMDS_TRY(amds_attention_vit_hd(qkvq, h2q, q.nt, T, c->heads, D / c->heads, dt, s));
-                }
                 AMDS_TRY(amds_gemm_lnfold_planes(h2q, D, b.proj_w, D, n, D, D, hq, loq, D, b.proj_b, ls1, rp, s));
                 AMDS_TRY(amds_ln_rowstat_diag(rp, n, NP, D, c->ln_eps, rs, diag, dt, s));
                 AMDS_TRY(amds_gemm_lnfold(hq, D, b.fc1_w, D, n, n_fc1, D, dt, epi1, mlpq, Hd, b.fc1_b, nullptr, nullptr, nullptr, rs, b.fc1_colsum, s));

@@ -362,9 +362,11 @@ def update_running_means(get, d: VitDims, cc: torch.Tensor) -> None:
         torch._foreach_add_(ns, 1.0)
 
 
-def _drop_struct(d: VitDims, training: bool, seed: int) -> "_lib.MilVitDropout":
+def _drop_struct(d: VitDims, training: bool, seed: int, device_index: int = 0) -> "_lib.MilVitDropout":
+    # cls_tail: the context's switch is read ONCE here; the struct travels with the saved arena, so forward and backward agree by construction
+    tail = int(_lib.lib().amds_get_mil_cls_tail(_lib.ctx(device_index)))
     return _lib.MilVitDropout(d.p_drop if training else 0.0, d.p_drop if (training and not d.alibi) else 0.0, d.p_ff if training else 0.0,
-                              int(seed) & (2 ** 64 - 1))
+                              int(seed) & (2 ** 64 - 1), tail)
 
 
 def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None, *, training: bool, seed: int = 0):
@@ -395,7 +397,7 @@ def forward_train(pk: PackedVit, bags: torch.Tensor, coords: torch.Tensor | None
         _lib.check(-1, "mil_vit_train_saved_bytes")
     arena = torch.empty(need, dtype=torch.uint8, device=dev)
     logits = torch.empty(Bb, d.C, dtype=torch.float32, device=dev)
-    drop = _drop_struct(d, training, seed)
+    drop = _drop_struct(d, training, seed, dev.index or 0)
     _lib.check(lib.amds_mil_vit_train_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), ops._DT[bags.dtype], c.data_ptr() if c is not None else None,
                                               C.byref(drop), logits.data_ptr(), Bb, Tn, arena.data_ptr(), arena.numel(), ops._stream()),
                "mil_vit_train_forward")

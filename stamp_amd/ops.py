@@ -50,13 +50,14 @@ def act_code(dtype: torch.dtype) -> int:
 
 
 def sync_float32_matmul_precision() -> str:
-    """Forward torch's process-wide `torch.get_float32_matmul_precision()` to the library (`amds_set_matmul_precision`): "highest" (torch's default) = exact
+    """Forward torch's process-wide `torch.get_float32_matmul_precision()` to the library's context of the current device (`amds_set_matmul_precision(ctx, level)`): "highest" (torch's default) = exact
     fp32 MFMA products; "high" / "medium" = every fp32 operand as the sum of two bf16 numbers, three bf16 MFMAs per product (one of torch's two documented
     forms of "high"; >= 16 mantissa bits against TF32's 10).  The reference sets "high" before training (`src/stamp/modeling/train.py:519`) and "medium"
     before deployment (`deploy.py:398`), so a drop-in run gets the bf16 x 3 products exactly where the reference asked torch for cheaper ones.  Called by every
     host entry point in front of `amds_bgemm_f32` (TransMIL / Nystrom, the MLP heads' training GEMMs)."""
     level = torch.get_float32_matmul_precision()
-    _lib.check(_lib.lib().amds_set_matmul_precision(0 if level == "highest" else 1), "set_matmul_precision")
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    _lib.check(_lib.lib().amds_set_matmul_precision(_lib.ctx(dev), 0 if level == "highest" else 1), "set_matmul_precision")
     return level
 
 
@@ -208,38 +209,6 @@ def attention_vit(qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int = 64)
     return out
 
 
-def gather_token_rows16(src: torch.Tensor, stat: torch.Tensor | None, B: int, T: int, row: int):
-    """Row `row` of every group of T rows of a 16-bit matrix [B*T, D] -> [B, D], with its row statistics [B*T, 2] -> [B, 2]."""
-    _dev(src, stat)
-    assert src.is_contiguous() and src.shape[0] == B * T and src.element_size() == 2
-    D = src.shape[1]
-    dst = torch.empty(B, D, dtype=src.dtype, device=src.device)
-    dstat = torch.empty(B, 2, dtype=torch.float32, device=src.device) if stat is not None else None
-    _lib.check(_lib.lib().amds_gather_token_rows16(_p(src), _p(stat), _p(dst), _p(dstat), B, T, D, row, _stream()), "gather_token_rows16")
-    return dst, dstat
-
-
-def qkv_attention_vit257(x: torch.Tensor, w_qkv: torch.Tensor, bias: torch.Tensor, B: int, H: int, *, rowstat=None, colsum=None, qkv_tail=None) -> torch.Tensor:
-    """The qkv Linear + attention of a ViT block as one kernel (T = 257, head_dim 64; include/amdstamp.h, amds_qkv_attention_vit257).  `qkv_tail`
-    [B*257, 3D] must hold the q | k | v row of every tile's token 256; when it is not given it is computed here the way vit.hip does it (gathered rows
-    through the ordinary GEMM)."""
-    _dev(x, w_qkv, bias, rowstat, colsum, qkv_tail)
-    D = H * 64
-    assert x.is_contiguous() and x.shape == (B * 257, D) and w_qkv.is_contiguous() and w_qkv.shape == (3 * D, D) and x.dtype == w_qkv.dtype
-    if qkv_tail is None:
-        qkv_tail = torch.empty(B * 257, 3 * D, dtype=x.dtype, device=x.device)
-        xt, st = gather_token_rows16(x, rowstat, B, 257, 256)
-        tail_rows = qkv_tail[256::257]
-        if rowstat is not None:
-            gemm_lnfold(xt, w_qkv, _lib.EPI_BIAS, out=tail_rows, bias=bias, rowstat=st, colsum=colsum)
-        else:
-            gemm(xt, w_qkv, _lib.EPI_BIAS, out=tail_rows, bias=bias, cfg=12)
-    out = torch.empty(B * 257, D, dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().amds_qkv_attention_vit257(_p(x), _p(w_qkv), _p(bias), _p(colsum), _p(rowstat), _p(qkv_tail), _p(out), B, H, D, act_code(x.dtype),
-                                                    _stream()), "qkv_attention_vit257")
-    return out
-
-
 def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     """softmax(q k^T / 8) v for any T (streaming K/V kernel); qkv [B*T, 3*H*64] -> [B*T, H*64]."""
     _dev(qkv)
@@ -249,11 +218,13 @@ def attention(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     return out
 
 
-def set_mil_cls_tail(on: bool) -> bool:
-    """Process-wide switch of the MIL `vit` head's class-row tail (`amds_set_mil_cls_tail`; default on): returns the previous setting."""
+def set_mil_cls_tail(on: bool, device: int | None = None) -> bool:
+    """The class-row tail of the MIL `vit` head / TransMIL deploy forward, a setting of the library's context of `device` (default: the current one;
+    `amds_set_mil_cls_tail(ctx, on)`; default on, AMDS_MIL_CLS_TAIL=0 turns the default off): returns the previous setting."""
     lib = _lib.lib()
-    prev = bool(lib.amds_get_mil_cls_tail())
-    _lib.check(lib.amds_set_mil_cls_tail(1 if on else 0), "set_mil_cls_tail")
+    cx = _lib.ctx(torch.cuda.current_device() if device is None else device)
+    prev = bool(lib.amds_get_mil_cls_tail(cx))
+    _lib.check(lib.amds_set_mil_cls_tail(cx, 1 if on else 0), "set_mil_cls_tail")
     return prev
 
 

@@ -48,7 +48,7 @@ def forward_infer_stepwise(pk: PackedVit, bags: torch.Tensor, coords: torch.Tens
         pad = torch.cat([mask.new_zeros(Bb, 1), mask], dim=1).to(dev, torch.uint8).contiguous()      # class token never padded (:356-358)
     hbuf = torch.zeros(M, d.Dp, dtype=act, device=dev) if d.Dp != d.D else None
     lib, st = _lib.lib(), ops._stream()
-    cls_tail = bool(_lib.lib().amds_get_mil_cls_tail()) and not d.alibi          # (a padding mask does not touch the class query's row: csrc/mil_vit.hip)
+    cls_tail = bool(_lib.lib().amds_get_mil_cls_tail(_lib.ctx(torch.cuda.current_device()))) and not d.alibi          # (a padding mask does not touch the class query's row: csrc/mil_vit.hip)
     n_layers = len(pk.m["layers"])
     for li, (Lm, Lw) in enumerate(zip(pk.m["layers"], pk.w["layers"])):
         h = _ln(x, M, d.D, d.Dp, *Lm["ln1"], act, d.Dp, hbuf)

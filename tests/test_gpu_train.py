@@ -518,7 +518,7 @@ def test_mil_vit_train_c_abi_guards(gpu):
     bags = torch.randn(2, 64, 512, device=gpu).half()
     out = torch.zeros(2, 2, device=gpu)
     small = torch.empty(4096, dtype=torch.uint8, device=gpu)
-    drop = _lib.MilVitDropout(0.0, 0.0, 0.0, 0)
+    drop = _lib.MilVitDropout(0.0, 0.0, 0.0, 0, -1)
     rc = lib.amds_mil_vit_train_forward(C.byref(cfg), C.byref(wc), bags.data_ptr(), _lib.F16, None, C.byref(drop), out.data_ptr(), 2, 64, small.data_ptr(), small.numel(), None)
     assert rc == -2 and b"arena" in lib.amds_last_error()
     with pytest.raises(RuntimeError, match="training pack"):
