@@ -256,6 +256,13 @@ int amds_attention_row(const void* q, long ldq, const void* qkv, void* out, long
  *        row qrow.  out / dout: the [B*T][H*64] tensors (only row qrow of each bag is read). */
 int amds_attention_row_fwd_train(const void* qkv, void* out, float* lse, int B, int T, int H, int qrow, int dtype, float p, uint64_t seed,
                                  uint32_t stream_id, void* stream);
+/* The same one-query pair for the ALiBi attention (reference vision_tranformer.py:42-74, mask = None so that the class row carries the distance term too):
+ * out = sum_k (p_k - bias_scale_h |c_q - c_k| / running_mean_h) v_k at row (bag, qrow) of out / u / osm [B*T][H*64] (u = the distance-weighted value sum, osm = the
+ * softmax part alone: what the backward needs); backward: dqkv [B*T][3*H*64] complete (zero dQ off the query row), dbs [B][H] = -dO . U (sum over bags = d bias_scale_h). */
+int amds_attention_row_alibi_fwd_train(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale, void* out, void* u, void* osm,
+                                       float* lse, int B, int T, int H, int qrow, int dtype, void* stream);
+int amds_attention_row_alibi_bwd_train(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords, const float* bias_scale,
+                                       const float* inv_running_mean, void* dqkv, float* dbs, int B, int T, int H, int qrow, int dtype, void* stream);
 int amds_attention_row_bwd_train(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T, int H, int qrow,
                                  int dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);
 /* Process-wide switch (default 1; AMDS_MIL_CLS_TAIL=0 in the environment starts at 0): the MIL `vit` head's last block computed for the class rows alone where the

@@ -328,6 +328,8 @@ PROTOTYPES = {
     "amds_gelu_dropout_fwd": (_i, [_vp, _vp, _l, _i, _i, _f, _u64, _u32, _vp]),
     "amds_gelu_dropout_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _f, _u64, _u32, _vp]),
     "amds_dropout_add": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _f, _u64, _u32, _vp]),
+    "amds_attention_row_alibi_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amds_attention_row_alibi_bwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amds_gelu_dropout_fwd_rows": (_i, [_vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_gelu_dropout_bwd_rows": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),
     "amds_dropout_add_rows": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _l, _f, C.c_uint64, C.c_uint32, _vp]),

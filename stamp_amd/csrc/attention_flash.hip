@@ -463,6 +463,179 @@ __global__ void __launch_bounds__(256) attn_row_bwd_kernel(const T* __restrict__
     }
 }
 
+// ---- the one-query attention WITH the ALiBi distance term (training; reference vision_tranformer.py:42-74 with mask = None, i.e. alibi_mask = None: the class
+// row carries the term too, :349-351 puts the class token at (0, 0)):  out = sum_k (p_k - bias_scale_h d_k) v_k,  d_k = |c_q - c_k| / running_mean_h.
+// Saves, like the blocked kernel, the softmax part Osm = sum_k p_k v_k and U = sum_k d_k v_k (rows of the (bag, qrow) token) and the log-sum-exp.  fp32 distances
+// (the blocked kernel rounds them to 16 bits for its MFMA).  No dropout: nn.MultiheadAttention's rate does not exist on the ALiBi path (:124-154).
+template <typename T>
+__global__ void __launch_bounds__(256) attn_row_alibi_kernel(const T* __restrict__ qkv, const float* __restrict__ coords, const float* __restrict__ inv_rm,
+                                                             const float* __restrict__ bias_scale, T* __restrict__ out, T* __restrict__ u_out, T* __restrict__ osm_out,
+                                                             float* __restrict__ lse, int Tn, int H, int qrow) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    extern __shared__ __attribute__((aligned(16))) float sS[];          // [Tn] scores -> weights | [Tn] scaled distances | 2 x [16][64] partial sums | [8] reductions
+    const int Tp = (Tn + 3) & ~3;
+    float* sD = sS + Tp;
+    float* sRed = sD + Tp;
+    float* sW = sRed + 2 * 16 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int Dm = H * 64;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * 64;
+    const float* cb = coords + (long)b * Tn * 2;
+    const float xq = cb[2 * qrow], yq = cb[2 * qrow + 1], irm = inv_rm[h];
+    const int sub = tid & 7, kk = tid >> 3;
+    float qc[8];
+    {
+        const vec8 v = *reinterpret_cast<const vec8*>(base + (long)qrow * ld + sub * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qc[e] = Act<T>::to_f32(v[e]);
+    }
+    const float sc = 0.125f * 1.44269504088896340736f;
+    float mx = -INFINITY;
+    for (int key = kk; key < Tn; key += 32) {
+        const vec8 v = *reinterpret_cast<const vec8*>(base + (long)key * ld + Dm + sub * 8);
+        float a0 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a0 = fmaf(qc[e], Act<T>::to_f32(v[e]), a0);
+        const float sv = sum8_dpp(a0) * sc;
+        if (sub == 0) {
+            sS[key] = sv;
+            const float dx = xq - cb[2 * key], dy = yq - cb[2 * key + 1];
+            sD[key] = sqrtf(dx * dx + dy * dy) * irm;
+        }
+        mx = fmaxf(mx, sv);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sW[wave] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(sW[0], sW[1]), fmaxf(sW[2], sW[3]));
+    float ls = 0.f;
+    for (int key = tid; key < Tn; key += 256) {
+        const float pw = __builtin_amdgcn_exp2f(sS[key] - m);
+        sS[key] = pw;
+        ls += pw;
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) sW[4 + wave] = ls;
+    __syncthreads();
+    const float l = (sW[4] + sW[5]) + (sW[6] + sW[7]);
+    if (tid == 0) lse[((long)b * H + h) * Tn + qrow] = m + log2f(l);
+    const int d4 = (tid & 15) * 4, ph = tid >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acu = {0.f, 0.f, 0.f, 0.f};
+    for (int key = ph; key < Tn; key += 16) {
+        const vec4 v = *reinterpret_cast<const vec4*>(base + (long)key * ld + 2 * Dm + d4);
+        const float pw = sS[key], dk = sD[key];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float vf = Act<T>::to_f32(v[e]);
+            acc[e] = fmaf(pw, vf, acc[e]);
+            acu[e] = fmaf(dk, vf, acu[e]);
+        }
+    }
+    *reinterpret_cast<f32x4*>(sRed + ph * 64 + d4) = acc;
+    *reinterpret_cast<f32x4*>(sRed + 1024 + ph * 64 + d4) = acu;
+    __syncthreads();
+    if (tid < 64) {
+        float o = 0.f, uu = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { o += sRed[k * 64 + tid]; uu += sRed[1024 + k * 64 + tid]; }
+        o /= l;
+        const long at = ((long)b * Tn + qrow) * Dm + h * 64 + tid;
+        out[at] = Act<T>::from_f32(o - bias_scale[h] * uu);
+        u_out[at] = Act<T>::from_f32(uu);
+        osm_out[at] = Act<T>::from_f32(o);
+    }
+}
+
+// Its backward when no other query row of the block has a gradient: dV_k = (p_k - dist_scale_h d_k) dO with dist_scale_h = bias_scale_h / running_mean_h folded
+// into d_k's factor below, dS_k = p_k (dO . v_k - dO . Osm), dK_k = dS_k q / 8, dQ = sum_k dS_k k_k / 8 on the query row alone, and
+// dbs[b][h] = - dO . U: summed over the bags it is the gradient of bias_scale_h.
+template <typename T>
+__global__ void __launch_bounds__(256) attn_row_alibi_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ osm, const T* __restrict__ u, const T* __restrict__ dout,
+                                                                 const float* __restrict__ lse, const float* __restrict__ coords, const float* __restrict__ bias_scale,
+                                                                 const float* __restrict__ inv_rm, T* __restrict__ dqkv, float* __restrict__ dbs, int Tn, int H, int qrow) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    extern __shared__ __attribute__((aligned(16))) float sS[];          // [Tn] dS | [16][64] partial dq
+    float* sRed = sS + ((Tn + 3) & ~3);
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int Dm = H * 64;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * 64;
+    T* dbase = dqkv + (long)b * Tn * ld + h * 64;
+    const float* cb = coords + (long)b * Tn * 2;
+    const float xq = cb[2 * qrow], yq = cb[2 * qrow + 1], dsc = bias_scale[h] * inv_rm[h];
+    const int sub = tid & 7, kk = tid >> 3;
+    float qc[8], gc[8];
+    float Dq = 0.f, gu = 0.f;
+    {
+        const long at = ((long)b * Tn + qrow) * Dm + h * 64 + sub * 8;
+        const vec8 qv = *reinterpret_cast<const vec8*>(base + (long)qrow * ld + sub * 8);
+        const vec8 gv = *reinterpret_cast<const vec8*>(dout + at);
+        const vec8 ov = *reinterpret_cast<const vec8*>(osm + at);
+        const vec8 uv = *reinterpret_cast<const vec8*>(u + at);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qc[e] = Act<T>::to_f32(qv[e]);
+            gc[e] = Act<T>::to_f32(gv[e]);
+            Dq = fmaf(gc[e], Act<T>::to_f32(ov[e]), Dq);
+            gu = fmaf(gc[e], Act<T>::to_f32(uv[e]), gu);
+        }
+        Dq = sum8_dpp(Dq);
+        gu = sum8_dpp(gu);
+    }
+    if (tid == 0) dbs[(long)b * H + h] = -gu;
+    const float sc = 0.125f * 1.44269504088896340736f;
+    const float L = lse[((long)b * H + h) * Tn + qrow];
+    for (int key = kk; key < Tn; key += 32) {
+        const T* krow = base + (long)key * ld + Dm + sub * 8;
+        const vec8 kv = *reinterpret_cast<const vec8*>(krow), vv = *reinterpret_cast<const vec8*>(krow + Dm);
+        float s0 = 0.f, p0 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s0 = fmaf(qc[e], Act<T>::to_f32(kv[e]), s0);
+            p0 = fmaf(gc[e], Act<T>::to_f32(vv[e]), p0);
+        }
+        s0 = sum8_dpp(s0);
+        p0 = sum8_dpp(p0);
+        const float pk = __builtin_amdgcn_exp2f(s0 * sc - L);
+        const float dx = xq - cb[2 * key], dy = yq - cb[2 * key + 1];
+        const float dS = pk * (p0 - Dq), pw = pk - dsc * sqrtf(dx * dx + dy * dy), dk = dS * 0.125f;
+        if (sub == 0) sS[key] = dS;
+        T* drow = dbase + (long)key * ld + sub * 8;
+        vec8 wq, wk, wv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wq[e] = (T)0.f;
+            wk[e] = Act<T>::from_f32(dk * qc[e]);
+            wv[e] = Act<T>::from_f32(pw * gc[e]);
+        }
+        if (key != qrow) *reinterpret_cast<vec8*>(drow) = wq;
+        *reinterpret_cast<vec8*>(drow + Dm) = wk;
+        *reinterpret_cast<vec8*>(drow + 2 * Dm) = wv;
+    }
+    __syncthreads();
+    const int d4 = (tid & 15) * 4, ph = tid >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int key = ph; key < Tn; key += 16) {
+        const vec4 kv = *reinterpret_cast<const vec4*>(base + (long)key * ld + Dm + d4);
+        const float dS = sS[key];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(dS, Act<T>::to_f32(kv[e]), acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(sRed + ph * 64 + d4) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float dq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dq += sRed[k * 64 + tid];
+        dbase[(long)qrow * ld + tid] = Act<T>::from_f32(dq * 0.125f);
+    }
+}
+
 }  // namespace amds
 
 using namespace amds;
@@ -549,6 +722,50 @@ extern "C" int amds_attention_row_bwd_train(const void* qkv, const void* out, co
     else { if (p > 0.f) AMDS_ROW_BWD(bf16, true, 2); else AMDS_ROW_BWD(bf16, false, 3); }
 #undef AMDS_ROW_BWD
     AMDS_LAUNCH_CHECK("attn_row_bwd_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_row_alibi_fwd_train(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale, void* out, void* u,
+                                                  void* osm, float* lse, int B, int T, int H, int qrow, int dtype, void* stream) {
+    AMDS_REQUIRE(qkv && coords && inv_running_mean && bias_scale && out && u && osm && lse, "amds_attention_row_alibi_fwd_train: null pointer");
+    AMDS_REQUIRE(B >= 0 && T > 0 && T <= 16384 && H > 0 && H <= 65535 && B <= 65535 && qrow >= 0 && qrow < T, "amds_attention_row_alibi_fwd_train: bad arguments B=%d T=%d H=%d row=%d",
+                 B, T, H, qrow);
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_attention_row_alibi_fwd_train: bad dtype %d", dtype);
+    if (B == 0) return AMDS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)2 * ((T + 3) & ~3) + 2 * 16 * 64 + 8) * 4;
+    static bool attr[2] = {false, false};
+    if (dtype == AMDS_F16) {
+        if (!attr[0]) { AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_alibi_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr[0] = true; }
+        hipLaunchKernelGGL((attn_row_alibi_kernel<f16>), dim3(H, B), dim3(256), lds, st, (const f16*)qkv, coords, inv_running_mean, bias_scale, (f16*)out, (f16*)u, (f16*)osm, lse, T, H, qrow);
+    } else {
+        if (!attr[1]) { AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_alibi_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr[1] = true; }
+        hipLaunchKernelGGL((attn_row_alibi_kernel<bf16>), dim3(H, B), dim3(256), lds, st, (const bf16*)qkv, coords, inv_running_mean, bias_scale, (bf16*)out, (bf16*)u, (bf16*)osm, lse, T, H, qrow);
+    }
+    AMDS_LAUNCH_CHECK("attn_row_alibi_kernel");
+    return AMDS_OK;
+}
+
+extern "C" int amds_attention_row_alibi_bwd_train(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords,
+                                                  const float* bias_scale, const float* inv_running_mean, void* dqkv, float* dbs, int B, int T, int H, int qrow, int dtype,
+                                                  void* stream) {
+    AMDS_REQUIRE(qkv && osm && u && dout && lse && coords && bias_scale && inv_running_mean && dqkv && dbs, "amds_attention_row_alibi_bwd_train: null pointer");
+    AMDS_REQUIRE(B > 0 && T > 0 && T <= 32768 && H > 0 && H <= 65535 && B <= 65535 && qrow >= 0 && qrow < T, "amds_attention_row_alibi_bwd_train: bad arguments B=%d T=%d H=%d row=%d",
+                 B, T, H, qrow);
+    AMDS_REQUIRE(dtype == AMDS_F16 || dtype == AMDS_BF16, "amds_attention_row_alibi_bwd_train: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)((T + 3) & ~3) + 16 * 64) * 4;
+    static bool attr[2] = {false, false};
+    if (dtype == AMDS_F16) {
+        if (!attr[0]) { AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_alibi_bwd_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr[0] = true; }
+        hipLaunchKernelGGL((attn_row_alibi_bwd_kernel<f16>), dim3(H, B), dim3(256), lds, st, (const f16*)qkv, (const f16*)osm, (const f16*)u, (const f16*)dout, lse, coords, bias_scale,
+                           inv_running_mean, (f16*)dqkv, dbs, T, H, qrow);
+    } else {
+        if (!attr[1]) { AMDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_row_alibi_bwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr[1] = true; }
+        hipLaunchKernelGGL((attn_row_alibi_bwd_kernel<bf16>), dim3(H, B), dim3(256), lds, st, (const bf16*)qkv, (const bf16*)osm, (const bf16*)u, (const bf16*)dout, lse, coords,
+                           bias_scale, inv_running_mean, (bf16*)dqkv, dbs, T, H, qrow);
+    }
+    AMDS_LAUNCH_CHECK("attn_row_alibi_bwd_kernel");
     return AMDS_OK;
 }
 

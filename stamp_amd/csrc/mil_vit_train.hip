@@ -212,15 +212,15 @@ int gelu_drop_bwd(const void* z, const void* du, void* dz, long n, int zdt, int 
 
 constexpr int CFG_TRAIN = -2;      // amds_gemm_ex: by shape, ragged last row tile as its own small launch (M = bags x 1025 is never a multiple of 256)
 
-// the last block on its class rows alone (amds_mil_vit_dropout.cls_tail, else the context's amds_set_mil_cls_tail; not with ALiBi: its attention has no one-query
-// form).  The pitched rows (a class row every S rows) must fit the 32-bit buffer descriptors of the GEMMs AND of the token-major weight-gradient kernel, which spans
+// the last block on its class rows alone (amds_mil_vit_dropout.cls_tail, else the context's amds_set_mil_cls_tail; with ALiBi the one-query kernel carries the
+// distance term: amds_attention_row_alibi_fwd_train).  The pitched rows (a class row every S rows) must fit the 32-bit buffer descriptors of the GEMMs AND of the token-major weight-gradient kernel, which spans
 // chunk + 63 rows of pitch S * width 16-bit elements per split (amds_wgrad_tn: chunk = 64 for Bb <= 64 split_k) -- a bag of 8192 tiles with dim_feedforward 2048 passes
 // the first bound and not the second: such shapes take the full-block path.
 bool cls_tail(const Dims& d, int want) {
     const bool on = want < 0 ? ctx_mil_cls_tail() != 0 : want != 0;
     const long wide = std::max(std::max(d.FFp, 3 * d.Da), d.Dp);
     const long chunk = (d.Bb + 63) / 64 * 64;
-    return on && !d.alibi && d.L > 0 && d.S <= 32768 && (long)(d.Bb + 1) * d.S * wide * 4 < (1L << 31) && (chunk + 63) * d.S * wide * 2 < (1L << 31);
+    return on && d.L > 0 && d.S <= (d.alibi ? 16384 : 32768) && (long)(d.Bb + 1) * d.S * wide * 4 < (1L << 31) && (chunk + 63) * d.S * wide * 2 < (1L << 31);
 }
 
 int gemm_dt(int dt, const void* A, long lda, const void* W, long ldw, long M, int N, int K, int epi, void* out, long ldo, const float* bias, void* st) {
@@ -334,7 +334,8 @@ extern "C" int amds_mil_vit_train_forward(const amds_mil_vit_cfg* cfg_host, cons
             RC(gemm(h1, Dp, reinterpret_cast<const char*>(Lw.in_w) + (size_t)Da * Dp * 2, Dp, M, 2 * Da, Dp, AMDS_EPI_BIAS, reinterpret_cast<char*>(qkv) + (size_t)Da * 2,
                     3 * Da, Lw.in_b + Da, stream));
             RC(gemm(h1, pS * Dp, Lw.in_w, Dp, Bb, Da, Dp, AMDS_EPI_BIAS, qkv, pS * 3 * Da, Lw.in_b, stream));
-            RC(amds_attention_row_fwd_train(qkv, att, lse, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
+            if (d.alibi) RC(amds_attention_row_alibi_fwd_train(qkv, cc, Lw.inv_running_mean, Lw.bias_scale, att, sv + o.u_al, sv + o.osm, lse, Bb, S, Ha, 0, BF, stream));
+            else RC(amds_attention_row_fwd_train(qkv, att, lse, Bb, S, Ha, 0, BF, p_att, seed, 10 * l + 1, stream));
             RC(gemm(att, pS * Da, Lw.out_w, Da, Bb, Dp, Da, AMDS_EPI_RESIDUAL, x_mid, pS * Dp, Lw.out_b, stream));
             RC(amds_layernorm_train_copy(x_mid, pS * Dp, Lw.ln2_w, Lw.ln2_b, h2, pS * Dp, reinterpret_cast<float*>(sv + o.mu2), reinterpret_cast<float*>(sv + o.rs2), Bb, D,
                                          1e-5f, BF, p_ff > 0.f ? nullptr : x_out, pS * Dp, Dp, stream));
@@ -624,7 +625,14 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         }
         }
         float* dqs = reinterpret_cast<float*>(wk + wp.dqs);
-        if (d.alibi) {
+        if (d.alibi && tail) {
+            // one query per (bag, head): dbs [Bb][Ha] = -dO . U, summed over the bags = the gradient of bias_scale_h
+            float* dbs = reinterpret_cast<float*>(wk + wp.dbsp);
+            AMDS_REQUIRE(Lw.inv_running_mean && Lw.bias_scale, "amds_mil_vit_train_backward: layer %d has no ALiBi scales", l);
+            RC(amds_attention_row_alibi_bwd_train(qkv, sv + o.osm, sv + o.u_al, datt, lse, reinterpret_cast<const float*>(sv + sp.cc), Lw.bias_scale, Lw.inv_running_mean,
+                                                  dqkv, dbs, Bb, S, Ha, 0, BF, stream));
+            if (need_params) RC(colsum(dbs, Ha, Gl->bias_scale, Bb, Ha, AMDS_F32));
+        } else if (d.alibi) {
             float* dbsp = reinterpret_cast<float*>(wk + wp.dbsp);
             AMDS_REQUIRE(Lw.head_scale && Lw.bias_scale, "amds_mil_vit_train_backward: layer %d has no ALiBi scales", l);     // head_scale = dist_scale
             RC(attention_alibi_bwd_dt(qkv, sv + o.osm, sv + o.u_al, datt, lse, reinterpret_cast<const float*>(sv + sp.cc), Lw.bias_scale, Lw.head_scale, dqs, dbsp,

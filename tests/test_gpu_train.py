@@ -456,6 +456,66 @@ def test_mil_vit_train_class_row_tail_equals_the_full_last_block(gpu, dims, p_dr
     assert _rel2(dbt, dbf) < 8e-3
 
 
+@pytest.mark.parametrize("act", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dims,p_drop,Tn,L", [((512, 512, 8, 512), 0.25, 1024, 2), ((456, 132, 4, 135), 0.1, 211, 2), ((256, 256, 4, 256), 0.0, 3, 1)])
+def test_mil_vit_train_alibi_class_row_tail_equals_the_full_last_block(gpu, dims, p_drop, Tn, L, act):
+    """The class-row tail of the ALiBi head (round 6): with mask = None -- every Lightning step, models/__init__.py:252 -- `alibi_mask` is None, so the class query's row is
+    out_0 = sum_k (p_k - bias_scale |c_k| / running_mean) v_k with the class token at (0, 0) (vision_tranformer.py:60-72, 349-351): amds_attention_row_alibi_fwd_train /
+    _bwd_train.  Against the full last block on the same inputs, seed and dropout counters: logits, EVERY gradient -- bias_scale of the last layer included, a sum of one
+    -dO . U term per bag -- and the bag gradient.  Tolerance as the plain head's tail test (the blocked kernel rounds probabilities and distances to 16 bits in front of
+    its MFMAs, the row kernel keeps them fp32): 8e-3 relative L2 (1.6e-2 for the 8 bias_scale scalars), + an absolute floor for numerically-zero tensors."""
+    from stamp_amd import mil_core, ops
+    from stamp_amd.mil import VisionTransformer
+    F, D, H, FF = dims
+    torch.manual_seed(F + D + Tn)
+    model = VisionTransformer(dim_output=3, dim_input=F, dim_model=D, n_layers=L, n_heads=H, dim_feedforward=FF, dropout=p_drop, use_alibi=True)
+    sd = {k: v.detach().to(gpu, torch.float32) for k, v in model.state_dict().items()}
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = sd[k] * 0 + 9000.0                   # the scale of the distances below (a trained scaler's state)
+    pk = mil_core.PackedVit(model.dims, lambda n: sd[n], act, train=True)
+    Bb = 3
+    bags = torch.randn(Bb, Tn, F).half().to(gpu)
+    coords = ((torch.rand(Bb, Tn, 2) * 2e4 / 256).round() * 256).to(gpu)
+    dlogits = torch.randn(Bb, 3, device=gpu)
+    res = {}
+    was = ops.set_mil_cls_tail(True)
+    try:
+        for tail in (True, False):
+            ops.set_mil_cls_tail(tail)
+            lg, sv = mil_core.forward_train(pk, bags, coords, training=p_drop > 0, seed=77)
+            G, db = mil_core.backward(pk, sv, dlogits, need_params=True, need_bags=True)
+            res[tail] = (lg.clone(), {k: v.clone() for k, v in G.items()}, db.clone())
+    finally:
+        ops.set_mil_cls_tail(was)
+    (lt, Gt, dbt), (lf, Gf, dbf) = res[True], res[False]
+    assert torch.isfinite(lt).all() and (lt - lf).abs().max().item() < 1e-2 * max(1.0, lf.abs().max().item())
+    # Judged as tests/test_gpu_mil_seam.py judges the bench-size step: key-encoder biases have a zero true gradient (a constant added to every score of a row) and
+    # hold rounding noise on both paths; q / k encoder gradients are small differences of large terms and are measured against 5 % of the sibling value-encoder
+    # gradient; the 8 bias_scale scalars of a layer are one vector.
+    worst, bsg = [], {}
+    for k in Gf:
+        if "key_encoders" in k and k.endswith(".bias"):
+            continue
+        a, b = Gt[k].double().reshape(-1), Gf[k].double().reshape(-1)
+        assert torch.isfinite(a).all(), k
+        if k.endswith("bias_scale"):
+            ga, gb = bsg.setdefault(k.split(".mhsa.")[0], ([], []))
+            ga.append(a), gb.append(b)
+            continue
+        floor = 1e-5
+        if "query_encoders" in k or "key_encoders" in k:
+            floor = max(floor, 0.05 * Gf[k.replace("query_encoders", "value_encoders").replace("key_encoders", "value_encoders")].double().norm().item())
+        worst.append(((a - b).norm().item() / max(b.norm().item(), floor), k))
+    for layer, (ga, gb) in bsg.items():
+        worst.append((_rel2(torch.cat(ga), torch.cat(gb)), layer + ".mhsa.attentions.*.bias_scale"))
+    worst.sort(reverse=True)
+    print("ALiBi class-row tail vs full last block, largest gradient differences:", [(round(a, 6), b) for a, b in worst[:4]], "bags", round(_rel2(dbt, dbf), 6))
+    for r, k in worst:
+        assert r < (1.6e-2 if "bias_scale" in k else 8e-3), (k, r)
+    assert (dbt.double() - dbf.double()).norm().item() < 8e-3 * dbf.double().norm().item() + 1e-5
+
+
 @pytest.mark.parametrize("L,Bb,Tn,p_drop", [(1, 1, 1, 0.0), (1, 2, 300, 0.25), (3, 2, 65, 0.1), (2, 5, 2, 0.0)])
 def test_mil_vit_class_row_tail_edge_shapes(gpu, L, Bb, Tn, p_drop):
     """The class-row tail on the shapes its row pitches could get wrong: a single block (the tail IS the model), one bag, one tile per bag (S = 2), three blocks; training
