@@ -331,8 +331,8 @@ __global__ void __launch_bounds__(256) bgemm_f32_big_kernel(const float* __restr
 // (k-major operands: [16 k pairs][rows + 8][2], written as ds_write_b128 of four rows' pairs: a thread fetches the float4 of k and of k + 1).  Only products whose
 // tiles are all interior and aligned (M % BM == N % BN == K % 32 == 0, float4 loads) come here -- every Nystrom / pinv / projection shape; the rest stays on the
 // kernel above.  Same epilogue (alpha, + diag I, bias, accumulate), same tile shapes and XCD order.
-template <int TRANSB, int TRANSA, int WM, int WN, bool DUAL = false>
-__global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__ A, int lda, long sAo, long sAi, const float* __restrict__ B, int ldb, long sBo,
+template <int TRANSB, int TRANSA, int WM, int WN, bool DUAL = false, bool ACC = false>
+__global__ void __launch_bounds__(256, 2) bgemm_x3_kernel(const float* __restrict__ A, int lda, long sAo, long sAi, const float* __restrict__ B, int ldb, long sBo,
                                                        long sBi, float* __restrict__ Cm, int ldc, long sCo, long sCi, int inner, int M, int N, int K, float alpha,
                                                        float diag, const float* __restrict__ bias, int accumulate, int xcd, BgDual dual) {
     static_assert(WM * WN == 4, "four waves");
@@ -489,6 +489,16 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
             const int n = n0 + wn * 64 + j * 32 + l31;
             const float bn = bias ? bias[n] : 0.f;
             float* cn = Cm + n;
+            // ACC (C += ...): the 32 old values of this column block first.  Read-add-store per element made every load wait for the store in front of it (same pointer:
+            // the compiler cannot reorder them) -- 64 dependent round trips per lane, 205 us for a 512 x 256^3 product against 90 us without the flag (round 6 trace).
+            // A template parameter, not the runtime flag: the 32 registers must not exist in the plain instance (242 VGPRs and one workgroup per CU when they did).
+            float old[2][16];
+            if constexpr (ACC) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[i][r] = cn[(long)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * ldc];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -496,7 +506,7 @@ __global__ void __launch_bounds__(256) bgemm_x3_kernel(const float* __restrict__
                     const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     float v = alpha * acc[i][j][r] + bn;
                     if (DG) v += m == n ? diag : 0.f;
-                    if (accumulate) v += cn[(long)m * ldc];
+                    if constexpr (ACC) v += old[i][r];
                     cn[(long)m * ldc] = v;
                 }
         }
@@ -1188,9 +1198,15 @@ static int bgemm_f32_at(int precision, const float* A, int lda, long sAo, long s
         static const bool x3_lds = !(getenv("AMDS_BGEMM_X3_LDS") && atoi(getenv("AMDS_BGEMM_X3_LDS")) == 0);
         const int bm = shape == 1 ? 256 : shape == 2 ? 64 : 128, bn = shape == 1 ? 64 : shape == 2 ? 256 : 128;
         if (x3 && x3_lds && vec_ok && M % bm == 0 && N % bn == 0 && K % 32 == 0) {
-#define AMDS_BX(TB, TA, WM_, WN_) \
-    hipLaunchKernelGGL((bgemm_x3_kernel<TB, TA, WM_, WN_>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, N, K, alpha, \
-                       diag, bias, accumulate, xcd, dual)
+#define AMDS_BX(TB, TA, WM_, WN_)                                                                                                                                  \
+    do {                                                                                                                                                          \
+        if (accumulate)                                                                                                                                           \
+            hipLaunchKernelGGL((bgemm_x3_kernel<TB, TA, WM_, WN_, false, true>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, \
+                               N, K, alpha, diag, bias, accumulate, xcd, dual);                                                                                   \
+        else                                                                                                                                                      \
+            hipLaunchKernelGGL((bgemm_x3_kernel<TB, TA, WM_, WN_, false, false>), grid3, dim3(256), 0, st, A, lda, sAo, sAi, B, ldb, sBo, sBi, Cm, ldc, sCo, sCi, inner, M, \
+                               N, K, alpha, diag, bias, accumulate, xcd, dual);                                                                                   \
+    } while (0)
 #define AMDS_BX_SHAPE(TB, TA)                                     \
     do {                                                          \
         if (shape == 1) AMDS_BX(TB, TA, 4, 1);                    \

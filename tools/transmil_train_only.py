@@ -24,10 +24,12 @@ def step():
     loss = torch.nn.functional.cross_entropy(tm(bags), tg)
     loss.backward()
     opt.step()
-    return loss
+    return loss.detach()        # (an attached loss pins the step's 15 GB arena: bench.py's note)
 
 
-step(); torch.cuda.synchronize()
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     l = step()
