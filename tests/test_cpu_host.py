@@ -367,7 +367,7 @@ def test_docs_cite_existing_symbols_and_lines():
     for p in ref.rglob("*.py"):
         by_name.setdefault(p.name, []).append(p)
     bad = []
-    docs = [ROOT / "INTEGRATION.md", ROOT / "DESIGN.md", ROOT / "README.md", ROOT / "include" / "amdstamp.h"]
+    docs = [ROOT / "INTEGRATION.md", ROOT / "DESIGN.md", ROOT / "README.md", ROOT / "include" / "amdstamp.h"] + sorted((ROOT / "docs" / "rounds").glob("*.md"))
     docs += sorted((ROOT / "stamp_amd").glob("*.py")) + sorted((ROOT / "oracle").glob("*.py")) + sorted((ROOT / "stamp_amd" / "csrc").glob("*.h*"))
     for d in docs:
         for m in re.finditer(r"([A-Za-z_][\w/\.]*\.py):(\d+)(?:[-–](\d+))?((?:,\s*\d+(?:[-–]\d+)?)*)", d.read_text()):
