@@ -470,10 +470,24 @@ class ClockPowerSampler:
 
     def __init__(self, local_rank: int = 0, period: float = 0.02):
         import glob
-        self.files = None
+        import os
+        self.files, self.picked_by = None, None
         cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
         if cards:
-            f = cards[min(local_rank, len(cards) - 1)]
+            # a box can expose more cards in sysfs than the one this process may use (a shared 8-GPU node): match this rank's device by PCI address;
+            # without one, the visible-device index
+            f = None
+            try:
+                pr = torch.cuda.get_device_properties(local_rank)
+                want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+                for c in cards:
+                    if os.path.basename(os.path.realpath(c.split("/hwmon/")[0])).startswith(want):
+                        f, self.picked_by = c, "pci " + want + "0"
+                        break
+            except Exception:
+                f = None
+            if f is None:
+                f, self.picked_by = cards[min(local_rank, len(cards) - 1)], "index"
             self.files = (f, f.replace("freq1_input", "power1_input"))
         self.period, self.samples, self._stop, self._th = period, [], False, None
 
@@ -507,7 +521,7 @@ class ClockPowerSampler:
         clk = [c for c, _ in self.samples]
         pw = [w for _, w in self.samples if w is not None]
         return {"sclk_mhz": round(sum(clk) / len(clk), 1) if clk else None, "sclk_mhz_min": round(min(clk), 1) if clk else None,
-                "socket_w": round(sum(pw) / len(pw), 1) if pw else None, "socket_w_max": round(max(pw), 1) if pw else None, "samples": len(clk)}
+                "socket_w": round(sum(pw) / len(pw), 1) if pw else None, "socket_w_max": round(max(pw), 1) if pw else None, "samples": len(clk), "card": self.picked_by}
 
 
 def gated_pool_leg(dev) -> dict:
@@ -809,7 +823,7 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary of the
     # two rocprofv3 --pmc passes over this same workload (profiles/*_pmc_gemm_traffic.json, tools/pmc_summary.py) is reported
     traffic, pmc_name = None, None
-    for pmc_file in (ROOT / "profiles" / "r05_pmc_gemm_traffic.json", ROOT / "profiles" / "r04_pmc_gemm_traffic.json", ROOT / "profiles" / "r03_pmc_gemm_traffic.json", ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
+    for pmc_file in (ROOT / "profiles" / "r06_pmc_gemm_traffic.json", ROOT / "profiles" / "r05_pmc_gemm_traffic.json", ROOT / "profiles" / "r04_pmc_gemm_traffic.json", ROOT / "profiles" / "r03_pmc_gemm_traffic.json", ROOT / "profiles" / "r02_pmc_gemm_traffic.json", ROOT / "profiles" / "r01_pmc_gemm_traffic.json"):
         if not is_swin and a.model == "vit_large_patch14_224" and a.chunk == 1020 and pmc_file.is_file():
             try:
                 traffic, pmc_name = json.loads(pmc_file.read_text())["traffic_bytes_per_launch"], pmc_file.name

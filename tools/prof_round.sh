@@ -1,6 +1,6 @@
 # Evidence of a round, one gpurun call:  gpurun --timeout 3000 -- 'bash tools/prof_round.sh r04'
 # Writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -37,4 +37,10 @@ DB=$(find /tmp/kt -name "*.db" | head -1); [ -n "$DB" ] && timeout 60 python $R/
 tail -1 /tmp/kt.log >> $O/${TAG}_rocprofv3_mil_train_kernel_stats.txt
 timeout 300 rocprofv3 --kernel-trace -d /tmp/sl -o sl -- python $R/tools/slide_only.py 12288 vit_large_patch14_224 canny 32 64 > /tmp/sl.log 2>&1 < /dev/null
 DB=$(find /tmp/sl -name "*.db" | head -1); [ -n "$DB" ] && (cd $R/tools && timeout 60 python rocprof_gaps.py "$DB" 1000 > $O/${TAG}_slide_pipeline_gaps.txt); tail -1 /tmp/sl.log >> $O/${TAG}_slide_pipeline_gaps.txt
+# 6. gated-attention pooling: A/B of the fused launch against the six-launch form, kernel trace of both
+timeout 300 python $R/tools/gap_only.py > $O/${TAG}_gap_ab.json 2>> $O/${TAG}_bench_err.log
+timeout 300 rocprofv3 --kernel-trace -d /tmp/kg -o kg -- python $R/tools/gap_only.py --trace > /tmp/kg.log 2>&1 < /dev/null
+DB=$(find /tmp/kg -name "*.db" | head -1); [ -n "$DB" ] && timeout 60 python $R/tools/rocprof_summary.py "$DB" --by-shape > $O/${TAG}_gap_kernel_trace.txt
+# 7. TransMIL training step
+bash $R/tools/r06_transmil_trace.sh
 cut -c1-400 $O/${TAG}_bench_default.json
