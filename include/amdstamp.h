@@ -927,7 +927,13 @@ int amds_ppeg(const float* x, float* y, const float* w7, const float* b7, const 
 /* The whole deploy / validation forward of the TransMIL head as one call (reference src/stamp/modeling/models/trans_mil.py:299-326 in eval
  * mode; called from the same Lightning steps as the `vit` head, models/__init__.py:288-313): fp32 throughout.  heads = 8, landmarks =
  * dim / 2, 6 pseudo-inverse iterations, 33-tap residual convolution (:252-254, :52). */
-typedef struct { int n_feats; int dim; int classes; } amds_transmil_cfg;      /* dim_input, dim_hidden (multiple of 8), dim_output */
+typedef struct {
+    int n_feats; int dim; int classes;             /* dim_input, dim_hidden (multiple of 8), dim_output */
+    int train_cls_tail;                            /* amds_transmil_train_forward / _backward only: 1 = layer2's attention output, to_out, Dropout and their backward
+                                                    * run on the class rows alone (only x[:, 0] is read after layer2, trans_mil.py:322-325; same values as 0 = every
+                                                    * row, to fp32 rounding of the reordered sums); -1 = ask the context (amds_set_mil_cls_tail).  The two calls of one
+                                                    * step must agree: the saved arena's layout follows it.  The inference forward ignores it (context setting). */
+} amds_transmil_cfg;
 typedef struct {
     const float* norm_w; const float* norm_b;      /* [dim]            layerN.norm                       :248 */
     const float* qkv_w;                            /* [3 dim][dim]     layerN.attn.to_qkv (no bias)      :64 */

@@ -100,7 +100,7 @@ class MilVitGrads(C.Structure):
 
 
 class TransMilCfg(C.Structure):
-    _fields_ = [("n_feats", C.c_int), ("dim", C.c_int), ("classes", C.c_int)]
+    _fields_ = [("n_feats", C.c_int), ("dim", C.c_int), ("classes", C.c_int), ("train_cls_tail", C.c_int)]
 
 
 class TransMilLayer(C.Structure):

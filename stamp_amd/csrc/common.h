@@ -338,6 +338,10 @@ int attention_alibi_fwd_train_dt(const void* qkv, const float* coords, const flo
                                  int B, int T, int H, int dtype, void* stream);
 int attention_alibi_bwd_dt(const void* qkv, const void* osm, const void* u, const void* dout, const float* lse, const float* coords, const float* bias_scale,
                            const float* dist_scale, float* dq_sum_ws, float* dbs_part, void* dqkv, int B, int T, int H, int dtype, void* stream);
+int nystrom_attn_fwd_ex(const amds_transmil_layer* w_host, int dim, const float* y, float* x_res, int n_bags, int n_tokens, float p_drop, uint64_t seed, uint32_t stream_id,
+                        void* saved, size_t saved_bytes, int cls_only, void* stream);
+int nystrom_attn_bwd_ex(const amds_transmil_layer* w_host, int dim, const float* dx, float* dy, const amds_nystrom_grads* grads_host, int n_bags, int n_tokens, float p_drop,
+                        uint64_t seed, uint32_t stream_id, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int cls_only, void* stream);
 int layernorm_bwd_cast_dt(const float* dy, long dy_stride, const float* x, long x_stride, const float* mean, const float* rstd, const float* gamma, float* dx, long dx_stride,
                           int add_skip, float* dgamma, float* dbeta, int accumulate_params, int rows, int cols, void* ws, size_t ws_bytes, void* dx16, long dx16_stride,
                           int dx16_dtype, float p, uint64_t seed, uint32_t stream_id, void* stream);

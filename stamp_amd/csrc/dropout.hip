@@ -277,12 +277,16 @@ extern "C" int amds_dropout_add_rows(const float* y, long ldy, const float* x_in
 }
 int amds::dropout_cast_bwd_rows_dt(const float* dx, long ldx, void* dy, long ldy, long rows, int cols, long row_mul, int dtype, float p, uint64_t seed, uint32_t stream_id,
                                    void* stream) {
-    AMDS_REQUIRE(dx && dy && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f && (dtype == AMDS_BF16 || dtype == AMDS_F16), "amds_dropout_cast_bwd_rows: bad arguments");
+    AMDS_REQUIRE(dx && dy && rows >= 0 && cols > 0 && row_mul > 0 && p >= 0.f && p < 1.f && (dtype == AMDS_BF16 || dtype == AMDS_F16 || dtype == AMDS_F32),
+                 "amds_dropout_cast_bwd_rows: bad arguments");
     if (rows == 0) return AMDS_OK;
     const uint32_t thr = p > 0.f ? drop_thr16(p) : 0;
     const int grid = (int)std::min<long>(4096, (rows * cols + 255) / 256);
     if (dtype == AMDS_BF16)
         hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (bf16*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,
+                           thr ? drop_scale(thr) : 1.0f);
+    else if (dtype == AMDS_F32)
+        hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (float*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,
                            thr ? drop_scale(thr) : 1.0f);
     else
         hipLaunchKernelGGL((dropout_cast_bwd_rows_kernel<f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, ldx, (f16*)dy, ldy, rows, cols, row_mul, seed, stream_id, thr,

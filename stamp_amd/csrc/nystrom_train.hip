@@ -132,6 +132,34 @@ __global__ void flip_taps_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// Backward of the 33-tap residual convolution when ONE position `row` of every sequence has a gradient g [outer][inner * d] (the class-row tail):
+// dv[zo][row + k - taps/2][zi * d + c] = w[zi][k] g[zo][zi * d + c] for the taps that land inside the sequence (plain stores: dv is zero there), and
+// dw[zi][k] = sum over zo, c of v[zo][row + k - taps/2][zi * d + c] g[zo][zi * d + c] (one workgroup per (tap, head), fixed summation order).
+__global__ void ny_dwconv_row_bwd_kernel(const float* __restrict__ g, long sgo, const float* __restrict__ w, float* __restrict__ dv, long svo, long svi, int ldv,
+                                         int inner, int n, int d, int taps, int row) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner, k = blockIdx.z;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tt = row + k - taps / 2;
+    if (c >= d || tt < 0 || tt >= n) return;
+    dv[zo * svo + zi * svi + (long)tt * ldv + c] = w[(long)zi * taps + k] * g[zo * sgo + (long)zi * d + c];
+}
+__global__ void __launch_bounds__(256) ny_dwconv_row_wgrad_kernel(const float* __restrict__ g, long sgo, const float* __restrict__ v, long svo, long svi, int ldv,
+                                                                  float* __restrict__ dw, int outer, int n, int d, int taps, int row) {
+    __shared__ float red[4];
+    const int k = blockIdx.x, zi = blockIdx.y, tid = threadIdx.x;
+    const int tt = row + k - taps / 2;
+    float s = 0.f;
+    if (tt >= 0 && tt < n)
+        for (int i = tid; i < outer * d; i += 256) {
+            const int zo = i / d, c = i - zo * d;
+            s = fmaf(v[zo * svo + zi * svi + (long)tt * ldv + c], g[zo * sgo + (long)zi * d + c], s);
+        }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) dw[(long)zi * taps + k] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 #define RC(call)                          \
     do {                                  \
         int rc__ = (call);                \
@@ -186,6 +214,15 @@ extern "C" size_t amds_nystrom_attn_workspace_bytes(int dim, int n_bags, int n_t
 
 extern "C" int amds_nystrom_attn_fwd(const amds_transmil_layer* w_host, int dim, const float* y, float* x_res, int n_bags, int n_tokens, float p_drop,
                                      uint64_t seed, uint32_t stream_id, void* saved, size_t saved_bytes, void* stream) {
+    return amds::nystrom_attn_fwd_ex(w_host, dim, y, x_res, n_bags, n_tokens, p_drop, seed, stream_id, saved, saved_bytes, 0, stream);
+}
+
+// cls_only: the caller reads row 0 of every bag of x_res and nothing else (TransMIL's second layer: `self.norm(h)[:, 0]`, trans_mil.py:319-323) -- attn1 and its
+// softmax, attn1 z, (attn1 z)(attn3 v), the residual convolution, to_out and its Dropout run for that one row per bag (row `pad` of the front-padded sequence; the
+// dropout bits are those of the full tensor's rows b * n); landmarks, attn2 and its pseudo-inverse, attn3 and attn3 v need every token and stay as they are.
+// The saved arena keeps its layout: a1 / a1z / merged hold [b][H][1][m] / [b][H][1][m] / [b][Cd] at the front of their regions.
+int amds::nystrom_attn_fwd_ex(const amds_transmil_layer* w_host, int dim, const float* y, float* x_res, int n_bags, int n_tokens, float p_drop, uint64_t seed,
+                              uint32_t stream_id, void* saved, size_t saved_bytes, int cls_only, void* stream) {
     AMDS_REQUIRE(w_host && y && x_res && saved, "amds_nystrom_attn_fwd: null pointer");
     const amds_transmil_layer& L = *w_host;
     AMDS_REQUIRE(L.qkv_w && L.out_w && L.out_b && L.conv_w, "amds_nystrom_attn_fwd: incomplete weights");
@@ -221,10 +258,12 @@ extern "C" int amds_nystrom_attn_fwd(const amds_transmil_layer* w_host, int dim,
     RC(amds_landmark_mean(kp, sb, sh, ld, kl, b, H, m, l, d, (float)(1.0 / l), stream));
     float *a1 = reinterpret_cast<float*>(sv + s.a1), *a2 = reinterpret_cast<float*>(sv + s.a2), *a3 = reinterpret_cast<float*>(sv + s.a3);
     const long md = (long)m * d, mmn = (long)m * m, nm = (long)np * m;
-    RC(bg(qp, ld, sb, sh, kl, d, H * md, md, 1, a1, m, H * nm, nm, b, H, np, m, d, scale, 0.0f, nullptr, 0, stream));
+    const long hm = (long)H * m;
+    if (cls_only) RC(bg(qp + (size_t)pad * ld, ld, sb, sh, kl, d, H * md, md, 1, a1, m, hm, m, b, H, 1, m, d, scale, 0.0f, nullptr, 0, stream));      // the class row of sim1
+    else RC(bg(qp, ld, sb, sh, kl, d, H * md, md, 1, a1, m, H * nm, nm, b, H, np, m, d, scale, 0.0f, nullptr, 0, stream));
     RC(bg(ql, d, H * md, md, kl, d, H * md, md, 1, a2, m, H * mmn, mmn, b, H, m, m, d, 1.0f, 0.0f, nullptr, 0, stream));
     RC(bg(ql, d, H * md, md, kp, ld, sb, sh, 1, a3, np, H * nm, nm, b, H, m, np, d, 1.0f, 0.0f, nullptr, 0, stream));
-    RC(amds_softmax_rows(a1, Z * np, m, stream));
+    RC(amds_softmax_rows(a1, cls_only ? Z : Z * np, m, stream));
     RC(amds_softmax_rows(a2, Z * m, m, stream));
     RC(amds_softmax_rows(a3, Z * m, np, stream));
     auto at = [&](size_t base, int k) { return reinterpret_cast<float*>(sv + base + (size_t)k * s.mm_bytes); };
@@ -241,6 +280,17 @@ extern "C" int amds_nystrom_attn_fwd(const amds_transmil_layer* w_host, int dim,
     const float* z = at(s.zs, ITERS);
     float *av = reinterpret_cast<float*>(sv + s.av), *a1z = reinterpret_cast<float*>(sv + s.a1z), *merged = reinterpret_cast<float*>(sv + s.merged);
     RC(bg(a3, np, H * nm, nm, vp, ld, sb, sh, 0, av, d, H * md, md, b, H, m, d, np, 1.0f, 0.0f, nullptr, 0, stream));
+    if (cls_only) {
+        RC(bg(a1, m, hm, m, z, m, H * mmn, mmn, 0, a1z, m, hm, m, b, H, 1, m, m, 1.0f, 0.0f, nullptr, 0, stream));                     // one row of attn1 pinv
+        RC(bg(a1z, m, hm, m, av, d, H * md, md, 0, merged, Cd, Cd, d, b, H, 1, d, m, 1.0f, 0.0f, nullptr, 0, stream));                 // merged: [b][Cd], the class rows
+        RC(amds_dwconv_seq_row(vp, sb, sh, ld, L.conv_w, merged, Cd, d, b, H, np, d, CONV_K, pad, stream));
+        if (p_drop > 0.f) {
+            float* out = reinterpret_cast<float*>(sv + s.out);
+            RC(bg(merged, Cd, Cd, 0, L.out_w, Cd, 0, 0, 1, out, Cd, Cd, 0, b, 1, 1, Cd, Cd, 1.0f, 0.0f, L.out_b, 0, stream));
+            return amds_dropout_add_rows(out, Cd, x_res, (long)n * Cd, x_res, (long)n * Cd, b, Cd, n, p_drop, seed, stream_id, stream);
+        }
+        return bg(merged, Cd, Cd, 0, L.out_w, Cd, 0, 0, 1, x_res, Cd, (long)n * Cd, 0, b, 1, 1, Cd, Cd, 1.0f, 0.0f, L.out_b, 1, stream);
+    }
     RC(mm(a1, z, 0, a1z, Z, np, m, m, 1.0f, 0.0f, 0, stream));
     RC(bg(a1z, m, H * nm, nm, av, d, H * md, md, 0, merged, Cd, (long)np * Cd, d, b, H, np, d, m, 1.0f, 0.0f, nullptr, 0, stream));
     RC(amds_dwconv_seq(vp, sb, sh, ld, L.conv_w, merged, (long)np * Cd, d, Cd, b, H, np, d, CONV_K, stream));
@@ -256,6 +306,13 @@ extern "C" int amds_nystrom_attn_fwd(const amds_transmil_layer* w_host, int dim,
 extern "C" int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim, const float* dx, float* dy, const amds_nystrom_grads* grads_host, int n_bags,
                                      int n_tokens, float p_drop, uint64_t seed, uint32_t stream_id, const void* saved, size_t saved_bytes, void* ws,
                                      size_t ws_bytes, void* stream) {
+    return amds::nystrom_attn_bwd_ex(w_host, dim, dx, dy, grads_host, n_bags, n_tokens, p_drop, seed, stream_id, saved, saved_bytes, ws, ws_bytes, 0, stream);
+}
+
+// cls_only: the backward of nystrom_attn_fwd_ex(cls_only = 1): dx has a gradient on row 0 of every bag only (its other rows are not read).
+int amds::nystrom_attn_bwd_ex(const amds_transmil_layer* w_host, int dim, const float* dx, float* dy, const amds_nystrom_grads* grads_host, int n_bags, int n_tokens,
+                              float p_drop, uint64_t seed, uint32_t stream_id, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int cls_only,
+                              void* stream) {
     AMDS_REQUIRE(w_host && dx && dy && saved && ws, "amds_nystrom_attn_bwd: null pointer");
     const amds_transmil_layer& L = *w_host;
     AMDS_REQUIRE(L.qkv_w && L.out_w && L.conv_w, "amds_nystrom_attn_bwd: incomplete weights");
@@ -292,6 +349,39 @@ extern "C" int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim,
         RC(bg(dy3, M, sdy, 0, x3, ldx, sx, 0, 2, part, N, (long)M * N, 0, b, 1, M, N, rows, 1.0f, 0.0f, nullptr, 0, stream));
         return colsum(part, (long)M * N, out, b, M * N);
     };
+    const long hm = (long)H * m;
+    float* dqkv = reinterpret_cast<float*>(wk + w.dqkv);
+    float *dqp = dqkv, *dkp = dqkv + Cd, *dvp = dqkv + 2 * Cd;
+    const float *av = reinterpret_cast<const float*>(sv + s.av), *a1z = reinterpret_cast<const float*>(sv + s.a1z);
+    const float *a1 = reinterpret_cast<const float*>(sv + s.a1), *a2 = reinterpret_cast<const float*>(sv + s.a2), *a3 = reinterpret_cast<const float*>(sv + s.a3);
+    const float *ql = reinterpret_cast<const float*>(sv + s.ql), *kl = reinterpret_cast<const float*>(sv + s.kl);
+    auto at = [&](size_t base, int k) { return reinterpret_cast<const float*>(sv + base + (size_t)k * s.mm_bytes); };
+    float *da1z = reinterpret_cast<float*>(wk + w.da1z), *dav = reinterpret_cast<float*>(wk + w.dav), *da1 = reinterpret_cast<float*>(wk + w.da1);
+    float *da3 = reinterpret_cast<float*>(wk + w.da3), *da2 = reinterpret_cast<float*>(wk + w.da2);
+    const float* zf = at(s.zs, ITERS);
+    float *dz = reinterpret_cast<float*>(wk + w.dzA), *dzk = reinterpret_cast<float*>(wk + w.dzB);
+    if (cls_only) {
+        // ---- the class rows alone: dout [b][Cd] = Dropout'(dx rows b * n), merged [b][Cd] as the forward left it
+        float* dout = reinterpret_cast<float*>(wk + w.dout);
+        RC(dropout_cast_bwd_rows_dt(dx, (long)n * Cd, dout, Cd, b, Cd, n, AMDS_F32, p_drop, seed, stream_id, stream));
+        if (G) {
+            RC(bg(dout, Cd, 0, 0, merged, Cd, 0, 0, 2, G->out_w, Cd, 0, 0, 1, 1, Cd, Cd, b, 1.0f, 0.0f, nullptr, 0, stream));                       // dWo = dout^T merged (K = bags)
+            RC(colsum(dout, Cd, G->out_b, b, Cd));
+        }
+        float* dmc = reinterpret_cast<float*>(wk + w.dmerged);                                                                                    // d(merged) [b][Cd]
+        RC(bg(dout, Cd, 0, 0, L.out_w, Cd, 0, 0, 0, dmc, Cd, 0, 0, 1, 1, b, Cd, Cd, 1.0f, 0.0f, nullptr, 0, stream));
+        AMDS_HIP(hipMemsetAsync(dqkv, 0, (size_t)b * np * 3 * Cd * 4, st));
+        hipLaunchKernelGGL(ny_dwconv_row_bwd_kernel, dim3(cdiv(d, 64), b * H, CONV_K), dim3(64), 0, st, dmc, (long)Cd, L.conv_w, dvp, sb, sh, ld, H, np, d, CONV_K, pad);
+        AMDS_LAUNCH_CHECK("ny_dwconv_row_bwd_kernel");
+        if (G) {
+            hipLaunchKernelGGL(ny_dwconv_row_wgrad_kernel, dim3(CONV_K, H), dim3(256), 0, st, dmc, (long)Cd, vp, sb, sh, ld, G->conv_w, b, np, d, CONV_K, pad);
+            AMDS_LAUNCH_CHECK("ny_dwconv_row_wgrad_kernel");
+        }
+        RC(bg(dmc, Cd, Cd, d, av, d, H * md, md, 1, da1z, m, hm, m, b, H, 1, m, d, 1.0f, 0.0f, nullptr, 0, stream));                               // do av^T        [1][m]
+        RC(bg(a1z, m, hm, m, dmc, Cd, Cd, d, 2, dav, d, H * md, md, b, H, m, d, 1, 1.0f, 0.0f, nullptr, 0, stream));                                // a1z^T do       rank 1
+        RC(bg(da1z, m, hm, m, zf, m, H * mmn, mmn, 1, da1, m, hm, m, b, H, 1, m, m, 1.0f, 0.0f, nullptr, 0, stream));                               // d(a1z) z^T     [1][m]
+        RC(bg(a1, m, hm, m, da1z, m, hm, m, 2, dz, m, H * mmn, mmn, b, H, m, m, 1, 1.0f, 0.0f, nullptr, 0, stream));                                // a1^T d(a1z)    rank 1
+    } else {
     // ---- to_out (+ Dropout)
     const float* dout = dx;
     if (p_drop > 0.f) {
@@ -307,9 +397,7 @@ extern "C" int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim,
     float* dmerged = reinterpret_cast<float*>(wk + w.dmerged);
     AMDS_HIP(hipMemsetAsync(dmerged, 0, (size_t)b * np * Cd * 4, st));
     RC(bg(dout, Cd, (long)n * Cd, 0, L.out_w, Cd, 0, 0, 0, dmerged + (size_t)pad * Cd, Cd, (long)np * Cd, 0, b, 1, n, Cd, Cd, 1.0f, 0.0f, nullptr, 0, stream));
-    float* dqkv = reinterpret_cast<float*>(wk + w.dqkv);
     AMDS_HIP(hipMemsetAsync(dqkv, 0, (size_t)b * np * 3 * Cd * 4, st));
-    float *dqp = dqkv, *dkp = dqkv + Cd, *dvp = dqkv + 2 * Cd;
     // 33-tap residual conv on v: data gradient = the same conv with reversed taps; weight gradient = a reduction
     float* wflip = reinterpret_cast<float*>(wk + w.wflip);
     hipLaunchKernelGGL(flip_taps_kernel, dim3(2), dim3(256), 0, st, L.conv_w, wflip, HEADS, CONV_K);
@@ -317,18 +405,11 @@ extern "C" int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim,
     RC(amds_dwconv_seq(dmerged, (long)np * Cd, d, Cd, wflip, dvp, sb, sh, ld, b, H, np, d, CONV_K, stream));
     if (G) RC(amds_dwconv_seq_wgrad(dmerged, (long)np * Cd, d, Cd, vp, sb, sh, ld, G->conv_w, b, H, np, d, CONV_K, wk + w.conv, w.conv_bytes, stream));
     // out_h = a1z av  (do = head slice of dmerged, [np, d] at row pitch Cd)
-    const float *av = reinterpret_cast<const float*>(sv + s.av), *a1z = reinterpret_cast<const float*>(sv + s.a1z);
-    const float *a1 = reinterpret_cast<const float*>(sv + s.a1), *a2 = reinterpret_cast<const float*>(sv + s.a2), *a3 = reinterpret_cast<const float*>(sv + s.a3);
-    const float *ql = reinterpret_cast<const float*>(sv + s.ql), *kl = reinterpret_cast<const float*>(sv + s.kl);
-    auto at = [&](size_t base, int k) { return reinterpret_cast<const float*>(sv + base + (size_t)k * s.mm_bytes); };
-    float *da1z = reinterpret_cast<float*>(wk + w.da1z), *dav = reinterpret_cast<float*>(wk + w.dav), *da1 = reinterpret_cast<float*>(wk + w.da1);
-    float *da3 = reinterpret_cast<float*>(wk + w.da3), *da2 = reinterpret_cast<float*>(wk + w.da2);
     RC(bg(dmerged, Cd, (long)np * Cd, d, av, d, H * md, md, 1, da1z, m, H * nm, nm, b, H, np, m, d, 1.0f, 0.0f, nullptr, 0, stream));                  // do av^T
     RC(bg(a1z, m, H * nm, nm, dmerged, Cd, (long)np * Cd, d, 2, dav, d, H * md, md, b, H, m, d, np, 1.0f, 0.0f, nullptr, 0, stream));                   // a1z^T do
-    const float* zf = at(s.zs, ITERS);
     RC(mm(da1z, zf, 1, da1, Z, np, m, m, 1.0f, 0.0f, 0, stream));                                                                                     // d(a1z) z^T
-    float *dz = reinterpret_cast<float*>(wk + w.dzA), *dzk = reinterpret_cast<float*>(wk + w.dzB);
     RC(mm(a1, da1z, 2, dz, Z, m, m, np, 1.0f, 0.0f, 0, stream));                                                                                      // a1^T d(a1z)
+    }
     RC(bg(dav, d, H * md, md, vp, ld, sb, sh, 1, da3, np, H * nm, nm, b, H, m, np, d, 1.0f, 0.0f, nullptr, 0, stream));                                // d(av) v^T
     RC(bg(a3, np, H * nm, nm, dav, d, H * md, md, 2, dvp, ld, sb, sh, b, H, np, d, m, 1.0f, 0.0f, nullptr, 1, stream));                                // dv += a3^T d(av)
     // pseudo-inverse iterations, last to first
@@ -348,13 +429,18 @@ extern "C" int amds_nystrom_attn_bwd(const amds_transmil_layer* w_host, int dim,
     }
     RC(amds_pinv_init_bwd(a2, dz, da2, (int)Z, m, wk + w.pinv, w.pinv_bytes, stream));
     // the three softmaxes (in place: da_i becomes dS_i)
-    RC(amds_softmax_rows_bwd(a1, da1, Z * np, m, stream));
+    RC(amds_softmax_rows_bwd(a1, da1, cls_only ? Z : Z * np, m, stream));
     RC(amds_softmax_rows_bwd(a2, da2, Z * m, m, stream));
     RC(amds_softmax_rows_bwd(a3, da3, Z * m, np, stream));
     const float *dS1 = da1, *dS2 = da2, *dS3 = da3;
     float *dkl = reinterpret_cast<float*>(wk + w.dkl), *dql = reinterpret_cast<float*>(wk + w.dql);
+    if (cls_only) {
+        RC(bg(dS1, m, hm, m, kl, d, H * md, md, 0, dqp + (size_t)pad * ld, ld, sb, sh, b, H, 1, d, m, scale, 0.0f, nullptr, 0, stream));                // the class query's row
+        RC(bg(dS1, m, hm, m, qp + (size_t)pad * ld, ld, sb, sh, 2, dkl, d, H * md, md, b, H, m, d, 1, scale, 0.0f, nullptr, 0, stream));                // dS1^T q, rank 1
+    } else {
     RC(bg(dS1, m, H * nm, nm, kl, d, H * md, md, 0, dqp, ld, sb, sh, b, H, np, d, m, scale, 0.0f, nullptr, 0, stream));
     RC(bg(dS1, m, H * nm, nm, qp, ld, sb, sh, 2, dkl, d, H * md, md, b, H, m, d, np, scale, 0.0f, nullptr, 0, stream));                                // dS1^T q
+    }
     RC(bg(dS2, m, H * mmn, mmn, ql, d, H * md, md, 2, dkl, d, H * md, md, b, H, m, d, m, 1.0f, 0.0f, nullptr, 1, stream));                             // + dS2^T q_l
     RC(bg(dS2, m, H * mmn, mmn, kl, d, H * md, md, 0, dql, d, H * md, md, b, H, m, d, m, 1.0f, 0.0f, nullptr, 0, stream));
     RC(bg(dS3, np, H * nm, nm, kp, ld, sb, sh, 0, dql, d, H * md, md, b, H, m, d, np, 1.0f, 0.0f, nullptr, 1, stream));

@@ -120,6 +120,8 @@ __global__ void tt_transpose_small_kernel(const float* __restrict__ src, float* 
 
 using namespace amds;
 
+static int tt_cls_tail(const amds_transmil_cfg* c) { return c->train_cls_tail < 0 ? (ctx_mil_cls_tail() != 0) : (c->train_cls_tail != 0); }
+
 extern "C" size_t amds_transmil_train_saved_bytes(const amds_transmil_cfg* cfg_host, int n_bags, int n_tiles) {
     TtDims d; TtSaved s;
     if (tt_dims(cfg_host, n_bags, n_tiles, &d) != AMDS_OK || tt_saved(d, &s) != AMDS_OK) return 0;
@@ -173,7 +175,8 @@ extern "C" int amds_transmil_train_forward(const amds_transmil_cfg* cfg_host, co
     RC(amds_layernorm_train(x2, Cd, w.layer[1].norm_w, w.layer[1].norm_b, y, Cd, reinterpret_cast<float*>(sv + s.mu2), reinterpret_cast<float*>(sv + s.rs2), (int)M, Cd, 1e-5f,
                             AMDS_F32, stream));
     AMDS_HIP(hipMemcpyAsync(xf, x2, (size_t)M * Cd * 4, hipMemcpyDeviceToDevice, st));
-    RC(amds_nystrom_attn_fwd(&w.layer[1], Cd, y, xf, Bb, n, p_drop, seed, 2, sv + s.ny2, s.ny_bytes, stream));
+    // layer2's output is read at the class rows alone (:322): the attention output, to_out and Dropout of the other rows are skipped on request
+    RC(nystrom_attn_fwd_ex(&w.layer[1], Cd, y, xf, Bb, n, p_drop, seed, 2, sv + s.ny2, s.ny_bytes, tt_cls_tail(cfg_host), stream));
     // final LayerNorm on the class rows, _fc2 (:322-325)
     float* clsn = reinterpret_cast<float*>(sv + s.clsn);
     RC(amds_layernorm_train(xf, (long)n * Cd, w.norm_w, w.norm_b, clsn, Cd, reinterpret_cast<float*>(sv + s.muf), reinterpret_cast<float*>(sv + s.rsf), Bb, Cd, 1e-5f, AMDS_F32,
@@ -225,7 +228,7 @@ extern "C" int amds_transmil_train_backward(const amds_transmil_cfg* cfg_host, c
     // ---- layer2
     amds_nystrom_grads g2{nullptr, nullptr, nullptr, nullptr}, g1 = g2;
     if (G) { g2 = amds_nystrom_grads{G->layer[1].qkv_w, G->layer[1].out_w, G->layer[1].out_b, G->layer[1].conv_w}; g1 = amds_nystrom_grads{G->layer[0].qkv_w, G->layer[0].out_w, G->layer[0].out_b, G->layer[0].conv_w}; }
-    RC(amds_nystrom_attn_bwd(&w.layer[1], Cd, dx, dy, G ? &g2 : nullptr, Bb, n, p_drop, seed, 2, sv + s.ny2, s.ny_bytes, wk + k.ny, k.ny_bytes, stream));
+    RC(nystrom_attn_bwd_ex(&w.layer[1], Cd, dx, dy, G ? &g2 : nullptr, Bb, n, p_drop, seed, 2, sv + s.ny2, s.ny_bytes, wk + k.ny, k.ny_bytes, tt_cls_tail(cfg_host), stream));
     RC(amds_layernorm_bwd(dy, Cd, reinterpret_cast<const float*>(sv + s.x2), Cd, reinterpret_cast<const float*>(sv + s.mu2), reinterpret_cast<const float*>(sv + s.rs2),
                           w.layer[1].norm_w, dx, Cd, 1, G ? G->layer[1].norm_w : scratch, G ? G->layer[1].norm_b : scratch + Cd, 0, (int)M, Cd, wk + k.lnb, k.lnb_bytes, stream));
     // ---- PPEG: tap correlations for the weights, the same convolutions with flipped kernels and zero biases for the data

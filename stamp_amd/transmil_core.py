@@ -185,9 +185,10 @@ def forward_train(get, bags: torch.Tensor, dims: tuple[int, int, int], *, traini
     if bags.dtype not in ops._DT:
         bags = bags.float()
     bags = bags.contiguous()
-    cfg = _lib.TransMilCfg(Fd, Cd, Cc)
-    w, keep = _c_weights(get, Cd)
     lib = _lib.lib()
+    # resolved HERE so that the backward of this step reads the arena the way this forward wrote it, whatever the context says by then
+    cfg = _lib.TransMilCfg(Fd, Cd, Cc, 1 if lib.amds_get_mil_cls_tail(_lib.ctx(dev.index if dev.index is not None else torch.cuda.current_device())) else 0)
+    w, keep = _c_weights(get, Cd)
     need = lib.amds_transmil_train_saved_bytes(C.byref(cfg), Bb, Tn)
     if need == 0:
         _lib.check(-1, "transmil_train_saved_bytes")

@@ -197,6 +197,7 @@ def test_transmil_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, 
     host loop) against the same kernels launched one by one from the host: logits, every parameter gradient and d/d(bags) bit-identical -- with and
     without front padding (n = 65 < one landmark block; n = 1025 -> 1280; n = 257 on 128 landmarks -> 384), wrap padding, dropout live (same
     counter-based masks from the same seed) and off; a second, input-gradient-only backward from the same saved activations."""
+    from stamp_amd import ops
     from stamp_amd import transmil_core as tc
     model, bags, targets = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn + 1)
     model = model.to(gpu)
@@ -204,6 +205,7 @@ def test_transmil_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, 
     dlogits = torch.randn(Bb, 2, device=gpu)
     res = []
     from chains import transmil as chain
+    tail_was = ops.set_mil_cls_tail(False)          # the chains run every row of layer2; the class-row tail has its own test below
     for level in (0, 1, 2):        # 0 = the whole-step C calls; 1 = host loop around amds_nystrom_attn_fwd / _bwd; 2 = every kernel from the host (tests/chains)
         fwd, bwd = (tc.forward_train, tc.backward) if level == 0 else (chain.forward_train_stepwise, chain.backward_stepwise)
         chain.NYSTROM_KERNEL_BY_KERNEL = level == 2
@@ -213,6 +215,8 @@ def test_transmil_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, 
             G2, db2 = bwd(saved, dlogits, need_params=False, need_bags=True)        # input gradient only, saved activations untouched
         finally:
             chain.NYSTROM_KERNEL_BY_KERNEL = False
+            if level == 2:
+                ops.set_mil_cls_tail(tail_was)
         assert G2 == {} and torch.equal(db2, db)
         res.append((logits, G, db))
     l0, G0, d0 = res[2]
@@ -227,6 +231,37 @@ def test_transmil_train_calls_equal_the_kernel_by_kernel_chain(gpu, Bb, Tn, Fd, 
     x = bags.to(gpu).requires_grad_(True)
     torch.nn.functional.cross_entropy(model(x), targets.to(gpu)).backward()
     assert x.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("Bb,Tn,Fd,Cd,train", [(2, 50, 96, 64, True), (3, 300, 128, 128, True), (2, 1024, 256, 512, True), (1, 255, 64, 256, False)])
+def test_transmil_train_class_row_tail_equals_every_row(gpu, Bb, Tn, Fd, Cd, train):
+    """cfg.train_cls_tail (default from the context, amds_set_mil_cls_tail): layer2's attention output (a1 z a3 v on one query row), residual convolution, to_out,
+    Dropout and the backward of all of them on the class rows alone, against the same step on every row -- same dropout seed, so the class rows draw the same
+    mask.  Same mathematics, reordered fp32 sums (rank-1 products instead of n-row ones): logits <= 2e-6 abs, every gradient <= 2e-5 relative L2."""
+    from stamp_amd import ops
+    from stamp_amd import transmil_core as tc
+    model, bags, _ = _setup(Bb, Tn, Fd, Cd, 2, seed=Tn + 3)
+    model = model.to(gpu)
+    get = model._get(torch.device(gpu))
+    dlogits = torch.randn(Bb, 2, device=gpu)
+    res = []
+    was = ops.set_mil_cls_tail(True)
+    try:
+        for tail in (False, True):
+            ops.set_mil_cls_tail(tail)
+            logits, saved = tc.forward_train(get, bags.to(gpu), (Fd, Cd, 2), training=train, seed=99)
+            assert saved["cfg"].train_cls_tail == int(tail)
+            ops.set_mil_cls_tail(not tail)           # the backward follows the forward's cfg, not the context of the moment
+            G, db = tc.backward(saved, dlogits, need_params=True, need_bags=True)
+            res.append((logits, G, db))
+    finally:
+        ops.set_mil_cls_tail(was)
+    (l0, G0, d0), (l1, G1, d1) = res
+    assert (l1 - l0).abs().max().item() < 2e-6 * max(1.0, l0.abs().max().item())
+    worst = sorted([(_rel(G1[k], G0[k]), k) for k in G0] + [(_rel(d1, d0), "bags")], reverse=True)
+    print(f"TransMIL tail vs full {Bb}x{Tn}x{Fd} hidden {Cd}:", [(float(f"{a:.2e}"), b) for a, b in worst[:4]])
+    for rel, k in worst:
+        assert rel < 2e-5, (k, rel)
 
 
 def test_nystrom_c_abi_guards(gpu):
