@@ -98,7 +98,8 @@ class _MilVitBackward(torch.autograd.Function):
         G, dbags = mil_core.backward(holder.pk, holder.saved, dlogits * sc if sc != 1.0 else dlogits, need_params=need_params, need_bags=need_bags)
         if sc != 1.0:
             dbags = dbags * (1.0 / sc) if need_bags else dbags
-            G = {k: v * (1.0 / sc) for k, v in G.items()} if need_params else G
+            for k in (list(G) if need_params else ()):         # in place: the mapping mil_core.backward returned is kept as it is
+                G[k] = G[k] * (1.0 / sc)
         outs = [dbags if need_bags else dlogits.new_zeros(())]
         outs += [G[n].contiguous() for n in names] if need_params else []
         return tuple(outs)
