@@ -11,6 +11,7 @@
 //   attn_bwd_dkdv_kernel : one workgroup = 128 keys (lane = key), loops over query tiles  -> dK, dV
 //   attn_bwd_dq_kernel   : one workgroup = 128 queries (lane = query), loops over key tiles -> dQ
 #include "common.h"
+#include <cstdlib>
 
 namespace amds {
 
@@ -18,6 +19,15 @@ constexpr int BT_TILE = 64;                        // tokens per streamed tile
 constexpr int BT_RS = 192;                         // row stride (bytes) of the transposed images: 12 slots + 16 B skew / 8 rows
 constexpr int BT_ROW_BYTES = BT_TILE * 128;        // row-major image: 64 tokens x 128 B
 constexpr int BT_TR_BYTES = 64 * BT_RS + 8 * 16;   // transposed image: 64 feature rows x 64 tokens (+ skew)
+// dQ kernel: LDS stages per workgroup and workgroups per CU the build asks for.  1 stage (28.8 KB) x 3 workgroups: 367 us at the bench shape against 414 us for
+// 2 stages (57.6 KB, one barrier per tile) x 2 workgroups -- the kernel needs 158-162 registers, and a third wave per SIMD hides more than the second barrier costs
+// (profiles/r06_attn_bwd_valu_diet.txt; -DDQ_STAGES=2 -DDQ_WGS=2 rebuilds the other form)
+#ifndef DQ_STAGES
+#define DQ_STAGES 1
+#endif
+#ifndef DQ_WGS
+#define DQ_WGS 3
+#endif
 
 __device__ __forceinline__ int perm16(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
@@ -172,6 +182,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
     const int swz = (l31 >> 1) & 7;
 
     const bool wave_live = kblk * 128 + wave * 32 < Tn;
+    // Dropout bits are one hash per (query, key PAIR) and a lane is a key: lanes 2m and 2m + 1 would compute the same 16 hashes per half.  Instead the even lane
+    // hashes the even registers' queries and the odd lane the odd ones; the two 16-bit compares of a hash become wave masks (SGPR pairs) that the scalar unit
+    // re-deals to the two lanes of the pair (the lane with the even key reads the low half-word, its neighbour the high one): 8 hashes + 16 compares per half
+    // instead of 16 + 16 + 16 extracts, the re-dealing on the SALU.  The kernels are VALU-issue-bound (~3.9 k VALU cycles against 1 k of MFMA per tile).
+    const int par = lane & 1;
+    const uint32_t pair_g = DROP ? ((uint32_t)key >> 1) * 0x9E3779B1u : 0u;
+    constexpr uint64_t EVEN = 0x5555555555555555ull;
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -186,6 +203,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
         if (wave_live)                                      // (a wave whose 32 keys all lie past the sequence only helps staging: T = 1025's ninth block)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (j * BT_TILE + half * 32 >= Tn) continue;    // 32 queries past the sequence (T = 1025: the second half of the 17th tile)
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -197,26 +215,36 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
                 s = Act<T>::mfma32(qa, kf[ks], s);
                 dp = Act<T>::mfma32(ga, vf[ks], dp);
             }
-            // lane = key, register r = query (r&3) + 8(r>>2) + 4hi of this 32-query half
+            uint64_t keepm[16];
+            if constexpr (DROP) {
+                const uint32_t* sRK = reinterpret_cast<const uint32_t*>(sL) + 2 * BT_TILE + half * 32 + 4 * hi + par;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {             // this lane's register 2 rr + par = query ((2 rr) & 3) + par + 8 (rr >> 1) (+ 4 hi) of the half
+                    const uint32_t hsh = fmix32(sRK[((2 * rr) & 3) + 8 * (rr >> 1)] ^ pair_g);
+                    const uint64_t k0 = __builtin_amdgcn_ballot_w64((hsh & 0xFFFFu) >= thr16);
+                    const uint64_t k1 = __builtin_amdgcn_ballot_w64((hsh >> 16) >= thr16);
+                    keepm[2 * rr] = (k0 & EVEN) | ((k1 & EVEN) << 1);              // hashed by the even lanes
+                    keepm[2 * rr + 1] = (k1 & ~EVEN) | ((k0 & ~EVEN) >> 1);        // hashed by the odd lanes
+                }
+            }
+            // lane = key, register r = query (r&3) + 8(r>>2) + 4hi of this 32-query half.  No bounds tests: a query past the sequence was staged as zeros (Q, dO, L,
+            // D: p = 1, dS = 0, and its dO / Q columns of the two products below are zero), a key past it is a lane of its own whose dK / dV are never stored.
             vec8 pf[2], df[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int qg = j * BT_TILE + ql;
-                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -sL[ql]));
-                if (qg >= Tn || key >= Tn) p = 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -sL[ql]));
                 float dpr = dp[r];
                 float pw = p;                                   // weight on v: P (dropped: M o P), minus the scaled distance for ALiBi
                 if constexpr (DROP) {
-                    const uint32_t bits = drop_pair_bits(reinterpret_cast<const uint32_t*>(sL)[2 * BT_TILE + ql], (uint32_t)key >> 1);
-                    const float mk = drop_keep(bits, key & 1, thr16) ? keep_scale : 0.f;
-                    dpr *= mk;
-                    pw *= mk;
+                    const bool keep = __builtin_amdgcn_inverse_ballot_w64(keepm[r]);
+                    dpr = keep ? dpr * keep_scale : 0.f;
+                    pw = keep ? pw * keep_scale : 0.f;
                 }
                 const float dsv = p * (dpr - sL[BT_TILE + ql]);
                 if constexpr (ALIBI) {
                     const float ddx = sL[2 * BT_TILE + ql] - xk, ddy = sL[3 * BT_TILE + ql] - yk;
-                    if (qg < Tn && key < Tn) pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
+                    pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
                 }
                 pf[r >> 3][r & 7] = Act<T>::from_f32(pw);
                 df[r >> 3][r & 7] = Act<T>::from_f32(dsv);
@@ -256,19 +284,244 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dK, dV, second form (the product): the same arithmetic, in the same order, with the data path of a gfx950 kernel.
+//   * the Q and dO tiles go global -> LDS by buffer-form LDS-DMA (no staging registers; rows past the sequence are out of the descriptor's range and read as 0),
+//     two stages of 17 KB, ONE barrier per tile;
+//   * there are no transposed images: the dO^T / Q^T fragments of the two second products are ds_read_b64_tr_b16 transpose reads of the row-major images (a
+//     16-lane group hands in 4 query rows x 32 B and each lane receives its feature column: 4 consecutive queries, exactly the order the accumulator registers
+//     of S / dP hold them in);
+//   * 16-byte chunk c of row q sits at chunk c ^ x(q), x(q) = bit 1 of q as bit 2 | bits 3..2 of q as bits 1..0: the row reads (ds_read_b128) AND the transpose
+//     reads (a 32-lane group = 4 consecutive rows x 64 B: rows q, q + 2 in opposite halves of their 128 bytes) are conflict-free;
+//   * 150-odd registers and 34 KB: THREE workgroups per CU (the first form: 208-245 registers, 42 KB, two).
+// The transpose reads are inline asm (the builtin makes the compiler wait for the LDS-DMA in flight before every read, gemm_4w16.h) and carry their own
+// s_waitcnt lgkmcnt(0): what the statement returns is there.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bt_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// eight transpose reads of one image (k-half ks in {0, 1} x feature half dt x query group w) + the wait; a[w][dt] = the lane's addresses for ks = 0
+#define BT_TR8(out, a00, a01, a10, a11, imm)                                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %10 offset:%12\n\t"                                  \
+                 "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %11 offset:%12\n\t"                                   \
+                 "ds_read_b64_tr_b16 %4, %8 offset:%13\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"                                   \
+                 "ds_read_b64_tr_b16 %6, %9 offset:%13\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\ts_waitcnt lgkmcnt(0)"               \
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])  \
+                 : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "n"(imm), "n"((imm) + 2048)                                                  \
+                 : "memory")
+
+template <typename T, bool ALIBI = false, bool DROP = false>
+__global__ void __launch_bounds__(256, 3) attn_bwd_dkdv2_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ dq_sum,
+                                                                T* __restrict__ dqkv, int Tn, int H, const float* __restrict__ coords = nullptr,
+                                                                const float* __restrict__ dist_scale = nullptr, uint64_t seed = 0,
+                                                                uint32_t drop_stream = 0, uint32_t thr16 = 0, float keep_scale = 1.f) {
+    typedef typename Act<T>::vec8 vec8;
+    typedef typename Act<T>::vec4 vec4;
+    constexpr int SC_OFF = 2 * BT_ROW_BYTES;                        // per-query scalars: L[64] | D[64] | row key[64] or (x, y)[64]
+    constexpr int STAGE = SC_OFF + 4 * BT_TILE * 4;                 // 17 408 bytes
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
+    const int Dm = H * 64;
+    const long ld = 3L * Dm;
+    const T* base = qkv + (long)b * Tn * ld + h * 64;           // q at +0, k at +Dm, v at +2Dm
+    const T* dobase = dout + (long)b * Tn * Dm + h * 64;
+    const int ntile = (Tn + BT_TILE - 1) / BT_TILE;
+
+    // this lane's key: K and V fragments stay in registers for the whole kernel
+    const int key = kblk * 128 + wave * 32 + l31;
+    const int keyc = min(key, Tn - 1);
+    vec8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *reinterpret_cast<const vec8*>(base + (long)keyc * ld + Dm + (ks * 2 + hi) * 8);
+        vf[ks] = *reinterpret_cast<const vec8*>(base + (long)keyc * ld + 2 * Dm + (ks * 2 + hi) * 8);
+    }
+    float xk = 0.f, yk = 0.f, ch_ = 0.f;
+    if constexpr (ALIBI) { xk = coords[((long)b * Tn + keyc) * 2]; yk = coords[((long)b * Tn + keyc) * 2 + 1]; ch_ = dist_scale[h]; }
+
+    // LDS-DMA: an image is 8 pieces of 8 rows (1 KB, lane-linear); wave w requests pieces w and w + 4 of both images (rows 32 apart share the swizzle: one lane
+    // offset per image, the second piece in the scalar offset).  The per-query scalars travel the same way, 4 bytes per lane: L by wave 0, D by wave 1, the ALiBi
+    // coordinates (x, y interleaved) by waves 2 and 3.  Everything past the sequence is out of its descriptor's range and reads as 0.
+    const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)((((long)Tn - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dobase), 0, (int)((((long)Tn - 1) * Dm + 64) * 2), 0x00020000);
+    const float* scal = wave == 0 ? lse + ((long)b * H + h) * Tn : wave == 1 ? dq_sum + ((long)b * H + h) * Tn : ALIBI ? coords + (long)b * Tn * 2 : lse;
+    const int scal_bytes = wave < 2 ? Tn * 4 : ALIBI ? Tn * 8 : 0;
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scal), 0, scal_bytes, 0x00020000);
+    const int drow_ = wave * 8 + (lane >> 3);
+    const int dlc = (lane & 7) ^ bt_swz(drow_);
+    const int voq = drow_ * (int)ld * 2 + dlc * 16, vog = drow_ * Dm * 2 + dlc * 16;
+    auto tile_request = [&](int j, int buf) {
+        char* sQ = smem + buf * STAGE;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            bufl16(rsrc_q, sQ + (wave + 4 * pc) * 1024, voq, (j * BT_TILE + 32 * pc) * (int)ld * 2);
+            bufl16(rsrc_g, sQ + BT_ROW_BYTES + (wave + 4 * pc) * 1024, vog, (j * BT_TILE + 32 * pc) * Dm * 2);
+        }
+        // wave 0: L -> dwords 0..63, wave 1: D -> 64..127, waves 2, 3 (ALiBi): the tile's 128 coordinate dwords -> 128..255
+        if (wave < 2 || ALIBI)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lptr_t)(sQ + SC_OFF + wave * 256), 4, lane * 4, (wave < 2 ? j * BT_TILE * 4 : j * BT_TILE * 8 + (wave - 2) * 256), 0, 0);
+    };
+    auto tile_rowkeys = [&](int j, int buf) {           // dropout: the tile's 64 row keys (hashes of the row index: nothing to wait for)
+        if constexpr (DROP) {
+            if (tid < BT_TILE)
+                reinterpret_cast<uint32_t*>(smem + buf * STAGE + SC_OFF)[2 * BT_TILE + tid] =
+                    drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + min(j * BT_TILE + tid, Tn - 1)));
+        }
+    };
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const float sc = 0.125f * 1.44269504088896340736f;
+    // LDS addresses, one register each, moved between the two stages in place (+/- STAGE per tile):
+    //   ra[ks]: this lane's 16-byte chunk ks*2 + hi of row l31 (the S / dP operand rows; + 4096 = the second half's rows, + 8192 = dO)
+    //   tra[w][dt]: transpose reads -- lane i of 16-lane group g hands in (query row (i >> 2) of the 4, 8-byte piece i & 3 of its 32 bytes); g & 1 = which 16 features
+    //   sla: the per-query scalars of queries 4 hi ..
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    unsigned ra[4], tra[2][2], sla = lds0 + SC_OFF + 16 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ra[ks] = lds0 + l31 * 128 + (((ks * 2 + hi) ^ bt_swz(l31)) << 4);
+    {
+        const int i16 = lane & 15, gd = (lane >> 4) & 1;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int row = hi * 4 + w * 8 + (i16 >> 2);
+                const int lc = dt * 4 + gd * 2 + ((i16 & 3) >> 1);
+                tra[w][dt] = lds0 + row * 128 + ((lc ^ bt_swz(row)) << 4) + (i16 & 1) * 8;
+            }
+    }
+    int flip = STAGE;
+
+    const bool wave_live = kblk * 128 + wave * 32 < Tn;
+    const int par = lane & 1;
+    const uint32_t pair_g = DROP ? ((uint32_t)key >> 1) * 0x9E3779B1u : 0u;
+    constexpr uint64_t EVEN = 0x5555555555555555ull;
+    typedef const __attribute__((address_space(3))) char* lds_cp;
+    tile_request(0, 0);
+    tile_rowkeys(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) tile_request(j + 1, (j & 1) ^ 1);
+        if (wave_live)                                      // (a wave whose 32 keys all lie past the sequence only requests: T = 1025's ninth block)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (j * BT_TILE + half * 32 >= Tn) continue;    // 32 queries past the sequence (T = 1025: the second half of the 17th tile)
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 qa = *reinterpret_cast<const __attribute__((address_space(3))) vec8*>((lds_cp)(size_t)(ra[ks] + half * 4096));
+                const vec8 ga = *reinterpret_cast<const __attribute__((address_space(3))) vec8*>((lds_cp)(size_t)(ra[ks] + half * 4096 + BT_ROW_BYTES));
+                s = Act<T>::mfma32(qa, kf[ks], s);
+                dp = Act<T>::mfma32(ga, vf[ks], dp);
+            }
+            const __attribute__((address_space(3))) float* sL = reinterpret_cast<const __attribute__((address_space(3))) float*>((lds_cp)(size_t)sla) + half * 32;
+            // lane = key, register r = query (r&3) + 8(r>>2) + 4hi of this 32-query half; four registers at a time: two dropout hashes (the sharing between the
+            // two lanes of a key pair: see the first form), four keep masks
+            vec8 pf[2], df[2];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                uint64_t keepm[4] = {0, 0, 0, 0};
+                if constexpr (DROP) {
+                    const __attribute__((address_space(3))) uint32_t* sRK = reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(sL) + 2 * BT_TILE + par;
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {             // this lane's register 4 r4 + 2 e2 + par
+                        const uint32_t hsh = fmix32(sRK[8 * r4 + 2 * e2] ^ pair_g);
+                        const uint64_t k0 = __builtin_amdgcn_ballot_w64((hsh & 0xFFFFu) >= thr16);
+                        const uint64_t k1 = __builtin_amdgcn_ballot_w64((hsh >> 16) >= thr16);
+                        keepm[2 * e2] = (k0 & EVEN) | ((k1 & EVEN) << 1);              // hashed by the even lanes
+                        keepm[2 * e2 + 1] = (k1 & ~EVEN) | ((k0 & ~EVEN) >> 1);        // hashed by the odd lanes
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * r4 + e;
+                    const int ql = e + 8 * r4;                   // (+ 4 hi: in sla)
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -sL[ql]));
+                    float dpr = dp[r];
+                    float pw = p;                                   // weight on v: P (dropped: M o P), minus the scaled distance for ALiBi
+                    if constexpr (DROP) {
+                        const bool keep = __builtin_amdgcn_inverse_ballot_w64(keepm[e]);
+                        dpr = keep ? dpr * keep_scale : 0.f;
+                        pw = keep ? pw * keep_scale : 0.f;
+                    }
+                    const float dsv = p * (dpr - sL[BT_TILE + ql]);
+                    if constexpr (ALIBI) {
+                        const float ddx = sL[2 * BT_TILE + 2 * ql + 4 * hi + half * 32] - xk, ddy = sL[2 * BT_TILE + 2 * ql + 4 * hi + half * 32 + 1] - yk;   // (x, y) pairs, 8 bytes per query: sL already points 4 hi + 32 half floats in
+                        pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
+                    }
+                    pf[r >> 3][r & 7] = Act<T>::from_f32(pw);
+                    df[r >> 3][r & 7] = Act<T>::from_f32(dsv);
+                }
+            }
+            // fragment [ks*4 + dt*2 + w]: queries 16 ks + 8 w + 4 hi + 0..3 of the half, feature dt*32 + l31
+            u32x2 tg[8], tq[8];
+            if (half == 0) BT_TR8(tg, tra[0][0], tra[0][1], tra[1][0], tra[1][1], BT_ROW_BYTES); else BT_TR8(tg, tra[0][0], tra[0][1], tra[1][0], tra[1][1], BT_ROW_BYTES + 4096);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const vec8 gt = __builtin_bit_cast(vec8, u32x4{tg[ks * 4 + dt * 2][0], tg[ks * 4 + dt * 2][1], tg[ks * 4 + dt * 2 + 1][0], tg[ks * 4 + dt * 2 + 1][1]});
+                    dv[dt] = Act<T>::mfma32(gt, pf[ks], dv[dt]);
+                }
+            if (half == 0) BT_TR8(tq, tra[0][0], tra[0][1], tra[1][0], tra[1][1], 0); else BT_TR8(tq, tra[0][0], tra[0][1], tra[1][0], tra[1][1], 4096);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const vec8 qt = __builtin_bit_cast(vec8, u32x4{tq[ks * 4 + dt * 2][0], tq[ks * 4 + dt * 2][1], tq[ks * 4 + dt * 2 + 1][0], tq[ks * 4 + dt * 2 + 1][1]});
+                    dk[dt] = Act<T>::mfma32(qt, df[ks], dk[dt]);
+                }
+            __builtin_amdgcn_sched_barrier(0);               // (the halves are not interleaved: 168 registers hold one of them)
+        }
+        if (j + 1 < ntile) tile_rowkeys(j + 1, (j & 1) ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ra[ks] += flip;
+        tra[0][0] += flip; tra[0][1] += flip; tra[1][0] += flip; tra[1][1] += flip;
+        sla += flip;
+        flip = -flip;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next tile has landed, this wave's reads of the current one are done
+        __builtin_amdgcn_s_barrier();
+    }
+    if (key < Tn) {
+        T* krow = dqkv + ((long)b * Tn + key) * ld + Dm + h * 64;
+        T* vrow = krow + Dm;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 wk, wv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wk[e] = Act<T>::from_f32(dk[dt][4 * g + e] * 0.125f); wv[e] = Act<T>::from_f32(dv[dt][4 * g + e]); }
+                *reinterpret_cast<vec4*>(krow + dt * 32 + 8 * g + 4 * hi) = wk;
+                *reinterpret_cast<vec4*>(vrow + dt * 32 + 8 * g + 4 * hi) = wv;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // dQ: lane = query.  Per key tile (64 keys, two 32-key halves):
 //   S^T[i=key][j=query] = K_rows . Q^T(regs)      dP^T[i=key][j=query] = V_rows . dO^T(regs)
 //   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, bool DROP = false>
-__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ void __launch_bounds__(256, DQ_WGS) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ dq_sum,
                                                              T* __restrict__ dqkv, int Tn, int H, uint64_t seed = 0, uint32_t drop_stream = 0,
                                                              uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
     constexpr int STAGE = 2 * BT_ROW_BYTES + BT_TR_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[DQ_STAGES * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,18 +582,21 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
     const int swz = (l31 >> 1) & 7;
 
     const bool wave_live = qblk * 128 + wave * 32 < Tn;
+    uint32_t pair_g = DROP ? (uint32_t)(2 * hi) * 0x9E3779B1u : 0u;            // (key pair index of the lane's first key in the tile) x the hash's multiplier
     stage_load(0);
     stage_store(0);
     __syncthreads();
     for (int j = 0; j < ntile; ++j) {
-        const int buf = j & 1;
+        const int buf = DQ_STAGES == 2 ? (j & 1) : 0;
         if (j + 1 < ntile) stage_load(j + 1);
         const char* sK = smem + buf * STAGE;
         const char* sV = sK + BT_ROW_BYTES;
         const char* sKt = sV + BT_ROW_BYTES;
+        const bool ragged = (j + 1) * BT_TILE > Tn;             // the last tile of a T that is no multiple of 64
         if (wave_live)                                      // (a wave whose 32 queries all lie past the sequence only helps staging: T = 1025's ninth block)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (j * BT_TILE + half * 32 >= Tn) continue;    // 32 keys past the sequence (T = 1025: the second half of the 17th tile)
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -352,15 +608,31 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
                 s = Act<T>::mfma32(ka, qf[ks], s);
                 dp = Act<T>::mfma32(va, gf[ks], dp);
             }
+            if (ragged) {
+                // keys past the sequence: p = exp2(-inf) = 0.  A branch taken once per workgroup: the empty asm statements cannot be speculated, so the block is not
+                // if-converted into 16 compares + 16 selects on every tile of a loop that is short of VALU issue slots, not of branch units
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (j * BT_TILE + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Tn) s[r] = -INFINITY;
+                    asm volatile("" : "+v"(s[r]));
+                }
+            }
             vec8 df[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kg = j * BT_TILE + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -Lq));
-                if (kg >= Tn) p = 0.f;
-                float dpr = dp[r];
-                if constexpr (DROP) dpr *= drop_keep(drop_pair_bits(rowkey, (uint32_t)kg >> 1), kg & 1, thr16) ? keep_scale : 0.f;
-                df[r >> 3][r & 7] = Act<T>::from_f32(p * (dpr - Dq));
+            for (int r = 0; r < 16; r += 2) {                       // registers r, r + 1 = an even key and its odd partner: one hash
+                bool keep0 = true, keep1 = true;
+                if constexpr (DROP) {
+                    const uint32_t bits = fmix32(rowkey ^ (pair_g + (uint32_t)(half * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * 0x9E3779B1u));
+                    keep0 = drop_keep(bits, 0, thr16);
+                    keep1 = drop_keep(bits, 1, thr16);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r + e], sc, -Lq));
+                    float dpr = dp[r + e];
+                    if constexpr (DROP) dpr = (e ? keep1 : keep0) ? dpr * keep_scale : 0.f;
+                    df[r >> 3][(r & 7) + e] = Act<T>::from_f32(p * (dpr - Dq));
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -373,7 +645,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const T* __restrict
                 }
             }
         }
-        if (j + 1 < ntile) stage_store(buf ^ 1);
+        if constexpr (DROP) pair_g += 32u * 0x9E3779B1u;
+        if constexpr (DQ_STAGES == 1) __syncthreads();      // every wave is done reading the stage
+        if (j + 1 < ntile) stage_store(DQ_STAGES == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
     if (q < Tn) {
@@ -395,21 +669,29 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* dout, con
                            hipStream_t st, const void* u = nullptr, const float* coords = nullptr, const float* bias_scale = nullptr,
                            const float* dist_scale = nullptr, float* dbs_part = nullptr, float p_drop = 0.f, uint64_t seed = 0, uint32_t drop_stream = 0) {
     const long total = (long)B * T_ * H;
+    AMDS_REQUIRE((long)T_ * 3 * H * 64 * 2 < (1L << 31), "attention backward: one bag's qkv rows (T=%d x %d bytes) exceed the 2 GB a buffer descriptor addresses", T_, 3 * H * 128);
     hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const T*)o, (const T*)dout, dq_sum, T_, H, total,
                        (const T*)u, bias_scale, dbs_part);
     AMDS_LAUNCH_CHECK("attn_bwd_prep_kernel");
     const dim3 grid((T_ + 127) / 128, H, B), block(256);
+    static const bool first_form = getenv("AMDS_ATTN_DKDV") && atoi(getenv("AMDS_ATTN_DKDV")) == 1;       // A/B switch (read once)
     if (!u && p_drop > 0.f) {
         const uint32_t thr = drop_thr16(p_drop);
         const float ks = drop_scale(thr);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
+        if (first_form) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
+        else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
         AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel<drop>");
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, seed, drop_stream, thr, ks);
         AMDS_LAUNCH_CHECK("attn_bwd_dq_kernel<drop>");
         return AMDS_OK;
     }
-    if (u) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
-    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
+    if (first_form) {
+        if (u) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
+        else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
+    } else {
+        if (u) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
+        else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
+    }
     AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H);
     AMDS_LAUNCH_CHECK("attn_bwd_dq_kernel");
