@@ -5,8 +5,8 @@
 // src/stamp/modeling/models/vision_tranformer.py:191, 217-227 (mask = None path).
 //
 // One workgroup = 128 queries (4 waves x 32) of one (bag, head); K / V stream through LDS in tiles of 64 keys,
-// double buffered (global -> registers -> LDS; V is transposed on the way, see attention_vit.hip for the layout
-// rules: S^T = K Q^T keeps a query's scores in one lane, the key order inside 16-key groups is bit-permuted so P is
+// double buffered by LDS-DMA (row-major images; V^T fragments by transpose reads; see attention_vit.hip for the layout
+// rules: S^T = K Q^T keeps a query's scores in one lane, the key order inside 16-key groups is such that P is
 // already the MFMA B operand).  Scores never leave registers: N^2 is never materialised, K/V are re-read once per
 // 128-query block (L2-resident: 2 x T x 128 B per head).
 #include "common.h"
@@ -14,11 +14,8 @@
 namespace amds {
 
 constexpr int FA_KT = 64;                       // keys per tile
-constexpr int FA_VS = 192;                      // V^T row stride in bytes (12 slots) + 16 B skew per 8 rows: conflict-free
-constexpr int FA_K_BYTES = FA_KT * 128;         // 8 KB
-constexpr int FA_V_BYTES = 64 * FA_VS + 8 * 16; // 12.1 KB
+constexpr int FA_K_BYTES = FA_KT * 128;         // a row-major image of 64 keys (K, and V alike): 8 KB
 constexpr int FA_C_BYTES = FA_KT * 8;            // key coordinates (float2) of a tile, ALiBi variant only
-constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES + FA_C_BYTES;
 
 // ALIBI: the reference's MultiHeadALiBi (src/stamp/modeling/models/vision_tranformer.py:42-74): the distance bias is
 // SUBTRACTED FROM THE PROBABILITIES (after the softmax):  out = softmax(q k^T/8) v  -  s_h * cdist(c_q, c_k) v,
@@ -36,6 +33,22 @@ constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES + FA_C_BYTES;
 // afterwards, and the distance term is dropped on the class-token row and column (alibi_mask, :370-372); mask row = bag b.
 // DROP (plain attention, training): nn.MultiheadAttention's dropout on the attention probabilities: out = drop(P) v with the
 // normaliser and the saved log-sum-exp those of the undropped P; mask bits from (seed, stream, (b,h,q), k) -- common.h drop_*.
+// Data path (round 6; the first form -- global -> registers -> LDS with a transposing store pass for V, 42 KB and 146-161 registers -- is kept as text in
+// tools/ubench/attic/attention_first_forms/, A/B in profiles/r06_attn_bwd_ab.txt: same bits, -7.5 %): K and V tiles by buffer-form LDS-DMA (no staging registers),
+// the V^T fragments of the P V product by ds_read_b64_tr_b16 transpose reads of the row-major V image, two 16 KB stages, a raw s_barrier per tile; 121-128 registers:
+// four workgroups per CU (ALiBi: 211, two).  16-byte chunk c of key row k sits at chunk c ^ attn_swz(k): row reads and transpose reads are both conflict-free.
+#define FA_TR8(out, a00, a01, a10, a11, imm)                                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %10 offset:%12\n\t"                                  \
+                 "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %11 offset:%12\n\t"                                   \
+                 "ds_read_b64_tr_b16 %4, %8 offset:%13\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"                                   \
+                 "ds_read_b64_tr_b16 %6, %9 offset:%13\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\ts_waitcnt lgkmcnt(0)"               \
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])  \
+                 : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "n"(imm), "n"((imm) + 2048)                                                  \
+                 : "memory")
+// the LDS-DMA addresses one bag's q | k | v rows through a buffer descriptor: 32-bit byte offsets
+#define FA_SPAN_OK(T, H) ((long)(T) * 3 * (H) * 128 < (1L << 31))
+__device__ __forceinline__ int attn_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
 template <typename T, bool ALIBI, typename TO = T, bool MASK = false, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int Tn, int H,
                                                             const float* __restrict__ coords, const float* __restrict__ head_scale,
@@ -44,7 +57,8 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                                                             const uint8_t* __restrict__ pad = nullptr, uint64_t seed = 0, uint32_t drop_stream = 0,
                                                             uint32_t thr16 = 0, float keep_scale = 1.f, int mask_heads = 0) {
     typedef typename Act<T>::vec8 vec8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE + (MASK ? 2 * FA_KT : 0)];
+    constexpr int F2_STAGE = 2 * FA_K_BYTES + FA_C_BYTES;                // K rows | V rows | key coordinates (ALiBi)
+    __shared__ __attribute__((aligned(16))) char smem[2 * F2_STAGE + (MASK ? 2 * FA_KT : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,61 +69,35 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     const T* base = qkv + (long)b * Tn * ld + h * 64;
     const int ntile = (Tn + FA_KT - 1) / FA_KT;
 
-    // staging registers (global -> regs -> LDS so the next tile's loads fly during this tile's MFMAs)
-    u32x4 kreg[2];
-    vec8 v0reg, v1reg;
-    float cxreg = 0.f, cyreg = 0.f;
+    // LDS-DMA (attention_train.hip, attn_bwd_dkdv2_kernel): wave w requests 8-row pieces w and w + 4 of the K and V images, rows past the sequence read as 0;
+    // ALiBi: the tile's 128 coordinate dwords by waves 0 and 1.  Only the padding flags (bytes at an odd stride) still travel through a register.
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + Dm), 0, (int)((((long)Tn - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + 2 * Dm), 0, (int)((((long)Tn - 1) * ld + 64) * 2), 0x00020000);
+    const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ALIBI ? cbase : head_scale), 0, ALIBI ? Tn * 8 : 0, 0x00020000);
     uint8_t mreg = 0;
     const uint8_t* prow = nullptr;
     if constexpr (MASK) prow = pad + (long)(ALIBI ? b : (int)(((long)b * mask_heads + min(h, mask_heads - 1)) % gridDim.z)) * Tn;
-    const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
-    const int k_key[2] = {tid >> 3, (tid >> 3) + 32};
-    const int k_ch = tid & 7;
-    const int v_kp = tid >> 3, v_ch = tid & 7;            // key pair 0..31, d chunk 0..7
-    auto stage_load = [&](int j) {
-        const int key0 = j * FA_KT;
+    const int drow_ = wave * 8 + (lane >> 3);
+    const int vo = drow_ * (int)ld * 2 + (((lane & 7) ^ attn_swz(drow_)) << 4);
+    auto stage_load = [&](int j, int buf) {
+        char* sK = smem + buf * F2_STAGE;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int key = key0 + k_key[r];
-            kreg[r] = u32x4{0u, 0u, 0u, 0u};
-            if (key < Tn) kreg[r] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + Dm + k_ch * 8);
+        for (int pc = 0; pc < 2; ++pc) {
+            bufl16(rsrc_k, sK + (wave + 4 * pc) * 1024, vo, (j * FA_KT + 32 * pc) * (int)ld * 2);
+            bufl16(rsrc_v, sK + FA_K_BYTES + (wave + 4 * pc) * 1024, vo, (j * FA_KT + 32 * pc) * (int)ld * 2);
         }
-        const int vk = key0 + v_kp * 2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v0reg[e] = (T)0.f; v1reg[e] = (T)0.f; }
-        if (vk < Tn) v0reg = *reinterpret_cast<const vec8*>(base + (long)vk * ld + 2 * Dm + v_ch * 8);
-        if (vk + 1 < Tn) v1reg = *reinterpret_cast<const vec8*>(base + (long)(vk + 1) * ld + 2 * Dm + v_ch * 8);
         if constexpr (ALIBI) {
-            cxreg = cyreg = 0.f;
-            if (tid < FA_KT && key0 + tid < Tn) { cxreg = cbase[(long)(key0 + tid) * 2]; cyreg = cbase[(long)(key0 + tid) * 2 + 1]; }
+            if (wave < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lptr_t)(sK + 2 * FA_K_BYTES + wave * 256), 4, lane * 4, j * FA_KT * 8 + wave * 256, 0, 0);
         }
         if constexpr (MASK) {
             mreg = 1;
-            if (tid < FA_KT && key0 + tid < Tn) mreg = prow[key0 + tid];
+            if (tid < FA_KT && j * FA_KT + tid < Tn) mreg = prow[j * FA_KT + tid];
         }
     };
     auto stage_store = [&](int buf) {
-        char* sK = smem + buf * FA_STAGE;
-        char* sV = sK + FA_K_BYTES;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int key = k_key[r];
-            *reinterpret_cast<u32x4*>(sK + key * 128 + ((k_ch ^ ((key >> 1) & 7)) << 4)) = kreg[r];
-        }
-        const int k0 = v_kp * 2;
-        const int pos = (k0 & ~12) | ((k0 & 4) << 1) | ((k0 & 8) >> 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            vec2 w;
-            w[0] = v0reg[e]; w[1] = v1reg[e];
-            *reinterpret_cast<vec2*>(sV + (v_ch * 8 + e) * FA_VS + v_ch * 16 + pos * 2) = w;
-        }
-        if constexpr (ALIBI) {
-            if (tid < FA_KT) { float* sC = reinterpret_cast<float*>(sV + FA_V_BYTES); sC[tid * 2] = cxreg; sC[tid * 2 + 1] = cyreg; }
-        }
         if constexpr (MASK) {
-            if (tid < FA_KT) (smem + 2 * FA_STAGE + buf * FA_KT)[tid] = (char)mreg;
+            if (tid < FA_KT) (smem + 2 * F2_STAGE + buf * FA_KT)[tid] = (char)mreg;
         }
     };
 
@@ -129,22 +117,37 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
     float xq = 0.f, yq = 0.f, sh = 0.f;
     if constexpr (ALIBI) { xq = cbase[(long)qc * 2]; yq = cbase[(long)qc * 2 + 1]; sh = head_scale[h]; }
     const float sc = 0.125f * 1.44269504088896340736f;
-    const int swz = (l31 >> 1) & 7;
+    const int swz = attn_swz(l31);
+    // transpose reads of the V image (attention_train.hip): lane i of 16-lane group g hands in (key row (i >> 2) of the 4, 8-byte piece i & 3 of its 32 bytes)
+    unsigned tra[2][2];
+    {
+        const int i16 = lane & 15, gd = (lane >> 4) & 1;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int row = hi * 4 + w * 8 + (i16 >> 2);
+                const int lc = dt * 4 + gd * 2 + ((i16 & 3) >> 1);
+                tra[w][dt] = (unsigned)(size_t)smem + FA_K_BYTES + row * 128 + ((lc ^ attn_swz(row)) << 4) + (i16 & 1) * 8;
+            }
+    }
+    int flip = F2_STAGE;
     bool qpad = false;
     if constexpr (MASK) qpad = prow[qc] != 0;
     uint32_t rowkey = 0;
     if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qc));
 
     const bool wave_live = qblk * 128 + wave * 32 < Tn;
-    stage_load(0);
+    stage_load(0, 0);
     stage_store(0);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int j = 0; j < ntile; ++j) {
         const int buf = j & 1;
-        if (j + 1 < ntile) stage_load(j + 1);
-        const char* sK = smem + buf * FA_STAGE;
+        if (j + 1 < ntile) stage_load(j + 1, buf ^ 1);
+        const char* sK = smem + buf * F2_STAGE;
         const char* sV = sK + FA_K_BYTES;
-        const char* sM = smem + 2 * FA_STAGE + buf * FA_KT;
+        const char* sM = smem + 2 * F2_STAGE + buf * FA_KT;
         // A wave whose 32 queries all lie past the sequence (T = 1025 = 8 blocks of 128 + ONE query: three of the ninth block's four waves) only helps staging:
         // its issue slots go to the workgroup that shares the CU (the ninth block was 11 % of the launch for 0.1 % of the queries)
         if (wave_live) {
@@ -227,16 +230,17 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            u32x2 tv[8];                    // V^T fragment [ks*4 + dt*2 + w]: keys 16 ks + 8 w + 4 hi + 0..3 of the tile's half t, feature dt*32 + l31
+            if (t == 0) FA_TR8(tv, tra[0][0], tra[0][1], tra[1][0], tra[1][1], 0); else FA_TR8(tv, tra[0][0], tra[0][1], tra[1][0], tra[1][1], 4096);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 vec8 pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = Act<T>::from_f32(s[t][ks * 8 + e]);
-                const int pos = t * 32 + ks * 16 + hi * 8;
                 vec8 bf;
                 if constexpr (ALIBI) {
-                    const float* sC = reinterpret_cast<const float*>(sV + FA_V_BYTES);
+                    const float* sC = reinterpret_cast<const float*>(sV + FA_K_BYTES);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int r = ks * 8 + e;
@@ -252,15 +256,18 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + l31;
-                    const vec8 vf = *reinterpret_cast<const vec8*>(sV + d * FA_VS + (d >> 3) * 16 + pos * 2);
+                    const vec8 vf = __builtin_bit_cast(vec8, u32x4{tv[ks * 4 + dt * 2][0], tv[ks * 4 + dt * 2][1], tv[ks * 4 + dt * 2 + 1][0], tv[ks * 4 + dt * 2 + 1][1]});
                     o[dt] = Act<T>::mfma32(vf, pf, o[dt]);
                     if constexpr (ALIBI) o2[dt] = Act<T>::mfma32(vf, bf, o2[dt]);
                 }
             }
         }
+        }
         if (j + 1 < ntile) stage_store(buf ^ 1);
-        __syncthreads();
+        tra[0][0] += flip; tra[0][1] += flip; tra[1][0] += flip; tra[1][1] += flip;
+        flip = -flip;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next tile has landed, this wave's reads of the current one are done
+        __builtin_amdgcn_s_barrier();
     }
     l += __shfl_xor(l, 32, 64);
     if (lse_out && q < Tn && hi == 0) lse_out[((long)b * H + h) * Tn + q] = mrun + log2f(l);   // log2-domain log-sum-exp
@@ -291,6 +298,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
             }
     }
 }
+
 
 
 // sum over the 8 lanes that share lane >> 3 (every lane gets it): xor 1, xor 2 (quad_perm), xor 7 (row_half_mirror)
@@ -642,7 +650,7 @@ using namespace amds;
 
 extern "C" int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && out, "amds_attention: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H), "amds_attention: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -772,7 +780,7 @@ extern "C" int amds_attention_row_alibi_bwd_train(const void* qkv, const void* o
 extern "C" int amds_attention_alibi(const void* qkv, const float* coords, const float* head_scale, void* out, int B, int T,
                                     int H, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && out && coords && head_scale, "amds_attention_alibi: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H), "amds_attention_alibi: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -787,7 +795,7 @@ extern "C" int amds_attention_alibi(const void* qkv, const float* coords, const 
 // forward that also stores L[b][h][q] = log2(sum_k exp2(s_qk * log2(e)/8)) for amds_attention_bwd
 extern "C" int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int T, int H, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && out && lse, "amds_attention_fwd_lse: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_fwd_lse: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H), "amds_attention_fwd_lse: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -805,7 +813,7 @@ extern "C" int amds_attention_fwd_lse(const void* qkv, void* out, float* lse, in
 extern "C" int amds_attention_alibi_fwd_train(const void* qkv, const float* coords, const float* inv_running_mean, const float* bias_scale,
                                               void* out_bf16, void* u_bf16, void* osm_bf16, float* lse, int B, int T, int H, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && coords && inv_running_mean && bias_scale && out_bf16 && u_bf16 && osm_bf16 && lse, "amds_attention_alibi_fwd_train: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_fwd_train: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H), "amds_attention_alibi_fwd_train: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -822,7 +830,7 @@ int amds::attention_alibi_fwd_train_dt(const void* qkv, const float* coords, con
                                        float* lse, int B, int T, int H, int dtype, void* stream) {
     if (dtype != AMDS_F16) return amds_attention_alibi_fwd_train(qkv, coords, inv_running_mean, bias_scale, out, u, osm, lse, B, T, H, dtype, stream);
     AMDS_REQUIRE(qkv && coords && inv_running_mean && bias_scale && out && u && osm && lse, "amds_attention_alibi_fwd_train: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_fwd_train: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H), "amds_attention_alibi_fwd_train: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -836,7 +844,7 @@ int amds::attention_alibi_fwd_train_dt(const void* qkv, const float* coords, con
 // with the class token included at t = 0 (never padded).  See the kernel comment for the literal blocking rule.
 extern "C" int amds_attention_masked(const void* qkv, const uint8_t* pad, void* out, int B, int T, int H, int mask_heads, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && out && pad, "amds_attention_masked: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && mask_heads > 0 && mask_heads <= H, "amds_attention_masked: bad shape B=%d T=%d H=%d mask_heads=%d", B, T, H, mask_heads);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H) && mask_heads > 0 && mask_heads <= H, "amds_attention_masked: bad shape B=%d T=%d H=%d mask_heads=%d", B, T, H, mask_heads);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -851,7 +859,7 @@ extern "C" int amds_attention_masked(const void* qkv, const uint8_t* pad, void* 
 extern "C" int amds_attention_alibi_masked(const void* qkv, const float* coords, const float* head_scale, const uint8_t* pad, void* out, int B, int T,
                                            int H, int dtype, void* stream) {
     AMDS_REQUIRE(qkv && out && coords && head_scale && pad, "amds_attention_alibi_masked: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535, "amds_attention_alibi_masked: bad shape B=%d T=%d H=%d", B, T, H);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H), "amds_attention_alibi_masked: bad shape B=%d T=%d H=%d", B, T, H);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);
@@ -869,7 +877,7 @@ extern "C" int amds_attention_fwd_train(const void* qkv, void* out, float* lse, 
                                         uint32_t stream_id, void* stream) {
     if (p == 0.f) return amds_attention_fwd_lse(qkv, out, lse, B, T, H, dtype, stream);
     AMDS_REQUIRE(qkv && out && lse, "amds_attention_fwd_train: null pointer");
-    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && p > 0.f && p < 1.f, "amds_attention_fwd_train: bad arguments B=%d T=%d H=%d p=%f", B, T, H, p);
+    AMDS_REQUIRE(B >= 0 && T > 0 && H > 0 && H <= 65535 && B <= 65535 && FA_SPAN_OK(T, H) && p > 0.f && p < 1.f, "amds_attention_fwd_train: bad arguments B=%d T=%d H=%d p=%f", B, T, H, p);
     if (B == 0) return AMDS_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((T + 127) / 128, H, B), block(256);

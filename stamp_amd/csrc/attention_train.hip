@@ -5,31 +5,20 @@
 // (src/stamp/modeling/models/__init__.py:239-279).
 //   P   = exp2(s * c - L[q]),  s = q . k,  c = log2(e) / 8
 //   dV  = P^T dO ;  dP = dO V^T ;  dS = P o (dP - Dq),  Dq = rowsum(dO o O) ;  dQ = dS K / 8 ;  dK = dS^T Q / 8
-// Two kernels, both built from the forward's MFMA layout rules (W/K-type operand rows in LDS row-major XOR-swizzled,
-// "transposed" operands as a skewed [d][token] LDS image whose token order inside 16-groups has bits 2<->3 swapped so
-// that a lane's accumulator registers ARE the next MFMA's B fragment -- no cross-lane data movement anywhere):
-//   attn_bwd_dkdv_kernel : one workgroup = 128 keys (lane = key), loops over query tiles  -> dK, dV
-//   attn_bwd_dq_kernel   : one workgroup = 128 queries (lane = query), loops over key tiles -> dQ
+// Two kernels, both built from the forward's MFMA layout rules (a lane's accumulator registers ARE the next MFMA's B fragment -- no cross-lane data movement
+// anywhere) and the forward's data path (round 6): tiles by buffer-form LDS-DMA into two row-major stages, "transposed" operands by ds_read_b64_tr_b16 transpose
+// reads of those rows, one raw s_barrier per tile:
+//   attn_bwd_dkdv2_kernel : one workgroup = 128 keys (lane = key), loops over query tiles  -> dK, dV      (150-158 registers, 34 KB: three workgroups per CU)
+//   attn_bwd_dq2_kernel   : one workgroup = 128 queries (lane = query), loops over key tiles -> dQ         (120-124 registers, 32 KB: four)
+// The kernels are VALU-issue-bound (per 64-token tile and wave ~400 VALU + 32 exp2 + 32 integer multiplies against 24-32 MFMAs): what round 6 removed is VALU work
+// (one dropout hash per key PAIR, no bounds tests in full tiles, no transposing store pass) and registers (more waves per SIMD); profiles/r06_attn_bwd_ab.txt.
+// The first forms (register staging, transposed LDS images) are kept as text in tools/ubench/attic/attention_first_forms/.
 #include "common.h"
-#include <cstdlib>
 
 namespace amds {
 
 constexpr int BT_TILE = 64;                        // tokens per streamed tile
-constexpr int BT_RS = 192;                         // row stride (bytes) of the transposed images: 12 slots + 16 B skew / 8 rows
 constexpr int BT_ROW_BYTES = BT_TILE * 128;        // row-major image: 64 tokens x 128 B
-constexpr int BT_TR_BYTES = 64 * BT_RS + 8 * 16;   // transposed image: 64 feature rows x 64 tokens (+ skew)
-// dQ kernel: LDS stages per workgroup and workgroups per CU the build asks for.  1 stage (28.8 KB) x 3 workgroups: 367 us at the bench shape against 414 us for
-// 2 stages (57.6 KB, one barrier per tile) x 2 workgroups -- the kernel needs 158-162 registers, and a third wave per SIMD hides more than the second barrier costs
-// (profiles/r06_attn_bwd_valu_diet.txt; -DDQ_STAGES=2 -DDQ_WGS=2 rebuilds the other form)
-#ifndef DQ_STAGES
-#define DQ_STAGES 1
-#endif
-#ifndef DQ_WGS
-#define DQ_WGS 3
-#endif
-
-__device__ __forceinline__ int perm16(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
 // Dq[b][h][q] = sum_d dO[q][h*64+d] * Osm[q][h*64+d], Osm = the softmax part of the output (`o`; for plain attention the output).
 // ALiBi (u != NULL): out = Osm - bias_scale_h U; dbs_part[b][h][q] = -sum_d dO U, whose sum over (b, q) is the gradient of
@@ -77,214 +66,11 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const T* __restrict_
 // dK, dV: lane = key.  Per query tile (64 queries, two 32-query halves):
 //   S[i=query][j=key]  = Q_rows . K^T(regs)        dP[i=query][j=key] = dO_rows . V^T(regs)
 //   dV^T[d][key] += dO^T[d][q] P[q][key]           dK^T[d][key] += Q^T[d][q] dS[q][key]
-// ---------------------------------------------------------------------------------------------------------------------
-// ALIBI: dV^T += dO^T (P - c_h D) with D = cdist(coords) and c_h = bias_scale_h / running_mean_h (the value path of the
-// post-softmax distance bias, vision_tranformer.py:60-72); dS, dK, dQ are those of the softmax part alone.
-// DROP: dropout on the attention probabilities (amds_attention_fwd_train): with M = keep-mask * 1/(1-p) regenerated from the same
-// counters, dV = (M o P)^T dO, dP = M o (dO V^T), dS = P o (dP - Dq) where Dq = rowsum(dO o O) still holds for O = (M o P) V.
-template <typename T, bool ALIBI = false, bool DROP = false>
-__global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                               const float* __restrict__ lse, const float* __restrict__ dq_sum,
-                                                               T* __restrict__ dqkv, int Tn, int H, const float* __restrict__ coords = nullptr,
-                                                               const float* __restrict__ dist_scale = nullptr, uint64_t seed = 0,
-                                                               uint32_t drop_stream = 0, uint32_t thr16 = 0, float keep_scale = 1.f) {
-    typedef typename Act<T>::vec8 vec8;
-    typedef typename Act<T>::vec4 vec4;
-    // ONE LDS stage (42 KB) and <= 256 registers: two workgroups per CU.  With two stages (84 KB, 288-304 registers) a CU held a single
-    // workgroup -- one wave per SIMD, every MFMA -> exp2 -> MFMA chain exposed -- and the kernel ran at 385 TFLOP/s against 620-630 for the
-    // forward and the dQ kernel, which always had two.  The next tile still travels global -> registers under the current tile's compute; it
-    // is written to the stage between two barriers, and the partner workgroup's MFMAs fill those.
-    constexpr int STAGE = 2 * BT_ROW_BYTES + 2 * BT_TR_BYTES + 2 * BT_TILE * 4 + ((ALIBI || DROP) ? 2 * BT_TILE * 4 : 0);
-    __shared__ __attribute__((aligned(16))) char smem[STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
-    const float* cbase = ALIBI ? coords + (long)b * Tn * 2 : nullptr;
-    const int Dm = H * 64;
-    const long ld = 3L * Dm;
-    const T* base = qkv + (long)b * Tn * ld + h * 64;           // q at +0, k at +Dm, v at +2Dm
-    const T* dobase = dout + (long)b * Tn * Dm + h * 64;
-    const float* lrow = lse + ((long)b * H + h) * Tn;
-    const float* drow = dq_sum + ((long)b * H + h) * Tn;
-    const int ntile = (Tn + BT_TILE - 1) / BT_TILE;
-
-    // this lane's key: K and V fragments stay in registers for the whole kernel
-    const int key = kblk * 128 + wave * 32 + l31;
-    const int keyc = min(key, Tn - 1);
-    vec8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = *reinterpret_cast<const vec8*>(base + (long)keyc * ld + Dm + (ks * 2 + hi) * 8);
-        vf[ks] = *reinterpret_cast<const vec8*>(base + (long)keyc * ld + 2 * Dm + (ks * 2 + hi) * 8);
-    }
-
-    // staging: per tile 64 queries x (Q row 128 B + dO row 128 B); thread -> (token pair, 8-wide d chunk)
-    const int pr = tid >> 3, ch = tid & 7;          // pair 0..31 -> tokens 2pr, 2pr+1
-    vec8 q0, q1, g0, g1;
-    float lreg = 0.f, dreg = 0.f, cxreg = 0.f, cyreg = 0.f;
-    uint32_t rkreg = 0;
-    float xk = 0.f, yk = 0.f, ch_ = 0.f;
-    if constexpr (ALIBI) { xk = cbase[(long)keyc * 2]; yk = cbase[(long)keyc * 2 + 1]; ch_ = dist_scale[h]; }
-    auto stage_load = [&](int j) {
-        const int t0 = j * BT_TILE + pr * 2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { q0[e] = (T)0.f; q1[e] = (T)0.f; g0[e] = (T)0.f; g1[e] = (T)0.f; }
-        if (t0 < Tn) { q0 = *reinterpret_cast<const vec8*>(base + (long)t0 * ld + ch * 8); g0 = *reinterpret_cast<const vec8*>(dobase + (long)t0 * Dm + ch * 8); }
-        if (t0 + 1 < Tn) { q1 = *reinterpret_cast<const vec8*>(base + (long)(t0 + 1) * ld + ch * 8); g1 = *reinterpret_cast<const vec8*>(dobase + (long)(t0 + 1) * Dm + ch * 8); }
-        lreg = dreg = 0.f;
-        if (tid < BT_TILE && j * BT_TILE + tid < Tn) { lreg = lrow[j * BT_TILE + tid]; dreg = drow[j * BT_TILE + tid]; }
-        if constexpr (ALIBI) {
-            cxreg = cyreg = 0.f;
-            if (tid < BT_TILE && j * BT_TILE + tid < Tn) { cxreg = cbase[(long)(j * BT_TILE + tid) * 2]; cyreg = cbase[(long)(j * BT_TILE + tid) * 2 + 1]; }
-        }
-        if constexpr (DROP) {      // per-query row keys of this tile (ALiBi has no attention dropout: the slot is free)
-            if (tid < BT_TILE) rkreg = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + min(j * BT_TILE + tid, Tn - 1)));
-        }
-    };
-    auto stage_store = [&](int buf) {
-        char* sQ = smem + buf * STAGE;
-        char* sG = sQ + BT_ROW_BYTES;
-        char* sQt = sG + BT_ROW_BYTES;
-        char* sGt = sQt + BT_TR_BYTES;
-        float* sL = reinterpret_cast<float*>(sGt + BT_TR_BYTES);
-        if constexpr (DROP) {
-            if (tid < BT_TILE) reinterpret_cast<uint32_t*>(sL)[2 * BT_TILE + tid] = rkreg;
-        }
-        const int t0 = pr * 2;
-        *reinterpret_cast<vec8*>(sQ + t0 * 128 + ((ch ^ ((t0 >> 1) & 7)) << 4)) = q0;
-        *reinterpret_cast<vec8*>(sQ + (t0 + 1) * 128 + ((ch ^ (((t0 + 1) >> 1) & 7)) << 4)) = q1;
-        *reinterpret_cast<vec8*>(sG + t0 * 128 + ((ch ^ ((t0 >> 1) & 7)) << 4)) = g0;
-        *reinterpret_cast<vec8*>(sG + (t0 + 1) * 128 + ((ch ^ (((t0 + 1) >> 1) & 7)) << 4)) = g1;
-        const int pos = perm16(t0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            vec2 w;
-            w[0] = q0[e]; w[1] = q1[e];
-            *reinterpret_cast<vec2*>(sQt + (ch * 8 + e) * BT_RS + ch * 16 + pos * 2) = w;
-            w[0] = g0[e]; w[1] = g1[e];
-            *reinterpret_cast<vec2*>(sGt + (ch * 8 + e) * BT_RS + ch * 16 + pos * 2) = w;
-        }
-        if (tid < BT_TILE) { sL[tid] = lreg; sL[BT_TILE + tid] = dreg; }
-        if constexpr (ALIBI) {
-            if (tid < BT_TILE) { sL[2 * BT_TILE + tid] = cxreg; sL[3 * BT_TILE + tid] = cyreg; }
-        }
-    };
-
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    const float sc = 0.125f * 1.44269504088896340736f;
-    const int swz = (l31 >> 1) & 7;
-
-    const bool wave_live = kblk * 128 + wave * 32 < Tn;
-    // Dropout bits are one hash per (query, key PAIR) and a lane is a key: lanes 2m and 2m + 1 would compute the same 16 hashes per half.  Instead the even lane
-    // hashes the even registers' queries and the odd lane the odd ones; the two 16-bit compares of a hash become wave masks (SGPR pairs) that the scalar unit
-    // re-deals to the two lanes of the pair (the lane with the even key reads the low half-word, its neighbour the high one): 8 hashes + 16 compares per half
-    // instead of 16 + 16 + 16 extracts, the re-dealing on the SALU.  The kernels are VALU-issue-bound (~3.9 k VALU cycles against 1 k of MFMA per tile).
-    const int par = lane & 1;
-    const uint32_t pair_g = DROP ? ((uint32_t)key >> 1) * 0x9E3779B1u : 0u;
-    constexpr uint64_t EVEN = 0x5555555555555555ull;
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int j = 0; j < ntile; ++j) {
-        const int buf = 0;
-        if (j + 1 < ntile) stage_load(j + 1);
-        const char* sQ = smem + buf * STAGE;
-        const char* sG = sQ + BT_ROW_BYTES;
-        const char* sQt = sG + BT_ROW_BYTES;
-        const char* sGt = sQt + BT_TR_BYTES;
-        const float* sL = reinterpret_cast<const float*>(sGt + BT_TR_BYTES);
-        if (wave_live)                                      // (a wave whose 32 keys all lie past the sequence only helps staging: T = 1025's ninth block)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (j * BT_TILE + half * 32 >= Tn) continue;    // 32 queries past the sequence (T = 1025: the second half of the 17th tile)
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = (half * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4);
-                const vec8 qa = *reinterpret_cast<const vec8*>(sQ + off);
-                const vec8 ga = *reinterpret_cast<const vec8*>(sG + off);
-                s = Act<T>::mfma32(qa, kf[ks], s);
-                dp = Act<T>::mfma32(ga, vf[ks], dp);
-            }
-            uint64_t keepm[16];
-            if constexpr (DROP) {
-                const uint32_t* sRK = reinterpret_cast<const uint32_t*>(sL) + 2 * BT_TILE + half * 32 + 4 * hi + par;
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {             // this lane's register 2 rr + par = query ((2 rr) & 3) + par + 8 (rr >> 1) (+ 4 hi) of the half
-                    const uint32_t hsh = fmix32(sRK[((2 * rr) & 3) + 8 * (rr >> 1)] ^ pair_g);
-                    const uint64_t k0 = __builtin_amdgcn_ballot_w64((hsh & 0xFFFFu) >= thr16);
-                    const uint64_t k1 = __builtin_amdgcn_ballot_w64((hsh >> 16) >= thr16);
-                    keepm[2 * rr] = (k0 & EVEN) | ((k1 & EVEN) << 1);              // hashed by the even lanes
-                    keepm[2 * rr + 1] = (k1 & ~EVEN) | ((k0 & ~EVEN) >> 1);        // hashed by the odd lanes
-                }
-            }
-            // lane = key, register r = query (r&3) + 8(r>>2) + 4hi of this 32-query half.  No bounds tests: a query past the sequence was staged as zeros (Q, dO, L,
-            // D: p = 1, dS = 0, and its dO / Q columns of the two products below are zero), a key past it is a lane of its own whose dK / dV are never stored.
-            vec8 pf[2], df[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -sL[ql]));
-                float dpr = dp[r];
-                float pw = p;                                   // weight on v: P (dropped: M o P), minus the scaled distance for ALiBi
-                if constexpr (DROP) {
-                    const bool keep = __builtin_amdgcn_inverse_ballot_w64(keepm[r]);
-                    dpr = keep ? dpr * keep_scale : 0.f;
-                    pw = keep ? pw * keep_scale : 0.f;
-                }
-                const float dsv = p * (dpr - sL[BT_TILE + ql]);
-                if constexpr (ALIBI) {
-                    const float ddx = sL[2 * BT_TILE + ql] - xk, ddy = sL[3 * BT_TILE + ql] - yk;
-                    pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
-                }
-                pf[r >> 3][r & 7] = Act<T>::from_f32(pw);
-                df[r >> 3][r & 7] = Act<T>::from_f32(dsv);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int pos = half * 32 + ks * 16 + hi * 8;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + l31;
-                    const int off = d * BT_RS + (d >> 3) * 16 + pos * 2;
-                    const vec8 gt = *reinterpret_cast<const vec8*>(sGt + off);
-                    const vec8 qt = *reinterpret_cast<const vec8*>(sQt + off);
-                    dv[dt] = Act<T>::mfma32(gt, pf[ks], dv[dt]);
-                    dk[dt] = Act<T>::mfma32(qt, df[ks], dk[dt]);
-                }
-            }
-        }
-        __syncthreads();                                  // every wave is done reading the stage
-        if (j + 1 < ntile) stage_store(0);
-        __syncthreads();
-    }
-    if (key < Tn) {
-        T* krow = dqkv + ((long)b * Tn + key) * ld + Dm + h * 64;
-        T* vrow = krow + Dm;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                vec4 wk, wv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { wk[e] = Act<T>::from_f32(dk[dt][4 * g + e] * 0.125f); wv[e] = Act<T>::from_f32(dv[dt][4 * g + e]); }
-                *reinterpret_cast<vec4*>(krow + dt * 32 + 8 * g + 4 * hi) = wk;
-                *reinterpret_cast<vec4*>(vrow + dt * 32 + 8 * g + 4 * hi) = wv;
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// dK, dV, second form (the product): the same arithmetic, in the same order, with the data path of a gfx950 kernel.
+// ALIBI: dV^T += dO^T (P - c_h D) with D = cdist(coords) and c_h = bias_scale_h / running_mean_h (the value path of the post-softmax distance bias,
+// vision_tranformer.py:60-72); dS, dK, dQ are those of the softmax part alone.
+// DROP: dropout on the attention probabilities (amds_attention_fwd_train): with M = keep-mask * 1/(1-p) regenerated from the same counters, dV = (M o P)^T dO,
+// dP = M o (dO V^T), dS = P o (dP - Dq) where Dq = rowsum(dO o O) still holds for O = (M o P) V.
+// Data path:
 //   * the Q and dO tiles go global -> LDS by buffer-form LDS-DMA (no staging registers; rows past the sequence are out of the descriptor's range and read as 0),
 //     two stages of 17 KB, ONE barrier per tile;
 //   * there are no transposed images: the dO^T / Q^T fragments of the two second products are ds_read_b64_tr_b16 transpose reads of the row-major images (a
@@ -292,7 +78,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const T* __restri
 //     of S / dP hold them in);
 //   * 16-byte chunk c of row q sits at chunk c ^ x(q), x(q) = bit 1 of q as bit 2 | bits 3..2 of q as bits 1..0: the row reads (ds_read_b128) AND the transpose
 //     reads (a 32-lane group = 4 consecutive rows x 64 B: rows q, q + 2 in opposite halves of their 128 bytes) are conflict-free;
-//   * 150-odd registers and 34 KB: THREE workgroups per CU (the first form: 208-245 registers, 42 KB, two).
+//   * 150-158 registers and 34 KB: THREE workgroups per CU (the first form: 208-245 registers, 42 KB, two).
 // The transpose reads are inline asm (the builtin makes the compiler wait for the LDS-DMA in flight before every read, gemm_4w16.h) and carry their own
 // s_waitcnt lgkmcnt(0): what the statement returns is there.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -425,12 +211,16 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkdv2_kernel(const T* __restr
                 dp = Act<T>::mfma32(ga, vf[ks], dp);
             }
             const __attribute__((address_space(3))) float* sL = reinterpret_cast<const __attribute__((address_space(3))) float*>((lds_cp)(size_t)sla) + half * 32;
-            // lane = key, register r = query (r&3) + 8(r>>2) + 4hi of this 32-query half; four registers at a time: two dropout hashes (the sharing between the
-            // two lanes of a key pair: see the first form), four keep masks
+            // lane = key, register r = query (r&3) + 8(r>>2) + 4hi of this 32-query half; four registers at a time: two dropout hashes, four keep masks.  No bounds
+            // tests: a query past the sequence reads as zeros (Q, dO, L, D: p = 1, dS = 0, and its dO / Q columns of the two products below are zero), a key past
+            // it is a lane of its own whose dK / dV are never stored.
             vec8 pf[2], df[2];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 uint64_t keepm[4] = {0, 0, 0, 0};
+                // Dropout bits are one hash per (query, key PAIR) and a lane is a key: lanes 2m and 2m + 1 would compute the same 16 hashes per half.  Instead the even
+                // lane hashes the even registers' queries and the odd lane the odd ones; the two 16-bit compares of a hash become wave masks (SGPR pairs) that the scalar
+                // unit re-deals to the two lanes of the pair (the lane with the even key reads the low half-word, its neighbour the high one).
                 if constexpr (DROP) {
                     const __attribute__((address_space(3))) uint32_t* sRK = reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(sL) + 2 * BT_TILE + par;
 #pragma unroll
@@ -512,16 +302,18 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkdv2_kernel(const T* __restr
 // dQ: lane = query.  Per key tile (64 keys, two 32-key halves):
 //   S^T[i=key][j=query] = K_rows . Q^T(regs)      dP^T[i=key][j=query] = V_rows . dO^T(regs)
 //   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+// The data path of attn_bwd_dkdv2_kernel: K and V tiles by LDS-DMA into two 16 KB stages, the K^T fragments of the dQ product by transpose reads of the row-major
+// K image, one barrier per tile, no staging registers.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, bool DROP = false>
-__global__ void __launch_bounds__(256, DQ_WGS) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ dq_sum,
-                                                             T* __restrict__ dqkv, int Tn, int H, uint64_t seed = 0, uint32_t drop_stream = 0,
-                                                             uint32_t thr16 = 0, float keep_scale = 1.f) {
+__global__ void __launch_bounds__(256, 4) attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                    const float* __restrict__ lse, const float* __restrict__ dq_sum,
+                                                                    T* __restrict__ dqkv, int Tn, int H, uint64_t seed = 0, uint32_t drop_stream = 0,
+                                                                    uint32_t thr16 = 0, float keep_scale = 1.f) {
     typedef typename Act<T>::vec8 vec8;
     typedef typename Act<T>::vec4 vec4;
-    constexpr int STAGE = 2 * BT_ROW_BYTES + BT_TR_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[DQ_STAGES * STAGE];
+    constexpr int STAGE = 2 * BT_ROW_BYTES;                         // K rows | V rows
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -545,31 +337,17 @@ __global__ void __launch_bounds__(256, DQ_WGS) attn_bwd_dq_kernel(const T* __res
     uint32_t rowkey = 0;
     if constexpr (DROP) rowkey = drop_rowkey(seed, drop_stream, (uint64_t)(((long)b * H + h) * Tn + qc));
 
-    const int pr = tid >> 3, ch = tid & 7;
-    vec8 k0, k1, v0, v1;
-    auto stage_load = [&](int j) {
-        const int t0 = j * BT_TILE + pr * 2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { k0[e] = (T)0.f; k1[e] = (T)0.f; v0[e] = (T)0.f; v1[e] = (T)0.f; }
-        if (t0 < Tn) { k0 = *reinterpret_cast<const vec8*>(base + (long)t0 * ld + Dm + ch * 8); v0 = *reinterpret_cast<const vec8*>(base + (long)t0 * ld + 2 * Dm + ch * 8); }
-        if (t0 + 1 < Tn) { k1 = *reinterpret_cast<const vec8*>(base + (long)(t0 + 1) * ld + Dm + ch * 8); v1 = *reinterpret_cast<const vec8*>(base + (long)(t0 + 1) * ld + 2 * Dm + ch * 8); }
-    };
-    auto stage_store = [&](int buf) {
+    // LDS-DMA (see attn_bwd_dkdv2_kernel): wave w requests 8-row pieces w and w + 4 of both images; key rows past the sequence read as 0
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + Dm), 0, (int)((((long)Tn - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + 2 * Dm), 0, (int)((((long)Tn - 1) * ld + 64) * 2), 0x00020000);
+    const int drow_ = wave * 8 + (lane >> 3);
+    const int vo = drow_ * (int)ld * 2 + (((lane & 7) ^ bt_swz(drow_)) << 4);
+    auto tile_request = [&](int j, int buf) {
         char* sK = smem + buf * STAGE;
-        char* sV = sK + BT_ROW_BYTES;
-        char* sKt = sV + BT_ROW_BYTES;
-        const int t0 = pr * 2;
-        *reinterpret_cast<vec8*>(sK + t0 * 128 + ((ch ^ ((t0 >> 1) & 7)) << 4)) = k0;
-        *reinterpret_cast<vec8*>(sK + (t0 + 1) * 128 + ((ch ^ (((t0 + 1) >> 1) & 7)) << 4)) = k1;
-        *reinterpret_cast<vec8*>(sV + t0 * 128 + ((ch ^ ((t0 >> 1) & 7)) << 4)) = v0;
-        *reinterpret_cast<vec8*>(sV + (t0 + 1) * 128 + ((ch ^ (((t0 + 1) >> 1) & 7)) << 4)) = v1;
-        const int pos = perm16(t0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            vec2 w;
-            w[0] = k0[e]; w[1] = k1[e];
-            *reinterpret_cast<vec2*>(sKt + (ch * 8 + e) * BT_RS + ch * 16 + pos * 2) = w;
+        for (int pc = 0; pc < 2; ++pc) {
+            bufl16(rsrc_k, sK + (wave + 4 * pc) * 1024, vo, (j * BT_TILE + 32 * pc) * (int)ld * 2);
+            bufl16(rsrc_v, sK + BT_ROW_BYTES + (wave + 4 * pc) * 1024, vo, (j * BT_TILE + 32 * pc) * (int)ld * 2);
         }
     };
 
@@ -579,21 +357,33 @@ __global__ void __launch_bounds__(256, DQ_WGS) attn_bwd_dq_kernel(const T* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
     const float sc = 0.125f * 1.44269504088896340736f;
-    const int swz = (l31 >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    unsigned ra[4], tra[2][2];                              // (attn_bwd_dkdv2_kernel: operand rows, transpose reads; moved between the stages in place)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ra[ks] = lds0 + l31 * 128 + (((ks * 2 + hi) ^ bt_swz(l31)) << 4);
+    {
+        const int i16 = lane & 15, gd = (lane >> 4) & 1;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int row = hi * 4 + w * 8 + (i16 >> 2);
+                const int lc = dt * 4 + gd * 2 + ((i16 & 3) >> 1);
+                tra[w][dt] = lds0 + row * 128 + ((lc ^ bt_swz(row)) << 4) + (i16 & 1) * 8;
+            }
+    }
+    int flip = STAGE;
+    typedef const __attribute__((address_space(3))) char* lds_cp;
 
     const bool wave_live = qblk * 128 + wave * 32 < Tn;
     uint32_t pair_g = DROP ? (uint32_t)(2 * hi) * 0x9E3779B1u : 0u;            // (key pair index of the lane's first key in the tile) x the hash's multiplier
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
+    tile_request(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int j = 0; j < ntile; ++j) {
-        const int buf = DQ_STAGES == 2 ? (j & 1) : 0;
-        if (j + 1 < ntile) stage_load(j + 1);
-        const char* sK = smem + buf * STAGE;
-        const char* sV = sK + BT_ROW_BYTES;
-        const char* sKt = sV + BT_ROW_BYTES;
+        if (j + 1 < ntile) tile_request(j + 1, (j & 1) ^ 1);
         const bool ragged = (j + 1) * BT_TILE > Tn;             // the last tile of a T that is no multiple of 64
-        if (wave_live)                                      // (a wave whose 32 queries all lie past the sequence only helps staging: T = 1025's ninth block)
+        if (wave_live)                                      // (a wave whose 32 queries all lie past the sequence only requests: T = 1025's ninth block)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (j * BT_TILE + half * 32 >= Tn) continue;    // 32 keys past the sequence (T = 1025: the second half of the 17th tile)
@@ -602,15 +392,13 @@ __global__ void __launch_bounds__(256, DQ_WGS) attn_bwd_dq_kernel(const T* __res
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int off = (half * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4);
-                const vec8 ka = *reinterpret_cast<const vec8*>(sK + off);
-                const vec8 va = *reinterpret_cast<const vec8*>(sV + off);
+                const vec8 ka = *reinterpret_cast<const __attribute__((address_space(3))) vec8*>((lds_cp)(size_t)(ra[ks] + half * 4096));
+                const vec8 va = *reinterpret_cast<const __attribute__((address_space(3))) vec8*>((lds_cp)(size_t)(ra[ks] + half * 4096 + BT_ROW_BYTES));
                 s = Act<T>::mfma32(ka, qf[ks], s);
                 dp = Act<T>::mfma32(va, gf[ks], dp);
             }
-            if (ragged) {
-                // keys past the sequence: p = exp2(-inf) = 0.  A branch taken once per workgroup: the empty asm statements cannot be speculated, so the block is not
-                // if-converted into 16 compares + 16 selects on every tile of a loop that is short of VALU issue slots, not of branch units
+            if (ragged) {       // keys past the sequence: p = exp2(-inf) = 0.  A branch taken once per workgroup: the empty asm statements cannot be speculated, so
+                                // the block is not if-converted into 16 compares + 16 selects on every tile of a loop that is short of VALU issue slots
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (j * BT_TILE + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Tn) s[r] = -INFINITY;
@@ -634,21 +422,24 @@ __global__ void __launch_bounds__(256, DQ_WGS) attn_bwd_dq_kernel(const T* __res
                     df[r >> 3][(r & 7) + e] = Act<T>::from_f32(p * (dpr - Dq));
                 }
             }
+            u32x2 tk[8];                                    // fragment [ks*4 + dt*2 + w]: keys 16 ks + 8 w + 4 hi + 0..3 of the half, feature dt*32 + l31
+            if (half == 0) BT_TR8(tk, tra[0][0], tra[0][1], tra[1][0], tra[1][1], 0); else BT_TR8(tk, tra[0][0], tra[0][1], tra[1][0], tra[1][1], 4096);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int pos = half * 32 + ks * 16 + hi * 8;
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + l31;
-                    const vec8 kt = *reinterpret_cast<const vec8*>(sKt + d * BT_RS + (d >> 3) * 16 + pos * 2);
+                    const vec8 kt = __builtin_bit_cast(vec8, u32x4{tk[ks * 4 + dt * 2][0], tk[ks * 4 + dt * 2][1], tk[ks * 4 + dt * 2 + 1][0], tk[ks * 4 + dt * 2 + 1][1]});
                     dq[dt] = Act<T>::mfma32(kt, df[ks], dq[dt]);
                 }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DROP) pair_g += 32u * 0x9E3779B1u;
-        if constexpr (DQ_STAGES == 1) __syncthreads();      // every wave is done reading the stage
-        if (j + 1 < ntile) stage_store(DQ_STAGES == 2 ? (buf ^ 1) : 0);
-        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ra[ks] += flip;
+        tra[0][0] += flip; tra[0][1] += flip; tra[1][0] += flip; tra[1][1] += flip;
+        flip = -flip;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next tile has landed, this wave's reads of the current one are done
+        __builtin_amdgcn_s_barrier();
     }
     if (q < Tn) {
         T* qrow = dqkv + ((long)b * Tn + q) * ld + h * 64;
@@ -674,27 +465,20 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* dout, con
                        (const T*)u, bias_scale, dbs_part);
     AMDS_LAUNCH_CHECK("attn_bwd_prep_kernel");
     const dim3 grid((T_ + 127) / 128, H, B), block(256);
-    static const bool first_form = getenv("AMDS_ATTN_DKDV") && atoi(getenv("AMDS_ATTN_DKDV")) == 1;       // A/B switch (read once)
     if (!u && p_drop > 0.f) {
         const uint32_t thr = drop_thr16(p_drop);
         const float ks = drop_scale(thr);
-        if (first_form) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
-        else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
-        AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel<drop>");
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, seed, drop_stream, thr, ks);
-        AMDS_LAUNCH_CHECK("attn_bwd_dq_kernel<drop>");
+        hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, false, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr, seed, drop_stream, thr, ks);
+        AMDS_LAUNCH_CHECK("attn_bwd_dkdv2_kernel<drop>");
+        hipLaunchKernelGGL((attn_bwd_dq2_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, seed, drop_stream, thr, ks);
+        AMDS_LAUNCH_CHECK("attn_bwd_dq2_kernel<drop>");
         return AMDS_OK;
     }
-    if (first_form) {
-        if (u) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
-        else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
-    } else {
-        if (u) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
-        else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
-    }
-    AMDS_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H);
-    AMDS_LAUNCH_CHECK("attn_bwd_dq_kernel");
+    if (u) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, true>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, coords, dist_scale);
+    else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<T, false>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H, nullptr, nullptr);
+    AMDS_LAUNCH_CHECK("attn_bwd_dkdv2_kernel");
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<T>), grid, block, 0, st, (const T*)qkv, (const T*)dout, lse, dq_sum, (T*)dqkv, T_, H);
+    AMDS_LAUNCH_CHECK("attn_bwd_dq2_kernel");
     return AMDS_OK;
 }
 
