@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                 }
         }
         uint32_t blocked = 0;            // bit t*16 + r: this (query, key) product is masked out
+        uint32_t nodist = 0;             // ALiBi: bit t*16 + r: no distance term either (alibi_mask: blocked, or the class token's row / column)
         if constexpr (MASK) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                     const int kl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const bool bl = (qpad && sM[kl] != 0) || (q > 0 && key0 + kl == 0);
                     blocked |= (bl ? 1u : 0u) << (t * 16 + r);
+                    if constexpr (ALIBI) nodist |= ((bl || q == 0 || key0 + kl == 0) ? 1u : 0u) << (t * 16 + r);
                     if (!ALIBI && bl) s[t][r] = -INFINITY;
                 }
         }
@@ -246,11 +248,10 @@ __global__ void __launch_bounds__(256, 2) attn_flash_kernel(const T* __restrict_
                         const int r = ks * 8 + e;
                         const int kl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         const float dx = xq - sC[kl * 2], dy = yq - sC[kl * 2 + 1];
-                        float dist = sqrtf(dx * dx + dy * dy) * sh;
-                        if (ragged && key0 + kl >= Tn) dist = 0.f;
-                        if constexpr (MASK) {
-                            if (((blocked >> (t * 16 + r)) & 1u) || q == 0 || key0 + kl == 0) dist = 0.f;
-                        }
+                        float dist = dist_sqrt(dx * dx + dy * dy) * sh;
+                        // (no bounds test: a key past the sequence has zero coordinates -- a finite distance -- and a zero V row)
+                        if constexpr (MASK)     // AND with a sign-extended bit: as selects, the 32 conditions were held as wave masks and spilled the scalar file
+                            dist = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, dist) & ~(uint32_t)(-(int32_t)((nodist >> (t * 16 + r)) & 1u)));
                         bf[e] = Act<T>::from_f32(dist);
                     }
                 }
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(256) attn_row_alibi_kernel(const T* __restrict
         if (sub == 0) {
             sS[key] = sv;
             const float dx = xq - cb[2 * key], dy = yq - cb[2 * key + 1];
-            sD[key] = sqrtf(dx * dx + dy * dy) * irm;
+            sD[key] = dist_sqrt(dx * dx + dy * dy) * irm;
         }
         mx = fmaxf(mx, sv);
     }
@@ -611,7 +612,7 @@ __global__ void __launch_bounds__(256) attn_row_alibi_bwd_kernel(const T* __rest
         p0 = sum8_dpp(p0);
         const float pk = __builtin_amdgcn_exp2f(s0 * sc - L);
         const float dx = xq - cb[2 * key], dy = yq - cb[2 * key + 1];
-        const float dS = pk * (p0 - Dq), pw = pk - dsc * sqrtf(dx * dx + dy * dy), dk = dS * 0.125f;
+        const float dS = pk * (p0 - Dq), pw = pk - dsc * dist_sqrt(dx * dx + dy * dy), dk = dS * 0.125f;
         if (sub == 0) sS[key] = dS;
         T* drow = dbase + (long)key * ld + sub * 8;
         vec8 wq, wk, wv;

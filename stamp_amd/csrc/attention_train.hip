@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkdv2_kernel(const T* __restr
                     const float dsv = p * (dpr - sL[BT_TILE + ql]);
                     if constexpr (ALIBI) {
                         const float ddx = sL[2 * BT_TILE + 2 * ql + 4 * hi + half * 32] - xk, ddy = sL[2 * BT_TILE + 2 * ql + 4 * hi + half * 32 + 1] - yk;   // (x, y) pairs, 8 bytes per query: sL already points 4 hi + 32 half floats in
-                        pw -= ch_ * sqrtf(ddx * ddx + ddy * ddy);
+                        pw -= ch_ * dist_sqrt(ddx * ddx + ddy * ddy);
                     }
                     pf[r >> 3][r & 7] = Act<T>::from_f32(pw);
                     df[r >> 3][r & 7] = Act<T>::from_f32(dsv);
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) cdist_rowsum_kernel(const float* __restri
     float s = 0.f;
     for (int k = lane; k < Tn; k += 64) {
         const float dx = xq - cb[k * 2], dy = yq - cb[k * 2 + 1];
-        s += sqrtf(dx * dx + dy * dy);
+        s += dist_sqrt(dx * dx + dy * dy);
     }
     s = wave_sum(s);
     if (lane == 0) rowsum[r] = s;

@@ -270,6 +270,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // M x FF is stored.  One 32-bit hash (murmur3 finaliser over a per-row key) serves the element PAIR (2j, 2j+1) of a row, 16
 // bits each:  keep  <=>  bits16 >= thr16,  thr16 = round(p * 65536)  ->  P(drop) = thr16 / 65536 (p = 0.5, 0.25 exact),
 // kept values are scaled by 65536 / (65536 - thr16).  `stream` separates the dropout sites of one training step.
+// Token distances of the ALiBi term: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf, which the compiler expands into ~18 VALU instructions around the
+// same v_sqrt_f32 -- 60 % of the ALiBi forward's VALU stream, in kernels that are VALU-issue-bound; the distance is rounded to 16 bits as an MFMA operand right after.
+__device__ __forceinline__ float dist_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __host__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;

@@ -115,8 +115,48 @@ def param_names(d: VitDims) -> list[str]:
     return names
 
 
+def flat_order(d: VitDims, names: list[str]) -> list[str]:
+    """Order of the tensors inside a trainer's flat master / gradient / moment buffers.  The reference's state_dict interleaves the ALiBi head's
+    per-head Linears (weight, bias, weight, bias ...); laid out per layer as [3 x H weights][3 x H biases][H bias scales][H running means][H counts]
+    the stacked in-projection the kernels consume IS a contiguous view of the buffer (`_stack`), in both directions: no per-head copies when the
+    operands are refreshed, and the library writes the gradients straight into the trainer's buffer (`_direct_grad_structs`).  Every name keeps
+    its own view; nothing outside the trainer sees the order."""
+    if not d.alibi:
+        return list(names)
+    out, done = [], set()
+    for n in names:
+        if n in done:
+            continue
+        first = layer_prefix(0)[:-2]            # "transformer.layers."
+        if n.startswith(first) and n.endswith(f"0.mhsa.{_ENC[0]}.0.weight"):
+            p = n[: -len(f"0.mhsa.{_ENC[0]}.0.weight")]
+            grp = [p + f"0.mhsa.{e}.{h}.{kind}" for kind in ("weight", "bias") for e in _ENC for h in range(d.H)]
+            grp += [p + f"0.mhsa.attentions.{h}.{leaf}" for leaf in ("bias_scale", "scale_distance.running_mean", "scale_distance.items_so_far") for h in range(d.H)]
+            out += grp
+            done.update(grp)
+        else:
+            out.append(n)
+            done.add(n)
+    assert sorted(out) == sorted(names)
+    return out
+
+
 def is_buffer(name: str) -> bool:
     return name.endswith("scale_distance.running_mean") or name.endswith("scale_distance.items_so_far")
+
+
+def _stack(ts: list) -> torch.Tensor:
+    """torch.stack(ts) -- as a strided VIEW (no launch) when the tensors are equally shaped slices of one storage at a constant pitch: the
+    trainer's parameters are views of one flat buffer, and the ALiBi head's per-head Linears (3 x H weights + 3 x H biases per layer, then 2 H
+    scalars) cost ~150 tiny device copies per refresh as a stack of separate tensors -- host time the step then waits for."""
+    t0 = ts[0]
+    if len(ts) > 1 and all(t.shape == t0.shape and t.stride() == t0.stride() and t.dtype == t0.dtype and t.device == t0.device
+                           and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in ts):
+        offs = [t.storage_offset() for t in ts]
+        pitch = offs[1] - offs[0]
+        if pitch > 0 and all(b - a == pitch for a, b in zip(offs, offs[1:])):
+            return t0.as_strided((len(ts),) + tuple(t0.shape), (pitch,) + tuple(t0.stride()), offs[0])
+    return torch.stack(ts)
 
 
 # ---- zero padding of the weights (data movement only) --------------------------------------------------------------------------
@@ -185,11 +225,11 @@ class PackedVit:
             Lm: dict = {"ln1": (get(p + "0.norm.weight").contiguous(), get(p + "0.norm.bias").contiguous()),
                         "ln2": (get(p + "1.0.weight").contiguous(), get(p + "1.0.bias").contiguous())}
             if d.alibi:     # per-head Linear(D, hd) encoders = a row-blocked in-projection [q heads | k heads | v heads]
-                w3 = torch.stack([torch.stack([get(p + f"0.mhsa.{e}.{h}.weight") for h in range(d.H)]) for e in _ENC])
-                b3 = torch.stack([torch.stack([get(p + f"0.mhsa.{e}.{h}.bias") for h in range(d.H)]) for e in _ENC])
+                w3 = _stack([_stack([get(p + f"0.mhsa.{e}.{h}.weight") for h in range(d.H)]) for e in _ENC])
+                b3 = _stack([_stack([get(p + f"0.mhsa.{e}.{h}.bias") for h in range(d.H)]) for e in _ENC])
                 Lm["out_w"], Lm["out_b"] = self._pad_out(get(p + "0.mhsa.fc.weight")), _pad1(get(p + "0.mhsa.fc.bias"), d.Dp)
-                bs = torch.cat([get(p + f"0.mhsa.attentions.{h}.bias_scale").reshape(1) for h in range(d.H)])
-                rm = torch.cat([get(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean").reshape(1) for h in range(d.H)])
+                bs = _stack([get(p + f"0.mhsa.attentions.{h}.bias_scale").reshape(1) for h in range(d.H)]).reshape(d.H)
+                rm = _stack([get(p + f"0.mhsa.attentions.{h}.scale_distance.running_mean").reshape(1) for h in range(d.H)]).reshape(d.H)
                 Lm["bias_scale"] = _pad1(bs, d.Ha)
                 Lm["inv_rm"] = F.pad(1.0 / rm, (0, d.Ha - d.H), value=1.0).contiguous()
             else:
@@ -434,20 +474,32 @@ def _grad_buffers(d: VitDims, dev):
 
 
 def _direct_grad_structs(d: VitDims, grad_views):
-    """When nothing is padded (widths multiples of 256, 64-channel heads in multiples of 4, no ALiBi) the padded gradient layout IS the reference's:
+    """When nothing is padded (widths multiples of 256, 64-channel heads in multiples of 4) the padded gradient layout IS the reference's (ALiBi: that of a
+    buffer in `flat_order`):
     amds_mil_vit_grads can point straight at the caller's own gradient tensors (`grad_views(name)`, e.g. views of a trainer's flat buffer) and
     the per-step copies disappear.  -> (MilVitGrads, keep-alive, {name: tensor}) or None when the shapes (or a pointer's alignment) do not allow it."""
-    if d.alibi or d.D != d.Dp or d.F != d.Fp or d.FF != d.FFp or d.hd != 64 or d.Ha != d.H:
+    if d.D != d.Dp or d.F != d.Fp or d.FF != d.FFp or d.hd != 64 or d.Ha != d.H:
         return None
-    names = param_names(d)
+    names = [n for n in param_names(d) if not is_buffer(n)]
     G = {n: grad_views(n) for n in names}
-    if any((not t.is_contiguous()) or t.dtype != torch.float32 or t.data_ptr() % 16 for t in G.values()):
+    # (the ALiBi head's per-head tensors are addressed through their stacks below: a lone bias scale is one float)
+    if any((not t.is_contiguous()) or t.dtype != torch.float32 or (t.data_ptr() % 16 and ".mhsa.attentions." not in n) for n, t in G.items()):
         return None
     lg = (_lib.MilVitLayerGrads * max(d.L, 1))()
     for l in range(d.L):
         p = layer_prefix(l)
-        lg[l] = _lib.MilVitLayerGrads(G[p + "0.norm.weight"].data_ptr(), G[p + "0.norm.bias"].data_ptr(), G[p + "0.mhsa.in_proj_weight"].data_ptr(),
-                                      G[p + "0.mhsa.in_proj_bias"].data_ptr(), G[p + "0.mhsa.out_proj.weight"].data_ptr(), G[p + "0.mhsa.out_proj.bias"].data_ptr(), None,
+        if d.alibi:     # the stacked in-projection [3][H][64][D] | [3][H][64] and the H bias scales must BE contiguous runs of the caller's buffer (flat_order)
+            in_w = _stack([_stack([G[p + f"0.mhsa.{e}.{h}.weight"] for h in range(d.H)]) for e in _ENC])
+            in_b = _stack([_stack([G[p + f"0.mhsa.{e}.{h}.bias"] for h in range(d.H)]) for e in _ENC])
+            bsc = _stack([G[p + f"0.mhsa.attentions.{h}.bias_scale"].reshape(1) for h in range(d.H)])
+            own = G[p + "0.norm.weight"].untyped_storage().data_ptr()
+            if any((not t.is_contiguous()) or t.untyped_storage().data_ptr() != own or t.data_ptr() % 16 for t in (in_w, in_b, bsc)):
+                return None
+            attn = (in_w.data_ptr(), in_b.data_ptr(), G[p + "0.mhsa.fc.weight"].data_ptr(), G[p + "0.mhsa.fc.bias"].data_ptr(), bsc.data_ptr())
+        else:
+            attn = (G[p + "0.mhsa.in_proj_weight"].data_ptr(), G[p + "0.mhsa.in_proj_bias"].data_ptr(), G[p + "0.mhsa.out_proj.weight"].data_ptr(),
+                    G[p + "0.mhsa.out_proj.bias"].data_ptr(), None)
+        lg[l] = _lib.MilVitLayerGrads(G[p + "0.norm.weight"].data_ptr(), G[p + "0.norm.bias"].data_ptr(), *attn,
                                       G[p + "1.0.weight"].data_ptr(), G[p + "1.0.bias"].data_ptr(), G[p + "1.1.weight"].data_ptr(), G[p + "1.1.bias"].data_ptr(),
                                       G[p + "1.4.weight"].data_ptr(), G[p + "1.4.bias"].data_ptr())
     gc = _lib.MilVitGrads(G["class_token"].data_ptr(), G["project_features.0.weight"].data_ptr(), G["project_features.0.bias"].data_ptr(), lg,

@@ -107,12 +107,15 @@ class HipMilVitTrainer:
         self.split_k = split_k
         # flat fp32 master parameters + buffers (reference state_dict order), gradients and Adam moments
         sd = model.state_dict()
-        self.names = list(sd.keys())
+        self.names = list(sd.keys())                                   # the reference's state_dict order (checkpoints, sync_to_model)
+        self.order = mil_core.flat_order(self.dims, self.names)        # order inside the flat buffers (ALiBi: per-head tensors stacked, mil_core.flat_order)
         self.shapes = {k: tuple(v.shape) for k, v in sd.items()}
-        sizes = [int(v.numel()) for v in sd.values()]
-        self.offs = {k: (sum(sizes[:i]), sizes[i]) for i, k in enumerate(self.names)}
-        n = sum(sizes)
-        self.P = torch.cat([v.detach().float().reshape(-1) for v in sd.values()]).to(self.dev).contiguous()
+        self.offs, n = {}, 0
+        for k in self.order:
+            self.offs[k] = (n, int(sd[k].numel()))
+            n += self.offs[k][1]
+        self._pv, self._gv = {}, {}                                    # name -> view (P and G are allocated once)
+        self.P = torch.cat([sd[k].detach().float().reshape(-1) for k in self.order]).to(self.dev).contiguous()
         self.G = torch.zeros(n, device=self.dev)
         self.m = torch.zeros(n, device=self.dev)
         self.v = torch.zeros(n, device=self.dev)
@@ -127,19 +130,25 @@ class HipMilVitTrainer:
 
     # ---- parameter views ------------------------------------------------------------------------------------------------
     def p(self, name: str) -> torch.Tensor:
-        o, n = self.offs[name]
-        return self.P[o:o + n].view(self.shapes[name])
+        v = self._pv.get(name)
+        if v is None:
+            o, n = self.offs[name]
+            v = self._pv[name] = self.P[o:o + n].view(self.shapes[name])
+        return v
 
     def g(self, name: str) -> torch.Tensor:
-        o, n = self.offs[name]
-        return self.G[o:o + n].view(self.shapes[name])
+        v = self._gv.get(name)
+        if v is None:
+            o, n = self.offs[name]
+            v = self._gv[name] = self.G[o:o + n].view(self.shapes[name])
+        return v
 
     def sync_to_model(self) -> None:
         self.model.load_state_dict({k: self.p(k).detach().clone() for k in self.names})
 
     def load_from_model(self) -> None:
         sd = self.model.state_dict()
-        self.P.copy_(torch.cat([sd[k].detach().float().reshape(-1) for k in self.names]).to(self.dev))
+        self.P.copy_(torch.cat([sd[k].detach().float().reshape(-1) for k in self.order]).to(self.dev))
         self._refresh()
 
     # ---- one optimisation step ------------------------------------------------------------------------------------------------
@@ -195,8 +204,9 @@ class HipMilVitTrainer:
         if self.loss_scale != 1.0:
             dlogits = dlogits * self.loss_scale
         G, _ = mil_core.backward(self.pk, saved, dlogits, need_params=True, need_bags=False, split_k=self.split_k, grad_views=self.g)
+        grouped = self._copy_grouped_grads(G) if self.alibi else ()
         for k, gk in G.items():          # (unpadded geometries: the library wrote into the flat buffer's views themselves -- nothing to copy)
-            if gk.data_ptr() != self.g(k).data_ptr():
+            if k not in grouped and gk.data_ptr() != self.g(k).data_ptr():
                 self.g(k).copy_(gk)
         if self.loss_scale != 1.0:
             self.G.mul_(1.0 / self.loss_scale)
@@ -213,6 +223,26 @@ class HipMilVitTrainer:
                 self.P[self._stat_idx] = stats
             self._refresh()
         return loss.detach(), logits
+
+    def _copy_grouped_grads(self, G: dict) -> set:
+        """ALiBi: the per-head Linears are 3 x H weights + 3 x H biases + H bias scales per layer -- separate tensors in the reference's state_dict, equally
+        pitched slices both of the library's packed gradient and of this trainer's flat buffer.  One strided copy per group instead of one launch per
+        tensor (~110 per layer and step, which the GPU then waited for).  -> the names served."""
+        d, done = self.dims, set()
+        first = mil_core.layer_prefix(0) + f"0.mhsa.{mil_core._ENC[0]}.0.weight"
+        if G[first].data_ptr() == self.g(first).data_ptr():
+            return done                  # (the library wrote into the flat buffer itself: mil_core._direct_grad_structs)
+        for l in range(d.L):
+            p = mil_core.layer_prefix(l)
+            groups = [[[p + f"0.mhsa.{e}.{h}.{kind}" for h in range(d.H)] for e in mil_core._ENC] for kind in ("weight", "bias")]
+            groups.append([[p + f"0.mhsa.attentions.{h}.bias_scale" for h in range(d.H)]])
+            for grp in groups:
+                dst = mil_core._stack([mil_core._stack([self.g(n) for n in row]) for row in grp])
+                if dst.untyped_storage().data_ptr() != self.G.untyped_storage().data_ptr():
+                    continue             # (not a view of the flat buffer: the per-tensor loop serves these)
+                dst.copy_(mil_core._stack([mil_core._stack([G[n] for n in row]) for row in grp]))
+                done.update(n for row in grp for n in row)
+        return done
 
     def epoch_end(self) -> None:
         """Lightning steps an epoch-interval scheduler once after every training epoch."""
