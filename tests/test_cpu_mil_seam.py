@@ -157,6 +157,43 @@ def _patch_kernels(monkeypatch):
     return _Zero
 
 
+def test_flat_order_makes_the_alibi_heads_per_head_tensors_contiguous_views():
+    """The trainer's flat buffers follow mil_core.flat_order: every name keeps its own view, and the ALiBi head's 3 x H per-head Linears (weight, bias, weight,
+    bias ... in the reference's state_dict) stack into CONTIGUOUS views of that buffer -- `_stack` copies nothing; on tensors that do not share a storage (an
+    nn.Module's own parameters) it is torch.stack."""
+    m = VisionTransformer(dim_output=2, dim_input=64, dim_model=128, n_layers=2, n_heads=2, dim_feedforward=64, dropout=0.0, use_alibi=True)
+    sd = m.state_dict()
+    names = list(sd.keys())
+    order = mil_core.flat_order(m.dims, names)
+    assert sorted(order) == sorted(names) and order != names
+    assert mil_core.flat_order(mil_core.VitDims(F=64, D=128, H=2, FF=64, C=2, L=2, alibi=False), ["a", "b"]) == ["a", "b"]
+    flat = torch.cat([sd[k].detach().float().reshape(-1) for k in order])
+    offs, n = {}, 0
+    for k in order:
+        offs[k] = n
+        n += sd[k].numel()
+    get = lambda k: flat[offs[k]: offs[k] + sd[k].numel()].view(sd[k].shape)  # noqa: E731
+    d = m.dims
+    for l in range(d.L):
+        p = mil_core.layer_prefix(l)
+        for kind, shape in (("weight", (3, d.H, d.hd, d.D)), ("bias", (3, d.H, d.hd))):
+            rows = [[p + f"0.mhsa.{e}.{h}.{kind}" for h in range(d.H)] for e in mil_core._ENC]
+            w3 = mil_core._stack([mil_core._stack([get(n_) for n_ in row]) for row in rows])
+            assert w3.shape == shape and w3.is_contiguous() and w3.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+            assert torch.equal(w3, torch.stack([torch.stack([sd[n_].float() for n_ in row]) for row in rows]))
+        bs = mil_core._stack([get(p + f"0.mhsa.attentions.{h}.bias_scale").reshape(1) for h in range(d.H)]).reshape(d.H)
+        assert bs.is_contiguous() and bs.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+    # the reference's own order: equally pitched but not contiguous -> still a view; separate tensors -> a copy with the same values
+    flat2 = torch.cat([sd[k].detach().float().reshape(-1) for k in names])
+    o2 = {k: sum(sd[j].numel() for j in names[:i]) for i, k in enumerate(names)}
+    g2 = lambda k: flat2[o2[k]: o2[k] + sd[k].numel()].view(sd[k].shape)  # noqa: E731
+    p = mil_core.layer_prefix(0)
+    v = mil_core._stack([g2(p + f"0.mhsa.{mil_core._ENC[0]}.{h}.weight") for h in range(d.H)])
+    assert not v.is_contiguous() and v.untyped_storage().data_ptr() == flat2.untyped_storage().data_ptr()
+    sep = [sd[p + f"0.mhsa.{mil_core._ENC[0]}.{h}.weight"] for h in range(d.H)]
+    assert torch.equal(mil_core._stack(sep), torch.stack(sep)) and torch.equal(v, torch.stack(sep))
+
+
 def test_autograd_and_jacrev_plumbing(monkeypatch):
     """loss.backward() fills .grad of the module's nn.Parameters through the custom Function, gradients w.r.t. the bag flow, and
     torch.func.jacrev (the reference's heatmaps, heatmaps/__init__.py:36-56) works: vmap over the backward has a rule."""
