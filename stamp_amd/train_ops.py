@@ -64,6 +64,8 @@ def colsum_multi(xs: list[torch.Tensor]) -> list[torch.Tensor]:
 
 def colsum(x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
     _dev(x)
+    if x.dim() == 2 and x.shape[1] == 1 and x.is_contiguous():
+        x = x.flatten().unsqueeze(1)        # (a single column: torch leaves the stride of a size-1 dimension arbitrary)
     assert x.dim() == 2 and x.stride(1) == 1
     M, N = x.shape
     lib = _lib.lib()

@@ -196,11 +196,13 @@ def test_dropout_masks_statistics_and_determinism(gpu):
     assert rows.min() > 0.55 and rows.max() < 0.95           # no (b, h, q) row is degenerate
 
 
+@pytest.mark.parametrize("Tn", [257, 64, 130, 3])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_attention_dropout_fwd_bwd_vs_autograd(gpu, dt):
+def test_attention_dropout_fwd_bwd_vs_autograd(gpu, dt, Tn):
     """nn.MultiheadAttention's dropout on the probabilities: the HIP forward / backward with p > 0 against fp64 autograd using the
-    mask the kernels regenerate from (seed, stream) -- dropped entries zero, kept ones scaled by 1/(1-p), softmax normaliser untouched."""
-    B, Tn, H, p, seed, sid = 2, 257, 3, 0.25, 4242, 21
+    mask the kernels regenerate from (seed, stream) -- dropped entries zero, kept ones scaled by 1/(1-p), softmax normaliser untouched.
+    (Tn: a ragged last tile, whole tiles only, a ragged tile with one live half, less than a tile.)"""
+    B, H, p, seed, sid = 2, 3, 0.25, 4242, 21
     g = torch.Generator().manual_seed(8)
     D = H * 64
     qkv = torch.randn(B * Tn, 3 * D, generator=g).to(dt)

@@ -102,7 +102,7 @@ def test_adamw_matches_torch(gpu):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,Tn,H", [(2, 1025, 8), (1, 200, 2), (1, 64, 1), (2, 129, 3), (1, 65, 1)])
+@pytest.mark.parametrize("B,Tn,H", [(2, 1025, 8), (1, 200, 2), (1, 64, 1), (2, 129, 3), (1, 65, 1), (1, 1, 1), (2, 7, 2), (1, 128, 2), (1, 4097, 1)])
 def test_attention_backward_vs_autograd(gpu, dt, B, Tn, H):
     g = torch.Generator().manual_seed(B * 100 + Tn + H)
     D = H * 64
@@ -218,7 +218,7 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("B,Tn,H", [(2, 200, 2), (1, 1025, 8)])
+@pytest.mark.parametrize("B,Tn,H", [(2, 200, 2), (1, 1025, 8), (1, 65, 1), (3, 5, 2)])
 def test_alibi_attention_fwd_bwd_vs_autograd(gpu, B, Tn, H):
     """Post-softmax distance bias (reference _ALiBi.forward): out = softmax(qk^T/8) v - bs_h * (cdist/rm_h) v.
     HIP forward + backward (dq, dk, dv, d bias_scale) against fp64 autograd on the same bf16-rounded q, k, v."""
@@ -247,7 +247,8 @@ def test_alibi_attention_fwd_bwd_vs_autograd(gpu, B, Tn, H):
     r = ref_dqkv.reshape(B * Tn, 3, D)
     for i, name in enumerate("qkv"):
         assert _rel(d[:, i], r[:, i]) < 1.5e-2, (name, _rel(d[:, i], r[:, i]))
-    assert _rel(dbs.cpu(), bsd.grad) < 1e-2, (dbs.cpu(), bsd.grad)
+    # (one scalar per head: a sum of B T^2 mixed-sign terms whose distance factors are rounded to bf16 -- on a few thousand terms the rounding does not average out)
+    assert _rel(dbs.cpu(), bsd.grad) < (1e-2 if B * Tn * Tn > 20000 else 3e-2), (dbs.cpu(), bsd.grad)
     m = T.cdist_mean(coords.to(gpu))
     assert abs(m.item() - dist.mean().item()) < 1e-3 * dist.mean().item()
 
