@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkdv2_kernel(const T* __restr
                     const __attribute__((address_space(3))) uint32_t* sRK = reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(sL) + 2 * BT_TILE + par;
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {             // this lane's register 4 r4 + 2 e2 + par
-                        const uint32_t hsh = fmix32(sRK[8 * r4 + 2 * e2] ^ pair_g);
+                        const uint32_t hsh = drop_mix(sRK[8 * r4 + 2 * e2] ^ pair_g);
                         const uint64_t k0 = __builtin_amdgcn_ballot_w64((hsh & 0xFFFFu) >= thr16);
                         const uint64_t k1 = __builtin_amdgcn_ballot_w64((hsh >> 16) >= thr16);
                         keepm[2 * e2] = (k0 & EVEN) | ((k1 & EVEN) << 1);              // hashed by the even lanes
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256, 4) attn_bwd_dq2_kernel(const T* __restric
             for (int r = 0; r < 16; r += 2) {                       // registers r, r + 1 = an even key and its odd partner: one hash
                 bool keep0 = true, keep1 = true;
                 if constexpr (DROP) {
-                    const uint32_t bits = fmix32(rowkey ^ (pair_g + (uint32_t)(half * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * 0x9E3779B1u));
+                    const uint32_t bits = drop_mix(rowkey ^ (pair_g + (uint32_t)(half * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * 0x9E3779B1u));
                     keep0 = drop_keep(bits, 0, thr16);
                     keep1 = drop_keep(bits, 1, thr16);
                 }
