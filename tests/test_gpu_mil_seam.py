@@ -194,6 +194,20 @@ def test_dropout_masks_statistics_and_determinism(gpu):
     assert a.shape == (2, 4, 193, 193) and abs(a.float().mean().item() - 0.75) < 5e-3
     rows = a.float().mean(-1)
     assert rows.min() > 0.55 and rows.max() < 0.95           # no (b, h, q) row is degenerate
+    # the generator tools/dropout_hash_stats.py analyses IS the kernels': flat element idx -> row key of idx >> 16, pair (idx & 0xffff) >> 1, half-word idx & 1
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("dropout_hash_stats", Path(__file__).resolve().parent.parent / "tools" / "dropout_hash_stats.py")
+    dh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dh)
+    n, p, seed, sid = 3 * 65536 + 1000, 0.25, 0x1234567812345, 9
+    idx = np.arange(n, dtype=np.uint64)
+    rk = dh.rowkey(seed, sid, idx >> np.uint64(16))
+    bits = dh.drop_mix(rk ^ (((idx & np.uint64(0xFFFF)) >> np.uint64(1)).astype(np.uint32) * dh.GOLD))
+    half = np.where((idx & np.uint64(1)) == 1, bits >> np.uint32(16), bits & np.uint32(0xFFFF))
+    want = half >= np.uint32(round(p * 65536))
+    got = T.dropout_mask(n, p, seed, sid, gpu).cpu().numpy().astype(bool)
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("Tn", [257, 64, 130, 3])
