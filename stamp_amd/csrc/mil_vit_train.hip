@@ -650,8 +650,15 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
         } else {
             RC(amds_attention_bwd_train(qkv, att, datt, lse, dqs, dqkv, Bb, S, Ha, BF, p_att, seed, 10 * l + 1, stream));
         }
+        // Class-row tail: dQ is zero outside the Bb class rows, so the Q third of dqkv contributes to the in-projection's weight gradient and to dh1 through those rows
+        // alone -- the two launches over all M rows take the K | V columns (2/3 of their N resp. K), the Q third follows on the class rows (row pitch S rows)
+        const bool q_rows = tail && use_tn && Da % 256 == 0;
+        const size_t esz = 2;                                               // dqkv / h1 / in_wt: 16-bit
         if (need_params) {
-            if (use_tn) RC(wgrad_tn(dqkv, 3 * Da, h1, Dp, M, 3 * Da, Dp, Gl->in_w));
+            if (q_rows) {
+                RC(wgrad_tn(reinterpret_cast<const char*>(dqkv) + (size_t)Da * esz, 3 * Da, h1, Dp, M, 2 * Da, Dp, Gl->in_w + (size_t)Da * Dp));      // rows Da .. 3 Da of dW_in
+                RC(wgrad_tn(dqkv, (long)S * 3 * Da, h1, (long)S * Dp, Bb, Da, Dp, Gl->in_w));                                                         // rows 0 .. Da from the class rows
+            } else if (use_tn) RC(wgrad_tn(dqkv, 3 * Da, h1, Dp, M, 3 * Da, Dp, Gl->in_w));
             else {
                 RC(transpose_pad(dqkv, 3 * Da, tg, M, Mp));
                 RC(transpose_pad(h1, Dp, ta, M, Mp));
@@ -659,6 +666,11 @@ extern "C" int amds_mil_vit_train_backward(const amds_mil_vit_cfg* cfg_host, con
             }
             RC(colsum(dqkv, 3 * Da, Gl->in_b, M, 3 * Da, BF));
         }
+        if (q_rows) {
+            RC(gemm(reinterpret_cast<const char*>(dqkv) + (size_t)Da * esz, 3 * Da, reinterpret_cast<const char*>(Lw.in_wt) + (size_t)Da * esz, 3 * Da, M, Dp, 2 * Da, AMDS_EPI_BIAS_F32,
+                    dh, Dp, nullptr, stream));                                                                              // dh1 = dK|dV W_in[K|V rows], every row
+            RC(gemm(dqkv, (long)S * 3 * Da, Lw.in_wt, 3 * Da, Bb, Dp, 3 * Da, AMDS_EPI_BIAS_F32, dh, (long)S * Dp, nullptr, stream));     // the class rows again, with their dQ
+        } else
         RC(gemm(dqkv, 3 * Da, Lw.in_wt, 3 * Da, M, Dp, 3 * Da, AMDS_EPI_BIAS_F32, dh, Dp, nullptr, stream));                 // dh1 fp32
         // (the layer below starts with g16 = bf16(Dropout'(dx)) at ITS feed-forward dropout site: written here, where dx is made)
         RC(ln_bwd(dh, Dp, x_in, Dp, reinterpret_cast<const float*>(sv + o.mu1), reinterpret_cast<const float*>(sv + o.rs1), Lw.ln1_w, dx, Dp, 1,
