@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: A/B against a second library stamp_amd/lib/libamdstamp_<tag>.so built from the previous commit (AMDSTAMP_LIB selects it); profiles/r06_attn_bwd_ab.txt.
 # A/B of attention-backward builds: default library vs stamp_amd/lib/libamdstamp_<tag>.so (AMDSTAMP_LIB), alternating; then a kernel trace of each with the by-shape table
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

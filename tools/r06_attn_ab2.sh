@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the AMDS_ATTN_DKDV / _DQ / _FWD switches existed only while both forms of the kernels were in the library (commits 320cdb4, 3e683cf); the first
+# forms now live as text under tools/ubench/attic/attention_first_forms/ -- this script documents how profiles/r06_attn_bwd_ab.txt was measured.
 # A/B of the two dK/dV kernels in one library (AMDS_ATTN_DKDV=1: first form): tests under both, alternating training rate, kernel trace of each
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

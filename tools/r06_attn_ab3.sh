@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the AMDS_ATTN_DKDV / _DQ / _FWD switches existed only while both forms of the kernels were in the library (commits 320cdb4, 3e683cf); the first
+# forms now live as text under tools/ubench/attic/attention_first_forms/ -- this script documents how profiles/r06_attn_bwd_ab.txt was measured.
 # The attention kernels on the LDS-DMA + transpose-read data path: the whole GPU suite on the new forms, then A/B against the first forms (AMDS_ATTN_FWD / _DQ / _DKDV = 1)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
