@@ -598,8 +598,50 @@ __global__ void landmark_mean_kernel(const float* __restrict__ x, long sxo, long
 }
 
 // per matrix: max over rows of sum_j |x_ij| and max over cols of sum_i |x_ij|; combined across matrices with integer
-// atomicMax on the (non-negative) float bit patterns -> order independent, deterministic
+// atomicMax on the (non-negative) float bit patterns -> order independent, deterministic.
+// Lanes along the row (coalesced 16-byte loads); a lane keeps the column sums of ITS columns over its rows, the eight half-waves' partials
+// meet in LDS.  (Round 1's form -- a thread per row walking it element by element, every load of a wave touching 64 cache lines -- took 243 us per call at
+// 512 matrices of 256 x 256: 0.55 TB/s.)  A HALF-wave per row (its sum by DPP, no LDS round trips), NV = float4 per lane and row: n <= 128 NV.
+template <int NV>
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int n, unsigned* __restrict__ out2) {
+    __shared__ float sc[8][128 * NV];
+    const float* p = x + (long)blockIdx.x * n * n;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = threadIdx.x >> 5;           // eight half-waves, a row each, two rows of a half-wave in flight
+    f32x4 cs[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) cs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rmax = 0.f;
+    for (int i = half; i < n; i += 32) {                          // rows i, i + 8, i + 16, i + 24: 4 NV loads of a lane in flight
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v[4][NV];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = (k * 32 + l31) * 4;
+                v[q][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c < n && i + 8 * q < n) v[q][k] = *reinterpret_cast<const f32x4*>(p + (long)(i + 8 * q) * n + c);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float a = fabsf(v[q][k][e]); rs[q] += a; cs[k][e] += a; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rmax = fmaxf(rmax, half_wave_sum(rs[q]));
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(&sc[half][(k * 32 + l31) * 4]) = cs[k];
+    __syncthreads();
+    float cmax = 0.f;
+    for (int c = threadIdx.x; c < n; c += 256)
+        cmax = fmaxf(cmax, ((sc[0][c] + sc[1][c]) + (sc[2][c] + sc[3][c])) + ((sc[4][c] + sc[5][c]) + (sc[6][c] + sc[7][c])));
+    rmax = wave_max(rmax); cmax = wave_max(cmax);
+    if (lane == 0) { atomicMax(out2, __float_as_uint(rmax)); atomicMax(out2 + 1, __float_as_uint(cmax)); }
+}
+// any n (unaligned rows, n > 1024): a thread per row / column
+__global__ void __launch_bounds__(256) absmax_any_kernel(const float* __restrict__ x, int n, unsigned* __restrict__ out2) {
     const float* p = x + (long)blockIdx.x * n * n;
     float rmax = 0.f, cmax = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -610,11 +652,24 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     rmax = wave_max(rmax); cmax = wave_max(cmax);
     if ((threadIdx.x & 63) == 0) { atomicMax(out2, __float_as_uint(rmax)); atomicMax(out2 + 1, __float_as_uint(cmax)); }
 }
-__global__ void transpose_scale_kernel(const float* __restrict__ x, float* __restrict__ z, int n, const unsigned* __restrict__ mx) {
+// z = x^T / (mx[0] * mx[1]) per matrix, 32 x 32 tiles through LDS (both sides coalesced; the 16 x 16 direct form read 64-byte pieces: 114 us per call)
+__global__ void __launch_bounds__(256) transpose_scale_kernel(const float* __restrict__ x, float* __restrict__ z, int n, const unsigned* __restrict__ mx) {
+    __shared__ float t[32][33];
     const float inv = 1.0f / (__uint_as_float(mx[0]) * __uint_as_float(mx[1]));
     const long base = (long)blockIdx.z * n * n;
-    const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
-    if (i < n && j < n) z[base + (long)i * n + j] = x[base + (long)j * n + i] * inv;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                      // 32 x 8
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;                        // z[i0 ..][j0 ..] = x[j0 ..][i0 ..]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r, i = i0 + tx;
+        if (j < n && i < n) t[ty + 8 * r][tx] = x[base + (long)j * n + i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < n && j < n) z[base + (long)i * n + j] = t[tx][ty + 8 * r] * inv;
+    }
 }
 
 // out[z][t][c] += sum_k w[head][k] * v[z][t + k - pad][c]   (z = b*H + head; v strided view with row stride ldv)
@@ -968,8 +1023,79 @@ __global__ void relu_bwd_kernel(const float* __restrict__ h, const float* __rest
 // pinv initialisation z0 = x^T / s, s = rmax * cmax (maxima over ALL matrices of the row sums / column sums of |x|): backward.
 // stage 1: per matrix, dot[z] = sum_ij dz0[z][j][i] * x[z][i][j]; and the arg-max of the row sums / column sums, packed as
 // (value bits << 32 | ~index) so that one 64-bit atomicMax gives the first index of the global maximum (deterministic).
+// Aligned matrices (n a multiple of 32, n <= 1024): one wave per row for the row / column sums (as absmax_kernel), the dot product over 32 x 32 tiles of x against
+// the transposed tiles of dz0 through LDS -- every load coalesced.  (A thread per row walking x[i][:], x[:][i] and dz0[:][i]: 244 us per call at 512 x 256 x 256.)
+template <int NV>
 __global__ void __launch_bounds__(256) pinv_init_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dz0, int n,
                                                                   float* __restrict__ dot, unsigned long long* __restrict__ arg2) {
+    __shared__ float sc[8][128 * NV];
+    __shared__ float tg[4][32][33];
+    __shared__ float red[4];
+    const long z = blockIdx.x;
+    const float* p = x + z * n * n;
+    const float* g = dz0 + z * n * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = threadIdx.x >> 5;
+    f32x4 cs[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) cs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned long long best_r = 0, best_c = 0;
+    for (int i = half; i < n; i += 8) {                          // a half-wave per row (absmax_kernel)
+        float rs = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (k * 32 + l31) * 4;
+            if (c < n) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long)i * n + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float a = fabsf(v[e]); rs += a; cs[k][e] += a; }
+            }
+        }
+        rs = half_wave_sum(rs);
+        const unsigned long long kr = ((unsigned long long)__float_as_uint(rs) << 32) | (unsigned)(~(unsigned)(z * n + i));
+        best_r = kr > best_r ? kr : best_r;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(&sc[half][(k * 32 + l31) * 4]) = cs[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float csum = ((sc[0][c] + sc[1][c]) + (sc[2][c] + sc[3][c])) + ((sc[4][c] + sc[5][c]) + (sc[6][c] + sc[7][c]));
+        const unsigned long long kc = ((unsigned long long)__float_as_uint(csum) << 32) | (unsigned)(~(unsigned)(z * n + c));
+        best_c = kc > best_c ? kc : best_c;
+    }
+    // dot = sum_ij dz0[j][i] x[i][j]: tile (I, J) of x against tile (J, I) of dz0, transposed in LDS; four tiles per barrier pair (32 loads of a thread in flight)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int nt = n / 32;
+    float s = 0.f;
+    for (int t0 = 0; t0 < nt * nt; t0 += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = t0 + q, I = tile / nt, J = tile - I * nt;
+            if (tile < nt * nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tg[q][ty + 8 * r][tx] = g[(long)(J * 32 + ty + 8 * r) * n + I * 32 + tx];       // tg[j][i] = dz0[J*32 + j][I*32 + i]
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = t0 + q, I = tile / nt, J = tile - I * nt;
+            if (tile < nt * nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += tg[q][tx][ty + 8 * r] * p[(long)(I * 32 + ty + 8 * r) * n + J * 32 + tx];   // x[i][j] * dz0[j][i], i = ty + 8 r, j = tx
+            }
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dot[z] = (red[0] + red[1]) + (red[2] + red[3]);
+    atomicMax(arg2, best_r);
+    atomicMax(arg2 + 1, best_c);
+}
+// any n: a thread per row / column
+__global__ void __launch_bounds__(256) pinv_init_bwd_stats_any_kernel(const float* __restrict__ x, const float* __restrict__ dz0, int n,
+                                                                      float* __restrict__ dot, unsigned long long* __restrict__ arg2) {
     __shared__ float red[256];
     const long z = blockIdx.x;
     const float* p = x + z * n * n;
@@ -1000,19 +1126,32 @@ __global__ void __launch_bounds__(256) pinv_init_bwd_stats_kernel(const float* _
     atomicMax(arg2 + 1, best_c);
 }
 // stage 2: dx[z][i][j] += dz0[z][j][i] / s  +  ds * (cmax on row i* of matrix z_r*  +  rmax on column j* of matrix z_c*),  ds = -sum(dot) / s^2
-__global__ void pinv_init_bwd_apply_kernel(const float* __restrict__ dz0, float* __restrict__ dx, int n, int nmat, const float* __restrict__ dot_sum,
-                                           const unsigned long long* __restrict__ arg2) {
+// (32 x 32 tiles of dz0 transposed through LDS: both sides coalesced)
+__global__ void __launch_bounds__(256) pinv_init_bwd_apply_kernel(const float* __restrict__ dz0, float* __restrict__ dx, int n, int nmat, const float* __restrict__ dot_sum,
+                                                                  const unsigned long long* __restrict__ arg2) {
+    __shared__ float t[32][33];
     const float rmax = __uint_as_float((unsigned)(arg2[0] >> 32)), cmax = __uint_as_float((unsigned)(arg2[1] >> 32));
     const unsigned ridx = ~(unsigned)(arg2[0] & 0xFFFFFFFFull), cidx = ~(unsigned)(arg2[1] & 0xFFFFFFFFull);
     const float s = rmax * cmax;
     const float ds = -dot_sum[0] / (s * s);
     const long z = blockIdx.z;
-    const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
-    if (i >= n || j >= n) return;
-    float g = dz0[z * n * n + (long)j * n + i] / s;
-    if ((unsigned)(z * n + i) == ridx) g += ds * cmax;         // d s / d (row sum i*) = cmax, spread over the row (x > 0: softmax output)
-    if ((unsigned)(z * n + j) == cidx) g += ds * rmax;
-    dx[z * n * n + (long)i * n + j] += g;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;                        // dx[i0 ..][j0 ..] gets dz0[j0 ..][i0 ..]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r, i = i0 + tx;
+        if (j < n && i < n) t[ty + 8 * r][tx] = dz0[z * n * n + (long)j * n + i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i >= n || j >= n) continue;
+        float g = t[tx][ty + 8 * r] / s;
+        if ((unsigned)(z * n + i) == ridx) g += ds * cmax;         // d s / d (row sum i*) = cmax, spread over the row (x > 0: softmax output)
+        if ((unsigned)(z * n + j) == cidx) g += ds * rmax;
+        dx[z * n * n + (long)i * n + j] += g;
+    }
 }
 
 }  // namespace amds
@@ -1108,11 +1247,14 @@ extern "C" int amds_pinv_init_bwd(const float* x, const float* dz0, float* dx, i
     float* dot_sum = dot + nmat;
     char* cws = (char*)(dot_sum + 4);
     AMDS_HIP(hipMemsetAsync(arg2, 0, 16, st));
-    hipLaunchKernelGGL(pinv_init_bwd_stats_kernel, dim3(nmat), dim3(256), 0, st, x, dz0, n, dot, arg2);
+    const bool al = n % 32 == 0 && (((uintptr_t)x | (uintptr_t)dz0) & 15) == 0;
+    if (al && n <= 256) hipLaunchKernelGGL((pinv_init_bwd_stats_kernel<2>), dim3(nmat), dim3(256), 0, st, x, dz0, n, dot, arg2);
+    else if (al && n <= 1024) hipLaunchKernelGGL((pinv_init_bwd_stats_kernel<8>), dim3(nmat), dim3(256), 0, st, x, dz0, n, dot, arg2);
+    else hipLaunchKernelGGL(pinv_init_bwd_stats_any_kernel, dim3(nmat), dim3(256), 0, st, x, dz0, n, dot, arg2);
     AMDS_LAUNCH_CHECK("pinv_init_bwd_stats_kernel");
     int rc = amds_colsum(dot, 1, dot_sum, nmat, 1, AMDS_F32, 0, cws, amds_colsum_workspace_bytes(nmat, 1), stream);
     if (rc != AMDS_OK) return rc;
-    hipLaunchKernelGGL(pinv_init_bwd_apply_kernel, dim3(cdiv(n, 16), cdiv(n, 16), nmat), dim3(16, 16), 0, st, dz0, dx, n, nmat, dot_sum, arg2);
+    hipLaunchKernelGGL(pinv_init_bwd_apply_kernel, dim3(cdiv(n, 32), cdiv(n, 32), nmat), dim3(256), 0, st, dz0, dx, n, nmat, dot_sum, arg2);
     AMDS_LAUNCH_CHECK("pinv_init_bwd_apply_kernel");
     return AMDS_OK;
 }
@@ -1275,9 +1417,11 @@ extern "C" int amds_pinv_init(const float* x, float* z, int nmat, int n, void* s
     AMDS_REQUIRE(x && z && scratch8 && nmat > 0 && nmat <= 65535 && n > 0, "amds_pinv_init: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     AMDS_HIP(hipMemsetAsync(scratch8, 0, 8, st));
-    hipLaunchKernelGGL(absmax_kernel, dim3(nmat), dim3(256), 0, st, x, n, (unsigned*)scratch8);
+    if (n % 4 == 0 && n <= 256 && ((uintptr_t)x & 15) == 0) hipLaunchKernelGGL((absmax_kernel<2>), dim3(nmat), dim3(256), 0, st, x, n, (unsigned*)scratch8);
+    else if (n % 4 == 0 && n <= 1024 && ((uintptr_t)x & 15) == 0) hipLaunchKernelGGL((absmax_kernel<8>), dim3(nmat), dim3(256), 0, st, x, n, (unsigned*)scratch8);
+    else hipLaunchKernelGGL(absmax_any_kernel, dim3(nmat), dim3(256), 0, st, x, n, (unsigned*)scratch8);
     AMDS_LAUNCH_CHECK("absmax_kernel");
-    hipLaunchKernelGGL(transpose_scale_kernel, dim3(cdiv(n, 16), cdiv(n, 16), nmat), dim3(16, 16), 0, st, x, z, n, (const unsigned*)scratch8);
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3(cdiv(n, 32), cdiv(n, 32), nmat), dim3(256), 0, st, x, z, n, (const unsigned*)scratch8);
     AMDS_LAUNCH_CHECK("transpose_scale_kernel");
     return AMDS_OK;
 }
