@@ -73,12 +73,13 @@ __global__ void __launch_bounds__(256) to_f32_kernel(const TI* __restrict__ src,
 }
 
 // token rows of x [Bb][n][Cd]: row 0 = class token, rows 1..T = the projected tiles, rows T+1..side^2 = the FIRST tiles again (:306-314)
-__global__ void __launch_bounds__(128) wrap_cls_kernel(const float* __restrict__ cls, const float* __restrict__ h, float* __restrict__ x, int Cd, int T, int n) {
+__global__ void __launch_bounds__(128) wrap_cls_kernel(const float* __restrict__ cls, const float* __restrict__ h, float* __restrict__ x, int Cd, int T, int n, int relu) {
     const long row = blockIdx.x;
     const long b = row / n;
     const int s = (int)(row - b * n);
     const float* src = s == 0 ? cls : h + (b * T + (s - 1 < T ? s - 1 : s - 1 - T)) * Cd;
     float* dst = x + row * Cd;
+    if (relu && s != 0) { for (int c = threadIdx.x; c < Cd; c += 128) dst[c] = fmaxf(src[c], 0.f); return; }      // (h holds the pre-activation of _fc1)
     for (int c = threadIdx.x; c < Cd; c += 128) dst[c] = src[c];
 }
 
@@ -217,8 +218,12 @@ extern "C" int amds_transmil_forward(const amds_transmil_cfg* cfg_host, const am
     }
     float *x = reinterpret_cast<float*>(wk + p.x), *y = reinterpret_cast<float*>(wk + p.y);
     float* h1 = reinterpret_cast<float*>(wk + p.qkv);                                    // _fc1 output [Bb*T][Cd]: scratch (the qkv region is larger and free here)
-    RC(amds_linear_f32(hf, w.fc1_w, w.fc1_b, h1, Bb * T, Cd, F, 1, stream));
-    hipLaunchKernelGGL(wrap_cls_kernel, dim3((unsigned)((long)Bb * n)), dim3(128), 0, st, w.cls_token, h1, x, Cd, T, n);
+    // _fc1 = Linear + ReLU (:303).  Below torch's "highest" the product is a product like the others (amds_bgemm_f32: bf16 x 3 at "high") and the ReLU rides on the
+    // copy into the wrapped sequence; at "highest" the exact-fp32 Linear of the MLP heads (a 64 x 64-tile kernel: 700 us at 65 536 x 1024 x 512 against ~400)
+    const bool fc1_x3 = ctx_matmul_precision() != AMDS_MATMUL_HIGHEST && ((long)Bb * T) % 128 == 0 && Cd % 128 == 0 && F % 32 == 0;
+    if (fc1_x3) RC(bg(hf, F, 0, 0, w.fc1_w, F, 0, 0, 1, h1, Cd, 0, 0, 1, 1, Bb * T, Cd, F, 1.0f, 0.0f, w.fc1_b, 0, stream));
+    else RC(amds_linear_f32(hf, w.fc1_w, w.fc1_b, h1, Bb * T, Cd, F, 1, stream));
+    hipLaunchKernelGGL(wrap_cls_kernel, dim3((unsigned)((long)Bb * n)), dim3(128), 0, st, w.cls_token, h1, x, Cd, T, n, fc1_x3 ? 1 : 0);
     AMDS_LAUNCH_CHECK("wrap_cls_kernel");
     // layer1, PPEG, layer2 (:317-319)
     RC(amds_layernorm(x, Cd, w.layer[0].norm_w, w.layer[0].norm_b, y, Cd, Bb * n, Cd, 1e-5f, AMDS_F32, stream));

@@ -77,12 +77,13 @@ __global__ void __launch_bounds__(256) tt_to_f32_kernel(const TI* __restrict__ s
     for (; i < n; i += stride) dst[i] = (float)src[i];
 }
 // x [Bb][n][Cd]: class token, the T projected tiles, then the FIRST tiles again up to side^2 (:306-314)
-__global__ void __launch_bounds__(128) tt_wrap_cls_kernel(const float* __restrict__ cls, const float* __restrict__ h, float* __restrict__ x, int Cd, int T, int n) {
+__global__ void __launch_bounds__(128) tt_wrap_cls_kernel(const float* __restrict__ cls, const float* __restrict__ h, float* __restrict__ x, int Cd, int T, int n, int relu) {
     const long row = blockIdx.x;
     const long b = row / n;
     const int s = (int)(row - b * n);
     const float* src = s == 0 ? cls : h + (b * T + (s - 1 < T ? s - 1 : s - 1 - T)) * Cd;
     float* dst = x + row * Cd;
+    if (relu && s != 0) { for (int c = threadIdx.x; c < Cd; c += 128) dst[c] = fmaxf(src[c], 0.f); return; }      // (h holds the pre-activation of _fc1)
     for (int c = threadIdx.x; c < Cd; c += 128) dst[c] = src[c];
 }
 // dh [Bb][T][Cd] = dx[:, 1 : 1 + T]
@@ -159,10 +160,14 @@ extern "C" int amds_transmil_train_forward(const amds_transmil_cfg* cfg_host, co
         AMDS_LAUNCH_CHECK("tt_to_f32_kernel");
     }
     float* h = reinterpret_cast<float*>(sv + s.h);
-    RC(amds_linear_f32(a, w.fc1_w, w.fc1_b, h, (int)Mt, Cd, d.F, 1, stream));                                   // _fc1: Linear + ReLU (:303)
+    // _fc1: Linear + ReLU (:303).  Below "highest": the product through amds_bgemm_f32 (bf16 x 3 at "high"), h keeps the PRE-activation (amds_relu_bwd tests h > 0:
+    // the same mask) and the ReLU rides on the copy into the wrapped sequence (transmil_fwd.hip)
+    const bool fc1_x3 = ctx_matmul_precision() != AMDS_MATMUL_HIGHEST && Mt % 128 == 0 && Cd % 128 == 0 && d.F % 32 == 0;
+    if (fc1_x3) RC(amds_bgemm_f32(a, d.F, 0, 0, w.fc1_w, d.F, 0, 0, 1, h, Cd, 0, 0, 1, 1, (int)Mt, Cd, d.F, 1.0f, 0.0f, w.fc1_b, 0, stream));
+    else RC(amds_linear_f32(a, w.fc1_w, w.fc1_b, h, (int)Mt, Cd, d.F, 1, stream));
     float *x1 = reinterpret_cast<float*>(sv + s.x1), *xp = reinterpret_cast<float*>(sv + s.xp), *x2 = reinterpret_cast<float*>(sv + s.x2);
     float *xf = reinterpret_cast<float*>(sv + s.xf), *y = reinterpret_cast<float*>(sv + s.y);
-    hipLaunchKernelGGL(tt_wrap_cls_kernel, dim3((unsigned)M), dim3(128), 0, st, w.cls_token, h, x1, Cd, T, n);
+    hipLaunchKernelGGL(tt_wrap_cls_kernel, dim3((unsigned)M), dim3(128), 0, st, w.cls_token, h, x1, Cd, T, n, fc1_x3 ? 1 : 0);
     AMDS_LAUNCH_CHECK("tt_wrap_cls_kernel");
     // layer1 (:317): xp = x1 + Dropout(to_out(Nystrom(LayerNorm(x1))))
     RC(amds_layernorm_train(x1, Cd, w.layer[0].norm_w, w.layer[0].norm_b, y, Cd, reinterpret_cast<float*>(sv + s.mu1), reinterpret_cast<float*>(sv + s.rs1), (int)M, Cd, 1e-5f,
