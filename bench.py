@@ -592,7 +592,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
         return (time.perf_counter() - t) / n, r
 
     with torch.no_grad():
-        dt, lg = timeit(lambda: mil(bags, coords=None, mask=None), 5)
+        dt, lg = timeit(lambda: mil(bags, coords=None, mask=None), 30, warm=3)          # (1.1 ms per call: five calls were a 5 ms window behind one synchronize)
     sec.update({"metric": "MIL bags/s (vit head forward, bags of 1024 x 1024-d fp16, batch 64, no mask)", "value": round(64 / dt, 1), "unit": "bags/s",
                 "gflop_per_bag_fwd": 11.83, "finite": bool(torch.isfinite(lg).all())})
     tg = torch.nn.functional.one_hot(torch.arange(64) % 2, 2).float()
@@ -622,7 +622,7 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     stg = torch.stack([torch.rand(64, generator=gs) * 1970 + 30, (torch.rand(64, generator=gs) < 0.7).float()], 1)
     sv = HipMil(dropout=0.25, use_alibi=False, dim_output=1, dim_input=768, dim_model=512, n_layers=2, n_heads=8, dim_feedforward=512).eval()
     trn = HipMilVitTrainer(sv, device=ctx.device, total_steps=100, sched_interval="step", precision="high")
-    dt, (lsv, _) = timeit(lambda: trn.step(sbags, stg, loss_fn=L.cox_survival_loss), 4)
+    dt, (lsv, _) = timeit(lambda: trn.step(sbags, stg, loss_fn=L.cox_survival_loss), 16, warm=3)
     sec["survival"] = {"metric": "MIL bags/s (Cox-survival `vit` head, dim_output 1, Efron partial likelihood, fwd + bwd + AdamW, bags of 1024 x 768-d, batch 64, "
                                  "float32_matmul_precision 'high': fp16 operands, loss scale 2^10; train-mode dropout)", "value": round(64 / dt, 1), "unit": "bags/s", "loss_finite": bool(torch.isfinite(lsv))}
     del trn, sbags
@@ -633,9 +633,9 @@ def secondary_metrics(ctx, a, tiles, is_swin) -> dict:
     # per product) and, beside it, at torch's default "highest" (exact fp32 MFMA products).
     from stamp_amd import ops as hip_ops
     with torch.no_grad():
-        dt_hi, lg_hi = timeit(lambda: tm(bags_f), 3, warm=1)
+        dt_hi, lg_hi = timeit(lambda: tm(bags_f), 6, warm=2)
         with hip_ops.float32_matmul_precision("high"):
-            dt, lg2 = timeit(lambda: tm(bags_f), 3, warm=1)
+            dt, lg2 = timeit(lambda: tm(bags_f), 6, warm=2)
     sec["transmil"] = {"metric": "TransMIL bags/s (forward, bags of 1024 x 1024-d, batch 64, float32_matmul_precision 'high' as the reference's deploy / train set it: bf16 x 3 products)",
                        "value": round(64 / dt, 1), "finite": bool(torch.isfinite(lg2).all()), "highest_exact_fp32": round(64 / dt_hi, 1),
                        "max_abs_logit_diff_high_vs_highest": float((lg2 - lg_hi).abs().max())}
