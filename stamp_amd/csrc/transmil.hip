@@ -638,7 +638,13 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     for (int c = threadIdx.x; c < n; c += 256)
         cmax = fmaxf(cmax, ((sc[0][c] + sc[1][c]) + (sc[2][c] + sc[3][c])) + ((sc[4][c] + sc[5][c]) + (sc[6][c] + sc[7][c])));
     rmax = wave_max(rmax); cmax = wave_max(cmax);
-    if (lane == 0) { atomicMax(out2, __float_as_uint(rmax)); atomicMax(out2 + 1, __float_as_uint(cmax)); }
+    __syncthreads();                                            // (sc is read: reuse its first words for the four waves' maxima -- ONE pair of atomics per workgroup)
+    if (lane == 0) { sc[0][threadIdx.x >> 6] = rmax; sc[0][4 + (threadIdx.x >> 6)] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out2, __float_as_uint(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]))));
+        atomicMax(out2 + 1, __float_as_uint(fmaxf(fmaxf(sc[0][4], sc[0][5]), fmaxf(sc[0][6], sc[0][7]))));
+    }
 }
 // any n (unaligned rows, n > 1024): a thread per row / column
 __global__ void __launch_bounds__(256) absmax_any_kernel(const float* __restrict__ x, int n, unsigned* __restrict__ out2) {
@@ -1087,11 +1093,24 @@ __global__ void __launch_bounds__(256) pinv_init_bwd_stats_kernel(const float* _
         }
     }
     s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
+    // the arg-max keys: wave, then workgroup, then ONE pair of 64-bit atomics (every thread issuing its own pair was 262 k atomics on two addresses per call)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long r2 = __shfl_xor(best_r, o, 64), c2 = __shfl_xor(best_c, o, 64);
+        best_r = r2 > best_r ? r2 : best_r;
+        best_c = c2 > best_c ? c2 : best_c;
+    }
+    __shared__ unsigned long long keys[8];
+    if (lane == 0) { red[wave] = s; keys[wave] = best_r; keys[4 + wave] = best_c; }
     __syncthreads();
-    if (threadIdx.x == 0) dot[z] = (red[0] + red[1]) + (red[2] + red[3]);
-    atomicMax(arg2, best_r);
-    atomicMax(arg2 + 1, best_c);
+    if (threadIdx.x == 0) {
+        dot[z] = (red[0] + red[1]) + (red[2] + red[3]);
+        unsigned long long br = keys[0], bc = keys[4];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { br = keys[w] > br ? keys[w] : br; bc = keys[4 + w] > bc ? keys[4 + w] : bc; }
+        atomicMax(arg2, br);
+        atomicMax(arg2 + 1, bc);
+    }
 }
 // any n: a thread per row / column
 __global__ void __launch_bounds__(256) pinv_init_bwd_stats_any_kernel(const float* __restrict__ x, const float* __restrict__ dz0, int n,
