@@ -10,6 +10,7 @@
 // (amds_bgemm_f32), the rest in the kernels of transmil.hip.  A plain sequence of launches on `stream` over one caller-owned workspace.
 #include <algorithm>
 #include "common.h"
+#include <cstdlib>
 
 namespace amds {
 namespace {
@@ -149,15 +150,27 @@ int nystrom(const TmPlan& p, const amds_transmil_layer& L, const float* y, float
     float *t1 = reinterpret_cast<float*>(wk + p.t1), *t2 = reinterpret_cast<float*>(wk + p.t2);
     AMDS_HIP(hipMemsetAsync(wk + p.scratch, 0, 8, st));
     RC(amds_pinv_init(a2, z, b * H, m, wk + p.scratch, stream));
-    auto sq = [&](const float* A, const float* B, float* Cm, float alpha, float diag) {
-        return bg(A, m, mm, 0, B, m, mm, 0, 0, Cm, m, mm, 0, b * H, 1, m, m, m, alpha, diag, nullptr, 0, stream);
-    };
-    for (int it = 0; it < ITERS; ++it) {
-        RC(amds_bgemm_f32_dual(a2, m, mm, 0, z, m, mm, 0, 0, xz, t1, m, mm, 0, b * H, 1, m, m, m, 1.0f, 0.0f, -1.0f, 7.0f, stream));      // xz and 7 I - xz from one product
-        RC(sq(xz, t1, t2, -1.0f, 15.0f));
-        RC(sq(xz, t2, t1, -1.0f, 13.0f));
-        RC(sq(z, t1, z2, 0.25f, 0.0f));
-        std::swap(z, z2);
+    // The chain runs chunk by chunk of the batch, 256 matrices (1024 workgroups per launch) at a time: the deploy forward keeps no iterate, so a chunk's five buffers
+    // are re-used while parts of them are still in the Infinity Cache -- 6 540 -> 6 720 bags/s at 64 bags (512 matrices: two chunks; four chunks of 128: +1.8 %, eight:
+    // -13 %: too few workgroups per launch).  The training forward keeps every iterate for the backward and gains nothing (profiles/r06_transmil_prefetch_ab.txt).
+    // AMDS_PINV_CHUNKS=n: n chunks (1 = the whole batch at once), A/B.
+    static const int n_chunks = getenv("AMDS_PINV_CHUNKS") ? atoi(getenv("AMDS_PINV_CHUNKS")) : 0;
+    const int Zall = b * H, Zc = n_chunks > 0 ? (Zall + n_chunks - 1) / n_chunks : std::min(Zall, 256);
+    float *z_in = z, *z2_in = z2;
+    for (int c0 = 0; c0 < Zall; c0 += Zc) {
+        const int zn = std::min(Zc, Zall - c0);
+        const long co = (long)c0 * mm;
+        z = z_in; z2 = z2_in;
+        auto sq = [&](const float* A, const float* B, float* Cm, float alpha, float diag) {
+            return bg(A + co, m, mm, 0, B + co, m, mm, 0, 0, Cm + co, m, mm, 0, zn, 1, m, m, m, alpha, diag, nullptr, 0, stream);
+        };
+        for (int it = 0; it < ITERS; ++it) {
+            RC(amds_bgemm_f32_dual(a2 + co, m, mm, 0, z + co, m, mm, 0, 0, xz + co, t1 + co, m, mm, 0, zn, 1, m, m, m, 1.0f, 0.0f, -1.0f, 7.0f, stream));      // xz and 7 I - xz from one product
+            RC(sq(xz, t1, t2, -1.0f, 15.0f));
+            RC(sq(xz, t2, t1, -1.0f, 13.0f));
+            RC(sq(z, t1, z2, 0.25f, 0.0f));
+            std::swap(z, z2);
+        }
     }
     float *av = reinterpret_cast<float*>(wk + p.av), *a1z = reinterpret_cast<float*>(wk + p.a1z), *merged = reinterpret_cast<float*>(wk + p.merged);
     RC(bg(a3, np, H * nm, nm, vp, ld, sb, sh, 0, av, d, H * md, md, b, H, m, d, np, 1.0f, 0.0f, nullptr, 0, stream));               // attn3 v
