@@ -597,6 +597,19 @@ __global__ void landmark_mean_kernel(const float* __restrict__ x, long sxo, long
     out[((long)z * m + j) * d + c] = s * scale;
 }
 
+// the same, four channels per thread (d, ld multiples of 4, 16-byte aligned rows): the head slices are 256-byte pieces of 6 KB rows -- wide loads, l of them in flight
+__global__ void landmark_mean4_kernel(const float* __restrict__ x, long sxo, long sxi, int ld, float* __restrict__ out, int inner, int m, int l, int d, float scale) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int d4 = d >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * d4) return;
+    const int j = idx / d4, c = (idx - j * d4) * 4;
+    const float* p = x + zo * sxo + zi * sxi + (long)j * l * ld + c;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < l; ++t) s += *reinterpret_cast<const f32x4*>(p + (long)t * ld);
+    *reinterpret_cast<f32x4*>(out + ((long)z * m + j) * d + c) = s * scale;
+}
+
 // per matrix: max over rows of sum_j |x_ij| and max over cols of sum_i |x_ij|; combined across matrices with integer
 // atomicMax on the (non-negative) float bit patterns -> order independent, deterministic.
 // Lanes along the row (coalesced 16-byte loads); a lane keeps the column sums of ITS columns over its rows, the eight half-waves' partials
@@ -866,6 +879,19 @@ __global__ void landmark_mean_bwd_kernel(const float* __restrict__ dout, float* 
     const int t = idx / d, c = idx - t * d;
     const float g = scale * dout[((long)z * m + t / l) * d + c];
     float* q = dx + zo * sxo + zi * sxi + (long)t * ld + c;
+    *q = accumulate ? *q + g : g;
+}
+
+// the same, four channels per thread (d, ld multiples of 4, 16-byte aligned rows)
+__global__ void landmark_mean_bwd4_kernel(const float* __restrict__ dout, float* __restrict__ dx, long sxo, long sxi, int ld, int inner, int m, int l, int d, float scale,
+                                          int accumulate) {
+    const int z = blockIdx.y, zo = z / inner, zi = z - zo * inner;
+    const int d4 = d >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * l * d4) return;
+    const int t = idx / d4, c = (idx - t * d4) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((long)z * m + t / l) * d + c) * scale;
+    f32x4* q = reinterpret_cast<f32x4*>(dx + zo * sxo + zi * sxi + (long)t * ld + c);
     *q = accumulate ? *q + g : g;
 }
 
@@ -1199,6 +1225,10 @@ extern "C" int amds_softmax_rows_bwd(const float* p, float* dp, long rows, int c
 extern "C" int amds_landmark_mean_bwd(const float* dout, float* dx, long sxo, long sxi, int ld, int outer, int inner, int m, int l, int d,
                                       float scale, int accumulate, void* stream) {
     AMDS_REQUIRE(dout && dx && outer > 0 && inner > 0 && m > 0 && l > 0 && d > 0, "amds_landmark_mean_bwd: bad arguments");
+    if (d % 4 == 0 && ld % 4 == 0 && sxo % 4 == 0 && sxi % 4 == 0 && (((uintptr_t)dx | (uintptr_t)dout) & 15) == 0)
+        hipLaunchKernelGGL(landmark_mean_bwd4_kernel, dim3(cdiv((long)m * l * (d / 4), 256), outer * inner), dim3(256), 0, (hipStream_t)stream, dout, dx, sxo, sxi, ld, inner,
+                           m, l, d, scale, accumulate);
+    else
     hipLaunchKernelGGL(landmark_mean_bwd_kernel, dim3(cdiv((long)m * l * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, dout, dx, sxo,
                        sxi, ld, inner, m, l, d, scale, accumulate);
     AMDS_LAUNCH_CHECK("landmark_mean_bwd_kernel");
@@ -1426,6 +1456,10 @@ extern "C" int amds_softmax_rows(float* x, long rows, int cols, void* stream) {
 extern "C" int amds_landmark_mean(const float* x, long sxo, long sxi, int ld, float* out, int outer, int inner, int m, int l, int d,
                                   float scale, void* stream) {
     AMDS_REQUIRE(x && out && outer > 0 && inner > 0 && m > 0 && l > 0 && d > 0, "amds_landmark_mean: bad arguments");
+    if (d % 4 == 0 && ld % 4 == 0 && sxo % 4 == 0 && sxi % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(landmark_mean4_kernel, dim3(cdiv((long)m * (d / 4), 256), outer * inner), dim3(256), 0, (hipStream_t)stream, x, sxo, sxi, ld, out, inner, m, l, d,
+                           scale);
+    else
     hipLaunchKernelGGL(landmark_mean_kernel, dim3(cdiv((long)m * d, 256), outer * inner), dim3(256), 0, (hipStream_t)stream, x, sxo, sxi, ld,
                        out, inner, m, l, d, scale);
     AMDS_LAUNCH_CHECK("landmark_mean_kernel");
