@@ -242,7 +242,10 @@ int amds_attention_vit_hd(const void* qkv, void* out, int B, int T, int H, int h
 /* Same contract for ANY T (K/V streamed through LDS in 64-key tiles, online softmax; the T x T matrix is never
  * materialised).  Used by the MIL heads: bags of 1024 tiles in training, whole slides (tens of thousands of
  * tiles) at deploy time (reference src/stamp/modeling/models/vision_tranformer.py:191, 217-227, mask=None path
- * of src/stamp/modeling/models/__init__.py:286-313). */
+ * of src/stamp/modeling/models/__init__.py:286-313).  The K / V tiles travel by buffer-form LDS-DMA: one bag's q | k | v
+ * rows must stay below the 2 GB a buffer descriptor addresses (T * 3 * H * 128 bytes < 2^31: T < 699 050 at 8 heads) --
+ * AMDS_ERR_INVALID otherwise; the same holds for every amds_attention_* entry of the streaming kernels (forward, masked,
+ * ALiBi, training forward / backward). */
 int amds_attention(const void* qkv, void* out, int B, int T, int H, int dtype, void* stream);
 /* ONE query row per (bag, head) against all T keys / values of the bag as stored in the packed qkv tensor [B*T][3*H*64] (16-bit): out[b][h*64..] = softmax(q[b][h*64..] K_b,h^T / 8) V_b,h,
  * fp32 arithmetic, 16-bit q [B][ldq] and out [B][ldo].  The class token's attention in the LAST block of the MIL `vit` head, whose other rows nothing reads (reference
